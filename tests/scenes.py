@@ -36,3 +36,30 @@ def random_scene(N, seed=0, sh_coeffs=1, scale=0.03, opacity=(0.2, 0.95), radius
     shs = rng.standard_normal((N, sh_coeffs, 3)) * 0.5
     shs[:, 0] += 0.8
     return dict(means3D=xyz, scales=scales, rotations=q, opacities=op, shs=shs)
+
+
+TIMENET_SHAPES = (
+    [("deformnet.0", 256, 104)] + [(f"deformnet.{i}", 256, 360 if i == 5 else 256) for i in range(1, 8)]
+    + [("pts_layers.0", 256, 256), ("pts_layers.2", 3, 256), ("rot_layers.0", 256, 256), ("rot_layers.2", 4, 256)]
+)
+
+
+def timenet_weights(seed, head_std=1e-2):
+    """Deterministic TimeNet state dict (names/shapes of renderer/latent_gs_renderer.py:184-203) from a numpy seed,
+    so fixtures need not store 647k weights.  Xavier-uniform-like body, small random heads, rot bias [1,0,0,0]."""
+    rng = np.random.default_rng(seed)
+    sd = {}
+    for name, o, i in TIMENET_SHAPES:
+        if name in ("pts_layers.2", "rot_layers.2"):
+            w = rng.standard_normal((o, i)) * head_std
+            b = np.array([1.0, 0, 0, 0]) if o == 4 else np.zeros(3)
+        else:
+            a = np.sqrt(6.0 / (i + o))
+            w = rng.uniform(-a, a, (o, i))
+            b = rng.uniform(-0.05, 0.05, o)
+        sd[name + ".weight"] = w.astype(np.float32)
+        sd[name + ".bias"] = b.astype(np.float32)
+    return sd
+
+
+GRAD_STRIDE = 97  # golden fixtures keep grad.flatten()[::GRAD_STRIDE] of the TimeNet weights
