@@ -218,7 +218,7 @@ def test_eval_sh_matches_reference_formula():
         st = _fwd(sc, cam2, deg=deg, f64=True)
         vis = st["radii"] > 0
         assert vis.sum() > 10
-        np.testing.assert_allclose(st["feat"][vis, :3], z[f"rgb_deg{deg}"][vis], atol=1e-9)
+        np.testing.assert_allclose(st["feat"][vis, :3], z[f"rgb_deg{deg}"][vis], atol=2e-6)  # fixture is fp32
 
 
 def test_knn_and_dist2_against_numpy():
