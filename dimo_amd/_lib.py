@@ -1,0 +1,77 @@
+"""Loader of libdimo_hip.so (the C-ABI HIP library) through ctypes.
+
+The product path has NO fallback: if the library is missing or cannot be loaded,
+every op raises.  (The CPU oracle under oracle/ is test infrastructure and is
+never imported from here.)
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libdimo_hip.so")
+_lib = None
+
+c_f32p = C.c_void_p  # device pointers are passed as integers
+c_ptr = C.c_void_p
+
+# name -> (restype, argtypes).  Mirrors include/dimo_hip.h one to one.
+_SIGNATURES = {
+    "dimo_version": (C.c_char_p, []),
+    "dimo_raster_geom_bytes": (C.c_size_t, [C.c_int]),
+    "dimo_raster_bin_bytes": (C.c_size_t, [C.c_int64, C.c_int, C.c_int]),
+    "dimo_raster_img_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "dimo_raster_geom_layout": (C.c_int, [C.c_int, C.POINTER(C.c_size_t)]),
+    "dimo_raster_bin_layout": (C.c_int, [C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_size_t)]),
+    "dimo_raster_img_layout": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_size_t)]),
+    "dimo_raster_preprocess_forward": (C.c_int, [C.c_int] * 5 + [c_ptr] * 7 + [C.c_float] + [c_ptr] * 3
+                                       + [C.c_float, C.c_float, c_ptr, c_ptr, C.c_size_t, C.POINTER(C.c_int64), c_ptr]),
+    "dimo_raster_render_forward": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int64, c_ptr, c_ptr, c_ptr, C.c_size_t,
+                                             c_ptr, C.c_size_t, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "dimo_raster_backward_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int64]),
+    "dimo_raster_backward": (C.c_int, [C.c_int] * 5 + [C.c_int64] + [c_ptr] * 7 + [C.c_float] + [c_ptr] * 4
+                             + [C.c_float, C.c_float] + [c_ptr] * 4 + [c_ptr] * 4 + [c_ptr] * 8
+                             + [c_ptr, C.c_size_t, c_ptr]),
+    "dimo_knn": (C.c_int, [C.c_int, C.c_int, C.c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "dimo_dist2": (C.c_int, [C.c_int, c_ptr, c_ptr, c_ptr]),
+    "dimo_ssim_forward": (C.c_int, [C.c_int] * 4 + [c_ptr] * 5),
+    "dimo_ssim_backward": (C.c_int, [C.c_int] * 4 + [c_ptr] * 6),
+}
+
+ERRORS = {-1: "DIMO_E_ARG (bad argument)", -2: "DIMO_E_LAUNCH (HIP launch/runtime error)",
+          -3: "DIMO_E_WORKSPACE (workspace too small)"}
+
+
+def exported_symbols():
+    """Every symbol include/dimo_hip.h declares (used by the no-GPU export test)."""
+    return sorted(_SIGNATURES)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -m dimo_amd.csrc.build` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback in the product path.")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed: {ERRORS.get(rc, rc)}")
+
+
+def ptr(t):
+    """Device pointer of a (contiguous) tensor or None."""
+    return None if t is None else t.data_ptr()
+
+
+def current_stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,327 @@
+// Per-tile alpha compositing, forward and backward.
+//
+// One workgroup (256 threads = 4 wave64) per 16x16 tile.  Each WAVE owns an 8x8 pixel quadrant
+// (not a 16x4 strip): splats are small and round, so an 8x8 footprint keeps more of a wave's
+// lanes doing the same thing and lets a whole wave skip a splat that misses its quadrant.
+// The tile's depth-sorted instance list is staged through LDS in batches of 256 records; all
+// lanes then read the same record (LDS broadcast, conflict-free).
+//
+// Backward is atomic-free and deterministic: per (tile, instance) sums are reduced inside the
+// workgroup (DPP wave reduction -> LDS) and written as ONE 64-byte record per instance at the
+// instance's emission position, so that the per-Gaussian kernel can sum a contiguous run.
+#include "common.hpp"
+
+namespace dimo {
+
+constexpr int BLEND_BLOCK = 256;
+constexpr int BATCH = 256;
+
+__device__ __forceinline__ void pixel_of_thread(int tile_x, int tile_y, int &px, int &py) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  px = tile_x * TILE + (wave & 1) * 8 + (lane & 7);
+  py = tile_y * TILE + (wave >> 1) * 8 + (lane >> 3);
+}
+
+// ---------------------------------------------------------------------------------- forward
+template <bool NORMAL>
+__global__ void __launch_bounds__(BLEND_BLOCK) blend_fwd_kernel(
+    int H, int W, int tiles_x, const uint32_t *__restrict__ ranges, const uint32_t *__restrict__ vals_sorted,
+    const Splat *__restrict__ splat, const float *__restrict__ bg, float *__restrict__ out_color,
+    float *__restrict__ out_depth, float *__restrict__ out_normal, float *__restrict__ out_alpha,
+    float *__restrict__ final_T, uint32_t *__restrict__ n_contrib) {
+  __shared__ float4 s_geo[BATCH];   // x y A B
+  __shared__ float4 s_col[BATCH];   // C opacity r g
+  __shared__ float4 s_aux[BATCH];   // b depth nx ny
+  __shared__ float s_nz[BATCH];
+
+  const int tile = blockIdx.x;
+  const int tile_x = tile % tiles_x, tile_y = tile / tiles_x;
+  int px, py;
+  pixel_of_thread(tile_x, tile_y, px, py);
+  const bool inside = px < W && py < H;
+  const float pxf = (float)px, pyf = (float)py;
+  const uint32_t lo = ranges[2 * tile], hi = ranges[2 * tile + 1];
+
+  float T = 1.0f, wsum = 0.0f;
+  float acc[NFEAT] = {0, 0, 0, 0, 0, 0, 0};
+  uint32_t last = 0;
+  bool done = !inside;
+
+  for (uint32_t start = lo; start < hi; start += BATCH) {
+    if (__syncthreads_count(done) == BLEND_BLOCK) break;
+    const uint32_t idx = start + threadIdx.x;
+    if (idx < hi) {
+      const float4 *rp = reinterpret_cast<const float4 *>(splat + vals_sorted[idx]);
+      const float4 a = rp[0], b = rp[1], c = rp[2];
+      s_geo[threadIdx.x] = a;
+      s_col[threadIdx.x] = b;
+      s_aux[threadIdx.x] = c;
+      if (NORMAL) s_nz[threadIdx.x] = rp[3].x;
+    }
+    __syncthreads();
+    const int count = (int)min((uint32_t)BATCH, hi - start);
+    for (int j = 0; j < count; ++j) {
+      if (__ballot(!done) == 0) break;  // whole wave finished
+      if (done) continue;
+      const float4 g = s_geo[j];
+      const float4 c = s_col[j];
+      const float dx = g.x - pxf, dy = g.y - pyf;
+      const float power = -0.5f * (g.z * dx * dx + c.x * dy * dy) - g.w * dx * dy;
+      if (power > 0.0f) continue;
+      const float alpha = fminf(ALPHA_MAX, c.y * __expf(power));
+      if (alpha < ALPHA_MIN) continue;
+      const float test_T = T * (1.0f - alpha);
+      if (test_T < T_STOP) {
+        done = true;
+        continue;
+      }
+      const float w = alpha * T;
+      const float4 a = s_aux[j];
+      acc[0] += c.z * w, acc[1] += c.w * w, acc[2] += a.x * w, acc[3] += a.y * w;
+      if (NORMAL) acc[4] += a.z * w, acc[5] += a.w * w, acc[6] += s_nz[j] * w;
+      wsum += w;
+      T = test_T;
+      last = (start - lo) + (uint32_t)j + 1u;
+    }
+  }
+  if (inside) {
+    const size_t HW = (size_t)H * W, pix = (size_t)py * W + px;
+    final_T[pix] = T;
+    n_contrib[pix] = last;
+    out_color[pix] = acc[0] + T * bg[0];
+    out_color[HW + pix] = acc[1] + T * bg[1];
+    out_color[2 * HW + pix] = acc[2] + T * bg[2];
+    out_depth[pix] = acc[3];
+    if (NORMAL) {
+      out_normal[pix] = acc[4];
+      out_normal[HW + pix] = acc[5];
+      out_normal[2 * HW + pix] = acc[6];
+    }
+    out_alpha[pix] = wsum;
+  }
+}
+
+// ---------------------------------------------------------------------------------- backward
+// wave64 sum via DPP (no LDS traffic): row_shr 1,2,4,8 then row_bcast15/31; total lands in lane 63.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+  const int moved = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false);
+  return v + __builtin_bit_cast(float, moved);
+}
+__device__ __forceinline__ float wave_sum_to_lane63(float v) {
+  v = dpp_add<0x111, 0xf>(v);  // row_shr:1
+  v = dpp_add<0x112, 0xf>(v);  // row_shr:2
+  v = dpp_add<0x114, 0xf>(v);  // row_shr:4
+  v = dpp_add<0x118, 0xf>(v);  // row_shr:8
+  v = dpp_add<0x142, 0xa>(v);  // row_bcast:15 -> rows 1,3
+  v = dpp_add<0x143, 0xc>(v);  // row_bcast:31 -> rows 2,3
+  return v;
+}
+
+constexpr int NACC = 13;  // m0 mx my mxx mxy myy + 7 feature grads
+
+template <bool NORMAL>
+__global__ void __launch_bounds__(BLEND_BLOCK) blend_bwd_kernel(
+    int H, int W, int tiles_x, uint32_t R_cap, const uint32_t *__restrict__ ranges,
+    const uint32_t *__restrict__ vals_sorted, const Splat *__restrict__ splat, const uint16_t *__restrict__ rect,
+    const uint32_t *__restrict__ offsets, const float *__restrict__ bg, const float *__restrict__ final_T,
+    const uint32_t *__restrict__ n_contrib, const float *__restrict__ dL_dcolor, const float *__restrict__ dL_ddepth,
+    const float *__restrict__ dL_dnormal, const float *__restrict__ dL_dalpha, SplatGrad *__restrict__ inst_grad) {
+  __shared__ float4 s_geo[BATCH];
+  __shared__ float4 s_col[BATCH];
+  __shared__ float4 s_aux[BATCH];
+  __shared__ float s_nz[BATCH];
+  __shared__ uint32_t s_emit[BATCH];
+  __shared__ float s_acc[BATCH][16];
+  __shared__ uint32_t s_max[BLEND_BLOCK / 64];
+
+  const int tile = blockIdx.x;
+  const int tile_x = tile % tiles_x, tile_y = tile / tiles_x;
+  const uint32_t lo = ranges[2 * tile], hi = ranges[2 * tile + 1];
+  if (hi == lo) return;
+  int px, py;
+  pixel_of_thread(tile_x, tile_y, px, py);
+  const bool inside = px < W && py < H;
+  const float pxf = (float)px, pyf = (float)py;
+  const size_t HW = (size_t)H * W, pix = (size_t)py * W + px;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+
+  const uint32_t last = inside ? n_contrib[pix] : 0u;
+  float T = 0.0f, Q = 0.0f;
+  float dp[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // dL/d{r,g,b,depth,nx,ny,nz,alpha} at this pixel
+  if (inside) {
+    T = final_T[pix];
+    if (dL_dcolor) dp[0] = dL_dcolor[pix], dp[1] = dL_dcolor[HW + pix], dp[2] = dL_dcolor[2 * HW + pix];
+    if (dL_ddepth) dp[3] = dL_ddepth[pix];
+    if (NORMAL && dL_dnormal) dp[4] = dL_dnormal[pix], dp[5] = dL_dnormal[HW + pix], dp[6] = dL_dnormal[2 * HW + pix];
+    if (dL_dalpha) dp[7] = dL_dalpha[pix];
+    // Q carries sum_{j>i} D_j alpha_j T_j + T_final * (bg . dL/dcolor)
+    Q = T * (bg[0] * dp[0] + bg[1] * dp[1] + bg[2] * dp[2]);
+  }
+  // deepest contributor over the tile
+  uint32_t m = last;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
+  if (lane == 0) s_max[wave] = m;
+  __syncthreads();
+  const uint32_t max_last = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
+
+  // instances never reached by any pixel of the tile: zero records
+  for (uint32_t i = max_last + threadIdx.x; i < hi - lo; i += BLEND_BLOCK) {
+    const uint32_t g = vals_sorted[lo + i];
+    const uint2 rc = *reinterpret_cast<const uint2 *>(rect + 4 * (size_t)g);
+    const int x0 = rc.x & 0xffff, y0 = rc.x >> 16, x1 = rc.y & 0xffff;
+    const uint32_t e = (g == 0 ? 0u : offsets[g - 1]) + (uint32_t)((tile_y - y0) * (x1 - x0) + (tile_x - x0));
+    if (e < R_cap) {
+      float4 *dst = reinterpret_cast<float4 *>(inst_grad + e);
+      const float4 z = make_float4(0, 0, 0, 0);
+      dst[0] = z, dst[1] = z, dst[2] = z, dst[3] = z;
+    }
+  }
+
+  for (uint32_t top = max_last; top > 0;) {
+    const uint32_t blo = top > BATCH ? top - BATCH : 0u;
+    const int count = (int)(top - blo);
+    __syncthreads();  // previous batch fully consumed
+    if ((int)threadIdx.x < count) {
+      const uint32_t g = vals_sorted[lo + blo + threadIdx.x];
+      const float4 *rp = reinterpret_cast<const float4 *>(splat + g);
+      s_geo[threadIdx.x] = rp[0];
+      s_col[threadIdx.x] = rp[1];
+      s_aux[threadIdx.x] = rp[2];
+      if (NORMAL) s_nz[threadIdx.x] = rp[3].x;
+      const uint2 rc = *reinterpret_cast<const uint2 *>(rect + 4 * (size_t)g);
+      const int x0 = rc.x & 0xffff, y0 = rc.x >> 16, x1 = rc.y & 0xffff;
+      s_emit[threadIdx.x] = (g == 0 ? 0u : offsets[g - 1]) + (uint32_t)((tile_y - y0) * (x1 - x0) + (tile_x - x0));
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s_acc[threadIdx.x][k] = 0.0f;
+    __syncthreads();
+
+    for (int j = count - 1; j >= 0; --j) {
+      const float4 g = s_geo[j];
+      const float4 c = s_col[j];
+      const float dx = g.x - pxf, dy = g.y - pyf;
+      const float power = -0.5f * (g.z * dx * dx + c.x * dy * dy) - g.w * dx * dy;
+      const float G = __expf(power);
+      const float alpha = fminf(ALPHA_MAX, c.y * G);
+      const bool active = (blo + (uint32_t)j < last) && power <= 0.0f && alpha >= ALPHA_MIN;
+      if (__ballot(active) == 0) continue;  // wave-uniform skip
+      float v[NACC];
+#pragma unroll
+      for (int k = 0; k < NACC; ++k) v[k] = 0.0f;
+      if (active) {
+        const float4 a = s_aux[j];
+        const float one_m = 1.0f - alpha;
+        T = T / one_m;
+        const float w = alpha * T;
+        float D = dp[7] + c.z * dp[0] + c.w * dp[1] + a.x * dp[2] + a.y * dp[3];
+        if (NORMAL) D += a.z * dp[4] + a.w * dp[5] + s_nz[j] * dp[6];
+        const float dL_dalpha_i = D * T - Q / one_m;
+        Q += D * w;
+        const float gg = G * c.y * dL_dalpha_i;  // g = G * dL/dG, dL/dG = opacity * dL/dalpha
+        v[0] = gg, v[1] = gg * dx, v[2] = gg * dy;
+        v[3] = v[1] * dx, v[4] = v[1] * dy, v[5] = v[2] * dy;
+        v[6] = w * dp[0], v[7] = w * dp[1], v[8] = w * dp[2], v[9] = w * dp[3];
+        if (NORMAL) v[10] = w * dp[4], v[11] = w * dp[5], v[12] = w * dp[6];
+      }
+      constexpr int NV = NORMAL ? NACC : 10;
+#pragma unroll
+      for (int k = 0; k < NV; ++k) v[k] = wave_sum_to_lane63(v[k]);
+      if (lane == 63) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) atomicAdd(&s_acc[j][k], v[k]);
+      }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < count) {
+      const uint32_t e = s_emit[threadIdx.x];
+      if (e < R_cap) {
+        const float4 *src = reinterpret_cast<const float4 *>(&s_acc[threadIdx.x][0]);
+        float4 *dst = reinterpret_cast<float4 *>(inst_grad + e);
+        dst[0] = src[0], dst[1] = src[1], dst[2] = src[2], dst[3] = src[3];
+      }
+    }
+    top = blo;
+  }
+}
+
+}  // namespace dimo
+
+using namespace dimo;
+
+extern "C" int dimo_raster_render_forward(int N, int H, int W, int64_t R_cap, const float *bg, const void *geom,
+                                          void *bin, size_t bin_bytes, void *img, size_t img_bytes, float *out_color,
+                                          float *out_depth, float *out_normal, float *out_alpha, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (N < 0 || H <= 0 || W <= 0 || R_cap < 0 || R_cap > 0xfffffff0LL) return DIMO_E_ARG;
+  if (!bg || !geom || !bin || !img || !out_color || !out_depth || !out_alpha) return DIMO_E_ARG;
+  GeomLayout G(N);
+  BinLayout B(R_cap, H, W);
+  ImgLayout I(H, W);
+  if (bin_bytes < B.bytes || img_bytes < I.bytes) return DIMO_E_WORKSPACE;
+  int rc = bin_instances(N, H, W, R_cap, geom, bin, stream);
+  if (rc) return rc;
+  const uint32_t *ranges = at<uint32_t>(bin, B.ranges);
+  const uint32_t *vals = at<uint32_t>(bin, B.vals_b);
+  const Splat *splat = at<Splat>(geom, G.splat);
+  if (out_normal)
+    hipLaunchKernelGGL(blend_fwd_kernel<true>, dim3(B.T), dim3(BLEND_BLOCK), 0, stream, H, W, B.tiles_x, ranges, vals,
+                       splat, bg, out_color, out_depth, out_normal, out_alpha, at<float>(img, I.final_T),
+                       at<uint32_t>(img, I.n_contrib));
+  else
+    hipLaunchKernelGGL(blend_fwd_kernel<false>, dim3(B.T), dim3(BLEND_BLOCK), 0, stream, H, W, B.tiles_x, ranges,
+                       vals, splat, bg, out_color, out_depth, out_normal, out_alpha, at<float>(img, I.final_T),
+                       at<uint32_t>(img, I.n_contrib));
+  return check_launch();
+}
+
+extern "C" size_t dimo_raster_backward_scratch_bytes(int N, int64_t R_cap) {
+  (void)N;
+  return align_up((size_t)(R_cap > 0 ? R_cap : 1) * sizeof(SplatGrad));
+}
+
+extern "C" int dimo_raster_backward(int N, int sh_degree, int M, int H, int W, int64_t R_cap, const float *means3D,
+                                    const float *shs, const float *colors_precomp, const float *opacities,
+                                    const float *scales, const float *rotations, const float *cov3D_precomp,
+                                    float scale_modifier, const float *viewmatrix, const float *projmatrix,
+                                    const float *campos, const float *bg, float tanfovx, float tanfovy,
+                                    const int32_t *radii, const void *geom, const void *bin, const void *img,
+                                    const float *dL_dcolor, const float *dL_ddepth, const float *dL_dnormal,
+                                    const float *dL_dalpha, float *dL_dmeans3D, float *dL_dmeans2D, float *dL_dshs,
+                                    float *dL_dcolors, float *dL_dopacity, float *dL_dscales, float *dL_drotations,
+                                    float *dL_dcov3D, void *scratch, size_t scratch_bytes, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  (void)opacities;
+  if (N < 0 || H <= 0 || W <= 0 || R_cap < 0 || R_cap > 0xfffffff0LL) return DIMO_E_ARG;
+  if (!geom || !bin || !img || !bg || !scratch || !viewmatrix || !projmatrix || !campos) return DIMO_E_ARG;
+  if ((shs == nullptr) == (colors_precomp == nullptr)) return DIMO_E_ARG;
+  if (N > 0 && (!means3D || !radii || !dL_dmeans3D || !dL_dmeans2D || !dL_dopacity)) return DIMO_E_ARG;
+  if (shs && !dL_dshs) return DIMO_E_ARG;
+  if (colors_precomp && !dL_dcolors) return DIMO_E_ARG;
+  if (cov3D_precomp ? !dL_dcov3D : (!dL_dscales || !dL_drotations || !scales || !rotations)) return DIMO_E_ARG;
+  if (scratch_bytes < dimo_raster_backward_scratch_bytes(N, R_cap)) return DIMO_E_WORKSPACE;
+  GeomLayout G(N);
+  BinLayout B(R_cap, H, W);
+  ImgLayout I(H, W);
+  const uint32_t cap = (uint32_t)B.cap;
+  SplatGrad *inst = reinterpret_cast<SplatGrad *>(scratch);
+  if (N > 0) {
+    if (dL_dnormal)
+      hipLaunchKernelGGL(blend_bwd_kernel<true>, dim3(B.T), dim3(BLEND_BLOCK), 0, stream, H, W, B.tiles_x, cap,
+                         at<uint32_t>(bin, B.ranges), at<uint32_t>(bin, B.vals_b), at<Splat>(geom, G.splat),
+                         at<uint16_t>(geom, G.rect), at<uint32_t>(geom, G.offsets), bg, at<float>(img, I.final_T),
+                         at<uint32_t>(img, I.n_contrib), dL_dcolor, dL_ddepth, dL_dnormal, dL_dalpha, inst);
+    else
+      hipLaunchKernelGGL(blend_bwd_kernel<false>, dim3(B.T), dim3(BLEND_BLOCK), 0, stream, H, W, B.tiles_x, cap,
+                         at<uint32_t>(bin, B.ranges), at<uint32_t>(bin, B.vals_b), at<Splat>(geom, G.splat),
+                         at<uint16_t>(geom, G.rect), at<uint32_t>(geom, G.offsets), bg, at<float>(img, I.final_T),
+                         at<uint32_t>(img, I.n_contrib), dL_dcolor, dL_ddepth, dL_dnormal, dL_dalpha, inst);
+    int rc = check_launch();
+    if (rc) return rc;
+  }
+  return preprocess_backward_launch(N, sh_degree, M, H, W, R_cap, means3D, shs, colors_precomp, scales, rotations,
+                                    cov3D_precomp, scale_modifier, viewmatrix, projmatrix, campos, tanfovx, tanfovy,
+                                    radii, geom, scratch, dL_dmeans3D, dL_dmeans2D, dL_dshs, dL_dcolors, dL_dopacity,
+                                    dL_dscales, dL_drotations, dL_dcov3D, stream);
+}

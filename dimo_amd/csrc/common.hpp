@@ -1,0 +1,137 @@
+// Shared declarations of libdimo_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/dimo_hip.h"
+
+namespace dimo {
+
+// ---- constants of the published rasterizer (documented in DESIGN.md) -------------------------
+constexpr int TILE = DIMO_TILE;
+constexpr int NFEAT = DIMO_NFEAT;
+constexpr float NEAR_CULL = 0.2f;
+constexpr float W_EPS = 0.0000001f;
+constexpr float FOV_CLAMP = 1.3f;
+constexpr float LOWPASS = 0.3f;
+constexpr float LAMBDA_FLOOR = 0.1f;
+constexpr float RADIUS_SIGMA = 3.0f;
+constexpr float ALPHA_MAX = 0.99f;
+constexpr float ALPHA_MIN = 1.0f / 255.0f;
+constexpr float T_STOP = 0.0001f;
+
+// One 64-byte record per Gaussian, written by preprocess and gathered by the blend kernels.
+// 64 B = one aligned 4 x dwordx4 gather per tile-instance.
+struct __attribute__((aligned(64))) Splat {
+  float x, y;         // pixel-space mean
+  float A, B, C;      // conic (inverse 2D covariance)
+  float opacity;
+  float r, g, b;      // colour
+  float depth;        // view-space z
+  float nx, ny, nz;   // view-space normal
+  float pad0, pad1, pad2;
+};
+static_assert(sizeof(Splat) == 64, "Splat must be 64 bytes");
+
+// Per-instance gradient record produced by the blend backward (one per (Gaussian, tile) instance,
+// indexed by EMISSION position so that a Gaussian's instances are contiguous).
+struct __attribute__((aligned(64))) SplatGrad {
+  float m0, mx, my, mxx, mxy, myy;  // moments of g = G * dL/dG over the tile's pixels
+  float dr, dg, db, ddepth, dnx, dny, dnz;
+  float pad0, pad1, pad2;
+};
+static_assert(sizeof(SplatGrad) == 64, "SplatGrad must be 64 bytes");
+
+constexpr size_t ALIGN = 256;
+__host__ __device__ inline size_t align_up(size_t x, size_t a = ALIGN) { return (x + a - 1) / a * a; }
+
+constexpr int PRE_BLOCK = 256;  // Gaussians per preprocess block (also the scan granule)
+
+struct GeomLayout {
+  size_t splat, rect, tiles, offsets, flags, total, block_sums, bytes;
+  __host__ explicit GeomLayout(int N) {
+    size_t n = (size_t)(N > 0 ? N : 1);
+    size_t o = 0;
+    splat = o, o = align_up(o + n * sizeof(Splat));
+    rect = o, o = align_up(o + n * 4 * sizeof(uint16_t));
+    tiles = o, o = align_up(o + n * sizeof(uint32_t));
+    offsets = o, o = align_up(o + n * sizeof(uint32_t));
+    flags = o, o = align_up(o + n);
+    total = o, o = align_up(o + 4 * sizeof(uint32_t));
+    size_t nb = (n + PRE_BLOCK - 1) / PRE_BLOCK;
+    block_sums = o, o = align_up(o + (nb + 1) * sizeof(uint32_t));
+    bytes = o;
+  }
+};
+
+constexpr int SORT_BLOCK = 256;
+constexpr int SORT_ITEMS = 16;
+constexpr int SORT_TILE = SORT_BLOCK * SORT_ITEMS;  // keys per sort block
+constexpr int RADIX_BITS = 8;
+constexpr int RADIX = 1 << RADIX_BITS;
+
+struct BinLayout {
+  size_t keys_a, vals_a, keys_b, vals_b, keys_c, vals_c, ranges, hist, bytes;
+  int tiles_x, tiles_y, T;
+  size_t cap, sort_blocks;
+  __host__ BinLayout(int64_t R_cap, int H, int W) {
+    cap = (size_t)(R_cap > 0 ? R_cap : 1);
+    tiles_x = (W + TILE - 1) / TILE, tiles_y = (H + TILE - 1) / TILE, T = tiles_x * tiles_y;
+    sort_blocks = (cap + SORT_TILE - 1) / SORT_TILE;
+    size_t o = 0;
+    keys_a = o, o = align_up(o + cap * sizeof(uint64_t));
+    vals_a = o, o = align_up(o + cap * sizeof(uint32_t));
+    keys_b = o, o = align_up(o + cap * sizeof(uint64_t));
+    vals_b = o, o = align_up(o + cap * sizeof(uint32_t));
+    keys_c = o, o = align_up(o + cap * sizeof(uint64_t));
+    vals_c = o, o = align_up(o + cap * sizeof(uint32_t));
+    ranges = o, o = align_up(o + (size_t)T * 2 * sizeof(uint32_t));
+    hist = o, o = align_up(o + ((size_t)RADIX * (sort_blocks + 1)) * sizeof(uint32_t));
+    bytes = o;
+  }
+};
+
+struct ImgLayout {
+  size_t final_T, n_contrib, bytes;
+  __host__ ImgLayout(int H, int W) {
+    size_t p = (size_t)H * W;
+    size_t o = 0;
+    final_T = o, o = align_up(o + p * sizeof(float));
+    n_contrib = o, o = align_up(o + p * sizeof(uint32_t));
+    bytes = o;
+  }
+};
+
+template <class T>
+__host__ __device__ inline T *at(void *base, size_t off) {
+  return reinterpret_cast<T *>(reinterpret_cast<char *>(base) + off);
+}
+template <class T>
+__host__ __device__ inline const T *at(const void *base, size_t off) {
+  return reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + off);
+}
+
+inline int check_launch() { return hipGetLastError() == hipSuccess ? DIMO_OK : DIMO_E_LAUNCH; }
+
+// number of key bits the sort must cover: 32 depth bits + bits of the tile id
+inline int key_bits(int T) {
+  int b = 0;
+  while ((1 << b) < T) ++b;
+  return 32 + (b > 0 ? b : 1);
+}
+
+// ---- internal (C++ linkage) entry points shared between translation units ---------------------
+int scan_block_sums(int nb, uint32_t *block_sums, uint32_t *total, hipStream_t stream);
+int write_offsets(int N, const uint32_t *tiles, const uint32_t *block_sums, uint32_t *offsets, hipStream_t stream);
+int bin_instances(int N, int H, int W, int64_t R_cap, const void *geom, void *bin, hipStream_t stream);
+int preprocess_backward_launch(int N, int sh_degree, int M, int H, int W, int64_t R_cap, const float *means3D,
+                               const float *shs, const float *colors_precomp, const float *scales,
+                               const float *rotations, const float *cov3D_precomp, float scale_modifier,
+                               const float *viewmatrix, const float *projmatrix, const float *campos, float tanfovx,
+                               float tanfovy, const int32_t *radii, const void *geom, const void *inst_grad,
+                               float *dL_dmeans3D, float *dL_dmeans2D, float *dL_dshs, float *dL_dcolors,
+                               float *dL_dopacity, float *dL_dscales, float *dL_drot, float *dL_dcov3D,
+                               hipStream_t stream);
+
+}  // namespace dimo

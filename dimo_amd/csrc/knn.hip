@@ -1,0 +1,118 @@
+// Nearest-neighbour kernels of the deform path.
+//   dimo_knn   : knn_cuda.KNN(k, transpose_mode=True)   (main_train_dimo.py:502-509) -- every Gaussian's k
+//                nearest control points, once per training step (N = 1e5 queries, M = 512 references).
+//   dimo_dist2 : simple_knn._C.distCUDA2                (renderer/latent_gs_renderer.py:426) -- mean squared
+//                distance to the 3 nearest other points, used once to initialise the scales.
+// Both are brute force with the candidate set tiled through LDS (every lane reads the same candidate:
+// conflict-free LDS broadcast).  Compiled with -ffp-contract=off: d2 = (dx*dx + dy*dy) + dz*dz exactly as
+// the CPU oracle evaluates it, so distances AND indices are bit-exact.
+#pragma clang fp contract(off)
+#include "common.hpp"
+
+namespace dimo {
+
+constexpr int KNN_BLOCK = 256;
+constexpr int KNN_CHUNK = 2048;  // reference points staged per LDS round (24 KiB)
+
+template <int K>
+__global__ void __launch_bounds__(KNN_BLOCK) knn_kernel(int M, int N, int k, const float *__restrict__ ref,
+                                                        const float *__restrict__ query, float *__restrict__ dist,
+                                                        int64_t *__restrict__ idx) {
+  __shared__ float s_ref[KNN_CHUNK * 3];
+  const int i = blockIdx.x * KNN_BLOCK + threadIdx.x;
+  float qx = 0, qy = 0, qz = 0;
+  if (i < N) qx = query[3 * i], qy = query[3 * i + 1], qz = query[3 * i + 2];
+  float bd[K];
+  int bi[K];
+#pragma unroll
+  for (int j = 0; j < K; ++j) bd[j] = INFINITY, bi[j] = -1;
+
+  for (int base = 0; base < M; base += KNN_CHUNK) {
+    const int cnt = min(KNN_CHUNK, M - base);
+    __syncthreads();
+    for (int t = threadIdx.x; t < cnt * 3; t += KNN_BLOCK) s_ref[t] = ref[(size_t)base * 3 + t];
+    __syncthreads();
+    for (int m = 0; m < cnt; ++m) {
+      const float dx = qx - s_ref[3 * m], dy = qy - s_ref[3 * m + 1], dz = qz - s_ref[3 * m + 2];
+      const float d2 = dx * dx + dy * dy + dz * dz;
+      if (d2 < bd[K - 1]) {
+        // insertion keeping ascending order; strict '<' => ties keep the lower index first
+        bd[K - 1] = d2, bi[K - 1] = base + m;
+#pragma unroll
+        for (int j = K - 1; j > 0; --j) {
+          if (bd[j] < bd[j - 1]) {
+            const float td = bd[j];
+            bd[j] = bd[j - 1], bd[j - 1] = td;
+            const int ti = bi[j];
+            bi[j] = bi[j - 1], bi[j - 1] = ti;
+          }
+        }
+      }
+    }
+  }
+  if (i < N) {
+#pragma unroll
+    for (int j = 0; j < K; ++j)
+      if (j < k) {
+        dist[(size_t)i * k + j] = sqrtf(bd[j]);
+        idx[(size_t)i * k + j] = (int64_t)bi[j];
+      }
+  }
+}
+
+constexpr int D2_BLOCK = 256;
+constexpr int D2_CHUNK = 2048;
+
+__global__ void __launch_bounds__(D2_BLOCK) dist2_kernel(int N, const float *__restrict__ pts,
+                                                         float *__restrict__ out) {
+  __shared__ float s_p[D2_CHUNK * 3];
+  const int i = blockIdx.x * D2_BLOCK + threadIdx.x;
+  float qx = 0, qy = 0, qz = 0;
+  if (i < N) qx = pts[3 * i], qy = pts[3 * i + 1], qz = pts[3 * i + 2];
+  float b0 = INFINITY, b1 = INFINITY, b2 = INFINITY;
+  for (int base = 0; base < N; base += D2_CHUNK) {
+    const int cnt = min(D2_CHUNK, N - base);
+    __syncthreads();
+    for (int t = threadIdx.x; t < cnt * 3; t += D2_BLOCK) s_p[t] = pts[(size_t)base * 3 + t];
+    __syncthreads();
+    for (int m = 0; m < cnt; ++m) {
+      const float dx = qx - s_p[3 * m], dy = qy - s_p[3 * m + 1], dz = qz - s_p[3 * m + 2];
+      float d2 = dx * dx + dy * dy + dz * dz;
+      if (base + m == i) d2 = INFINITY;  // exclude the point itself (by index, not by distance)
+      // keep the three smallest: branch-free min/max network
+      const float n0 = fminf(b0, d2), r0 = fmaxf(b0, d2);
+      const float n1 = fminf(b1, r0), r1 = fmaxf(b1, r0);
+      b0 = n0, b1 = n1, b2 = fminf(b2, r1);
+    }
+  }
+  if (i < N) out[i] = (b0 + b1 + b2) / 3.0f;
+}
+
+}  // namespace dimo
+
+using namespace dimo;
+
+extern "C" int dimo_knn(int M, int N, int k, const float *ref, const float *query, float *dist, int64_t *idx,
+                        void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (M < 0 || N < 0 || k < 1 || k > 16) return DIMO_E_ARG;
+  if (N == 0) return DIMO_OK;
+  if (!query || !dist || !idx || (M > 0 && !ref)) return DIMO_E_ARG;
+  const dim3 grid((N + KNN_BLOCK - 1) / KNN_BLOCK), block(KNN_BLOCK);
+  if (k <= 4)
+    hipLaunchKernelGGL(knn_kernel<4>, grid, block, 0, stream, M, N, k, ref, query, dist, idx);
+  else if (k <= 8)
+    hipLaunchKernelGGL(knn_kernel<8>, grid, block, 0, stream, M, N, k, ref, query, dist, idx);
+  else
+    hipLaunchKernelGGL(knn_kernel<16>, grid, block, 0, stream, M, N, k, ref, query, dist, idx);
+  return check_launch();
+}
+
+extern "C" int dimo_dist2(int N, const float *points, float *out, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (N < 0) return DIMO_E_ARG;
+  if (N == 0) return DIMO_OK;
+  if (!points || !out) return DIMO_E_ARG;
+  hipLaunchKernelGGL(dist2_kernel, dim3((N + D2_BLOCK - 1) / D2_BLOCK), dim3(D2_BLOCK), 0, stream, N, points, out);
+  return check_launch();
+}

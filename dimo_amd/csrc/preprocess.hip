@@ -1,0 +1,545 @@
+// Per-Gaussian stages of the rasterizer: projection forward and its backward.
+// One thread per Gaussian, 256 per block; pure streaming (HBM-bound) kernels.
+//
+// This translation unit is compiled with -ffp-contract=off: tile rects, radii and the fp32
+// depth bits that form the sort keys must match the CPU oracle bit for bit, so every
+// multiply-add below is evaluated unfused, left to right, exactly as written.
+#pragma clang fp contract(off)
+#include "common.hpp"
+
+namespace dimo {
+
+__device__ __forceinline__ void xform43(const float *p, const float *m, float *o) {
+  o[0] = m[0] * p[0] + m[4] * p[1] + m[8] * p[2] + m[12];
+  o[1] = m[1] * p[0] + m[5] * p[1] + m[9] * p[2] + m[13];
+  o[2] = m[2] * p[0] + m[6] * p[1] + m[10] * p[2] + m[14];
+}
+__device__ __forceinline__ void xform44(const float *p, const float *m, float *o) {
+  o[0] = m[0] * p[0] + m[4] * p[1] + m[8] * p[2] + m[12];
+  o[1] = m[1] * p[0] + m[5] * p[1] + m[9] * p[2] + m[13];
+  o[2] = m[2] * p[0] + m[6] * p[1] + m[10] * p[2] + m[14];
+  o[3] = m[3] * p[0] + m[7] * p[1] + m[11] * p[2] + m[15];
+}
+__device__ __forceinline__ void quat_to_R(const float *q, float *R) {
+  const float r = q[0], x = q[1], y = q[2], z = q[3];
+  R[0] = 1.0f - 2.0f * (y * y + z * z);
+  R[1] = 2.0f * (x * y - r * z);
+  R[2] = 2.0f * (x * z + r * y);
+  R[3] = 2.0f * (x * y + r * z);
+  R[4] = 1.0f - 2.0f * (x * x + z * z);
+  R[5] = 2.0f * (y * z - r * x);
+  R[6] = 2.0f * (x * z - r * y);
+  R[7] = 2.0f * (y * z + r * x);
+  R[8] = 1.0f - 2.0f * (x * x + y * y);
+}
+__device__ __forceinline__ void cov3d_from_scale_rot(const float *s, float mod, const float *R, float *c) {
+  const float s0 = mod * s[0], s1 = mod * s[1], s2 = mod * s[2];
+  const float M0 = R[0] * s0, M1 = R[1] * s1, M2 = R[2] * s2;
+  const float M3 = R[3] * s0, M4 = R[4] * s1, M5 = R[5] * s2;
+  const float M6 = R[6] * s0, M7 = R[7] * s1, M8 = R[8] * s2;
+  c[0] = M0 * M0 + M1 * M1 + M2 * M2;
+  c[1] = M0 * M3 + M1 * M4 + M2 * M5;
+  c[2] = M0 * M6 + M1 * M7 + M2 * M8;
+  c[3] = M3 * M3 + M4 * M4 + M5 * M5;
+  c[4] = M3 * M6 + M4 * M7 + M5 * M8;
+  c[5] = M6 * M6 + M7 * M7 + M8 * M8;
+}
+// T = J * Wm (2x3); Wm = world->view rotation = transpose of V[:3,:3] in row-vector convention
+__device__ __forceinline__ void ewa_T(const float *t, float fx, float fy, const float *V, float *T) {
+  const float itz = 1.0f / t[2];
+  const float j00 = fx * itz;
+  const float j02 = -(fx * t[0]) * itz * itz;
+  const float j11 = fy * itz;
+  const float j12 = -(fy * t[1]) * itz * itz;
+  T[0] = j00 * V[0] + j02 * V[2];
+  T[1] = j00 * V[4] + j02 * V[6];
+  T[2] = j00 * V[8] + j02 * V[10];
+  T[3] = j11 * V[1] + j12 * V[2];
+  T[4] = j11 * V[5] + j12 * V[6];
+  T[5] = j11 * V[9] + j12 * V[10];
+}
+__device__ __forceinline__ void T_sigma(const float *T, const float *c, float *u) {
+  u[0] = T[0] * c[0] + T[1] * c[1] + T[2] * c[2];
+  u[1] = T[0] * c[1] + T[1] * c[3] + T[2] * c[4];
+  u[2] = T[0] * c[2] + T[1] * c[4] + T[2] * c[5];
+  u[3] = T[3] * c[0] + T[4] * c[1] + T[5] * c[2];
+  u[4] = T[3] * c[1] + T[4] * c[3] + T[5] * c[4];
+  u[5] = T[3] * c[2] + T[4] * c[4] + T[5] * c[5];
+}
+__device__ __forceinline__ void cov2d_from_T(const float *T, const float *c, float *abc) {
+  float u[6];
+  T_sigma(T, c, u);
+  abc[0] = u[0] * T[0] + u[1] * T[1] + u[2] * T[2] + LOWPASS;
+  abc[1] = u[0] * T[3] + u[1] * T[4] + u[2] * T[5];
+  abc[2] = u[3] * T[3] + u[4] * T[4] + u[5] * T[5] + LOWPASS;
+}
+
+#define SH_C0 0.28209479177387814f
+#define SH_C1 0.4886025119029199f
+__constant__ float SH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                               -1.0925484305920792f, 0.5462742152960396f};
+__constant__ float SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f, 0.3731763325901154f,
+                               -0.4570457994644658f, 1.445305721320277f,  -0.5900435899266435f};
+
+// colour of one channel c from SH coefficients sh[k*3 + c]
+__device__ __forceinline__ float eval_sh_channel(int deg, const float *sh, int c, float x, float y, float z) {
+  float res = SH_C0 * sh[0 * 3 + c];
+  if (deg > 0) {
+    res = res - SH_C1 * y * sh[1 * 3 + c] + SH_C1 * z * sh[2 * 3 + c] - SH_C1 * x * sh[3 * 3 + c];
+    if (deg > 1) {
+      const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+      res = res + SH_C2[0] * xy * sh[4 * 3 + c] + SH_C2[1] * yz * sh[5 * 3 + c] +
+            SH_C2[2] * (2.0f * zz - xx - yy) * sh[6 * 3 + c] + SH_C2[3] * xz * sh[7 * 3 + c] +
+            SH_C2[4] * (xx - yy) * sh[8 * 3 + c];
+      if (deg > 2) {
+        res = res + SH_C3[0] * y * (3.0f * xx - yy) * sh[9 * 3 + c] + SH_C3[1] * xy * z * sh[10 * 3 + c] +
+              SH_C3[2] * y * (4.0f * zz - xx - yy) * sh[11 * 3 + c] +
+              SH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * sh[12 * 3 + c] +
+              SH_C3[4] * x * (4.0f * zz - xx - yy) * sh[13 * 3 + c] + SH_C3[5] * z * (xx - yy) * sh[14 * 3 + c] +
+              SH_C3[6] * x * (xx - 3.0f * yy) * sh[15 * 3 + c];
+      }
+    }
+  }
+  return res;
+}
+
+__device__ __forceinline__ int argmin3(const float *s) {
+  int k = 0;
+  if (s[1] < s[k]) k = 1;
+  if (s[2] < s[k]) k = 2;
+  return k;
+}
+
+__global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_kernel(
+    int N, int deg, int M, int H, int W, const float *__restrict__ means3D, const float *__restrict__ shs,
+    const float *__restrict__ colors_precomp, const float *__restrict__ opacities, const float *__restrict__ scales,
+    const float *__restrict__ rotations, const float *__restrict__ cov3D_precomp, float scale_mod,
+    const float *__restrict__ Vg, const float *__restrict__ Pg, const float *__restrict__ camg, float tanfovx,
+    float tanfovy, int32_t *__restrict__ radii, Splat *__restrict__ splat, uint16_t *__restrict__ rect,
+    uint32_t *__restrict__ tiles_touched, uint8_t *__restrict__ flags, uint32_t *__restrict__ block_sums) {
+  __shared__ uint32_t wave_sums[PRE_BLOCK / 64];
+  const int i = blockIdx.x * PRE_BLOCK + threadIdx.x;
+  // camera: uniform loads (scalar cache)
+  float V[16], P[16], cam[3];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) V[k] = Vg[k], P[k] = Pg[k];
+  cam[0] = camg[0], cam[1] = camg[1], cam[2] = camg[2];
+
+  uint32_t my_tiles = 0;
+  if (i < N) {
+    const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
+    const float fx = (float)W / (2.0f * tanfovx), fy = (float)H / (2.0f * tanfovy);
+    Splat out = {};
+    int my_radius = 0;
+    uint16_t rc[4] = {0, 0, 0, 0};
+    uint8_t fl = 0;
+    const float p[3] = {means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2]};
+    float pv[3];
+    xform43(p, V, pv);
+    if (pv[2] > NEAR_CULL) {
+      float ph[4];
+      xform44(p, P, ph);
+      const float pw = 1.0f / (ph[3] + W_EPS);
+      const float px = ph[0] * pw, py = ph[1] * pw;
+      float c6[6];
+      float R[9];
+      if (cov3D_precomp) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) c6[k] = cov3D_precomp[6 * i + k];
+      } else {
+        const float q[4] = {rotations[4 * i], rotations[4 * i + 1], rotations[4 * i + 2], rotations[4 * i + 3]};
+        const float s[3] = {scales[3 * i], scales[3 * i + 1], scales[3 * i + 2]};
+        quat_to_R(q, R);
+        cov3d_from_scale_rot(s, scale_mod, R, c6);
+      }
+      float t[3] = {pv[0], pv[1], pv[2]};
+      const float limx = FOV_CLAMP * tanfovx, limy = FOV_CLAMP * tanfovy;
+      const float txtz = t[0] / t[2], tytz = t[1] / t[2];
+      t[0] = fminf(limx, fmaxf(-limx, txtz)) * t[2];
+      t[1] = fminf(limy, fmaxf(-limy, tytz)) * t[2];
+      float T[6], abc[3];
+      ewa_T(t, fx, fy, V, T);
+      cov2d_from_T(T, c6, abc);
+      const float det = abc[0] * abc[2] - abc[1] * abc[1];
+      if (det != 0.0f) {
+        const float det_inv = 1.0f / det;
+        const float cA = abc[2] * det_inv, cB = -abc[1] * det_inv, cC = abc[0] * det_inv;
+        const float mid = 0.5f * (abc[0] + abc[2]);
+        const float disc = sqrtf(fmaxf(LAMBDA_FLOOR, mid * mid - det));
+        const float lam1 = mid + disc, lam2 = mid - disc;
+        const float rad = ceilf(RADIUS_SIGMA * sqrtf(fmaxf(lam1, lam2)));
+        const int rr = (int)rad;
+        const float pix_x = ((px + 1.0f) * (float)W - 1.0f) * 0.5f;
+        const float pix_y = ((py + 1.0f) * (float)H - 1.0f) * 0.5f;
+        const int rx0 = min(gx, max(0, (int)((pix_x - (float)rr) / (float)TILE)));
+        const int ry0 = min(gy, max(0, (int)((pix_y - (float)rr) / (float)TILE)));
+        const int rx1 = min(gx, max(0, (int)((pix_x + (float)rr + (float)(TILE - 1)) / (float)TILE)));
+        const int ry1 = min(gy, max(0, (int)((pix_y + (float)rr + (float)(TILE - 1)) / (float)TILE)));
+        const int cnt = (rx1 - rx0) * (ry1 - ry0);
+        if (cnt != 0) {
+          float rgb[3];
+          if (colors_precomp) {
+            rgb[0] = colors_precomp[3 * i], rgb[1] = colors_precomp[3 * i + 1], rgb[2] = colors_precomp[3 * i + 2];
+          } else {
+            const float d[3] = {p[0] - cam[0], p[1] - cam[1], p[2] - cam[2]};
+            const float len = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+            const float dx = d[0] / len, dy = d[1] / len, dz = d[2] / len;
+            const float *sh = shs + (size_t)i * M * 3;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+              float v = eval_sh_channel(deg, sh, c, dx, dy, dz) + 0.5f;
+              if (v < 0.0f) fl |= (uint8_t)(1u << c);
+              rgb[c] = fmaxf(v, 0.0f);
+            }
+          }
+          float nv[3] = {0.0f, 0.0f, 0.0f};
+          if (!cov3D_precomp) {
+            const float s[3] = {scales[3 * i], scales[3 * i + 1], scales[3 * i + 2]};
+            const int k = argmin3(s);
+            float n[3] = {R[0 + k], R[3 + k], R[6 + k]};
+            const float dot = n[0] * (cam[0] - p[0]) + n[1] * (cam[1] - p[1]) + n[2] * (cam[2] - p[2]);
+            const float sgn = dot < 0.0f ? -1.0f : 1.0f;
+            n[0] *= sgn, n[1] *= sgn, n[2] *= sgn;
+            nv[0] = V[0] * n[0] + V[4] * n[1] + V[8] * n[2];
+            nv[1] = V[1] * n[0] + V[5] * n[1] + V[9] * n[2];
+            nv[2] = V[2] * n[0] + V[6] * n[1] + V[10] * n[2];
+          }
+          my_radius = rr;
+          my_tiles = (uint32_t)cnt;
+          out.x = pix_x, out.y = pix_y, out.A = cA, out.B = cB, out.C = cC, out.opacity = opacities[i];
+          out.r = rgb[0], out.g = rgb[1], out.b = rgb[2], out.depth = pv[2];
+          out.nx = nv[0], out.ny = nv[1], out.nz = nv[2];
+          rc[0] = (uint16_t)rx0, rc[1] = (uint16_t)ry0, rc[2] = (uint16_t)rx1, rc[3] = (uint16_t)ry1;
+        }
+      }
+    }
+    radii[i] = my_radius;
+    tiles_touched[i] = my_tiles;
+    flags[i] = fl;
+    // 64-B record and 8-B rect as wide stores
+    float4 *dst = reinterpret_cast<float4 *>(splat + i);
+    const float4 *src = reinterpret_cast<const float4 *>(&out);
+    dst[0] = src[0], dst[1] = src[1], dst[2] = src[2], dst[3] = src[3];
+    *reinterpret_cast<uint2 *>(rect + 4 * (size_t)i) =
+        make_uint2((uint32_t)rc[0] | ((uint32_t)rc[1] << 16), (uint32_t)rc[2] | ((uint32_t)rc[3] << 16));
+  }
+  // block sum of tiles_touched (feeds the 2-level scan)
+  uint32_t v = my_tiles;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  if ((threadIdx.x & 63) == 0) wave_sums[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) block_sums[blockIdx.x] = wave_sums[0] + wave_sums[1] + wave_sums[2] + wave_sums[3];
+}
+
+// ----------------------------------------------------------------------------------------------
+// Backward: sums the per-instance records of the blend backward (contiguous per Gaussian, indexed
+// by emission position -> deterministic, atomic-free), then differentiates conic -> cov2D ->
+// (Sigma, t) -> (scale, quaternion, mean), the perspective projection, depth, SH colour, normal.
+__global__ void __launch_bounds__(PRE_BLOCK) preprocess_bwd_kernel(
+    int N, int deg, int M, int H, int W, uint32_t R_cap, const float *__restrict__ means3D,
+    const float *__restrict__ shs, const float *__restrict__ colors_precomp, const float *__restrict__ scales,
+    const float *__restrict__ rotations, const float *__restrict__ cov3D_precomp, float scale_mod,
+    const float *__restrict__ Vg, const float *__restrict__ Pg, const float *__restrict__ camg, float tanfovx,
+    float tanfovy, const int32_t *__restrict__ radii, const Splat *__restrict__ splat,
+    const uint32_t *__restrict__ offsets, const uint8_t *__restrict__ flags, const SplatGrad *__restrict__ inst_grad,
+    float *__restrict__ dL_dmeans3D, float *__restrict__ dL_dmeans2D, float *__restrict__ dL_dshs,
+    float *__restrict__ dL_dcolors, float *__restrict__ dL_dopacity, float *__restrict__ dL_dscales,
+    float *__restrict__ dL_drot, float *__restrict__ dL_dcov3D) {
+  const int i = blockIdx.x * PRE_BLOCK + threadIdx.x;
+  if (i >= N) return;
+  float V[16], P[16], cam[3];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) V[k] = Vg[k], P[k] = Pg[k];
+  cam[0] = camg[0], cam[1] = camg[1], cam[2] = camg[2];
+
+  float dmean[3] = {0, 0, 0}, dm2d[2] = {0, 0}, dop = 0.0f;
+  float dsc[3] = {0, 0, 0}, dq[4] = {0, 0, 0, 0}, dSig[6] = {0, 0, 0, 0, 0, 0};
+  float dfeat[NFEAT] = {0, 0, 0, 0, 0, 0, 0};
+  const bool visible = radii[i] > 0;
+
+  if (visible) {
+    // ---- gather the instance records
+    float m0 = 0, mx = 0, my = 0, mxx = 0, mxy = 0, myy = 0;
+    uint32_t lo = i == 0 ? 0u : offsets[i - 1], hi = offsets[i];
+    lo = min(lo, R_cap), hi = min(hi, R_cap);
+    for (uint32_t e = lo; e < hi; ++e) {
+      const float4 *rp = reinterpret_cast<const float4 *>(inst_grad + e);
+      const float4 a = rp[0], b = rp[1], c = rp[2], d = rp[3];
+      m0 += a.x, mx += a.y, my += a.z, mxx += a.w;
+      mxy += b.x, myy += b.y, dfeat[0] += b.z, dfeat[1] += b.w;
+      dfeat[2] += c.x, dfeat[3] += c.y, dfeat[4] += c.z, dfeat[5] += c.w;
+      dfeat[6] += d.x;
+    }
+    const Splat sp = splat[i];
+    // moments -> gradients of (pixel mean, conic, opacity)
+    const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
+    dm2d[0] = -(sp.A * mx + sp.B * my) * ddelx_dx;
+    dm2d[1] = -(sp.C * my + sp.B * mx) * ddely_dy;
+    const float dLA = -0.5f * mxx, dLB = -mxy, dLC = -0.5f * myy;
+    dop = (m0 != 0.0f) ? m0 / sp.opacity : 0.0f;
+
+    const float fx = (float)W / (2.0f * tanfovx), fy = (float)H / (2.0f * tanfovy);
+    const float p[3] = {means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2]};
+    float c6[6], R[9], q[4] = {1, 0, 0, 0}, s[3] = {0, 0, 0};
+    if (cov3D_precomp) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) c6[k] = cov3D_precomp[6 * i + k];
+    } else {
+      q[0] = rotations[4 * i], q[1] = rotations[4 * i + 1], q[2] = rotations[4 * i + 2], q[3] = rotations[4 * i + 3];
+      s[0] = scales[3 * i], s[1] = scales[3 * i + 1], s[2] = scales[3 * i + 2];
+      quat_to_R(q, R);
+      cov3d_from_scale_rot(s, scale_mod, R, c6);
+    }
+    float pv[3];
+    xform43(p, V, pv);
+    float t[3] = {pv[0], pv[1], pv[2]};
+    const float limx = FOV_CLAMP * tanfovx, limy = FOV_CLAMP * tanfovy;
+    const float txtz = t[0] / t[2], tytz = t[1] / t[2];
+    t[0] = fminf(limx, fmaxf(-limx, txtz)) * t[2];
+    t[1] = fminf(limy, fmaxf(-limy, tytz)) * t[2];
+    const float xmul = (txtz < -limx || txtz > limx) ? 0.0f : 1.0f;
+    const float ymul = (tytz < -limy || tytz > limy) ? 0.0f : 1.0f;
+    float T[6], abc[3];
+    ewa_T(t, fx, fy, V, T);
+    cov2d_from_T(T, c6, abc);
+    const float a = abc[0], b = abc[1], c = abc[2];
+    const float det = a * c - b * b;
+    if (det != 0.0f) {
+      const float d2 = 1.0f / (det * det + 0.0000001f);
+      const float dLa = d2 * (-c * c * dLA + b * c * dLB - b * b * dLC);
+      const float dLc = d2 * (-b * b * dLA + a * b * dLB - a * a * dLC);
+      const float dLb = d2 * (2.0f * b * c * dLA - (det + 2.0f * b * b) * dLB + 2.0f * a * b * dLC);
+      dSig[0] = T[0] * T[0] * dLa + T[0] * T[3] * dLb + T[3] * T[3] * dLc;
+      dSig[3] = T[1] * T[1] * dLa + T[1] * T[4] * dLb + T[4] * T[4] * dLc;
+      dSig[5] = T[2] * T[2] * dLa + T[2] * T[5] * dLb + T[5] * T[5] * dLc;
+      dSig[1] = 2.0f * T[0] * T[1] * dLa + (T[0] * T[4] + T[1] * T[3]) * dLb + 2.0f * T[3] * T[4] * dLc;
+      dSig[2] = 2.0f * T[0] * T[2] * dLa + (T[0] * T[5] + T[2] * T[3]) * dLb + 2.0f * T[3] * T[5] * dLc;
+      dSig[4] = 2.0f * T[2] * T[1] * dLa + (T[1] * T[5] + T[2] * T[4]) * dLb + 2.0f * T[4] * T[5] * dLc;
+      float u[6];
+      T_sigma(T, c6, u);
+      const float dT0 = 2.0f * dLa * u[0] + dLb * u[3], dT1 = 2.0f * dLa * u[1] + dLb * u[4];
+      const float dT2 = 2.0f * dLa * u[2] + dLb * u[5], dT3 = dLb * u[0] + 2.0f * dLc * u[3];
+      const float dT4 = dLb * u[1] + 2.0f * dLc * u[4], dT5 = dLb * u[2] + 2.0f * dLc * u[5];
+      const float dJ00 = dT0 * V[0] + dT1 * V[4] + dT2 * V[8];
+      const float dJ02 = dT0 * V[2] + dT1 * V[6] + dT2 * V[10];
+      const float dJ11 = dT3 * V[1] + dT4 * V[5] + dT5 * V[9];
+      const float dJ12 = dT3 * V[2] + dT4 * V[6] + dT5 * V[10];
+      const float tz = 1.0f / t[2], tz2 = tz * tz, tz3 = tz2 * tz;
+      const float dtx = xmul * -fx * tz2 * dJ02;
+      const float dty = ymul * -fy * tz2 * dJ12;
+      const float dtz = -fx * tz2 * dJ00 - fy * tz2 * dJ11 + (2.0f * fx * t[0]) * tz3 * dJ02 +
+                        (2.0f * fy * t[1]) * tz3 * dJ12;
+      dmean[0] += V[0] * dtx + V[1] * dty + V[2] * dtz;
+      dmean[1] += V[4] * dtx + V[5] * dty + V[6] * dtz;
+      dmean[2] += V[8] * dtx + V[9] * dty + V[10] * dtz;
+    }
+    {  // NDC mean -> world mean through the projection
+      float ph[4];
+      xform44(p, P, ph);
+      const float mw = 1.0f / (ph[3] + W_EPS);
+      const float mul1 = ph[0] * mw * mw, mul2 = ph[1] * mw * mw;
+      dmean[0] += (P[0] * mw - P[3] * mul1) * dm2d[0] + (P[1] * mw - P[3] * mul2) * dm2d[1];
+      dmean[1] += (P[4] * mw - P[7] * mul1) * dm2d[0] + (P[5] * mw - P[7] * mul2) * dm2d[1];
+      dmean[2] += (P[8] * mw - P[11] * mul1) * dm2d[0] + (P[9] * mw - P[11] * mul2) * dm2d[1];
+    }
+    // depth feature
+    dmean[0] += V[2] * dfeat[3], dmean[1] += V[6] * dfeat[3], dmean[2] += V[10] * dfeat[3];
+
+    // colour
+    if (!colors_precomp) {
+      const float d[3] = {p[0] - cam[0], p[1] - cam[1], p[2] - cam[2]};
+      const float len = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+      const float x = d[0] / len, y = d[1] / len, z = d[2] / len;
+      float ddir[3] = {0, 0, 0};
+      const float *sh = shs + (size_t)i * M * 3;
+      float *dsh = dL_dshs + (size_t)i * M * 3;
+      const uint8_t fl = flags[i];
+#pragma unroll
+      for (int cc = 0; cc < 3; ++cc) {
+        const float g = ((fl >> cc) & 1) ? 0.0f : dfeat[cc];
+        float dx_ = 0, dy_ = 0, dz_ = 0;
+        dsh[0 * 3 + cc] = SH_C0 * g;
+        if (deg > 0) {
+          dsh[1 * 3 + cc] = -SH_C1 * y * g;
+          dsh[2 * 3 + cc] = SH_C1 * z * g;
+          dsh[3 * 3 + cc] = -SH_C1 * x * g;
+          dx_ = -SH_C1 * sh[3 * 3 + cc];
+          dy_ = -SH_C1 * sh[1 * 3 + cc];
+          dz_ = SH_C1 * sh[2 * 3 + cc];
+          if (deg > 1) {
+            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            dsh[4 * 3 + cc] = SH_C2[0] * xy * g;
+            dsh[5 * 3 + cc] = SH_C2[1] * yz * g;
+            dsh[6 * 3 + cc] = SH_C2[2] * (2.0f * zz - xx - yy) * g;
+            dsh[7 * 3 + cc] = SH_C2[3] * xz * g;
+            dsh[8 * 3 + cc] = SH_C2[4] * (xx - yy) * g;
+            dx_ += SH_C2[0] * y * sh[4 * 3 + cc] + SH_C2[2] * 2.0f * -x * sh[6 * 3 + cc] +
+                   SH_C2[3] * z * sh[7 * 3 + cc] + SH_C2[4] * 2.0f * x * sh[8 * 3 + cc];
+            dy_ += SH_C2[0] * x * sh[4 * 3 + cc] + SH_C2[1] * z * sh[5 * 3 + cc] +
+                   SH_C2[2] * 2.0f * -y * sh[6 * 3 + cc] + SH_C2[4] * 2.0f * -y * sh[8 * 3 + cc];
+            dz_ += SH_C2[1] * y * sh[5 * 3 + cc] + SH_C2[2] * 2.0f * 2.0f * z * sh[6 * 3 + cc] +
+                   SH_C2[3] * x * sh[7 * 3 + cc];
+            if (deg > 2) {
+              dsh[9 * 3 + cc] = SH_C3[0] * y * (3.0f * xx - yy) * g;
+              dsh[10 * 3 + cc] = SH_C3[1] * xy * z * g;
+              dsh[11 * 3 + cc] = SH_C3[2] * y * (4.0f * zz - xx - yy) * g;
+              dsh[12 * 3 + cc] = SH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * g;
+              dsh[13 * 3 + cc] = SH_C3[4] * x * (4.0f * zz - xx - yy) * g;
+              dsh[14 * 3 + cc] = SH_C3[5] * z * (xx - yy) * g;
+              dsh[15 * 3 + cc] = SH_C3[6] * x * (xx - 3.0f * yy) * g;
+              dx_ += SH_C3[0] * sh[9 * 3 + cc] * 3.0f * 2.0f * xy + SH_C3[1] * sh[10 * 3 + cc] * yz +
+                     SH_C3[2] * sh[11 * 3 + cc] * -2.0f * xy + SH_C3[3] * sh[12 * 3 + cc] * -3.0f * 2.0f * xz +
+                     SH_C3[4] * sh[13 * 3 + cc] * (-3.0f * xx + 4.0f * zz - yy) +
+                     SH_C3[5] * sh[14 * 3 + cc] * 2.0f * xz + SH_C3[6] * sh[15 * 3 + cc] * 3.0f * (xx - yy);
+              dy_ += SH_C3[0] * sh[9 * 3 + cc] * 3.0f * (xx - yy) + SH_C3[1] * sh[10 * 3 + cc] * xz +
+                     SH_C3[2] * sh[11 * 3 + cc] * (-3.0f * yy + 4.0f * zz - xx) +
+                     SH_C3[3] * sh[12 * 3 + cc] * -3.0f * 2.0f * yz + SH_C3[4] * sh[13 * 3 + cc] * -2.0f * xy +
+                     SH_C3[5] * sh[14 * 3 + cc] * -2.0f * yz + SH_C3[6] * sh[15 * 3 + cc] * -3.0f * 2.0f * xy;
+              dz_ += SH_C3[1] * sh[10 * 3 + cc] * xy + SH_C3[2] * sh[11 * 3 + cc] * 4.0f * 2.0f * yz +
+                     SH_C3[3] * sh[12 * 3 + cc] * 3.0f * (2.0f * zz - xx - yy) +
+                     SH_C3[4] * sh[13 * 3 + cc] * 4.0f * 2.0f * xz + SH_C3[5] * sh[14 * 3 + cc] * (xx - yy);
+            }
+          }
+        }
+        ddir[0] += dx_ * g, ddir[1] += dy_ * g, ddir[2] += dz_ * g;
+      }
+      if (deg > 0) {
+        const float sum2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+        const float inv32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
+        dmean[0] += ((sum2 - d[0] * d[0]) * ddir[0] - d[1] * d[0] * ddir[1] - d[2] * d[0] * ddir[2]) * inv32;
+        dmean[1] += (-d[0] * d[1] * ddir[0] + (sum2 - d[1] * d[1]) * ddir[1] - d[2] * d[1] * ddir[2]) * inv32;
+        dmean[2] += (-d[0] * d[2] * ddir[0] - d[1] * d[2] * ddir[1] + (sum2 - d[2] * d[2]) * ddir[2]) * inv32;
+      }
+    }
+
+    // Sigma -> scale, rotation ; normal -> rotation
+    if (!cov3D_precomp) {
+      const float sm[3] = {scale_mod * s[0], scale_mod * s[1], scale_mod * s[2]};
+      const float Gm[9] = {dSig[0], 0.5f * dSig[1], 0.5f * dSig[2], 0.5f * dSig[1], dSig[3],
+                           0.5f * dSig[4], 0.5f * dSig[2], 0.5f * dSig[4], dSig[5]};
+      float dR[9];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        float dMk[3];
+#pragma unroll
+        for (int r_ = 0; r_ < 3; ++r_) {
+          float acc = 0.0f;
+#pragma unroll
+          for (int j = 0; j < 3; ++j) acc += Gm[r_ * 3 + j] * (R[j * 3 + k] * sm[k]);
+          dMk[r_] = 2.0f * acc;
+        }
+        dsc[k] = (dMk[0] * R[0 * 3 + k] + dMk[1] * R[1 * 3 + k] + dMk[2] * R[2 * 3 + k]) * scale_mod;
+#pragma unroll
+        for (int r_ = 0; r_ < 3; ++r_) dR[r_ * 3 + k] = dMk[r_] * sm[k];
+      }
+      {
+        const int k = argmin3(s);
+        const float n0 = R[0 + k], n1 = R[3 + k], n2 = R[6 + k];
+        const float dot = n0 * (cam[0] - p[0]) + n1 * (cam[1] - p[1]) + n2 * (cam[2] - p[2]);
+        const float sgn = dot < 0.0f ? -1.0f : 1.0f;
+        const float g0 = dfeat[4], g1 = dfeat[5], g2 = dfeat[6];
+        const float wn[3] = {V[0] * g0 + V[1] * g1 + V[2] * g2, V[4] * g0 + V[5] * g1 + V[6] * g2,
+                             V[8] * g0 + V[9] * g1 + V[10] * g2};
+#pragma unroll
+        for (int r_ = 0; r_ < 3; ++r_) {
+          // static index selection keeps dR in registers
+          if (k == 0) dR[r_ * 3 + 0] += sgn * wn[r_];
+          else if (k == 1) dR[r_ * 3 + 1] += sgn * wn[r_];
+          else dR[r_ * 3 + 2] += sgn * wn[r_];
+        }
+      }
+      const float r = q[0], x = q[1], y = q[2], z = q[3];
+      dq[0] = 2.0f * (-z * dR[1] + y * dR[2] + z * dR[3] - x * dR[5] - y * dR[6] + x * dR[7]);
+      dq[1] = 2.0f * (y * dR[1] + z * dR[2] + y * dR[3] - 2.0f * x * dR[4] - r * dR[5] + z * dR[6] + r * dR[7] -
+                      2.0f * x * dR[8]);
+      dq[2] = 2.0f * (-2.0f * y * dR[0] + x * dR[1] + r * dR[2] + x * dR[3] + z * dR[5] - r * dR[6] + z * dR[7] -
+                      2.0f * y * dR[8]);
+      dq[3] = 2.0f * (-2.0f * z * dR[0] - r * dR[1] + x * dR[2] + r * dR[3] - 2.0f * z * dR[4] + y * dR[5] +
+                      x * dR[6] + y * dR[7]);
+    }
+  } else if (!colors_precomp) {
+    float *dsh = dL_dshs + (size_t)i * M * 3;
+    for (int k = 0; k < M * 3; ++k) dsh[k] = 0.0f;
+  }
+
+  dL_dmeans3D[3 * i] = dmean[0], dL_dmeans3D[3 * i + 1] = dmean[1], dL_dmeans3D[3 * i + 2] = dmean[2];
+  dL_dmeans2D[3 * i] = dm2d[0], dL_dmeans2D[3 * i + 1] = dm2d[1], dL_dmeans2D[3 * i + 2] = 0.0f;
+  dL_dopacity[i] = dop;
+  if (colors_precomp) {
+    dL_dcolors[3 * i] = dfeat[0], dL_dcolors[3 * i + 1] = dfeat[1], dL_dcolors[3 * i + 2] = dfeat[2];
+  } else if (visible) {
+    float *dsh = dL_dshs + (size_t)i * M * 3;
+    const int used = (deg + 1) * (deg + 1);
+    for (int k = used * 3; k < M * 3; ++k) dsh[k] = 0.0f;  // coefficients above the active degree
+  }
+  if (cov3D_precomp) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) dL_dcov3D[6 * i + k] = dSig[k];
+  } else {
+    dL_dscales[3 * i] = dsc[0], dL_dscales[3 * i + 1] = dsc[1], dL_dscales[3 * i + 2] = dsc[2];
+    dL_drot[4 * i] = dq[0], dL_drot[4 * i + 1] = dq[1], dL_drot[4 * i + 2] = dq[2], dL_drot[4 * i + 3] = dq[3];
+  }
+}
+
+}  // namespace dimo
+
+using namespace dimo;
+
+extern "C" int dimo_raster_preprocess_forward(int N, int sh_degree, int M, int H, int W, const float *means3D,
+                                              const float *shs, const float *colors_precomp, const float *opacities,
+                                              const float *scales, const float *rotations,
+                                              const float *cov3D_precomp, float scale_modifier,
+                                              const float *viewmatrix, const float *projmatrix, const float *campos,
+                                              float tanfovx, float tanfovy, int32_t *radii, void *geom,
+                                              size_t geom_bytes, int64_t *R_host, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (N < 0 || H <= 0 || W <= 0 || !geom || !viewmatrix || !projmatrix || !campos) return DIMO_E_ARG;
+  if ((shs == nullptr) == (colors_precomp == nullptr)) return DIMO_E_ARG;
+  if (!cov3D_precomp && (!scales || !rotations)) return DIMO_E_ARG;
+  if (shs && (sh_degree < 0 || sh_degree > 3 || M < (sh_degree + 1) * (sh_degree + 1))) return DIMO_E_ARG;
+  if ((W + TILE - 1) / TILE > 65535 || (H + TILE - 1) / TILE > 65535) return DIMO_E_ARG;
+  GeomLayout L(N);
+  if (geom_bytes < L.bytes) return DIMO_E_WORKSPACE;
+  if (N > 0 && (!means3D || !opacities || !radii)) return DIMO_E_ARG;
+  const int nb = (N + PRE_BLOCK - 1) / PRE_BLOCK;
+  if (nb > 0) {
+    hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(nb), dim3(PRE_BLOCK), 0, stream, N, sh_degree, M, H, W, means3D,
+                       shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, scale_modifier, viewmatrix,
+                       projmatrix, campos, tanfovx, tanfovy, radii, at<Splat>(geom, L.splat),
+                       at<uint16_t>(geom, L.rect), at<uint32_t>(geom, L.tiles), at<uint8_t>(geom, L.flags),
+                       at<uint32_t>(geom, L.block_sums));
+  }
+  int rc = scan_block_sums(nb, at<uint32_t>(geom, L.block_sums), at<uint32_t>(geom, L.total), stream);
+  if (rc) return rc;
+  rc = write_offsets(N, at<uint32_t>(geom, L.tiles), at<uint32_t>(geom, L.block_sums),
+                          at<uint32_t>(geom, L.offsets), stream);
+  if (rc) return rc;
+  if (R_host) {
+    uint32_t tot[4] = {0, 0, 0, 0};
+    if (hipMemcpyAsync(tot, at<uint32_t>(geom, L.total), sizeof(tot), hipMemcpyDeviceToHost, stream) != hipSuccess)
+      return DIMO_E_LAUNCH;
+    if (hipStreamSynchronize(stream) != hipSuccess) return DIMO_E_LAUNCH;
+    *R_host = (int64_t)tot[0];
+  }
+  return check_launch();
+}
+
+int dimo::preprocess_backward_launch(
+    int N, int sh_degree, int M, int H, int W, int64_t R_cap, const float *means3D, const float *shs,
+    const float *colors_precomp, const float *scales, const float *rotations, const float *cov3D_precomp,
+    float scale_modifier, const float *viewmatrix, const float *projmatrix, const float *campos, float tanfovx,
+    float tanfovy, const int32_t *radii, const void *geom, const void *inst_grad, float *dL_dmeans3D,
+    float *dL_dmeans2D, float *dL_dshs, float *dL_dcolors, float *dL_dopacity, float *dL_dscales, float *dL_drot,
+    float *dL_dcov3D, hipStream_t stream) {
+  GeomLayout L(N);
+  const int nb = (N + PRE_BLOCK - 1) / PRE_BLOCK;
+  if (nb == 0) return DIMO_OK;
+  hipLaunchKernelGGL(preprocess_bwd_kernel, dim3(nb), dim3(PRE_BLOCK), 0, stream, N, sh_degree, M, H, W,
+                     (uint32_t)(R_cap > 0xffffffffLL ? 0xffffffffu : (uint32_t)R_cap), means3D, shs, colors_precomp,
+                     scales, rotations, cov3D_precomp, scale_modifier, viewmatrix, projmatrix, campos, tanfovx,
+                     tanfovy, radii, at<Splat>(geom, L.splat), at<uint32_t>(geom, L.offsets),
+                     at<uint8_t>(geom, L.flags), reinterpret_cast<const SplatGrad *>(inst_grad), dL_dmeans3D,
+                     dL_dmeans2D, dL_dshs, dL_dcolors, dL_dopacity, dL_dscales, dL_drot, dL_dcov3D);
+  return check_launch();
+}

@@ -1,0 +1,51 @@
+"""Drop-in for `fused_ssim.fused_ssim(img1, img2)` (main_test_dimo.py:29,979) and for the
+pure-PyTorch `src.loss.ssim` the trainer calls (src/loss.py:132-175, main_train_dimo.py:343):
+mean SSIM with an 11x11 sigma-1.5 window and zero padding, differentiable w.r.t. img1.
+
+Runs dimo_ssim_forward/backward (dimo_amd/csrc/ssim.hip).  No CPU fallback.
+"""
+import torch
+
+from . import _lib
+
+
+class _FusedSSIM(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, img1, img2):
+        if not img1.is_cuda:
+            raise RuntimeError("dimo_amd.fused_ssim needs GPU tensors (no CPU fallback in the product path)")
+        img1c, img2c = img1.float().contiguous(), img2.detach().float().contiguous()
+        B, C, H, W = img1c.shape
+        need_grad = img1.requires_grad
+        ssum = torch.empty(1, dtype=torch.float32, device=img1.device)
+        partials = torch.empty(3, B, C, H, W, dtype=torch.float32, device=img1.device) if need_grad else None
+        _lib.check(_lib.lib().dimo_ssim_forward(B, C, H, W, _lib.ptr(img1c), _lib.ptr(img2c), _lib.ptr(ssum),
+                                                _lib.ptr(partials), _lib.current_stream()), "dimo_ssim_forward")
+        ctx.save_for_backward(img1c, img2c, partials)
+        return (ssum / float(B * C * H * W)).reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        img1c, img2c, partials = ctx.saved_tensors
+        B, C, H, W = img1c.shape
+        g = g.float().contiguous().reshape(1)
+        out = torch.empty_like(img1c)
+        _lib.check(_lib.lib().dimo_ssim_backward(B, C, H, W, _lib.ptr(img1c), _lib.ptr(img2c), _lib.ptr(partials),
+                                                 _lib.ptr(g), _lib.ptr(out), _lib.current_stream()),
+                   "dimo_ssim_backward")
+        return out, None
+
+
+def fused_ssim(img1, img2, padding="same", train=True):
+    if padding != "same":
+        raise NotImplementedError("only zero 'same' padding (the reference's src/loss.py:144 semantics)")
+    if img1.dim() == 3:
+        img1, img2 = img1[None], img2[None]
+    return _FusedSSIM.apply(img1, img2)
+
+
+def ssim(img1, img2, window_size=11, size_average=True):
+    """src.loss.ssim signature."""
+    if window_size != 11 or not size_average:
+        raise NotImplementedError("fused path implements window_size=11, size_average=True")
+    return fused_ssim(img1, img2)

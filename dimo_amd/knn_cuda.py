@@ -1,0 +1,46 @@
+"""Drop-in for `knn_cuda.KNN` (unlimblue/KNN_CUDA) as used at main_train_dimo.py:24,502-509:
+
+    knn = KNN(k=4, transpose_mode=True)
+    dist, indx = knn(ref[1, M, 3], query[1, N, 3])   # -> [1, N, k] float32, [1, N, k] int64
+
+Distances are Euclidean (not squared), ascending; ties resolve to the lower reference index.
+Runs dimo_knn (dimo_amd/csrc/knn.hip) on the current stream; no CPU fallback.
+"""
+import torch
+
+from . import _lib
+
+
+def knn_points(ref, query, k):
+    """ref [M,3], query [N,3] (cuda, fp32) -> (dist [N,k], idx [N,k] int64)."""
+    if not (ref.is_cuda and query.is_cuda):
+        raise RuntimeError("dimo_amd.knn_cuda needs GPU tensors (no CPU fallback in the product path)")
+    ref, query = ref.detach().float().contiguous(), query.detach().float().contiguous()
+    M, N = ref.shape[0], query.shape[0]
+    dist = torch.empty(N, k, dtype=torch.float32, device=query.device)
+    idx = torch.empty(N, k, dtype=torch.int64, device=query.device)
+    _lib.check(_lib.lib().dimo_knn(M, N, k, _lib.ptr(ref), _lib.ptr(query), _lib.ptr(dist), _lib.ptr(idx),
+                                   _lib.current_stream()), "dimo_knn")
+    return dist, idx
+
+
+class KNN(torch.nn.Module):
+    def __init__(self, k, transpose_mode=False):
+        super().__init__()
+        self.k = k
+        self._t = transpose_mode
+
+    def forward(self, ref, query):
+        assert ref.size(0) == query.size(0), "ref.shape={} != query.shape={}".format(ref.shape, query.shape)
+        with torch.no_grad():
+            if not self._t:  # [B, dim, n] layout
+                ref, query = ref.transpose(1, 2), query.transpose(1, 2)
+            D, I = [], []
+            for b in range(ref.size(0)):
+                d, i = knn_points(ref[b], query[b], self.k)
+                D.append(d)
+                I.append(i)
+            D, I = torch.stack(D), torch.stack(I)
+            if not self._t:
+                D, I = D.transpose(1, 2).contiguous(), I.transpose(1, 2).contiguous()
+        return D, I

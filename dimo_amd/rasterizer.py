@@ -1,0 +1,249 @@
+"""Differentiable tile rasterizer on libdimo_hip -- the drop-in for the two CUDA
+extensions DIMO imports:
+
+  diff_gauss.GaussianRasterizer                   (6 outputs, default training path)
+      settings renderer/latent_gs_renderer.py:1132-1147, call :1255-1266
+  diff_gaussian_rasterization.GaussianRasterizer  (4 outputs)
+      settings renderer/latent_gs_renderer.py:1149-1163, call :1268-1277
+
+`dimo_amd.diff_gauss` / `dimo_amd.diff_gaussian_rasterization` re-export the
+classes below under the reference's module names.
+
+Everything runs on the caller's current stream through the C ABI (include/dimo_hip.h);
+workspaces come from torch's caching allocator and live in the autograd ctx until
+backward.  There is no CPU fallback: without the HIP library / a GPU tensor this raises.
+
+Instance capacity.  The number of (Gaussian, tile) instances R is only known on the
+device after projection.  `capacity=None` (default) reads it back (one stream sync per
+render, like the CUDA original).  A `CapacityPolicy` instead sizes the sort buffers from
+a running bound so the whole render is enqueued without a host round trip; an overflow
+is flagged on the device and surfaced by `CapacityPolicy.check()`.
+"""
+import ctypes as C
+from typing import NamedTuple, Optional
+
+import torch
+
+from . import _lib
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+
+
+class CapacityPolicy:
+    """Sync-free sizing of the instance buffers: capacity = margin * max(R seen), grown on overflow."""
+
+    def __init__(self, initial=1 << 20, margin=1.5):
+        self.capacity = int(initial)
+        self.margin = float(margin)
+        self._pending = []  # geom `total` views (R, overflow) of renders since the last check
+
+    def next_capacity(self):
+        return self.capacity
+
+    def track(self, total_view):
+        self._pending.append(total_view)
+
+    def check(self):
+        """One host sync for all renders since the last call. Returns True if every render fitted;
+        on overflow the capacity is raised and the caller must redo the step."""
+        if not self._pending:
+            return True
+        tot = torch.stack(self._pending).cpu()
+        self._pending = []
+        r_max = int(tot[:, 0].max())
+        ok = int(tot[:, 1].max()) == 0
+        self.capacity = max(self.capacity if ok else 0, int(r_max * self.margin) + 1024)
+        return ok
+
+
+def _f32c(t):
+    if t is None:
+        return None
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t if t.is_contiguous() else t.contiguous()
+
+
+class _Rasterize(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, settings,
+                with_normal, capacity):
+        L = _lib.lib()
+        if not means3D.is_cuda:
+            raise RuntimeError("dimo_amd rasterizer needs GPU tensors (no CPU fallback in the product path)")
+        dev = means3D.device
+        s = settings
+        N = means3D.shape[0]
+        H, W = int(s.image_height), int(s.image_width)
+        means3D, opacities = _f32c(means3D), _f32c(opacities)
+        shs, colors_precomp = _f32c(shs), _f32c(colors_precomp)
+        scales, rotations, cov3D_precomp = _f32c(scales), _f32c(rotations), _f32c(cov3D_precomp)
+        if shs is not None and shs.numel() == 0:
+            shs = None
+        if colors_precomp is not None and colors_precomp.numel() == 0:
+            colors_precomp = None
+        if cov3D_precomp is not None and cov3D_precomp.numel() == 0:
+            cov3D_precomp = None
+        if (shs is None) == (colors_precomp is None):
+            raise ValueError("Please provide exactly one of either SHs or precomputed colors!")
+        if cov3D_precomp is None and (scales is None or rotations is None):
+            raise ValueError("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+        M = 0 if shs is None else shs.shape[1]
+        view, proj = _f32c(s.viewmatrix), _f32c(s.projmatrix)
+        campos, bg = _f32c(s.campos), _f32c(s.bg)
+        stream = _lib.current_stream()
+
+        geom = torch.empty(L.dimo_raster_geom_bytes(N), dtype=torch.uint8, device=dev)
+        radii = torch.empty(N, dtype=torch.int32, device=dev)
+        r_host = C.c_int64(0)
+        exact = capacity is None
+        _lib.check(L.dimo_raster_preprocess_forward(
+            N, int(s.sh_degree), M, H, W, _lib.ptr(means3D), _lib.ptr(shs), _lib.ptr(colors_precomp),
+            _lib.ptr(opacities), _lib.ptr(scales), _lib.ptr(rotations), _lib.ptr(cov3D_precomp),
+            float(s.scale_modifier), _lib.ptr(view), _lib.ptr(proj), _lib.ptr(campos), float(s.tanfovx),
+            float(s.tanfovy), _lib.ptr(radii), _lib.ptr(geom), geom.numel(),
+            C.byref(r_host) if exact else None, stream), "dimo_raster_preprocess_forward")
+        if exact:
+            r_cap = max(int(r_host.value), 1)
+        else:
+            r_cap = int(capacity.next_capacity())
+            off = (C.c_size_t * 6)()
+            L.dimo_raster_geom_layout(N, off)
+            capacity.track(geom[off[5]:off[5] + 8].view(torch.int32))
+
+        bin_ws = torch.empty(L.dimo_raster_bin_bytes(r_cap, H, W), dtype=torch.uint8, device=dev)
+        img_ws = torch.empty(L.dimo_raster_img_bytes(H, W), dtype=torch.uint8, device=dev)
+        color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
+        depth = torch.empty(1, H, W, dtype=torch.float32, device=dev)
+        normal = torch.empty(3, H, W, dtype=torch.float32, device=dev) if with_normal else None
+        alpha = torch.empty(1, H, W, dtype=torch.float32, device=dev)
+        _lib.check(L.dimo_raster_render_forward(
+            N, H, W, r_cap, _lib.ptr(bg), _lib.ptr(geom), _lib.ptr(bin_ws), bin_ws.numel(), _lib.ptr(img_ws),
+            img_ws.numel(), _lib.ptr(color), _lib.ptr(depth), _lib.ptr(normal), _lib.ptr(alpha), stream),
+            "dimo_raster_render_forward")
+
+        ctx.settings, ctx.with_normal, ctx.r_cap, ctx.dims = s, with_normal, r_cap, (N, M, H, W)
+        ctx.save_for_backward(means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, view, proj,
+                              campos, bg, radii, geom, bin_ws, img_ws)
+        ctx.mark_non_differentiable(radii)
+        if with_normal:
+            return color, depth, normal, alpha, radii
+        return color, depth, alpha, radii
+
+    @staticmethod
+    def backward(ctx, *grads):
+        L = _lib.lib()
+        (means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, view, proj, campos, bg, radii,
+         geom, bin_ws, img_ws) = ctx.saved_tensors
+        s, (N, M, H, W), r_cap = ctx.settings, ctx.dims, ctx.r_cap
+        if ctx.with_normal:
+            g_color, g_depth, g_normal, g_alpha, _ = grads
+        else:
+            g_color, g_depth, g_alpha, _ = grads
+            g_normal = None
+        g_color, g_depth, g_normal, g_alpha = _f32c(g_color), _f32c(g_depth), _f32c(g_normal), _f32c(g_alpha)
+        dev = means3D.device
+        new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
+        d_means3D, d_means2D, d_opac = new(N, 3), new(N, 3), new(N, 1)
+        d_shs = new(N, M, 3) if shs is not None else None
+        d_colors = new(N, 3) if colors_precomp is not None else None
+        d_scales = new(N, 3) if cov3D_precomp is None else None
+        d_rot = new(N, 4) if cov3D_precomp is None else None
+        d_cov = new(N, 6) if cov3D_precomp is not None else None
+        scratch = torch.empty(L.dimo_raster_backward_scratch_bytes(N, r_cap), dtype=torch.uint8, device=dev)
+        _lib.check(L.dimo_raster_backward(
+            N, int(s.sh_degree), M, H, W, r_cap, _lib.ptr(means3D), _lib.ptr(shs), _lib.ptr(colors_precomp),
+            _lib.ptr(opacities), _lib.ptr(scales), _lib.ptr(rotations), _lib.ptr(cov3D_precomp),
+            float(s.scale_modifier), _lib.ptr(view), _lib.ptr(proj), _lib.ptr(campos), _lib.ptr(bg),
+            float(s.tanfovx), float(s.tanfovy), _lib.ptr(radii), _lib.ptr(geom), _lib.ptr(bin_ws), _lib.ptr(img_ws),
+            _lib.ptr(g_color), _lib.ptr(g_depth), _lib.ptr(g_normal) if ctx.with_normal else None, _lib.ptr(g_alpha),
+            _lib.ptr(d_means3D), _lib.ptr(d_means2D), _lib.ptr(d_shs), _lib.ptr(d_colors), _lib.ptr(d_opac),
+            _lib.ptr(d_scales), _lib.ptr(d_rot), _lib.ptr(d_cov), _lib.ptr(scratch), scratch.numel(),
+            _lib.current_stream()), "dimo_raster_backward")
+        return (d_means3D, d_means2D, d_shs, d_colors, d_opac.view(opacities.shape), d_scales, d_rot, d_cov, None,
+                None, None)
+
+
+def rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
+                        raster_settings, with_normal=True, capacity: Optional[CapacityPolicy] = None):
+    return _Rasterize.apply(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
+                            raster_settings, with_normal, capacity)
+
+
+class GaussianRasterizerNormal(torch.nn.Module):
+    """diff_gauss flavour: (image, depth, normal, alpha, radii, extra)."""
+
+    def __init__(self, raster_settings, capacity: Optional[CapacityPolicy] = None):
+        super().__init__()
+        self.raster_settings = raster_settings
+        self.capacity = capacity
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3Ds_precomp=None, extra_attrs=None):
+        if extra_attrs is not None:
+            raise NotImplementedError("extra_attrs is not used on DIMO's path (latent_gs_renderer.py:1265 passes None)")
+        image, depth, normal, alpha, radii = rasterize_gaussians(
+            means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, self.raster_settings,
+            True, self.capacity)
+        return image, depth, normal, alpha, radii, None
+
+
+class GaussianRasterizer(torch.nn.Module):
+    """diff_gaussian_rasterization (ashawkey) flavour: (image, radii, depth, alpha)."""
+
+    def __init__(self, raster_settings, capacity: Optional[CapacityPolicy] = None):
+        super().__init__()
+        self.raster_settings = raster_settings
+        self.capacity = capacity
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None):
+        image, depth, alpha, radii = rasterize_gaussians(
+            means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, self.raster_settings,
+            False, self.capacity)
+        return image, radii, depth, alpha
+
+
+def inspect_state(ctx_tensors, N, H, W, r_cap):
+    """Test helper: views of the inspectable workspace sub-buffers (see include/dimo_hip.h)."""
+    L = _lib.lib()
+    geom, bin_ws, img_ws = ctx_tensors
+    go, bo, io = (C.c_size_t * 6)(), (C.c_size_t * 5)(), (C.c_size_t * 2)()
+    L.dimo_raster_geom_layout(N, go)
+    L.dimo_raster_bin_layout(r_cap, H, W, bo)
+    L.dimo_raster_img_layout(H, W, io)
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+
+    def view(buf, off, nbytes, dtype):
+        return buf[off:off + nbytes].view(dtype)
+
+    n = max(N, 1)
+    total = view(geom, go[5], 16, torch.int32)
+    return dict(
+        splat=view(geom, go[0], n * 64, torch.float32).view(n, 16)[:N],
+        rect=view(geom, go[1], n * 8, torch.int16).view(n, 4)[:N],
+        tiles_touched=view(geom, go[2], n * 4, torch.int32)[:N],
+        offsets=view(geom, go[3], n * 4, torch.int32)[:N],
+        flags=view(geom, go[4], n, torch.uint8)[:N],
+        total=total,
+        keys_unsorted=view(bin_ws, bo[0], r_cap * 8, torch.int64),
+        vals_unsorted=view(bin_ws, bo[1], r_cap * 4, torch.int32),
+        keys_sorted=view(bin_ws, bo[2], r_cap * 8, torch.int64),
+        vals_sorted=view(bin_ws, bo[3], r_cap * 4, torch.int32),
+        ranges=view(bin_ws, bo[4], T * 8, torch.int32).view(T, 2),
+        final_T=view(img_ws, io[0], H * W * 4, torch.float32).view(H, W),
+        n_contrib=view(img_ws, io[1], H * W * 4, torch.int32).view(H, W),
+    )

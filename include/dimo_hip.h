@@ -1,0 +1,135 @@
+/*
+ * dimo_hip.h -- C ABI of libdimo_hip.so (gfx950 / MI355X).
+ *
+ * These entry points are what the reference's native-extension bindings for the
+ * deform-then-render path would bind.  Each replaces one CUDA torch-extension
+ * call site of Friedrich-M/DIMO (paths relative to the reference repo):
+ *
+ *   dimo_raster_*      diff_gauss.GaussianRasterizer (6 outputs)     renderer/latent_gs_renderer.py:13-16,1132-1147,1255-1266
+ *                      diff_gaussian_rasterization.GaussianRasterizer renderer/latent_gs_renderer.py:9-12,1149-1163,1268-1277
+ *   dimo_knn           knn_cuda.KNN(k, transpose_mode=True)          main_train_dimo.py:24,502-509
+ *   dimo_dist2         simple_knn._C.distCUDA2                       renderer/latent_gs_renderer.py:17,426
+ *   dimo_ssim_*        fused_ssim.fused_ssim / src.loss.ssim         main_test_dimo.py:29,979 ; src/loss.py:132-175
+ *   dimo_deform_*      the LBS block of Renderer.render              renderer/latent_gs_renderer.py:1187-1219
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host; the library never
+ *     allocates or frees caller-visible memory and keeps no global state (re-entrant);
+ *   - all work is enqueued on `stream` (a hipStream_t passed as void*); nothing synchronises
+ *     unless stated;
+ *   - matrices are row-major 4x4 in the row-vector convention MiniCam builds
+ *     (renderer/latent_gs_renderer.py:960-969): p_clip = [x y z 1] @ projmatrix;
+ *   - return value: 0 = ok, negative = DIMO_E_* (never aborts).
+ */
+#ifndef DIMO_HIP_H
+#define DIMO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DIMO_OK 0
+#define DIMO_E_ARG (-1)      /* bad argument (null pointer, negative size, unsupported degree ...) */
+#define DIMO_E_LAUNCH (-2)   /* hip launch / runtime error */
+#define DIMO_E_WORKSPACE (-3)/* workspace too small */
+
+#define DIMO_TILE 16         /* tile edge in pixels (BLOCK_X = BLOCK_Y of the published rasterizer) */
+#define DIMO_NFEAT 7         /* blended per-Gaussian features: r g b depth nx ny nz */
+
+/* library / build identification: returns "dimo_hip gfx950 <version>" */
+const char *dimo_version(void);
+
+/* ------------------------------------------------------------------ rasterizer workspaces
+ * geom : per-Gaussian state written by preprocess (splat records, tile rects, tiles_touched,
+ *        offsets, flags, block sums).  Needed by backward.
+ * bin  : tile-instance state (unsorted/sorted keys and values, tile ranges, sort scratch).
+ *        Sized for a CAPACITY R_cap >= R (number of (Gaussian, tile) instances).  Needed by backward.
+ * img  : per-pixel state (final transmittance, n_contrib).  Needed by backward.
+ */
+size_t dimo_raster_geom_bytes(int N);
+size_t dimo_raster_bin_bytes(int64_t R_cap, int H, int W);
+size_t dimo_raster_img_bytes(int H, int W);
+
+/* Byte offsets of the inspectable sub-buffers (used by the parity tests; all 256-B aligned).
+ * geom: [0] splat float[N][16] = (x y A B C opacity r g b depth nx ny nz pad pad pad)
+ *       [1] rect  uint16[N][4] = (xmin ymin xmax ymax) in tiles     [2] tiles_touched uint32[N]
+ *       [3] offsets uint32[N] (inclusive scan)                      [4] flags uint8[N] (bit c = SH channel c clamped)
+ *       [5] total  uint32[4]  = (R, overflow flag, 0, 0)
+ * bin : [0] keys_unsorted uint64[R_cap] [1] vals_unsorted uint32[R_cap] [2] keys_sorted uint64[R_cap]
+ *       [3] vals_sorted uint32[R_cap]   [4] ranges uint32[T][2]
+ * img : [0] final_T float[H*W]          [1] n_contrib uint32[H*W]
+ */
+int dimo_raster_geom_layout(int N, size_t out_offsets[6]);
+int dimo_raster_bin_layout(int64_t R_cap, int H, int W, size_t out_offsets[5]);
+int dimo_raster_img_layout(int H, int W, size_t out_offsets[2]);
+
+/*
+ * Stage 1 (per Gaussian): cull, project, 3D->2D covariance, conic, radius, tile rect, SH->RGB,
+ * depth, view-space normal, tiles_touched + its inclusive scan.
+ *   means3D[N,3] shs[N,M,3]|NULL colors_precomp[N,3]|NULL opacities[N] scales[N,3]|NULL rotations[N,4]|NULL
+ *   cov3D_precomp[N,6]|NULL (exactly one of shs/colors_precomp; scales+rotations or cov3D_precomp)
+ *   viewmatrix[16] projmatrix[16] campos[3]: device pointers.
+ *   radii[N] int32 out.
+ *   R_host: if non-NULL the call synchronises `stream` and stores R (the exact instance count) there,
+ *           so the caller can size the bin workspace exactly; if NULL nothing synchronises and the
+ *           caller must provide R_cap from a bound (overflow is flagged in geom total[1], never written OOB).
+ */
+int dimo_raster_preprocess_forward(int N, int sh_degree, int M, int H, int W, const float *means3D, const float *shs,
+                                   const float *colors_precomp, const float *opacities, const float *scales,
+                                   const float *rotations, const float *cov3D_precomp, float scale_modifier,
+                                   const float *viewmatrix, const float *projmatrix, const float *campos,
+                                   float tanfovx, float tanfovy, int32_t *radii, void *geom, size_t geom_bytes,
+                                   int64_t *R_host, void *stream);
+
+/*
+ * Stage 2+3: key emission, stable radix sort on (tile | fp32 depth bits), tile ranges, and
+ * front-to-back alpha compositing.
+ *   bg[3] device pointer.  out_color[3,H,W] out_depth[1,H,W] out_normal[3,H,W]|NULL out_alpha[1,H,W].
+ *   out_normal == NULL selects the 4-output (diff_gaussian_rasterization) flavour.
+ */
+int dimo_raster_render_forward(int N, int H, int W, int64_t R_cap, const float *bg, const void *geom, void *bin,
+                               size_t bin_bytes, void *img, size_t img_bytes, float *out_color, float *out_depth,
+                               float *out_normal, float *out_alpha, void *stream);
+
+/*
+ * Backward of stages 3 and 1.  dL_d* image gradients may be NULL (treated as zero).
+ * Outputs (all written, not accumulated): dL_dmeans3D[N,3] dL_dmeans2D[N,3] (NDC units, z = 0)
+ * dL_dshs[N,M,3]|NULL dL_dcolors[N,3]|NULL dL_dopacity[N] dL_dscales[N,3]|NULL dL_drotations[N,4]|NULL
+ * dL_dcov3D[N,6]|NULL.
+ * scratch: dimo_raster_backward_scratch_bytes(N, R_cap) bytes.
+ */
+size_t dimo_raster_backward_scratch_bytes(int N, int64_t R_cap);
+int dimo_raster_backward(int N, int sh_degree, int M, int H, int W, int64_t R_cap, const float *means3D,
+                         const float *shs, const float *colors_precomp, const float *opacities, const float *scales,
+                         const float *rotations, const float *cov3D_precomp, float scale_modifier,
+                         const float *viewmatrix, const float *projmatrix, const float *campos, const float *bg,
+                         float tanfovx, float tanfovy, const int32_t *radii, const void *geom, const void *bin,
+                         const void *img, const float *dL_dcolor, const float *dL_ddepth, const float *dL_dnormal,
+                         const float *dL_dalpha, float *dL_dmeans3D, float *dL_dmeans2D, float *dL_dshs,
+                         float *dL_dcolors, float *dL_dopacity, float *dL_dscales, float *dL_drotations,
+                         float *dL_dcov3D, void *scratch, size_t scratch_bytes, void *stream);
+
+/* ------------------------------------------------------------------ nearest neighbours
+ * dimo_knn: brute-force k nearest reference points (k <= 16) per query; NON-squared distances,
+ * ascending; ties -> lowest reference index.  ref[M,3] query[N,3] dist[N,k] idx[N,k] (int64). */
+int dimo_knn(int M, int N, int k, const float *ref, const float *query, float *dist, int64_t *idx, void *stream);
+
+/* dimo_dist2: mean squared distance of each point to its 3 nearest other points. points[N,3] out[N]. */
+int dimo_dist2(int N, const float *points, float *out, void *stream);
+
+/* ------------------------------------------------------------------ fused SSIM (11x11, sigma 1.5, zero padding)
+ * img1,img2 [B,C,H,W]; ssim_sum: one float accumulator (zeroed by the call) receiving the SUM of the
+ * SSIM map (mean = sum / (B*C*H*W)); partials [3,B,C,H,W] saved for backward (dm/dmu1, dm/dsigma1_sq,
+ * dm/dsigma12 at every pixel).  Backward: dL_dimg1 = dL_dmean/(B*C*H*W) * conv^T(partials). */
+int dimo_ssim_forward(int B, int C, int H, int W, const float *img1, const float *img2, float *ssim_sum,
+                      float *partials, void *stream);
+int dimo_ssim_backward(int B, int C, int H, int W, const float *img1, const float *img2, const float *partials,
+                       const float *dL_dmean /* 1 float, device */, float *dL_dimg1, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DIMO_HIP_H */

@@ -1,0 +1,82 @@
+"""GPU parity of the neighbour-search and SSIM kernels (through the C ABI) vs oracle / golden fixtures."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import raster_oracle as ro
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.mark.parametrize("M,N,k", [(512, 10000, 4), (24, 300, 4), (3, 50, 4), (5000, 2000, 8), (700, 1000, 1)])
+def test_knn_bit_exact(M, N, k):
+    from dimo_amd.knn_cuda import KNN
+    rng = np.random.default_rng(M + N)
+    ref = rng.standard_normal((M, 3)).astype(np.float32)
+    q = rng.standard_normal((N, 3)).astype(np.float32)
+    q[: min(N, M) // 2] = ref[: min(N, M) // 2]  # exact hits (zero distance) and ties
+    ref[1] = ref[0]
+    d, i = KNN(k=k, transpose_mode=True)(torch.tensor(ref).cuda()[None], torch.tensor(q).cuda()[None])
+    assert d.shape == (1, N, k) and i.dtype == torch.int64
+    do, io = ro.knn(ref, q, k)
+    assert np.array_equal(i[0].cpu().numpy(), io)
+    assert np.array_equal(d[0].cpu().numpy().view(np.uint32), do.view(np.uint32))
+
+
+def test_knn_matches_deform_fixture():
+    from dimo_amd.knn_cuda import knn_points
+    z = np.load(os.path.join(GOLD, "deform_latent.npz"))
+    d, i = knn_points(torch.tensor(z["param.c_xyz"]).cuda(), torch.tensor(z["param.xyz"]).cuda(), 4)
+    assert np.array_equal(i.cpu().numpy(), z["knn_idx"])
+    np.testing.assert_array_equal(d.cpu().numpy(), z["knn_dist"])
+
+
+@pytest.mark.parametrize("N", [5, 1000, 30000])
+def test_dist2_bit_exact(N):
+    from dimo_amd.simple_knn._C import distCUDA2
+    rng = np.random.default_rng(N)
+    pts = rng.standard_normal((N, 3)).astype(np.float32)
+    if N > 10:
+        pts[7] = pts[3]  # duplicate point: distance 0 to its twin, still excluded only by index
+    out = distCUDA2(torch.tensor(pts).cuda()).cpu().numpy()
+    assert np.array_equal(out.view(np.uint32), ro.dist2(pts).view(np.uint32))
+
+
+def test_ssim_matches_reference_fixture():
+    from dimo_amd.fused_ssim import fused_ssim
+    z = np.load(os.path.join(GOLD, "image_losses.npz"))
+    a = torch.tensor(z["img1"]).cuda().requires_grad_(True)
+    b = torch.tensor(z["img2"]).cuda()
+    s = fused_ssim(a, b)
+    s.backward()
+    assert abs(s.item() - float(z["ssim"])) < 1e-5
+    assert np.abs(a.grad.cpu().numpy() - z["g_img1"]).max() < 1e-6 + 1e-4 * np.abs(z["g_img1"]).max()
+
+
+@pytest.mark.parametrize("shape", [(1, 3, 128, 128), (4, 3, 67, 45), (2, 1, 16, 16), (8, 3, 512, 512)])
+def test_ssim_against_torch_conv(shape):
+    """Same formula as src/loss.py:144-175 evaluated with torch conv2d on the GPU (fp32 reference)."""
+    import torch.nn.functional as F
+    from dimo_amd.fused_ssim import fused_ssim
+    g = torch.Generator().manual_seed(shape[2])
+    a = torch.rand(shape, generator=g).cuda().requires_grad_(True)
+    b = (torch.rand(shape, generator=g).cuda() * 0.5 + 0.25 * a.detach())
+    w1 = torch.tensor([np.exp(-(x - 5) ** 2 / (2 * 1.5 ** 2)) for x in range(11)], dtype=torch.float32)
+    w1 = (w1 / w1.sum()).unsqueeze(1)
+    win = w1.mm(w1.t())[None, None].expand(shape[1], 1, 11, 11).contiguous().cuda()
+
+    def ref(x, y):
+        conv = lambda t: F.conv2d(t, win, padding=5, groups=shape[1])
+        mu1, mu2 = conv(x), conv(y)
+        s1, s2, s12 = conv(x * x) - mu1 ** 2, conv(y * y) - mu2 ** 2, conv(x * y) - mu1 * mu2
+        return (((2 * mu1 * mu2 + 1e-4) * (2 * s12 + 9e-4)) / ((mu1 ** 2 + mu2 ** 2 + 1e-4) * (s1 + s2 + 9e-4))).mean()
+
+    r = ref(a, b)
+    (gr,) = torch.autograd.grad(r, a)
+    s = fused_ssim(a, b)
+    (gs,) = torch.autograd.grad(s, a)
+    assert abs(s.item() - r.item()) < 2e-5
+    assert (gs - gr).abs().sum() / gr.abs().sum() < 1e-3

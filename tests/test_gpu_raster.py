@@ -1,0 +1,252 @@
+"""GPU parity: HIP rasterizer (through the C ABI) vs the CPU oracle on identical seeded inputs.
+
+Integer stages (radii, tile rects, tiles_touched, offsets, sort keys, sorted order, tile ranges)
+and the per-Gaussian fp32 projection outputs must be BIT-EXACT; images and gradients must agree
+within 1e-4 L1 (north-star tolerance).  n_contrib may differ only where expf rounding flips a
+threshold test (bounded fraction).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import raster_oracle as ro
+from tests.scenes import camera_np, random_scene
+
+pytestmark = pytest.mark.gpu
+L1_TOL = 1e-4
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch.device("cuda:0")
+
+
+def _settings(cam, bg, deg, scale_mod=1.0):
+    from dimo_amd.rasterizer import GaussianRasterizationSettings
+    d = _dev()
+    f = lambda a: torch.tensor(np.asarray(a), dtype=torch.float32, device=d)
+    return GaussianRasterizationSettings(cam["H"], cam["W"], cam["tanfovx"], cam["tanfovy"], f(bg), scale_mod,
+                                         f(cam["view"]), f(cam["proj"]), deg, f(cam["campos"]), False, False)
+
+
+def _run_hip(sc, cam, bg, deg, with_normal=True, grads=None, scale_mod=1.0, capacity=None):
+    """Returns (outputs dict, state dict, grads dict)."""
+    from dimo_amd import rasterizer as rz
+    d = _dev()
+    t = {k: (torch.tensor(np.asarray(v), dtype=torch.float32, device=d).requires_grad_(True) if v is not None else None)
+         for k, v in sc.items()}
+    settings = _settings(cam, bg, deg, scale_mod)
+    means2D = torch.zeros_like(t["means3D"], requires_grad=True)
+    captured = {}
+    orig = rz._Rasterize.forward
+
+    out = rz._Rasterize.apply(t["means3D"], means2D, t.get("shs"), t.get("colors"), t["opacities"], t.get("scales"),
+                              t.get("rotations"), t.get("cov3D"), settings, with_normal, capacity)
+    if with_normal:
+        color, depth, normal, alpha, radii = out
+    else:
+        color, depth, alpha, radii = out
+        normal = None
+    fn = color.grad_fn
+    saved = fn.saved_tensors
+    geom, bin_ws, img_ws = saved[-3], saved[-2], saved[-1]
+    N = t["means3D"].shape[0]
+    st = rz.inspect_state((geom, bin_ws, img_ws), N, cam["H"], cam["W"], fn.r_cap)
+    R = int(st["total"][0].item())
+    res = dict(color=color, depth=depth, normal=normal, alpha=alpha, radii=radii)
+    g = {}
+    if grads is not None:
+        loss = (color * grads[0]).sum() + (depth * grads[1]).sum() + (alpha * grads[3]).sum()
+        if with_normal:
+            loss = loss + (normal * grads[2]).sum()
+        loss.backward()
+        g = {k: v.grad for k, v in t.items() if v is not None}
+        g["means2D"] = means2D.grad
+    torch.cuda.synchronize()
+    return res, st, R, g
+
+
+def _oracle(sc, cam, bg, deg, scale_mod=1.0):
+    f = lambda k: None if sc.get(k) is None else np.asarray(sc[k], np.float32)
+    return ro.forward(f("means3D"), f("shs"), f("colors"), f("opacities"), f("scales"), f("rotations"), f("cov3D"),
+                      scale_mod, cam["view"], cam["proj"], cam["campos"], np.asarray(bg, np.float32), cam["tanfovx"],
+                      cam["tanfovy"], cam["H"], cam["W"], deg, f64=False)
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def _check_forward(sc, cam, bg, deg, with_normal=True, scale_mod=1.0):
+    res, st, R, _ = _run_hip(sc, cam, bg, deg, with_normal, scale_mod=scale_mod)
+    o = _oracle(sc, cam, bg, deg, scale_mod)
+    n = lambda x: x.detach().cpu().numpy()
+    # ---- integer / per-Gaussian stages: bit-exact
+    assert R == o["R"]
+    assert np.array_equal(n(res["radii"]), o["radii"])
+    assert np.array_equal(n(st["tiles_touched"]).view(np.uint32), o["tiles_touched"])
+    assert np.array_equal(n(st["offsets"]).view(np.uint32), o["offsets"])
+    assert np.array_equal(n(st["rect"]).astype(np.int32), o["rect"])
+    sp = n(st["splat"])
+    vis = o["radii"] > 0
+    assert np.array_equal(_bits(sp[vis, 0:2]), _bits(o["xy"][vis])), "pixel means differ"
+    assert np.array_equal(_bits(sp[vis, 2:5]), _bits(o["conic_op"][vis, :3])), "conics differ"
+    assert np.array_equal(_bits(sp[vis, 9]), _bits(o["feat"][vis, 3])), "depths differ"
+    assert np.array_equal(_bits(sp[vis, 6:9]), _bits(o["feat"][vis, 0:3])), "colours differ"
+    assert np.array_equal(_bits(sp[vis, 10:13]), _bits(o["feat"][vis, 4:7])), "normals differ"
+    assert np.array_equal(n(st["keys_unsorted"])[:R].view(np.uint64), o["keys_unsorted"])
+    assert np.array_equal(n(st["vals_unsorted"])[:R].view(np.uint32), o["vals_unsorted"])
+    assert np.array_equal(n(st["keys_sorted"])[:R].view(np.uint64), o["keys_sorted"]), "sort keys differ"
+    assert np.array_equal(n(st["vals_sorted"])[:R].view(np.uint32), o["vals_sorted"]), "sorted order differs"
+    assert np.array_equal(n(st["ranges"]).view(np.uint32), o["ranges"])
+    # ---- images
+    H, W = cam["H"], cam["W"]
+    nc = n(st["n_contrib"]).view(np.uint32)
+    assert (nc != o["n_contrib"]).mean() <= 2e-3, "n_contrib mismatch beyond expf threshold flips"
+    for k, ok in (("color", "out_color"), ("depth", "out_depth"), ("alpha", "out_alpha"), ("normal", "out_normal")):
+        if res[k] is None:
+            continue
+        err = np.abs(n(res[k]) - o[ok]).mean()
+        assert err <= L1_TOL, (k, err)
+    assert np.abs(n(st["final_T"]) - o["final_T"]).mean() <= L1_TOL
+    return res, st, o
+
+
+@pytest.mark.parametrize("N,H,W,deg,M", [(1000, 128, 128, 0, 1), (5000, 80, 96, 0, 1), (3000, 128, 160, 3, 16),
+                                         (2000, 64, 64, 1, 4), (20000, 256, 256, 0, 1)])
+def test_forward_parity(N, H, W, deg, M):
+    cam = camera_np(25.0, elevation=8, W=W, H=H)
+    sc = random_scene(N, seed=N, sh_coeffs=M, scale=0.02)
+    _check_forward(sc, cam, (1.0, 1.0, 1.0), deg)
+
+
+def test_forward_parity_four_output_flavour_and_scale_modifier():
+    cam = camera_np(-70.0, W=128, H=96)
+    sc = random_scene(4000, seed=11, scale=0.03)
+    res, st, o = _check_forward(sc, cam, (0.2, 0.4, 0.6), 0, with_normal=False, scale_mod=0.7)
+    assert res["normal"] is None
+
+
+def test_forward_parity_precomputed_colour_and_cov():
+    cam = camera_np(120.0, elevation=-20, W=96, H=96)
+    sc = random_scene(1500, seed=5, scale=0.04)
+    rng = np.random.default_rng(2)
+    A = rng.standard_normal((1500, 3, 3)) * 0.03
+    S = A @ A.transpose(0, 2, 1) + 1e-5 * np.eye(3)
+    sc2 = dict(means3D=sc["means3D"], opacities=sc["opacities"], colors=rng.random((1500, 3)),
+               cov3D=np.stack([S[:, 0, 0], S[:, 0, 1], S[:, 0, 2], S[:, 1, 1], S[:, 1, 2], S[:, 2, 2]], 1))
+    _check_forward(sc2, cam, (0, 0, 0), 0)
+
+
+def test_edge_cases_empty_culled_offscreen():
+    cam = camera_np(0.0, W=64, H=64)
+    empty = dict(means3D=np.zeros((0, 3)), shs=np.zeros((0, 1, 3)), opacities=np.zeros((0, 1)),
+                 scales=np.zeros((0, 3)), rotations=np.zeros((0, 4)))
+    res, st, R, _ = _run_hip(empty, cam, (1, 1, 1), 0)
+    assert R == 0 and torch.all(res["color"] == 1) and torch.all(res["alpha"] == 0)
+    # all Gaussians behind the camera / outside the frustum
+    sc = random_scene(100, seed=1)
+    sc["means3D"][:, 2] += 5.0
+    _check_forward(sc, cam, (0, 0, 0), 0)
+    # duplicated depths -> ties resolved by emission order; huge Gaussians covering every tile
+    sc = random_scene(300, seed=3, scale=0.6)
+    sc["means3D"][100:200] = sc["means3D"][0:100]
+    _check_forward(sc, cam, (0.5, 0.5, 0.5), 0)
+
+
+def _rel_l1(a, b):
+    return np.abs(a - b).sum() / (np.abs(b).sum() + 1e-12)
+
+
+def _check_backward(sc, cam, bg, deg, names, with_normal=True, seed=0):
+    H, W = cam["H"], cam["W"]
+    rng = np.random.default_rng(seed)
+    gw = [rng.standard_normal(s).astype(np.float32) for s in ((3, H, W), (1, H, W), (3, H, W), (1, H, W))]
+    if not with_normal:
+        gw[2] = np.zeros((3, H, W), np.float32)
+    d = _dev()
+    res, st, R, g = _run_hip(sc, cam, bg, deg, with_normal, grads=[torch.tensor(x, device=d) for x in gw])
+    o = _oracle(sc, cam, bg, deg)
+    go = ro.backward(o, *gw)
+    n = lambda x: x.detach().cpu().numpy()
+    for k, gk in names.items():
+        a, b = n(g[k]).reshape(-1), go[gk].reshape(-1)
+        if k == "means2D":
+            a = n(g[k])[:, :2].reshape(-1)
+        err = _rel_l1(a, b)
+        assert err <= L1_TOL, (k, err)
+        assert np.isfinite(a).all()
+
+
+GRADS_SH = dict(means3D="dL_dmeans3D", means2D="dL_dmean2D", shs="dL_dshs", opacities="dL_dopacity",
+                scales="dL_dscales", rotations="dL_drot")
+
+
+@pytest.mark.parametrize("N,H,W,deg,M", [(1000, 128, 128, 0, 1), (4000, 80, 96, 3, 16), (20000, 256, 256, 0, 1)])
+def test_backward_parity(N, H, W, deg, M):
+    cam = camera_np(25.0, elevation=8, W=W, H=H)
+    sc = random_scene(N, seed=N + 1, sh_coeffs=M, scale=0.02)
+    _check_backward(sc, cam, (1.0, 1.0, 1.0), deg, GRADS_SH)
+
+
+def test_backward_parity_four_output_flavour():
+    cam = camera_np(200.0, W=96, H=128)
+    sc = random_scene(3000, seed=21, scale=0.03)
+    _check_backward(sc, cam, (0.1, 0.2, 0.3), 0, GRADS_SH, with_normal=False)
+
+
+def test_backward_parity_precomp():
+    cam = camera_np(120.0, elevation=-20, W=96, H=96)
+    sc = random_scene(1500, seed=5, scale=0.04)
+    rng = np.random.default_rng(2)
+    A = rng.standard_normal((1500, 3, 3)) * 0.03
+    S = A @ A.transpose(0, 2, 1) + 1e-5 * np.eye(3)
+    sc2 = dict(means3D=sc["means3D"], opacities=sc["opacities"], colors=rng.random((1500, 3)),
+               cov3D=np.stack([S[:, 0, 0], S[:, 0, 1], S[:, 0, 2], S[:, 1, 1], S[:, 1, 2], S[:, 2, 2]], 1))
+    _check_backward(sc2, cam, (0, 0, 0), 0, dict(means3D="dL_dmeans3D", colors="dL_dcolors",
+                                                   opacities="dL_dopacity", cov3D="dL_dcov3D"))
+
+
+def test_capacity_policy_async_and_overflow():
+    from dimo_amd.rasterizer import CapacityPolicy
+    cam = camera_np(10.0, W=128, H=128)
+    sc = random_scene(3000, seed=9, scale=0.03)
+    exact, st_e, R, _ = _run_hip(sc, cam, (1, 1, 1), 0)
+    pol = CapacityPolicy(initial=2 * R)
+    res, st, R2, _ = _run_hip(sc, cam, (1, 1, 1), 0, capacity=pol)
+    assert R2 == R and pol.check()
+    assert torch.equal(res["color"], exact["color"]) and torch.equal(res["alpha"], exact["alpha"])
+    small = CapacityPolicy(initial=R // 2)
+    _run_hip(sc, cam, (1, 1, 1), 0, capacity=small)  # must not crash or write out of bounds
+    assert small.check() is False and small.capacity >= R
+    res3, _, _, _ = _run_hip(sc, cam, (1, 1, 1), 0, capacity=small)
+    assert small.check() and torch.equal(res3["color"], exact["color"])
+
+
+def test_full_size_properties_100k_512():
+    """BASELINE config size (100k Gaussians, 512^2): size-independent properties instead of the oracle."""
+    cam = camera_np(40.0, W=512, H=512)
+    sc = random_scene(100_000, seed=100, scale=0.012, anisotropy=0.2)
+    res, st, R, _ = _run_hip(sc, cam, (0, 0, 0), 0)
+    n = lambda x: x.detach().cpu().numpy()
+    keys = n(st["keys_sorted"])[:R].view(np.uint64)
+    assert np.all(keys[1:] >= keys[:-1]), "keys not sorted"
+    # the sorted multiset equals the emitted multiset (checksum of keys and of values)
+    ku = n(st["keys_unsorted"])[:R].view(np.uint64)
+    assert int(ku.sum(dtype=np.uint64)) == int(keys.sum(dtype=np.uint64))
+    assert int(n(st["vals_unsorted"])[:R].astype(np.uint64).sum()) == int(n(st["vals_sorted"])[:R].astype(np.uint64).sum())
+    ranges = n(st["ranges"]).view(np.uint32).astype(np.int64)
+    assert (ranges[:, 1] - ranges[:, 0]).sum() == R
+    a = n(res["alpha"])
+    T = n(st["final_T"])
+    assert np.abs(a[0] - (1 - T)).max() < 1e-4  # alpha = 1 - final transmittance
+    assert a.min() >= 0 and a.max() <= 1 + 1e-5 and T.min() >= 1e-4 - 1e-7
+    # linearity in colour: doubling the SH DC term (with zero background) doubles C - 0.5*alpha ... use colours
+    col = np.random.default_rng(0).random((100_000, 3))
+    sc_c = dict(means3D=sc["means3D"], scales=sc["scales"], rotations=sc["rotations"], opacities=sc["opacities"],
+                colors=col)
+    r1, _, _, _ = _run_hip(sc_c, cam, (0, 0, 0), 0)
+    sc_c["colors"] = 2 * col
+    r2, _, _, _ = _run_hip(sc_c, cam, (0, 0, 0), 0)
+    assert torch.allclose(2 * r1["color"], r2["color"], atol=1e-5)
+    assert torch.equal(r1["alpha"], r2["alpha"])
