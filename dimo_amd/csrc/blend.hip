@@ -295,11 +295,11 @@ extern "C" int dimo_raster_backward(int N, int sh_degree, int M, int H, int W, i
   (void)opacities;
   if (N < 0 || H <= 0 || W <= 0 || R_cap < 0 || R_cap > 0xfffffff0LL) return DIMO_E_ARG;
   if (!geom || !bin || !img || !bg || !scratch || !viewmatrix || !projmatrix || !campos) return DIMO_E_ARG;
-  if ((shs == nullptr) == (colors_precomp == nullptr)) return DIMO_E_ARG;
+  if (N > 0 && (shs == nullptr) == (colors_precomp == nullptr)) return DIMO_E_ARG;
   if (N > 0 && (!means3D || !radii || !dL_dmeans3D || !dL_dmeans2D || !dL_dopacity)) return DIMO_E_ARG;
-  if (shs && !dL_dshs) return DIMO_E_ARG;
-  if (colors_precomp && !dL_dcolors) return DIMO_E_ARG;
-  if (cov3D_precomp ? !dL_dcov3D : (!dL_dscales || !dL_drotations || !scales || !rotations)) return DIMO_E_ARG;
+  if (N > 0 && shs && !dL_dshs) return DIMO_E_ARG;
+  if (N > 0 && colors_precomp && !dL_dcolors) return DIMO_E_ARG;
+  if (N > 0 && (cov3D_precomp ? !dL_dcov3D : (!dL_dscales || !dL_drotations || !scales || !rotations))) return DIMO_E_ARG;
   if (scratch_bytes < dimo_raster_backward_scratch_bytes(N, R_cap)) return DIMO_E_WORKSPACE;
   GeomLayout G(N);
   BinLayout B(R_cap, H, W);

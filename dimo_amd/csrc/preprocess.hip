@@ -495,8 +495,8 @@ extern "C" int dimo_raster_preprocess_forward(int N, int sh_degree, int M, int H
                                               size_t geom_bytes, int64_t *R_host, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (N < 0 || H <= 0 || W <= 0 || !geom || !viewmatrix || !projmatrix || !campos) return DIMO_E_ARG;
-  if ((shs == nullptr) == (colors_precomp == nullptr)) return DIMO_E_ARG;
-  if (!cov3D_precomp && (!scales || !rotations)) return DIMO_E_ARG;
+  if (N > 0 && (shs == nullptr) == (colors_precomp == nullptr)) return DIMO_E_ARG;
+  if (N > 0 && !cov3D_precomp && (!scales || !rotations)) return DIMO_E_ARG;
   if (shs && (sh_degree < 0 || sh_degree > 3 || M < (sh_degree + 1) * (sh_degree + 1))) return DIMO_E_ARG;
   if ((W + TILE - 1) / TILE > 65535 || (H + TILE - 1) / TILE > 65535) return DIMO_E_ARG;
   GeomLayout L(N);

@@ -91,12 +91,13 @@ class _Rasterize(torch.autograd.Function):
         means3D, opacities = _f32c(means3D), _f32c(opacities)
         shs, colors_precomp = _f32c(shs), _f32c(colors_precomp)
         scales, rotations, cov3D_precomp = _f32c(scales), _f32c(rotations), _f32c(cov3D_precomp)
-        if shs is not None and shs.numel() == 0:
-            shs = None
-        if colors_precomp is not None and colors_precomp.numel() == 0:
-            colors_precomp = None
-        if cov3D_precomp is not None and cov3D_precomp.numel() == 0:
-            cov3D_precomp = None
+        if N > 0:  # the CUDA wrappers pass "absent" as empty tensors
+            if shs is not None and shs.numel() == 0:
+                shs = None
+            if colors_precomp is not None and colors_precomp.numel() == 0:
+                colors_precomp = None
+            if cov3D_precomp is not None and cov3D_precomp.numel() == 0:
+                cov3D_precomp = None
         if (shs is None) == (colors_precomp is None):
             raise ValueError("Please provide exactly one of either SHs or precomputed colors!")
         if cov3D_precomp is None and (scales is None or rotations is None):
