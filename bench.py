@@ -1,0 +1,201 @@
+#!/usr/bin/env python
+"""bench.py -- train-step frames/s of the deform-then-render path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+
+Workload (BASELINE.json configs[2], the configuration the metric is quoted on): 100k synthetic Gaussians
+(initialised as the reference initialises them), 512 control points, 512x512, stage s2, 8 renders
+(2 motions x 2 views x 2 frames) per GPU per step through deform -> rasterize -> losses -> backward ->
+RCCL all-reduce of the flat gradient bucket -> Adam.  "frames" = (motion, view, frame) renders taken through
+forward + backward + optimizer.  Weak scaling: per-GPU work is fixed, the step's motion count grows with N.
+
+One JSON line is printed by rank 0.  `roofline` describes the dominant kernel (blend backward): ALGORITHMIC
+bytes per launch (B1 = (28+4C) R + (8(C+1)+8) P + (24+4C) V with C = 7 feature channels and
+the measured R = tile instances, V = visible Gaussians, P = pixels) divided by its mean duration measured
+with HIP events on the launch stream during the timed region.  `cpu_baseline` is the same train step on the
+host cores with the CPU oracle injected (a reported baseline, not the optimisation target).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+NFEAT = 7
+TIMED = ["preprocess_fwd", "scan", "emit", "sort", "ranges", "blend_fwd", "blend_bwd", "preprocess_bwd", "knn",
+         "ssim_fwd", "ssim_bwd"]
+
+
+def make_trainer(device, rank, world, num_pts, resolution, per_gpu=(2, 2, 2), capacity=True):
+    from dimo_amd.rasterizer import CapacityPolicy
+    from dimo_amd.renderer import Renderer
+    from dimo_amd.synth import init_synthetic_model
+    from dimo_amd.trainer import TrainConfig, Trainer
+    m, v, f = per_gpu
+    cfg = TrainConfig(num_pts=num_pts, resolution=resolution, motions_per_step=min(51, m * world), views_per_step=v,
+                      frames_per_step=f)
+    pol = CapacityPolicy(initial=max(1 << 20, 40 * num_pts)) if capacity else None
+    rd = Renderer(sh_degree=0, white_background=True, radius=cfg.radius, num_latent_code=cfg.num_motions,
+                  latent_code_dim=cfg.latent_code_dim, add_normal=True, device=device, capacity=pol)
+    init_synthetic_model(rd, cfg.num_pts, cfg.num_cpts, seed=0, regime="trained", num_latent=cfg.num_motions)
+    return Trainer(cfg, rd, rank=rank, world_size=world), pol
+
+
+def read_timing():
+    from dimo_amd import _lib
+    L = _lib.lib()
+    out = {}
+    for name in TIMED:
+        ms, n = C.c_double(0), C.c_int64(0)
+        _lib.check(L.dimo_timing_read(name.encode(), C.byref(ms), C.byref(n)), "dimo_timing_read")
+        out[name] = (ms.value, n.value)
+    return out
+
+
+def cpu_baseline(num_pts, resolution, renders=2):
+    """Same train step on the host cores: product host logic + CPU oracle kernels (kind 'port')."""
+    from dimo_amd.trainer import TrainConfig
+    from tests.cpu_backend import make_cpu_trainer
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = TrainConfig(num_pts=num_pts, resolution=resolution, motions_per_step=1, views_per_step=1,
+                      frames_per_step=renders)
+    tr = make_cpu_trainer(cfg)
+    t0 = time.time()
+    n = tr.train_step()
+    dt = time.time() - t0
+    return {"value": n / dt, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"1 train step of {n} renders (1 motion x 1 view x {renders} frames) at {num_pts} Gaussians "
+                      f"{resolution}x{resolution}: torch-CPU deform/losses/Adam + C oracle rasterizer "
+                      f"(forward OpenMP over {cores} threads, backward single-threaded); {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--num-pts", type=int, default=100000)
+    ap.add_argument("--resolution", type=int, default=512)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sync-exact", action="store_true", help="size sort buffers by reading R back (one sync per render)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit(f"--gpus {args.gpus} needs a torch.distributed.run launch with --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (the product path has no CPU fallback)")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from dimo_amd import _lib
+    L = _lib.lib()
+    tr, pol = make_trainer(device, rank, world, args.num_pts, args.resolution, capacity=not args.sync_exact)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        tr.train_step()
+    barrier()
+    L.dimo_timing_enable(1)
+    t0 = time.perf_counter()
+    renders = 0
+    for _ in range(args.steps):
+        renders += tr.train_step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    L.dimo_timing_enable(0)
+    tt = torch.tensor([elapsed, float(renders)], dtype=torch.float64, device=device)
+    if world > 1:
+        tmax = tt.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+        elapsed, renders_total = float(tmax[0]), float(tt[1])
+    else:
+        renders_total = float(renders)
+    timing = read_timing()
+
+    if rank == 0:
+        # measured R (tile instances) and V (visible Gaussians) of this workload, outside the timed region
+        cam = tr.cams.get(0, tr.azimuths[0], tr.cfg.radius, args.resolution, args.resolution)
+        tr.find_knn()
+        with torch.no_grad():
+            out = tr.renderer.render(cam, time=tr.source_time[3], stage="s2", latent_index=0)
+        V = int((out["radii"] > 0).sum())
+        if pol is not None:
+            pol.check()
+            R = int(getattr(pol, "last_r_mean", 0)) or None
+        else:
+            R = None
+        if R is None:
+            from dimo_amd.rasterizer import CapacityPolicy
+            p2 = CapacityPolicy(initial=pol.capacity if pol else 1 << 24)
+            tr.renderer.capacity = p2
+            with torch.no_grad():
+                tr.renderer.render(cam, time=tr.source_time[3], stage="s2", latent_index=0)
+            tot = torch.stack(p2._pending).cpu()
+            R = int(tot[:, 0].max())
+        P = args.resolution * args.resolution
+        bwd_ms, bwd_n = timing["blend_bwd"]
+        alg_bytes = (28 + 4 * NFEAT) * R + (8 * (NFEAT + 1) + 8) * P + (24 + 4 * NFEAT) * V
+        avg_s = (bwd_ms / max(bwd_n, 1)) * 1e-3
+        achieved = alg_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_blend_bwd.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        res = {
+            "metric": "train-step frames/sec @100k Gaussians 512^2 (renders through deform+raster fwd+bwd+losses+Adam)",
+            "value": renders_total / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic (seeded Gaussians initialised as the reference does, random-init TimeNet, "
+                    "random targets; no dataset/LPIPS weights offline; LPIPS/ARAP/GA/KL terms excluded)",
+            "config": {"workload": f"C3: {args.num_pts} Gaussians, 512 control points, {args.resolution}^2, stage s2, "
+                                   f"diff_gauss flavour (rgb+depth+normal+alpha), 8 renders/GPU/step "
+                                   f"(2 motions x 2 views x 2 frames per GPU)",
+                       "renders_per_step": int(renders_total / args.steps), "parallelism": f"dp{world}",
+                       "R_tile_instances": R, "V_visible": V},
+            "roofline": {"bound": "hbm", "kernel": "blend_bwd_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_ms": bwd_ms / max(bwd_n, 1),
+                         "launches": bwd_n,
+                         "note": "tile blend is FP32-VALU/LDS bound, not HBM bound (each 64-B record is reused by 256 "
+                                 "pixels); the HBM fraction is reported as required, see DESIGN.md"},
+            "kernels_ms_per_render": {k: (v[0] / v[1] if v[1] else None) for k, v in timing.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                res["cpu_baseline"] = cpu_baseline(args.num_pts, args.resolution)
+            except Exception as e:  # the baseline must never take the GPU number down with it
+                res["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": os.cpu_count(), "kind": "port",
+                                       "sample": f"failed: {e!r}"}
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

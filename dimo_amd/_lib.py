@@ -17,6 +17,8 @@ c_ptr = C.c_void_p
 # name -> (restype, argtypes).  Mirrors include/dimo_hip.h one to one.
 _SIGNATURES = {
     "dimo_version": (C.c_char_p, []),
+    "dimo_timing_enable": (C.c_int, [C.c_int]),
+    "dimo_timing_read": (C.c_int, [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "dimo_raster_geom_bytes": (C.c_size_t, [C.c_int]),
     "dimo_raster_bin_bytes": (C.c_size_t, [C.c_int64, C.c_int, C.c_int]),
     "dimo_raster_img_bytes": (C.c_size_t, [C.c_int, C.c_int]),

@@ -27,3 +27,71 @@ extern "C" int dimo_raster_img_layout(int H, int W, size_t out[2]) {
   out[0] = L.final_T, out[1] = L.n_contrib;
   return DIMO_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Optional kernel timing with HIP events, recorded on the very stream each kernel is launched on.
+// This is the one piece of process-global state in the library; it is OFF by default and is meant
+// for bench.py's live roofline figure (the rocprofv3 summaries under profiles/ must agree with it).
+#include <mutex>
+#include <string>
+#include <vector>
+
+namespace dimo {
+namespace {
+struct Rec {
+  int id;
+  hipEvent_t a, b;
+};
+std::mutex g_mu;
+bool g_on = false;
+std::vector<Rec> g_recs;
+const char *const g_names[TIMED_COUNT] = {"preprocess_fwd", "scan", "emit",     "sort",     "ranges",  "blend_fwd",
+                                          "blend_bwd",      "preprocess_bwd", "knn", "dist2", "ssim_fwd", "ssim_bwd"};
+}  // namespace
+
+ScopedTimer::ScopedTimer(int id, hipStream_t s) : id_(id), stream_(s), a_(nullptr), b_(nullptr) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (!g_on) return;
+  if (hipEventCreate(&a_) != hipSuccess || hipEventCreate(&b_) != hipSuccess) {
+    a_ = b_ = nullptr;
+    return;
+  }
+  hipEventRecord(a_, stream_);
+}
+ScopedTimer::~ScopedTimer() {
+  if (!a_) return;
+  hipEventRecord(b_, stream_);
+  std::lock_guard<std::mutex> lk(g_mu);
+  g_recs.push_back({id_, a_, b_});
+}
+}  // namespace dimo
+
+extern "C" int dimo_timing_enable(int on) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  const int prev = g_on ? 1 : 0;
+  if (on && !g_on) {
+    for (auto &r : g_recs) hipEventDestroy(r.a), hipEventDestroy(r.b);
+    g_recs.clear();
+  }
+  g_on = on != 0;
+  return prev;
+}
+
+extern "C" int dimo_timing_read(const char *name, double *total_ms, int64_t *launches) {
+  if (!name || !total_ms || !launches) return DIMO_E_ARG;
+  int id = -1;
+  for (int i = 0; i < TIMED_COUNT; ++i)
+    if (std::string(name) == g_names[i]) id = i;
+  if (id < 0) return DIMO_E_ARG;
+  if (hipDeviceSynchronize() != hipSuccess) return DIMO_E_LAUNCH;
+  std::lock_guard<std::mutex> lk(g_mu);
+  double tot = 0.0;
+  int64_t n = 0;
+  for (auto &r : g_recs)
+    if (r.id == id) {
+      float ms = 0.0f;
+      if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) tot += ms, ++n;
+    }
+  *total_ms = tot, *launches = n;
+  return DIMO_OK;
+}

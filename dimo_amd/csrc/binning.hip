@@ -280,6 +280,7 @@ int bin_instances(int N, int H, int W, int64_t R_cap, const void *geom, void *bi
   const int passes = (bits + RADIX_BITS - 1) / RADIX_BITS;
 
   if (N > 0) {
+    ScopedTimer tm(T_EMIT, stream);
     hipLaunchKernelGGL(emit_keys_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, N, B.tiles_x, cap,
                        at<Splat>(geom, G.splat), at<uint16_t>(geom, G.rect), at<uint32_t>(geom, G.offsets), total,
                        keys_u, vals_u);
@@ -287,6 +288,7 @@ int bin_instances(int N, int H, int W, int64_t R_cap, const void *geom, void *bi
   const uint32_t nblk = (uint32_t)B.sort_blocks;
   const uint64_t *kin = keys_u;
   const uint32_t *vin = vals_u;
+  ScopedTimer *sort_tm = new ScopedTimer(T_SORT, stream);
   for (int p = 0; p < passes; ++p) {
     const bool to_sorted = ((passes - 1 - p) & 1) == 0;
     uint64_t *kout = to_sorted ? keys_s : keys_c;
@@ -298,8 +300,12 @@ int bin_instances(int N, int H, int W, int64_t R_cap, const void *geom, void *bi
                        shift, nblk, hist);
     kin = kout, vin = vout;
   }
-  hipLaunchKernelGGL(clear_ranges_kernel, dim3((2 * B.T + 255) / 256), dim3(256), 0, stream, B.T, ranges);
-  hipLaunchKernelGGL(tile_ranges_kernel, dim3((cap + 255) / 256), dim3(256), 0, stream, keys_s, total, cap, ranges);
+  delete sort_tm;
+  {
+    ScopedTimer tm(T_RANGES, stream);
+    hipLaunchKernelGGL(clear_ranges_kernel, dim3((2 * B.T + 255) / 256), dim3(256), 0, stream, B.T, ranges);
+    hipLaunchKernelGGL(tile_ranges_kernel, dim3((cap + 255) / 256), dim3(256), 0, stream, keys_s, total, cap, ranges);
+  }
   return check_launch();
 }
 

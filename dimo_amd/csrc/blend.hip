@@ -265,6 +265,7 @@ extern "C" int dimo_raster_render_forward(int N, int H, int W, int64_t R_cap, co
   const uint32_t *ranges = at<uint32_t>(bin, B.ranges);
   const uint32_t *vals = at<uint32_t>(bin, B.vals_b);
   const Splat *splat = at<Splat>(geom, G.splat);
+  ScopedTimer tm(T_BLEND_FWD, stream);
   if (out_normal)
     hipLaunchKernelGGL(blend_fwd_kernel<true>, dim3(B.T), dim3(BLEND_BLOCK), 0, stream, H, W, B.tiles_x, ranges, vals,
                        splat, bg, out_color, out_depth, out_normal, out_alpha, at<float>(img, I.final_T),
@@ -307,6 +308,7 @@ extern "C" int dimo_raster_backward(int N, int sh_degree, int M, int H, int W, i
   const uint32_t cap = (uint32_t)B.cap;
   SplatGrad *inst = reinterpret_cast<SplatGrad *>(scratch);
   if (N > 0) {
+    ScopedTimer tm(T_BLEND_BWD, stream);
     if (dL_dnormal)
       hipLaunchKernelGGL(blend_bwd_kernel<true>, dim3(B.T), dim3(BLEND_BLOCK), 0, stream, H, W, B.tiles_x, cap,
                          at<uint32_t>(bin, B.ranges), at<uint32_t>(bin, B.vals_b), at<Splat>(geom, G.splat),

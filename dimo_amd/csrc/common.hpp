@@ -121,6 +121,24 @@ inline int key_bits(int T) {
   return 32 + (b > 0 ? b : 1);
 }
 
+// ---- optional HIP-event timing of kernel groups (off by default; see api.hip) ------------------
+enum TimedKernel {
+  T_PREPROCESS_FWD = 0, T_SCAN, T_EMIT, T_SORT, T_RANGES, T_BLEND_FWD, T_BLEND_BWD, T_PREPROCESS_BWD, T_KNN, T_DIST2,
+  T_SSIM_FWD, T_SSIM_BWD, TIMED_COUNT
+};
+class ScopedTimer {
+ public:
+  ScopedTimer(int id, hipStream_t s);
+  ~ScopedTimer();
+  ScopedTimer(const ScopedTimer &) = delete;
+  ScopedTimer &operator=(const ScopedTimer &) = delete;
+
+ private:
+  int id_;
+  hipStream_t stream_;
+  hipEvent_t a_, b_;
+};
+
 // ---- internal (C++ linkage) entry points shared between translation units ---------------------
 int scan_block_sums(int nb, uint32_t *block_sums, uint32_t *total, hipStream_t stream);
 int write_offsets(int N, const uint32_t *tiles, const uint32_t *block_sums, uint32_t *offsets, hipStream_t stream);

@@ -99,6 +99,7 @@ extern "C" int dimo_knn(int M, int N, int k, const float *ref, const float *quer
   if (N == 0) return DIMO_OK;
   if (!query || !dist || !idx || (M > 0 && !ref)) return DIMO_E_ARG;
   const dim3 grid((N + KNN_BLOCK - 1) / KNN_BLOCK), block(KNN_BLOCK);
+  ScopedTimer tm(T_KNN, stream);
   if (k <= 4)
     hipLaunchKernelGGL(knn_kernel<4>, grid, block, 0, stream, M, N, k, ref, query, dist, idx);
   else if (k <= 8)
@@ -113,6 +114,7 @@ extern "C" int dimo_dist2(int N, const float *points, float *out, void *stream_)
   if (N < 0) return DIMO_E_ARG;
   if (N == 0) return DIMO_OK;
   if (!points || !out) return DIMO_E_ARG;
+  ScopedTimer tm(T_DIST2, stream);
   hipLaunchKernelGGL(dist2_kernel, dim3((N + D2_BLOCK - 1) / D2_BLOCK), dim3(D2_BLOCK), 0, stream, N, points, out);
   return check_launch();
 }

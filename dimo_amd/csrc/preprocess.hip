@@ -504,16 +504,19 @@ extern "C" int dimo_raster_preprocess_forward(int N, int sh_degree, int M, int H
   if (N > 0 && (!means3D || !opacities || !radii)) return DIMO_E_ARG;
   const int nb = (N + PRE_BLOCK - 1) / PRE_BLOCK;
   if (nb > 0) {
+    ScopedTimer tm(T_PREPROCESS_FWD, stream);
     hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(nb), dim3(PRE_BLOCK), 0, stream, N, sh_degree, M, H, W, means3D,
                        shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, scale_modifier, viewmatrix,
                        projmatrix, campos, tanfovx, tanfovy, radii, at<Splat>(geom, L.splat),
                        at<uint16_t>(geom, L.rect), at<uint32_t>(geom, L.tiles), at<uint8_t>(geom, L.flags),
                        at<uint32_t>(geom, L.block_sums));
   }
+  ScopedTimer *scan_tm = new ScopedTimer(T_SCAN, stream);
   int rc = scan_block_sums(nb, at<uint32_t>(geom, L.block_sums), at<uint32_t>(geom, L.total), stream);
   if (rc) return rc;
   rc = write_offsets(N, at<uint32_t>(geom, L.tiles), at<uint32_t>(geom, L.block_sums),
                           at<uint32_t>(geom, L.offsets), stream);
+  delete scan_tm;
   if (rc) return rc;
   if (R_host) {
     uint32_t tot[4] = {0, 0, 0, 0};
@@ -535,6 +538,7 @@ int dimo::preprocess_backward_launch(
   GeomLayout L(N);
   const int nb = (N + PRE_BLOCK - 1) / PRE_BLOCK;
   if (nb == 0) return DIMO_OK;
+  ScopedTimer tm(T_PREPROCESS_BWD, stream);
   hipLaunchKernelGGL(preprocess_bwd_kernel, dim3(nb), dim3(PRE_BLOCK), 0, stream, N, sh_degree, M, H, W,
                      (uint32_t)(R_cap > 0xffffffffLL ? 0xffffffffu : (uint32_t)R_cap), means3D, shs, colors_precomp,
                      scales, rotations, cov3D_precomp, scale_modifier, viewmatrix, projmatrix, campos, tanfovx,

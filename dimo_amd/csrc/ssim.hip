@@ -174,6 +174,7 @@ extern "C" int dimo_ssim_forward(int B, int C, int H, int W, const float *img1, 
   if (!img1 || !img2 || planes > 65535) return DIMO_E_ARG;
   static const Window win = make_window();
   const dim3 grid((W + ST - 1) / ST, (H + ST - 1) / ST, (unsigned)planes), block(ST, ST);
+  ScopedTimer tm(T_SSIM_FWD, stream);
   hipLaunchKernelGGL(ssim_fwd_kernel, grid, block, 0, stream, H, W, win, img1, img2, ssim_sum, partials,
                      (size_t)planes * H * W);
   return check_launch();
@@ -188,6 +189,7 @@ extern "C" int dimo_ssim_backward(int B, int C, int H, int W, const float *img1,
   if (!img1 || !img2 || !partials || !dL_dmean || !dL_dimg1 || planes > 65535) return DIMO_E_ARG;
   static const Window win = make_window();
   const dim3 grid((W + ST - 1) / ST, (H + ST - 1) / ST, (unsigned)planes), block(ST, ST);
+  ScopedTimer tm(T_SSIM_BWD, stream);
   hipLaunchKernelGGL(ssim_bwd_kernel, grid, block, 0, stream, H, W, win, img1, img2, partials,
                      (size_t)planes * H * W, dL_dmean, 1.0f / (float)((double)planes * H * W), dL_dimg1);
   return check_launch();

@@ -64,6 +64,7 @@ class CapacityPolicy:
         tot = torch.stack(self._pending).cpu()
         self._pending = []
         r_max = int(tot[:, 0].max())
+        self.last_r_mean, self.last_r_max = float(tot[:, 0].float().mean()), r_max
         ok = int(tot[:, 1].max()) == 0
         self.capacity = max(self.capacity if ok else 0, int(r_max * self.margin) + 1024)
         return ok

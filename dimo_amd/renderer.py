@@ -1,0 +1,157 @@
+"""`Renderer` -- the call surface the trainer depends on (drop-in for
+renderer/latent_gs_renderer.py:973-1293 and, with `vae_latent=True`, renderer/gaussian_gs_renderer.py).
+
+`render()` keeps the reference's signature, stage semantics ("s1": TimeNet moves the Gaussians
+directly; "s2": TimeNet moves the control points and the Gaussians follow by LBS) and return dict
+{image, depth, normal, alpha, viewspace_points, visibility_filter, radii, pts_t, cpts_t}.
+
+Differences that do not change results:
+  * rasterizer = dimo_amd HIP kernels (both flavours; `add_normal=False` returns normal=None instead of
+    the reference's NameError, latent_gs_renderer.py:1286);
+  * settings tuples / tan(fov) come from a per-camera cache instead of being rebuilt per call;
+  * an optional `CapacityPolicy` makes the call free of host synchronisation.
+"""
+import math
+
+import numpy as np
+import torch
+
+from .deform import lbs_deform
+from .gaussian_model import BasicPointCloud, GaussianModel, SH2RGB
+
+
+def _ball_points(n, radius, rng):
+    """Uniform-in-ball sampling exactly as latent_gs_renderer.py:999-1007 (draw order: phi, cos(theta), mu)."""
+    phis = rng.random((n,)) * 2 * np.pi
+    costheta = rng.random((n,)) * 2 - 1
+    thetas = np.arccos(costheta)
+    mu = rng.random((n,))
+    r = radius * np.cbrt(mu)
+    return np.stack((r * np.sin(thetas) * np.cos(phis), r * np.sin(thetas) * np.sin(phis), r * np.cos(thetas)), axis=1)
+
+
+class Renderer:
+    def __init__(self, sh_degree=3, white_background=True, radius=1, delta_t=1 / 32, num_latent_code=1,
+                 latent_code_dim=32, add_normal=False, vae_latent=False, device=None, rasterizer_factory=None,
+                 capacity=None, dist2_fn=None):
+        self.sh_degree = sh_degree
+        self.white_background = white_background
+        self.radius = radius
+        self.gaussians = GaussianModel(sh_degree=sh_degree, num_latent_code=num_latent_code,
+                                       latent_code_dim=latent_code_dim, vae_latent=vae_latent, device=device,
+                                       dist2_fn=dist2_fn)
+        self.device = self.gaussians.device
+        self.bg_color = torch.tensor([1, 1, 1] if white_background else [0, 0, 0], dtype=torch.float32,
+                                     device=self.device)
+        self.delta_t = delta_t
+        self.add_normal = add_normal
+        self.capacity = capacity
+        # tests inject a CPU rasterizer here; the product default is the HIP one (no fallback)
+        self._rasterizer_factory = rasterizer_factory
+        self._np_rng = np.random  # the reference draws from numpy's global RNG
+
+    # ------------------------------------------------------------------ initialisation
+    def initialize(self, input=None, num_pts=5000, num_cpts=512, radius=0.5, radius2=0.5, only_init_gaussians=False):
+        if input is None:
+            rng = self._np_rng
+            xyz = _ball_points(num_pts, radius, rng)
+            shs = rng.random((num_pts, 3)) / 255.0
+            pcd = BasicPointCloud(points=xyz, colors=SH2RGB(shs), normals=np.zeros((num_pts, 3)))
+            xyz2 = _ball_points(num_cpts, radius2, rng)
+            shs2 = rng.random((num_cpts, 3)) / 255.0
+            pcd2 = BasicPointCloud(points=xyz2, colors=SH2RGB(shs2), normals=np.zeros((num_cpts, 3)))
+            self.gaussians.create_from_pcd(pcd, pcd2, 1, only_init_gaussians=only_init_gaussians)
+        elif isinstance(input, BasicPointCloud):
+            self.gaussians.create_from_pcd(input, input, 1)
+        else:
+            raise ValueError("Unsupported initialization type!!!")
+
+    def initialize_ag(self, c_xyz, c_radius, num_cpts=512, num_pts_per_cpt=200, init_ratio=1):
+        """'Adaptive Gaussian' re-init: num_pts_per_cpt Gaussians around every control point
+        (latent_gs_renderer.py:1038-1058)."""
+        rng = self._np_rng
+        local = _ball_points(num_pts_per_cpt, c_radius.mean().item() * init_ratio, rng)
+        xyz = torch.tensor(local)[None].repeat(num_cpts, 1, 1).flatten(0, 1)
+        centers = c_xyz.detach().cpu()[:, None].repeat(1, num_pts_per_cpt, 1).flatten(0, 1)
+        xyz = (xyz + centers).numpy()
+        shs = rng.random((num_pts_per_cpt * num_cpts, 3)) / 255.0
+        pcd = BasicPointCloud(points=xyz, colors=SH2RGB(shs), normals=np.zeros((num_pts_per_cpt * num_cpts, 3)))
+        self.gaussians.create_from_pcd(pcd, pcd, 1, only_init_gaussians=True)
+
+    def reparameterize(self, mu, log_var):
+        std = torch.exp(0.5 * log_var)
+        return torch.randn_like(std) * std + mu
+
+    # ------------------------------------------------------------------ rasterizer plumbing
+    def _make_rasterizer(self, settings):
+        if self._rasterizer_factory is not None:
+            return self._rasterizer_factory(settings, self.add_normal)
+        from . import rasterizer as rz
+        cls = rz.GaussianRasterizerNormal if self.add_normal else rz.GaussianRasterizer
+        return cls(raster_settings=settings, capacity=self.capacity)
+
+    def _settings(self, cam, scaling_modifier, bg_color):
+        from .rasterizer import GaussianRasterizationSettings
+        tanfovx = getattr(cam, "tanfovx", None) or math.tan(cam.FoVx * 0.5)
+        tanfovy = getattr(cam, "tanfovy", None) or math.tan(cam.FoVy * 0.5)
+        return GaussianRasterizationSettings(
+            image_height=int(cam.image_height), image_width=int(cam.image_width), tanfovx=tanfovx, tanfovy=tanfovy,
+            bg=self.bg_color if bg_color is None else bg_color, scale_modifier=scaling_modifier,
+            viewmatrix=cam.world_view_transform, projmatrix=cam.full_proj_transform,
+            sh_degree=self.gaussians.active_sh_degree, campos=cam.camera_center, prefiltered=False, debug=False)
+
+    # ------------------------------------------------------------------ the hot path
+    def render(self, viewpoint_camera, scaling_modifier=1.0, bg_color=None, override_color=None,
+               compute_cov3D_python=False, convert_SHs_python=False, time=0.0, stage="s1", rot_as_res=True,
+               xyz_detach=False, local_frame=True, direct_deform=False, vertices_deform=None, latent_index=0):
+        g = self.gaussians
+        if compute_cov3D_python or convert_SHs_python:
+            raise NotImplementedError("python-side covariance / SH conversion is not on DIMO's training path")
+        # gradient sink for the screen-space means (densification statistics read .grad)
+        screenspace_points = torch.zeros_like(g.get_xyz, requires_grad=True)
+        settings = self._settings(viewpoint_camera, scaling_modifier, bg_color)
+        rasterizer = self._make_rasterizer(settings)
+
+        means3D = g.get_xyz
+        opacity = g.get_opacity
+        latent_code = g.latent_code(latent_index)
+        scales = g.get_scaling
+        rotations = g._rotation
+
+        if stage >= "s2":
+            c_means3D = g.get_c_xyz
+            means3D_deform, rots_deform = g._timenet(c_means3D, time, latent_code)
+            cpts_t = c_means3D + means3D_deform
+            means3D, rotations = lbs_deform(means3D, rotations, c_means3D, g.get_c_radius(stage), means3D_deform,
+                                            rots_deform, g.neighbor_dists, g.neighbor_indices, local_frame)
+        elif stage == "s1":
+            means3D_deform, _ = g._timenet(means3D, time, latent_code)
+            cpts_t = means3D + means3D_deform
+            means3D = means3D + means3D_deform
+        else:
+            raise ValueError("Nonexistent stage!!!")
+        if xyz_detach:
+            means3D = means3D.detach()
+        rotations = g.rotation_activation(rotations)
+
+        shs = colors_precomp = None
+        if override_color is None:
+            shs = g.get_features
+        else:
+            colors_precomp = override_color
+
+        if self.add_normal:
+            image, depth, normal, alpha, radii, _extra = rasterizer(
+                means3D=means3D, means2D=screenspace_points, shs=shs, colors_precomp=colors_precomp,
+                opacities=opacity, scales=scales, rotations=rotations, cov3Ds_precomp=None, extra_attrs=None)
+        else:
+            image, radii, depth, alpha = rasterizer(
+                means3D=means3D, means2D=screenspace_points, shs=shs, colors_precomp=colors_precomp,
+                opacities=opacity, scales=scales, rotations=rotations, cov3D_precomp=None)
+            normal = None
+        image = image.clamp(0, 1)
+        return {
+            "image": image, "depth": depth, "normal": normal, "alpha": alpha,
+            "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "radii": radii,
+            "pts_t": means3D, "cpts_t": cpts_t,
+        }

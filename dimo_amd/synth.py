@@ -1,0 +1,103 @@
+"""Seeded synthetic inputs of the benchmark / parity configurations.
+
+No dataset is available offline (the "Trump n51" example is a Google-Drive download,
+README.md:44-46), so the measured workload uses Gaussians initialised exactly the way the
+reference initialises them, random-init TimeNet weights of the reference architecture, and
+seeded random target images of the reference's shapes (51 motions x 9 views x 21 frames).
+"""
+import math
+
+import numpy as np
+import torch
+from torch import nn
+
+from .gaussian_model import RGB2SH, inverse_sigmoid
+
+
+def ball_points(n, radius, rng):
+    """Uniform in a ball: r = R cbrt(u), theta = arccos(2u-1), phi = 2 pi u (latent_gs_renderer.py:999-1007)."""
+    phis = rng.random(n) * 2 * np.pi
+    costheta = rng.random(n) * 2 - 1
+    thetas = np.arccos(costheta)
+    r = radius * np.cbrt(rng.random(n))
+    return np.stack((r * np.sin(thetas) * np.cos(phis), r * np.sin(thetas) * np.sin(phis), r * np.cos(thetas)), 1)
+
+
+def init_synthetic_model(renderer, num_pts, num_cpts, seed=0, regime="trained", num_latent=51):
+    """Fills renderer.gaussians with the SURVEY 8d synthetic state (stage-2 layout: Gaussians + control points)."""
+    g = renderer.gaussians
+    dev = g.device
+    rng = np.random.default_rng(seed)
+    tg = torch.Generator().manual_seed(seed)
+    xyz = torch.tensor(ball_points(num_pts, 0.5, rng), dtype=torch.float32, device=dev)
+    dist2 = torch.clamp_min(g._dist2(xyz), 1e-7)
+    scales = torch.log(torch.sqrt(dist2))[:, None].repeat(1, 3)
+    rots = torch.zeros(num_pts, 4)
+    rots[:, 0] = 1
+    rots = rots + 0.1 * torch.randn(num_pts, 4, generator=tg)
+    if regime == "init":
+        opac = inverse_sigmoid(0.05 * torch.ones(num_pts, 1))
+    else:  # "trained": logits U(-2, 4)
+        opac = torch.rand(num_pts, 1, generator=tg) * 6 - 2
+    f_dc = RGB2SH(torch.rand(num_pts, 1, 3, generator=tg))
+    k = (g.max_sh_degree + 1) ** 2
+    P = lambda t: nn.Parameter(t.to(dev).float().contiguous().requires_grad_(True))
+    g._xyz, g._scaling, g._rotation, g._opacity = P(xyz), P(scales), P(rots), P(opac)
+    g._features_dc, g._features_rest = P(f_dc), P(torch.zeros(num_pts, k - 1, 3))
+    g._c_xyz = P(torch.tensor(ball_points(num_cpts, 0.5, rng), dtype=torch.float32))
+    g._c_radius = P(scales.mean().cpu() * torch.ones(num_cpts, 1))
+    g._r = torch.empty(0, device=dev)
+    g.max_radii2D = torch.zeros(num_pts, device=dev)
+    g.spatial_lr_scale = 1
+    with torch.no_grad():
+        torch.manual_seed(seed)
+        for m in g._timenet.modules():
+            if isinstance(m, nn.Linear):  # weights AND biases from the seed, so every DP replica starts identical
+                nn.init.xavier_uniform_(m.weight, gain=1)
+                bound = 1.0 / math.sqrt(m.in_features)
+                nn.init.uniform_(m.bias, -bound, bound)
+        g._timenet.pts_layers[-1].bias.zero_()
+        g._timenet.rot_layers[-1].bias.copy_(torch.tensor([1.0, 0.0, 0.0, 0.0]))
+        # the reference zero-inits the heads (no motion); use small random heads so deformation is non-trivial
+        g._timenet.pts_layers[-1].weight.normal_(0, 1e-2)
+        g._timenet.rot_layers[-1].weight.normal_(0, 1e-2)
+        lat = torch.randn(num_latent, g.latent_code_dim, generator=tg).to(dev)
+        if g.vae_latent:
+            g._mu, g._log_var = nn.Parameter(lat), nn.Parameter(torch.full_like(lat, -4.0))
+        else:
+            g._latent_codes = nn.Parameter(lat)
+    g.num_latent_code = num_latent
+    return g
+
+
+class SyntheticTargets:
+    """Device-resident target images / masks, generated on first use from (motion, view, frame)."""
+
+    def __init__(self, resolution, device, seed=0):
+        self.res, self.device, self.seed = resolution, device, seed
+        self._cache = {}
+        yy, xx = torch.meshgrid(torch.arange(resolution), torch.arange(resolution), indexing="ij")
+        c = (resolution - 1) / 2
+        self._disc = (((xx - c) ** 2 + (yy - c) ** 2) <= (0.4 * resolution) ** 2).float()[None].to(device)
+
+    def get(self, motion, view, frame):
+        key = (motion, view, frame)
+        t = self._cache.get(key)
+        if t is None:
+            gen = torch.Generator().manual_seed(self.seed * 1_000_003 + motion * 10_007 + view * 101 + frame)
+            img = torch.rand(3, self.res, self.res, generator=gen).to(self.device)
+            t = (img, self._disc)
+            self._cache[key] = t
+        return t
+
+
+def default_azimuths(num_views=9):
+    return [360.0 / num_views * i for i in range(num_views)]  # main_train_dimo.py:80
+
+
+def frame_times(num_frames=21):
+    return [f / num_frames for f in range(num_frames)]  # main_train_dimo.py:104
+
+
+def focal_pixels(resolution, fovy_deg=33.9):
+    return resolution / (2 * math.tan(math.radians(fovy_deg) / 2))

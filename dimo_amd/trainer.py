@@ -1,0 +1,199 @@
+"""One training step of DIMO's motion-latent stage, sharded over (motion, view, frame).
+
+Mirrors `GUI.train_step` (main_train_dimo.py:221-451): learning-rate update, KNN of every Gaussian among
+the control points (stage s2), sampling of motions x views x frames, one `Renderer.render` per triple,
+per-motion image losses (weighted MSE, SSIM, mask MSE, edge-aware depth smoothness, bilateral normal
+smoothness), ONE backward, Adam (eps 1e-15), gradient reset.  LPIPS (needs downloaded VGG weights), ARAP,
+the chamfer "GA" term and the VAE KL term are excluded and reported as excluded by bench.py.
+
+Data parallelism (new -- the reference is single-GPU): every rank holds a full replica, draws the SAME
+sample (shared seeds), renders its contiguous slice of the triples, and the flat gradient bucket
+(GaussianModel.flat_grads) is summed with one RCCL all-reduce before the identical Adam update.  The
+reference's batch loss is a SUM over renders/motions, so the reduction is SUM, not mean; per-motion
+mean-type terms are written per image with weight 1/(images per motion), which makes the loss
+independent of how the triples are split.
+"""
+import random
+from dataclasses import dataclass, field
+from typing import Callable, List, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .camera import CameraCache
+from .losses import compute_bilateral_normal_smoothness_loss, compute_edge_aware_smoothness_loss
+from .synth import SyntheticTargets, default_azimuths, frame_times
+
+
+@dataclass
+class TrainConfig:
+    """The hot-path-relevant keys of configs/train_config.yaml (same names, same defaults)."""
+    # scene
+    num_pts: int = 100000
+    num_cpts: int = 512
+    sh_degree: int = 0
+    latent_code_dim: int = 32
+    num_motions: int = 51
+    num_frames: int = 21
+    num_views: int = 9
+    vae_latent: bool = False
+    # sampling (the reference draws batch_size frames, batch_size views, min(2*batch_size, motions) motions)
+    motions_per_step: int = 4
+    views_per_step: int = 2
+    frames_per_step: int = 2
+    resolution: int = 512
+    # camera
+    radius: float = 2
+    fovy: float = 33.9
+    elevation: float = 0
+    # losses
+    lambda_mse: float = 5000.0
+    lambda_ssim: float = 500.0
+    lambda_mask: float = 500.0
+    add_depth: bool = True
+    lambda_smooth: float = 100.0
+    add_normal: bool = True
+    lambda_bilateral: float = 0.05
+    lambda_kl: float = 0.05
+    # optimizer
+    opacity_lr: float = 0.05
+    scaling_lr: float = 0.005
+    percent_dense: float = 0.01
+    position_lr_init: float = 0.01
+    position_lr_final: float = 0.0002
+    position_lr_delay_mult: float = 0.02
+    position_lr_max_steps: int = 1000
+    feature_lr: float = 0.01
+    rotation_lr: float = 0.005
+    c_radius_lr: float = 0.005
+    latent_code_lr_init: float = 0.005
+    latent_code_lr_final: float = 0.0002
+    deform_lr_init: float = 0.0002
+    deform_lr_final: float = 0.000002
+    c_position_lr_init: float = 0.000002
+    c_position_lr_final: float = 0.000002
+    c_position_lr_delay_mult: float = 0.02
+    r_lr: float = 0.01
+    seed: int = 0
+    stage: str = "s2"
+
+
+def enumerate_triples(motions, views, frames):
+    """The reference's loop order: motion outermost, then view, then frame (main_train_dimo.py:276-281)."""
+    return [(m, v, f) for m in motions for v in views for f in frames]
+
+
+def shard(items, rank, world):
+    """Contiguous slice of `items` for `rank` (sizes differ by at most one)."""
+    n = len(items)
+    lo, hi = (n * rank) // world, (n * (rank + 1)) // world
+    return items[lo:hi]
+
+
+class Trainer:
+    def __init__(self, cfg: TrainConfig, renderer, rank=0, world_size=1, process_group=None,
+                 ssim_fn: Optional[Callable] = None, knn_fn: Optional[Callable] = None, targets=None):
+        self.cfg, self.renderer = cfg, renderer
+        self.rank, self.world, self.pg = rank, world_size, process_group
+        self.device = renderer.device
+        self.step = 0
+        self.stage = cfg.stage
+        if ssim_fn is None:
+            from .fused_ssim import ssim as ssim_fn  # HIP, GPU only
+        if knn_fn is None:
+            from .knn_cuda import knn_points as knn_fn  # HIP, GPU only
+        self.ssim, self.knn = ssim_fn, knn_fn
+        self.cams = CameraCache(fovy_deg=cfg.fovy, device=self.device)
+        self.azimuths = default_azimuths(cfg.num_views)
+        self.source_time = frame_times(cfg.num_frames)
+        self.targets = targets or SyntheticTargets(cfg.resolution, self.device, seed=cfg.seed)
+        # rank-identical sampling: all three RNGs the reference uses are seeded (it leaves `random` unseeded)
+        self._py_rng = random.Random(cfg.seed)
+        self._np_rng = np.random.default_rng(cfg.seed)
+        renderer.gaussians.training_setup(cfg)
+        self.optimizer = renderer.gaussians.optimizer
+        self.last_loss = None
+
+    # ------------------------------------------------------------------ pieces of train_step
+    def find_knn(self, k=4):
+        g = self.renderer.gaussians
+        d, i = self.knn(g._c_xyz.detach(), g._xyz.detach(), k)
+        g.neighbor_dists, g.neighbor_indices = d, i
+
+    def sample(self) -> List[Tuple[int, int, int]]:
+        c = self.cfg
+        frames = self._py_rng.sample(range(c.num_frames), c.frames_per_step)
+        views = self._py_rng.sample(range(c.num_views), c.views_per_step)
+        motions = self._np_rng.choice(c.num_motions, min(c.motions_per_step, c.num_motions), replace=False)
+        return enumerate_triples([int(m) for m in motions], views, frames)
+
+    def render_triple(self, m, v, f):
+        c = self.cfg
+        cam = self.cams.get(c.elevation, self.azimuths[v], c.radius, c.resolution, c.resolution)
+        return self.renderer.render(cam, time=self.source_time[f], stage=self.stage, latent_index=m)
+
+    def motion_loss(self, outs, gts, masks, weights, n_img):
+        """Loss of one motion's local images; mean-type terms carry the share len(outs)/n_img."""
+        c = self.cfg
+        img = torch.stack([o["image"] for o in outs])
+        gt = torch.stack(gts)
+        share = len(outs) / n_img
+        w = torch.tensor(weights, dtype=img.dtype, device=img.device)
+        per_img_mse = ((img - gt) ** 2).mean(dim=(1, 2, 3))
+        loss = c.lambda_mse * (w * per_img_mse).sum()
+        loss = loss + c.lambda_ssim * share * (1 - self.ssim(img, gt))
+        alpha = torch.stack([o["alpha"] for o in outs])
+        loss = loss + c.lambda_mask * share * ((alpha - torch.stack(masks)) ** 2).mean()
+        img_hwc = img.permute(0, 2, 3, 1)
+        if c.add_depth:
+            depth = torch.stack([o["depth"] for o in outs]).permute(0, 2, 3, 1)
+            loss = loss + c.lambda_smooth * share * compute_edge_aware_smoothness_loss(depth, img_hwc)
+        if c.add_normal:
+            normal = torch.stack([o["normal"] for o in outs]).permute(0, 2, 3, 1)
+            loss = loss + c.lambda_bilateral * share * compute_bilateral_normal_smoothness_loss(normal, img_hwc)
+        return loss
+
+    def all_reduce_grads(self):
+        if self.world > 1:
+            dist.all_reduce(self.renderer.gaussians.flat_grads, op=dist.ReduceOp.SUM, group=self.pg)
+
+    # ------------------------------------------------------------------ the step
+    def train_step(self, triples=None):
+        """Runs one optimisation step; returns the number of renders THIS rank performed."""
+        c, g = self.cfg, self.renderer.gaussians
+        self.step += 1
+        g.update_learning_rate(self.step, self.stage)
+        if self.stage >= "s2":
+            self.find_knn(k=4)
+        if triples is None:
+            triples = self.sample()
+        mine = shard(triples, self.rank, self.world)
+        n_img = max(1, len(triples) // max(1, len({t[0] for t in triples})))  # images per motion (b^2)
+        ref_view, ref_frame = 0, 0
+
+        loss = None
+        by_motion = {}
+        for (m, v, f) in mine:
+            out = self.render_triple(m, v, f)
+            gt, mask = self.targets.get(m, v, f)
+            w = 1.0 if (v == ref_view or f == ref_frame) else 0.5  # reference view / frame weighting
+            rec = by_motion.setdefault(m, ([], [], [], []))
+            rec[0].append(out), rec[1].append(gt), rec[2].append(mask), rec[3].append(w)
+        for m, (outs, gts, masks, ws) in by_motion.items():
+            lm = self.motion_loss(outs, gts, masks, ws, n_img)
+            if g.vae_latent:
+                mu, lv = g._mu[m], g._log_var[m]
+                lm = lm + c.lambda_kl * (-0.5 * torch.sum(1 + lv - mu.pow(2) - lv.exp()))
+            loss = lm if loss is None else loss + lm
+        if loss is not None:
+            loss.backward()
+        cap = self.renderer.capacity
+        if cap is not None and not cap.check():  # the step's only host sync; parameters are still untouched
+            g.zero_grad()
+            raise RuntimeError("instance capacity overflow: CapacityPolicy grew its bound, redo the step")
+        self.all_reduce_grads()
+        self.optimizer.step()
+        g.zero_grad()
+        self.last_loss = loss.detach() if loss is not None else None
+        return len(mine)

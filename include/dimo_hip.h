@@ -42,6 +42,15 @@ extern "C" {
 /* library / build identification: returns "dimo_hip gfx950 <version>" */
 const char *dimo_version(void);
 
+/* Optional kernel timing (the library's only process-global state; off by default).
+ * While enabled, every instrumented kernel group is bracketed by a hipEvent pair recorded on the
+ * stream it is launched on.  dimo_timing_read synchronises the device and returns the summed
+ * duration and launch count of one group: "preprocess_fwd" "scan" "emit" "sort" "ranges" "blend_fwd"
+ * "blend_bwd" "preprocess_bwd" "knn" "dist2" "ssim_fwd" "ssim_bwd".
+ * dimo_timing_enable(1) clears earlier records; returns the previous state. */
+int dimo_timing_enable(int on);
+int dimo_timing_read(const char *name, double *total_ms, int64_t *launches);
+
 /* ------------------------------------------------------------------ rasterizer workspaces
  * geom : per-Gaussian state written by preprocess (splat records, tile rects, tiles_touched,
  *        offsets, flags, block sums).  Needed by backward.
