@@ -61,11 +61,13 @@ def read_timing():
     return out
 
 
-def cpu_baseline(num_pts, resolution, renders=2):
+def cpu_baseline(num_pts, resolution, renders=4):
     """Same train step on the host cores: product host logic + CPU oracle kernels (kind 'port')."""
     from dimo_amd.trainer import TrainConfig
     from tests.cpu_backend import make_cpu_trainer
-    cores = os.cpu_count() or 1
+    # 16 threads: beyond that the small torch-CPU ops and the OpenMP rows of the oracle stop scaling
+    # (a 256-thread run on the GPU node's host was 35x SLOWER than 8 threads)
+    cores = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(cores)
     cfg = TrainConfig(num_pts=num_pts, resolution=resolution, motions_per_step=1, views_per_step=1,
                       frames_per_step=renders)

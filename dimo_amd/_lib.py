@@ -17,6 +17,7 @@ c_ptr = C.c_void_p
 # name -> (restype, argtypes).  Mirrors include/dimo_hip.h one to one.
 _SIGNATURES = {
     "dimo_version": (C.c_char_p, []),
+    "dimo_last_error": (C.c_char_p, []),
     "dimo_timing_enable": (C.c_int, [C.c_int]),
     "dimo_timing_read": (C.c_int, [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "dimo_raster_geom_bytes": (C.c_size_t, [C.c_int]),
@@ -35,6 +36,10 @@ _SIGNATURES = {
                              + [c_ptr, C.c_size_t, c_ptr]),
     "dimo_knn": (C.c_int, [C.c_int, C.c_int, C.c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     "dimo_dist2": (C.c_int, [C.c_int, c_ptr, c_ptr, c_ptr]),
+    "dimo_deform_max_ctrl_points": (C.c_int, []),
+    "dimo_deform_backward_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "dimo_deform_forward": (C.c_int, [C.c_int] * 3 + [c_ptr] * 15),
+    "dimo_deform_backward": (C.c_int, [C.c_int] * 3 + [c_ptr] * 22 + [c_ptr, C.c_size_t, c_ptr]),
     "dimo_ssim_forward": (C.c_int, [C.c_int] * 4 + [c_ptr] * 5),
     "dimo_ssim_backward": (C.c_int, [C.c_int] * 4 + [c_ptr] * 6),
 }
@@ -55,6 +60,9 @@ def lib():
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build it with `python -m dimo_amd.csrc.build` "
                 "(hipcc --offload-arch=gfx950). There is no CPU fallback in the product path.")
+        # torch first: its bundled libamdhip64 must be THE HIP runtime of the process; loading ours before
+        # it would pull /opt/rocm's copy in as a second runtime (observed: hipErrorNoDevice on every launch)
+        import torch  # noqa: F401
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError if the symbol is not exported
@@ -66,7 +74,10 @@ def lib():
 
 def check(rc, what):
     if rc != 0:
-        raise RuntimeError(f"{what} failed: {ERRORS.get(rc, rc)}")
+        detail = ""
+        if rc == -2 and _lib is not None:
+            detail = ": " + _lib.dimo_last_error().decode(errors="replace")
+        raise RuntimeError(f"{what} failed: {ERRORS.get(rc, rc)}{detail}")
 
 
 def ptr(t):

@@ -46,7 +46,8 @@ std::mutex g_mu;
 bool g_on = false;
 std::vector<Rec> g_recs;
 const char *const g_names[TIMED_COUNT] = {"preprocess_fwd", "scan", "emit",     "sort",     "ranges",  "blend_fwd",
-                                          "blend_bwd",      "preprocess_bwd", "knn", "dist2", "ssim_fwd", "ssim_bwd"};
+                                          "blend_bwd",      "preprocess_bwd", "knn", "dist2", "ssim_fwd", "ssim_bwd",
+                                          "deform_fwd",     "deform_bwd", "image_loss"};
 }  // namespace
 
 ScopedTimer::ScopedTimer(int id, hipStream_t s) : id_(id), stream_(s), a_(nullptr), b_(nullptr) {
@@ -56,11 +57,11 @@ ScopedTimer::ScopedTimer(int id, hipStream_t s) : id_(id), stream_(s), a_(nullpt
     a_ = b_ = nullptr;
     return;
   }
-  hipEventRecord(a_, stream_);
+  (void)hipEventRecord(a_, stream_);
 }
 ScopedTimer::~ScopedTimer() {
   if (!a_) return;
-  hipEventRecord(b_, stream_);
+  (void)hipEventRecord(b_, stream_);
   std::lock_guard<std::mutex> lk(g_mu);
   g_recs.push_back({id_, a_, b_});
 }
@@ -70,7 +71,7 @@ extern "C" int dimo_timing_enable(int on) {
   std::lock_guard<std::mutex> lk(g_mu);
   const int prev = g_on ? 1 : 0;
   if (on && !g_on) {
-    for (auto &r : g_recs) hipEventDestroy(r.a), hipEventDestroy(r.b);
+    for (auto &r : g_recs) (void)hipEventDestroy(r.a), (void)hipEventDestroy(r.b);
     g_recs.clear();
   }
   g_on = on != 0;
@@ -95,3 +96,15 @@ extern "C" int dimo_timing_read(const char *name, double *total_ms, int64_t *lau
   *total_ms = tot, *launches = n;
   return DIMO_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+namespace dimo {
+namespace {
+thread_local char g_last_error[256] = "";
+}
+void set_last_error(hipError_t e, const char *where) {
+  snprintf(g_last_error, sizeof(g_last_error), "%s (%d) at %s", hipGetErrorString(e), (int)e, where);
+}
+}  // namespace dimo
+
+extern "C" const char *dimo_last_error(void) { return dimo::g_last_error; }

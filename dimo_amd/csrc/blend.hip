@@ -254,6 +254,7 @@ extern "C" int dimo_raster_render_forward(int N, int H, int W, int64_t R_cap, co
                                           void *bin, size_t bin_bytes, void *img, size_t img_bytes, float *out_color,
                                           float *out_depth, float *out_normal, float *out_alpha, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  clear_errors();
   if (N < 0 || H <= 0 || W <= 0 || R_cap < 0 || R_cap > 0xfffffff0LL) return DIMO_E_ARG;
   if (!bg || !geom || !bin || !img || !out_color || !out_depth || !out_alpha) return DIMO_E_ARG;
   GeomLayout G(N);
@@ -293,6 +294,7 @@ extern "C" int dimo_raster_backward(int N, int sh_degree, int M, int H, int W, i
                                     float *dL_dcolors, float *dL_dopacity, float *dL_dscales, float *dL_drotations,
                                     float *dL_dcov3D, void *scratch, size_t scratch_bytes, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  clear_errors();
   (void)opacities;
   if (N < 0 || H <= 0 || W <= 0 || R_cap < 0 || R_cap > 0xfffffff0LL) return DIMO_E_ARG;
   if (!geom || !bin || !img || !bg || !scratch || !viewmatrix || !projmatrix || !campos) return DIMO_E_ARG;

@@ -112,7 +112,18 @@ __host__ __device__ inline const T *at(const void *base, size_t off) {
   return reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + off);
 }
 
-inline int check_launch() { return hipGetLastError() == hipSuccess ? DIMO_OK : DIMO_E_LAUNCH; }
+void set_last_error(hipError_t e, const char *where);  // api.hip; text retrievable with dimo_last_error()
+#define check_launch() ::dimo::check_launch_at(__FILE__ ":" DIMO_STR(__LINE__))
+#define DIMO_STR2(x) #x
+#define DIMO_STR(x) DIMO_STR2(x)
+inline int check_launch_at(const char *where) {
+  const hipError_t e = hipGetLastError();
+  if (e == hipSuccess) return DIMO_OK;
+  set_last_error(e, where);
+  return DIMO_E_LAUNCH;
+}
+// drop a stale (sticky) error left by another user of the HIP runtime in this thread, e.g. PyTorch
+inline void clear_errors() { (void)hipGetLastError(); }
 
 // number of key bits the sort must cover: 32 depth bits + bits of the tile id
 inline int key_bits(int T) {
@@ -124,7 +135,7 @@ inline int key_bits(int T) {
 // ---- optional HIP-event timing of kernel groups (off by default; see api.hip) ------------------
 enum TimedKernel {
   T_PREPROCESS_FWD = 0, T_SCAN, T_EMIT, T_SORT, T_RANGES, T_BLEND_FWD, T_BLEND_BWD, T_PREPROCESS_BWD, T_KNN, T_DIST2,
-  T_SSIM_FWD, T_SSIM_BWD, TIMED_COUNT
+  T_SSIM_FWD, T_SSIM_BWD, T_DEFORM_FWD, T_DEFORM_BWD, T_LOSS, TIMED_COUNT
 };
 class ScopedTimer {
  public:

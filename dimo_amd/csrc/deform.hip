@@ -1,0 +1,351 @@
+// Fused skinning stage of Renderer.render (stage s2): LBS weights, per-neighbour rotation, blend of the
+// k = 4 control-point transforms, quaternion product, normalisation and the exp / sigmoid activations --
+// renderer/latent_gs_renderer.py:1187-1219 -- as ONE streaming kernel forward and one backward.
+//
+// The reference (and a literal PyTorch restatement) runs this as ~25 eager kernels per direction, including
+// a batched 3x3 matmul over N*4 tiny matrices and index_put scatter-adds into the 512 control points
+// (measured on MI355X: 15 ms of the 19 ms a render took).  Here every Gaussian is one thread; the control
+// point table (M rows x 11 floats) lives in LDS for the gathers, and the backward accumulates the
+// control-point gradients in per-workgroup LDS (ds_add_f32), writes one partial table per workgroup and a
+// second tiny kernel sums the partials in a fixed order: no global atomics, deterministic.
+#include "common.hpp"
+
+namespace dimo {
+
+constexpr int DEF_BLOCK = 256;
+constexpr int DEF_K = 4;          // neighbours per Gaussian (find_knn k=4, main_train_dimo.py:257)
+constexpr int CP_STRIDE = 11;     // per control point: c(3) lr(1)->r dc(3) dq(4)   |  grads: gc(3) glr(1) gdc(3) gdq(4)
+constexpr float LBS_EPS = 1e-7f;
+constexpr float NORM_EPS = 1e-12f;
+
+struct CtrlTable {
+  const float *c_xyz;     // [M,3]
+  const float *c_lr;      // [M]   log radius (_c_radius)
+  const float *d_xyz;     // [M,3] TimeNet translation
+  const float *d_rot;     // [M,4] TimeNet quaternion (w,x,y,z), not normalised
+};
+
+__device__ __forceinline__ void load_ctrl_to_lds(const CtrlTable &t, int M, float *s) {
+  for (int j = threadIdx.x; j < M; j += blockDim.x) {
+    float *r = s + j * CP_STRIDE;
+    r[0] = t.c_xyz[3 * j], r[1] = t.c_xyz[3 * j + 1], r[2] = t.c_xyz[3 * j + 2];
+    r[3] = __expf(t.c_lr[j]);
+    r[4] = t.d_xyz[3 * j], r[5] = t.d_xyz[3 * j + 1], r[6] = t.d_xyz[3 * j + 2];
+    r[7] = t.d_rot[4 * j], r[8] = t.d_rot[4 * j + 1], r[9] = t.d_rot[4 * j + 2], r[10] = t.d_rot[4 * j + 3];
+  }
+}
+
+__device__ __forceinline__ void quat_R(float w, float x, float y, float z, float *R) {
+  R[0] = 1.f - 2.f * (y * y + z * z), R[1] = 2.f * (x * y - w * z), R[2] = 2.f * (x * z + w * y);
+  R[3] = 2.f * (x * y + w * z), R[4] = 1.f - 2.f * (x * x + z * z), R[5] = 2.f * (y * z - w * x);
+  R[6] = 2.f * (x * z - w * y), R[7] = 2.f * (y * z + w * x), R[8] = 1.f - 2.f * (x * x + y * y);
+}
+
+struct GaussIO {
+  const float *xyz, *rot, *scaling, *opacity;   // [N,3] [N,4] [N,3] [N]  (raw parameters)
+  const float *nn_dist;                         // [N,4]
+  const int64_t *nn_idx;                        // [N,4]
+};
+
+template <bool LOCAL_FRAME>
+__global__ void __launch_bounds__(DEF_BLOCK) lbs_fwd_kernel(int N, int M, GaussIO g, CtrlTable t,
+                                                            float *__restrict__ out_xyz, float *__restrict__ out_rot,
+                                                            float *__restrict__ out_scales,
+                                                            float *__restrict__ out_opacity) {
+  extern __shared__ __attribute__((aligned(16))) float s_cp[];
+  load_ctrl_to_lds(t, M, s_cp);
+  __syncthreads();
+  for (int i = blockIdx.x * DEF_BLOCK + threadIdx.x; i < N; i += gridDim.x * DEF_BLOCK) {
+    const float x0 = g.xyz[3 * i], x1 = g.xyz[3 * i + 1], x2 = g.xyz[3 * i + 2];
+    const float4 q0 = *reinterpret_cast<const float4 *>(g.rot + 4 * (size_t)i);
+    const float4 dd = *reinterpret_cast<const float4 *>(g.nn_dist + 4 * (size_t)i);
+    const float dist[DEF_K] = {dd.x, dd.y, dd.z, dd.w};
+    float wt[DEF_K], W = 0.f;
+    int idx[DEF_K];
+#pragma unroll
+    for (int k = 0; k < DEF_K; ++k) {
+      idx[k] = (int)g.nn_idx[4 * (size_t)i + k];
+      const float r = s_cp[idx[k] * CP_STRIDE + 3];
+      wt[k] = __expf(-1.0f * dist[k] * dist[k] / (2.0f * (r * r))) + LBS_EPS;
+      W += wt[k];
+    }
+    const float invW = 1.0f / fmaxf(W, NORM_EPS);
+    float p0 = 0.f, p1 = 0.f, p2 = 0.f, sw = 0.f, sx = 0.f, sy = 0.f, sz = 0.f;
+#pragma unroll
+    for (int k = 0; k < DEF_K; ++k) {
+      const float *cp = s_cp + idx[k] * CP_STRIDE;
+      const float w = wt[k] * invW;
+      const float qw = cp[7], qx = cp[8], qy = cp[9], qz = cp[10];
+      if (LOCAL_FRAME) {
+        const float inv = 1.0f / sqrtf(qw * qw + qx * qx + qy * qy + qz * qz);
+        float R[9];
+        quat_R(qw * inv, qx * inv, qy * inv, qz * inv, R);
+        const float l0 = x0 - cp[0], l1 = x1 - cp[1], l2 = x2 - cp[2];
+        p0 += w * (R[0] * l0 + R[1] * l1 + R[2] * l2 + cp[0] + cp[4]);
+        p1 += w * (R[3] * l0 + R[4] * l1 + R[5] * l2 + cp[1] + cp[5]);
+        p2 += w * (R[6] * l0 + R[7] * l1 + R[8] * l2 + cp[2] + cp[6]);
+      } else {
+        p0 += w * cp[4], p1 += w * cp[5], p2 += w * cp[6];
+      }
+      sw += w * qw, sx += w * qx, sy += w * qy, sz += w * qz;
+    }
+    if (!LOCAL_FRAME) p0 += x0, p1 += x1, p2 += x2;
+    // q1 = qs (x) q0, then unit-normalise
+    const float aw = sw, ax = sx, ay = sy, az = sz, bw = q0.x, bx = q0.y, by = q0.z, bz = q0.w;
+    const float ow = aw * bw - ax * bx - ay * by - az * bz;
+    const float ox = aw * bx + ax * bw + ay * bz - az * by;
+    const float oy = aw * by - ax * bz + ay * bw + az * bx;
+    const float oz = aw * bz + ax * by - ay * bx + az * bw;
+    const float inv_n = 1.0f / fmaxf(sqrtf(ow * ow + ox * ox + oy * oy + oz * oz), NORM_EPS);
+    out_xyz[3 * i] = p0, out_xyz[3 * i + 1] = p1, out_xyz[3 * i + 2] = p2;
+    *reinterpret_cast<float4 *>(out_rot + 4 * (size_t)i) = make_float4(ow * inv_n, ox * inv_n, oy * inv_n, oz * inv_n);
+    out_scales[3 * i] = __expf(g.scaling[3 * i]);
+    out_scales[3 * i + 1] = __expf(g.scaling[3 * i + 1]);
+    out_scales[3 * i + 2] = __expf(g.scaling[3 * i + 2]);
+    out_opacity[i] = 1.0f / (1.0f + __expf(-g.opacity[i]));
+  }
+}
+
+template <bool LOCAL_FRAME>
+__global__ void __launch_bounds__(DEF_BLOCK) lbs_bwd_kernel(
+    int N, int M, GaussIO g, CtrlTable t, const float *__restrict__ g_xyz, const float *__restrict__ g_rot,
+    const float *__restrict__ g_scales, const float *__restrict__ g_opacity, float *__restrict__ d_xyz_out,
+    float *__restrict__ d_rot_out, float *__restrict__ d_scaling_out, float *__restrict__ d_opacity_out,
+    float *__restrict__ partials /* [gridDim.x][M][CP_STRIDE] */) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *s_cp = smem;                    // control-point table
+  float *s_acc = smem + M * CP_STRIDE;   // control-point gradient accumulators
+  load_ctrl_to_lds(t, M, s_cp);
+  for (int j = threadIdx.x; j < M * CP_STRIDE; j += blockDim.x) s_acc[j] = 0.f;
+  __syncthreads();
+  for (int i = blockIdx.x * DEF_BLOCK + threadIdx.x; i < N; i += gridDim.x * DEF_BLOCK) {
+    const float x0 = g.xyz[3 * i], x1 = g.xyz[3 * i + 1], x2 = g.xyz[3 * i + 2];
+    const float4 q0 = *reinterpret_cast<const float4 *>(g.rot + 4 * (size_t)i);
+    const float4 dd = *reinterpret_cast<const float4 *>(g.nn_dist + 4 * (size_t)i);
+    const float dist[DEF_K] = {dd.x, dd.y, dd.z, dd.w};
+    float wt[DEF_K], ex[DEF_K], W = 0.f;
+    int idx[DEF_K];
+#pragma unroll
+    for (int k = 0; k < DEF_K; ++k) {
+      idx[k] = (int)g.nn_idx[4 * (size_t)i + k];
+      const float r = s_cp[idx[k] * CP_STRIDE + 3];
+      ex[k] = __expf(-1.0f * dist[k] * dist[k] / (2.0f * (r * r)));
+      wt[k] = ex[k] + LBS_EPS;
+      W += wt[k];
+    }
+    const float invW = 1.0f / fmaxf(W, NORM_EPS);
+    // recompute the blended quaternion
+    float sw = 0.f, sx = 0.f, sy = 0.f, sz = 0.f;
+#pragma unroll
+    for (int k = 0; k < DEF_K; ++k) {
+      const float *cp = s_cp + idx[k] * CP_STRIDE;
+      const float w = wt[k] * invW;
+      sw += w * cp[7], sx += w * cp[8], sy += w * cp[9], sz += w * cp[10];
+    }
+    const float bw = q0.x, bx = q0.y, by = q0.z, bz = q0.w;
+    const float ow = sw * bw - sx * bx - sy * by - sz * bz;
+    const float ox = sw * bx + sx * bw + sy * bz - sz * by;
+    const float oy = sw * by - sx * bz + sy * bw + sz * bx;
+    const float oz = sw * bz + sx * by - sy * bx + sz * bw;
+    const float nrm = fmaxf(sqrtf(ow * ow + ox * ox + oy * oy + oz * oz), NORM_EPS);
+    const float inv_n = 1.0f / nrm;
+    const float uw = ow * inv_n, ux = ox * inv_n, uy = oy * inv_n, uz = oz * inv_n;
+    // normalisation backward
+    const float4 go = *reinterpret_cast<const float4 *>(g_rot + 4 * (size_t)i);
+    const float dotg = uw * go.x + ux * go.y + uy * go.z + uz * go.w;
+    const float gw = (go.x - uw * dotg) * inv_n, gx = (go.y - ux * dotg) * inv_n;
+    const float gy = (go.z - uy * dotg) * inv_n, gz = (go.w - uz * dotg) * inv_n;
+    // quaternion product backward: a = blended (sw..), b = the Gaussian's own rotation
+    const float gaw = gw * bw + gx * bx + gy * by + gz * bz;
+    const float gax = -gw * bx + gx * bw - gy * bz + gz * by;
+    const float gay = -gw * by + gx * bz + gy * bw - gz * bx;
+    const float gaz = -gw * bz - gx * by + gy * bx + gz * bw;
+    const float gbw = gw * sw + gx * sx + gy * sy + gz * sz;
+    const float gbx = -gw * sx + gx * sw + gy * sz - gz * sy;
+    const float gby = -gw * sy - gx * sz + gy * sw + gz * sx;
+    const float gbz = -gw * sz + gx * sy - gy * sx + gz * sw;
+    *reinterpret_cast<float4 *>(d_rot_out + 4 * (size_t)i) = make_float4(gbw, gbx, gby, gbz);
+
+    const float gp0 = g_xyz[3 * i], gp1 = g_xyz[3 * i + 1], gp2 = g_xyz[3 * i + 2];
+    float dx0 = LOCAL_FRAME ? 0.f : gp0, dx1 = LOCAL_FRAME ? 0.f : gp1, dx2 = LOCAL_FRAME ? 0.f : gp2;
+    float gwk[DEF_K], sum_wg = 0.f;
+#pragma unroll
+    for (int k = 0; k < DEF_K; ++k) {
+      const float *cp = s_cp + idx[k] * CP_STRIDE;
+      float *ac = s_acc + idx[k] * CP_STRIDE;
+      const float w = wt[k] * invW;
+      const float qw = cp[7], qx = cp[8], qy = cp[9], qz = cp[10];
+      // d/d(dq) through the blended quaternion
+      float gq_w = w * gaw, gq_x = w * gax, gq_y = w * gay, gq_z = w * gaz;
+      float gwt = qw * gaw + qx * gax + qy * gay + qz * gaz;  // dL/dw_k
+      if (LOCAL_FRAME) {
+        const float qn = sqrtf(qw * qw + qx * qx + qy * qy + qz * qz), inv = 1.0f / qn;
+        const float r_ = qw * inv, x_ = qx * inv, y_ = qy * inv, z_ = qz * inv;
+        float R[9];
+        quat_R(r_, x_, y_, z_, R);
+        const float l0 = x0 - cp[0], l1 = x1 - cp[1], l2 = x2 - cp[2];
+        const float y0 = R[0] * l0 + R[1] * l1 + R[2] * l2 + cp[0] + cp[4];
+        const float y1 = R[3] * l0 + R[4] * l1 + R[5] * l2 + cp[1] + cp[5];
+        const float y2 = R[6] * l0 + R[7] * l1 + R[8] * l2 + cp[2] + cp[6];
+        gwt += y0 * gp0 + y1 * gp1 + y2 * gp2;
+        const float gy0 = w * gp0, gy1 = w * gp1, gy2 = w * gp2;  // dL/dy_k
+        // R^T gy
+        const float rt0 = R[0] * gy0 + R[3] * gy1 + R[6] * gy2;
+        const float rt1 = R[1] * gy0 + R[4] * gy1 + R[7] * gy2;
+        const float rt2 = R[2] * gy0 + R[5] * gy1 + R[8] * gy2;
+        dx0 += rt0, dx1 += rt1, dx2 += rt2;
+        atomicAdd(ac + 0, gy0 - rt0), atomicAdd(ac + 1, gy1 - rt1), atomicAdd(ac + 2, gy2 - rt2);
+        atomicAdd(ac + 4, gy0), atomicAdd(ac + 5, gy1), atomicAdd(ac + 6, gy2);
+        // dL/dR = gy (x - c)^T  -> unit quaternion -> raw quaternion
+        const float d00 = gy0 * l0, d01 = gy0 * l1, d02 = gy0 * l2;
+        const float d10 = gy1 * l0, d11 = gy1 * l1, d12 = gy1 * l2;
+        const float d20 = gy2 * l0, d21 = gy2 * l1, d22 = gy2 * l2;
+        const float gur = 2.f * (-z_ * d01 + y_ * d02 + z_ * d10 - x_ * d12 - y_ * d20 + x_ * d21);
+        const float gux = 2.f * (y_ * d01 + z_ * d02 + y_ * d10 - 2.f * x_ * d11 - r_ * d12 + z_ * d20 + r_ * d21 -
+                                 2.f * x_ * d22);
+        const float guy = 2.f * (-2.f * y_ * d00 + x_ * d01 + r_ * d02 + x_ * d10 + z_ * d12 - r_ * d20 + z_ * d21 -
+                                 2.f * y_ * d22);
+        const float guz = 2.f * (-2.f * z_ * d00 - r_ * d01 + x_ * d02 + r_ * d10 - 2.f * z_ * d11 + y_ * d12 +
+                                 x_ * d20 + y_ * d21);
+        const float du = r_ * gur + x_ * gux + y_ * guy + z_ * guz;
+        gq_w += (gur - r_ * du) * inv, gq_x += (gux - x_ * du) * inv;
+        gq_y += (guy - y_ * du) * inv, gq_z += (guz - z_ * du) * inv;
+      } else {
+        gwt += cp[4] * gp0 + cp[5] * gp1 + cp[6] * gp2;
+        atomicAdd(ac + 4, w * gp0), atomicAdd(ac + 5, w * gp1), atomicAdd(ac + 6, w * gp2);
+      }
+      atomicAdd(ac + 7, gq_w), atomicAdd(ac + 8, gq_x), atomicAdd(ac + 9, gq_y), atomicAdd(ac + 10, gq_z);
+      gwk[k] = gwt;
+      sum_wg += w * gwt;
+    }
+    // L1 normalisation and radial weight backward -> log radius
+#pragma unroll
+    for (int k = 0; k < DEF_K; ++k) {
+      const float r = s_cp[idx[k] * CP_STRIDE + 3];
+      const float g_wt = (W > NORM_EPS) ? (gwk[k] - sum_wg) * invW : 0.f;
+      // wt = exp(-d^2/(2 r^2)) + eps ; d(wt)/dr = ex * d^2 / r^3 ; r = exp(lr) -> * r
+      const float g_lr = g_wt * ex[k] * dist[k] * dist[k] / (r * r);
+      atomicAdd(s_acc + idx[k] * CP_STRIDE + 3, g_lr);
+    }
+    d_xyz_out[3 * i] = dx0, d_xyz_out[3 * i + 1] = dx1, d_xyz_out[3 * i + 2] = dx2;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) d_scaling_out[3 * i + c] = g_scales[3 * i + c] * __expf(g.scaling[3 * i + c]);
+    const float o = 1.0f / (1.0f + __expf(-g.opacity[i]));
+    d_opacity_out[i] = g_opacity[i] * o * (1.0f - o);
+  }
+  __syncthreads();
+  float *dst = partials + (size_t)blockIdx.x * M * CP_STRIDE;
+  for (int j = threadIdx.x; j < M * CP_STRIDE; j += blockDim.x) dst[j] = s_acc[j];
+}
+
+// sums the per-workgroup partial tables in a fixed order and scatters into the four gradient tensors
+__global__ void __launch_bounds__(256) lbs_reduce_kernel(int M, int nblocks, const float *__restrict__ partials,
+                                                         float *__restrict__ d_c_xyz, float *__restrict__ d_c_lr,
+                                                         float *__restrict__ d_d_xyz, float *__restrict__ d_d_rot) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= M * CP_STRIDE) return;
+  float s = 0.f;
+  for (int b = 0; b < nblocks; ++b) s += partials[(size_t)b * M * CP_STRIDE + j];
+  const int m = j / CP_STRIDE, c = j % CP_STRIDE;
+  if (c < 3) d_c_xyz[3 * m + c] = s;
+  else if (c == 3) d_c_lr[m] = s;
+  else if (c < 7) d_d_xyz[3 * m + (c - 4)] = s;
+  else d_d_rot[4 * m + (c - 7)] = s;
+}
+
+// one workgroup per CU at most: the backward writes one partial control-point table per workgroup
+inline int deform_grid(int N) {
+  const int want = (N + DEF_BLOCK - 1) / DEF_BLOCK;
+  return want < 1 ? 1 : (want > 256 ? 256 : want);
+}
+
+// control-point tables larger than the default 64 KiB dynamic-LDS window need the opt-in attribute
+inline void allow_big_lds() {
+  static const bool once = [] {
+    const int lim = 160 * 1024;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(lbs_fwd_kernel<true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(lbs_fwd_kernel<false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(lbs_bwd_kernel<true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(lbs_bwd_kernel<false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+    return true;
+  }();
+  (void)once;
+}
+
+}  // namespace dimo
+
+using namespace dimo;
+
+extern "C" int dimo_deform_max_ctrl_points(void) { return (160 * 1024 / 2) / (CP_STRIDE * (int)sizeof(float)); }
+
+extern "C" size_t dimo_deform_backward_scratch_bytes(int N, int M) {
+  return align_up((size_t)deform_grid(N) * (size_t)(M > 0 ? M : 1) * CP_STRIDE * sizeof(float));
+}
+
+extern "C" int dimo_deform_forward(int N, int M, int local_frame, const float *xyz, const float *rotation,
+                                   const float *scaling, const float *opacity, const float *c_xyz,
+                                   const float *c_log_radius, const float *d_xyz, const float *d_rot,
+                                   const float *nn_dist, const int64_t *nn_idx, float *out_xyz, float *out_rot,
+                                   float *out_scales, float *out_opacity, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  clear_errors();
+  if (N < 0 || M <= 0 || M > dimo_deform_max_ctrl_points()) return DIMO_E_ARG;
+  if (N == 0) return DIMO_OK;
+  if (!xyz || !rotation || !scaling || !opacity || !c_xyz || !c_log_radius || !d_xyz || !d_rot || !nn_dist ||
+      !nn_idx || !out_xyz || !out_rot || !out_scales || !out_opacity)
+    return DIMO_E_ARG;
+  GaussIO g{xyz, rotation, scaling, opacity, nn_dist, nn_idx};
+  CtrlTable t{c_xyz, c_log_radius, d_xyz, d_rot};
+  const size_t lds = (size_t)M * CP_STRIDE * sizeof(float);
+  allow_big_lds();
+  ScopedTimer tm(T_DEFORM_FWD, stream);
+  if (local_frame)
+    hipLaunchKernelGGL(lbs_fwd_kernel<true>, dim3(deform_grid(N)), dim3(DEF_BLOCK), lds, stream, N, M, g, t, out_xyz,
+                       out_rot, out_scales, out_opacity);
+  else
+    hipLaunchKernelGGL(lbs_fwd_kernel<false>, dim3(deform_grid(N)), dim3(DEF_BLOCK), lds, stream, N, M, g, t, out_xyz,
+                       out_rot, out_scales, out_opacity);
+  return check_launch();
+}
+
+extern "C" int dimo_deform_backward(int N, int M, int local_frame, const float *xyz, const float *rotation,
+                                    const float *scaling, const float *opacity, const float *c_xyz,
+                                    const float *c_log_radius, const float *d_xyz, const float *d_rot,
+                                    const float *nn_dist, const int64_t *nn_idx, const float *g_out_xyz,
+                                    const float *g_out_rot, const float *g_out_scales, const float *g_out_opacity,
+                                    float *dL_dxyz, float *dL_drotation, float *dL_dscaling, float *dL_dopacity,
+                                    float *dL_dc_xyz, float *dL_dc_log_radius, float *dL_dd_xyz, float *dL_dd_rot,
+                                    void *scratch, size_t scratch_bytes, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  clear_errors();
+  if (N < 0 || M <= 0 || M > dimo_deform_max_ctrl_points()) return DIMO_E_ARG;
+  if (!dL_dc_xyz || !dL_dc_log_radius || !dL_dd_xyz || !dL_dd_rot || !scratch) return DIMO_E_ARG;
+  if (scratch_bytes < dimo_deform_backward_scratch_bytes(N, M)) return DIMO_E_WORKSPACE;
+  if (N > 0 && (!xyz || !rotation || !scaling || !opacity || !c_xyz || !c_log_radius || !d_xyz || !d_rot ||
+                !nn_dist || !nn_idx || !g_out_xyz || !g_out_rot || !g_out_scales || !g_out_opacity || !dL_dxyz ||
+                !dL_drotation || !dL_dscaling || !dL_dopacity))
+    return DIMO_E_ARG;
+  GaussIO g{xyz, rotation, scaling, opacity, nn_dist, nn_idx};
+  CtrlTable t{c_xyz, c_log_radius, d_xyz, d_rot};
+  const int grid = N > 0 ? deform_grid(N) : 0;
+  const size_t lds = 2 * (size_t)M * CP_STRIDE * sizeof(float);
+  allow_big_lds();
+  ScopedTimer tm(T_DEFORM_BWD, stream);
+  if (grid > 0) {
+    if (local_frame)
+      hipLaunchKernelGGL(lbs_bwd_kernel<true>, dim3(grid), dim3(DEF_BLOCK), lds, stream, N, M, g, t, g_out_xyz,
+                         g_out_rot, g_out_scales, g_out_opacity, dL_dxyz, dL_drotation, dL_dscaling, dL_dopacity,
+                         reinterpret_cast<float *>(scratch));
+    else
+      hipLaunchKernelGGL(lbs_bwd_kernel<false>, dim3(grid), dim3(DEF_BLOCK), lds, stream, N, M, g, t, g_out_xyz,
+                         g_out_rot, g_out_scales, g_out_opacity, dL_dxyz, dL_drotation, dL_dscaling, dL_dopacity,
+                         reinterpret_cast<float *>(scratch));
+  }
+  hipLaunchKernelGGL(lbs_reduce_kernel, dim3((M * CP_STRIDE + 255) / 256), dim3(256), 0, stream, M, grid,
+                     reinterpret_cast<const float *>(scratch), dL_dc_xyz, dL_dc_log_radius, dL_dd_xyz, dL_dd_rot);
+  return check_launch();
+}

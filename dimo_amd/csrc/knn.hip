@@ -95,6 +95,7 @@ using namespace dimo;
 extern "C" int dimo_knn(int M, int N, int k, const float *ref, const float *query, float *dist, int64_t *idx,
                         void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  clear_errors();
   if (M < 0 || N < 0 || k < 1 || k > 16) return DIMO_E_ARG;
   if (N == 0) return DIMO_OK;
   if (!query || !dist || !idx || (M > 0 && !ref)) return DIMO_E_ARG;
@@ -111,6 +112,7 @@ extern "C" int dimo_knn(int M, int N, int k, const float *ref, const float *quer
 
 extern "C" int dimo_dist2(int N, const float *points, float *out, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  clear_errors();
   if (N < 0) return DIMO_E_ARG;
   if (N == 0) return DIMO_OK;
   if (!points || !out) return DIMO_E_ARG;

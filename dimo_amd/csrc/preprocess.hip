@@ -494,6 +494,7 @@ extern "C" int dimo_raster_preprocess_forward(int N, int sh_degree, int M, int H
                                               float tanfovx, float tanfovy, int32_t *radii, void *geom,
                                               size_t geom_bytes, int64_t *R_host, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  clear_errors();
   if (N < 0 || H <= 0 || W <= 0 || !geom || !viewmatrix || !projmatrix || !campos) return DIMO_E_ARG;
   if (N > 0 && (shs == nullptr) == (colors_precomp == nullptr)) return DIMO_E_ARG;
   if (N > 0 && !cov3D_precomp && (!scales || !rotations)) return DIMO_E_ARG;

@@ -167,6 +167,7 @@ using namespace dimo;
 extern "C" int dimo_ssim_forward(int B, int C, int H, int W, const float *img1, const float *img2, float *ssim_sum,
                                  float *partials, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  clear_errors();
   if (B < 0 || C < 0 || H <= 0 || W <= 0 || !ssim_sum) return DIMO_E_ARG;
   if (hipMemsetAsync(ssim_sum, 0, sizeof(float), stream) != hipSuccess) return DIMO_E_LAUNCH;
   const long planes = (long)B * C;
@@ -183,6 +184,7 @@ extern "C" int dimo_ssim_forward(int B, int C, int H, int W, const float *img1, 
 extern "C" int dimo_ssim_backward(int B, int C, int H, int W, const float *img1, const float *img2,
                                   const float *partials, const float *dL_dmean, float *dL_dimg1, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  clear_errors();
   if (B < 0 || C < 0 || H <= 0 || W <= 0) return DIMO_E_ARG;
   const long planes = (long)B * C;
   if (planes == 0) return DIMO_OK;

@@ -116,6 +116,65 @@ def quat_mul(q1, q2):
         w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2], dim=-1)
 
 
+class _FusedSkinning(torch.autograd.Function):
+    """dimo_deform_forward / dimo_deform_backward (dimo_amd/csrc/deform.hip): the whole stage-s2 skinning
+    block plus the exp / sigmoid / normalize activations as one HIP kernel per direction."""
+
+    @staticmethod
+    def forward(ctx, xyz, rotation, scaling, opacity, c_xyz, c_log_radius, d_xyz, d_rot, nn_dist, nn_idx,
+                local_frame):
+        from . import _lib
+        L = _lib.lib()
+        c = lambda t: t.detach().float().contiguous()
+        xyz, rotation, scaling, opacity = c(xyz), c(rotation), c(scaling), c(opacity)
+        c_xyz, c_log_radius, d_xyz, d_rot = c(c_xyz), c(c_log_radius), c(d_xyz), c(d_rot)
+        nn_dist, nn_idx = c(nn_dist), nn_idx.contiguous()
+        N, M = xyz.shape[0], c_xyz.shape[0]
+        new = lambda *s: torch.empty(*s, dtype=torch.float32, device=xyz.device)
+        o_xyz, o_rot, o_scales, o_opac = new(N, 3), new(N, 4), new(N, 3), new(N, 1)
+        _lib.check(L.dimo_deform_forward(
+            N, M, int(bool(local_frame)), _lib.ptr(xyz), _lib.ptr(rotation), _lib.ptr(scaling), _lib.ptr(opacity),
+            _lib.ptr(c_xyz), _lib.ptr(c_log_radius), _lib.ptr(d_xyz), _lib.ptr(d_rot), _lib.ptr(nn_dist),
+            _lib.ptr(nn_idx), _lib.ptr(o_xyz), _lib.ptr(o_rot), _lib.ptr(o_scales), _lib.ptr(o_opac),
+            _lib.current_stream()), "dimo_deform_forward")
+        ctx.save_for_backward(xyz, rotation, scaling, opacity, c_xyz, c_log_radius, d_xyz, d_rot, nn_dist, nn_idx)
+        ctx.local_frame = bool(local_frame)
+        return o_xyz, o_rot, o_scales, o_opac
+
+    @staticmethod
+    def backward(ctx, g_xyz, g_rot, g_scales, g_opac):
+        from . import _lib
+        L = _lib.lib()
+        xyz, rotation, scaling, opacity, c_xyz, c_lr, d_xyz, d_rot, nn_dist, nn_idx = ctx.saved_tensors
+        N, M = xyz.shape[0], c_xyz.shape[0]
+        dev = xyz.device
+        z = lambda g, *s: (torch.zeros(*s, dtype=torch.float32, device=dev) if g is None else g.float().contiguous())
+        g_xyz, g_rot, g_scales, g_opac = z(g_xyz, N, 3), z(g_rot, N, 4), z(g_scales, N, 3), z(g_opac, N, 1)
+        new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        d = [new(N, 3), new(N, 4), new(N, 3), new(*opacity.shape), new(M, 3), new(*c_lr.shape), new(M, 3), new(M, 4)]
+        scratch = torch.empty(L.dimo_deform_backward_scratch_bytes(N, M), dtype=torch.uint8, device=dev)
+        _lib.check(L.dimo_deform_backward(
+            N, M, int(ctx.local_frame), _lib.ptr(xyz), _lib.ptr(rotation), _lib.ptr(scaling), _lib.ptr(opacity),
+            _lib.ptr(c_xyz), _lib.ptr(c_lr), _lib.ptr(d_xyz), _lib.ptr(d_rot), _lib.ptr(nn_dist), _lib.ptr(nn_idx),
+            _lib.ptr(g_xyz), _lib.ptr(g_rot), _lib.ptr(g_scales), _lib.ptr(g_opac), *[_lib.ptr(t) for t in d],
+            _lib.ptr(scratch), scratch.numel(), _lib.current_stream()), "dimo_deform_backward")
+        return (*d, None, None, None)
+
+
+def fused_skinning_available(xyz, c_xyz, nn_idx):
+    if not xyz.is_cuda or nn_idx is None or nn_idx.shape[-1] != 4:
+        return False
+    from . import _lib
+    return 0 < c_xyz.shape[0] <= _lib.lib().dimo_deform_max_ctrl_points()
+
+
+def fused_skinning(xyz, rotation, scaling, opacity, c_xyz, c_log_radius, d_xyz, d_rot, nn_dist, nn_idx,
+                   local_frame=True):
+    """(pts3D [N,3], unit rotations [N,4], exp(scaling) [N,3], sigmoid(opacity) [N,1]) on the GPU."""
+    return _FusedSkinning.apply(xyz, rotation, scaling, opacity, c_xyz, c_log_radius, d_xyz, d_rot, nn_dist, nn_idx,
+                                local_frame)
+
+
 def lbs_weights(neighbor_dists, c_radius_n, eps=1e-7):
     """w = L1-normalise(exp(-d^2 / (2 r^2)) + eps) over the k neighbours (latent_gs_renderer.py:1193-1199)."""
     w = torch.exp(-1.0 * neighbor_dists ** 2 / (2.0 * (c_radius_n[:, :, 0] ** 2))) + eps

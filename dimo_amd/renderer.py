@@ -16,7 +16,7 @@ import math
 import numpy as np
 import torch
 
-from .deform import lbs_deform
+from .deform import fused_skinning, fused_skinning_available, lbs_deform
 from .gaussian_model import BasicPointCloud, GaussianModel, SH2RGB
 
 
@@ -103,7 +103,10 @@ class Renderer:
     # ------------------------------------------------------------------ the hot path
     def render(self, viewpoint_camera, scaling_modifier=1.0, bg_color=None, override_color=None,
                compute_cov3D_python=False, convert_SHs_python=False, time=0.0, stage="s1", rot_as_res=True,
-               xyz_detach=False, local_frame=True, direct_deform=False, vertices_deform=None, latent_index=0):
+               xyz_detach=False, local_frame=True, direct_deform=False, vertices_deform=None, latent_index=0,
+               deform=None):
+        """`deform=(delta_xyz[M,3], delta_quat[M,4])` (extension): TimeNet outputs computed elsewhere, e.g. by
+        `Trainer` for all renders of a step in one batched MLP call; `time`/`latent_index` are then unused."""
         g = self.gaussians
         if compute_cov3D_python or convert_SHs_python:
             raise NotImplementedError("python-side covariance / SH conversion is not on DIMO's training path")
@@ -113,17 +116,32 @@ class Renderer:
         rasterizer = self._make_rasterizer(settings)
 
         means3D = g.get_xyz
-        opacity = g.get_opacity
-        latent_code = g.latent_code(latent_index)
-        scales = g.get_scaling
         rotations = g._rotation
+        use_fused = (stage >= "s2" and len(g._r) == 0
+                     and fused_skinning_available(means3D, g.get_c_xyz, g.neighbor_indices))
+        if not use_fused:  # the fused kernel applies exp / sigmoid itself
+            opacity = g.get_opacity
+            scales = g.get_scaling
+        latent_code = g.latent_code(latent_index) if deform is None else None
 
+        fused = False
         if stage >= "s2":
             c_means3D = g.get_c_xyz
-            means3D_deform, rots_deform = g._timenet(c_means3D, time, latent_code)
+            if deform is not None:  # batched TimeNet output handed in by the trainer
+                means3D_deform, rots_deform = deform
+            else:
+                means3D_deform, rots_deform = g._timenet(c_means3D, time, latent_code)
             cpts_t = c_means3D + means3D_deform
-            means3D, rotations = lbs_deform(means3D, rotations, c_means3D, g.get_c_radius(stage), means3D_deform,
-                                            rots_deform, g.neighbor_dists, g.neighbor_indices, local_frame)
+            if use_fused:
+                # one HIP kernel: skinning + quat product + normalize + exp/sigmoid activations
+                means3D, rotations, scales, opacity = fused_skinning(
+                    g._xyz, g._rotation, g._scaling, g._opacity, c_means3D, g._c_radius, means3D_deform, rots_deform,
+                    g.neighbor_dists, g.neighbor_indices, local_frame)
+                fused = True
+            else:
+                means3D, rotations = lbs_deform(means3D, rotations, c_means3D, g.get_c_radius(stage),
+                                                means3D_deform, rots_deform, g.neighbor_dists, g.neighbor_indices,
+                                                local_frame)
         elif stage == "s1":
             means3D_deform, _ = g._timenet(means3D, time, latent_code)
             cpts_t = means3D + means3D_deform
@@ -132,7 +150,8 @@ class Renderer:
             raise ValueError("Nonexistent stage!!!")
         if xyz_detach:
             means3D = means3D.detach()
-        rotations = g.rotation_activation(rotations)
+        if not fused:
+            rotations = g.rotation_activation(rotations)
 
         shs = colors_precomp = None
         if override_color is None:

@@ -128,10 +128,30 @@ class Trainer:
         motions = self._np_rng.choice(c.num_motions, min(c.motions_per_step, c.num_motions), replace=False)
         return enumerate_triples([int(m) for m in motions], views, frames)
 
-    def render_triple(self, m, v, f):
+    def render_triple(self, m, v, f, deform=None):
         c = self.cfg
         cam = self.cams.get(c.elevation, self.azimuths[v], c.radius, c.resolution, c.resolution)
-        return self.renderer.render(cam, time=self.source_time[f], stage=self.stage, latent_index=m)
+        return self.renderer.render(cam, time=self.source_time[f], stage=self.stage, latent_index=m, deform=deform)
+
+    def batched_deform(self, triples):
+        """TimeNet for all DISTINCT (motion, frame) pairs of the step in one MLP call (stage s2).
+
+        The reference evaluates the MLP once per render (M = 512 rows each: launch-bound, and views of the
+        same (motion, frame) repeat identical work); the control points, times and latents of a step are all
+        known up front, so one [pairs*M, 104] batch replaces 2b^3 small ones.  Returns {(m, f): (dxyz, dquat)}."""
+        g = self.renderer.gaussians
+        # VAE latents are re-sampled per render in the reference, so only the plain-latent flavour dedupes views
+        key = (lambda m, v, f: (m, v, f)) if g.vae_latent else (lambda m, v, f: (m, f))
+        pairs = list(dict.fromkeys(key(m, v, f) for (m, v, f) in triples))
+        if not pairs:
+            return {}
+        M = g._c_xyz.shape[0]
+        times = torch.tensor([self.source_time[p[-1]] for p in pairs], dtype=torch.float32, device=self.device)
+        times = times[:, None, None].expand(-1, M, 1)
+        lat = torch.stack([g.latent_code(p[0]) for p in pairs])[:, None, :].expand(-1, M, -1)
+        dxyz, dquat = g._timenet(g._c_xyz[None], times, lat, t_apply=True)
+        out = {p: (dxyz[i], dquat[i]) for i, p in enumerate(pairs)}
+        return {(m, v, f): out[key(m, v, f)] for (m, v, f) in triples}
 
     def motion_loss(self, outs, gts, masks, weights, n_img):
         """Loss of one motion's local images; mean-type terms carry the share len(outs)/n_img."""
@@ -174,8 +194,9 @@ class Trainer:
 
         loss = None
         by_motion = {}
+        deforms = self.batched_deform(mine) if self.stage >= "s2" else {}
         for (m, v, f) in mine:
-            out = self.render_triple(m, v, f)
+            out = self.render_triple(m, v, f, deform=deforms.get((m, v, f)))
             gt, mask = self.targets.get(m, v, f)
             w = 1.0 if (v == ref_view or f == ref_frame) else 0.5  # reference view / frame weighting
             rec = by_motion.setdefault(m, ([], [], [], []))

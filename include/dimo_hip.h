@@ -41,6 +41,8 @@ extern "C" {
 
 /* library / build identification: returns "dimo_hip gfx950 <version>" */
 const char *dimo_version(void);
+/* text of the calling thread's most recent DIMO_E_LAUNCH (HIP error string + source location) */
+const char *dimo_last_error(void);
 
 /* Optional kernel timing (the library's only process-global state; off by default).
  * While enabled, every instrumented kernel group is bracketed by a hipEvent pair recorded on the
@@ -137,6 +139,30 @@ int dimo_ssim_forward(int B, int C, int H, int W, const float *img1, const float
                       float *partials, void *stream);
 int dimo_ssim_backward(int B, int C, int H, int W, const float *img1, const float *img2, const float *partials,
                        const float *dL_dmean /* 1 float, device */, float *dL_dimg1, void *stream);
+
+/* ------------------------------------------------------------------ fused skinning (stage s2 of Renderer.render)
+ * One kernel for renderer/latent_gs_renderer.py:1187-1219: LBS weights w_k = L1norm(exp(-d_k^2/(2 r_k^2)) + 1e-7),
+ * out_xyz = sum_k w_k (R(dq_k/|dq_k|)(x - c_k) + c_k + dc_k)   (local_frame != 0; else x + sum_k w_k dc_k),
+ * out_rot = normalize(quat_mul(sum_k w_k dq_k, rotation)), out_scales = exp(scaling), out_opacity = sigmoid(opacity).
+ *   xyz[N,3] rotation[N,4] scaling[N,3] opacity[N]  : raw canonical-Gaussian parameters
+ *   c_xyz[M,3] c_log_radius[M] (= _c_radius)        : control points;  d_xyz[M,3] d_rot[M,4] : TimeNet outputs
+ *   nn_dist[N,4] nn_idx[N,4] (int64)                : dimo_knn results (k = 4)
+ * M <= dimo_deform_max_ctrl_points() (the control-point table and its gradient accumulators live in LDS).
+ * Backward writes (does not accumulate) all eight gradients; control-point gradients are reduced without
+ * global atomics in a fixed order (deterministic). scratch: dimo_deform_backward_scratch_bytes(N, M). */
+int dimo_deform_max_ctrl_points(void);
+size_t dimo_deform_backward_scratch_bytes(int N, int M);
+int dimo_deform_forward(int N, int M, int local_frame, const float *xyz, const float *rotation, const float *scaling,
+                        const float *opacity, const float *c_xyz, const float *c_log_radius, const float *d_xyz,
+                        const float *d_rot, const float *nn_dist, const int64_t *nn_idx, float *out_xyz,
+                        float *out_rot, float *out_scales, float *out_opacity, void *stream);
+int dimo_deform_backward(int N, int M, int local_frame, const float *xyz, const float *rotation,
+                         const float *scaling, const float *opacity, const float *c_xyz, const float *c_log_radius,
+                         const float *d_xyz, const float *d_rot, const float *nn_dist, const int64_t *nn_idx,
+                         const float *g_out_xyz, const float *g_out_rot, const float *g_out_scales,
+                         const float *g_out_opacity, float *dL_dxyz, float *dL_drotation, float *dL_dscaling,
+                         float *dL_dopacity, float *dL_dc_xyz, float *dL_dc_log_radius, float *dL_dd_xyz,
+                         float *dL_dd_rot, void *scratch, size_t scratch_bytes, void *stream);
 
 #ifdef __cplusplus
 }
