@@ -39,9 +39,11 @@ _SIGNATURES = {
     "dimo_deform_max_ctrl_points": (C.c_int, []),
     "dimo_deform_backward_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "dimo_deform_forward": (C.c_int, [C.c_int] * 3 + [c_ptr] * 15),
-    "dimo_deform_backward": (C.c_int, [C.c_int] * 3 + [c_ptr] * 22 + [c_ptr, C.c_size_t, c_ptr]),
-    "dimo_ssim_forward": (C.c_int, [C.c_int] * 4 + [c_ptr] * 5),
-    "dimo_ssim_backward": (C.c_int, [C.c_int] * 4 + [c_ptr] * 6),
+    "dimo_deform_backward": (C.c_int, [C.c_int] * 4 + [c_ptr] * 22 + [c_ptr, C.c_size_t, c_ptr]),
+    "dimo_ssim_forward": (C.c_int, [C.c_int] * 5 + [c_ptr] * 5),
+    "dimo_ssim_backward": (C.c_int, [C.c_int] * 5 + [c_ptr] * 6),
+    "dimo_image_loss": (C.c_int, [C.c_int] * 3 + [c_ptr] * 6 + [C.c_int, C.POINTER(C.c_float)] + [C.c_float] * 5
+                        + [c_ptr] * 7),
 }
 
 ERRORS = {-1: "DIMO_E_ARG (bad argument)", -2: "DIMO_E_LAUNCH (HIP launch/runtime error)",

@@ -21,6 +21,7 @@ SOURCES = {
     "knn.hip": ["-ffp-contract=off"],
     "ssim.hip": [],
     "deform.hip": [],
+    "image_loss.hip": [],
 }
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
 

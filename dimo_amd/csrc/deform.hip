@@ -106,7 +106,9 @@ __global__ void __launch_bounds__(DEF_BLOCK) lbs_fwd_kernel(int N, int M, GaussI
   }
 }
 
-template <bool LOCAL_FRAME>
+// ACC: add into the per-Gaussian outputs instead of overwriting them (a training step sums the gradients
+// of all its renders straight into the flat gradient bucket).
+template <bool LOCAL_FRAME, bool ACC>
 __global__ void __launch_bounds__(DEF_BLOCK) lbs_bwd_kernel(
     int N, int M, GaussIO g, CtrlTable t, const float *__restrict__ g_xyz, const float *__restrict__ g_rot,
     const float *__restrict__ g_scales, const float *__restrict__ g_opacity, float *__restrict__ d_xyz_out,
@@ -164,7 +166,15 @@ __global__ void __launch_bounds__(DEF_BLOCK) lbs_bwd_kernel(
     const float gbx = -gw * sx + gx * sw + gy * sz - gz * sy;
     const float gby = -gw * sy - gx * sz + gy * sw + gz * sx;
     const float gbz = -gw * sz + gx * sy - gy * sx + gz * sw;
-    *reinterpret_cast<float4 *>(d_rot_out + 4 * (size_t)i) = make_float4(gbw, gbx, gby, gbz);
+    {
+      float4 *dst = reinterpret_cast<float4 *>(d_rot_out + 4 * (size_t)i);
+      float4 v = make_float4(gbw, gbx, gby, gbz);
+      if (ACC) {
+        const float4 old = *dst;
+        v.x += old.x, v.y += old.y, v.z += old.z, v.w += old.w;
+      }
+      *dst = v;
+    }
 
     const float gp0 = g_xyz[3 * i], gp1 = g_xyz[3 * i + 1], gp2 = g_xyz[3 * i + 2];
     float dx0 = LOCAL_FRAME ? 0.f : gp0, dx1 = LOCAL_FRAME ? 0.f : gp1, dx2 = LOCAL_FRAME ? 0.f : gp2;
@@ -227,11 +237,16 @@ __global__ void __launch_bounds__(DEF_BLOCK) lbs_bwd_kernel(
       const float g_lr = g_wt * ex[k] * dist[k] * dist[k] / (r * r);
       atomicAdd(s_acc + idx[k] * CP_STRIDE + 3, g_lr);
     }
-    d_xyz_out[3 * i] = dx0, d_xyz_out[3 * i + 1] = dx1, d_xyz_out[3 * i + 2] = dx2;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) d_scaling_out[3 * i + c] = g_scales[3 * i + c] * __expf(g.scaling[3 * i + c]);
     const float o = 1.0f / (1.0f + __expf(-g.opacity[i]));
-    d_opacity_out[i] = g_opacity[i] * o * (1.0f - o);
+    const float gop = g_opacity[i] * o * (1.0f - o);
+    const float dxs[3] = {dx0, dx1, dx2};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float gs = g_scales[3 * i + c] * __expf(g.scaling[3 * i + c]);
+      d_xyz_out[3 * i + c] = ACC ? d_xyz_out[3 * i + c] + dxs[c] : dxs[c];
+      d_scaling_out[3 * i + c] = ACC ? d_scaling_out[3 * i + c] + gs : gs;
+    }
+    d_opacity_out[i] = ACC ? d_opacity_out[i] + gop : gop;
   }
   __syncthreads();
   float *dst = partials + (size_t)blockIdx.x * M * CP_STRIDE;
@@ -239,7 +254,8 @@ __global__ void __launch_bounds__(DEF_BLOCK) lbs_bwd_kernel(
 }
 
 // sums the per-workgroup partial tables in a fixed order and scatters into the four gradient tensors
-__global__ void __launch_bounds__(256) lbs_reduce_kernel(int M, int nblocks, const float *__restrict__ partials,
+__global__ void __launch_bounds__(256) lbs_reduce_kernel(int M, int nblocks, int accumulate,
+                                                         const float *__restrict__ partials,
                                                          float *__restrict__ d_c_xyz, float *__restrict__ d_c_lr,
                                                          float *__restrict__ d_d_xyz, float *__restrict__ d_d_rot) {
   const int j = blockIdx.x * 256 + threadIdx.x;
@@ -247,10 +263,12 @@ __global__ void __launch_bounds__(256) lbs_reduce_kernel(int M, int nblocks, con
   float s = 0.f;
   for (int b = 0; b < nblocks; ++b) s += partials[(size_t)b * M * CP_STRIDE + j];
   const int m = j / CP_STRIDE, c = j % CP_STRIDE;
-  if (c < 3) d_c_xyz[3 * m + c] = s;
-  else if (c == 3) d_c_lr[m] = s;
-  else if (c < 7) d_d_xyz[3 * m + (c - 4)] = s;
-  else d_d_rot[4 * m + (c - 7)] = s;
+  float *dst;
+  if (c < 3) dst = d_c_xyz + 3 * m + c;
+  else if (c == 3) dst = d_c_lr + m;
+  else if (c < 7) dst = d_d_xyz + 3 * m + (c - 4);
+  else dst = d_d_rot + 4 * m + (c - 7);
+  *dst = accumulate ? *dst + s : s;
 }
 
 // one workgroup per CU at most: the backward writes one partial control-point table per workgroup
@@ -267,9 +285,13 @@ inline void allow_big_lds() {
                               hipFuncAttributeMaxDynamicSharedMemorySize, lim);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(lbs_fwd_kernel<false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lim);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(lbs_bwd_kernel<true>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(lbs_bwd_kernel<true, false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lim);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(lbs_bwd_kernel<false>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(lbs_bwd_kernel<false, false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(lbs_bwd_kernel<true, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(lbs_bwd_kernel<false, true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lim);
     return true;
   }();
@@ -312,7 +334,8 @@ extern "C" int dimo_deform_forward(int N, int M, int local_frame, const float *x
   return check_launch();
 }
 
-extern "C" int dimo_deform_backward(int N, int M, int local_frame, const float *xyz, const float *rotation,
+extern "C" int dimo_deform_backward(int N, int M, int local_frame, int accumulate, const float *xyz,
+                                    const float *rotation,
                                     const float *scaling, const float *opacity, const float *c_xyz,
                                     const float *c_log_radius, const float *d_xyz, const float *d_rot,
                                     const float *nn_dist, const int64_t *nn_idx, const float *g_out_xyz,
@@ -336,16 +359,18 @@ extern "C" int dimo_deform_backward(int N, int M, int local_frame, const float *
   allow_big_lds();
   ScopedTimer tm(T_DEFORM_BWD, stream);
   if (grid > 0) {
-    if (local_frame)
-      hipLaunchKernelGGL(lbs_bwd_kernel<true>, dim3(grid), dim3(DEF_BLOCK), lds, stream, N, M, g, t, g_out_xyz,
-                         g_out_rot, g_out_scales, g_out_opacity, dL_dxyz, dL_drotation, dL_dscaling, dL_dopacity,
-                         reinterpret_cast<float *>(scratch));
-    else
-      hipLaunchKernelGGL(lbs_bwd_kernel<false>, dim3(grid), dim3(DEF_BLOCK), lds, stream, N, M, g, t, g_out_xyz,
-                         g_out_rot, g_out_scales, g_out_opacity, dL_dxyz, dL_drotation, dL_dscaling, dL_dopacity,
-                         reinterpret_cast<float *>(scratch));
+#define DIMO_LAUNCH_LBS_BWD(LF, AC)                                                                              \
+  hipLaunchKernelGGL((lbs_bwd_kernel<LF, AC>), dim3(grid), dim3(DEF_BLOCK), lds, stream, N, M, g, t, g_out_xyz, \
+                     g_out_rot, g_out_scales, g_out_opacity, dL_dxyz, dL_drotation, dL_dscaling, dL_dopacity,   \
+                     reinterpret_cast<float *>(scratch))
+    if (local_frame && accumulate) DIMO_LAUNCH_LBS_BWD(true, true);
+    else if (local_frame) DIMO_LAUNCH_LBS_BWD(true, false);
+    else if (accumulate) DIMO_LAUNCH_LBS_BWD(false, true);
+    else DIMO_LAUNCH_LBS_BWD(false, false);
+#undef DIMO_LAUNCH_LBS_BWD
   }
   hipLaunchKernelGGL(lbs_reduce_kernel, dim3((M * CP_STRIDE + 255) / 256), dim3(256), 0, stream, M, grid,
-                     reinterpret_cast<const float *>(scratch), dL_dc_xyz, dL_dc_log_radius, dL_dd_xyz, dL_dd_rot);
+                     accumulate ? 1 : 0, reinterpret_cast<const float *>(scratch), dL_dc_xyz, dL_dc_log_radius,
+                     dL_dd_xyz, dL_dd_rot);
   return check_launch();
 }

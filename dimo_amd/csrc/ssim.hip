@@ -37,7 +37,10 @@ static Window make_window() {
   return win;
 }
 
-__global__ void __launch_bounds__(ST *ST) ssim_fwd_kernel(int H, int W, Window win, const float *__restrict__ img1,
+__device__ __forceinline__ float maybe_clamp(float v, int on) { return on ? fminf(fmaxf(v, 0.0f), 1.0f) : v; }
+
+__global__ void __launch_bounds__(ST *ST) ssim_fwd_kernel(int H, int W, int clamp1, Window win,
+                                                          const float *__restrict__ img1,
                                                           const float *__restrict__ img2,
                                                           float *__restrict__ ssim_sum, float *__restrict__ partials,
                                                           size_t plane_stride_total) {
@@ -56,7 +59,7 @@ __global__ void __launch_bounds__(ST *ST) ssim_fwd_kernel(int H, int W, Window w
     const int ly = t / SH_, lx = t % SH_;
     const int gy = y0 + ly - SR, gx = x0 + lx - SR;
     const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
-    s_x[ly][lx] = in ? p1[(size_t)gy * W + gx] : 0.0f;
+    s_x[ly][lx] = in ? maybe_clamp(p1[(size_t)gy * W + gx], clamp1) : 0.0f;
     s_y[ly][lx] = in ? p2[(size_t)gy * W + gx] : 0.0f;
   }
   __syncthreads();
@@ -113,7 +116,8 @@ __global__ void __launch_bounds__(ST *ST) ssim_fwd_kernel(int H, int W, Window w
   if (tid == 0) atomicAdd(ssim_sum, s_red[0] + s_red[1] + s_red[2] + s_red[3]);
 }
 
-__global__ void __launch_bounds__(ST *ST) ssim_bwd_kernel(int H, int W, Window win, const float *__restrict__ img1,
+__global__ void __launch_bounds__(ST *ST) ssim_bwd_kernel(int H, int W, int clamp1, Window win,
+                                                          const float *__restrict__ img1,
                                                           const float *__restrict__ img2,
                                                           const float *__restrict__ partials,
                                                           size_t plane_stride_total,
@@ -155,7 +159,7 @@ __global__ void __launch_bounds__(ST *ST) ssim_bwd_kernel(int H, int W, Window w
   const int gx = x0 + threadIdx.x, gy = y0 + threadIdx.y;
   if (gx < W && gy < H) {
     const size_t o = (size_t)plane * H * W + (size_t)gy * W + gx;
-    const float x = img1[o], y = img2[o];
+    const float x = maybe_clamp(img1[o], clamp1), y = img2[o];
     dL_dimg1[o] = (a + 2.0f * x * b + y * c) * (dL_dmean[0] * inv_numel);
   }
 }
@@ -164,8 +168,8 @@ __global__ void __launch_bounds__(ST *ST) ssim_bwd_kernel(int H, int W, Window w
 
 using namespace dimo;
 
-extern "C" int dimo_ssim_forward(int B, int C, int H, int W, const float *img1, const float *img2, float *ssim_sum,
-                                 float *partials, void *stream_) {
+extern "C" int dimo_ssim_forward(int B, int C, int H, int W, int clamp_img1, const float *img1, const float *img2,
+                                 float *ssim_sum, float *partials, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   clear_errors();
   if (B < 0 || C < 0 || H <= 0 || W <= 0 || !ssim_sum) return DIMO_E_ARG;
@@ -176,12 +180,12 @@ extern "C" int dimo_ssim_forward(int B, int C, int H, int W, const float *img1, 
   static const Window win = make_window();
   const dim3 grid((W + ST - 1) / ST, (H + ST - 1) / ST, (unsigned)planes), block(ST, ST);
   ScopedTimer tm(T_SSIM_FWD, stream);
-  hipLaunchKernelGGL(ssim_fwd_kernel, grid, block, 0, stream, H, W, win, img1, img2, ssim_sum, partials,
+  hipLaunchKernelGGL(ssim_fwd_kernel, grid, block, 0, stream, H, W, clamp_img1, win, img1, img2, ssim_sum, partials,
                      (size_t)planes * H * W);
   return check_launch();
 }
 
-extern "C" int dimo_ssim_backward(int B, int C, int H, int W, const float *img1, const float *img2,
+extern "C" int dimo_ssim_backward(int B, int C, int H, int W, int clamp_img1, const float *img1, const float *img2,
                                   const float *partials, const float *dL_dmean, float *dL_dimg1, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   clear_errors();
@@ -192,7 +196,7 @@ extern "C" int dimo_ssim_backward(int B, int C, int H, int W, const float *img1,
   static const Window win = make_window();
   const dim3 grid((W + ST - 1) / ST, (H + ST - 1) / ST, (unsigned)planes), block(ST, ST);
   ScopedTimer tm(T_SSIM_BWD, stream);
-  hipLaunchKernelGGL(ssim_bwd_kernel, grid, block, 0, stream, H, W, win, img1, img2, partials,
+  hipLaunchKernelGGL(ssim_bwd_kernel, grid, block, 0, stream, H, W, clamp_img1, win, img1, img2, partials,
                      (size_t)planes * H * W, dL_dmean, 1.0f / (float)((double)planes * H * W), dL_dimg1);
   return check_launch();
 }

@@ -154,7 +154,7 @@ class _FusedSkinning(torch.autograd.Function):
         d = [new(N, 3), new(N, 4), new(N, 3), new(*opacity.shape), new(M, 3), new(*c_lr.shape), new(M, 3), new(M, 4)]
         scratch = torch.empty(L.dimo_deform_backward_scratch_bytes(N, M), dtype=torch.uint8, device=dev)
         _lib.check(L.dimo_deform_backward(
-            N, M, int(ctx.local_frame), _lib.ptr(xyz), _lib.ptr(rotation), _lib.ptr(scaling), _lib.ptr(opacity),
+            N, M, int(ctx.local_frame), 0, _lib.ptr(xyz), _lib.ptr(rotation), _lib.ptr(scaling), _lib.ptr(opacity),
             _lib.ptr(c_xyz), _lib.ptr(c_lr), _lib.ptr(d_xyz), _lib.ptr(d_rot), _lib.ptr(nn_dist), _lib.ptr(nn_idx),
             _lib.ptr(g_xyz), _lib.ptr(g_rot), _lib.ptr(g_scales), _lib.ptr(g_opac), *[_lib.ptr(t) for t in d],
             _lib.ptr(scratch), scratch.numel(), _lib.current_stream()), "dimo_deform_backward")

@@ -19,7 +19,7 @@ class _FusedSSIM(torch.autograd.Function):
         need_grad = img1.requires_grad
         ssum = torch.empty(1, dtype=torch.float32, device=img1.device)
         partials = torch.empty(3, B, C, H, W, dtype=torch.float32, device=img1.device) if need_grad else None
-        _lib.check(_lib.lib().dimo_ssim_forward(B, C, H, W, _lib.ptr(img1c), _lib.ptr(img2c), _lib.ptr(ssum),
+        _lib.check(_lib.lib().dimo_ssim_forward(B, C, H, W, 0, _lib.ptr(img1c), _lib.ptr(img2c), _lib.ptr(ssum),
                                                 _lib.ptr(partials), _lib.current_stream()), "dimo_ssim_forward")
         ctx.save_for_backward(img1c, img2c, partials)
         return (ssum / float(B * C * H * W)).reshape(())
@@ -30,7 +30,7 @@ class _FusedSSIM(torch.autograd.Function):
         B, C, H, W = img1c.shape
         g = g.float().contiguous().reshape(1)
         out = torch.empty_like(img1c)
-        _lib.check(_lib.lib().dimo_ssim_backward(B, C, H, W, _lib.ptr(img1c), _lib.ptr(img2c), _lib.ptr(partials),
+        _lib.check(_lib.lib().dimo_ssim_backward(B, C, H, W, 0, _lib.ptr(img1c), _lib.ptr(img2c), _lib.ptr(partials),
                                                  _lib.ptr(g), _lib.ptr(out), _lib.current_stream()),
                    "dimo_ssim_backward")
         return out, None

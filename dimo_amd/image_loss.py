@@ -1,0 +1,46 @@
+"""Raw (non-autograd) front end of dimo_image_loss (dimo_amd/csrc/image_loss.hip): all per-image training
+losses of one motion's batch and the gradient images the rasterizer backward consumes, in one kernel.
+Loss definitions: main_train_dimo.py:331-372, src/loss.py:64-106.  GPU only."""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+
+def loss_weights(cfg, n_local, n_img, H, W):
+    """Folds lambda, the 1/numel of each mean-type term and this rank's share n_local/n_img of the motion's
+    images into per-element weights (see Trainer.motion_loss for the autograd formulation)."""
+    share = n_local / n_img
+    B = n_local
+    return dict(
+        w_mask=cfg.lambda_mask * share / (B * H * W),
+        w_smooth_x=(cfg.lambda_smooth * share / (B * H * (W - 1))) if cfg.add_depth and W > 1 else 0.0,
+        w_smooth_y=(cfg.lambda_smooth * share / (B * (H - 1) * W)) if cfg.add_depth and H > 1 else 0.0,
+        w_bilat_x=(cfg.lambda_bilateral * share / (3 * B * H * (W - 1))) if cfg.add_normal and W > 1 else 0.0,
+        w_bilat_y=(cfg.lambda_bilateral * share / (3 * B * (H - 1) * W)) if cfg.add_normal and H > 1 else 0.0,
+    )
+
+
+def fused_image_loss(image, depth, normal, alpha, gt, mask, w_mse, weights, ssim_grad, loss_accum, out=None):
+    """image[B,3,H,W] (raw, unclamped) depth[B,1,H,W]|None normal[B,3,H,W]|None alpha[B,1,H,W] gt[B,3,H,W]
+    mask [1,H,W] (shared) or [B,1,H,W]; w_mse: python list of B floats (already divided by 3HW).
+    Adds the loss to `loss_accum` (1 float) and returns (g_image, g_depth|None, g_normal|None, g_alpha)."""
+    if not image.is_cuda:
+        raise RuntimeError("dimo_amd.image_loss needs GPU tensors (no CPU fallback in the product path)")
+    B, _, H, W = image.shape
+    new = lambda ref: torch.empty_like(ref)
+    if out is None:
+        g_image, g_alpha = new(image), new(alpha)
+        g_depth = new(depth) if depth is not None else None
+        g_normal = new(normal) if normal is not None else None
+    else:
+        g_image, g_depth, g_normal, g_alpha = out
+    per_image = 1 if (mask.dim() == 4 and mask.shape[0] == B and B > 1) else 0
+    w_arr = (C.c_float * B)(*w_mse)
+    _lib.check(_lib.lib().dimo_image_loss(
+        B, H, W, _lib.ptr(image), _lib.ptr(depth), _lib.ptr(normal), _lib.ptr(alpha), _lib.ptr(gt), _lib.ptr(mask),
+        per_image, w_arr, weights["w_mask"], weights["w_smooth_x"], weights["w_smooth_y"], weights["w_bilat_x"],
+        weights["w_bilat_y"], _lib.ptr(ssim_grad), _lib.ptr(loss_accum), _lib.ptr(g_image), _lib.ptr(g_depth),
+        _lib.ptr(g_normal), _lib.ptr(g_alpha), _lib.current_stream()), "dimo_image_loss")
+    return g_image, g_depth, g_normal, g_alpha

@@ -13,6 +13,11 @@ Everything runs on the caller's current stream through the C ABI (include/dimo_h
 workspaces come from torch's caching allocator and live in the autograd ctx until
 backward.  There is no CPU fallback: without the HIP library / a GPU tensor this raises.
 
+Two layers:
+  * `raster_forward` / `raster_backward` -- plain functions on tensors (no autograd), used by the
+    trainer's direct pipeline, which chains the HIP kernels itself;
+  * `_Rasterize` (autograd.Function) + the two `GaussianRasterizer` modules -- the reference's call surface.
+
 Instance capacity.  The number of (Gaussian, tile) instances R is only known on the
 device after projection.  `capacity=None` (default) reads it back (one stream sync per
 render, like the CUDA original).  A `CapacityPolicy` instead sizes the sort buffers from
@@ -49,6 +54,7 @@ class CapacityPolicy:
         self.capacity = int(initial)
         self.margin = float(margin)
         self._pending = []  # geom `total` views (R, overflow) of renders since the last check
+        self.last_r_mean = self.last_r_max = None
 
     def next_capacity(self):
         return self.capacity
@@ -78,68 +84,145 @@ def _f32c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
-class _Rasterize(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, settings,
-                with_normal, capacity):
-        L = _lib.lib()
-        if not means3D.is_cuda:
-            raise RuntimeError("dimo_amd rasterizer needs GPU tensors (no CPU fallback in the product path)")
-        dev = means3D.device
-        s = settings
-        N = means3D.shape[0]
-        H, W = int(s.image_height), int(s.image_width)
-        means3D, opacities = _f32c(means3D), _f32c(opacities)
-        shs, colors_precomp = _f32c(shs), _f32c(colors_precomp)
-        scales, rotations, cov3D_precomp = _f32c(scales), _f32c(rotations), _f32c(cov3D_precomp)
-        if N > 0:  # the CUDA wrappers pass "absent" as empty tensors
-            if shs is not None and shs.numel() == 0:
-                shs = None
-            if colors_precomp is not None and colors_precomp.numel() == 0:
-                colors_precomp = None
-            if cov3D_precomp is not None and cov3D_precomp.numel() == 0:
-                cov3D_precomp = None
-        if (shs is None) == (colors_precomp is None):
-            raise ValueError("Please provide exactly one of either SHs or precomputed colors!")
-        if cov3D_precomp is None and (scales is None or rotations is None):
-            raise ValueError("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
-        M = 0 if shs is None else shs.shape[1]
-        view, proj = _f32c(s.viewmatrix), _f32c(s.projmatrix)
-        campos, bg = _f32c(s.campos), _f32c(s.bg)
-        stream = _lib.current_stream()
+_TOTAL_OFFSET = {}
 
-        geom = torch.empty(L.dimo_raster_geom_bytes(N), dtype=torch.uint8, device=dev)
-        radii = torch.empty(N, dtype=torch.int32, device=dev)
-        r_host = C.c_int64(0)
-        exact = capacity is None
-        _lib.check(L.dimo_raster_preprocess_forward(
-            N, int(s.sh_degree), M, H, W, _lib.ptr(means3D), _lib.ptr(shs), _lib.ptr(colors_precomp),
-            _lib.ptr(opacities), _lib.ptr(scales), _lib.ptr(rotations), _lib.ptr(cov3D_precomp),
-            float(s.scale_modifier), _lib.ptr(view), _lib.ptr(proj), _lib.ptr(campos), float(s.tanfovx),
-            float(s.tanfovy), _lib.ptr(radii), _lib.ptr(geom), geom.numel(),
-            C.byref(r_host) if exact else None, stream), "dimo_raster_preprocess_forward")
-        if exact:
-            r_cap = max(int(r_host.value), 1)
-        else:
-            r_cap = int(capacity.next_capacity())
-            off = (C.c_size_t * 6)()
-            L.dimo_raster_geom_layout(N, off)
-            capacity.track(geom[off[5]:off[5] + 8].view(torch.int32))
 
-        bin_ws = torch.empty(L.dimo_raster_bin_bytes(r_cap, H, W), dtype=torch.uint8, device=dev)
-        img_ws = torch.empty(L.dimo_raster_img_bytes(H, W), dtype=torch.uint8, device=dev)
+def _total_view(geom, N):
+    off = _TOTAL_OFFSET.get(N)
+    if off is None:
+        arr = (C.c_size_t * 6)()
+        _lib.lib().dimo_raster_geom_layout(N, arr)
+        off = _TOTAL_OFFSET[N] = int(arr[5])
+    return geom[off:off + 8].view(torch.int32)
+
+
+class RasterState:
+    """Everything the backward needs (inputs are kept by reference, workspaces by ownership)."""
+    __slots__ = ("settings", "N", "M", "H", "W", "r_cap", "with_normal", "means3D", "shs", "colors_precomp",
+                 "opacities", "scales", "rotations", "cov3D_precomp", "view", "proj", "campos", "bg", "radii", "geom",
+                 "bin_ws", "img_ws")
+
+
+def raster_forward(means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, settings,
+                   with_normal=True, capacity: Optional[CapacityPolicy] = None, out=None):
+    """Runs preprocess + binning + blend.  `out` = optional (color[3,H,W], depth[1,H,W], normal[3,H,W]|None,
+    alpha[1,H,W]) contiguous tensors to render into (e.g. slices of a batch buffer).
+    Returns (color, depth, normal|None, alpha, radii, RasterState)."""
+    L = _lib.lib()
+    if not means3D.is_cuda:
+        raise RuntimeError("dimo_amd rasterizer needs GPU tensors (no CPU fallback in the product path)")
+    dev = means3D.device
+    s = settings
+    N = means3D.shape[0]
+    H, W = int(s.image_height), int(s.image_width)
+    means3D, opacities = _f32c(means3D), _f32c(opacities)
+    shs, colors_precomp = _f32c(shs), _f32c(colors_precomp)
+    scales, rotations, cov3D_precomp = _f32c(scales), _f32c(rotations), _f32c(cov3D_precomp)
+    if N > 0:  # the CUDA wrappers pass "absent" as empty tensors
+        if shs is not None and shs.numel() == 0:
+            shs = None
+        if colors_precomp is not None and colors_precomp.numel() == 0:
+            colors_precomp = None
+        if cov3D_precomp is not None and cov3D_precomp.numel() == 0:
+            cov3D_precomp = None
+    if (shs is None) == (colors_precomp is None):
+        raise ValueError("Please provide exactly one of either SHs or precomputed colors!")
+    if cov3D_precomp is None and (scales is None or rotations is None):
+        raise ValueError("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+    M = 0 if shs is None else shs.shape[1]
+    view, proj = _f32c(s.viewmatrix), _f32c(s.projmatrix)
+    campos, bg = _f32c(s.campos), _f32c(s.bg)
+    stream = _lib.current_stream()
+
+    geom = torch.empty(L.dimo_raster_geom_bytes(N), dtype=torch.uint8, device=dev)
+    radii = torch.empty(N, dtype=torch.int32, device=dev)
+    r_host = C.c_int64(0)
+    exact = capacity is None
+    _lib.check(L.dimo_raster_preprocess_forward(
+        N, int(s.sh_degree), M, H, W, _lib.ptr(means3D), _lib.ptr(shs), _lib.ptr(colors_precomp),
+        _lib.ptr(opacities), _lib.ptr(scales), _lib.ptr(rotations), _lib.ptr(cov3D_precomp),
+        float(s.scale_modifier), _lib.ptr(view), _lib.ptr(proj), _lib.ptr(campos), float(s.tanfovx),
+        float(s.tanfovy), _lib.ptr(radii), _lib.ptr(geom), geom.numel(),
+        C.byref(r_host) if exact else None, stream), "dimo_raster_preprocess_forward")
+    if exact:
+        r_cap = max(int(r_host.value), 1)
+    else:
+        r_cap = int(capacity.next_capacity())
+        capacity.track(_total_view(geom, N))
+
+    bin_ws = torch.empty(L.dimo_raster_bin_bytes(r_cap, H, W), dtype=torch.uint8, device=dev)
+    img_ws = torch.empty(L.dimo_raster_img_bytes(H, W), dtype=torch.uint8, device=dev)
+    if out is None:
         color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
         depth = torch.empty(1, H, W, dtype=torch.float32, device=dev)
         normal = torch.empty(3, H, W, dtype=torch.float32, device=dev) if with_normal else None
         alpha = torch.empty(1, H, W, dtype=torch.float32, device=dev)
-        _lib.check(L.dimo_raster_render_forward(
-            N, H, W, r_cap, _lib.ptr(bg), _lib.ptr(geom), _lib.ptr(bin_ws), bin_ws.numel(), _lib.ptr(img_ws),
-            img_ws.numel(), _lib.ptr(color), _lib.ptr(depth), _lib.ptr(normal), _lib.ptr(alpha), stream),
-            "dimo_raster_render_forward")
+    else:
+        color, depth, normal, alpha = out
+        if not with_normal:
+            normal = None
+    _lib.check(L.dimo_raster_render_forward(
+        N, H, W, r_cap, _lib.ptr(bg), _lib.ptr(geom), _lib.ptr(bin_ws), bin_ws.numel(), _lib.ptr(img_ws),
+        img_ws.numel(), _lib.ptr(color), _lib.ptr(depth), _lib.ptr(normal), _lib.ptr(alpha), stream),
+        "dimo_raster_render_forward")
+    st = RasterState()
+    st.settings, st.N, st.M, st.H, st.W, st.r_cap, st.with_normal = s, N, M, H, W, r_cap, with_normal
+    st.means3D, st.shs, st.colors_precomp, st.opacities = means3D, shs, colors_precomp, opacities
+    st.scales, st.rotations, st.cov3D_precomp = scales, rotations, cov3D_precomp
+    st.view, st.proj, st.campos, st.bg, st.radii = view, proj, campos, bg, radii
+    st.geom, st.bin_ws, st.img_ws = geom, bin_ws, img_ws
+    return color, depth, normal, alpha, radii, st
 
-        ctx.settings, ctx.with_normal, ctx.r_cap, ctx.dims = s, with_normal, r_cap, (N, M, H, W)
-        ctx.save_for_backward(means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, view, proj,
-                              campos, bg, radii, geom, bin_ws, img_ws)
+
+def raster_backward(st: RasterState, g_color, g_depth, g_normal, g_alpha, out=None, scratch=None):
+    """-> dict(means3D, means2D, shs|colors, opacities, scales, rotations | cov3D).  `out` may provide
+    preallocated gradient tensors under the same keys (reused across the renders of a step)."""
+    L = _lib.lib()
+    s, N, M, H, W, r_cap = st.settings, st.N, st.M, st.H, st.W, st.r_cap
+    g_color, g_depth, g_normal, g_alpha = _f32c(g_color), _f32c(g_depth), _f32c(g_normal), _f32c(g_alpha)
+    dev = st.means3D.device
+    out = {} if out is None else out
+
+    def buf(key, *shape):
+        t = out.get(key)
+        if t is None:
+            t = out[key] = torch.empty(*shape, dtype=torch.float32, device=dev)
+        return t
+
+    d_means3D, d_means2D, d_opac = buf("means3D", N, 3), buf("means2D", N, 3), buf("opacities", N, 1)
+    d_shs = buf("shs", N, M, 3) if st.shs is not None else None
+    d_colors = buf("colors", N, 3) if st.colors_precomp is not None else None
+    d_scales = buf("scales", N, 3) if st.cov3D_precomp is None else None
+    d_rot = buf("rotations", N, 4) if st.cov3D_precomp is None else None
+    d_cov = buf("cov3D", N, 6) if st.cov3D_precomp is not None else None
+    need = L.dimo_raster_backward_scratch_bytes(N, r_cap)
+    if scratch is None or scratch.numel() < need:
+        scratch = torch.empty(need, dtype=torch.uint8, device=dev)
+    _lib.check(L.dimo_raster_backward(
+        N, int(s.sh_degree), M, H, W, r_cap, _lib.ptr(st.means3D), _lib.ptr(st.shs), _lib.ptr(st.colors_precomp),
+        _lib.ptr(st.opacities), _lib.ptr(st.scales), _lib.ptr(st.rotations), _lib.ptr(st.cov3D_precomp),
+        float(s.scale_modifier), _lib.ptr(st.view), _lib.ptr(st.proj), _lib.ptr(st.campos), _lib.ptr(st.bg),
+        float(s.tanfovx), float(s.tanfovy), _lib.ptr(st.radii), _lib.ptr(st.geom), _lib.ptr(st.bin_ws),
+        _lib.ptr(st.img_ws), _lib.ptr(g_color), _lib.ptr(g_depth), _lib.ptr(g_normal) if st.with_normal else None,
+        _lib.ptr(g_alpha), _lib.ptr(d_means3D), _lib.ptr(d_means2D), _lib.ptr(d_shs), _lib.ptr(d_colors),
+        _lib.ptr(d_opac), _lib.ptr(d_scales), _lib.ptr(d_rot), _lib.ptr(d_cov), _lib.ptr(scratch), scratch.numel(),
+        _lib.current_stream()), "dimo_raster_backward")
+    out["_scratch"] = scratch
+    return out
+
+
+class _Rasterize(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, settings,
+                with_normal, capacity):
+        color, depth, normal, alpha, radii, st = raster_forward(
+            means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, settings, with_normal,
+            capacity)
+        ctx.st = st
+        ctx.r_cap = st.r_cap
+        ctx.opacity_shape = opacities.shape
+        # keep the workspaces visible as saved tensors too (tests inspect them)
+        ctx.save_for_backward(st.geom, st.bin_ws, st.img_ws)
         ctx.mark_non_differentiable(radii)
         if with_normal:
             return color, depth, normal, alpha, radii
@@ -147,36 +230,15 @@ class _Rasterize(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *grads):
-        L = _lib.lib()
-        (means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, view, proj, campos, bg, radii,
-         geom, bin_ws, img_ws) = ctx.saved_tensors
-        s, (N, M, H, W), r_cap = ctx.settings, ctx.dims, ctx.r_cap
-        if ctx.with_normal:
+        st = ctx.st
+        if st.with_normal:
             g_color, g_depth, g_normal, g_alpha, _ = grads
         else:
             g_color, g_depth, g_alpha, _ = grads
             g_normal = None
-        g_color, g_depth, g_normal, g_alpha = _f32c(g_color), _f32c(g_depth), _f32c(g_normal), _f32c(g_alpha)
-        dev = means3D.device
-        new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
-        d_means3D, d_means2D, d_opac = new(N, 3), new(N, 3), new(N, 1)
-        d_shs = new(N, M, 3) if shs is not None else None
-        d_colors = new(N, 3) if colors_precomp is not None else None
-        d_scales = new(N, 3) if cov3D_precomp is None else None
-        d_rot = new(N, 4) if cov3D_precomp is None else None
-        d_cov = new(N, 6) if cov3D_precomp is not None else None
-        scratch = torch.empty(L.dimo_raster_backward_scratch_bytes(N, r_cap), dtype=torch.uint8, device=dev)
-        _lib.check(L.dimo_raster_backward(
-            N, int(s.sh_degree), M, H, W, r_cap, _lib.ptr(means3D), _lib.ptr(shs), _lib.ptr(colors_precomp),
-            _lib.ptr(opacities), _lib.ptr(scales), _lib.ptr(rotations), _lib.ptr(cov3D_precomp),
-            float(s.scale_modifier), _lib.ptr(view), _lib.ptr(proj), _lib.ptr(campos), _lib.ptr(bg),
-            float(s.tanfovx), float(s.tanfovy), _lib.ptr(radii), _lib.ptr(geom), _lib.ptr(bin_ws), _lib.ptr(img_ws),
-            _lib.ptr(g_color), _lib.ptr(g_depth), _lib.ptr(g_normal) if ctx.with_normal else None, _lib.ptr(g_alpha),
-            _lib.ptr(d_means3D), _lib.ptr(d_means2D), _lib.ptr(d_shs), _lib.ptr(d_colors), _lib.ptr(d_opac),
-            _lib.ptr(d_scales), _lib.ptr(d_rot), _lib.ptr(d_cov), _lib.ptr(scratch), scratch.numel(),
-            _lib.current_stream()), "dimo_raster_backward")
-        return (d_means3D, d_means2D, d_shs, d_colors, d_opac.view(opacities.shape), d_scales, d_rot, d_cov, None,
-                None, None)
+        g = raster_backward(st, g_color, g_depth, g_normal, g_alpha)
+        return (g["means3D"], g["means2D"], g.get("shs"), g.get("colors"), g["opacities"].view(ctx.opacity_shape),
+                g.get("scales"), g.get("rotations"), g.get("cov3D"), None, None, None)
 
 
 def rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,

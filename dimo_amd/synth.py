@@ -50,17 +50,20 @@ def init_synthetic_model(renderer, num_pts, num_cpts, seed=0, regime="trained", 
     g.max_radii2D = torch.zeros(num_pts, device=dev)
     g.spatial_lr_scale = 1
     with torch.no_grad():
-        torch.manual_seed(seed)
+        # weights AND biases drawn on the host from the seeded generator (identical on CPU, GPU and every DP rank)
         for m in g._timenet.modules():
-            if isinstance(m, nn.Linear):  # weights AND biases from the seed, so every DP replica starts identical
-                nn.init.xavier_uniform_(m.weight, gain=1)
+            if isinstance(m, nn.Linear):
+                w = torch.empty(m.weight.shape)
+                nn.init.xavier_uniform_(w, gain=1, generator=tg)
                 bound = 1.0 / math.sqrt(m.in_features)
-                nn.init.uniform_(m.bias, -bound, bound)
+                b = (torch.rand(m.bias.shape, generator=tg) * 2 - 1) * bound
+                m.weight.copy_(w)
+                m.bias.copy_(b)
         g._timenet.pts_layers[-1].bias.zero_()
         g._timenet.rot_layers[-1].bias.copy_(torch.tensor([1.0, 0.0, 0.0, 0.0]))
         # the reference zero-inits the heads (no motion); use small random heads so deformation is non-trivial
-        g._timenet.pts_layers[-1].weight.normal_(0, 1e-2)
-        g._timenet.rot_layers[-1].weight.normal_(0, 1e-2)
+        g._timenet.pts_layers[-1].weight.copy_(torch.randn(g._timenet.pts_layers[-1].weight.shape, generator=tg) * 1e-2)
+        g._timenet.rot_layers[-1].weight.copy_(torch.randn(g._timenet.rot_layers[-1].weight.shape, generator=tg) * 1e-2)
         lat = torch.randn(num_latent, g.latent_code_dim, generator=tg).to(dev)
         if g.vae_latent:
             g._mu, g._log_var = nn.Parameter(lat), nn.Parameter(torch.full_like(lat, -4.0))
@@ -73,21 +76,27 @@ def init_synthetic_model(renderer, num_pts, num_cpts, seed=0, regime="trained", 
 class SyntheticTargets:
     """Device-resident target images / masks, generated on first use from (motion, view, frame)."""
 
+    POOL = 64  # distinct target images kept resident; (motion, view, frame) hashes into the pool
+
     def __init__(self, resolution, device, seed=0):
         self.res, self.device, self.seed = resolution, device, seed
-        self._cache = {}
+        self._pool = {}
         yy, xx = torch.meshgrid(torch.arange(resolution), torch.arange(resolution), indexing="ij")
         c = (resolution - 1) / 2
         self._disc = (((xx - c) ** 2 + (yy - c) ** 2) <= (0.4 * resolution) ** 2).float()[None].to(device)
+        for slot in range(self.POOL):  # generated once, on the host RNG (identical on every rank), uploaded once
+            gen = torch.Generator().manual_seed(self.seed * 1_000_003 + slot)
+            self._pool[slot] = (torch.rand(3, resolution, resolution, generator=gen).to(device), self._disc)
 
     def get(self, motion, view, frame):
-        key = (motion, view, frame)
-        t = self._cache.get(key)
+        """The reference keeps every ground-truth frame in host RAM and uploads one per render
+        (main_train_dimo.py:283-284); here targets stay in HBM (288 GB) and are never regenerated."""
+        slot = (motion * 10_007 + view * 101 + frame) % self.POOL
+        t = self._pool.get(slot)
         if t is None:
-            gen = torch.Generator().manual_seed(self.seed * 1_000_003 + motion * 10_007 + view * 101 + frame)
+            gen = torch.Generator().manual_seed(self.seed * 1_000_003 + slot)
             img = torch.rand(3, self.res, self.res, generator=gen).to(self.device)
-            t = (img, self._disc)
-            self._cache[key] = t
+            t = self._pool[slot] = (img, self._disc)
         return t
 
 

@@ -93,7 +93,7 @@ def shard(items, rank, world):
 
 class Trainer:
     def __init__(self, cfg: TrainConfig, renderer, rank=0, world_size=1, process_group=None,
-                 ssim_fn: Optional[Callable] = None, knn_fn: Optional[Callable] = None, targets=None):
+                 ssim_fn: Optional[Callable] = None, knn_fn: Optional[Callable] = None, targets=None, direct=None):
         self.cfg, self.renderer = cfg, renderer
         self.rank, self.world, self.pg = rank, world_size, process_group
         self.device = renderer.device
@@ -114,6 +114,12 @@ class Trainer:
         renderer.gaussians.training_setup(cfg)
         self.optimizer = renderer.gaussians.optimizer
         self.last_loss = None
+        self._consts = {}
+        self._deform_batch = None
+        # direct HIP pipeline: GPU, stage s2, degree-0 colour (DIMO's configuration), product rasterizer
+        self.direct = (direct if direct is not None else True) and self.device.type == "cuda" \
+            and cfg.stage >= "s2" and cfg.sh_degree == 0 and renderer._rasterizer_factory is None \
+            and len(renderer.gaussians._r) == 0 and renderer.gaussians._c_xyz.shape[0] <= 1800
 
     # ------------------------------------------------------------------ pieces of train_step
     def find_knn(self, k=4):
@@ -150,6 +156,7 @@ class Trainer:
         times = times[:, None, None].expand(-1, M, 1)
         lat = torch.stack([g.latent_code(p[0]) for p in pairs])[:, None, :].expand(-1, M, -1)
         dxyz, dquat = g._timenet(g._c_xyz[None], times, lat, t_apply=True)
+        self._deform_batch = (dxyz, dquat, {(m, v, f): pairs.index(key(m, v, f)) for (m, v, f) in triples})
         out = {p: (dxyz[i], dquat[i]) for i, p in enumerate(pairs)}
         return {(m, v, f): out[key(m, v, f)] for (m, v, f) in triples}
 
@@ -178,6 +185,133 @@ class Trainer:
         if self.world > 1:
             dist.all_reduce(self.renderer.gaussians.flat_grads, op=dist.ReduceOp.SUM, group=self.pg)
 
+    # ------------------------------------------------------------------ forward + backward, two ways
+    def _forward_backward_autograd(self, mine, n_img):
+        """Reference-shaped path: Renderer.render per triple, torch losses, ONE autograd backward."""
+        c, g = self.cfg, self.renderer.gaussians
+        loss = None
+        by_motion = {}
+        deforms = self.batched_deform(mine) if self.stage >= "s2" else {}
+        for (m, v, f) in mine:
+            out = self.render_triple(m, v, f, deform=deforms.get((m, v, f)))
+            gt, mask = self.targets.get(m, v, f)
+            w = 1.0 if (v == 0 or f == 0) else 0.5  # reference view / frame weighting (main_train_dimo.py:334)
+            rec = by_motion.setdefault(m, ([], [], [], []))
+            rec[0].append(out), rec[1].append(gt), rec[2].append(mask), rec[3].append(w)
+        for m, (outs, gts, masks, ws) in by_motion.items():
+            lm = self.motion_loss(outs, gts, masks, ws, n_img)
+            if g.vae_latent:
+                mu, lv = g._mu[m], g._log_var[m]
+                lm = lm + c.lambda_kl * (-0.5 * torch.sum(1 + lv - mu.pow(2) - lv.exp()))
+            loss = lm if loss is None else loss + lm
+        if loss is not None:
+            loss.backward()
+        return loss
+
+    def _forward_backward_direct(self, mine, n_img):
+        """MI355X pipeline: the HIP kernels are chained explicitly instead of through autograd.
+
+        skinning -> project/bin/sort/blend (rendered straight into the motion's batch buffers) -> fused SSIM +
+        fused image losses (emit the four gradient images) -> blend/projection backward -> skinning backward
+        ACCUMULATING into the flat gradient bucket.  Only the (batched) TimeNet MLP still uses autograd.  Same
+        math as `_forward_backward_autograd` (tests compare the two), ~3x fewer kernel launches and no
+        per-render Python/autograd graph work."""
+        from . import _lib
+        from .image_loss import fused_image_loss, loss_weights
+        from .rasterizer import raster_backward, raster_forward
+        c, g, L = self.cfg, self.renderer.gaussians, _lib.lib()
+        dev, stream = self.device, _lib.current_stream()
+        N, M = g._xyz.shape[0], g._c_xyz.shape[0]
+        H = W = c.resolution
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.batched_deform(mine)
+        dxyz_all, dquat_all, pair_of = self._deform_batch  # [P,M,3], [P,M,4], triple -> row
+        dxyz_c, dquat_c = dxyz_all.detach().contiguous(), dquat_all.detach().contiguous()
+        g_dxyz, g_dquat = torch.zeros_like(dxyz_c), torch.zeros_like(dquat_c)  # accumulated by the skinning backward
+        by_motion = {}
+        for t in mine:
+            by_motion.setdefault(t[0], []).append(t)
+        loss_accum = torch.zeros(1, **f32)
+        ssim_terms = []
+        g_ras, scratch = {}, None
+        lbs_scratch = torch.empty(L.dimo_deform_backward_scratch_bytes(N, M), dtype=torch.uint8, device=dev)
+        nn_d, nn_i = g.neighbor_dists, g.neighbor_indices
+        c_lr = g._c_radius
+        for m, trs in by_motion.items():
+            B = len(trs)
+            img = torch.empty(B, 3, H, W, **f32)
+            depth = torch.empty(B, 1, H, W, **f32)
+            normal = torch.empty(B, 3, H, W, **f32) if self.renderer.add_normal else None
+            alpha = torch.empty(B, 1, H, W, **f32)
+            states = []
+            for b, (_m, v, f) in enumerate(trs):
+                p = pair_of[(m, v, f)]
+                dx, dq = dxyz_c[p], dquat_c[p]
+                pts, rot, scales, opac = (torch.empty(N, 3, **f32), torch.empty(N, 4, **f32),
+                                          torch.empty(N, 3, **f32), torch.empty(N, 1, **f32))
+                _lib.check(L.dimo_deform_forward(
+                    N, M, 1, _lib.ptr(g._xyz), _lib.ptr(g._rotation), _lib.ptr(g._scaling), _lib.ptr(g._opacity),
+                    _lib.ptr(g._c_xyz), _lib.ptr(c_lr), _lib.ptr(dx), _lib.ptr(dq), _lib.ptr(nn_d), _lib.ptr(nn_i),
+                    _lib.ptr(pts), _lib.ptr(rot), _lib.ptr(scales), _lib.ptr(opac), stream), "dimo_deform_forward")
+                cam = self.cams.get(c.elevation, self.azimuths[v], c.radius, W, H)
+                settings = self.renderer._settings(cam, 1.0, None)
+                *_, st = raster_forward(pts, g._features_dc, None, opac, scales, rot, None, settings,
+                                        self.renderer.add_normal, self.renderer.capacity,
+                                        out=(img[b], depth[b], normal[b] if normal is not None else None, alpha[b]))
+                states.append((st, p))
+            gts = [self.targets.get(*t) for t in trs]
+            gt = torch.stack([x[0] for x in gts])
+            mask = gts[0][1]
+            share = B / n_img
+            # SSIM on the clamped render; its gradient image feeds the loss kernel
+            ssum = torch.empty(1, **f32)
+            partials = torch.empty(3, B, 3, H, W, **f32)
+            _lib.check(L.dimo_ssim_forward(B, 3, H, W, 1, _lib.ptr(img), _lib.ptr(gt), _lib.ptr(ssum),
+                                           _lib.ptr(partials), stream), "dimo_ssim_forward")
+            coef = self._const(-c.lambda_ssim * share)
+            ssim_grad = torch.empty(B, 3, H, W, **f32)
+            _lib.check(L.dimo_ssim_backward(B, 3, H, W, 1, _lib.ptr(img), _lib.ptr(gt), _lib.ptr(partials),
+                                            _lib.ptr(coef), _lib.ptr(ssim_grad), stream), "dimo_ssim_backward")
+            ssim_terms.append((ssum, c.lambda_ssim * share, float(B * 3 * H * W)))
+            w_mse = [c.lambda_mse * (1.0 if (v == 0 or f == 0) else 0.5) / (3 * H * W) for (_m, v, f) in trs]
+            gi, gd, gn, ga = fused_image_loss(img, depth if c.add_depth else None, normal if c.add_normal else None,
+                                              alpha, gt, mask, w_mse, loss_weights(c, B, n_img, H, W), ssim_grad,
+                                              loss_accum)
+            for b in reversed(range(B)):
+                st, p = states[b]
+                dx, dq, adx, adq = dxyz_c[p], dquat_c[p], g_dxyz[p], g_dquat[p]
+                g_ras = raster_backward(st, gi[b], gd[b] if gd is not None else None,
+                                        gn[b] if gn is not None else None, ga[b], out=g_ras,
+                                        scratch=g_ras.get("_scratch"))
+                g._features_dc.grad.add_(g_ras["shs"])
+                _lib.check(L.dimo_deform_backward(
+                    N, M, 1, 1, _lib.ptr(g._xyz), _lib.ptr(g._rotation), _lib.ptr(g._scaling), _lib.ptr(g._opacity),
+                    _lib.ptr(g._c_xyz), _lib.ptr(c_lr), _lib.ptr(dx), _lib.ptr(dq), _lib.ptr(nn_d), _lib.ptr(nn_i),
+                    _lib.ptr(g_ras["means3D"]), _lib.ptr(g_ras["rotations"]), _lib.ptr(g_ras["scales"]),
+                    _lib.ptr(g_ras["opacities"]), _lib.ptr(g._xyz.grad), _lib.ptr(g._rotation.grad),
+                    _lib.ptr(g._scaling.grad), _lib.ptr(g._opacity.grad), _lib.ptr(g._c_xyz.grad),
+                    _lib.ptr(g._c_radius.grad), _lib.ptr(adx), _lib.ptr(adq), _lib.ptr(lbs_scratch),
+                    lbs_scratch.numel(), stream), "dimo_deform_backward")
+            if g.vae_latent:  # KL term of this motion (main_train_dimo.py:355-360): tiny, autograd
+                mu, lv = g._mu[m], g._log_var[m]
+                kl = c.lambda_kl * (-0.5 * torch.sum(1 + lv - mu.pow(2) - lv.exp()))
+                kl.backward()
+                loss_accum += kl.detach()
+        # TimeNet backward for all renders at once
+        if mine:
+            torch.autograd.backward([dxyz_all, dquat_all], [g_dxyz, g_dquat])
+        loss = loss_accum[0]
+        for ssum, lam, numel in ssim_terms:
+            loss = loss + lam * (1 - ssum[0] / numel)
+        return loss
+
+    def _const(self, value):
+        """Cached 1-element device tensors for scalar kernel arguments."""
+        t = self._consts.get(value)
+        if t is None:
+            t = self._consts[value] = torch.tensor([value], dtype=torch.float32, device=self.device)
+        return t
+
     # ------------------------------------------------------------------ the step
     def train_step(self, triples=None):
         """Runs one optimisation step; returns the number of renders THIS rank performed."""
@@ -192,23 +326,10 @@ class Trainer:
         n_img = max(1, len(triples) // max(1, len({t[0] for t in triples})))  # images per motion (b^2)
         ref_view, ref_frame = 0, 0
 
-        loss = None
-        by_motion = {}
-        deforms = self.batched_deform(mine) if self.stage >= "s2" else {}
-        for (m, v, f) in mine:
-            out = self.render_triple(m, v, f, deform=deforms.get((m, v, f)))
-            gt, mask = self.targets.get(m, v, f)
-            w = 1.0 if (v == ref_view or f == ref_frame) else 0.5  # reference view / frame weighting
-            rec = by_motion.setdefault(m, ([], [], [], []))
-            rec[0].append(out), rec[1].append(gt), rec[2].append(mask), rec[3].append(w)
-        for m, (outs, gts, masks, ws) in by_motion.items():
-            lm = self.motion_loss(outs, gts, masks, ws, n_img)
-            if g.vae_latent:
-                mu, lv = g._mu[m], g._log_var[m]
-                lm = lm + c.lambda_kl * (-0.5 * torch.sum(1 + lv - mu.pow(2) - lv.exp()))
-            loss = lm if loss is None else loss + lm
-        if loss is not None:
-            loss.backward()
+        if self.direct:
+            loss = self._forward_backward_direct(mine, n_img)
+        else:
+            loss = self._forward_backward_autograd(mine, n_img)
         cap = self.renderer.capacity
         if cap is not None and not cap.check():  # the step's only host sync; parameters are still untouched
             g.zero_grad()

@@ -134,11 +134,29 @@ int dimo_dist2(int N, const float *points, float *out, void *stream);
 /* ------------------------------------------------------------------ fused SSIM (11x11, sigma 1.5, zero padding)
  * img1,img2 [B,C,H,W]; ssim_sum: one float accumulator (zeroed by the call) receiving the SUM of the
  * SSIM map (mean = sum / (B*C*H*W)); partials [3,B,C,H,W] saved for backward (dm/dmu1, dm/dsigma1_sq,
- * dm/dsigma12 at every pixel).  Backward: dL_dimg1 = dL_dmean/(B*C*H*W) * conv^T(partials). */
-int dimo_ssim_forward(int B, int C, int H, int W, const float *img1, const float *img2, float *ssim_sum,
-                      float *partials, void *stream);
-int dimo_ssim_backward(int B, int C, int H, int W, const float *img1, const float *img2, const float *partials,
-                       const float *dL_dmean /* 1 float, device */, float *dL_dimg1, void *stream);
+ * dm/dsigma12 at every pixel).  Backward: dL_dimg1 = dL_dmean/(B*C*H*W) * conv^T(partials).
+ * clamp_img1 != 0: img1 is read as clamp(img1, 0, 1) (the rasterizer's raw colour output; the gradient
+ * returned is then w.r.t. the CLAMPED image and the caller applies the clamp mask). */
+int dimo_ssim_forward(int B, int C, int H, int W, int clamp_img1, const float *img1, const float *img2,
+                      float *ssim_sum, float *partials, void *stream);
+int dimo_ssim_backward(int B, int C, int H, int W, int clamp_img1, const float *img1, const float *img2,
+                       const float *partials, const float *dL_dmean /* 1 float, device */, float *dL_dimg1,
+                       void *stream);
+
+/* ------------------------------------------------------------------ fused image losses + their gradients
+ * One motion's batch of B <= 64 renders (main_train_dimo.py:331-372, src/loss.py:64-106):
+ *   loss += sum_b w_mse[b] |clamp(image_b,0,1) - gt_b|^2  + w_mask |alpha - mask|^2
+ *         + w_smooth_{x,y} |d depth| exp(-mean_c |d rgb|)  + w_bilat_{x,y} sqrt(1 + (|d n| exp(-3 mean_c |d rgb|))^2)
+ * (the caller folds lambda, the 1/numel of each mean and the data-parallel share into the weights), and
+ * g_image/g_depth/g_normal/g_alpha receive dloss/d(raw rasterizer outputs); ssim_grad (optional, [B,3,H,W],
+ * w.r.t. the clamped image) is added before the clamp mask.  image[B,3,H,W] depth[B,1,H,W]|NULL
+ * normal[B,3,H,W]|NULL alpha[B,1,H,W] gt[B,3,H,W] mask[B,1,H,W] (mask_per_image != 0) or [1,H,W] shared.
+ * w_mse_host: B floats on the HOST (passed by value to the kernel).  loss_accum: 1 device float, added to. */
+int dimo_image_loss(int B, int H, int W, const float *image, const float *depth, const float *normal,
+                    const float *alpha, const float *gt, const float *mask, int mask_per_image,
+                    const float *w_mse_host, float w_mask, float w_smooth_x, float w_smooth_y, float w_bilat_x,
+                    float w_bilat_y, const float *ssim_grad, float *loss_accum, float *g_image, float *g_depth,
+                    float *g_normal, float *g_alpha, void *stream);
 
 /* ------------------------------------------------------------------ fused skinning (stage s2 of Renderer.render)
  * One kernel for renderer/latent_gs_renderer.py:1187-1219: LBS weights w_k = L1norm(exp(-d_k^2/(2 r_k^2)) + 1e-7),
@@ -156,7 +174,9 @@ int dimo_deform_forward(int N, int M, int local_frame, const float *xyz, const f
                         const float *opacity, const float *c_xyz, const float *c_log_radius, const float *d_xyz,
                         const float *d_rot, const float *nn_dist, const int64_t *nn_idx, float *out_xyz,
                         float *out_rot, float *out_scales, float *out_opacity, void *stream);
-int dimo_deform_backward(int N, int M, int local_frame, const float *xyz, const float *rotation,
+/* accumulate != 0: all eight gradient outputs are added to (a training step sums its renders' gradients
+ * directly in the flat gradient bucket) instead of overwritten. */
+int dimo_deform_backward(int N, int M, int local_frame, int accumulate, const float *xyz, const float *rotation,
                          const float *scaling, const float *opacity, const float *c_xyz, const float *c_log_radius,
                          const float *d_xyz, const float *d_rot, const float *nn_dist, const int64_t *nn_idx,
                          const float *g_out_xyz, const float *g_out_rot, const float *g_out_scales,

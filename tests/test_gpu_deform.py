@@ -46,6 +46,9 @@ def _compare(a, local_frame=True, seed=0):
     loss_g.backward()
     for k in names:
         r, o = cpu[k].grad, gpu[k].grad.cpu().double()
+        if r is None:  # input unused by this variant (c_xyz when local_frame=False): the kernel writes zeros
+            assert o.abs().max() == 0, k
+            continue
         rel = (o - r).abs().sum() / (r.abs().sum() + 1e-12)
         assert rel <= TOL, (k, rel.item())
 
@@ -84,7 +87,7 @@ def test_train_step_gpu_matches_cpu_oracle_pipeline():
     init_synthetic_model(rd, cfg.num_pts, cfg.num_cpts, seed=cfg.seed, num_latent=cfg.num_motions)
     gpu = Trainer(cfg, rd)
     p0 = cpu.renderer.gaussians.flat_params.clone()
-    assert torch.allclose(p0, rd.gaussians.flat_params.cpu(), atol=1e-6)
+    assert torch.allclose(p0, rd.gaussians.flat_params.cpu(), atol=2e-6)  # log(sqrt(dist2)) rounds per device
     # gradients of the first step (before Adam's sign-like normalisation amplifies rounding)
     for t in (cpu, gpu):
         t.optimizer.step = lambda: None
