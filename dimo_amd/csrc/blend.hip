@@ -2,12 +2,17 @@
 //
 // One workgroup (256 threads = 4 wave64) per 16x16 tile.  Each WAVE owns an 8x8 pixel quadrant
 // (not a 16x4 strip): splats are small and round, so an 8x8 footprint keeps more of a wave's
-// lanes doing the same thing and lets a whole wave skip a splat that misses its quadrant.
-// The tile's depth-sorted instance list is staged through LDS in batches of 256 records; all
-// lanes then read the same record (LDS broadcast, conflict-free).
+// lanes doing the same thing.  The tile's depth-sorted instance list is staged through LDS in
+// batches of 256 records (all lanes then read the same record: conflict-free LDS broadcast).
 //
-// Backward is atomic-free and deterministic: per (tile, instance) sums are reduced inside the
-// workgroup (DPP wave reduction -> LDS) and written as ONE 64-byte record per instance at the
+// Quadrant culling: while staging, the loading thread computes the bounding box of the region where the
+// splat's alpha can reach 1/255 (Mahalanobis radius^2 <= 2 ln(255 opacity)) and a 4-bit mask of the
+// quadrants it overlaps; every wave then compacts the batch into its own index list (ballot + popcount)
+// and only visits the records that can touch its 64 pixels.  The box is conservative, so results are
+// unchanged; at ~1e5 small splats per frame it removes most of the per-record rejection tests.
+//
+// Backward is free of global atomics: per (tile, instance) sums are reduced inside the workgroup
+// (DPP butterfly over the wave -> LDS) and written as ONE 64-byte record per instance at the
 // instance's emission position, so that the per-Gaussian kernel can sum a contiguous run.
 #include "common.hpp"
 
@@ -22,6 +27,40 @@ __device__ __forceinline__ void pixel_of_thread(int tile_x, int tile_y, int &px,
   py = tile_y * TILE + (wave >> 1) * 8 + (lane >> 3);
 }
 
+// 4-bit mask of the tile's 8x8 quadrants (bit = wave index) that the alpha >= 1/255 region of a splat
+// can reach.  Conservative: the threshold radius is inflated and half a pixel is added on each side.
+__device__ __forceinline__ uint32_t quadrant_mask(float gx, float gy, float A, float B, float C, float opacity,
+                                                  int tile_x, int tile_y) {
+  if (!(opacity * 255.0f >= 1.0f)) return 0u;  // alpha = min(.99, o * G) with G <= 1 can never reach 1/255
+  const float det = A * C - B * B;
+  if (!(det > 0.0f)) return 0xfu;  // degenerate conic: no culling
+  const float tau = 2.0f * __logf(opacity * 255.0f) * 1.02f + 0.05f;  // d_M^2 bound with slack for exp/log rounding
+  const float inv_det = 1.0f / det;
+  const float hx = sqrtf(tau * C * inv_det) + 0.5f, hy = sqrtf(tau * A * inv_det) + 0.5f;
+  const float x0 = (float)(tile_x * TILE), y0 = (float)(tile_y * TILE);
+  const bool left = gx - hx <= x0 + 7.0f && gx + hx >= x0;
+  const bool right = gx - hx <= x0 + 15.0f && gx + hx >= x0 + 8.0f;
+  const bool top = gy - hy <= y0 + 7.0f && gy + hy >= y0;
+  const bool bottom = gy - hy <= y0 + 15.0f && gy + hy >= y0 + 8.0f;
+  return (uint32_t)(left && top) | ((uint32_t)(right && top) << 1) | ((uint32_t)(left && bottom) << 2) |
+         ((uint32_t)(right && bottom) << 3);
+}
+
+// Every wave builds the ascending list of batch entries whose mask has its bit set.  Returns the count.
+__device__ __forceinline__ int compact_for_wave(const uint32_t *s_mask, uint16_t *my_list, int count, int wave,
+                                                int lane) {
+  int cnt = 0;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  for (int c = 0; c < count; c += 64) {
+    const int j = c + lane;
+    const bool hit = j < count && ((s_mask[j] >> wave) & 1u);
+    const unsigned long long bal = __ballot(hit);
+    if (hit) my_list[cnt + __popcll(bal & lt)] = (uint16_t)j;
+    cnt += __popcll(bal);
+  }
+  return cnt;
+}
+
 // ---------------------------------------------------------------------------------- forward
 template <bool NORMAL>
 __global__ void __launch_bounds__(BLEND_BLOCK) blend_fwd_kernel(
@@ -33,9 +72,12 @@ __global__ void __launch_bounds__(BLEND_BLOCK) blend_fwd_kernel(
   __shared__ float4 s_col[BATCH];   // C opacity r g
   __shared__ float4 s_aux[BATCH];   // b depth nx ny
   __shared__ float s_nz[BATCH];
+  __shared__ uint32_t s_mask[BATCH];
+  __shared__ uint16_t s_list[BLEND_BLOCK / 64][BATCH];
 
   const int tile = blockIdx.x;
   const int tile_x = tile % tiles_x, tile_y = tile / tiles_x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int px, py;
   pixel_of_thread(tile_x, tile_y, px, py);
   const bool inside = px < W && py < H;
@@ -57,11 +99,14 @@ __global__ void __launch_bounds__(BLEND_BLOCK) blend_fwd_kernel(
       s_col[threadIdx.x] = b;
       s_aux[threadIdx.x] = c;
       if (NORMAL) s_nz[threadIdx.x] = rp[3].x;
+      s_mask[threadIdx.x] = quadrant_mask(a.x, a.y, a.z, a.w, b.x, b.y, tile_x, tile_y);
     }
     __syncthreads();
     const int count = (int)min((uint32_t)BATCH, hi - start);
-    for (int j = 0; j < count; ++j) {
+    const int mine = compact_for_wave(s_mask, s_list[wave], count, wave, lane);
+    for (int t = 0; t < mine; ++t) {
       if (__ballot(!done) == 0) break;  // whole wave finished
+      const int j = __builtin_amdgcn_readfirstlane((int)s_list[wave][t]);
       if (done) continue;
       const float4 g = s_geo[j];
       const float4 c = s_col[j];
@@ -102,23 +147,43 @@ __global__ void __launch_bounds__(BLEND_BLOCK) blend_fwd_kernel(
 }
 
 // ---------------------------------------------------------------------------------- backward
-// wave64 sum via DPP (no LDS traffic): row_shr 1,2,4,8 then row_bcast15/31; total lands in lane 63.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_add(float v) {
-  const int moved = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false);
-  return v + __builtin_bit_cast(float, moved);
+// DPP helpers.  update_dpp(old, src, ctrl, row_mask, bank_mask, bound_ctrl): lane l reads src of the lane the
+// control selects; lanes whose source is out of range keep `old` (= 0 here).
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
 }
-__device__ __forceinline__ float wave_sum_to_lane63(float v) {
-  v = dpp_add<0x111, 0xf>(v);  // row_shr:1
-  v = dpp_add<0x112, 0xf>(v);  // row_shr:2
-  v = dpp_add<0x114, 0xf>(v);  // row_shr:4
-  v = dpp_add<0x118, 0xf>(v);  // row_shr:8
-  v = dpp_add<0x142, 0xa>(v);  // row_bcast:15 -> rows 1,3
-  v = dpp_add<0x143, 0xc>(v);  // row_bcast:31 -> rows 2,3
-  return v;
-}
+constexpr int DPP_QUAD_XOR1 = 0xB1;  // quad_perm:[1,0,3,2]
+constexpr int DPP_QUAD_XOR2 = 0x4E;  // quad_perm:[2,3,0,1]
+constexpr int DPP_ROW_SHR4 = 0x114;
+constexpr int DPP_ROW_SHR8 = 0x118;
 
-constexpr int NACC = 13;  // m0 mx my mxx mxy myy + 7 feature grads
+constexpr int NACC = 13;  // m0 mx my mxx mxy myy + 7 feature grads (padded to 16 for the butterfly)
+
+// Wave reduction of 16 values per lane down to row sums in ~48 VALU instead of 16 x 6:
+//   step 1 (lane ^ 1): each lane keeps 8 of the 16 values and adds its partner's copy of those;
+//   step 2 (lane ^ 2): keeps 4 of the 8;   steps 3-4 (row_shr 4, 8): plain adds on the 4 survivors.
+// After step 1 slot s (0..7) of a lane with bit0 = b holds value 8b + s; after step 2 slot t (0..3) of a lane
+// with (bit1, bit0) = (c, b) holds value 8b + 4c + t.  Lanes 12..15 of every row end up with the ROW sums.
+__device__ __forceinline__ void butterfly16(const float (&v)[16], int lane, float (&out)[4]) {
+  const bool b0 = lane & 1, b1 = lane & 2;
+  float h[8];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    const float keep = b0 ? v[8 + s] : v[s];
+    const float send = b0 ? v[s] : v[8 + s];
+    h[s] = keep + dpp_mov<DPP_QUAD_XOR1>(send);
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const float keep = b1 ? h[4 + t] : h[t];
+    const float send = b1 ? h[t] : h[4 + t];
+    float r = keep + dpp_mov<DPP_QUAD_XOR2>(send);
+    r += dpp_mov<DPP_ROW_SHR4>(r);
+    r += dpp_mov<DPP_ROW_SHR8>(r);
+    out[t] = r;  // valid in lanes 12..15 of every row
+  }
+}
 
 template <bool NORMAL>
 __global__ void __launch_bounds__(BLEND_BLOCK) blend_bwd_kernel(
@@ -132,6 +197,8 @@ __global__ void __launch_bounds__(BLEND_BLOCK) blend_bwd_kernel(
   __shared__ float4 s_aux[BATCH];
   __shared__ float s_nz[BATCH];
   __shared__ uint32_t s_emit[BATCH];
+  __shared__ uint32_t s_mask[BATCH];
+  __shared__ uint16_t s_list[BLEND_BLOCK / 64][BATCH];
   __shared__ float s_acc[BATCH][16];
   __shared__ uint32_t s_max[BLEND_BLOCK / 64];
 
@@ -186,10 +253,12 @@ __global__ void __launch_bounds__(BLEND_BLOCK) blend_bwd_kernel(
     if ((int)threadIdx.x < count) {
       const uint32_t g = vals_sorted[lo + blo + threadIdx.x];
       const float4 *rp = reinterpret_cast<const float4 *>(splat + g);
-      s_geo[threadIdx.x] = rp[0];
-      s_col[threadIdx.x] = rp[1];
+      const float4 a = rp[0], b = rp[1];
+      s_geo[threadIdx.x] = a;
+      s_col[threadIdx.x] = b;
       s_aux[threadIdx.x] = rp[2];
       if (NORMAL) s_nz[threadIdx.x] = rp[3].x;
+      s_mask[threadIdx.x] = quadrant_mask(a.x, a.y, a.z, a.w, b.x, b.y, tile_x, tile_y);
       const uint2 rc = *reinterpret_cast<const uint2 *>(rect + 4 * (size_t)g);
       const int x0 = rc.x & 0xffff, y0 = rc.x >> 16, x1 = rc.y & 0xffff;
       s_emit[threadIdx.x] = (g == 0 ? 0u : offsets[g - 1]) + (uint32_t)((tile_y - y0) * (x1 - x0) + (tile_x - x0));
@@ -197,8 +266,10 @@ __global__ void __launch_bounds__(BLEND_BLOCK) blend_bwd_kernel(
 #pragma unroll
     for (int k = 0; k < 16; ++k) s_acc[threadIdx.x][k] = 0.0f;
     __syncthreads();
+    const int mine = compact_for_wave(s_mask, s_list[wave], count, wave, lane);
 
-    for (int j = count - 1; j >= 0; --j) {
+    for (int t = mine - 1; t >= 0; --t) {
+      const int j = __builtin_amdgcn_readfirstlane((int)s_list[wave][t]);
       const float4 g = s_geo[j];
       const float4 c = s_col[j];
       const float dx = g.x - pxf, dy = g.y - pyf;
@@ -207,17 +278,17 @@ __global__ void __launch_bounds__(BLEND_BLOCK) blend_bwd_kernel(
       const float alpha = fminf(ALPHA_MAX, c.y * G);
       const bool active = (blo + (uint32_t)j < last) && power <= 0.0f && alpha >= ALPHA_MIN;
       if (__ballot(active) == 0) continue;  // wave-uniform skip
-      float v[NACC];
+      float v[16];
 #pragma unroll
-      for (int k = 0; k < NACC; ++k) v[k] = 0.0f;
+      for (int k = 0; k < 16; ++k) v[k] = 0.0f;
       if (active) {
         const float4 a = s_aux[j];
-        const float one_m = 1.0f - alpha;
-        T = T / one_m;
+        const float rinv = __builtin_amdgcn_rcpf(1.0f - alpha);
+        T *= rinv;
         const float w = alpha * T;
         float D = dp[7] + c.z * dp[0] + c.w * dp[1] + a.x * dp[2] + a.y * dp[3];
         if (NORMAL) D += a.z * dp[4] + a.w * dp[5] + s_nz[j] * dp[6];
-        const float dL_dalpha_i = D * T - Q / one_m;
+        const float dL_dalpha_i = D * T - Q * rinv;
         Q += D * w;
         const float gg = G * c.y * dL_dalpha_i;  // g = G * dL/dG, dL/dG = opacity * dL/dalpha
         v[0] = gg, v[1] = gg * dx, v[2] = gg * dy;
@@ -225,12 +296,14 @@ __global__ void __launch_bounds__(BLEND_BLOCK) blend_bwd_kernel(
         v[6] = w * dp[0], v[7] = w * dp[1], v[8] = w * dp[2], v[9] = w * dp[3];
         if (NORMAL) v[10] = w * dp[4], v[11] = w * dp[5], v[12] = w * dp[6];
       }
-      constexpr int NV = NORMAL ? NACC : 10;
+      float red[4];
+      butterfly16(v, lane, red);
+      // lanes 12..15 of each row hold row sums; lane (12 + q) owns values 8*(q&1) + 4*(q>>1) + t, t = 0..3
+      if ((lane & 15) >= 12) {
+        const int q = lane & 3;
+        const int base = 8 * (q & 1) + 4 * (q >> 1);
 #pragma unroll
-      for (int k = 0; k < NV; ++k) v[k] = wave_sum_to_lane63(v[k]);
-      if (lane == 63) {
-#pragma unroll
-        for (int k = 0; k < NV; ++k) atomicAdd(&s_acc[j][k], v[k]);
+        for (int t4 = 0; t4 < 4; ++t4) atomicAdd(&s_acc[j][base + t4], red[t4]);
       }
     }
     __syncthreads();
@@ -302,7 +375,8 @@ extern "C" int dimo_raster_backward(int N, int sh_degree, int M, int H, int W, i
   if (N > 0 && (!means3D || !radii || !dL_dmeans3D || !dL_dmeans2D || !dL_dopacity)) return DIMO_E_ARG;
   if (N > 0 && shs && !dL_dshs) return DIMO_E_ARG;
   if (N > 0 && colors_precomp && !dL_dcolors) return DIMO_E_ARG;
-  if (N > 0 && (cov3D_precomp ? !dL_dcov3D : (!dL_dscales || !dL_drotations || !scales || !rotations))) return DIMO_E_ARG;
+  if (N > 0 && (cov3D_precomp ? !dL_dcov3D : (!dL_dscales || !dL_drotations || !scales || !rotations)))
+    return DIMO_E_ARG;
   if (scratch_bytes < dimo_raster_backward_scratch_bytes(N, R_cap)) return DIMO_E_WORKSPACE;
   GeomLayout G(N);
   BinLayout B(R_cap, H, W);

@@ -258,10 +258,21 @@ __global__ void __launch_bounds__(256) lbs_reduce_kernel(int M, int nblocks, int
                                                          const float *__restrict__ partials,
                                                          float *__restrict__ d_c_xyz, float *__restrict__ d_c_lr,
                                                          float *__restrict__ d_d_xyz, float *__restrict__ d_d_rot) {
-  const int j = blockIdx.x * 256 + threadIdx.x;
-  if (j >= M * CP_STRIDE) return;
+  // A workgroup owns 16 consecutive outputs; thread (jj = tid & 15, chunk = tid >> 4) sums tables chunk,
+  // chunk+16, ... for output j0 + jj (16 lanes read 64 contiguous bytes), then the 16 chunk sums are added
+  // in a fixed order through LDS -> deterministic, and M*11/16 workgroups keep every CU busy.
+  __shared__ float s_part[16][17];
+  const int jj = threadIdx.x & 15, chunk = threadIdx.x >> 4;
+  const int j = blockIdx.x * 16 + jj;
   float s = 0.f;
-  for (int b = 0; b < nblocks; ++b) s += partials[(size_t)b * M * CP_STRIDE + j];
+  if (j < M * CP_STRIDE)
+    for (int b = chunk; b < nblocks; b += 16) s += partials[(size_t)b * M * CP_STRIDE + j];
+  s_part[chunk][jj] = s;
+  __syncthreads();
+  if (chunk != 0 || j >= M * CP_STRIDE) return;
+  s = 0.f;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) s += s_part[k][jj];
   const int m = j / CP_STRIDE, c = j % CP_STRIDE;
   float *dst;
   if (c < 3) dst = d_c_xyz + 3 * m + c;
@@ -369,7 +380,7 @@ extern "C" int dimo_deform_backward(int N, int M, int local_frame, int accumulat
     else DIMO_LAUNCH_LBS_BWD(false, false);
 #undef DIMO_LAUNCH_LBS_BWD
   }
-  hipLaunchKernelGGL(lbs_reduce_kernel, dim3((M * CP_STRIDE + 255) / 256), dim3(256), 0, stream, M, grid,
+  hipLaunchKernelGGL(lbs_reduce_kernel, dim3((M * CP_STRIDE + 15) / 16), dim3(256), 0, stream, M, grid,
                      accumulate ? 1 : 0, reinterpret_cast<const float *>(scratch), dL_dc_xyz, dL_dc_log_radius,
                      dL_dd_xyz, dL_dd_rot);
   return check_launch();
