@@ -154,6 +154,18 @@ def test_edge_cases_empty_culled_offscreen():
     _check_forward(sc, cam, (0.5, 0.5, 0.5), 0)
 
 
+@pytest.mark.parametrize("N", [2500, 9000])
+def test_long_tile_lists_with_depth_ties(N):
+    """Every Gaussian covers every tile (per-tile lists of N instances, multi-block sort) and half of them
+    share their depth with another one: the order must still be the published stable order."""
+    cam = camera_np(15.0, W=48, H=32)
+    sc = random_scene(N, seed=N, scale=0.5, opacity=(0.01, 0.05))
+    sc["means3D"] *= 0.2
+    sc["means3D"][N // 2:] = sc["means3D"][: N - N // 2]  # ties in depth -> order decided by Gaussian id
+    res, st, o = _check_forward(sc, cam, (0.3, 0.3, 0.3), 0)
+    assert (o["ranges"][:, 1] - o["ranges"][:, 0]).max() >= 0.9 * N
+
+
 def _rel_l1(a, b):
     return np.abs(a - b).sum() / (np.abs(b).sum() + 1e-12)
 

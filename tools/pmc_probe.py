@@ -1,0 +1,20 @@
+"""Workload for the rocprofv3 --pmc passes: a calibration copy of known size (1 GiB read + 1 GiB write with
+16-byte lanes) followed by a few training steps of the bench workload.  See tools/pmc_summarise.py."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+import bench
+
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+src = torch.empty(1 << 28, dtype=torch.float32, device=dev).normal_()
+for _ in range(3):
+    dst = src.clone()  # vectorized copy kernel: 1 GiB in, 1 GiB out
+torch.cuda.synchronize()
+tr, pol = bench.make_trainer(dev, 0, 1, 100000, 512)
+for _ in range(4):
+    tr.train_step()
+torch.cuda.synchronize()
