@@ -24,7 +24,9 @@ def main():
     find = lambda d, pat: next((v for k, v in d.items() if pat in k), [])
     mean = lambda xs: sum(xs) / len(xs) if xs else None
     GiB_KiB = float(1 << 20)
-    cal_f, cal_w = mean(find(fetch, "direct_copy")) or mean(find(fetch, "copy")), mean(find(write, "direct_copy")) or mean(find(write, "copy"))
+    # the 1 GiB clone runs as __amd_rocclr_copyBuffer: take its largest dispatches (other copies are tiny)
+    big = lambda d: [v for v in find(d, "__amd_rocclr_copyBuffer") if v > 100000.0]
+    cal_f, cal_w = mean(big(fetch)), mean(big(write))
     res = {"units": "bytes per launch", "calibration": {"kernel": "torch clone of 1 GiB (1 GiB read + 1 GiB write)",
                                                          "FETCH_SIZE_KiB": cal_f, "WRITE_SIZE_KiB": cal_w}}
     kf = (GiB_KiB / cal_f) if cal_f else 2.0
