@@ -191,7 +191,8 @@ __global__ void __launch_bounds__(BLEND_BLOCK) blend_bwd_kernel(
     const uint32_t *__restrict__ vals_sorted, const Splat *__restrict__ splat, const uint16_t *__restrict__ rect,
     const uint32_t *__restrict__ offsets, const float *__restrict__ bg, const float *__restrict__ final_T,
     const uint32_t *__restrict__ n_contrib, const float *__restrict__ dL_dcolor, const float *__restrict__ dL_ddepth,
-    const float *__restrict__ dL_dnormal, const float *__restrict__ dL_dalpha, SplatGrad *__restrict__ inst_grad) {
+    const float *__restrict__ dL_dnormal, const float *__restrict__ dL_dalpha, SplatGrad *__restrict__ inst_grad,
+    uint8_t *__restrict__ inst_flag) {
   __shared__ float4 s_geo[BATCH];
   __shared__ float4 s_col[BATCH];
   __shared__ float4 s_aux[BATCH];
@@ -233,18 +234,8 @@ __global__ void __launch_bounds__(BLEND_BLOCK) blend_bwd_kernel(
   __syncthreads();
   const uint32_t max_last = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
 
-  // instances never reached by any pixel of the tile: zero records
-  for (uint32_t i = max_last + threadIdx.x; i < hi - lo; i += BLEND_BLOCK) {
-    const uint32_t g = vals_sorted[lo + i];
-    const uint2 rc = *reinterpret_cast<const uint2 *>(rect + 4 * (size_t)g);
-    const int x0 = rc.x & 0xffff, y0 = rc.x >> 16, x1 = rc.y & 0xffff;
-    const uint32_t e = (g == 0 ? 0u : offsets[g - 1]) + (uint32_t)((tile_y - y0) * (x1 - x0) + (tile_x - x0));
-    if (e < R_cap) {
-      float4 *dst = reinterpret_cast<float4 *>(inst_grad + e);
-      const float4 z = make_float4(0, 0, 0, 0);
-      dst[0] = z, dst[1] = z, dst[2] = z, dst[3] = z;
-    }
-  }
+  // Instances no pixel reaches (behind the saturation depth of the whole tile, or culled) are the majority in a
+  // trained scene: they get no record at all -- inst_flag (zeroed by one small memset) stays 0 for them.
 
   for (uint32_t top = max_last; top > 0;) {
     const uint32_t blo = top > BATCH ? top - BATCH : 0u;
@@ -309,10 +300,15 @@ __global__ void __launch_bounds__(BLEND_BLOCK) blend_bwd_kernel(
     __syncthreads();
     if ((int)threadIdx.x < count) {
       const uint32_t e = s_emit[threadIdx.x];
-      if (e < R_cap) {
-        const float4 *src = reinterpret_cast<const float4 *>(&s_acc[threadIdx.x][0]);
+      const float4 *src = reinterpret_cast<const float4 *>(&s_acc[threadIdx.x][0]);
+      const float4 r0 = src[0], r1 = src[1], r2 = src[2], r3 = src[3];
+      const bool any = r0.x != 0.f || r0.y != 0.f || r0.z != 0.f || r0.w != 0.f || r1.x != 0.f || r1.y != 0.f ||
+                       r1.z != 0.f || r1.w != 0.f || r2.x != 0.f || r2.y != 0.f || r2.z != 0.f || r2.w != 0.f ||
+                       r3.x != 0.f;
+      if (e < R_cap && any) {
         float4 *dst = reinterpret_cast<float4 *>(inst_grad + e);
-        dst[0] = src[0], dst[1] = src[1], dst[2] = src[2], dst[3] = src[3];
+        dst[0] = r0, dst[1] = r1, dst[2] = r2, dst[3] = r3;
+        inst_flag[e] = 1;
       }
     }
     top = blo;
@@ -351,9 +347,11 @@ extern "C" int dimo_raster_render_forward(int N, int H, int W, int64_t R_cap, co
   return check_launch();
 }
 
+// scratch = [R_cap x 64-byte SplatGrad records][R_cap x 1-byte "record written" flags]
 extern "C" size_t dimo_raster_backward_scratch_bytes(int N, int64_t R_cap) {
   (void)N;
-  return align_up((size_t)(R_cap > 0 ? R_cap : 1) * sizeof(SplatGrad));
+  const size_t cap = (size_t)(R_cap > 0 ? R_cap : 1);
+  return align_up(cap * sizeof(SplatGrad)) + align_up(cap);
 }
 
 extern "C" int dimo_raster_backward(int N, int sh_degree, int M, int H, int W, int64_t R_cap, const float *means3D,
@@ -383,18 +381,20 @@ extern "C" int dimo_raster_backward(int N, int sh_degree, int M, int H, int W, i
   ImgLayout I(H, W);
   const uint32_t cap = (uint32_t)B.cap;
   SplatGrad *inst = reinterpret_cast<SplatGrad *>(scratch);
+  uint8_t *inst_flag = reinterpret_cast<uint8_t *>(scratch) + align_up(B.cap * sizeof(SplatGrad));
   if (N > 0) {
     ScopedTimer tm(T_BLEND_BWD, stream);
+    if (hipMemsetAsync(inst_flag, 0, B.cap, stream) != hipSuccess) return DIMO_E_LAUNCH;
     if (dL_dnormal)
       hipLaunchKernelGGL(blend_bwd_kernel<true>, dim3(B.T), dim3(BLEND_BLOCK), 0, stream, H, W, B.tiles_x, cap,
                          at<uint32_t>(bin, B.ranges), at<uint32_t>(bin, B.vals_b), at<Splat>(geom, G.splat),
                          at<uint16_t>(geom, G.rect), at<uint32_t>(geom, G.offsets), bg, at<float>(img, I.final_T),
-                         at<uint32_t>(img, I.n_contrib), dL_dcolor, dL_ddepth, dL_dnormal, dL_dalpha, inst);
+                         at<uint32_t>(img, I.n_contrib), dL_dcolor, dL_ddepth, dL_dnormal, dL_dalpha, inst, inst_flag);
     else
       hipLaunchKernelGGL(blend_bwd_kernel<false>, dim3(B.T), dim3(BLEND_BLOCK), 0, stream, H, W, B.tiles_x, cap,
                          at<uint32_t>(bin, B.ranges), at<uint32_t>(bin, B.vals_b), at<Splat>(geom, G.splat),
                          at<uint16_t>(geom, G.rect), at<uint32_t>(geom, G.offsets), bg, at<float>(img, I.final_T),
-                         at<uint32_t>(img, I.n_contrib), dL_dcolor, dL_ddepth, dL_dnormal, dL_dalpha, inst);
+                         at<uint32_t>(img, I.n_contrib), dL_dcolor, dL_ddepth, dL_dnormal, dL_dalpha, inst, inst_flag);
     int rc = check_launch();
     if (rc) return rc;
   }

@@ -243,6 +243,7 @@ __global__ void __launch_bounds__(PRE_BLOCK) preprocess_bwd_kernel(
     const float *__restrict__ Vg, const float *__restrict__ Pg, const float *__restrict__ camg, float tanfovx,
     float tanfovy, const int32_t *__restrict__ radii, const Splat *__restrict__ splat,
     const uint32_t *__restrict__ offsets, const uint8_t *__restrict__ flags, const SplatGrad *__restrict__ inst_grad,
+    const uint8_t *__restrict__ inst_flag,
     float *__restrict__ dL_dmeans3D, float *__restrict__ dL_dmeans2D, float *__restrict__ dL_dshs,
     float *__restrict__ dL_dcolors, float *__restrict__ dL_dopacity, float *__restrict__ dL_dscales,
     float *__restrict__ dL_drot, float *__restrict__ dL_dcov3D) {
@@ -264,6 +265,7 @@ __global__ void __launch_bounds__(PRE_BLOCK) preprocess_bwd_kernel(
     uint32_t lo = i == 0 ? 0u : offsets[i - 1], hi = offsets[i];
     lo = min(lo, R_cap), hi = min(hi, R_cap);
     for (uint32_t e = lo; e < hi; ++e) {
+      if (!inst_flag[e]) continue;  // instance not reached by any pixel: no record was written
       const float4 *rp = reinterpret_cast<const float4 *>(inst_grad + e);
       const float4 a = rp[0], b = rp[1], c = rp[2], d = rp[3];
       m0 += a.x, mx += a.y, my += a.z, mxx += a.w;
@@ -544,7 +546,10 @@ int dimo::preprocess_backward_launch(
                      (uint32_t)(R_cap > 0xffffffffLL ? 0xffffffffu : (uint32_t)R_cap), means3D, shs, colors_precomp,
                      scales, rotations, cov3D_precomp, scale_modifier, viewmatrix, projmatrix, campos, tanfovx,
                      tanfovy, radii, at<Splat>(geom, L.splat), at<uint32_t>(geom, L.offsets),
-                     at<uint8_t>(geom, L.flags), reinterpret_cast<const SplatGrad *>(inst_grad), dL_dmeans3D,
+                     at<uint8_t>(geom, L.flags), reinterpret_cast<const SplatGrad *>(inst_grad),
+                     reinterpret_cast<const uint8_t *>(inst_grad) +
+                         align_up((size_t)(R_cap > 0 ? R_cap : 1) * sizeof(SplatGrad)),
+                     dL_dmeans3D,
                      dL_dmeans2D, dL_dshs, dL_dcolors, dL_dopacity, dL_dscales, dL_drot, dL_dcov3D);
   return check_launch();
 }
