@@ -1,0 +1,101 @@
+// Adam over the flat parameter / gradient buckets in ONE launch (main_train_dimo.py:416-417,
+// renderer/latent_gs_renderer.py:460-476: torch.optim.Adam, 12 parameter groups, eps = 1e-15).
+//
+// PyTorch's fused Adam issues one multi-tensor launch per parameter group (10 launches of ~36 us for 2 M
+// parameters: launch-bound).  Every trainable tensor here is a view into one flat fp32 buffer, so the whole
+// update is a single streaming pass: read p, g, m, v / write p, m, v (+ g = 0): 32 bytes per parameter,
+// HBM-bound.  Per-group learning rates come from a small by-value segment table.  An optional device flag
+// (the rasterizer's "instance capacity overflow" word) turns the update into a no-op, so a step whose
+// gradients are invalid is skipped without the host ever waiting for the device.
+#include "common.hpp"
+
+namespace dimo {
+
+constexpr int ADAM_MAX_SEG = 32;
+struct AdamSegs {
+  int n;
+  long long end[ADAM_MAX_SEG];  // exclusive end offset of segment k (segments are contiguous from 0)
+  float lr[ADAM_MAX_SEG];
+};
+
+__global__ void __launch_bounds__(256) flat_adam_kernel(long long n, float *__restrict__ p, float *__restrict__ g,
+                                                        float *__restrict__ m, float *__restrict__ v, AdamSegs segs,
+                                                        float beta1, float beta2, float eps, float inv_bc1,
+                                                        float inv_sqrt_bc2, const int *__restrict__ skip_flags,
+                                                        int n_flags, int flag_stride, int zero_grad) {
+  bool skip = false;
+  for (int k = 0; k < n_flags; ++k) skip |= skip_flags[(size_t)k * flag_stride] != 0;
+  const long long stride = (long long)gridDim.x * 256 * 4;
+  for (long long i0 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4; i0 < n; i0 += stride) {
+    if (i0 + 3 < n) {
+      float4 gp = *reinterpret_cast<float4 *>(g + i0);
+      if (!skip) {
+        float4 pp = *reinterpret_cast<float4 *>(p + i0), mm = *reinterpret_cast<float4 *>(m + i0);
+        float4 vv = *reinterpret_cast<float4 *>(v + i0);
+        float *P = &pp.x, *G = &gp.x, *Mm = &mm.x, *V = &vv.x;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          int s = 0;
+          while (s + 1 < segs.n && i0 + c >= segs.end[s]) ++s;
+          const float lr = segs.lr[s];
+          Mm[c] = Mm[c] + (G[c] - Mm[c]) * (1.0f - beta1);
+          V[c] = V[c] * beta2 + (1.0f - beta2) * G[c] * G[c];
+          const float denom = sqrtf(V[c]) * inv_sqrt_bc2 + eps;
+          P[c] = P[c] - (lr * inv_bc1) * (Mm[c] / denom);
+        }
+        *reinterpret_cast<float4 *>(p + i0) = pp;
+        *reinterpret_cast<float4 *>(m + i0) = mm;
+        *reinterpret_cast<float4 *>(v + i0) = vv;
+      }
+      if (zero_grad) *reinterpret_cast<float4 *>(g + i0) = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+      for (long long i = i0; i < n; ++i) {
+        if (!skip) {
+          int s = 0;
+          while (s + 1 < segs.n && i >= segs.end[s]) ++s;
+          const float gi = g[i];
+          const float mi = m[i] + (gi - m[i]) * (1.0f - beta1);
+          const float vi = v[i] * beta2 + (1.0f - beta2) * gi * gi;
+          m[i] = mi, v[i] = vi;
+          p[i] = p[i] - (segs.lr[s] * inv_bc1) * (mi / (sqrtf(vi) * inv_sqrt_bc2 + eps));
+        }
+        if (zero_grad) g[i] = 0.f;
+      }
+    }
+  }
+}
+
+}  // namespace dimo
+
+using namespace dimo;
+
+extern "C" int dimo_flat_adam_step(int64_t n, float *params, float *grads, float *exp_avg, float *exp_avg_sq,
+                                   int n_segments, const int64_t *segment_end_host, const float *segment_lr_host,
+                                   float beta1, float beta2, float eps, int64_t step, const int *skip_flags,
+                                   int n_flags, int flag_stride, int zero_grad, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  clear_errors();
+  if (n < 0 || n_segments < 1 || n_segments > ADAM_MAX_SEG || step < 1 || n_flags < 0) return DIMO_E_ARG;
+  if (n == 0) return DIMO_OK;
+  if (!params || !grads || !exp_avg || !exp_avg_sq || !segment_end_host || !segment_lr_host) return DIMO_E_ARG;
+  if (n_flags > 0 && !skip_flags) return DIMO_E_ARG;
+  if ((reinterpret_cast<uintptr_t>(params) | reinterpret_cast<uintptr_t>(grads) |
+       reinterpret_cast<uintptr_t>(exp_avg) | reinterpret_cast<uintptr_t>(exp_avg_sq)) & 15)
+    return DIMO_E_ARG;  // float4 path needs 16-byte aligned buckets
+  AdamSegs segs;
+  segs.n = n_segments;
+  for (int k = 0; k < ADAM_MAX_SEG; ++k) {
+    segs.end[k] = k < n_segments ? (long long)segment_end_host[k] : (long long)n;
+    segs.lr[k] = k < n_segments ? segment_lr_host[k] : 0.0f;
+  }
+  if (segs.end[n_segments - 1] != n) return DIMO_E_ARG;
+  const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+  long long blocks = (n / 4 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  ScopedTimer tm(T_ADAM, stream);
+  hipLaunchKernelGGL(flat_adam_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (long long)n, params, grads,
+                     exp_avg, exp_avg_sq, segs, beta1, beta2, eps, (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)),
+                     skip_flags, n_flags, flag_stride, zero_grad);
+  return check_launch();
+}

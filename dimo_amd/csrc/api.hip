@@ -47,7 +47,7 @@ bool g_on = false;
 std::vector<Rec> g_recs;
 const char *const g_names[TIMED_COUNT] = {"preprocess_fwd", "scan", "emit",     "sort",     "ranges",  "blend_fwd",
                                           "blend_bwd",      "preprocess_bwd", "knn", "dist2", "ssim_fwd", "ssim_bwd",
-                                          "deform_fwd",     "deform_bwd", "image_loss"};
+                                          "deform_fwd",     "deform_bwd", "image_loss", "adam"};
 }  // namespace
 
 ScopedTimer::ScopedTimer(int id, hipStream_t s) : id_(id), stream_(s), a_(nullptr), b_(nullptr) {

@@ -22,6 +22,7 @@ SOURCES = {
     "ssim.hip": [],
     "deform.hip": [],
     "image_loss.hip": [],
+    "adam.hip": [],
 }
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
 

@@ -1,0 +1,69 @@
+"""`FlatAdam`: torch.optim.Adam semantics (renderer/latent_gs_renderer.py:460-476: 12 named groups, lr set per
+step by `update_learning_rate`, eps 1e-15) executed as ONE HIP launch over the flat parameter / gradient buckets
+(`dimo_flat_adam_step`, dimo_amd/csrc/adam.hip) instead of one multi-tensor launch per group.
+
+It keeps the part of the optimizer interface the training path uses: `param_groups` (list of dicts with "name",
+"lr", "params"), `step()`, `zero_grad()`, `defaults`, `state_dict()` / `load_state_dict()` of the moment buffers.
+GPU only; the CPU/test path keeps torch.optim.Adam.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+
+class FlatAdam:
+    def __init__(self, groups, flat_params, flat_grads, betas=(0.9, 0.999), eps=1e-15):
+        if not flat_params.is_cuda:
+            raise RuntimeError("FlatAdam needs the flat buckets on the GPU (no CPU fallback in the product path)")
+        self.param_groups = groups
+        self.defaults = dict(lr=0.0, betas=betas, eps=eps)
+        self.flat_params, self.flat_grads = flat_params, flat_grads
+        self.exp_avg = torch.zeros_like(flat_params)
+        self.exp_avg_sq = torch.zeros_like(flat_params)
+        self.step_count = 0
+        # groups must tile the bucket contiguously, in order (GaussianModel.flatten_parameters builds it that way)
+        base = flat_params.data_ptr()
+        ends, o = [], 0
+        for g in groups:
+            for p in g["params"]:
+                if p.numel() == 0:
+                    continue
+                assert p.data_ptr() == base + 4 * o, "parameter is not a view of the flat bucket in group order"
+                o += p.numel()
+            ends.append(o)
+        assert o == flat_params.numel()
+        self._ends = (C.c_int64 * len(ends))(*ends)
+        self._n_seg = len(ends)
+
+    def step(self, skip_flags=None, zero_grad=False):
+        """skip_flags: optional int32 tensor [k, 2] (rasterizer `total` words: R, overflow) -- any non-zero
+        overflow word turns this step into a no-op on the device."""
+        self.step_count += 1
+        lrs = (C.c_float * self._n_seg)(*[float(g["lr"]) for g in self.param_groups])
+        b1, b2 = self.defaults["betas"]
+        if skip_flags is not None and skip_flags.numel() > 0:
+            assert skip_flags.dtype == torch.int32 and skip_flags.is_contiguous()
+            if skip_flags.dim() == 2 and skip_flags.shape[-1] == 2:  # rasterizer `total` words (R, overflow)
+                fptr, nfl, fstride = skip_flags.data_ptr() + 4, skip_flags.shape[0], 2
+            else:  # plain flag words
+                fptr, nfl, fstride = skip_flags.data_ptr(), skip_flags.numel(), 1
+        else:
+            fptr, nfl, fstride = None, 0, 1
+        _lib.check(_lib.lib().dimo_flat_adam_step(
+            self.flat_params.numel(), _lib.ptr(self.flat_params), _lib.ptr(self.flat_grads), _lib.ptr(self.exp_avg),
+            _lib.ptr(self.exp_avg_sq), self._n_seg, self._ends, lrs, b1, b2, self.defaults["eps"], self.step_count,
+            fptr, nfl, fstride, int(bool(zero_grad)), _lib.current_stream()), "dimo_flat_adam_step")
+
+    def zero_grad(self, set_to_none=False):
+        self.flat_grads.zero_()
+
+    def state_dict(self):
+        return {"step": self.step_count, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq,
+                "lrs": [g["lr"] for g in self.param_groups]}
+
+    def load_state_dict(self, sd):
+        self.step_count = int(sd["step"])
+        self.exp_avg.copy_(sd["exp_avg"])
+        self.exp_avg_sq.copy_(sd["exp_avg_sq"])

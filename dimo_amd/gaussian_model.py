@@ -210,7 +210,11 @@ class GaussianModel:
         params = [p for g in groups for p in g["params"] if p.numel() > 0]
         total = sum(p.numel() for p in params)
         flat = torch.empty(total, dtype=torch.float32, device=self.device)
-        grads = torch.zeros(total, dtype=torch.float32, device=self.device)
+        # 4 extra floats ride along with the gradient bucket (and its all-reduce): [0] = "some render of this
+        # step overflowed its instance capacity on some rank" -> every replica skips the update together
+        self.flat_grads_ext = torch.zeros(total + 4, dtype=torch.float32, device=self.device)
+        grads = self.flat_grads_ext[:total]
+        self.grad_flag = self.flat_grads_ext[total:total + 1]
         o = 0
         with torch.no_grad():
             for p in params:
@@ -230,12 +234,13 @@ class GaussianModel:
         groups = self.param_groups(training_args)
         groups = [g for g in groups if all(p.numel() > 0 for p in g["params"])]
         self.flatten_parameters(groups)
-        kw = {}
         if fused is None:
-            fused = self.device.type == "cuda"
-        if fused:
-            kw["fused"] = True
-        self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15, **kw)
+            fused = "flat" if self.device.type == "cuda" else False
+        if fused == "flat":  # one HIP launch over the flat bucket (dimo_amd/csrc/adam.hip)
+            from .flat_adam import FlatAdam
+            self.optimizer = FlatAdam(groups, self.flat_params, self.flat_grads, eps=1e-15)
+        else:
+            self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15, **({"fused": True} if fused else {}))
         self.lr_setup(training_args)
 
     def zero_grad(self):

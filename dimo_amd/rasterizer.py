@@ -62,6 +62,13 @@ class CapacityPolicy:
     def track(self, total_view):
         self._pending.append(total_view)
 
+    def _update(self, tot):
+        r_max = int(tot[:, 0].max())
+        self.last_r_mean, self.last_r_max = float(tot[:, 0].float().mean()), r_max
+        ok = int(tot[:, 1].max()) == 0
+        self.capacity = max(self.capacity if ok else 0, int(r_max * self.margin) + 1024)
+        return ok
+
     def check(self):
         """One host sync for all renders since the last call. Returns True if every render fitted;
         on overflow the capacity is raised and the caller must redo the step."""
@@ -69,11 +76,33 @@ class CapacityPolicy:
             return True
         tot = torch.stack(self._pending).cpu()
         self._pending = []
-        r_max = int(tot[:, 0].max())
-        self.last_r_mean, self.last_r_max = float(tot[:, 0].float().mean()), r_max
-        ok = int(tot[:, 1].max()) == 0
-        self.capacity = max(self.capacity if ok else 0, int(r_max * self.margin) + 1024)
-        return ok
+        return self._update(tot)
+
+    def collect_async(self):
+        """Sync-free variant: returns the stacked device words [k, 2] (R, overflow) of the renders since the last
+        call (for device-side consumers, e.g. the optimizer's skip flag) and starts a pinned-memory copy that
+        `poll()` evaluates later."""
+        if not self._pending:
+            return None
+        tot = torch.stack(self._pending)
+        self._pending = []
+        host = torch.empty(tot.shape, dtype=tot.dtype, pin_memory=True)
+        host.copy_(tot, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._inflight = getattr(self, "_inflight", [])
+        self._inflight.append((host, ev))
+        return tot
+
+    def poll(self):
+        """Evaluates finished asynchronous copies. Returns the number of steps that had overflowed."""
+        bad = 0
+        for host, ev in getattr(self, "_inflight", []):
+            ev.synchronize()  # recorded a whole step ago: already complete in steady state
+            if not self._update(host):
+                bad += 1
+        self._inflight = []
+        return bad
 
 
 def _f32c(t):

@@ -117,6 +117,8 @@ class Trainer:
         self._consts = {}
         self._deform_batch = None
         self._side = None
+        self.skipped_steps = 0
+        self._flat_adam = type(self.optimizer).__name__ == "FlatAdam"
         # direct HIP pipeline: GPU, stage s2, degree-0 colour (DIMO's configuration), product rasterizer
         self.direct = (direct if direct is not None else True) and self.device.type == "cuda" \
             and cfg.stage >= "s2" and cfg.sh_degree == 0 and renderer._rasterizer_factory is None \
@@ -183,8 +185,9 @@ class Trainer:
         return loss
 
     def all_reduce_grads(self):
+        """ONE collective per step: the flat gradient bucket (+ its 4-float tail carrying the overflow flag)."""
         if self.world > 1:
-            dist.all_reduce(self.renderer.gaussians.flat_grads, op=dist.ReduceOp.SUM, group=self.pg)
+            dist.all_reduce(self.renderer.gaussians.flat_grads_ext, op=dist.ReduceOp.SUM, group=self.pg)
 
     # ------------------------------------------------------------------ forward + backward, two ways
     def _forward_backward_autograd(self, mine, n_img):
@@ -357,6 +360,11 @@ class Trainer:
     def train_step(self, triples=None):
         """Runs one optimisation step; returns the number of renders THIS rank performed."""
         c, g = self.cfg, self.renderer.gaussians
+        if self._flat_adam and self.renderer.capacity is not None:
+            bad = self.renderer.capacity.poll()  # last step's instance counts (copied asynchronously)
+            if bad:  # that update was skipped on the device; the capacity bound has been raised
+                self.skipped_steps += bad
+                self.optimizer.step_count -= bad
         self.step += 1
         g.update_learning_rate(self.step, self.stage)
         if self.stage >= "s2":
@@ -372,11 +380,22 @@ class Trainer:
         else:
             loss = self._forward_backward_autograd(mine, n_img)
         cap = self.renderer.capacity
-        if cap is not None and not cap.check():  # the step's only host sync; parameters are still untouched
+        if self._flat_adam:
+            # no host sync at all: the overflow words of this step's renders become a device-side skip flag that
+            # travels through the all-reduce; the host looks at them one step later (CapacityPolicy.poll)
+            tot = cap.collect_async() if cap is not None else None
+            if tot is not None:
+                g.grad_flag.copy_(tot[:, 1].max().to(torch.float32))
+            else:
+                g.grad_flag.zero_()
+            self.all_reduce_grads()
+            self.optimizer.step(skip_flags=g.grad_flag.view(torch.int32), zero_grad=True)
+        else:
+            if cap is not None and not cap.check():  # host sync; parameters are still untouched
+                g.zero_grad()
+                raise RuntimeError("instance capacity overflow: CapacityPolicy grew its bound, redo the step")
+            self.all_reduce_grads()
+            self.optimizer.step()
             g.zero_grad()
-            raise RuntimeError("instance capacity overflow: CapacityPolicy grew its bound, redo the step")
-        self.all_reduce_grads()
-        self.optimizer.step()
-        g.zero_grad()
         self.last_loss = loss.detach() if loss is not None else None
         return len(mine)

@@ -184,6 +184,18 @@ int dimo_deform_backward(int N, int M, int local_frame, int accumulate, const fl
                          float *dL_dopacity, float *dL_dc_xyz, float *dL_dc_log_radius, float *dL_dd_xyz,
                          float *dL_dd_rot, void *scratch, size_t scratch_bytes, void *stream);
 
+/* ------------------------------------------------------------------ Adam over the flat parameter bucket
+ * torch.optim.Adam semantics (no weight decay / amsgrad; renderer/latent_gs_renderer.py:475: eps = 1e-15) for all
+ * parameter groups in one launch.  params/grads/exp_avg/exp_avg_sq: n floats each, 16-byte aligned; the groups are
+ * n_segments contiguous ranges [segment_end[k-1], segment_end[k]) with learning rate segment_lr[k] (HOST arrays,
+ * passed by value, n_segments <= 32, segment_end[n_segments-1] == n).  step = 1-based step count (bias correction).
+ * skip_flags: optional device ints (n_flags of them, flag_stride ints apart); if any is non-zero the update is a
+ * no-op (used with the rasterizer's capacity-overflow word).  zero_grad != 0 clears grads in the same pass. */
+int dimo_flat_adam_step(int64_t n, float *params, float *grads, float *exp_avg, float *exp_avg_sq, int n_segments,
+                        const int64_t *segment_end_host, const float *segment_lr_host, float beta1, float beta2,
+                        float eps, int64_t step, const int *skip_flags, int n_flags, int flag_stride, int zero_grad,
+                        void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -90,7 +90,7 @@ def test_train_step_gpu_matches_cpu_oracle_pipeline():
     assert torch.allclose(p0, rd.gaussians.flat_params.cpu(), atol=2e-6)  # log(sqrt(dist2)) rounds per device
     # gradients of the first step (before Adam's sign-like normalisation amplifies rounding)
     for t in (cpu, gpu):
-        t.optimizer.step = lambda: None
+        t.optimizer.step = lambda *a, **k: None
         t.renderer.gaussians.zero_grad = lambda: None
     triples = cpu.sample()
     cpu.train_step(triples)

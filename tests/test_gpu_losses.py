@@ -78,7 +78,7 @@ def test_direct_pipeline_equals_autograd_pipeline(vae):
         init_synthetic_model(rd, cfg.num_pts, cfg.num_cpts, seed=0, num_latent=cfg.num_motions)
         tr = Trainer(cfg, rd, direct=direct)
         assert tr.direct == direct
-        tr.optimizer.step = lambda: None
+        tr.optimizer.step = lambda *a, **k: None
         rd.gaussians.zero_grad = lambda: None
         triples = tr.sample()
         torch.manual_seed(5)  # same VAE eps draws in both pipelines

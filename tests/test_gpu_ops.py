@@ -80,3 +80,49 @@ def test_ssim_against_torch_conv(shape):
     (gs,) = torch.autograd.grad(s, a)
     assert abs(s.item() - r.item()) < 2e-5
     assert (gs - gr).abs().sum() / gr.abs().sum() < 1e-3
+
+
+def test_flat_adam_matches_torch_adam_and_skip_flag():
+    """FlatAdam (one HIP launch over the flat bucket) vs torch.optim.Adam with per-group learning rates."""
+    from dimo_amd.flat_adam import FlatAdam
+    g = torch.Generator().manual_seed(0)
+    shapes = [(1000, 3), (1000, 1, 3), (1000, 1), (37,), (256, 104), (5, 32)]
+    lrs = [0.01, 0.0025, 0.05, 0.005, 0.0002, 0.0]
+    total = sum(int(np.prod(s)) for s in shapes)
+    flat = torch.randn(total, generator=g).cuda()
+    grads = torch.zeros(total + 4, device="cuda")
+    views, ref_params, o = [], [], 0
+    for s in shapes:
+        n = int(np.prod(s))
+        p = torch.nn.Parameter(flat[o:o + n].view(s))
+        p.grad = grads[o:o + n].view(s)
+        views.append(p)
+        ref_params.append(torch.nn.Parameter(flat[o:o + n].view(s).clone()))
+        o += n
+    groups = [{"params": [p], "lr": lr, "name": str(i)} for i, (p, lr) in enumerate(zip(views, lrs))]
+    opt = FlatAdam(groups, flat, grads[:total], eps=1e-15)
+    ref = torch.optim.Adam([{"params": [p], "lr": lr} for p, lr in zip(ref_params, lrs)], lr=0.0, eps=1e-15)
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    for step in range(5):
+        gr = torch.randn(total, generator=g).cuda() * (10.0 ** (step - 2))
+        grads[:total].copy_(gr)
+        o = 0
+        for p in ref_params:
+            p.grad = gr[o:o + p.numel()].view(p.shape).clone()
+            o += p.numel()
+        if step == 3:  # change a learning rate like update_learning_rate does
+            groups[0]["lr"] = 0.002
+            ref.param_groups[0]["lr"] = 0.002
+        opt.step(skip_flags=flag, zero_grad=True)
+        ref.step()
+        assert torch.count_nonzero(grads[:total]) == 0
+    got = flat.cpu()
+    want = torch.cat([p.detach().reshape(-1) for p in ref_params]).cpu()
+    assert (got - want).abs().max() <= 2e-6 * max(1.0, want.abs().max().item())
+    # skip flag: parameters and moments untouched, gradients still cleared
+    before = (flat.clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone())
+    grads[:total].normal_()
+    flag.fill_(1)
+    opt.step(skip_flags=flag, zero_grad=True)
+    assert torch.equal(flat, before[0]) and torch.equal(opt.exp_avg, before[1]) and torch.equal(opt.exp_avg_sq, before[2])
+    assert torch.count_nonzero(grads[:total]) == 0
