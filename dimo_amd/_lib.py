@@ -42,6 +42,10 @@ _SIGNATURES = {
     "dimo_deform_backward": (C.c_int, [C.c_int] * 4 + [c_ptr] * 22 + [c_ptr, C.c_size_t, c_ptr]),
     "dimo_ssim_forward": (C.c_int, [C.c_int] * 5 + [c_ptr] * 5),
     "dimo_ssim_backward": (C.c_int, [C.c_int] * 5 + [c_ptr] * 6),
+    "dimo_executor_create": (C.c_void_p, [C.c_int]),
+    "dimo_executor_destroy": (None, [C.c_void_p]),
+    "dimo_executor_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "dimo_executor_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "dimo_flat_adam_step": (C.c_int, [C.c_int64] + [c_ptr] * 4 + [C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_float)]
                             + [C.c_float] * 3 + [C.c_int64, c_ptr, C.c_int, C.c_int, C.c_int, c_ptr]),
     "dimo_image_loss": (C.c_int, [C.c_int] * 3 + [c_ptr] * 6 + [C.c_int, C.POINTER(C.c_float)] + [C.c_float] * 5

@@ -180,8 +180,21 @@ __device__ __forceinline__ void butterfly16(const float (&v)[16], int lane, floa
     const float send = b1 ? h[t] : h[4 + t];
     float r = keep + dpp_mov<DPP_QUAD_XOR2>(send);
     r += dpp_mov<DPP_ROW_SHR4>(r);
-    r += dpp_mov<DPP_ROW_SHR8>(r);
-    out[t] = r;  // valid in lanes 12..15 of every row
+    r += dpp_mov<DPP_ROW_SHR8>(r);  // lanes 12..15 of every row: row sums
+    // Fold the four rows lane-for-lane (lanes 12..15 of each row hold four DIFFERENT quantities, so row_bcast
+    // cannot be used): gfx950's v_permlane16_swap / v_permlane32_swap exchange odd/even rows and the two wave
+    // halves inside the VALU.  Finishing in registers costs ~6 VALU per value but lets ONE conflict-free 4-lane
+    // LDS add replace four 4-way-conflicting ones -- the LDS pipe, not the VALU, was this kernel's busiest unit
+    // (SQ_LDS_IDX_ACTIVE ~ 1.6x SQ_INSTS_VALU).
+    {
+      float a = r, b = r;
+      asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+      r = a + b;  // rows (0,1) and (2,3) summed, replicated
+      a = r, b = r;
+      asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+      r = a + b;  // all four rows
+    }
+    out[t] = r;  // valid in lanes 12..15 of every row (identical across rows)
   }
 }
 
@@ -289,8 +302,8 @@ __global__ void __launch_bounds__(BLEND_BLOCK) blend_bwd_kernel(
       }
       float red[4];
       butterfly16(v, lane, red);
-      // lanes 12..15 of each row hold row sums; lane (12 + q) owns values 8*(q&1) + 4*(q>>1) + t, t = 0..3
-      if ((lane & 15) >= 12) {
+      // lanes 60..63 hold the wave sums; lane (60 + q) owns values 8*(q&1) + 4*(q>>1) + t, t = 0..3
+      if (lane >= 60) {
         const int q = lane & 3;
         const int base = 8 * (q & 1) + 4 * (q >> 1);
 #pragma unroll

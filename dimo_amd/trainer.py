@@ -1,20 +1,25 @@
 """One training step of DIMO's motion-latent stage, sharded over (motion, view, frame).
 
 Mirrors `GUI.train_step` (main_train_dimo.py:221-451): learning-rate update, KNN of every Gaussian among
-the control points (stage s2), sampling of motions x views x frames, one `Renderer.render` per triple,
-per-motion image losses (weighted MSE, SSIM, mask MSE, edge-aware depth smoothness, bilateral normal
-smoothness), ONE backward, Adam (eps 1e-15), gradient reset.  LPIPS (needs downloaded VGG weights), ARAP,
-the chamfer "GA" term and the VAE KL term are excluded and reported as excluded by bench.py.
+the control points (stage s2), sampling of motions x views x frames, one render per triple, per-motion image
+losses (weighted MSE, SSIM, mask MSE, edge-aware depth smoothness, bilateral normal smoothness), ONE backward,
+Adam (eps 1e-15), gradient reset.  LPIPS (needs downloaded VGG weights), ARAP and the chamfer "GA" term are
+excluded and reported as excluded by bench.py.
 
 Data parallelism (new -- the reference is single-GPU): every rank holds a full replica, draws the SAME
 sample (shared seeds), renders its contiguous slice of the triples, and the flat gradient bucket
-(GaussianModel.flat_grads) is summed with one RCCL all-reduce before the identical Adam update.  The
+(GaussianModel.flat_grads_ext) is summed with one RCCL all-reduce before the identical Adam update.  The
 reference's batch loss is a SUM over renders/motions, so the reduction is SUM, not mean; per-motion
 mean-type terms are written per image with weight 1/(images per motion), which makes the loss
 independent of how the triples are split.
+
+Two interchangeable forward+backward pipelines (tested equal):
+  * autograd : `Renderer.render` per triple + torch losses + one `loss.backward()` -- the reference's shape;
+  * direct   : the native step executor (dimo_amd/executor.py): two host calls run every render's HIP kernel
+               chain on private streams, losses are two fused kernels per motion, only TimeNet uses autograd.
 """
 import random
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 from typing import Callable, List, Optional, Tuple
 
 import numpy as np
@@ -116,13 +121,16 @@ class Trainer:
         self.last_loss = None
         self._consts = {}
         self._deform_batch = None
-        self._side = None
+        self._exec = None
         self.skipped_steps = 0
         self._flat_adam = type(self.optimizer).__name__ == "FlatAdam"
         # direct HIP pipeline: GPU, stage s2, degree-0 colour (DIMO's configuration), product rasterizer
         self.direct = (direct if direct is not None else True) and self.device.type == "cuda" \
             and cfg.stage >= "s2" and cfg.sh_degree == 0 and renderer._rasterizer_factory is None \
             and len(renderer.gaussians._r) == 0 and renderer.gaussians._c_xyz.shape[0] <= 1800
+        if self.direct and renderer.capacity is None:
+            from .rasterizer import CapacityPolicy
+            renderer.capacity = CapacityPolicy(initial=max(1 << 20, 40 * cfg.num_pts))
 
     # ------------------------------------------------------------------ pieces of train_step
     def find_knn(self, k=4):
@@ -147,7 +155,7 @@ class Trainer:
 
         The reference evaluates the MLP once per render (M = 512 rows each: launch-bound, and views of the
         same (motion, frame) repeat identical work); the control points, times and latents of a step are all
-        known up front, so one [pairs*M, 104] batch replaces 2b^3 small ones.  Returns {(m, f): (dxyz, dquat)}."""
+        known up front, so one [pairs*M, 104] batch replaces 2b^3 small ones.  Returns {triple: (dxyz, dquat)}."""
         g = self.renderer.gaussians
         # VAE latents are re-sampled per render in the reference, so only the plain-latent flavour dedupes views
         key = (lambda m, v, f: (m, v, f)) if g.vae_latent else (lambda m, v, f: (m, f))
@@ -212,22 +220,33 @@ class Trainer:
             loss.backward()
         return loss
 
-    def _forward_backward_direct(self, mine, n_img):
-        """MI355X pipeline: the HIP kernels are chained explicitly instead of through autograd.
+    def _executor(self, n_renders):
+        from .executor import StepExecutor
+        g, c = self.renderer.gaussians, self.cfg
+        cap = self.renderer.capacity.next_capacity()
+        if self._exec is None or self._exec.max_renders < n_renders:
+            self._exec = StepExecutor(g._xyz.shape[0], g._c_xyz.shape[0], c.resolution, c.resolution,
+                                      max(n_renders, 8), cap, self.device)
+        self._exec.resize_capacity(cap)
+        return self._exec
 
-        skinning -> project/bin/sort/blend (rendered straight into the motion's batch buffers) -> fused SSIM +
-        fused image losses (emit the four gradient images) -> blend/projection backward -> skinning backward
-        ACCUMULATING into the flat gradient bucket.  Only the (batched) TimeNet MLP still uses autograd.  Same
-        math as `_forward_backward_autograd` (tests compare the two), ~3x fewer kernel launches and no
-        per-render Python/autograd graph work."""
+    def _forward_backward_direct(self, mine, n_img):
+        """MI355X pipeline: explicit HIP kernel chains instead of autograd.
+
+        skinning -> project/bin/sort/blend of every render (native executor, renders overlap on private streams and
+        write straight into their motion's batch buffers) -> per motion: fused SSIM + fused image losses (emit the
+        four gradient images) -> blend/projection backward of every render -> skinning backward ACCUMULATING into the
+        flat gradient bucket.  Only the (batched) TimeNet MLP uses autograd.  Same math as
+        `_forward_backward_autograd` (tests compare the two)."""
         from . import _lib
         from .image_loss import fused_image_loss, loss_weights
-        from .rasterizer import raster_backward, raster_forward
         c, g, L = self.cfg, self.renderer.gaussians, _lib.lib()
         dev, stream = self.device, _lib.current_stream()
-        N, M = g._xyz.shape[0], g._c_xyz.shape[0]
         H = W = c.resolution
         f32 = dict(dtype=torch.float32, device=dev)
+        n = len(mine)
+        ex = self._executor(n)
+        ex.set_common(g, self.renderer.bg_color, self.renderer.add_normal)
         self.batched_deform(mine)
         dxyz_all, dquat_all, pair_of = self._deform_batch  # [P,M,3], [P,M,4], triple -> row
         dxyz_c, dquat_c = dxyz_all.detach().contiguous(), dquat_all.detach().contiguous()
@@ -235,52 +254,35 @@ class Trainer:
         by_motion = {}
         for t in mine:
             by_motion.setdefault(t[0], []).append(t)
-        loss_accum = torch.zeros(1, **f32)
-        ssim_terms = []
-        g_ras, scratch = {}, None
-        lbs_scratch = torch.empty(L.dimo_deform_backward_scratch_bytes(N, M), dtype=torch.uint8, device=dev)
-        nn_d, nn_i = g.neighbor_dists, g.neighbor_indices
-        c_lr = g._c_radius
-        # ---- forward of every render, round-robin over a few side streams.  A single render's kernel chain is
-        # latency-bound (a 512^2 frame has ~800 busy tiles = ~3 waves per SIMD, and the sort is ~20 short dependent
-        # launches), so independent renders overlap almost for free: 4 streams measured 1.7x on raster fwd+bwd.
-        main = torch.cuda.current_stream()
-        side = self._side_streams()
-        bufs = {}
+        M3, M4 = dxyz_c.shape[1] * 3 * 4, dquat_c.shape[1] * 4 * 4  # row strides in bytes
+        HW4 = H * W * 4
+        bufs, first = {}, {}
+        i = 0
         for m, trs in by_motion.items():
             B = len(trs)
-            bufs[m] = (torch.empty(B, 3, H, W, **f32), torch.empty(B, 1, H, W, **f32),
-                       torch.empty(B, 3, H, W, **f32) if self.renderer.add_normal else None,
-                       torch.empty(B, 1, H, W, **f32))
-        for s in side:
-            s.wait_stream(main)  # TimeNet outputs, KNN, parameters and the fresh batch buffers are ready
-        states, k = {}, 0
-        for m, trs in by_motion.items():
-            img, depth, normal, alpha = bufs[m]
+            img, depth = torch.empty(B, 3, H, W, **f32), torch.empty(B, 1, H, W, **f32)
+            normal = torch.empty(B, 3, H, W, **f32) if self.renderer.add_normal else None
+            alpha = torch.empty(B, 1, H, W, **f32)
+            bufs[m], first[m] = (img, depth, normal, alpha), i
             for b, (_m, v, f) in enumerate(trs):
+                d = ex.descs[i]
+                cam = self.cams.get(c.elevation, self.azimuths[v], c.radius, W, H)
+                d.view, d.proj, d.campos = (cam.world_view_transform.data_ptr(), cam.full_proj_transform.data_ptr(),
+                                            cam.camera_center.data_ptr())
+                d.tanfovx, d.tanfovy = cam.tanfovx, cam.tanfovy
                 p = pair_of[(m, v, f)]
-                dx, dq = dxyz_c[p], dquat_c[p]
-                s = side[k % len(side)]
-                k += 1
-                with torch.cuda.stream(s):
-                    pts, rot, scales, opac = (torch.empty(N, 3, **f32), torch.empty(N, 4, **f32),
-                                              torch.empty(N, 3, **f32), torch.empty(N, 1, **f32))
-                    _lib.check(L.dimo_deform_forward(
-                        N, M, 1, _lib.ptr(g._xyz), _lib.ptr(g._rotation), _lib.ptr(g._scaling),
-                        _lib.ptr(g._opacity), _lib.ptr(g._c_xyz), _lib.ptr(c_lr), _lib.ptr(dx), _lib.ptr(dq),
-                        _lib.ptr(nn_d), _lib.ptr(nn_i), _lib.ptr(pts), _lib.ptr(rot), _lib.ptr(scales),
-                        _lib.ptr(opac), s.cuda_stream), "dimo_deform_forward")
-                    cam = self.cams.get(c.elevation, self.azimuths[v], c.radius, W, H)
-                    settings = self.renderer._settings(cam, 1.0, None)
-                    *_, st = raster_forward(pts, g._features_dc, None, opac, scales, rot, None, settings,
-                                            self.renderer.add_normal, self.renderer.capacity,
-                                            out=(img[b], depth[b], normal[b] if normal is not None else None,
-                                                 alpha[b]))
-                states[(m, b)] = (st, p, s)
-        for s in side:
-            main.wait_stream(s)
-        # ---- losses per motion on the main stream, then backward of every render (side streams again)
-        pending = []
+                d.d_xyz, d.d_rot = dxyz_c.data_ptr() + p * M3, dquat_c.data_ptr() + p * M4
+                d.g_d_xyz, d.g_d_rot = g_dxyz.data_ptr() + p * M3, g_dquat.data_ptr() + p * M4
+                d.out_color, d.out_depth = img.data_ptr() + b * 3 * HW4, depth.data_ptr() + b * HW4
+                d.out_normal = (normal.data_ptr() + b * 3 * HW4) if normal is not None else None
+                d.out_alpha = alpha.data_ptr() + b * HW4
+                i += 1
+        ex.forward(n)
+        for w_ in ex.total_words(n):
+            self.renderer.capacity.track(w_)
+
+        loss_accum = torch.zeros(1, **f32)
+        ssim_terms, keep = [], []
         for m, trs in by_motion.items():
             B = len(trs)
             img, depth, normal, alpha = bufs[m]
@@ -302,40 +304,18 @@ class Trainer:
             gi, gd, gn, ga = fused_image_loss(img, depth if c.add_depth else None, normal if c.add_normal else None,
                                               alpha, gt, mask, w_mse, loss_weights(c, B, n_img, H, W), ssim_grad,
                                               loss_accum)
-            pending.append((m, B, gi, gd, gn, ga))
+            keep.append((gi, gd, gn, ga))
+            for b in range(B):
+                d = ex.descs[first[m] + b]
+                d.g_color, d.g_alpha = gi.data_ptr() + b * 3 * HW4, ga.data_ptr() + b * HW4
+                d.g_depth = (gd.data_ptr() + b * HW4) if gd is not None else None
+                d.g_normal = (gn.data_ptr() + b * 3 * HW4) if gn is not None else None
             if g.vae_latent:  # KL term of this motion (main_train_dimo.py:355-360): tiny, autograd
                 mu, lv = g._mu[m], g._log_var[m]
                 kl = c.lambda_kl * (-0.5 * torch.sum(1 + lv - mu.pow(2) - lv.exp()))
                 kl.backward()
                 loss_accum += kl.detach()
-        # ---- backward of every render: blend/projection backward on the render's side stream, then (ordered by an
-        # event) the skinning backward on the main stream, where it ACCUMULATES into the shared gradient bucket
-        for s in side:
-            s.wait_stream(main)  # gradient images are ready
-        keep = []
-        for (m, B, gi, gd, gn, ga) in pending:
-            for b in reversed(range(B)):
-                st, p, s = states[(m, b)]
-                dx, dq, adx, adq = dxyz_c[p], dquat_c[p], g_dxyz[p], g_dquat[p]
-                with torch.cuda.stream(s):
-                    gr = raster_backward(st, gi[b], gd[b] if gd is not None else None,
-                                         gn[b] if gn is not None else None, ga[b])
-                    done = s.record_event()
-                keep.append(gr)
-                main.wait_event(done)
-                g._features_dc.grad.add_(gr["shs"])
-                _lib.check(L.dimo_deform_backward(
-                    N, M, 1, 1, _lib.ptr(g._xyz), _lib.ptr(g._rotation), _lib.ptr(g._scaling), _lib.ptr(g._opacity),
-                    _lib.ptr(g._c_xyz), _lib.ptr(c_lr), _lib.ptr(dx), _lib.ptr(dq), _lib.ptr(nn_d), _lib.ptr(nn_i),
-                    _lib.ptr(gr["means3D"]), _lib.ptr(gr["rotations"]), _lib.ptr(gr["scales"]),
-                    _lib.ptr(gr["opacities"]), _lib.ptr(g._xyz.grad), _lib.ptr(g._rotation.grad),
-                    _lib.ptr(g._scaling.grad), _lib.ptr(g._opacity.grad), _lib.ptr(g._c_xyz.grad),
-                    _lib.ptr(g._c_radius.grad), _lib.ptr(adx), _lib.ptr(adq), _lib.ptr(lbs_scratch),
-                    lbs_scratch.numel(), stream), "dimo_deform_backward")
-        # side-stream tensors (workspaces, per-render gradients) are released when this function returns: order
-        # every later use of those streams after the main stream's reads
-        for s in side:
-            s.wait_stream(main)
+        ex.backward(n)
         # TimeNet backward for all renders at once
         if mine:
             torch.autograd.backward([dxyz_all, dquat_all], [g_dxyz, g_dquat])
@@ -343,11 +323,6 @@ class Trainer:
         for ssum, lam, numel in ssim_terms:
             loss = loss + lam * (1 - ssum[0] / numel)
         return loss
-
-    def _side_streams(self, n=4):
-        if self._side is None:
-            self._side = [torch.cuda.Stream(device=self.device) for _ in range(n)]
-        return self._side
 
     def _const(self, value):
         """Cached 1-element device tensors for scalar kernel arguments."""
@@ -359,9 +334,10 @@ class Trainer:
     # ------------------------------------------------------------------ the step
     def train_step(self, triples=None):
         """Runs one optimisation step; returns the number of renders THIS rank performed."""
-        c, g = self.cfg, self.renderer.gaussians
-        if self._flat_adam and self.renderer.capacity is not None:
-            bad = self.renderer.capacity.poll()  # last step's instance counts (copied asynchronously)
+        g = self.renderer.gaussians
+        cap = self.renderer.capacity
+        if self._flat_adam and cap is not None:
+            bad = cap.poll()  # last step's instance counts (copied asynchronously)
             if bad:  # that update was skipped on the device; the capacity bound has been raised
                 self.skipped_steps += bad
                 self.optimizer.step_count -= bad
@@ -373,13 +349,11 @@ class Trainer:
             triples = self.sample()
         mine = shard(triples, self.rank, self.world)
         n_img = max(1, len(triples) // max(1, len({t[0] for t in triples})))  # images per motion (b^2)
-        ref_view, ref_frame = 0, 0
 
         if self.direct:
             loss = self._forward_backward_direct(mine, n_img)
         else:
             loss = self._forward_backward_autograd(mine, n_img)
-        cap = self.renderer.capacity
         if self._flat_adam:
             # no host sync at all: the overflow words of this step's renders become a device-side skip flag that
             # travels through the all-reduce; the host looks at them one step later (CapacityPolicy.poll)

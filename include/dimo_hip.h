@@ -196,6 +196,49 @@ int dimo_flat_adam_step(int64_t n, float *params, float *grads, float *exp_avg, 
                         float eps, int64_t step, const int *skip_flags, int n_flags, int flag_stride, int zero_grad,
                         void *stream);
 
+/* ------------------------------------------------------------------ native step executor
+ * Runs the per-render kernel chains of one training step (main_train_dimo.py:276-318 forward, the mirrored
+ * backward of :415) from one host call each: render i runs on private stream i % n_streams, joined with events
+ * against `main_stream`.  Every pointer is caller-owned, persistent device memory; nothing is allocated.
+ *   forward : dimo_deform_forward -> dimo_raster_preprocess_forward (no host read-back) -> dimo_raster_render_forward
+ *   backward: dimo_raster_backward on the render's stream; then, ordered on main_stream, g_f_dc += g_shs and
+ *             dimo_deform_backward(accumulate = 1) into the shared gradient views of dimo_step_common.
+ * Degree-0 colour (f_dc [N,1,3]) and scale/rotation covariance only -- DIMO's training configuration. */
+#define DIMO_EXECUTOR_TYPES 1
+typedef struct {
+  int N, M, H, W, with_normal, local_frame;
+  int64_t R_cap;
+  const float *xyz, *rotation, *scaling, *opacity, *f_dc;
+  const float *c_xyz, *c_log_radius;
+  const float *nn_dist;
+  const int64_t *nn_idx;
+  const float *bg;
+  float scale_modifier;
+  float *g_xyz, *g_rotation, *g_scaling, *g_opacity, *g_f_dc, *g_c_xyz, *g_c_log_radius;
+  void *lbs_scratch;
+  size_t lbs_scratch_bytes, geom_bytes, bin_bytes, img_bytes, bwd_scratch_bytes;
+} dimo_step_common;
+
+typedef struct {
+  const float *view, *proj, *campos;
+  float tanfovx, tanfovy;
+  const float *d_xyz, *d_rot;   /* TimeNet outputs of this render [M,3] [M,4] */
+  float *g_d_xyz, *g_d_rot;     /* their gradient rows (accumulated) */
+  float *out_color, *out_depth, *out_normal, *out_alpha;
+  const float *g_color, *g_depth, *g_normal, *g_alpha;
+  float *pts, *rot, *scales, *opac;   /* per-slot persistent workspaces from here on */
+  int32_t *radii;
+  void *geom, *bin, *img, *bwd_scratch;
+  float *g_means3D, *g_means2D, *g_shs, *g_opac, *g_scales, *g_rot;
+} dimo_render_desc;
+
+void *dimo_executor_create(int n_streams);
+void dimo_executor_destroy(void *executor);
+int dimo_executor_forward(void *executor, const dimo_step_common *common, int n_renders,
+                          const dimo_render_desc *renders, void *main_stream);
+int dimo_executor_backward(void *executor, const dimo_step_common *common, int n_renders,
+                           const dimo_render_desc *renders, void *main_stream);
+
 #ifdef __cplusplus
 }
 #endif
