@@ -45,7 +45,10 @@ _SIGNATURES = {
     "dimo_executor_create": (C.c_void_p, [C.c_int]),
     "dimo_executor_destroy": (None, [C.c_void_p]),
     "dimo_executor_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
-    "dimo_executor_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "dimo_executor_join": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "dimo_executor_backward_launch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "dimo_executor_backward_accumulate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                                    C.c_void_p]),
     "dimo_flat_adam_step": (C.c_int, [C.c_int64] + [c_ptr] * 4 + [C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_float)]
                             + [C.c_float] * 3 + [C.c_int64, c_ptr, C.c_int, C.c_int, C.c_int, c_ptr]),
     "dimo_image_loss": (C.c_int, [C.c_int] * 3 + [c_ptr] * 6 + [C.c_int, C.POINTER(C.c_float)] + [C.c_float] * 5

@@ -49,6 +49,7 @@ struct Executor {
   std::vector<hipStream_t> streams;
   std::vector<hipEvent_t> stream_done;
   std::vector<hipEvent_t> render_done;
+  std::vector<hipEvent_t> fwd_done;
   hipEvent_t main_ready = nullptr;
 };
 
@@ -89,6 +90,7 @@ extern "C" void dimo_executor_destroy(void *h) {
   for (auto s : ex->streams) (void)hipStreamDestroy(s);
   for (auto e : ex->stream_done) (void)hipEventDestroy(e);
   for (auto e : ex->render_done) (void)hipEventDestroy(e);
+  for (auto e : ex->fwd_done) (void)hipEventDestroy(e);
   if (ex->main_ready) (void)hipEventDestroy(ex->main_ready);
   delete ex;
 }
@@ -102,9 +104,19 @@ static int fork_from_main(Executor *ex, hipStream_t main) {
 
 extern "C" int dimo_executor_forward(void *h, const dimo_step_common *c, int n, const dimo_render_desc *d,
                                      void *main_stream) {
+  // Launches the forward chain of renders [0, n) on the private streams (render i on stream i % S) and records
+  // one event per render.  Does NOT make the caller's stream wait: see dimo_executor_join.
   Executor *ex = reinterpret_cast<Executor *>(h);
   hipStream_t main = (hipStream_t)main_stream;
   if (!ex || !c || n < 0 || (n > 0 && !d)) return DIMO_E_ARG;
+  while ((int)ex->render_done.size() < n || (int)ex->fwd_done.size() < n) {
+    hipEvent_t e, f;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&f, hipEventDisableTiming) != hipSuccess)
+      return DIMO_E_LAUNCH;
+    ex->render_done.push_back(e);
+    ex->fwd_done.push_back(f);
+  }
   int rc = fork_from_main(ex, main);
   if (rc) return rc;
   const int S = (int)ex->streams.size();
@@ -123,29 +135,33 @@ extern "C" int dimo_executor_forward(void *h, const dimo_step_common *c, int n, 
                                     c->img_bytes, r.out_color, r.out_depth, c->with_normal ? r.out_normal : nullptr,
                                     r.out_alpha, s);
     if (rc) return rc;
-  }
-  for (int k = 0; k < S && k < n; ++k) {
-    if (hipEventRecord(ex->stream_done[k], ex->streams[k]) != hipSuccess) return DIMO_E_LAUNCH;
-    if (hipStreamWaitEvent(main, ex->stream_done[k], 0) != hipSuccess) return DIMO_E_LAUNCH;
+    if (hipEventRecord(ex->fwd_done[i], s) != hipSuccess) return DIMO_E_LAUNCH;
   }
   return DIMO_OK;
 }
 
-extern "C" int dimo_executor_backward(void *h, const dimo_step_common *c, int n, const dimo_render_desc *d,
-                                      void *main_stream) {
+// The caller's stream waits for the forward of renders [first, first + count).
+extern "C" int dimo_executor_join(void *h, int first, int count, void *main_stream) {
   Executor *ex = reinterpret_cast<Executor *>(h);
   hipStream_t main = (hipStream_t)main_stream;
-  if (!ex || !c || n < 0 || (n > 0 && !d)) return DIMO_E_ARG;
-  while ((int)ex->render_done.size() < n) {
-    hipEvent_t e;
-    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return DIMO_E_LAUNCH;
-    ex->render_done.push_back(e);
-  }
-  int rc = fork_from_main(ex, main);  // the gradient images are ready
+  if (!ex || first < 0 || count < 0 || first + count > (int)ex->fwd_done.size()) return DIMO_E_ARG;
+  for (int i = first; i < first + count; ++i)
+    if (hipStreamWaitEvent(main, ex->fwd_done[i], 0) != hipSuccess) return DIMO_E_LAUNCH;
+  return DIMO_OK;
+}
+
+// Rasterizer backward of renders [first, first + count) on their private streams (ordered after everything the
+// caller's stream has enqueued so far, i.e. after the kernels that produced the gradient images).
+extern "C" int dimo_executor_backward_launch(void *h, const dimo_step_common *c, int first, int count,
+                                             const dimo_render_desc *d, void *main_stream) {
+  Executor *ex = reinterpret_cast<Executor *>(h);
+  hipStream_t main = (hipStream_t)main_stream;
+  if (!ex || !c || first < 0 || count < 0 || first + count > (int)ex->render_done.size() || (count > 0 && !d))
+    return DIMO_E_ARG;
+  int rc = fork_from_main(ex, main);
   if (rc) return rc;
   const int S = (int)ex->streams.size();
-  // enqueue every render's rasterizer backward first (side streams run ahead), then the ordered accumulations
-  for (int i = n - 1; i >= 0; --i) {
+  for (int i = first + count - 1; i >= first; --i) {
     hipStream_t s = ex->streams[i % S];
     const dimo_render_desc &r = d[i];
     rc = dimo_raster_backward(c->N, 0, 1, c->H, c->W, c->R_cap, r.pts, c->f_dc, nullptr, r.opac, r.scales, r.rot,
@@ -156,16 +172,28 @@ extern "C" int dimo_executor_backward(void *h, const dimo_step_common *c, int n,
     if (rc) return rc;
     if (hipEventRecord(ex->render_done[i], s) != hipSuccess) return DIMO_E_LAUNCH;
   }
+  return DIMO_OK;
+}
+
+// On the caller's stream, in render order: wait for render i's rasterizer backward, then g_f_dc += g_shs and the
+// skinning backward accumulating into the shared gradient views.
+extern "C" int dimo_executor_backward_accumulate(void *h, const dimo_step_common *c, int first, int count,
+                                                 const dimo_render_desc *d, void *main_stream) {
+  Executor *ex = reinterpret_cast<Executor *>(h);
+  hipStream_t main = (hipStream_t)main_stream;
+  if (!ex || !c || first < 0 || count < 0 || first + count > (int)ex->render_done.size() || (count > 0 && !d))
+    return DIMO_E_ARG;
   const size_t n_dc = (size_t)c->N * 3;
-  for (int i = n - 1; i >= 0; --i) {
+  for (int i = first + count - 1; i >= first; --i) {
     const dimo_render_desc &r = d[i];
     if (hipStreamWaitEvent(main, ex->render_done[i], 0) != hipSuccess) return DIMO_E_LAUNCH;
     hipLaunchKernelGGL(accumulate_kernel, dim3((unsigned)((n_dc + 255) / 256)), dim3(256), 0, main, n_dc, c->g_f_dc,
                        r.g_shs);
-    rc = dimo_deform_backward(c->N, c->M, c->local_frame, 1, c->xyz, c->rotation, c->scaling, c->opacity, c->c_xyz,
-                              c->c_log_radius, r.d_xyz, r.d_rot, c->nn_dist, c->nn_idx, r.g_means3D, r.g_rot,
-                              r.g_scales, r.g_opac, c->g_xyz, c->g_rotation, c->g_scaling, c->g_opacity, c->g_c_xyz,
-                              c->g_c_log_radius, r.g_d_xyz, r.g_d_rot, c->lbs_scratch, c->lbs_scratch_bytes, main);
+    int rc = dimo_deform_backward(c->N, c->M, c->local_frame, 1, c->xyz, c->rotation, c->scaling, c->opacity,
+                                  c->c_xyz, c->c_log_radius, r.d_xyz, r.d_rot, c->nn_dist, c->nn_idx, r.g_means3D,
+                                  r.g_rot, r.g_scales, r.g_opac, c->g_xyz, c->g_rotation, c->g_scaling, c->g_opacity,
+                                  c->g_c_xyz, c->g_c_log_radius, r.g_d_xyz, r.g_d_rot, c->lbs_scratch,
+                                  c->lbs_scratch_bytes, main);
     if (rc) return rc;
   }
   return check_launch();

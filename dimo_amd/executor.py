@@ -38,7 +38,7 @@ class RenderDesc(C.Structure):
 
 
 class StepExecutor:
-    def __init__(self, N, M, H, W, max_renders, r_cap, device, n_streams=4):
+    def __init__(self, N, M, H, W, max_renders, r_cap, device, n_streams=3):
         if torch.device(device).type != "cuda":
             raise RuntimeError("StepExecutor needs a GPU (no CPU fallback in the product path)")
         self.L = _lib.lib()
@@ -116,6 +116,15 @@ class StepExecutor:
         _lib.check(self.L.dimo_executor_forward(self.handle, C.addressof(self.common), n, C.addressof(self.descs),
                                                 _lib.current_stream()), "dimo_executor_forward")
 
-    def backward(self, n):
-        _lib.check(self.L.dimo_executor_backward(self.handle, C.addressof(self.common), n, C.addressof(self.descs),
-                                                 _lib.current_stream()), "dimo_executor_backward")
+    def join(self, first, count):
+        _lib.check(self.L.dimo_executor_join(self.handle, first, count, _lib.current_stream()), "dimo_executor_join")
+
+    def backward_launch(self, first, count):
+        _lib.check(self.L.dimo_executor_backward_launch(self.handle, C.addressof(self.common), first, count,
+                                                        C.addressof(self.descs), _lib.current_stream()),
+                   "dimo_executor_backward_launch")
+
+    def backward_accumulate(self, first, count):
+        _lib.check(self.L.dimo_executor_backward_accumulate(self.handle, C.addressof(self.common), first, count,
+                                                            C.addressof(self.descs), _lib.current_stream()),
+                   "dimo_executor_backward_accumulate")

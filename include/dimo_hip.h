@@ -234,10 +234,18 @@ typedef struct {
 
 void *dimo_executor_create(int n_streams);
 void dimo_executor_destroy(void *executor);
+/* forward chains of renders [0, n_renders) on the private streams (after everything enqueued on main_stream so
+ * far); main_stream does NOT wait -- dimo_executor_join makes it wait for a sub-range, so the losses of one motion
+ * can run while the other motions are still rendering */
 int dimo_executor_forward(void *executor, const dimo_step_common *common, int n_renders,
                           const dimo_render_desc *renders, void *main_stream);
-int dimo_executor_backward(void *executor, const dimo_step_common *common, int n_renders,
-                           const dimo_render_desc *renders, void *main_stream);
+int dimo_executor_join(void *executor, int first, int count, void *main_stream);
+/* rasterizer backward of renders [first, first+count) on their streams (after main_stream's current tail) ... */
+int dimo_executor_backward_launch(void *executor, const dimo_step_common *common, int first, int count,
+                                  const dimo_render_desc *renders, void *main_stream);
+/* ... and, on main_stream, per render: wait for it, g_f_dc += g_shs, skinning backward (accumulate) */
+int dimo_executor_backward_accumulate(void *executor, const dimo_step_common *common, int first, int count,
+                                      const dimo_render_desc *renders, void *main_stream);
 
 #ifdef __cplusplus
 }
