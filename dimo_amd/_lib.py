@@ -19,6 +19,7 @@ _SIGNATURES = {
     "dimo_version": (C.c_char_p, []),
     "dimo_last_error": (C.c_char_p, []),
     "dimo_timing_enable": (C.c_int, [C.c_int]),
+    "dimo_timing_select": (C.c_int, [C.c_char_p]),
     "dimo_timing_read": (C.c_int, [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "dimo_raster_geom_bytes": (C.c_size_t, [C.c_int]),
     "dimo_raster_bin_bytes": (C.c_size_t, [C.c_int64, C.c_int, C.c_int]),
@@ -42,6 +43,11 @@ _SIGNATURES = {
     "dimo_deform_backward": (C.c_int, [C.c_int] * 4 + [c_ptr] * 22 + [c_ptr, C.c_size_t, c_ptr]),
     "dimo_ssim_forward": (C.c_int, [C.c_int] * 5 + [c_ptr] * 5),
     "dimo_ssim_backward": (C.c_int, [C.c_int] * 5 + [c_ptr] * 6),
+    "dimo_timenet_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
+    "dimo_timenet_forward": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_ptr, C.c_void_p, c_ptr, C.c_void_p, c_ptr, c_ptr,
+                                       c_ptr, C.c_size_t, c_ptr]),
+    "dimo_timenet_backward": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_ptr, c_ptr, C.c_void_p, C.c_void_p, c_ptr,
+                                        c_ptr, c_ptr, C.c_size_t, c_ptr]),
     "dimo_executor_create": (C.c_void_p, [C.c_int]),
     "dimo_executor_destroy": (None, [C.c_void_p]),
     "dimo_executor_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),

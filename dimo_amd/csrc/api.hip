@@ -32,6 +32,7 @@ extern "C" int dimo_raster_img_layout(int H, int W, size_t out[2]) {
 // Optional kernel timing with HIP events, recorded on the very stream each kernel is launched on.
 // This is the one piece of process-global state in the library; it is OFF by default and is meant
 // for bench.py's live roofline figure (the rocprofv3 summaries under profiles/ must agree with it).
+#include <algorithm>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -44,16 +45,31 @@ struct Rec {
 };
 std::mutex g_mu;
 bool g_on = false;
+uint32_t g_mask = ~0u;            // groups being timed while g_on
 std::vector<Rec> g_recs;
+std::vector<hipEvent_t> g_free;   // events are recycled: creating two per launch costs more than the record
+bool take_event(hipEvent_t *e) {
+  if (!g_free.empty()) {
+    *e = g_free.back();
+    g_free.pop_back();
+    return true;
+  }
+  return hipEventCreate(e) == hipSuccess;
+}
 const char *const g_names[TIMED_COUNT] = {"preprocess_fwd", "scan", "emit",     "sort",     "ranges",  "blend_fwd",
                                           "blend_bwd",      "preprocess_bwd", "knn", "dist2", "ssim_fwd", "ssim_bwd",
-                                          "deform_fwd",     "deform_bwd", "image_loss", "adam"};
+                                          "deform_fwd",     "deform_bwd", "image_loss", "adam", "timenet_fwd", "timenet_bwd"};
 }  // namespace
 
 ScopedTimer::ScopedTimer(int id, hipStream_t s) : id_(id), stream_(s), a_(nullptr), b_(nullptr) {
   std::lock_guard<std::mutex> lk(g_mu);
-  if (!g_on) return;
-  if (hipEventCreate(&a_) != hipSuccess || hipEventCreate(&b_) != hipSuccess) {
+  if (!g_on || !((g_mask >> id) & 1u)) return;
+  if (!take_event(&a_)) {
+    a_ = nullptr;
+    return;
+  }
+  if (!take_event(&b_)) {
+    g_free.push_back(a_);
     a_ = b_ = nullptr;
     return;
   }
@@ -71,11 +87,34 @@ extern "C" int dimo_timing_enable(int on) {
   std::lock_guard<std::mutex> lk(g_mu);
   const int prev = g_on ? 1 : 0;
   if (on && !g_on) {
-    for (auto &r : g_recs) (void)hipEventDestroy(r.a), (void)hipEventDestroy(r.b);
+    for (auto &r : g_recs) g_free.push_back(r.a), g_free.push_back(r.b);
     g_recs.clear();
   }
   g_on = on != 0;
   return prev;
+}
+
+extern "C" int dimo_timing_select(const char *names) {
+  uint32_t mask = 0;
+  if (!names || !*names) {
+    mask = ~0u;
+  } else {
+    std::string all(names);
+    size_t pos = 0;
+    while (pos <= all.size()) {
+      const size_t end = std::min(all.find(',', pos), all.size());
+      const std::string one = all.substr(pos, end - pos);
+      int id = -1;
+      for (int i = 0; i < TIMED_COUNT; ++i)
+        if (one == g_names[i]) id = i;
+      if (id < 0) return DIMO_E_ARG;
+      mask |= 1u << id;
+      pos = end + 1;
+    }
+  }
+  std::lock_guard<std::mutex> lk(g_mu);
+  g_mask = mask;
+  return DIMO_OK;
 }
 
 extern "C" int dimo_timing_read(const char *name, double *total_ms, int64_t *launches) {

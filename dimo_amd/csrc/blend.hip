@@ -158,7 +158,6 @@ constexpr int DPP_QUAD_XOR2 = 0x4E;  // quad_perm:[2,3,0,1]
 constexpr int DPP_ROW_SHR4 = 0x114;
 constexpr int DPP_ROW_SHR8 = 0x118;
 
-constexpr int NACC = 13;  // m0 mx my mxx mxy myy + 7 feature grads (padded to 16 for the butterfly)
 
 // Wave reduction of 16 values per lane down to row sums in ~48 VALU instead of 16 x 6:
 //   step 1 (lane ^ 1): each lane keeps 8 of the 16 values and adds its partner's copy of those;

@@ -23,6 +23,7 @@ SOURCES = {
     "deform.hip": [],
     "image_loss.hip": [],
     "adam.hip": [],
+    "timenet.hip": [],
     "executor.hip": [],
 }
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-fast-math", "-Wall", "-Wno-unused-function"]

@@ -1,0 +1,516 @@
+// TimeNet (renderer/latent_gs_renderer.py:184-245) forward and backward for a whole training step's batch of
+// (motion, frame) pairs as a short chain of fp32 MFMA GEMMs -- rows = pairs x control points (2048 at the
+// benchmark configuration), widths 104 / 256 / 360.  PyTorch's eager version of the same MLP is ~190 launches of
+// 2-20 us kernels per step (1.4 ms of a 4.7 ms step); here forward is D + 3 launches and backward D + 5.
+//
+//   forward : embed (NeRF positional encoding of control points and time + latent, src/pos_enc.py:6-54)
+//             -> D x [Y = relu(X W^T + b)]   (the skip layer writes beside the embedding: the concat is free)
+//             -> both head hidden layers in one launch -> head outputs (3 + 4 columns, wave dot products)
+//   backward: head outputs -> one two-segment dgrad for both heads -> D dgrads with the ReLU mask fused in the
+//             epilogue -> ONE grouped split-K wgrad launch for every weight and bias (HW fp32 atomics straight into
+//             the flat gradient bucket) -> embedding backward (control points, latent rows).
+//
+// GEMM core: v_mfma_f32_32x32x2_f32 (exact fp32, k-ordered fma chain), 64x64 block tile, 4 waves of 32x32, K staged
+// through LDS 16 deep in [k][m] order (operand reads are then one ds_read_b32 per lane, conflict-free), register
+// prefetch of the next K stage.  The f32 MFMA issues at the vector rate (64 cycles / instruction), so these GEMMs
+// are MFMA-issue bound, not LDS or HBM bound: 128 workgroups x 3.4 us for a 2048x256x256 layer.
+#include <hip/hip_runtime.h>
+
+#include "common.hpp"
+#include "../../include/dimo_hip.h"
+
+using namespace dimo;
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 64, BN = 64, BK = 16, LDT = 68;
+constexpr int MAX_LAYERS = DIMO_TIMENET_MAX_LAYERS;
+constexpr int MAX_PAIRS = DIMO_TIMENET_MAX_PAIRS;
+
+// ---- operand staging -------------------------------------------------------------------------------------------
+// KC (k contiguous): element (r, k) at src[r * ld + k]; otherwise (r contiguous) at src[k * ld + r].
+template <bool KC>
+__device__ __forceinline__ void load_stage(const float *__restrict__ src, int ld, int rows, int r0, int k0, int kend,
+                                           float (&v)[4]) {
+  const int t = threadIdx.x;
+  if (KC) {
+    const int k = k0 + (t & 15), r = r0 + (t >> 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int rr = r + 16 * e;
+      v[e] = (rr < rows && k < kend) ? src[(size_t)rr * ld + k] : 0.f;
+    }
+  } else {
+    const int r = r0 + (t & 63), k = k0 + (t >> 6);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int kk = k + 4 * e;
+      v[e] = (r < rows && kk < kend) ? src[(size_t)kk * ld + r] : 0.f;
+    }
+  }
+}
+template <bool KC>
+__device__ __forceinline__ void store_stage(float (*S)[LDT], const float (&v)[4]) {
+  const int t = threadIdx.x;
+  if (KC) {
+    const int k = t & 15, r = t >> 4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) S[k][r + 16 * e] = v[e];
+  } else {
+    const int r = t & 63, k = t >> 6;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) S[k + 4 * e][r] = v[e];
+  }
+}
+
+// acc (32x32 per wave) += A[m0.., kbeg..kend) * B[kbeg..kend), n0..); bias_sum (threads 0..63) += column sums of A
+template <bool A_KC, bool B_KC, bool BIAS_SUM>
+__device__ __forceinline__ void gemm_segment(const float *__restrict__ A, int lda, const float *__restrict__ B,
+                                             int ldb, int M, int N, int m0, int n0, int kbeg, int kend,
+                                             float (*As)[BK][LDT], float (*Bs)[BK][LDT], f32x16 &acc,
+                                             float &bias_sum) {
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+  const int nk = (kend - kbeg + BK - 1) / BK;
+  float ra[4], rb[4];
+  load_stage<A_KC>(A, lda, M, m0, kbeg, kend, ra);
+  load_stage<B_KC>(B, ldb, N, n0, kbeg, kend, rb);
+  store_stage<A_KC>(As[0], ra);
+  store_stage<B_KC>(Bs[0], rb);
+  __syncthreads();
+  for (int it = 0; it < nk; ++it) {
+    const int cur = it & 1;
+    const bool more = it + 1 < nk;
+    if (more) {
+      load_stage<A_KC>(A, lda, M, m0, kbeg + (it + 1) * BK, kend, ra);
+      load_stage<B_KC>(B, ldb, N, n0, kbeg + (it + 1) * BK, kend, rb);
+    }
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      const float a = As[cur][kk + (lane >> 5)][wm + (lane & 31)];
+      const float b = Bs[cur][kk + (lane >> 5)][wn + (lane & 31)];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+    if (BIAS_SUM && t < 64) {
+#pragma unroll
+      for (int kk = 0; kk < BK; ++kk) bias_sum += As[cur][kk][t];
+    }
+    if (more) {
+      store_stage<A_KC>(As[cur ^ 1], ra);
+      store_stage<B_KC>(Bs[cur ^ 1], rb);
+    }
+    __syncthreads();
+  }
+}
+
+// ---- dense layer / dgrad ---------------------------------------------------------------------------------------
+struct GemmArgs {
+  const float *A[2], *B[2];  // up to two K segments accumulated into the same tile
+  int lda[2], ldb[2], K[2], nseg;
+  float *C;
+  int ldc, M, N;
+  const float *bias;              // [N] or null
+  const float *mask;              // C *= (mask > 0) for columns >= mask_from_col (ReLU backward), or null
+  int ldmask, mask_from_col, relu, accumulate;
+  // blockIdx.z == 1 (second problem sharing A): the two head hidden layers
+  const float *B_alt, *bias_alt;
+  float *C_alt;
+};
+
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+  __shared__ float As[2][BK][LDT], Bs[2][BK][LDT];
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const bool alt = blockIdx.z == 1;
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  float unused = 0.f;
+  for (int s = 0; s < g.nseg; ++s)
+    gemm_segment<A_KC, B_KC, false>(g.A[s], g.lda[s], (alt && s == 0) ? g.B_alt : g.B[s], g.ldb[s], g.M, g.N, m0, n0,
+                                    0, g.K[s], As, Bs, acc, unused);
+  const float *bias = alt ? g.bias_alt : g.bias;
+  float *C = alt ? g.C_alt : g.C;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = n0 + (wave & 1) * 32 + (lane & 31);
+  const int mb = m0 + (wave >> 1) * 32 + 4 * (lane >> 5);
+  if (n >= g.N) return;
+  const float bv = bias ? bias[n] : 0.f;
+  const bool masked = g.mask && n >= g.mask_from_col;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = mb + (r & 3) + 8 * (r >> 2);
+    if (m >= g.M) continue;
+    float v = acc[r] + bv;
+    if (g.relu) v = fmaxf(v, 0.f);
+    if (masked && !(g.mask[(size_t)m * g.ldmask + n] > 0.f)) v = 0.f;
+    float *dst = C + (size_t)m * g.ldc + n;
+    *dst = g.accumulate ? *dst + v : v;
+  }
+}
+
+// ---- grouped split-K weight gradients --------------------------------------------------------------------------
+// problem p: gW[M x N] += dZ^T X with dZ [rows x M], X [rows x N] (both row-major), gbias[M] += column sums of dZ
+struct WgradProblem {
+  const float *dZ, *X;
+  float *gW, *gbias;
+  int ld_dz, ld_x, ld_w, M, N, tiles_n, tile_begin;
+};
+struct WgradArgs {
+  WgradProblem p[MAX_LAYERS];
+  int nprob, rows, kchunk;
+};
+
+__global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs g) {
+  __shared__ float As[2][BK][LDT], Bs[2][BK][LDT];
+  int pi = 0;
+  while (pi + 1 < g.nprob && (int)blockIdx.x >= g.p[pi + 1].tile_begin) ++pi;
+  const WgradProblem &p = g.p[pi];
+  const int tile = blockIdx.x - p.tile_begin;
+  const int tm = tile / p.tiles_n, tn = tile % p.tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int kbeg = blockIdx.y * g.kchunk, kend = min(g.rows, kbeg + g.kchunk);
+  if (kbeg >= kend) return;
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  float bsum = 0.f;
+  if (tn == 0)
+    gemm_segment<false, false, true>(p.dZ, p.ld_dz, p.X, p.ld_x, p.M, p.N, m0, n0, kbeg, kend, As, Bs, acc, bsum);
+  else
+    gemm_segment<false, false, false>(p.dZ, p.ld_dz, p.X, p.ld_x, p.M, p.N, m0, n0, kbeg, kend, As, Bs, acc, bsum);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (tn == 0 && p.gbias && threadIdx.x < 64 && m0 + (int)threadIdx.x < p.M)
+    unsafeAtomicAdd(p.gbias + m0 + threadIdx.x, bsum);
+  const int n = n0 + (wave & 1) * 32 + (lane & 31);
+  const int mb = m0 + (wave >> 1) * 32 + 4 * (lane >> 5);
+  if (n >= p.N) return;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = mb + (r & 3) + 8 * (r >> 2);
+    if (m < p.M) unsafeAtomicAdd(p.gW + (size_t)m * p.ld_w + n, acc[r]);
+  }
+}
+
+// ---- embedding -------------------------------------------------------------------------------------------------
+struct PairTable {
+  float time[MAX_PAIRS];
+  int latent_row[MAX_PAIRS];
+};
+
+// cat[row, 0:E] = [sin/cos(2^f x) f < pts_freqs | sin/cos(2^f t) f < time_freqs | latent]  (src/pos_enc.py:36-45:
+// per frequency sin(all dims) then cos(all dims))
+__global__ void embed_kernel(int P, int Mc, int E, int ld, int pts_freqs, int time_freqs, int latent_dim,
+                             const float *__restrict__ c_xyz, const float *__restrict__ latent_table, PairTable pt,
+                             float *__restrict__ cat) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= P * Mc * E) return;
+  const int col = idx % E, row = idx / E;
+  const int p = row / Mc, m = row % Mc;
+  const int npts = 6 * pts_freqs, ntime = 2 * time_freqs;
+  float v;
+  if (col < npts) {
+    const int f = col / 6, w = col % 6;
+    const float x = c_xyz[m * 3 + (w % 3)] * exp2f((float)f);
+    v = w < 3 ? sinf(x) : cosf(x);
+  } else if (col < npts + ntime) {
+    const int c = col - npts, f = c >> 1;
+    const float x = pt.time[p] * exp2f((float)f);
+    v = (c & 1) ? cosf(x) : sinf(x);
+  } else {
+    v = latent_table[(size_t)pt.latent_row[p] * latent_dim + (col - npts - ntime)];
+  }
+  cat[(size_t)row * ld + col] = v;
+}
+
+// g_c_xyz[m, d] += sum_p sum_f 2^f (g_sin cos - g_cos sin)   (sin/cos re-read from the saved embedding)
+__global__ void embed_bwd_pts_kernel(int P, int Mc, int ld, int pts_freqs, const float *__restrict__ cat,
+                                     const float *__restrict__ g_cat, float *__restrict__ g_c_xyz) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= Mc * 3) return;
+  const int m = idx / 3, d = idx % 3;
+  float s = 0.f;
+  for (int p = 0; p < P; ++p) {
+    const size_t base = (size_t)(p * Mc + m) * ld;
+    for (int f = 0; f < pts_freqs; ++f) {
+      const float sn = cat[base + 6 * f + d], cs = cat[base + 6 * f + 3 + d];
+      s += exp2f((float)f) * (g_cat[base + 6 * f + d] * cs - g_cat[base + 6 * f + 3 + d] * sn);
+    }
+  }
+  g_c_xyz[idx] += s;
+}
+
+// g_latent_table[row(p), j] += sum_m g_cat[(p, m), lat0 + j]; one block per pair
+__global__ __launch_bounds__(256) void embed_bwd_latent_kernel(int Mc, int ld, int lat0, int latent_dim,
+                                                               const float *__restrict__ g_cat, PairTable pt,
+                                                               float *__restrict__ g_latent_table) {
+  __shared__ float red[256];
+  const int p = blockIdx.x;
+  for (int j0 = 0; j0 < latent_dim; j0 += 32) {
+    const int j = j0 + (threadIdx.x & 31), grp = threadIdx.x >> 5;
+    float s = 0.f;
+    if (j < latent_dim)
+      for (int m = grp; m < Mc; m += 8) s += g_cat[(size_t)(p * Mc + m) * ld + lat0 + j];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x < 32 && j < latent_dim) {
+      float tot = 0.f;
+      for (int q = 0; q < 8; ++q) tot += red[q * 32 + threadIdx.x];
+      unsafeAtomicAdd(g_latent_table + (size_t)pt.latent_row[p] * latent_dim + j, tot);
+    }
+    __syncthreads();
+  }
+}
+
+// ---- head output layers (W -> 3 and W -> 4): one wave per row ---------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+__global__ __launch_bounds__(256) void head_out_kernel(int rows, int Wd, const float *__restrict__ hp,
+                                                       const float *__restrict__ hr, const float *__restrict__ Wp,
+                                                       const float *__restrict__ bp, const float *__restrict__ Wr,
+                                                       const float *__restrict__ br, float *__restrict__ d_xyz,
+                                                       float *__restrict__ d_rot) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  float a[3] = {0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int c = lane; c < Wd; c += 64) {
+    const float x = hp[(size_t)row * Wd + c], y = hr[(size_t)row * Wd + c];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) a[i] = fmaf(x, Wp[i * Wd + c], a[i]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) q[i] = fmaf(y, Wr[i * Wd + c], q[i]);
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) a[i] = wave_sum(a[i]);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) q[i] = wave_sum(q[i]);
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) d_xyz[(size_t)row * 3 + i] = a[i] + bp[i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) d_rot[(size_t)row * 4 + i] = q[i] + br[i];
+  }
+}
+
+// dZp = (g_d_xyz Wp) * (hp > 0), dZr = (g_d_rot Wr) * (hr > 0)
+__global__ void head_out_bwd_kernel(int rows, int Wd, const float *__restrict__ g_xyz, const float *__restrict__ g_rot,
+                                    const float *__restrict__ hp, const float *__restrict__ hr,
+                                    const float *__restrict__ Wp, const float *__restrict__ Wr,
+                                    float *__restrict__ dzp, float *__restrict__ dzr) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * Wd) return;
+  const int row = idx / Wd, c = idx % Wd;
+  float vp = 0.f, vr = 0.f;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) vp = fmaf(g_xyz[row * 3 + i], Wp[i * Wd + c], vp);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) vr = fmaf(g_rot[row * 4 + i], Wr[i * Wd + c], vr);
+  dzp[idx] = hp[idx] > 0.f ? vp : 0.f;
+  dzr[idx] = hr[idx] > 0.f ? vr : 0.f;
+}
+
+// ---- host side -------------------------------------------------------------------------------------------------
+struct Plan {
+  int D, Wd, skip, E, CAT, rows;
+  // float offsets into the workspace
+  size_t cat, g_cat, hp, hr, dzp, dzr, act[MAX_LAYERS], dz[MAX_LAYERS], total;
+};
+
+bool make_plan(const dimo_timenet_desc *d, int rows, Plan &pl) {
+  if (!d || d->D < 2 || d->D + 4 > MAX_LAYERS || d->W < 1 || d->skip >= d->D - 1 || d->pts_freqs < 0 ||
+      d->time_freqs < 0 || d->latent_dim < 0 || rows < 0)
+    return false;
+  pl.D = d->D, pl.Wd = d->W, pl.skip = d->skip, pl.rows = rows;
+  pl.E = 6 * d->pts_freqs + 2 * d->time_freqs + d->latent_dim;
+  pl.CAT = pl.E + (d->skip >= 0 ? d->W : 0);
+  size_t o = 0;
+  auto take = [&](size_t n) {
+    size_t at = o;
+    o += (n + 63) & ~size_t(63);
+    return at;
+  };
+  const size_t R = (size_t)rows;
+  pl.cat = take(R * pl.CAT), pl.g_cat = take(R * pl.CAT);
+  pl.hp = take(R * pl.Wd), pl.hr = take(R * pl.Wd), pl.dzp = take(R * pl.Wd), pl.dzr = take(R * pl.Wd);
+  for (int l = 0; l < d->D; ++l) {
+    if (l == d->skip) {
+      pl.act[l] = pl.cat + pl.E, pl.dz[l] = pl.g_cat + pl.E;
+    } else {
+      pl.act[l] = take(R * pl.Wd), pl.dz[l] = take(R * pl.Wd);
+    }
+  }
+  pl.total = o;
+  return true;
+}
+
+// input of deformnet layer l: (offset, leading dimension, K)
+void layer_input(const Plan &pl, int l, size_t &off, int &ld, int &K) {
+  if (l == 0) {
+    off = pl.cat, ld = pl.CAT, K = pl.E;
+  } else if (l - 1 == pl.skip) {
+    off = pl.cat, ld = pl.CAT, K = pl.CAT;
+  } else {
+    off = pl.act[l - 1], ld = pl.Wd, K = pl.Wd;
+  }
+}
+int act_ld(const Plan &pl, int l) { return l == pl.skip ? pl.CAT : pl.Wd; }
+
+template <bool A_KC, bool B_KC>
+void launch_gemm(const GemmArgs &g, int z, hipStream_t s) {
+  dim3 grid((g.M + BM - 1) / BM, (g.N + BN - 1) / BN, z);
+  gemm_kernel<A_KC, B_KC><<<grid, 256, 0, s>>>(g);
+}
+
+bool fill_pairs(int P, const float *times, const int *rows, PairTable &pt) {
+  if (P > MAX_PAIRS) return false;
+  for (int p = 0; p < P; ++p) pt.time[p] = times[p], pt.latent_row[p] = rows ? rows[p] : p;
+  return true;
+}
+
+}  // namespace
+
+extern "C" size_t dimo_timenet_workspace_bytes(const dimo_timenet_desc *d, int P, int M) {
+  Plan pl;
+  if (P < 0 || M < 0 || !make_plan(d, P * M, pl)) return 0;
+  return pl.total * sizeof(float) + 256;
+}
+
+extern "C" int dimo_timenet_forward(const dimo_timenet_desc *d, int P, int M, const float *c_xyz,
+                                    const float *times_host, const float *latent_table, const int *latent_rows_host,
+                                    float *d_xyz, float *d_rot, void *workspace, size_t workspace_bytes,
+                                    void *stream) {
+  Plan pl;
+  if (P < 0 || M < 0 || !make_plan(d, P * M, pl)) return DIMO_E_ARG;
+  if (P == 0 || M == 0) return DIMO_OK;
+  if (!c_xyz || !times_host || !d_xyz || !d_rot || !workspace || (d->latent_dim > 0 && !latent_table))
+    return DIMO_E_ARG;
+  for (int l = 0; l < d->D + 4; ++l)
+    if (!d->weight[l] || !d->bias[l]) return DIMO_E_ARG;
+  if (workspace_bytes < pl.total * sizeof(float)) return DIMO_E_WORKSPACE;
+  PairTable pt;
+  if (!fill_pairs(P, times_host, latent_rows_host, pt)) return DIMO_E_ARG;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  clear_errors();
+  ScopedTimer timer(T_TIMENET_FWD, s);
+  float *ws = static_cast<float *>(workspace);
+  const int R = pl.rows;
+  {
+    const int n = R * pl.E;
+    embed_kernel<<<(n + 255) / 256, 256, 0, s>>>(P, M, pl.E, pl.CAT, d->pts_freqs, d->time_freqs, d->latent_dim,
+                                                 c_xyz, latent_table, pt, ws + pl.cat);
+  }
+  for (int l = 0; l < d->D; ++l) {
+    GemmArgs g = {};
+    size_t off;
+    layer_input(pl, l, off, g.lda[0], g.K[0]);
+    g.A[0] = ws + off, g.B[0] = d->weight[l], g.ldb[0] = g.K[0], g.nseg = 1;
+    g.C = ws + pl.act[l], g.ldc = act_ld(pl, l), g.M = R, g.N = pl.Wd, g.bias = d->bias[l], g.relu = 1;
+    launch_gemm<true, true>(g, 1, s);
+  }
+  {  // pts_layers[0] and rot_layers[0] share the input
+    GemmArgs g = {};
+    g.A[0] = ws + pl.act[d->D - 1], g.lda[0] = act_ld(pl, d->D - 1), g.K[0] = pl.Wd, g.nseg = 1;
+    g.B[0] = d->weight[d->D], g.ldb[0] = pl.Wd, g.bias = d->bias[d->D], g.C = ws + pl.hp;
+    g.B_alt = d->weight[d->D + 2], g.bias_alt = d->bias[d->D + 2], g.C_alt = ws + pl.hr;
+    g.ldc = pl.Wd, g.M = R, g.N = pl.Wd, g.relu = 1;
+    launch_gemm<true, true>(g, 2, s);
+  }
+  head_out_kernel<<<(R + 3) / 4, 256, 0, s>>>(R, pl.Wd, ws + pl.hp, ws + pl.hr, d->weight[d->D + 1],
+                                              d->bias[d->D + 1], d->weight[d->D + 3], d->bias[d->D + 3], d_xyz,
+                                              d_rot);
+  return check_launch();
+}
+
+extern "C" int dimo_timenet_backward(const dimo_timenet_desc *d, int P, int M, const float *g_d_xyz,
+                                     const float *g_d_rot, const float *times_host, const int *latent_rows_host,
+                                     float *g_c_xyz, float *g_latent_table, void *workspace, size_t workspace_bytes,
+                                     void *stream) {
+  Plan pl;
+  if (P < 0 || M < 0 || !make_plan(d, P * M, pl)) return DIMO_E_ARG;
+  if (P == 0 || M == 0) return DIMO_OK;
+  if (!g_d_xyz || !g_d_rot || !times_host || !workspace) return DIMO_E_ARG;
+  for (int l = 0; l < d->D + 4; ++l)
+    if (!d->weight[l] || !d->g_weight[l] || !d->g_bias[l]) return DIMO_E_ARG;
+  if (workspace_bytes < pl.total * sizeof(float)) return DIMO_E_WORKSPACE;
+  PairTable pt;
+  if (!fill_pairs(P, times_host, latent_rows_host, pt)) return DIMO_E_ARG;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  clear_errors();
+  ScopedTimer timer(T_TIMENET_BWD, s);
+  float *ws = static_cast<float *>(workspace);
+  const int R = pl.rows, D = d->D, Wd = pl.Wd;
+  {
+    const int n = R * Wd;
+    head_out_bwd_kernel<<<(n + 255) / 256, 256, 0, s>>>(R, Wd, g_d_xyz, g_d_rot, ws + pl.hp, ws + pl.hr,
+                                                        d->weight[D + 1], d->weight[D + 3], ws + pl.dzp,
+                                                        ws + pl.dzr);
+  }
+  {  // dZ[D-1] = (dZp Wp0 + dZr Wr0) * (h[D-1] > 0)
+    GemmArgs g = {};
+    g.nseg = 2;
+    g.A[0] = ws + pl.dzp, g.A[1] = ws + pl.dzr, g.lda[0] = g.lda[1] = Wd, g.K[0] = g.K[1] = Wd;
+    g.B[0] = d->weight[D], g.B[1] = d->weight[D + 2], g.ldb[0] = g.ldb[1] = Wd;
+    g.C = ws + pl.dz[D - 1], g.ldc = act_ld(pl, D - 1), g.M = R, g.N = Wd;
+    g.mask = ws + pl.act[D - 1], g.ldmask = act_ld(pl, D - 1);
+    launch_gemm<true, false>(g, 1, s);
+  }
+  for (int l = D - 1; l >= 0; --l) {  // gradient of layer l's input
+    GemmArgs g = {};
+    size_t in_off;
+    int in_ld, K;
+    layer_input(pl, l, in_off, in_ld, K);
+    g.nseg = 1, g.A[0] = ws + pl.dz[l], g.lda[0] = act_ld(pl, l), g.K[0] = Wd;
+    g.B[0] = d->weight[l], g.ldb[0] = K, g.M = R, g.N = K;
+    if (l == 0) {  // embedding columns: accumulate onto the skip layer's contribution (if any)
+      g.C = ws + pl.g_cat, g.ldc = pl.CAT, g.accumulate = pl.skip >= 0;
+    } else if (l - 1 == pl.skip) {  // [embedding | h_skip]: only the h columns pass a ReLU
+      g.C = ws + pl.g_cat, g.ldc = pl.CAT, g.mask = ws + pl.cat, g.ldmask = pl.CAT, g.mask_from_col = pl.E;
+    } else {
+      g.C = ws + pl.dz[l - 1], g.ldc = act_ld(pl, l - 1);
+      g.mask = ws + pl.act[l - 1], g.ldmask = act_ld(pl, l - 1);
+    }
+    launch_gemm<true, false>(g, 1, s);
+  }
+  {  // every weight / bias gradient in one grouped split-K launch
+    WgradArgs w = {};
+    int tiles = 0, np = 0;
+    auto add = [&](const float *dz, int ld_dz, const float *x, int ld_x, int Mo, int No, int li) {
+      WgradProblem &p = w.p[np++];
+      p.dZ = dz, p.ld_dz = ld_dz, p.X = x, p.ld_x = ld_x, p.gW = d->g_weight[li], p.gbias = d->g_bias[li];
+      p.ld_w = No, p.M = Mo, p.N = No, p.tiles_n = (No + BN - 1) / BN, p.tile_begin = tiles;
+      tiles += ((Mo + BM - 1) / BM) * p.tiles_n;
+    };
+    for (int l = 0; l < D; ++l) {
+      size_t off;
+      int ld, K;
+      layer_input(pl, l, off, ld, K);
+      add(ws + pl.dz[l], act_ld(pl, l), ws + off, ld, Wd, K, l);
+    }
+    const float *hlast = ws + pl.act[D - 1];
+    const int ldl = act_ld(pl, D - 1);
+    add(ws + pl.dzp, Wd, hlast, ldl, Wd, Wd, D);
+    add(g_d_xyz, 3, ws + pl.hp, Wd, 3, Wd, D + 1);
+    add(ws + pl.dzr, Wd, hlast, ldl, Wd, Wd, D + 2);
+    add(g_d_rot, 4, ws + pl.hr, Wd, 4, Wd, D + 3);
+    w.nprob = np, w.rows = R;
+    // ~8 K-slices: enough workgroups to fill 256 CUs several times over, few enough atomics per element
+    int ksplit = (R + 255) / 256;
+    ksplit = ksplit < 1 ? 1 : (ksplit > 64 ? 64 : ksplit);
+    w.kchunk = (((R + ksplit - 1) / ksplit) + BK - 1) / BK * BK;
+    ksplit = (R + w.kchunk - 1) / w.kchunk;
+    wgrad_kernel<<<dim3(tiles, ksplit), 256, 0, s>>>(w);
+  }
+  if (g_c_xyz && d->pts_freqs > 0)
+    embed_bwd_pts_kernel<<<(M * 3 + 63) / 64, 64, 0, s>>>(P, M, pl.CAT, d->pts_freqs, ws + pl.cat, ws + pl.g_cat,
+                                                          g_c_xyz);
+  if (g_latent_table && d->latent_dim > 0)
+    embed_bwd_latent_kernel<<<P, 256, 0, s>>>(M, pl.CAT, 6 * d->pts_freqs + 2 * d->time_freqs, d->latent_dim,
+                                              ws + pl.g_cat, pt, g_latent_table);
+  return check_launch();
+}

@@ -126,6 +126,9 @@ class Trainer:
         import os
         # opt-in: HIP-graph capture of the MLP (measured gain 4 %; the capture crashed one pytest run -> off)
         self.graph_timenet = os.environ.get("DIMO_GRAPH_TIMENET", "0") == "1"
+        # TimeNet as two native calls (dimo_amd/csrc/timenet.hip) in the direct pipeline; "0": PyTorch autograd MLP
+        self.fused_timenet = os.environ.get("DIMO_FUSED_TIMENET", "1") == "1"
+        self._fused_tn = None
         self.marks = None  # set to [] to collect (name, torch.cuda.Event) phase marks on the main stream
         self.skipped_steps = 0
         self._flat_adam = type(self.optimizer).__name__ == "FlatAdam"
@@ -175,6 +178,23 @@ class Trainer:
         self._deform_batch = (dxyz, dquat, {(m, v, f): pairs.index(key(m, v, f)) for (m, v, f) in triples})
         out = {p: (dxyz[i], dquat[i]) for i, p in enumerate(pairs)}
         return {(m, v, f): out[key(m, v, f)] for (m, v, f) in triples}
+
+    def _fused_deform(self, triples):
+        """`batched_deform` on the HIP library: one dimo_timenet_forward for the step's distinct pairs."""
+        from .fused_timenet import FusedTimeNet
+        g = self.renderer.gaussians
+        key = (lambda m, v, f: (m, v, f)) if g.vae_latent else (lambda m, v, f: (m, f))
+        pairs = list(dict.fromkeys(key(m, v, f) for (m, v, f) in triples))
+        times = [self.source_time[p[-1]] for p in pairs]
+        if self._fused_tn is None:
+            self._fused_tn = FusedTimeNet(g._timenet)
+        if g.vae_latent:
+            lat = torch.stack([g.latent_code(p[0]) for p in pairs]) if pairs else None
+            table, rows = (lat.detach().contiguous() if pairs else g._mu), None
+        else:
+            lat, table, rows = None, g._latent_codes, [p[0] for p in pairs]
+        dxyz, dquat = self._fused_tn.forward(g._c_xyz, times, table, rows)
+        return dxyz, dquat, {(m, v, f): pairs.index(key(m, v, f)) for (m, v, f) in triples}, lat
 
     def _timenet_batched(self, pts, times, lat):
         """TimeNet on the whole step's batch.  On the GPU the MLP's forward and backward are each captured once
@@ -281,10 +301,14 @@ class Trainer:
         ex = self._executor(n)
         ex.set_common(g, self.renderer.bg_color, self.renderer.add_normal)
         self._mark("start")
-        self.batched_deform(mine)
+        fused_tn = self.fused_timenet and len(g._timenet.skips) <= 1
+        if fused_tn:
+            dxyz_c, dquat_c, pair_of, lat = self._fused_deform(mine)
+        else:
+            self.batched_deform(mine)
+            dxyz_all, dquat_all, pair_of = self._deform_batch  # [P,M,3], [P,M,4], triple -> row
+            dxyz_c, dquat_c = dxyz_all.detach().contiguous(), dquat_all.detach().contiguous()
         self._mark("timenet_fwd")
-        dxyz_all, dquat_all, pair_of = self._deform_batch  # [P,M,3], [P,M,4], triple -> row
-        dxyz_c, dquat_c = dxyz_all.detach().contiguous(), dquat_all.detach().contiguous()
         g_dxyz, g_dquat = torch.zeros_like(dxyz_c), torch.zeros_like(dquat_c)  # accumulated by the skinning backward
         by_motion = {}
         for t in mine:
@@ -357,7 +381,14 @@ class Trainer:
             ex.backward_accumulate(first[m], len(trs))
         self._mark("raster_bwd+skinning_bwd")
         # TimeNet backward for all renders at once
-        if mine:
+        if mine and fused_tn:
+            if lat is not None:  # VAE latents: re-parameterised rows, their gradient continues through autograd
+                g_lat = torch.zeros_like(lat)
+                self._fused_tn.backward(g_dxyz, g_dquat, g._c_xyz.grad, g_lat)
+                lat.backward(g_lat)
+            else:
+                self._fused_tn.backward(g_dxyz, g_dquat, g._c_xyz.grad, g._latent_codes.grad)
+        elif mine:
             torch.autograd.backward([dxyz_all, dquat_all], [g_dxyz, g_dquat])
         self._mark("timenet_bwd")
         loss = loss_accum[0]

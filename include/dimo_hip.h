@@ -48,9 +48,13 @@ const char *dimo_last_error(void);
  * While enabled, every instrumented kernel group is bracketed by a hipEvent pair recorded on the
  * stream it is launched on.  dimo_timing_read synchronises the device and returns the summed
  * duration and launch count of one group: "preprocess_fwd" "scan" "emit" "sort" "ranges" "blend_fwd"
- * "blend_bwd" "preprocess_bwd" "knn" "dist2" "ssim_fwd" "ssim_bwd".
- * dimo_timing_enable(1) clears earlier records; returns the previous state. */
+ * "blend_bwd" "preprocess_bwd" "knn" "dist2" "ssim_fwd" "ssim_bwd" "deform_fwd" "deform_bwd" "image_loss" "adam"
+ * "timenet_fwd" "timenet_bwd".
+ * dimo_timing_enable(1) clears earlier records; returns the previous state.  dimo_timing_select restricts the
+ * instrumentation to a comma-separated list of groups (NULL or "": all) -- two event records per launch are not
+ * free, a throughput run that only needs one kernel's duration selects that kernel. */
 int dimo_timing_enable(int on);
+int dimo_timing_select(const char *names);
 int dimo_timing_read(const char *name, double *total_ms, int64_t *launches);
 
 /* ------------------------------------------------------------------ rasterizer workspaces
@@ -195,6 +199,35 @@ int dimo_flat_adam_step(int64_t n, float *params, float *grads, float *exp_avg, 
                         const int64_t *segment_end_host, const float *segment_lr_host, float beta1, float beta2,
                         float eps, int64_t step, const int *skip_flags, int n_flags, int flag_stride, int zero_grad,
                         void *stream);
+
+/* ------------------------------------------------------------------ TimeNet (the deformation MLP)
+ * renderer/latent_gs_renderer.py:184-245 (`TimeNet.forward` with t_apply: one time per batch entry) for a whole
+ * step's batch of P (motion, frame) pairs x M control points, forward and backward as fp32 MFMA GEMM chains.
+ * Input row (p, m) = [posenc(c_xyz[m]; pts_freqs) | posenc(time[p]; time_freqs) | latent_table[latent_rows[p]]]
+ * (src/pos_enc.py:6-54 ordering: per frequency sin(all dims), cos(all dims)); deformnet = D Linear+ReLU layers of
+ * width W, the output of layer `skip` is concatenated BEHIND the input row (skip < 0: no skip); heads
+ * pts_layers / rot_layers = Linear(W,W)+ReLU+Linear(W,3|4).
+ * weight[l]/bias[l] (torch.nn.Linear layout [out,in] row-major), l = 0..D-1: deformnet.l; D: pts_layers.0;
+ * D+1: pts_layers.2; D+2: rot_layers.0; D+3: rot_layers.2.  g_weight/g_bias: gradient buffers of the same shapes,
+ * ADDED to (hardware fp32 atomics: summation order is not fixed run to run).
+ * times_host[P], latent_rows_host[P] (NULL: row p) are HOST arrays (passed by value to the kernels), P <=
+ * DIMO_TIMENET_MAX_PAIRS.  workspace (dimo_timenet_workspace_bytes) carries the activations from forward to
+ * backward.  backward: g_d_xyz[P,M,3] g_d_rot[P,M,4] in; g_c_xyz[M,3] (NULL ok) and g_latent_table (NULL ok) are
+ * ADDED to. */
+#define DIMO_TIMENET_MAX_LAYERS 20
+#define DIMO_TIMENET_MAX_PAIRS 256
+typedef struct {
+  int D, W, skip, pts_freqs, time_freqs, latent_dim;
+  const float *weight[DIMO_TIMENET_MAX_LAYERS], *bias[DIMO_TIMENET_MAX_LAYERS];
+  float *g_weight[DIMO_TIMENET_MAX_LAYERS], *g_bias[DIMO_TIMENET_MAX_LAYERS];
+} dimo_timenet_desc;
+size_t dimo_timenet_workspace_bytes(const dimo_timenet_desc *net, int P, int M);
+int dimo_timenet_forward(const dimo_timenet_desc *net, int P, int M, const float *c_xyz, const float *times_host,
+                         const float *latent_table, const int *latent_rows_host, float *d_xyz, float *d_rot,
+                         void *workspace, size_t workspace_bytes, void *stream);
+int dimo_timenet_backward(const dimo_timenet_desc *net, int P, int M, const float *g_d_xyz, const float *g_d_rot,
+                          const float *times_host, const int *latent_rows_host, float *g_c_xyz,
+                          float *g_latent_table, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------ native step executor
  * Runs the per-render kernel chains of one training step (main_train_dimo.py:276-318 forward, the mirrored
