@@ -58,7 +58,7 @@ bool take_event(hipEvent_t *e) {
 }
 const char *const g_names[TIMED_COUNT] = {"preprocess_fwd", "scan", "emit",     "sort",     "ranges",  "blend_fwd",
                                           "blend_bwd",      "preprocess_bwd", "knn", "dist2", "ssim_fwd", "ssim_bwd",
-                                          "deform_fwd",     "deform_bwd", "image_loss", "adam", "timenet_fwd", "timenet_bwd"};
+                                          "deform_fwd",     "deform_bwd", "image_loss", "adam", "timenet_fwd", "timenet_bwd", "tile_sort"};
 }  // namespace
 
 ScopedTimer::ScopedTimer(int id, hipStream_t s) : id_(id), stream_(s), a_(nullptr), b_(nullptr) {

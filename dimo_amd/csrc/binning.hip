@@ -1,5 +1,10 @@
-// Tile binning: scan of tiles_touched, key emission, stable LSD radix sort of
-// (tile | fp32 depth bits) keys with the Gaussian id as payload, and tile ranges.
+// Tile binning: scan of tiles_touched, key emission, sort of (tile | fp32 depth bits) keys with the Gaussian id
+// as payload, and tile ranges.  The sorted arrays equal a stable LSD radix sort over the whole key (the published
+// rasterizer's cub::DeviceRadixSort), but are produced in two steps that fit the machine better: stable radix
+// passes over the TILE bits only (2 passes at 512^2 instead of 6 over 42 bits -- every pass is three launches
+// whose cost is latency, not bandwidth: the instance arrays live in L2), then one workgroup per tile orders its
+// segment by (depth bits, Gaussian id) with a bitonic network in LDS.  The radix passes keep the emission order
+// (ascending Gaussian id) inside a tile, so (depth, id) is exactly the stable order.
 //
 // All kernels read the live instance count R from device memory (geom.total[0]) and are launched
 // over the CAPACITY R_cap, so the whole chain is enqueued without a host round trip.
@@ -252,6 +257,155 @@ __global__ void __launch_bounds__(256) tile_ranges_kernel(const uint64_t *__rest
   if (i == R - 1) ranges[2 * tile + 1] = R;
 }
 
+// ------------------------------------------------------------------------------------ per-tile depth sort
+// One workgroup per tile orders the tile's segment by the 32 depth bits (stable, so ties keep the ascending
+// Gaussian id the radix passes over the tile bits left them in).  Segments of up to TS_CAP instances -- all of
+// them in practice -- are sorted in LDS with the same wave-ballot counting scatter as the global passes, 8 bits
+// at a time, skipping digits every key of the tile agrees on (view-space depths of one tile share their exponent
+// byte).  Linear in the segment length: the few crowded tiles do not leave a long tail behind.
+constexpr int TS_CAP = 4096;
+constexpr int TS_ITEMS = TS_CAP / 256;
+constexpr size_t TS_LDS_BYTES = 2 * TS_CAP * sizeof(uint64_t) + 4 * RADIX * sizeof(uint32_t);
+
+// Oversized segments fall back to a bitonic network on the global arrays (slow, exact).  "Mirror" form: every
+// compare-exchange moves the smaller element down, so an arbitrary length n behaves as if padded with +inf --
+// pairs whose upper index is >= n are skipped.
+template <class CmpSwap>
+__device__ __forceinline__ void bitonic_network(uint32_t n, CmpSwap cmp_swap) {
+  uint32_t np2 = 1;
+  while (np2 < n) np2 <<= 1;
+  const uint32_t half = np2 >> 1;
+  for (uint32_t k = 2; k <= np2; k <<= 1) {
+    for (uint32_t p = threadIdx.x; p < half; p += blockDim.x) {  // mirror step
+      const uint32_t blk = p / (k >> 1), l = p % (k >> 1);
+      const uint32_t lo = blk * k + l, hi = blk * k + k - 1 - l;
+      if (hi < n) cmp_swap(lo, hi);
+    }
+    __syncthreads();
+    for (uint32_t j = k >> 2; j > 0; j >>= 1) {
+      for (uint32_t p = threadIdx.x; p < half; p += blockDim.x) {
+        const uint32_t lo = (p / j) * 2 * j + (p % j), hi = lo + j;
+        if (hi < n) cmp_swap(lo, hi);
+      }
+      __syncthreads();
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) tile_depth_sort_kernel(const uint32_t *__restrict__ ranges,
+                                                              uint64_t *__restrict__ keys,
+                                                              uint32_t *__restrict__ vals) {
+  extern __shared__ uint64_t ts_smem[];
+  __shared__ uint32_t wtot[4];
+  __shared__ uint32_t diff_s;
+  const uint32_t tile = blockIdx.x;
+  const uint32_t beg = ranges[2 * tile], end = ranges[2 * tile + 1];
+  if (end <= beg + 1) return;
+  const uint32_t n = end - beg;
+  if (n > TS_CAP) {
+    uint64_t *k = keys + beg;
+    uint32_t *v = vals + beg;
+    bitonic_network(n, [&](uint32_t lo, uint32_t hi) {
+      const uint64_t ka = k[lo], kb = k[hi];
+      const uint32_t va = v[lo], vb = v[hi];
+      if (kb < ka || (kb == ka && vb < va)) k[lo] = kb, k[hi] = ka, v[lo] = vb, v[hi] = va;
+    });
+    return;
+  }
+  uint64_t *src = ts_smem, *dst = ts_smem + TS_CAP;  // composites (depth bits << 32 | Gaussian id)
+  uint32_t(*cnt)[RADIX] = reinterpret_cast<uint32_t(*)[RADIX]>(ts_smem + 2 * TS_CAP);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) diff_s = 0;
+  __syncthreads();
+  {
+    const uint32_t first = (uint32_t)keys[beg];
+    uint32_t diff = 0;
+    for (uint32_t i = threadIdx.x; i < n; i += 256) {
+      const uint32_t d = (uint32_t)keys[beg + i];
+      src[i] = ((uint64_t)d << 32) | vals[beg + i];
+      diff |= d ^ first;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) diff |= __shfl_xor(diff, o, 64);
+    if (lane == 0 && diff) atomicOr(&diff_s, diff);
+  }
+  __syncthreads();
+  const uint32_t diff = diff_s;
+  const uint32_t chunk = (((n + 3) >> 2) + 63) & ~63u;  // contiguous elements per wave, a multiple of 64
+  const int nitems = (int)(chunk >> 6);                 // <= TS_ITEMS
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  for (int pass = 0; pass < 4; ++pass) {
+    if (((diff >> (8 * pass)) & 0xffu) == 0) continue;  // every key of the tile has the same digit
+    const int shift = 32 + 8 * pass;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) cnt[w][threadIdx.x] = 0;
+    __syncthreads();
+    uint64_t k[TS_ITEMS];
+    uint32_t rank[TS_ITEMS];
+#pragma unroll
+    for (int j = 0; j < TS_ITEMS; ++j) {
+      if (j < nitems) {
+        const uint32_t idx = wave * chunk + j * 64 + lane;
+        const bool valid = idx < n;
+        k[j] = valid ? src[idx] : ~0ull;
+        const uint32_t d = digit_of(k[j], shift);
+        unsigned long long peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < RADIX_BITS; ++b) {
+          const unsigned long long bal = __ballot((d >> b) & 1u);
+          peers &= ((d >> b) & 1u) ? bal : ~bal;
+        }
+        const uint32_t before = (uint32_t)__popcll(peers & lt_mask);
+        uint32_t prev = 0;
+        if (valid && before == 0) {
+          prev = cnt[wave][d];
+          cnt[wave][d] = prev + (uint32_t)__popcll(peers);
+        }
+        const int leader = __ffsll((long long)peers) - 1;
+        prev = __shfl(prev, leader < 0 ? 0 : leader, 64);
+        rank[j] = prev + before;
+      }
+    }
+    __syncthreads();
+    {  // thread d: exclusive scan of the digit totals, then the per-wave bases of digit d
+      const uint32_t c0 = cnt[0][threadIdx.x], c1 = cnt[1][threadIdx.x], c2 = cnt[2][threadIdx.x],
+                     c3 = cnt[3][threadIdx.x];
+      const uint32_t tot = c0 + c1 + c2 + c3;
+      uint32_t inc = tot;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += t;
+      }
+      if (lane == 63) wtot[wave] = inc;
+      __syncthreads();
+      uint32_t run = inc - tot;
+      for (int w = 0; w < wave; ++w) run += wtot[w];
+      cnt[0][threadIdx.x] = run, run += c0;
+      cnt[1][threadIdx.x] = run, run += c1;
+      cnt[2][threadIdx.x] = run, run += c2;
+      cnt[3][threadIdx.x] = run;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < TS_ITEMS; ++j) {
+      if (j < nitems) {
+        const uint32_t idx = wave * chunk + j * 64 + lane;
+        if (idx < n) dst[cnt[wave][digit_of(k[j], shift)] + rank[j]] = k[j];
+      }
+    }
+    __syncthreads();
+    uint64_t *t = src;
+    src = dst, dst = t;
+  }
+  const uint64_t tbits = (uint64_t)tile << 32;
+  for (uint32_t i = threadIdx.x; i < n; i += 256) {
+    const uint64_t c = src[i];
+    keys[beg + i] = tbits | (c >> 32);
+    vals[beg + i] = (uint32_t)c;
+  }
+}
+
 int scan_block_sums(int nb, uint32_t *block_sums, uint32_t *total, hipStream_t stream) {
   hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(1024), 0, stream, nb, block_sums, total);
   return check_launch();
@@ -276,8 +430,8 @@ int bin_instances(int N, int H, int W, int64_t R_cap, const void *geom, void *bi
   uint64_t *keys_c = at<uint64_t>(bin, B.keys_c);
   uint32_t *vals_c = at<uint32_t>(bin, B.vals_c);
   uint32_t *ranges = at<uint32_t>(bin, B.ranges), *hist = at<uint32_t>(bin, B.hist);
-  const int bits = key_bits(B.T);
-  const int passes = (bits + RADIX_BITS - 1) / RADIX_BITS;
+  const int tile_bits = key_bits(B.T) - 32;  // the radix passes cover the tile id only
+  const int passes = (tile_bits + RADIX_BITS - 1) / RADIX_BITS;
 
   if (N > 0) {
     ScopedTimer tm(T_EMIT, stream);
@@ -293,7 +447,7 @@ int bin_instances(int N, int H, int W, int64_t R_cap, const void *geom, void *bi
     const bool to_sorted = ((passes - 1 - p) & 1) == 0;
     uint64_t *kout = to_sorted ? keys_s : keys_c;
     uint32_t *vout = to_sorted ? vals_s : vals_c;
-    const int shift = p * RADIX_BITS;
+    const int shift = 32 + p * RADIX_BITS;
     hipLaunchKernelGGL(radix_hist_kernel, dim3(nblk), dim3(SORT_BLOCK), 0, stream, kin, total, cap, shift, nblk, hist);
     hipLaunchKernelGGL(radix_rowscan_kernel, dim3(RADIX / 4), dim3(256), 0, stream, nblk, hist);
     hipLaunchKernelGGL(radix_scatter_kernel, dim3(nblk), dim3(SORT_BLOCK), 0, stream, kin, vin, kout, vout, total, cap,
@@ -305,6 +459,14 @@ int bin_instances(int N, int H, int W, int64_t R_cap, const void *geom, void *bi
     ScopedTimer tm(T_RANGES, stream);
     hipLaunchKernelGGL(clear_ranges_kernel, dim3((2 * B.T + 255) / 256), dim3(256), 0, stream, B.T, ranges);
     hipLaunchKernelGGL(tile_ranges_kernel, dim3((cap + 255) / 256), dim3(256), 0, stream, keys_s, total, cap, ranges);
+  }
+  {
+    ScopedTimer tm(T_TILE_SORT, stream);
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(tile_depth_sort_kernel),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                       (int)TS_LDS_BYTES);
+    (void)attr;
+    hipLaunchKernelGGL(tile_depth_sort_kernel, dim3(B.T), dim3(256), TS_LDS_BYTES, stream, ranges, keys_s, vals_s);
   }
   return check_launch();
 }

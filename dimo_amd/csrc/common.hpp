@@ -135,7 +135,7 @@ inline int key_bits(int T) {
 // ---- optional HIP-event timing of kernel groups (off by default; see api.hip) ------------------
 enum TimedKernel {
   T_PREPROCESS_FWD = 0, T_SCAN, T_EMIT, T_SORT, T_RANGES, T_BLEND_FWD, T_BLEND_BWD, T_PREPROCESS_BWD, T_KNN, T_DIST2,
-  T_SSIM_FWD, T_SSIM_BWD, T_DEFORM_FWD, T_DEFORM_BWD, T_LOSS, T_ADAM, T_TIMENET_FWD, T_TIMENET_BWD, TIMED_COUNT
+  T_SSIM_FWD, T_SSIM_BWD, T_DEFORM_FWD, T_DEFORM_BWD, T_LOSS, T_ADAM, T_TIMENET_FWD, T_TIMENET_BWD, T_TILE_SORT, TIMED_COUNT
 };
 class ScopedTimer {
  public:

@@ -11,9 +11,9 @@
 //             the flat gradient bucket) -> embedding backward (control points, latent rows).
 //
 // GEMM core: v_mfma_f32_32x32x2_f32 (exact fp32, k-ordered fma chain), 64x64 block tile, 4 waves of 32x32, K staged
-// through LDS 16 deep in [k][m] order (operand reads are then one ds_read_b32 per lane, conflict-free), register
-// prefetch of the next K stage.  The f32 MFMA issues at the vector rate (64 cycles / instruction), so these GEMMs
-// are MFMA-issue bound, not LDS or HBM bound: 128 workgroups x 3.4 us for a 2048x256x256 layer.
+// through LDS 64 deep in [k][m] order (operand reads are then one ds_read_b32 per lane, conflict-free), register
+// prefetch of the next K stage.  The f32 MFMA issues at the vector rate (64 cycles / instruction), so the floor
+// of a 2048x256x256 layer is 128 workgroups x 3.4 us of MFMA issue; HBM and LDS traffic are far from binding.
 #include <hip/hip_runtime.h>
 
 #include "common.hpp"
@@ -25,83 +25,109 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 64, BN = 64, BK = 16, LDT = 68;
+constexpr int BM = 64, BN = 64, BK = 64, LDT = 65;
 constexpr int MAX_LAYERS = DIMO_TIMENET_MAX_LAYERS;
 constexpr int MAX_PAIRS = DIMO_TIMENET_MAX_PAIRS;
+constexpr int STAGE = BM * BK / 256;  // operand elements per thread per K stage
 
 // ---- operand staging -------------------------------------------------------------------------------------------
-// KC (k contiguous): element (r, k) at src[r * ld + k]; otherwise (r contiguous) at src[k * ld + r].
-template <bool KC>
-__device__ __forceinline__ void load_stage(const float *__restrict__ src, int ld, int rows, int r0, int k0, int kend,
-                                           float (&v)[4]) {
-  const int t = threadIdx.x;
-  if (KC) {
-    const int k = k0 + (t & 15), r = r0 + (t >> 4);
+// A K stage is a 64 x 64 block of each operand, kept in LDS as S[k][m] (LDT = 65: both the transposing store of a
+// k-contiguous source and the row store of an m-contiguous one hit 64 distinct banks; the MFMA operand read
+// S[k + lane/32][m0 + lane%32] is one conflict-free ds_read_b32).  KC (k contiguous): element (r, k) at
+// src[r * ld + k]; otherwise (r contiguous) at src[k * ld + r].  Either way 64 lanes read 256 contiguous bytes.
+// Deep stages on purpose: one workgroup per CU and one wave per SIMD means nothing hides a global load except the
+// 32 MFMAs (2048 cycles) of the stage in flight -- with 16-deep stages the chain was load-latency bound (15 us per
+// 2048x256x256 layer instead of 4).
+// `vec`: 16-byte loads along the contiguous dimension (pointer 16-B aligned, ld and the contiguous extent
+// multiples of 4) -- a quarter of the load instructions, which is what bounds these GEMMs: one dword load per lane
+// moves 256 B per wave-instruction and the CU's load path (not HBM, not the MFMA pipe) was the limit.
+// Loads are UNCONDITIONAL from clamped addresses and the out-of-range lanes are zeroed when the stage is stored
+// to LDS (`ok` bit per load): a branch around each load makes the compiler drain vmcnt at every join, which
+// serialises the prefetch with the MFMAs it is supposed to hide under.
+template <bool KC, bool VEC>
+__device__ __forceinline__ uint32_t load_stage(const float *__restrict__ src, int ld, int rows, int r0, int k0,
+                                               int kend, float (&v)[STAGE]) {
+  uint32_t ok = 0;
+  if (VEC) {
+    const int q = (threadIdx.x & 15) * 4, h = threadIdx.x >> 4;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int rr = r + 16 * e;
-      v[e] = (rr < rows && k < kend) ? src[(size_t)rr * ld + k] : 0.f;
+    for (int e = 0; e < STAGE / 4; ++e) {
+      const int r = r0 + (KC ? h + 16 * e : q), k = k0 + (KC ? q : h + 16 * e);
+      ok |= (uint32_t)(r < rows && k < kend) << e;
+      const int rc = min(r, rows - (KC ? 1 : 4)), kc = min(k, kend - (KC ? 4 : 1));
+      const float4 x = *reinterpret_cast<const float4 *>(src + (KC ? (size_t)rc * ld + kc : (size_t)kc * ld + rc));
+      v[4 * e] = x.x, v[4 * e + 1] = x.y, v[4 * e + 2] = x.z, v[4 * e + 3] = x.w;
     }
-  } else {
-    const int r = r0 + (t & 63), k = k0 + (t >> 6);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int kk = k + 4 * e;
-      v[e] = (r < rows && kk < kend) ? src[(size_t)kk * ld + r] : 0.f;
-    }
+    return ok;
   }
+  const int lo = threadIdx.x & 63, hi = threadIdx.x >> 6;
+#pragma unroll
+  for (int e = 0; e < STAGE; ++e) {
+    const int r = r0 + (KC ? hi + 4 * e : lo), k = k0 + (KC ? lo : hi + 4 * e);
+    ok |= (uint32_t)(r < rows && k < kend) << e;
+    const int rc = min(r, rows - 1), kc = min(k, kend - 1);
+    v[e] = src[KC ? (size_t)rc * ld + kc : (size_t)kc * ld + rc];
+  }
+  return ok;
 }
-template <bool KC>
-__device__ __forceinline__ void store_stage(float (*S)[LDT], const float (&v)[4]) {
-  const int t = threadIdx.x;
-  if (KC) {
-    const int k = t & 15, r = t >> 4;
+template <bool KC, bool VEC>
+__device__ __forceinline__ void store_stage(float (*S)[LDT], uint32_t ok, const float (&v)[STAGE]) {
+  if (VEC) {  // banks (k + m) % 64: 16 quads x 4 rows of a wave cover all 64 for each j
+    const int q = (threadIdx.x & 15) * 4, h = threadIdx.x >> 4;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) S[k][r + 16 * e] = v[e];
-  } else {
-    const int r = t & 63, k = t >> 6;
+    for (int e = 0; e < STAGE / 4; ++e)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) S[k + 4 * e][r] = v[e];
+      for (int j = 0; j < 4; ++j) {
+        const float x = ((ok >> e) & 1u) ? v[4 * e + j] : 0.f;
+        if (KC)
+          S[q + j][h + 16 * e] = x;
+        else
+          S[h + 16 * e][q + j] = x;
+      }
+    return;
+  }
+  const int lo = threadIdx.x & 63, hi = threadIdx.x >> 6;
+#pragma unroll
+  for (int e = 0; e < STAGE; ++e) {
+    const float x = ((ok >> e) & 1u) ? v[e] : 0.f;
+    if (KC)
+      S[lo][hi + 4 * e] = x;
+    else
+      S[hi + 4 * e][lo] = x;
   }
 }
 
-// acc (32x32 per wave) += A[m0.., kbeg..kend) * B[kbeg..kend), n0..); bias_sum (threads 0..63) += column sums of A
-template <bool A_KC, bool B_KC, bool BIAS_SUM>
+// acc (32x32 per wave) += A[m0.., kbeg..kend) * B[kbeg..kend), n0..); bias_sum += this thread's share of the column
+// sums of A (column threadIdx % 64, k rows (threadIdx / 64) * 16 .. + 16 of every stage)
+template <bool A_KC, bool B_KC, bool BIAS_SUM, bool VEC>
 __device__ __forceinline__ void gemm_segment(const float *__restrict__ A, int lda, const float *__restrict__ B,
                                              int ldb, int M, int N, int m0, int n0, int kbeg, int kend,
-                                             float (*As)[BK][LDT], float (*Bs)[BK][LDT], f32x16 &acc,
-                                             float &bias_sum) {
+                                             float (*As)[LDT], float (*Bs)[LDT], f32x16 &acc, float &bias_sum) {
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
   const int nk = (kend - kbeg + BK - 1) / BK;
-  float ra[4], rb[4];
-  load_stage<A_KC>(A, lda, M, m0, kbeg, kend, ra);
-  load_stage<B_KC>(B, ldb, N, n0, kbeg, kend, rb);
-  store_stage<A_KC>(As[0], ra);
-  store_stage<B_KC>(Bs[0], rb);
-  __syncthreads();
+  float ra[STAGE], rb[STAGE];
+  uint32_t oka = load_stage<A_KC, VEC>(A, lda, M, m0, kbeg, kend, ra);
+  uint32_t okb = load_stage<B_KC, VEC>(B, ldb, N, n0, kbeg, kend, rb);
   for (int it = 0; it < nk; ++it) {
-    const int cur = it & 1;
-    const bool more = it + 1 < nk;
-    if (more) {
-      load_stage<A_KC>(A, lda, M, m0, kbeg + (it + 1) * BK, kend, ra);
-      load_stage<B_KC>(B, ldb, N, n0, kbeg + (it + 1) * BK, kend, rb);
+    __syncthreads();  // the previous stage (or segment) has been consumed
+    store_stage<A_KC, VEC>(As, oka, ra);
+    store_stage<B_KC, VEC>(Bs, okb, rb);
+    __syncthreads();
+    if (it + 1 < nk) {  // in flight under this stage's MFMAs
+      oka = load_stage<A_KC, VEC>(A, lda, M, m0, kbeg + (it + 1) * BK, kend, ra);
+      okb = load_stage<B_KC, VEC>(B, ldb, N, n0, kbeg + (it + 1) * BK, kend, rb);
     }
-#pragma unroll
+#pragma unroll 8
     for (int kk = 0; kk < BK; kk += 2) {
-      const float a = As[cur][kk + (lane >> 5)][wm + (lane & 31)];
-      const float b = Bs[cur][kk + (lane >> 5)][wn + (lane & 31)];
+      const float a = As[kk + (lane >> 5)][wm + (lane & 31)];
+      const float b = Bs[kk + (lane >> 5)][wn + (lane & 31)];
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
     }
-    if (BIAS_SUM && t < 64) {
+    if (BIAS_SUM) {
 #pragma unroll
-      for (int kk = 0; kk < BK; ++kk) bias_sum += As[cur][kk][t];
+      for (int kk = 0; kk < 16; ++kk) bias_sum += As[wave * 16 + kk][lane];
     }
-    if (more) {
-      store_stage<A_KC>(As[cur ^ 1], ra);
-      store_stage<B_KC>(Bs[cur ^ 1], rb);
-    }
-    __syncthreads();
   }
 }
 
@@ -119,9 +145,9 @@ struct GemmArgs {
   float *C_alt;
 };
 
-template <bool A_KC, bool B_KC>
+template <bool A_KC, bool B_KC, bool VEC>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
-  __shared__ float As[2][BK][LDT], Bs[2][BK][LDT];
+  __shared__ float As[BK][LDT], Bs[BK][LDT];
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
   const bool alt = blockIdx.z == 1;
   f32x16 acc;
@@ -129,8 +155,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
   float unused = 0.f;
   for (int s = 0; s < g.nseg; ++s)
-    gemm_segment<A_KC, B_KC, false>(g.A[s], g.lda[s], (alt && s == 0) ? g.B_alt : g.B[s], g.ldb[s], g.M, g.N, m0, n0,
-                                    0, g.K[s], As, Bs, acc, unused);
+    gemm_segment<A_KC, B_KC, false, VEC>(g.A[s], g.lda[s], (alt && s == 0) ? g.B_alt : g.B[s], g.ldb[s], g.M, g.N,
+                                         m0, n0, 0, g.K[s], As, Bs, acc, unused);
   const float *bias = alt ? g.bias_alt : g.bias;
   float *C = alt ? g.C_alt : g.C;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -156,7 +182,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 struct WgradProblem {
   const float *dZ, *X;
   float *gW, *gbias;
-  int ld_dz, ld_x, ld_w, M, N, tiles_n, tile_begin;
+  int ld_dz, ld_x, ld_w, M, N, tiles_n, tile_begin, vec;
 };
 struct WgradArgs {
   WgradProblem p[MAX_LAYERS];
@@ -164,7 +190,7 @@ struct WgradArgs {
 };
 
 __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs g) {
-  __shared__ float As[2][BK][LDT], Bs[2][BK][LDT];
+  __shared__ float As[BK][LDT], Bs[BK][LDT];
   int pi = 0;
   while (pi + 1 < g.nprob && (int)blockIdx.x >= g.p[pi + 1].tile_begin) ++pi;
   const WgradProblem &p = g.p[pi];
@@ -177,13 +203,16 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs g) {
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
   float bsum = 0.f;
-  if (tn == 0)
-    gemm_segment<false, false, true>(p.dZ, p.ld_dz, p.X, p.ld_x, p.M, p.N, m0, n0, kbeg, kend, As, Bs, acc, bsum);
-  else
-    gemm_segment<false, false, false>(p.dZ, p.ld_dz, p.X, p.ld_x, p.M, p.N, m0, n0, kbeg, kend, As, Bs, acc, bsum);
+  if (p.vec) {
+    if (tn == 0)
+      gemm_segment<false, false, true, true>(p.dZ, p.ld_dz, p.X, p.ld_x, p.M, p.N, m0, n0, kbeg, kend, As, Bs, acc, bsum);
+    else
+      gemm_segment<false, false, false, true>(p.dZ, p.ld_dz, p.X, p.ld_x, p.M, p.N, m0, n0, kbeg, kend, As, Bs, acc, bsum);
+  } else {
+    gemm_segment<false, false, true, false>(p.dZ, p.ld_dz, p.X, p.ld_x, p.M, p.N, m0, n0, kbeg, kend, As, Bs, acc, bsum);
+  }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (tn == 0 && p.gbias && threadIdx.x < 64 && m0 + (int)threadIdx.x < p.M)
-    unsafeAtomicAdd(p.gbias + m0 + threadIdx.x, bsum);
+  if (tn == 0 && p.gbias && m0 + lane < p.M) unsafeAtomicAdd(p.gbias + m0 + lane, bsum);
   const int n = n0 + (wave & 1) * 32 + (lane & 31);
   const int mb = m0 + (wave >> 1) * 32 + 4 * (lane >> 5);
   if (n >= p.N) return;
@@ -225,42 +254,43 @@ __global__ void embed_kernel(int P, int Mc, int E, int ld, int pts_freqs, int ti
   cat[(size_t)row * ld + col] = v;
 }
 
-// g_c_xyz[m, d] += sum_p sum_f 2^f (g_sin cos - g_cos sin)   (sin/cos re-read from the saved embedding)
-__global__ void embed_bwd_pts_kernel(int P, int Mc, int ld, int pts_freqs, const float *__restrict__ cat,
-                                     const float *__restrict__ g_cat, float *__restrict__ g_c_xyz) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= Mc * 3) return;
-  const int m = idx / 3, d = idx % 3;
-  float s = 0.f;
-  for (int p = 0; p < P; ++p) {
-    const size_t base = (size_t)(p * Mc + m) * ld;
-    for (int f = 0; f < pts_freqs; ++f) {
-      const float sn = cat[base + 6 * f + d], cs = cat[base + 6 * f + 3 + d];
-      s += exp2f((float)f) * (g_cat[base + 6 * f + d] * cs - g_cat[base + 6 * f + 3 + d] * sn);
+// Backward of the embedding, 64 rows (pair p, control point m) per block:
+//   g_c_xyz[m, d]              += sum_f 2^f (g_sin cos - g_cos sin)      (sin / cos re-read from the saved embedding)
+//   g_latent_table[row(p), j]  += g_cat[(p, m), lat0 + j]
+// Each thread folds its rows first; the adds across blocks / pairs are hardware fp32 atomics.
+__global__ __launch_bounds__(256) void embed_bwd_kernel(int rows, int Mc, int ld, int pts_freqs, int lat0,
+                                                        int latent_dim, const float *__restrict__ cat,
+                                                        const float *__restrict__ g_cat, PairTable pt,
+                                                        float *__restrict__ g_c_xyz,
+                                                        float *__restrict__ g_latent_table) {
+  const int row0 = blockIdx.x * 64, t = threadIdx.x;
+  if (g_c_xyz && t < 192) {
+    const int row = row0 + t / 3, d = t % 3;
+    if (row < rows) {
+      const size_t base = (size_t)row * ld;
+      float s = 0.f;
+      for (int f = 0; f < pts_freqs; ++f) {
+        const float sn = cat[base + 6 * f + d], cs = cat[base + 6 * f + 3 + d];
+        s += exp2f((float)f) * (g_cat[base + 6 * f + d] * cs - g_cat[base + 6 * f + 3 + d] * sn);
+      }
+      unsafeAtomicAdd(g_c_xyz + (row % Mc) * 3 + d, s);
     }
   }
-  g_c_xyz[idx] += s;
-}
-
-// g_latent_table[row(p), j] += sum_m g_cat[(p, m), lat0 + j]; one block per pair
-__global__ __launch_bounds__(256) void embed_bwd_latent_kernel(int Mc, int ld, int lat0, int latent_dim,
-                                                               const float *__restrict__ g_cat, PairTable pt,
-                                                               float *__restrict__ g_latent_table) {
-  __shared__ float red[256];
-  const int p = blockIdx.x;
+  if (!g_latent_table) return;
   for (int j0 = 0; j0 < latent_dim; j0 += 32) {
-    const int j = j0 + (threadIdx.x & 31), grp = threadIdx.x >> 5;
+    const int j = j0 + (t & 31), first = row0 + (t >> 5) * 8;
+    if (j >= latent_dim) continue;
     float s = 0.f;
-    if (j < latent_dim)
-      for (int m = grp; m < Mc; m += 8) s += g_cat[(size_t)(p * Mc + m) * ld + lat0 + j];
-    red[threadIdx.x] = s;
-    __syncthreads();
-    if (threadIdx.x < 32 && j < latent_dim) {
-      float tot = 0.f;
-      for (int q = 0; q < 8; ++q) tot += red[q * 32 + threadIdx.x];
-      unsafeAtomicAdd(g_latent_table + (size_t)pt.latent_row[p] * latent_dim + j, tot);
+    int cur = -1;
+    for (int row = first; row < min(rows, first + 8); ++row) {
+      const int p = row / Mc;
+      if (p != cur) {
+        if (cur >= 0) unsafeAtomicAdd(g_latent_table + (size_t)pt.latent_row[cur] * latent_dim + j, s);
+        cur = p, s = 0.f;
+      }
+      s += g_cat[(size_t)row * ld + lat0 + j];
     }
-    __syncthreads();
+    if (cur >= 0) unsafeAtomicAdd(g_latent_table + (size_t)pt.latent_row[cur] * latent_dim + j, s);
   }
 }
 
@@ -361,10 +391,22 @@ void layer_input(const Plan &pl, int l, size_t &off, int &ld, int &K) {
 }
 int act_ld(const Plan &pl, int l) { return l == pl.skip ? pl.CAT : pl.Wd; }
 
+// 16-byte loads are legal for an operand whose base is 16-B aligned, ld % 4 == 0 and contiguous extent % 4 == 0
+bool vec_ok(const float *p, int ld, int extent) {
+  return p && (reinterpret_cast<uintptr_t>(p) & 15) == 0 && (ld & 3) == 0 && (extent & 3) == 0;
+}
+
 template <bool A_KC, bool B_KC>
 void launch_gemm(const GemmArgs &g, int z, hipStream_t s) {
+  bool vec = true;
+  for (int i = 0; i < g.nseg; ++i)
+    vec = vec && vec_ok(g.A[i], g.lda[i], A_KC ? g.K[i] : g.M) && vec_ok(g.B[i], g.ldb[i], B_KC ? g.K[i] : g.N);
+  if (z > 1) vec = vec && vec_ok(g.B_alt, g.ldb[0], B_KC ? g.K[0] : g.N);
   dim3 grid((g.M + BM - 1) / BM, (g.N + BN - 1) / BN, z);
-  gemm_kernel<A_KC, B_KC><<<grid, 256, 0, s>>>(g);
+  if (vec)
+    gemm_kernel<A_KC, B_KC, true><<<grid, 256, 0, s>>>(g);
+  else
+    gemm_kernel<A_KC, B_KC, false><<<grid, 256, 0, s>>>(g);
 }
 
 bool fill_pairs(int P, const float *times, const int *rows, PairTable &pt) {
@@ -484,6 +526,7 @@ extern "C" int dimo_timenet_backward(const dimo_timenet_desc *d, int P, int M, c
       WgradProblem &p = w.p[np++];
       p.dZ = dz, p.ld_dz = ld_dz, p.X = x, p.ld_x = ld_x, p.gW = d->g_weight[li], p.gbias = d->g_bias[li];
       p.ld_w = No, p.M = Mo, p.N = No, p.tiles_n = (No + BN - 1) / BN, p.tile_begin = tiles;
+      p.vec = vec_ok(dz, ld_dz, Mo) && vec_ok(x, ld_x, No);
       tiles += ((Mo + BM - 1) / BM) * p.tiles_n;
     };
     for (int l = 0; l < D; ++l) {
@@ -506,11 +549,12 @@ extern "C" int dimo_timenet_backward(const dimo_timenet_desc *d, int P, int M, c
     ksplit = (R + w.kchunk - 1) / w.kchunk;
     wgrad_kernel<<<dim3(tiles, ksplit), 256, 0, s>>>(w);
   }
-  if (g_c_xyz && d->pts_freqs > 0)
-    embed_bwd_pts_kernel<<<(M * 3 + 63) / 64, 64, 0, s>>>(P, M, pl.CAT, d->pts_freqs, ws + pl.cat, ws + pl.g_cat,
-                                                          g_c_xyz);
-  if (g_latent_table && d->latent_dim > 0)
-    embed_bwd_latent_kernel<<<P, 256, 0, s>>>(M, pl.CAT, 6 * d->pts_freqs + 2 * d->time_freqs, d->latent_dim,
-                                              ws + pl.g_cat, pt, g_latent_table);
+  {
+    float *gc = d->pts_freqs > 0 ? g_c_xyz : nullptr;
+    float *gl = d->latent_dim > 0 ? g_latent_table : nullptr;
+    if (gc || gl)
+      embed_bwd_kernel<<<(R + 63) / 64, 256, 0, s>>>(R, M, pl.CAT, d->pts_freqs, 6 * d->pts_freqs + 2 * d->time_freqs,
+                                                     d->latent_dim, ws + pl.cat, ws + pl.g_cat, pt, gc, gl);
+  }
   return check_launch();
 }

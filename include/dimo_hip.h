@@ -49,7 +49,8 @@ const char *dimo_last_error(void);
  * stream it is launched on.  dimo_timing_read synchronises the device and returns the summed
  * duration and launch count of one group: "preprocess_fwd" "scan" "emit" "sort" "ranges" "blend_fwd"
  * "blend_bwd" "preprocess_bwd" "knn" "dist2" "ssim_fwd" "ssim_bwd" "deform_fwd" "deform_bwd" "image_loss" "adam"
- * "timenet_fwd" "timenet_bwd".
+ * "timenet_fwd" "timenet_bwd" "tile_sort" ("sort" = the radix passes over the tile bits, "tile_sort" = the per-tile
+ * depth ordering).
  * dimo_timing_enable(1) clears earlier records; returns the previous state.  dimo_timing_select restricts the
  * instrumentation to a comma-separated list of groups (NULL or "": all) -- two event records per launch are not
  * free, a throughput run that only needs one kernel's duration selects that kernel. */
