@@ -186,7 +186,8 @@ def main():
             (o["image"].sum() + o["depth"].sum() + o["normal"].sum() + o["alpha"].sum()).backward()
         torch.cuda.synchronize()
         L.dimo_timing_enable(0)
-        iso_ms, iso_n = read_timing()["blend_bwd"]
+        timing_iso = read_timing()
+        iso_ms, iso_n = timing_iso["blend_bwd"]
         tr.renderer.gaussians.zero_grad()
         if pol is not None:
             pol.check()
@@ -227,6 +228,7 @@ def main():
                          "note": "tile blend is FP32-VALU/LDS bound, not HBM bound (each 64-B record is reused by 256 "
                                  "pixels); the HBM fraction is reported as required, see DESIGN.md"},
             "kernels_ms_per_launch": {k: (v[0] / v[1] if v[1] else None) for k, v in timing_all.items()},
+            "kernels_ms_per_launch_isolated": {k: (v[0] / v[1] if v[1] else None) for k, v in timing_iso.items()},
         }
         if world == 1 and not args.no_cpu_baseline:
             try:

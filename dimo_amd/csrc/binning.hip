@@ -234,9 +234,11 @@ __global__ void __launch_bounds__(SORT_BLOCK) radix_scatter_kernel(
 }
 
 // ------------------------------------------------------------------------------------ ranges
-__global__ void __launch_bounds__(256) clear_ranges_kernel(int T, uint32_t *__restrict__ ranges) {
+__global__ void __launch_bounds__(256) clear_ranges_kernel(int T, uint32_t *__restrict__ ranges,
+                                                           uint32_t *__restrict__ work_count) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i < 2 * T) ranges[i] = 0;
+  if (i == 0) *work_count = 0;  // the blend forward queues the backward's (tile, bucket) items behind it
 }
 __global__ void __launch_bounds__(256) tile_ranges_kernel(const uint64_t *__restrict__ keys,
                                                           const uint32_t *__restrict__ total, uint32_t R_cap,
@@ -457,7 +459,8 @@ int bin_instances(int N, int H, int W, int64_t R_cap, const void *geom, void *bi
   delete sort_tm;
   {
     ScopedTimer tm(T_RANGES, stream);
-    hipLaunchKernelGGL(clear_ranges_kernel, dim3((2 * B.T + 255) / 256), dim3(256), 0, stream, B.T, ranges);
+    hipLaunchKernelGGL(clear_ranges_kernel, dim3((2 * B.T + 255) / 256), dim3(256), 0, stream, B.T, ranges,
+                       at<uint32_t>(bin, B.work));
     hipLaunchKernelGGL(tile_ranges_kernel, dim3((cap + 255) / 256), dim3(256), 0, stream, keys_s, total, cap, ranges);
   }
   {

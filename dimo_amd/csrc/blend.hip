@@ -14,12 +14,23 @@
 // Backward is free of global atomics: per (tile, instance) sums are reduced inside the workgroup
 // (DPP butterfly over the wave -> LDS) and written as ONE 64-byte record per instance at the
 // instance's emission position, so that the per-Gaussian kernel can sum a contiguous run.
+//
+// Backward work items are BUCKETS of 64 consecutive list entries, not tiles.  A tile's list is a sequential
+// recurrence (transmittance), a trained scene saturates after ~160 of ~1200 entries on average but after 550 on
+// the worst tile, and 800 tile-sized workgroups on 256 CUs leave the chip waiting for that one chain.  The forward
+// pass therefore checkpoints every pixel's compositing state (T, the 7 accumulated features, the accumulated
+// weight) at each bucket boundary it crosses and queues one item per bucket some pixel of the tile reaches; the
+// backward runs each bucket front-to-back from its checkpoint:
+//     dL/dalpha_i = D_i T_i - (S - P_i) / (1 - alpha_i),   P_i = sum_{j<=i} D_j w_j,  S = P_last + T_final (bg . dL/dC)
+// with P at the bucket start = dL/dout . (checkpointed accumulators) and S from the final accumulators.  T_i is
+// the forward's own product (no division chain), and ~2700 equal-sized items replace ~800 unequal ones.
 #include "common.hpp"
 
 namespace dimo {
 
 constexpr int BLEND_BLOCK = 256;
 constexpr int BATCH = 256;
+constexpr int BWD_GRID = 4096;  // persistent workgroups looping over the (tile, bucket) items
 
 __device__ __forceinline__ void pixel_of_thread(int tile_x, int tile_y, int &px, int &py) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -67,7 +78,9 @@ __global__ void __launch_bounds__(BLEND_BLOCK) blend_fwd_kernel(
     int H, int W, int tiles_x, const uint32_t *__restrict__ ranges, const uint32_t *__restrict__ vals_sorted,
     const Splat *__restrict__ splat, const float *__restrict__ bg, float *__restrict__ out_color,
     float *__restrict__ out_depth, float *__restrict__ out_normal, float *__restrict__ out_alpha,
-    float *__restrict__ final_T, uint32_t *__restrict__ n_contrib) {
+    float *__restrict__ final_T, uint32_t *__restrict__ n_contrib, float *__restrict__ final_acc,
+    float *__restrict__ ckpt, uint32_t *__restrict__ work) {
+  __shared__ uint32_t s_last[BLEND_BLOCK / 64];
   __shared__ float4 s_geo[BATCH];   // x y A B
   __shared__ float4 s_col[BATCH];   // C opacity r g
   __shared__ float4 s_aux[BATCH];   // b depth nx ny
@@ -88,6 +101,10 @@ __global__ void __launch_bounds__(BLEND_BLOCK) blend_fwd_kernel(
   float acc[NFEAT] = {0, 0, 0, 0, 0, 0, 0};
   uint32_t last = 0;
   bool done = !inside;
+  // checkpoint slots of this tile: (lo / BUCKET + tile) + bucket -- strictly increasing with the tile index and
+  // never overlapping (ceil(len / BUCKET) <= floor((lo + len) / BUCKET) - floor(lo / BUCKET) + 1)
+  float *const ck_base = ckpt + ((size_t)(lo / BUCKET) + tile) * (CKPT_FLOATS * TILE * TILE) + threadIdx.x;
+  uint32_t next_ck = 0;  // first bucket whose start state this wave has not stored yet (wave-uniform)
 
   for (uint32_t start = lo; start < hi; start += BATCH) {
     if (__syncthreads_count(done) == BLEND_BLOCK) break;
@@ -104,12 +121,31 @@ __global__ void __launch_bounds__(BLEND_BLOCK) blend_fwd_kernel(
     __syncthreads();
     const int count = (int)min((uint32_t)BATCH, hi - start);
     const int mine = compact_for_wave(s_mask, s_list[wave], count, wave, lane);
+    // Software pipeline over the wave's list: the index of visit t+2 and the record of visit t+1 are in flight
+    // from LDS while visit t computes (index -> readfirstlane -> record is a dependent two-hop chain otherwise
+    // paid in full on every visit of this sequential loop).
+    int raw_next = (int)s_list[wave][mine > 1 ? 1 : 0];
+    int jn = mine > 0 ? __builtin_amdgcn_readfirstlane((int)s_list[wave][0]) : 0;
+    float4 gn = s_geo[jn], cn = s_col[jn], an = s_aux[jn];
+    float nzn = NORMAL ? s_nz[jn] : 0.0f;
     for (int t = 0; t < mine; ++t) {
       if (__ballot(!done) == 0) break;  // whole wave finished
-      const int j = __builtin_amdgcn_readfirstlane((int)s_list[wave][t]);
+      const int j = jn;
+      const float4 g = gn, c = cn, a = an;
+      const float nz = nzn;
+      jn = __builtin_amdgcn_readfirstlane(raw_next);
+      raw_next = (int)s_list[wave][min(t + 2, mine - 1)];
+      gn = s_geo[jn], cn = s_col[jn], an = s_aux[jn];
+      if (NORMAL) nzn = s_nz[jn];
+      for (const uint32_t eb = ((start - lo) + (uint32_t)j) / BUCKET; next_ck <= eb; ++next_ck) {
+        float *ck = ck_base + (size_t)next_ck * (CKPT_FLOATS * TILE * TILE);
+        ck[0] = T;
+#pragma unroll
+        for (int k = 0; k < NFEAT; ++k) ck[(1 + k) * TILE * TILE] = acc[k];
+        ck[8 * TILE * TILE] = wsum;
+      }
+      // (a branch-free, predicated form of this visit was measured slower: 103 -> 109 us; the wave-level skips pay)
       if (done) continue;
-      const float4 g = s_geo[j];
-      const float4 c = s_col[j];
       const float dx = g.x - pxf, dy = g.y - pyf;
       const float power = -0.5f * (g.z * dx * dx + c.x * dy * dy) - g.w * dx * dy;
       if (power > 0.0f) continue;
@@ -121,9 +157,8 @@ __global__ void __launch_bounds__(BLEND_BLOCK) blend_fwd_kernel(
         continue;
       }
       const float w = alpha * T;
-      const float4 a = s_aux[j];
       acc[0] += c.z * w, acc[1] += c.w * w, acc[2] += a.x * w, acc[3] += a.y * w;
-      if (NORMAL) acc[4] += a.z * w, acc[5] += a.w * w, acc[6] += s_nz[j] * w;
+      if (NORMAL) acc[4] += a.z * w, acc[5] += a.w * w, acc[6] += nz * w;
       wsum += w;
       T = test_T;
       last = (start - lo) + (uint32_t)j + 1u;
@@ -133,6 +168,9 @@ __global__ void __launch_bounds__(BLEND_BLOCK) blend_fwd_kernel(
     const size_t HW = (size_t)H * W, pix = (size_t)py * W + px;
     final_T[pix] = T;
     n_contrib[pix] = last;
+#pragma unroll
+    for (int k = 0; k < NFEAT; ++k) final_acc[k * HW + pix] = acc[k];
+    final_acc[7 * HW + pix] = wsum;
     out_color[pix] = acc[0] + T * bg[0];
     out_color[HW + pix] = acc[1] + T * bg[1];
     out_color[2 * HW + pix] = acc[2] + T * bg[2];
@@ -143,6 +181,20 @@ __global__ void __launch_bounds__(BLEND_BLOCK) blend_fwd_kernel(
       out_normal[2 * HW + pix] = acc[6];
     }
     out_alpha[pix] = wsum;
+  }
+  // queue one backward item per bucket some pixel of this tile reaches
+  uint32_t m = last;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
+  if (lane == 0) s_last[wave] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t deepest = max(max(s_last[0], s_last[1]), max(s_last[2], s_last[3]));
+    const uint32_t nb = (deepest + BUCKET - 1) / BUCKET;
+    if (nb) {
+      const uint32_t base = atomicAdd(work, nb);
+      for (uint32_t b = 0; b < nb; ++b) work[1 + base + b] = ((uint32_t)tile << 12) | b;
+    }
   }
 }
 
@@ -202,57 +254,59 @@ __global__ void __launch_bounds__(BLEND_BLOCK) blend_bwd_kernel(
     int H, int W, int tiles_x, uint32_t R_cap, const uint32_t *__restrict__ ranges,
     const uint32_t *__restrict__ vals_sorted, const Splat *__restrict__ splat, const uint16_t *__restrict__ rect,
     const uint32_t *__restrict__ offsets, const float *__restrict__ bg, const float *__restrict__ final_T,
-    const uint32_t *__restrict__ n_contrib, const float *__restrict__ dL_dcolor, const float *__restrict__ dL_ddepth,
+    const uint32_t *__restrict__ n_contrib, const float *__restrict__ final_acc, const float *__restrict__ ckpt,
+    const uint32_t *__restrict__ work, const float *__restrict__ dL_dcolor, const float *__restrict__ dL_ddepth,
     const float *__restrict__ dL_dnormal, const float *__restrict__ dL_dalpha, SplatGrad *__restrict__ inst_grad,
     uint8_t *__restrict__ inst_flag) {
-  __shared__ float4 s_geo[BATCH];
-  __shared__ float4 s_col[BATCH];
-  __shared__ float4 s_aux[BATCH];
-  __shared__ float s_nz[BATCH];
-  __shared__ uint32_t s_emit[BATCH];
-  __shared__ uint32_t s_mask[BATCH];
-  __shared__ uint16_t s_list[BLEND_BLOCK / 64][BATCH];
-  __shared__ float s_acc[BATCH][16];
-  __shared__ uint32_t s_max[BLEND_BLOCK / 64];
+  __shared__ float4 s_geo[BUCKET];
+  __shared__ float4 s_col[BUCKET];
+  __shared__ float4 s_aux[BUCKET];
+  __shared__ float s_nz[BUCKET];
+  __shared__ uint32_t s_emit[BUCKET];
+  __shared__ uint32_t s_mask[BUCKET];
+  __shared__ uint16_t s_list[BLEND_BLOCK / 64][BUCKET];
+  __shared__ float s_acc[BUCKET][16];
 
-  const int tile = blockIdx.x;
-  const int tile_x = tile % tiles_x, tile_y = tile / tiles_x;
-  const uint32_t lo = ranges[2 * tile], hi = ranges[2 * tile + 1];
-  if (hi == lo) return;
-  int px, py;
-  pixel_of_thread(tile_x, tile_y, px, py);
-  const bool inside = px < W && py < H;
-  const float pxf = (float)px, pyf = (float)py;
-  const size_t HW = (size_t)H * W, pix = (size_t)py * W + px;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const size_t HW = (size_t)H * W;
+  const uint32_t n_items = work[0];
+  for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
+    const uint32_t code = work[1 + item];
+    const int tile = (int)(code >> 12);
+    const uint32_t blo = (code & 0xfffu) * BUCKET;
+    const int tile_x = tile % tiles_x, tile_y = tile / tiles_x;
+    const uint32_t lo = ranges[2 * tile], hi = ranges[2 * tile + 1];
+    const int count = (int)min((uint32_t)BUCKET, hi - lo - blo);
+    int px, py;
+    pixel_of_thread(tile_x, tile_y, px, py);
+    const bool inside = px < W && py < H;
+    const float pxf = (float)px, pyf = (float)py;
+    const size_t pix = (size_t)py * W + px;
 
-  const uint32_t last = inside ? n_contrib[pix] : 0u;
-  float T = 0.0f, Q = 0.0f;
-  float dp[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // dL/d{r,g,b,depth,nx,ny,nz,alpha} at this pixel
-  if (inside) {
-    T = final_T[pix];
-    if (dL_dcolor) dp[0] = dL_dcolor[pix], dp[1] = dL_dcolor[HW + pix], dp[2] = dL_dcolor[2 * HW + pix];
-    if (dL_ddepth) dp[3] = dL_ddepth[pix];
-    if (NORMAL && dL_dnormal) dp[4] = dL_dnormal[pix], dp[5] = dL_dnormal[HW + pix], dp[6] = dL_dnormal[2 * HW + pix];
-    if (dL_dalpha) dp[7] = dL_dalpha[pix];
-    // Q carries sum_{j>i} D_j alpha_j T_j + T_final * (bg . dL/dcolor)
-    Q = T * (bg[0] * dp[0] + bg[1] * dp[1] + bg[2] * dp[2]);
-  }
-  // deepest contributor over the tile
-  uint32_t m = last;
+    const uint32_t last = inside ? n_contrib[pix] : 0u;
+    float T = 0.0f, P = 0.0f, S = 0.0f;
+    float dp[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // dL/d{r,g,b,depth,nx,ny,nz,alpha} at this pixel
+    if (last > blo) {
+      if (dL_dcolor) dp[0] = dL_dcolor[pix], dp[1] = dL_dcolor[HW + pix], dp[2] = dL_dcolor[2 * HW + pix];
+      if (dL_ddepth) dp[3] = dL_ddepth[pix];
+      if (NORMAL && dL_dnormal) dp[4] = dL_dnormal[pix], dp[5] = dL_dnormal[HW + pix], dp[6] = dL_dnormal[2 * HW + pix];
+      if (dL_dalpha) dp[7] = dL_dalpha[pix];
+      const float *c = ckpt + ((size_t)(lo / BUCKET) + tile + blo / BUCKET) * (CKPT_FLOATS * TILE * TILE) + threadIdx.x;
+      T = c[0];
+      P = dp[7] * c[8 * TILE * TILE];
+      S = dp[7] * final_acc[7 * HW + pix] + final_T[pix] * (bg[0] * dp[0] + bg[1] * dp[1] + bg[2] * dp[2]);
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
-  if (lane == 0) s_max[wave] = m;
-  __syncthreads();
-  const uint32_t max_last = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
+      for (int k = 0; k < (NORMAL ? 7 : 4); ++k) {
+        P += dp[k] * c[(1 + k) * TILE * TILE];
+        S += dp[k] * final_acc[k * HW + pix];
+      }
+    }
+    // deepest entry any pixel of this wave still looks at
+    uint32_t wlast = last;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) wlast = max(wlast, (uint32_t)__shfl_xor((int)wlast, o, 64));
 
-  // Instances no pixel reaches (behind the saturation depth of the whole tile, or culled) are the majority in a
-  // trained scene: they get no record at all -- inst_flag (zeroed by one small memset) stays 0 for them.
-
-  for (uint32_t top = max_last; top > 0;) {
-    const uint32_t blo = top > BATCH ? top - BATCH : 0u;
-    const int count = (int)(top - blo);
-    __syncthreads();  // previous batch fully consumed
+    __syncthreads();  // previous item fully consumed
     if ((int)threadIdx.x < count) {
       const uint32_t g = vals_sorted[lo + blo + threadIdx.x];
       const float4 *rp = reinterpret_cast<const float4 *>(splat + g);
@@ -266,13 +320,15 @@ __global__ void __launch_bounds__(BLEND_BLOCK) blend_bwd_kernel(
       const int x0 = rc.x & 0xffff, y0 = rc.x >> 16, x1 = rc.y & 0xffff;
       s_emit[threadIdx.x] = (g == 0 ? 0u : offsets[g - 1]) + (uint32_t)((tile_y - y0) * (x1 - x0) + (tile_x - x0));
     }
-#pragma unroll
-    for (int k = 0; k < 16; ++k) s_acc[threadIdx.x][k] = 0.0f;
+    reinterpret_cast<float4 *>(&s_acc[0][0])[threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
     const int mine = compact_for_wave(s_mask, s_list[wave], count, wave, lane);
 
-    for (int t = mine - 1; t >= 0; --t) {
+    // (no software pipelining here, unlike the forward: this loop is VALU-issue bound and the prefetch of the
+    // feature record for visits that turn out inactive cost more than the hidden latency returned: 142 -> 155 us)
+    for (int t = 0; t < mine; ++t) {
       const int j = __builtin_amdgcn_readfirstlane((int)s_list[wave][t]);
+      if (blo + (uint32_t)j >= wlast) break;  // the list is ascending: nothing further reaches this wave
       const float4 g = s_geo[j];
       const float4 c = s_col[j];
       const float dx = g.x - pxf, dy = g.y - pyf;
@@ -286,13 +342,12 @@ __global__ void __launch_bounds__(BLEND_BLOCK) blend_bwd_kernel(
       for (int k = 0; k < 16; ++k) v[k] = 0.0f;
       if (active) {
         const float4 a = s_aux[j];
-        const float rinv = __builtin_amdgcn_rcpf(1.0f - alpha);
-        T *= rinv;
         const float w = alpha * T;
         float D = dp[7] + c.z * dp[0] + c.w * dp[1] + a.x * dp[2] + a.y * dp[3];
         if (NORMAL) D += a.z * dp[4] + a.w * dp[5] + s_nz[j] * dp[6];
-        const float dL_dalpha_i = D * T - Q * rinv;
-        Q += D * w;
+        P += D * w;
+        const float dL_dalpha_i = D * T - (S - P) * __builtin_amdgcn_rcpf(1.0f - alpha);
+        T *= 1.0f - alpha;
         const float gg = G * c.y * dL_dalpha_i;  // g = G * dL/dG, dL/dG = opacity * dL/dalpha
         v[0] = gg, v[1] = gg * dx, v[2] = gg * dy;
         v[3] = v[1] * dx, v[4] = v[1] * dy, v[5] = v[2] * dy;
@@ -323,7 +378,6 @@ __global__ void __launch_bounds__(BLEND_BLOCK) blend_bwd_kernel(
         inst_flag[e] = 1;
       }
     }
-    top = blo;
   }
 }
 
@@ -351,11 +405,13 @@ extern "C" int dimo_raster_render_forward(int N, int H, int W, int64_t R_cap, co
   if (out_normal)
     hipLaunchKernelGGL(blend_fwd_kernel<true>, dim3(B.T), dim3(BLEND_BLOCK), 0, stream, H, W, B.tiles_x, ranges, vals,
                        splat, bg, out_color, out_depth, out_normal, out_alpha, at<float>(img, I.final_T),
-                       at<uint32_t>(img, I.n_contrib));
+                       at<uint32_t>(img, I.n_contrib), at<float>(img, I.final_acc), at<float>(bin, B.ckpt),
+                       at<uint32_t>(bin, B.work));
   else
     hipLaunchKernelGGL(blend_fwd_kernel<false>, dim3(B.T), dim3(BLEND_BLOCK), 0, stream, H, W, B.tiles_x, ranges,
                        vals, splat, bg, out_color, out_depth, out_normal, out_alpha, at<float>(img, I.final_T),
-                       at<uint32_t>(img, I.n_contrib));
+                       at<uint32_t>(img, I.n_contrib), at<float>(img, I.final_acc), at<float>(bin, B.ckpt),
+                       at<uint32_t>(bin, B.work));
   return check_launch();
 }
 
@@ -398,15 +454,17 @@ extern "C" int dimo_raster_backward(int N, int sh_degree, int M, int H, int W, i
     ScopedTimer tm(T_BLEND_BWD, stream);
     if (hipMemsetAsync(inst_flag, 0, B.cap, stream) != hipSuccess) return DIMO_E_LAUNCH;
     if (dL_dnormal)
-      hipLaunchKernelGGL(blend_bwd_kernel<true>, dim3(B.T), dim3(BLEND_BLOCK), 0, stream, H, W, B.tiles_x, cap,
+      hipLaunchKernelGGL(blend_bwd_kernel<true>, dim3(BWD_GRID), dim3(BLEND_BLOCK), 0, stream, H, W, B.tiles_x, cap,
                          at<uint32_t>(bin, B.ranges), at<uint32_t>(bin, B.vals_b), at<Splat>(geom, G.splat),
                          at<uint16_t>(geom, G.rect), at<uint32_t>(geom, G.offsets), bg, at<float>(img, I.final_T),
-                         at<uint32_t>(img, I.n_contrib), dL_dcolor, dL_ddepth, dL_dnormal, dL_dalpha, inst, inst_flag);
+                         at<uint32_t>(img, I.n_contrib), at<float>(img, I.final_acc), at<float>(bin, B.ckpt),
+                         at<uint32_t>(bin, B.work), dL_dcolor, dL_ddepth, dL_dnormal, dL_dalpha, inst, inst_flag);
     else
-      hipLaunchKernelGGL(blend_bwd_kernel<false>, dim3(B.T), dim3(BLEND_BLOCK), 0, stream, H, W, B.tiles_x, cap,
+      hipLaunchKernelGGL(blend_bwd_kernel<false>, dim3(BWD_GRID), dim3(BLEND_BLOCK), 0, stream, H, W, B.tiles_x, cap,
                          at<uint32_t>(bin, B.ranges), at<uint32_t>(bin, B.vals_b), at<Splat>(geom, G.splat),
                          at<uint16_t>(geom, G.rect), at<uint32_t>(geom, G.offsets), bg, at<float>(img, I.final_T),
-                         at<uint32_t>(img, I.n_contrib), dL_dcolor, dL_ddepth, dL_dnormal, dL_dalpha, inst, inst_flag);
+                         at<uint32_t>(img, I.n_contrib), at<float>(img, I.final_acc), at<float>(bin, B.ckpt),
+                         at<uint32_t>(bin, B.work), dL_dcolor, dL_ddepth, dL_dnormal, dL_dalpha, inst, inst_flag);
     int rc = check_launch();
     if (rc) return rc;
   }

@@ -65,6 +65,8 @@ struct GeomLayout {
   }
 };
 
+constexpr int BUCKET = 64;       // list entries per backward work item
+constexpr int CKPT_FLOATS = 9;   // T, 7 accumulated features, accumulated weight
 constexpr int SORT_BLOCK = 256;
 constexpr int SORT_ITEMS = 16;
 constexpr int SORT_TILE = SORT_BLOCK * SORT_ITEMS;  // keys per sort block
@@ -72,9 +74,9 @@ constexpr int RADIX_BITS = 8;
 constexpr int RADIX = 1 << RADIX_BITS;
 
 struct BinLayout {
-  size_t keys_a, vals_a, keys_b, vals_b, keys_c, vals_c, ranges, hist, bytes;
+  size_t keys_a, vals_a, keys_b, vals_b, keys_c, vals_c, ranges, hist, ckpt, work, bytes;
   int tiles_x, tiles_y, T;
-  size_t cap, sort_blocks;
+  size_t cap, sort_blocks, ckpt_slots;
   __host__ BinLayout(int64_t R_cap, int H, int W) {
     cap = (size_t)(R_cap > 0 ? R_cap : 1);
     tiles_x = (W + TILE - 1) / TILE, tiles_y = (H + TILE - 1) / TILE, T = tiles_x * tiles_y;
@@ -88,17 +90,24 @@ struct BinLayout {
     vals_c = o, o = align_up(o + cap * sizeof(uint32_t));
     ranges = o, o = align_up(o + (size_t)T * 2 * sizeof(uint32_t));
     hist = o, o = align_up(o + ((size_t)RADIX * (sort_blocks + 1)) * sizeof(uint32_t));
+    // blend checkpoints: per (tile, bucket of BUCKET list entries) the 256 pixels' compositing state at the
+    // bucket's first entry -- slot (lo_tile / BUCKET + tile + bucket), see blend.hip; work: [0] = item count,
+    // then one word (tile << 12 | bucket) per bucket some pixel of the tile reaches
+    ckpt_slots = cap / BUCKET + (size_t)T + 2;
+    ckpt = o, o = align_up(o + ckpt_slots * CKPT_FLOATS * TILE * TILE * sizeof(float));
+    work = o, o = align_up(o + (ckpt_slots + 1) * sizeof(uint32_t));
     bytes = o;
   }
 };
 
 struct ImgLayout {
-  size_t final_T, n_contrib, bytes;
+  size_t final_T, n_contrib, final_acc, bytes;
   __host__ ImgLayout(int H, int W) {
     size_t p = (size_t)H * W;
     size_t o = 0;
     final_T = o, o = align_up(o + p * sizeof(float));
     n_contrib = o, o = align_up(o + p * sizeof(uint32_t));
+    final_acc = o, o = align_up(o + 8 * p * sizeof(float));  // [7 features + weight][H*W], background not included
     bytes = o;
   }
 };

@@ -23,17 +23,22 @@ class FlatAdam:
         self.exp_avg = torch.zeros_like(flat_params)
         self.exp_avg_sq = torch.zeros_like(flat_params)
         self.step_count = 0
-        # groups must tile the bucket contiguously, in order (GaussianModel.flatten_parameters builds it that way)
+        # groups must tile the bucket in order, at most 3 padding floats (16-byte alignment) between tensors
+        # (GaussianModel.flatten_parameters builds it that way); padding is updated with the group it precedes
         base = flat_params.data_ptr()
         ends, o = [], 0
         for g in groups:
             for p in g["params"]:
                 if p.numel() == 0:
                     continue
-                assert p.data_ptr() == base + 4 * o, "parameter is not a view of the flat bucket in group order"
-                o += p.numel()
+                at = (p.data_ptr() - base) // 4
+                assert 0 <= at - o < 4 and (p.data_ptr() - base) % 4 == 0, \
+                    "parameter is not a view of the flat bucket in group order"
+                o = at + p.numel()
             ends.append(o)
-        assert o == flat_params.numel()
+        assert 0 <= flat_params.numel() - o < 4
+        if ends:
+            ends[-1] = flat_params.numel()
         self._ends = (C.c_int64 * len(ends))(*ends)
         self._n_seg = len(ends)
 

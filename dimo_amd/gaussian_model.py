@@ -208,8 +208,11 @@ class GaussianModel:
     def flatten_parameters(self, groups):
         """Re-home every trainable tensor (and its .grad) into one flat fp32 buffer each."""
         params = [p for g in groups for p in g["params"] if p.numel() > 0]
-        total = sum(p.numel() for p in params)
-        flat = torch.empty(total, dtype=torch.float32, device=self.device)
+        # every tensor starts on a 16-byte boundary (the GEMM kernels of csrc/timenet.hip use 16-byte loads on
+        # aligned operands); the <= 3 padding floats keep zero value and zero gradient, so Adam leaves them at 0
+        pad4 = lambda n: (n + 3) & ~3
+        total = sum(pad4(p.numel()) for p in params)
+        flat = torch.zeros(total, dtype=torch.float32, device=self.device)
         # 4 extra floats ride along with the gradient bucket (and its all-reduce): [0] = "some render of this
         # step overflowed its instance capacity on some rank" -> every replica skips the update together
         self.flat_grads_ext = torch.zeros(total + 4, dtype=torch.float32, device=self.device)
@@ -222,7 +225,7 @@ class GaussianModel:
                 flat[o:o + n].copy_(p.detach().reshape(-1))
                 p.data = flat[o:o + n].view(p.shape)
                 p.grad = grads[o:o + n].view(p.shape)
-                o += n
+                o += pad4(n)
         self.flat_params, self.flat_grads = flat, grads
         return flat, grads
 
