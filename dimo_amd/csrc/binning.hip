@@ -15,8 +15,8 @@ namespace dimo {
 // ------------------------------------------------------------------------------------ scan
 // Exclusive scan of the per-block sums (nb <= a few thousand) by one workgroup; writes the
 // grand total R to total[0] and clears the overflow flag total[1].
-__global__ void __launch_bounds__(1024) scan_block_sums_kernel(int nb, uint32_t *__restrict__ sums,
-                                                               uint32_t *__restrict__ total) {
+__device__ __forceinline__ void scan_block_sums_body(int nb, uint32_t *__restrict__ sums,
+                                                     uint32_t *__restrict__ total) {
   __shared__ uint32_t wave_tot[16];
   __shared__ uint32_t carry_s;
   if (threadIdx.x == 0) carry_s = 0;
@@ -51,9 +51,9 @@ __global__ void __launch_bounds__(1024) scan_block_sums_kernel(int nb, uint32_t 
 }
 
 // offsets[i] = inclusive scan of tiles_touched (block prefix + in-block scan)
-__global__ void __launch_bounds__(PRE_BLOCK) write_offsets_kernel(int N, const uint32_t *__restrict__ tiles,
-                                                                  const uint32_t *__restrict__ block_prefix,
-                                                                  uint32_t *__restrict__ offsets) {
+__device__ __forceinline__ void write_offsets_body(int N, const uint32_t *__restrict__ tiles,
+                                                   const uint32_t *__restrict__ block_prefix,
+                                                   uint32_t *__restrict__ offsets) {
   __shared__ uint32_t wave_tot[PRE_BLOCK / 64];
   const int i = blockIdx.x * PRE_BLOCK + threadIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -74,12 +74,10 @@ __global__ void __launch_bounds__(PRE_BLOCK) write_offsets_kernel(int N, const u
 // ------------------------------------------------------------------------------------ emission
 // One thread per Gaussian: writes its (key, id) run at [offsets[i-1], offsets[i]).
 // key = (tile_id << 32) | depth bits; emission order = tile y, then tile x.
-__global__ void __launch_bounds__(256) emit_keys_kernel(int N, int tiles_x, uint32_t R_cap,
-                                                        const Splat *__restrict__ splat,
-                                                        const uint16_t *__restrict__ rect,
-                                                        const uint32_t *__restrict__ offsets,
-                                                        uint32_t *__restrict__ total, uint64_t *__restrict__ keys,
-                                                        uint32_t *__restrict__ vals) {
+__device__ __forceinline__ void emit_keys_body(int N, int tiles_x, uint32_t R_cap, const Splat *__restrict__ splat,
+                                               const uint16_t *__restrict__ rect,
+                                               const uint32_t *__restrict__ offsets, uint32_t *__restrict__ total,
+                                               uint64_t *__restrict__ keys, uint32_t *__restrict__ vals) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= N) return;
   const uint32_t hi = offsets[i];
@@ -111,10 +109,9 @@ constexpr int SORT_WAVES = SORT_BLOCK / 64;
 
 __device__ __forceinline__ uint32_t digit_of(uint64_t k, int shift) { return (uint32_t)(k >> shift) & (RADIX - 1); }
 
-__global__ void __launch_bounds__(SORT_BLOCK) radix_hist_kernel(const uint64_t *__restrict__ keys,
-                                                                const uint32_t *__restrict__ total, uint32_t R_cap,
-                                                                int shift, uint32_t num_blocks,
-                                                                uint32_t *__restrict__ hist) {
+__device__ __forceinline__ void radix_hist_body(const uint64_t *__restrict__ keys,
+                                                const uint32_t *__restrict__ total, uint32_t R_cap, int shift,
+                                                uint32_t num_blocks, uint32_t *__restrict__ hist) {
   __shared__ uint32_t h[RADIX];
   const uint32_t R = min(total[0], R_cap);
   h[threadIdx.x] = 0;
@@ -133,7 +130,7 @@ __global__ void __launch_bounds__(SORT_BLOCK) radix_hist_kernel(const uint64_t *
 
 // Row scan: one wave per digit turns hist[d][0..num_blocks) into its exclusive prefix and stores
 // the digit total at hist[RADIX*num_blocks + d].  256 independent waves -> no single-block tail.
-__global__ void __launch_bounds__(256) radix_rowscan_kernel(uint32_t num_blocks, uint32_t *__restrict__ hist) {
+__device__ __forceinline__ void radix_rowscan_body(uint32_t num_blocks, uint32_t *__restrict__ hist) {
   const int lane = threadIdx.x & 63;
   const uint32_t d = blockIdx.x * 4 + (threadIdx.x >> 6);
   uint32_t *row = hist + (size_t)d * num_blocks;
@@ -153,7 +150,7 @@ __global__ void __launch_bounds__(256) radix_rowscan_kernel(uint32_t num_blocks,
   if (lane == 0) hist[(size_t)RADIX * num_blocks + d] = carry;
 }
 
-__global__ void __launch_bounds__(SORT_BLOCK) radix_scatter_kernel(
+__device__ __forceinline__ void radix_scatter_body(
     const uint64_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, uint64_t *__restrict__ keys_out,
     uint32_t *__restrict__ vals_out, const uint32_t *__restrict__ total, uint32_t R_cap, int shift,
     uint32_t num_blocks, const uint32_t *__restrict__ hist) {
@@ -234,15 +231,15 @@ __global__ void __launch_bounds__(SORT_BLOCK) radix_scatter_kernel(
 }
 
 // ------------------------------------------------------------------------------------ ranges
-__global__ void __launch_bounds__(256) clear_ranges_kernel(int T, uint32_t *__restrict__ ranges,
-                                                           uint32_t *__restrict__ work_count) {
+__device__ __forceinline__ void clear_ranges_body(int T, uint32_t *__restrict__ ranges,
+                                                  uint32_t *__restrict__ work_count) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i < 2 * T) ranges[i] = 0;
   if (i == 0) *work_count = 0;  // the blend forward queues the backward's (tile, bucket) items behind it
 }
-__global__ void __launch_bounds__(256) tile_ranges_kernel(const uint64_t *__restrict__ keys,
-                                                          const uint32_t *__restrict__ total, uint32_t R_cap,
-                                                          uint32_t *__restrict__ ranges) {
+__device__ __forceinline__ void tile_ranges_body(const uint64_t *__restrict__ keys,
+                                                 const uint32_t *__restrict__ total, uint32_t R_cap,
+                                                 uint32_t *__restrict__ ranges) {
   const uint32_t R = min(total[0], R_cap);
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
   if (i >= R) return;
@@ -294,9 +291,8 @@ __device__ __forceinline__ void bitonic_network(uint32_t n, CmpSwap cmp_swap) {
   }
 }
 
-__global__ void __launch_bounds__(256) tile_depth_sort_kernel(const uint32_t *__restrict__ ranges,
-                                                              uint64_t *__restrict__ keys,
-                                                              uint32_t *__restrict__ vals) {
+__device__ __forceinline__ void tile_depth_sort_body(const uint32_t *__restrict__ ranges, uint64_t *__restrict__ keys,
+                                                     uint32_t *__restrict__ vals) {
   extern __shared__ uint64_t ts_smem[];
   __shared__ uint32_t wtot[4];
   __shared__ uint32_t diff_s;
@@ -408,6 +404,110 @@ __global__ void __launch_bounds__(256) tile_depth_sort_kernel(const uint32_t *__
   }
 }
 
+// ------------------------------------------------------------------------------------ kernel entry points
+// Every stage exists as a single-render kernel (the C-ABI calls) and as a batched one whose blockIdx.y selects the
+// render of a RenderBatch (the native step executor: one launch per stage for all renders of a step).
+__global__ void __launch_bounds__(1024) scan_block_sums_kernel(int nb, uint32_t *__restrict__ sums,
+                                                               uint32_t *__restrict__ total) {
+  scan_block_sums_body(nb, sums, total);
+}
+__global__ void __launch_bounds__(PRE_BLOCK) write_offsets_kernel(int N, const uint32_t *__restrict__ tiles,
+                                                                  const uint32_t *__restrict__ block_prefix,
+                                                                  uint32_t *__restrict__ offsets) {
+  write_offsets_body(N, tiles, block_prefix, offsets);
+}
+__global__ void __launch_bounds__(256) emit_keys_kernel(int N, int tiles_x, uint32_t R_cap,
+                                                        const Splat *__restrict__ splat,
+                                                        const uint16_t *__restrict__ rect,
+                                                        const uint32_t *__restrict__ offsets,
+                                                        uint32_t *__restrict__ total, uint64_t *__restrict__ keys,
+                                                        uint32_t *__restrict__ vals) {
+  emit_keys_body(N, tiles_x, R_cap, splat, rect, offsets, total, keys, vals);
+}
+__global__ void __launch_bounds__(SORT_BLOCK) radix_hist_kernel(const uint64_t *__restrict__ keys,
+                                                                const uint32_t *__restrict__ total, uint32_t R_cap,
+                                                                int shift, uint32_t num_blocks,
+                                                                uint32_t *__restrict__ hist) {
+  radix_hist_body(keys, total, R_cap, shift, num_blocks, hist);
+}
+__global__ void __launch_bounds__(256) radix_rowscan_kernel(uint32_t num_blocks, uint32_t *__restrict__ hist) {
+  radix_rowscan_body(num_blocks, hist);
+}
+__global__ void __launch_bounds__(SORT_BLOCK) radix_scatter_kernel(
+    const uint64_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, uint64_t *__restrict__ keys_out,
+    uint32_t *__restrict__ vals_out, const uint32_t *__restrict__ total, uint32_t R_cap, int shift,
+    uint32_t num_blocks, const uint32_t *__restrict__ hist) {
+  radix_scatter_body(keys_in, vals_in, keys_out, vals_out, total, R_cap, shift, num_blocks, hist);
+}
+__global__ void __launch_bounds__(256) clear_ranges_kernel(int T, uint32_t *__restrict__ ranges,
+                                                           uint32_t *__restrict__ work_count) {
+  clear_ranges_body(T, ranges, work_count);
+}
+__global__ void __launch_bounds__(256) tile_ranges_kernel(const uint64_t *__restrict__ keys,
+                                                          const uint32_t *__restrict__ total, uint32_t R_cap,
+                                                          uint32_t *__restrict__ ranges) {
+  tile_ranges_body(keys, total, R_cap, ranges);
+}
+__global__ void __launch_bounds__(256) tile_depth_sort_kernel(const uint32_t *__restrict__ ranges,
+                                                              uint64_t *__restrict__ keys,
+                                                              uint32_t *__restrict__ vals) {
+  tile_depth_sort_body(ranges, keys, vals);
+}
+
+__global__ void __launch_bounds__(1024) scan_block_sums_batched_kernel(int nb, GeomLayout L, RenderBatch b) {
+  void *geom = b.r[blockIdx.y].geom;
+  scan_block_sums_body(nb, at<uint32_t>(geom, L.block_sums), at<uint32_t>(geom, L.total));
+}
+__global__ void __launch_bounds__(PRE_BLOCK) write_offsets_batched_kernel(int N, GeomLayout L, RenderBatch b) {
+  void *geom = b.r[blockIdx.y].geom;
+  write_offsets_body(N, at<uint32_t>(geom, L.tiles), at<uint32_t>(geom, L.block_sums), at<uint32_t>(geom, L.offsets));
+}
+__global__ void __launch_bounds__(256) emit_keys_batched_kernel(int N, int tiles_x, uint32_t R_cap, GeomLayout L,
+                                                                size_t keys_off, size_t vals_off, RenderBatch b) {
+  const dimo_render_desc &r = b.r[blockIdx.y];
+  emit_keys_body(N, tiles_x, R_cap, at<Splat>(r.geom, L.splat), at<uint16_t>(r.geom, L.rect),
+                 at<uint32_t>(r.geom, L.offsets), at<uint32_t>(r.geom, L.total), at<uint64_t>(r.bin, keys_off),
+                 at<uint32_t>(r.bin, vals_off));
+}
+__global__ void __launch_bounds__(SORT_BLOCK) radix_hist_batched_kernel(size_t keys_off, size_t total_off,
+                                                                        uint32_t R_cap, int shift,
+                                                                        uint32_t num_blocks, size_t hist_off,
+                                                                        RenderBatch b) {
+  const dimo_render_desc &r = b.r[blockIdx.y];
+  radix_hist_body(at<uint64_t>(r.bin, keys_off), at<uint32_t>(r.geom, total_off), R_cap, shift, num_blocks,
+                  at<uint32_t>(r.bin, hist_off));
+}
+__global__ void __launch_bounds__(256) radix_rowscan_batched_kernel(uint32_t num_blocks, size_t hist_off,
+                                                                    RenderBatch b) {
+  radix_rowscan_body(num_blocks, at<uint32_t>(b.r[blockIdx.y].bin, hist_off));
+}
+__global__ void __launch_bounds__(SORT_BLOCK) radix_scatter_batched_kernel(size_t kin, size_t vin, size_t kout,
+                                                                           size_t vout, size_t total_off,
+                                                                           uint32_t R_cap, int shift,
+                                                                           uint32_t num_blocks, size_t hist_off,
+                                                                           RenderBatch b) {
+  const dimo_render_desc &r = b.r[blockIdx.y];
+  radix_scatter_body(at<uint64_t>(r.bin, kin), at<uint32_t>(r.bin, vin), at<uint64_t>(r.bin, kout),
+                     at<uint32_t>(r.bin, vout), at<uint32_t>(r.geom, total_off), R_cap, shift, num_blocks,
+                     at<uint32_t>(r.bin, hist_off));
+}
+__global__ void __launch_bounds__(256) clear_ranges_batched_kernel(int T, size_t ranges_off, size_t work_off,
+                                                                   RenderBatch b) {
+  void *bin = b.r[blockIdx.y].bin;
+  clear_ranges_body(T, at<uint32_t>(bin, ranges_off), at<uint32_t>(bin, work_off));
+}
+__global__ void __launch_bounds__(256) tile_ranges_batched_kernel(size_t keys_off, size_t total_off, uint32_t R_cap,
+                                                                  size_t ranges_off, RenderBatch b) {
+  const dimo_render_desc &r = b.r[blockIdx.y];
+  tile_ranges_body(at<uint64_t>(r.bin, keys_off), at<uint32_t>(r.geom, total_off), R_cap,
+                   at<uint32_t>(r.bin, ranges_off));
+}
+__global__ void __launch_bounds__(256) tile_depth_sort_batched_kernel(size_t ranges_off, size_t keys_off,
+                                                                      size_t vals_off, RenderBatch b) {
+  void *bin = b.r[blockIdx.y].bin;
+  tile_depth_sort_body(at<uint32_t>(bin, ranges_off), at<uint64_t>(bin, keys_off), at<uint32_t>(bin, vals_off));
+}
+
 int scan_block_sums(int nb, uint32_t *block_sums, uint32_t *total, hipStream_t stream) {
   hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(1024), 0, stream, nb, block_sums, total);
   return check_launch();
@@ -470,6 +570,61 @@ int bin_instances(int N, int H, int W, int64_t R_cap, const void *geom, void *bi
                                                        (int)TS_LDS_BYTES);
     (void)attr;
     hipLaunchKernelGGL(tile_depth_sort_kernel, dim3(B.T), dim3(256), TS_LDS_BYTES, stream, ranges, keys_s, vals_s);
+  }
+  return check_launch();
+}
+
+int scan_offsets_batched(int N, const GeomLayout &L, const RenderBatch &b, int n, hipStream_t stream) {
+  const int nb = (N + PRE_BLOCK - 1) / PRE_BLOCK;
+  hipLaunchKernelGGL(scan_block_sums_batched_kernel, dim3(1, n), dim3(1024), 0, stream, nb, L, b);
+  if (nb > 0) hipLaunchKernelGGL(write_offsets_batched_kernel, dim3(nb, n), dim3(PRE_BLOCK), 0, stream, N, L, b);
+  return check_launch();
+}
+
+int bin_instances_batched(const dimo_step_common &c, const RenderBatch &b, int n, hipStream_t stream) {
+  if (n <= 0) return DIMO_OK;
+  GeomLayout G(c.N);
+  BinLayout B(c.R_cap, c.H, c.W);
+  if (c.bin_bytes < B.bytes) return DIMO_E_WORKSPACE;
+  const uint32_t cap = (uint32_t)B.cap;
+  const int tile_bits = key_bits(B.T) - 32;
+  const int passes = (tile_bits + RADIX_BITS - 1) / RADIX_BITS;
+  if (c.N > 0) {
+    ScopedTimer tm(T_EMIT, stream);
+    hipLaunchKernelGGL(emit_keys_batched_kernel, dim3((c.N + 255) / 256, n), dim3(256), 0, stream, c.N, B.tiles_x, cap,
+                       G, B.keys_a, B.vals_a, b);
+  }
+  const uint32_t nblk = (uint32_t)B.sort_blocks;
+  size_t kin = B.keys_a, vin = B.vals_a;
+  {
+    ScopedTimer tm(T_SORT, stream);
+    for (int p = 0; p < passes; ++p) {
+      const bool to_sorted = ((passes - 1 - p) & 1) == 0;
+      const size_t kout = to_sorted ? B.keys_b : B.keys_c, vout = to_sorted ? B.vals_b : B.vals_c;
+      const int shift = 32 + p * RADIX_BITS;
+      hipLaunchKernelGGL(radix_hist_batched_kernel, dim3(nblk, n), dim3(SORT_BLOCK), 0, stream, kin, G.total, cap,
+                         shift, nblk, B.hist, b);
+      hipLaunchKernelGGL(radix_rowscan_batched_kernel, dim3(RADIX / 4, n), dim3(256), 0, stream, nblk, B.hist, b);
+      hipLaunchKernelGGL(radix_scatter_batched_kernel, dim3(nblk, n), dim3(SORT_BLOCK), 0, stream, kin, vin, kout,
+                         vout, G.total, cap, shift, nblk, B.hist, b);
+      kin = kout, vin = vout;
+    }
+  }
+  {
+    ScopedTimer tm(T_RANGES, stream);
+    hipLaunchKernelGGL(clear_ranges_batched_kernel, dim3((2 * B.T + 255) / 256, n), dim3(256), 0, stream, B.T,
+                       B.ranges, B.work, b);
+    hipLaunchKernelGGL(tile_ranges_batched_kernel, dim3((cap + 255) / 256, n), dim3(256), 0, stream, B.keys_b, G.total,
+                       cap, B.ranges, b);
+  }
+  {
+    ScopedTimer tm(T_TILE_SORT, stream);
+    static const hipError_t attr =
+        hipFuncSetAttribute(reinterpret_cast<const void *>(tile_depth_sort_batched_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)TS_LDS_BYTES);
+    (void)attr;
+    hipLaunchKernelGGL(tile_depth_sort_batched_kernel, dim3(B.T, n), dim3(256), TS_LDS_BYTES, stream, B.ranges,
+                       B.keys_b, B.vals_b, b);
   }
   return check_launch();
 }

@@ -74,7 +74,7 @@ __device__ __forceinline__ int compact_for_wave(const uint32_t *s_mask, uint16_t
 
 // ---------------------------------------------------------------------------------- forward
 template <bool NORMAL>
-__global__ void __launch_bounds__(BLEND_BLOCK) blend_fwd_kernel(
+__device__ __forceinline__ void blend_fwd_body(
     int H, int W, int tiles_x, const uint32_t *__restrict__ ranges, const uint32_t *__restrict__ vals_sorted,
     const Splat *__restrict__ splat, const float *__restrict__ bg, float *__restrict__ out_color,
     float *__restrict__ out_depth, float *__restrict__ out_normal, float *__restrict__ out_alpha,
@@ -250,7 +250,7 @@ __device__ __forceinline__ void butterfly16(const float (&v)[16], int lane, floa
 }
 
 template <bool NORMAL>
-__global__ void __launch_bounds__(BLEND_BLOCK) blend_bwd_kernel(
+__device__ __forceinline__ void blend_bwd_body(
     int H, int W, int tiles_x, uint32_t R_cap, const uint32_t *__restrict__ ranges,
     const uint32_t *__restrict__ vals_sorted, const Splat *__restrict__ splat, const uint16_t *__restrict__ rect,
     const uint32_t *__restrict__ offsets, const float *__restrict__ bg, const float *__restrict__ final_T,
@@ -379,6 +379,114 @@ __global__ void __launch_bounds__(BLEND_BLOCK) blend_bwd_kernel(
       }
     }
   }
+}
+
+// ---------------------------------------------------------------------------------- kernel entry points
+template <bool NORMAL>
+__global__ void __launch_bounds__(BLEND_BLOCK) blend_fwd_kernel(
+    int H, int W, int tiles_x, const uint32_t *__restrict__ ranges, const uint32_t *__restrict__ vals_sorted,
+    const Splat *__restrict__ splat, const float *__restrict__ bg, float *__restrict__ out_color,
+    float *__restrict__ out_depth, float *__restrict__ out_normal, float *__restrict__ out_alpha,
+    float *__restrict__ final_T, uint32_t *__restrict__ n_contrib, float *__restrict__ final_acc,
+    float *__restrict__ ckpt, uint32_t *__restrict__ work) {
+  blend_fwd_body<NORMAL>(H, W, tiles_x, ranges, vals_sorted, splat, bg, out_color, out_depth, out_normal, out_alpha,
+                         final_T, n_contrib, final_acc, ckpt, work);
+}
+template <bool NORMAL>
+__global__ void __launch_bounds__(BLEND_BLOCK) blend_bwd_kernel(
+    int H, int W, int tiles_x, uint32_t R_cap, const uint32_t *__restrict__ ranges,
+    const uint32_t *__restrict__ vals_sorted, const Splat *__restrict__ splat, const uint16_t *__restrict__ rect,
+    const uint32_t *__restrict__ offsets, const float *__restrict__ bg, const float *__restrict__ final_T,
+    const uint32_t *__restrict__ n_contrib, const float *__restrict__ final_acc, const float *__restrict__ ckpt,
+    const uint32_t *__restrict__ work, const float *__restrict__ dL_dcolor, const float *__restrict__ dL_ddepth,
+    const float *__restrict__ dL_dnormal, const float *__restrict__ dL_dalpha, SplatGrad *__restrict__ inst_grad,
+    uint8_t *__restrict__ inst_flag) {
+  blend_bwd_body<NORMAL>(H, W, tiles_x, R_cap, ranges, vals_sorted, splat, rect, offsets, bg, final_T, n_contrib,
+                         final_acc, ckpt, work, dL_dcolor, dL_ddepth, dL_dnormal, dL_dalpha, inst_grad, inst_flag);
+}
+
+// Batched entry points (native step executor): blockIdx.y = render of the batch.
+struct BlendOffsets {
+  size_t splat, rect, offsets, total;           // geom
+  size_t ranges, vals, ckpt, work;              // bin
+  size_t final_T, n_contrib, final_acc;         // img
+  size_t flag;                                  // backward scratch: records at 0, flags here
+};
+template <bool NORMAL>
+__global__ void __launch_bounds__(BLEND_BLOCK) blend_fwd_batched_kernel(int H, int W, int tiles_x,
+                                                                        const float *__restrict__ bg, BlendOffsets o,
+                                                                        RenderBatch b) {
+  const dimo_render_desc &r = b.r[blockIdx.y];
+  blend_fwd_body<NORMAL>(H, W, tiles_x, at<uint32_t>(r.bin, o.ranges), at<uint32_t>(r.bin, o.vals),
+                         at<Splat>(r.geom, o.splat), bg, r.out_color, r.out_depth, NORMAL ? r.out_normal : nullptr,
+                         r.out_alpha, at<float>(r.img, o.final_T), at<uint32_t>(r.img, o.n_contrib),
+                         at<float>(r.img, o.final_acc), at<float>(r.bin, o.ckpt), at<uint32_t>(r.bin, o.work));
+}
+template <bool NORMAL>
+__global__ void __launch_bounds__(BLEND_BLOCK) blend_bwd_batched_kernel(int H, int W, int tiles_x, uint32_t R_cap,
+                                                                        const float *__restrict__ bg, BlendOffsets o,
+                                                                        RenderBatch b) {
+  const dimo_render_desc &r = b.r[blockIdx.y];
+  blend_bwd_body<NORMAL>(H, W, tiles_x, R_cap, at<uint32_t>(r.bin, o.ranges), at<uint32_t>(r.bin, o.vals),
+                         at<Splat>(r.geom, o.splat), at<uint16_t>(r.geom, o.rect), at<uint32_t>(r.geom, o.offsets), bg,
+                         at<float>(r.img, o.final_T), at<uint32_t>(r.img, o.n_contrib), at<float>(r.img, o.final_acc),
+                         at<float>(r.bin, o.ckpt), at<uint32_t>(r.bin, o.work), r.g_color, r.g_depth,
+                         NORMAL ? r.g_normal : nullptr, r.g_alpha, reinterpret_cast<SplatGrad *>(r.bwd_scratch),
+                         at<uint8_t>(r.bwd_scratch, o.flag));
+}
+// clears the "record written" flags of the instances a render actually has ([0, R), 16 bytes per thread)
+__global__ void __launch_bounds__(256) clear_flags_batched_kernel(uint32_t R_cap, BlendOffsets o, RenderBatch b) {
+  const dimo_render_desc &r = b.r[blockIdx.y];
+  const uint32_t R = min(*at<uint32_t>(r.geom, o.total), R_cap);
+  const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 16;
+  if (i < R) *reinterpret_cast<uint4 *>(at<uint8_t>(r.bwd_scratch, o.flag) + i) = make_uint4(0, 0, 0, 0);
+}
+
+static BlendOffsets blend_offsets(const GeomLayout &G, const BinLayout &B, const ImgLayout &I) {
+  BlendOffsets o;
+  o.splat = G.splat, o.rect = G.rect, o.offsets = G.offsets, o.total = G.total;
+  o.ranges = B.ranges, o.vals = B.vals_b, o.ckpt = B.ckpt, o.work = B.work;
+  o.final_T = I.final_T, o.n_contrib = I.n_contrib, o.final_acc = I.final_acc;
+  o.flag = align_up(B.cap * sizeof(SplatGrad));
+  return o;
+}
+
+int blend_forward_batched(const dimo_step_common &c, const RenderBatch &b, int n, hipStream_t stream) {
+  if (n <= 0) return DIMO_OK;
+  GeomLayout G(c.N);
+  BinLayout B(c.R_cap, c.H, c.W);
+  ImgLayout I(c.H, c.W);
+  if (c.bin_bytes < B.bytes || c.img_bytes < I.bytes) return DIMO_E_WORKSPACE;
+  const BlendOffsets o = blend_offsets(G, B, I);
+  ScopedTimer tm(T_BLEND_FWD, stream);
+  if (c.with_normal)
+    hipLaunchKernelGGL(blend_fwd_batched_kernel<true>, dim3(B.T, n), dim3(BLEND_BLOCK), 0, stream, c.H, c.W, B.tiles_x,
+                       c.bg, o, b);
+  else
+    hipLaunchKernelGGL(blend_fwd_batched_kernel<false>, dim3(B.T, n), dim3(BLEND_BLOCK), 0, stream, c.H, c.W,
+                       B.tiles_x, c.bg, o, b);
+  return check_launch();
+}
+
+int blend_backward_batched(const dimo_step_common &c, const RenderBatch &b, int n, hipStream_t stream) {
+  if (n <= 0 || c.N <= 0) return DIMO_OK;
+  GeomLayout G(c.N);
+  BinLayout B(c.R_cap, c.H, c.W);
+  ImgLayout I(c.H, c.W);
+  if (c.bwd_scratch_bytes < align_up(B.cap * sizeof(SplatGrad)) + align_up(B.cap)) return DIMO_E_WORKSPACE;
+  const BlendOffsets o = blend_offsets(G, B, I);
+  const uint32_t cap = (uint32_t)B.cap;
+  ScopedTimer tm(T_BLEND_BWD, stream);
+  hipLaunchKernelGGL(clear_flags_batched_kernel, dim3((unsigned)((B.cap / 16 + 255) / 256 + 1), n), dim3(256), 0,
+                     stream, cap, o, b);
+  const int grid = (BWD_GRID + n - 1) / n < 512 ? 512 : (BWD_GRID + n - 1) / n;
+  if (c.with_normal)
+    hipLaunchKernelGGL(blend_bwd_batched_kernel<true>, dim3(grid, n), dim3(BLEND_BLOCK), 0, stream, c.H, c.W,
+                       B.tiles_x, cap, c.bg, o, b);
+  else
+    hipLaunchKernelGGL(blend_bwd_batched_kernel<false>, dim3(grid, n), dim3(BLEND_BLOCK), 0, stream, c.H, c.W,
+                       B.tiles_x, cap, c.bg, o, b);
+  return check_launch();
 }
 
 }  // namespace dimo

@@ -159,6 +159,22 @@ class ScopedTimer {
   hipEvent_t a_, b_;
 };
 
+// ---- batched execution of a step's renders (native step executor) -----------------------------
+// The executor's descriptors travel BY VALUE in the kernel arguments (8 x 256 B), blockIdx.y selects the render:
+// one launch per stage for all renders of a step instead of one per render and stage.
+constexpr int MAX_BATCH = 8;
+struct RenderBatch {
+  dimo_render_desc r[MAX_BATCH];
+};
+int lbs_forward_batched(const dimo_step_common &c, const RenderBatch &b, int n, hipStream_t stream);
+size_t lbs_backward_batched_scratch_bytes(int N, int M, int n);
+int lbs_backward_batched(const dimo_step_common &c, const RenderBatch &b, int n, hipStream_t stream);
+int preprocess_forward_batched(const dimo_step_common &c, const RenderBatch &b, int n, hipStream_t stream);
+int preprocess_backward_batched(const dimo_step_common &c, const RenderBatch &b, int n, hipStream_t stream);
+int bin_instances_batched(const dimo_step_common &c, const RenderBatch &b, int n, hipStream_t stream);
+int blend_forward_batched(const dimo_step_common &c, const RenderBatch &b, int n, hipStream_t stream);
+int blend_backward_batched(const dimo_step_common &c, const RenderBatch &b, int n, hipStream_t stream);
+
 // ---- internal (C++ linkage) entry points shared between translation units ---------------------
 int scan_block_sums(int nb, uint32_t *block_sums, uint32_t *total, hipStream_t stream);
 int write_offsets(int N, const uint32_t *tiles, const uint32_t *block_sums, uint32_t *offsets, hipStream_t stream);

@@ -48,10 +48,9 @@ struct GaussIO {
 };
 
 template <bool LOCAL_FRAME>
-__global__ void __launch_bounds__(DEF_BLOCK) lbs_fwd_kernel(int N, int M, GaussIO g, CtrlTable t,
-                                                            float *__restrict__ out_xyz, float *__restrict__ out_rot,
-                                                            float *__restrict__ out_scales,
-                                                            float *__restrict__ out_opacity) {
+__device__ __forceinline__ void lbs_fwd_body(int N, int M, GaussIO g, CtrlTable t, float *__restrict__ out_xyz,
+                                             float *__restrict__ out_rot, float *__restrict__ out_scales,
+                                             float *__restrict__ out_opacity) {
   extern __shared__ __attribute__((aligned(16))) float s_cp[];
   load_ctrl_to_lds(t, M, s_cp);
   __syncthreads();
@@ -106,14 +105,31 @@ __global__ void __launch_bounds__(DEF_BLOCK) lbs_fwd_kernel(int N, int M, GaussI
   }
 }
 
+template <bool LOCAL_FRAME>
+__global__ void __launch_bounds__(DEF_BLOCK) lbs_fwd_kernel(int N, int M, GaussIO g, CtrlTable t,
+                                                            float *__restrict__ out_xyz, float *__restrict__ out_rot,
+                                                            float *__restrict__ out_scales,
+                                                            float *__restrict__ out_opacity) {
+  lbs_fwd_body<LOCAL_FRAME>(N, M, g, t, out_xyz, out_rot, out_scales, out_opacity);
+}
+// blockIdx.y = render of the batch (every render skins the same canonical Gaussians with its own TimeNet rows)
+template <bool LOCAL_FRAME>
+__global__ void __launch_bounds__(DEF_BLOCK) lbs_fwd_batched_kernel(int N, int M, GaussIO g, const float *c_xyz,
+                                                                    const float *c_lr, RenderBatch b) {
+  const dimo_render_desc &r = b.r[blockIdx.y];
+  lbs_fwd_body<LOCAL_FRAME>(N, M, g, CtrlTable{c_xyz, c_lr, r.d_xyz, r.d_rot}, r.pts, r.rot, r.scales, r.opac);
+}
+
 // ACC: add into the per-Gaussian outputs instead of overwriting them (a training step sums the gradients
 // of all its renders straight into the flat gradient bucket).
+// The batched launch runs this in place (outputs over the inputs of the same Gaussian, each element read before
+// it is written by its own thread), hence no __restrict__ on the eight per-Gaussian arrays.
 template <bool LOCAL_FRAME, bool ACC>
-__global__ void __launch_bounds__(DEF_BLOCK) lbs_bwd_kernel(
-    int N, int M, GaussIO g, CtrlTable t, const float *__restrict__ g_xyz, const float *__restrict__ g_rot,
-    const float *__restrict__ g_scales, const float *__restrict__ g_opacity, float *__restrict__ d_xyz_out,
-    float *__restrict__ d_rot_out, float *__restrict__ d_scaling_out, float *__restrict__ d_opacity_out,
-    float *__restrict__ partials /* [gridDim.x][M][CP_STRIDE] */) {
+__device__ __forceinline__ void lbs_bwd_body(int N, int M, GaussIO g, CtrlTable t, const float *g_xyz,
+                                             const float *g_rot, const float *g_scales, const float *g_opacity,
+                                             float *d_xyz_out, float *d_rot_out, float *d_scaling_out,
+                                             float *d_opacity_out,
+                                             float *__restrict__ partials /* [gridDim.x][M][CP_STRIDE] */) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float *s_cp = smem;                    // control-point table
   float *s_acc = smem + M * CP_STRIDE;   // control-point gradient accumulators
@@ -253,6 +269,85 @@ __global__ void __launch_bounds__(DEF_BLOCK) lbs_bwd_kernel(
   for (int j = threadIdx.x; j < M * CP_STRIDE; j += blockDim.x) dst[j] = s_acc[j];
 }
 
+template <bool LOCAL_FRAME, bool ACC>
+__global__ void __launch_bounds__(DEF_BLOCK) lbs_bwd_kernel(
+    int N, int M, GaussIO g, CtrlTable t, const float *__restrict__ g_xyz, const float *__restrict__ g_rot,
+    const float *__restrict__ g_scales, const float *__restrict__ g_opacity, float *__restrict__ d_xyz_out,
+    float *__restrict__ d_rot_out, float *__restrict__ d_scaling_out, float *__restrict__ d_opacity_out,
+    float *__restrict__ partials) {
+  lbs_bwd_body<LOCAL_FRAME, ACC>(N, M, g, t, g_xyz, g_rot, g_scales, g_opacity, d_xyz_out, d_rot_out, d_scaling_out,
+                                 d_opacity_out, partials);
+}
+// blockIdx.y = render.  Per-Gaussian gradients are written IN PLACE over the render's rasterizer gradients
+// (g_means3D -> d xyz, g_rot -> d rotation, g_scales -> d scaling, g_opac -> d opacity: same shapes);
+// accumulate_batched_kernel then folds the renders into the shared gradient views in a fixed order.
+template <bool LOCAL_FRAME>
+__global__ void __launch_bounds__(DEF_BLOCK) lbs_bwd_batched_kernel(int N, int M, GaussIO g, const float *c_xyz,
+                                                                    const float *c_lr, RenderBatch b,
+                                                                    float *__restrict__ partials) {
+  const dimo_render_desc &r = b.r[blockIdx.y];
+  lbs_bwd_body<LOCAL_FRAME, false>(N, M, g, CtrlTable{c_xyz, c_lr, r.d_xyz, r.d_rot}, r.g_means3D, r.g_rot,
+                                   r.g_scales, r.g_opac, r.g_means3D, r.g_rot, r.g_scales, r.g_opac,
+                                   partials + (size_t)blockIdx.y * gridDim.x * M * CP_STRIDE);
+}
+
+// Batched control-point reduction: one thread owns output j of EVERY render (renders that share a (motion, frame)
+// pair share their TimeNet gradient rows, and all share the control points), so the adds are ordered.
+__global__ void __launch_bounds__(256) lbs_reduce_batched_kernel(int M, int nblocks, int n_renders,
+                                                                 const float *__restrict__ partials,
+                                                                 float *d_c_xyz, float *d_c_lr, RenderBatch b) {
+  __shared__ float s_part[16][17];
+  const int jj = threadIdx.x & 15, chunk = threadIdx.x >> 4;
+  const int j = blockIdx.x * 16 + jj;
+  const int m = j / CP_STRIDE, c = j % CP_STRIDE;
+  for (int r = 0; r < n_renders; ++r) {
+    const float *p = partials + (size_t)r * nblocks * M * CP_STRIDE;
+    float s = 0.f;
+    if (j < M * CP_STRIDE)
+      for (int k = chunk; k < nblocks; k += 16) s += p[(size_t)k * M * CP_STRIDE + j];
+    __syncthreads();
+    s_part[chunk][jj] = s;
+    __syncthreads();
+    if (chunk == 0 && j < M * CP_STRIDE) {
+      s = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) s += s_part[k][jj];
+      float *dst;
+      if (c < 3) dst = d_c_xyz + 3 * m + c;
+      else if (c == 3) dst = d_c_lr + m;
+      else if (c < 7) dst = b.r[r].g_d_xyz + 3 * m + (c - 4);
+      else dst = b.r[r].g_d_rot + 4 * m + (c - 7);
+      *dst += s;
+    }
+  }
+}
+
+// dst[i] += sum_r src_r[i] for the five per-Gaussian gradient arrays of a batch (fixed render order)
+__global__ void __launch_bounds__(256) accumulate_batched_kernel(int N, int n_renders, RenderBatch b, float *g_xyz,
+                                                                 float *g_rotation, float *g_scaling,
+                                                                 float *g_opacity, float *g_f_dc) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  // segments: [0,3N) xyz | [3N,7N) rotation | [7N,10N) scaling | [10N,11N) opacity | [11N,14N) f_dc
+  const size_t n = (size_t)N;
+  if (i >= 14 * n) return;
+  float *dst;
+  size_t k;
+  int which;
+  if (i < 3 * n) dst = g_xyz, k = i, which = 0;
+  else if (i < 7 * n) dst = g_rotation, k = i - 3 * n, which = 1;
+  else if (i < 10 * n) dst = g_scaling, k = i - 7 * n, which = 2;
+  else if (i < 11 * n) dst = g_opacity, k = i - 10 * n, which = 3;
+  else dst = g_f_dc, k = i - 11 * n, which = 4;
+  float s = dst[k];
+  for (int r = 0; r < n_renders; ++r) {
+    const dimo_render_desc &d = b.r[r];
+    const float *src = which == 0 ? d.g_means3D : which == 1 ? d.g_rot : which == 2 ? d.g_scales
+                       : which == 3 ? d.g_opac : d.g_shs;
+    s += src[k];
+  }
+  dst[k] = s;
+}
+
 // sums the per-workgroup partial tables in a fixed order and scatters into the four gradient tensors
 __global__ void __launch_bounds__(256) lbs_reduce_kernel(int M, int nblocks, int accumulate,
                                                          const float *__restrict__ partials,
@@ -304,9 +399,62 @@ inline void allow_big_lds() {
                               hipFuncAttributeMaxDynamicSharedMemorySize, lim);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(lbs_bwd_kernel<false, true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(lbs_fwd_batched_kernel<true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(lbs_fwd_batched_kernel<false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(lbs_bwd_batched_kernel<true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(lbs_bwd_batched_kernel<false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lim);
     return true;
   }();
   (void)once;
+}
+
+// ---- batched host entry points (native step executor) ------------------------------------------------------------
+int lbs_forward_batched(const dimo_step_common &c, const RenderBatch &b, int n, hipStream_t stream) {
+  if (c.N <= 0 || n <= 0) return DIMO_OK;
+  GaussIO g{c.xyz, c.rotation, c.scaling, c.opacity, c.nn_dist, c.nn_idx};
+  const size_t lds = (size_t)c.M * CP_STRIDE * sizeof(float);
+  allow_big_lds();
+  ScopedTimer tm(T_DEFORM_FWD, stream);
+  // the control-point table is re-built per workgroup: fewer, fatter workgroups per render when batching
+  const int grid = max(1, deform_grid(c.N) / (n > 1 ? 2 : 1));
+  if (c.local_frame)
+    hipLaunchKernelGGL(lbs_fwd_batched_kernel<true>, dim3(grid, n), dim3(DEF_BLOCK), lds, stream, c.N, c.M, g, c.c_xyz,
+                       c.c_log_radius, b);
+  else
+    hipLaunchKernelGGL(lbs_fwd_batched_kernel<false>, dim3(grid, n), dim3(DEF_BLOCK), lds, stream, c.N, c.M, g,
+                       c.c_xyz, c.c_log_radius, b);
+  return check_launch();
+}
+
+size_t lbs_backward_batched_scratch_bytes(int N, int M, int n) {
+  return (size_t)n * align_up((size_t)deform_grid(N) * (size_t)(M > 0 ? M : 1) * CP_STRIDE * sizeof(float));
+}
+
+int lbs_backward_batched(const dimo_step_common &c, const RenderBatch &b, int n, hipStream_t stream) {
+  if (c.N <= 0 || n <= 0) return DIMO_OK;
+  if (c.lbs_scratch_bytes < lbs_backward_batched_scratch_bytes(c.N, c.M, n)) return DIMO_E_WORKSPACE;
+  GaussIO g{c.xyz, c.rotation, c.scaling, c.opacity, c.nn_dist, c.nn_idx};
+  const size_t lds = 2 * (size_t)c.M * CP_STRIDE * sizeof(float);
+  allow_big_lds();
+  const int grid = max(1, deform_grid(c.N) / (n > 1 ? 2 : 1));
+  float *partials = reinterpret_cast<float *>(c.lbs_scratch);
+  ScopedTimer tm(T_DEFORM_BWD, stream);
+  if (c.local_frame)
+    hipLaunchKernelGGL(lbs_bwd_batched_kernel<true>, dim3(grid, n), dim3(DEF_BLOCK), lds, stream, c.N, c.M, g, c.c_xyz,
+                       c.c_log_radius, b, partials);
+  else
+    hipLaunchKernelGGL(lbs_bwd_batched_kernel<false>, dim3(grid, n), dim3(DEF_BLOCK), lds, stream, c.N, c.M, g,
+                       c.c_xyz, c.c_log_radius, b, partials);
+  hipLaunchKernelGGL(lbs_reduce_batched_kernel, dim3((c.M * CP_STRIDE + 15) / 16), dim3(256), 0, stream, c.M, grid, n,
+                     partials, c.g_c_xyz, c.g_c_log_radius, b);
+  const size_t total = 14 * (size_t)c.N;
+  hipLaunchKernelGGL(accumulate_batched_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, c.N, n, b,
+                     c.g_xyz, c.g_rotation, c.g_scaling, c.g_opacity, c.g_f_dc);
+  return check_launch();
 }
 
 }  // namespace dimo

@@ -45,11 +45,20 @@ typedef struct {
 
 namespace dimo {
 
+// Three ways to run the renders of a step (dimo_executor_create(n_streams)):
+//   n > 0  per-render chains: render i runs its ~20 launches on private stream i % n
+//   n == 0 batched: every stage is ONE launch over all renders of the call (blockIdx.y = render), caller's stream
+//   n < 0  batched ranges: each [first, first + count) range given to forward_range / backward_launch is one
+//          batch, ranges go round-robin over |n| private streams (a motion's renders form a range: its losses run
+//          on the caller's stream while the other motions' batches are still rendering)
 struct Executor {
+  bool batched = false;
   std::vector<hipStream_t> streams;
   std::vector<hipEvent_t> stream_done;
   std::vector<hipEvent_t> render_done;
   std::vector<hipEvent_t> fwd_done;
+  std::vector<int> range_stream;  // batched ranges: stream of the range that starts at render i (-1: none)
+  int next_stream = 0;
   hipEvent_t main_ready = nullptr;
 };
 
@@ -64,9 +73,11 @@ __global__ void __launch_bounds__(256) accumulate_kernel(size_t n, float *__rest
 using namespace dimo;
 
 extern "C" void *dimo_executor_create(int n_streams) {
-  if (n_streams < 1 || n_streams > 16) return nullptr;
+  if (n_streams < -16 || n_streams > 16) return nullptr;
   Executor *ex = new Executor();
-  for (int i = 0; i < n_streams; ++i) {
+  ex->batched = n_streams <= 0;
+  const int S = n_streams < 0 ? -n_streams : n_streams;
+  for (int i = 0; i < S; ++i) {
     hipStream_t s;
     hipEvent_t e;
     if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess ||
@@ -95,20 +106,11 @@ extern "C" void dimo_executor_destroy(void *h) {
   delete ex;
 }
 
-static int fork_from_main(Executor *ex, hipStream_t main) {
-  if (hipEventRecord(ex->main_ready, main) != hipSuccess) return DIMO_E_LAUNCH;
-  for (auto s : ex->streams)
-    if (hipStreamWaitEvent(s, ex->main_ready, 0) != hipSuccess) return DIMO_E_LAUNCH;
-  return DIMO_OK;
+static void fill_batch(RenderBatch &b, const dimo_render_desc *d, int n) {
+  for (int i = 0; i < MAX_BATCH; ++i) b.r[i] = d[i < n ? i : n - 1];
 }
 
-extern "C" int dimo_executor_forward(void *h, const dimo_step_common *c, int n, const dimo_render_desc *d,
-                                     void *main_stream) {
-  // Launches the forward chain of renders [0, n) on the private streams (render i on stream i % S) and records
-  // one event per render.  Does NOT make the caller's stream wait: see dimo_executor_join.
-  Executor *ex = reinterpret_cast<Executor *>(h);
-  hipStream_t main = (hipStream_t)main_stream;
-  if (!ex || !c || n < 0 || (n > 0 && !d)) return DIMO_E_ARG;
+static int ensure_events(Executor *ex, int n) {
   while ((int)ex->render_done.size() < n || (int)ex->fwd_done.size() < n) {
     hipEvent_t e, f;
     if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess ||
@@ -117,10 +119,75 @@ extern "C" int dimo_executor_forward(void *h, const dimo_step_common *c, int n, 
     ex->render_done.push_back(e);
     ex->fwd_done.push_back(f);
   }
-  int rc = fork_from_main(ex, main);
-  if (rc) return rc;
+  if ((int)ex->range_stream.size() < n) ex->range_stream.resize(n, -1);
+  return DIMO_OK;
+}
+
+static int fork_from_main(Executor *ex, hipStream_t main) {
+  if (hipEventRecord(ex->main_ready, main) != hipSuccess) return DIMO_E_LAUNCH;
+  for (auto s : ex->streams)
+    if (hipStreamWaitEvent(s, ex->main_ready, 0) != hipSuccess) return DIMO_E_LAUNCH;
+  return DIMO_OK;
+}
+
+static int fork_one(Executor *ex, hipStream_t main, hipStream_t s) {
+  if (hipEventRecord(ex->main_ready, main) != hipSuccess) return DIMO_E_LAUNCH;
+  return hipStreamWaitEvent(s, ex->main_ready, 0) == hipSuccess ? DIMO_OK : DIMO_E_LAUNCH;
+}
+
+static int batched_forward(const dimo_step_common *c, const dimo_render_desc *d, int first, int count,
+                           hipStream_t s) {
+  for (int i0 = first; i0 < first + count; i0 += MAX_BATCH) {
+    const int m = first + count - i0 < MAX_BATCH ? first + count - i0 : MAX_BATCH;
+    RenderBatch b;
+    fill_batch(b, d + i0, m);
+    int rc = lbs_forward_batched(*c, b, m, s);
+    if (!rc) rc = preprocess_forward_batched(*c, b, m, s);
+    if (!rc) rc = bin_instances_batched(*c, b, m, s);
+    if (!rc) rc = blend_forward_batched(*c, b, m, s);
+    if (rc) return rc;
+  }
+  return DIMO_OK;
+}
+
+static int batched_backward_raster(const dimo_step_common *c, const dimo_render_desc *d, int first, int count,
+                                   hipStream_t s) {
+  for (int i0 = first; i0 < first + count; i0 += MAX_BATCH) {
+    const int m = first + count - i0 < MAX_BATCH ? first + count - i0 : MAX_BATCH;
+    RenderBatch b;
+    fill_batch(b, d + i0, m);
+    int rc = blend_backward_batched(*c, b, m, s);
+    if (!rc) rc = preprocess_backward_batched(*c, b, m, s);
+    if (rc) return rc;
+  }
+  return DIMO_OK;
+}
+
+extern "C" int dimo_executor_forward_range(void *h, const dimo_step_common *c, int first, int count,
+                                           const dimo_render_desc *d, void *main_stream) {
+  // Forward chains of renders [first, first + count), after everything enqueued on the caller's stream so far.
+  // With private streams the caller's stream does NOT wait: see dimo_executor_join.
+  Executor *ex = reinterpret_cast<Executor *>(h);
+  hipStream_t main = (hipStream_t)main_stream;
+  if (!ex || !c || first < 0 || count < 0 || (count > 0 && !d)) return DIMO_E_ARG;
+  if (count == 0) return DIMO_OK;
+  clear_errors();
   const int S = (int)ex->streams.size();
-  for (int i = 0; i < n; ++i) {
+  if (ex->batched && S == 0) return batched_forward(c, d, first, count, main);
+  int rc = ensure_events(ex, first + count);
+  if (rc) return rc;
+  if (ex->batched) {
+    const int si = ex->next_stream++ % S;
+    hipStream_t s = ex->streams[si];
+    ex->range_stream[first] = si;
+    rc = fork_one(ex, main, s);
+    if (!rc) rc = batched_forward(c, d, first, count, s);
+    if (rc) return rc;
+    return hipEventRecord(ex->fwd_done[first], s) == hipSuccess ? DIMO_OK : DIMO_E_LAUNCH;
+  }
+  rc = fork_from_main(ex, main);
+  if (rc) return rc;
+  for (int i = first; i < first + count; ++i) {
     hipStream_t s = ex->streams[i % S];
     const dimo_render_desc &r = d[i];
     rc = dimo_deform_forward(c->N, c->M, c->local_frame, c->xyz, c->rotation, c->scaling, c->opacity, c->c_xyz,
@@ -140,13 +207,22 @@ extern "C" int dimo_executor_forward(void *h, const dimo_step_common *c, int n, 
   return DIMO_OK;
 }
 
+extern "C" int dimo_executor_forward(void *h, const dimo_step_common *c, int n, const dimo_render_desc *d,
+                                     void *main_stream) {
+  return dimo_executor_forward_range(h, c, 0, n, d, main_stream);
+}
+
 // The caller's stream waits for the forward of renders [first, first + count).
 extern "C" int dimo_executor_join(void *h, int first, int count, void *main_stream) {
   Executor *ex = reinterpret_cast<Executor *>(h);
   hipStream_t main = (hipStream_t)main_stream;
-  if (!ex || first < 0 || count < 0 || first + count > (int)ex->fwd_done.size()) return DIMO_E_ARG;
-  for (int i = first; i < first + count; ++i)
+  if (!ex || first < 0 || count < 0) return DIMO_E_ARG;
+  if (ex->streams.empty()) return DIMO_OK;  // everything already runs on the caller's stream
+  if (first + count > (int)ex->fwd_done.size()) return DIMO_E_ARG;
+  for (int i = first; i < first + count; ++i) {
+    if (ex->batched && ex->range_stream[i] < 0) continue;  // only range starts carry an event
     if (hipStreamWaitEvent(main, ex->fwd_done[i], 0) != hipSuccess) return DIMO_E_LAUNCH;
+  }
   return DIMO_OK;
 }
 
@@ -156,11 +232,22 @@ extern "C" int dimo_executor_backward_launch(void *h, const dimo_step_common *c,
                                              const dimo_render_desc *d, void *main_stream) {
   Executor *ex = reinterpret_cast<Executor *>(h);
   hipStream_t main = (hipStream_t)main_stream;
-  if (!ex || !c || first < 0 || count < 0 || first + count > (int)ex->render_done.size() || (count > 0 && !d))
-    return DIMO_E_ARG;
+  if (!ex || !c || first < 0 || count < 0 || (count > 0 && !d)) return DIMO_E_ARG;
+  if (count == 0) return DIMO_OK;
+  clear_errors();
+  const int S = (int)ex->streams.size();
+  if (ex->batched && S == 0) return batched_backward_raster(c, d, first, count, main);
+  if (first + count > (int)ex->render_done.size()) return DIMO_E_ARG;
+  if (ex->batched) {
+    const int si = ex->range_stream[first] >= 0 ? ex->range_stream[first] : 0;
+    hipStream_t s = ex->streams[si];
+    int rc = fork_one(ex, main, s);
+    if (!rc) rc = batched_backward_raster(c, d, first, count, s);
+    if (rc) return rc;
+    return hipEventRecord(ex->render_done[first], s) == hipSuccess ? DIMO_OK : DIMO_E_LAUNCH;
+  }
   int rc = fork_from_main(ex, main);
   if (rc) return rc;
-  const int S = (int)ex->streams.size();
   for (int i = first + count - 1; i >= first; --i) {
     hipStream_t s = ex->streams[i % S];
     const dimo_render_desc &r = d[i];
@@ -175,14 +262,30 @@ extern "C" int dimo_executor_backward_launch(void *h, const dimo_step_common *c,
   return DIMO_OK;
 }
 
-// On the caller's stream, in render order: wait for render i's rasterizer backward, then g_f_dc += g_shs and the
-// skinning backward accumulating into the shared gradient views.
+// On the caller's stream: wait for the rasterizer backward of renders [first, first + count), then the skinning
+// backward accumulating into the shared gradient views (g_f_dc += g_shs included).
 extern "C" int dimo_executor_backward_accumulate(void *h, const dimo_step_common *c, int first, int count,
                                                  const dimo_render_desc *d, void *main_stream) {
   Executor *ex = reinterpret_cast<Executor *>(h);
   hipStream_t main = (hipStream_t)main_stream;
-  if (!ex || !c || first < 0 || count < 0 || first + count > (int)ex->render_done.size() || (count > 0 && !d))
-    return DIMO_E_ARG;
+  if (!ex || !c || first < 0 || count < 0 || (count > 0 && !d)) return DIMO_E_ARG;
+  if (count == 0) return DIMO_OK;
+  clear_errors();
+  if (ex->batched) {
+    if (!ex->streams.empty()) {
+      if (first + count > (int)ex->render_done.size()) return DIMO_E_ARG;
+      if (hipStreamWaitEvent(main, ex->render_done[first], 0) != hipSuccess) return DIMO_E_LAUNCH;
+    }
+    for (int i0 = first; i0 < first + count; i0 += MAX_BATCH) {
+      const int m = first + count - i0 < MAX_BATCH ? first + count - i0 : MAX_BATCH;
+      RenderBatch b;
+      fill_batch(b, d + i0, m);
+      const int rc = lbs_backward_batched(*c, b, m, main);
+      if (rc) return rc;
+    }
+    return DIMO_OK;
+  }
+  if (first + count > (int)ex->render_done.size()) return DIMO_E_ARG;
   const size_t n_dc = (size_t)c->N * 3;
   for (int i = first + count - 1; i >= first; --i) {
     const dimo_render_desc &r = d[i];

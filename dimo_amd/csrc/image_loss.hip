@@ -74,18 +74,22 @@ __device__ __forceinline__ float pair_term(const Px &A, const Px &B, float side,
 
 template <bool DEPTH, bool NORMAL>
 __global__ void __launch_bounds__(256) image_loss_kernel(
-    int H, int W, LossParams prm, const float *__restrict__ image, const float *__restrict__ depth,
+    int H, int W, int n_images, LossParams prm, const float *__restrict__ image, const float *__restrict__ depth,
     const float *__restrict__ normal, const float *__restrict__ alpha, const float *__restrict__ gt,
     const float *__restrict__ mask, size_t mask_stride, const float *__restrict__ ssim_grad,
     float *__restrict__ loss_out, float *__restrict__ g_image, float *__restrict__ g_depth,
     float *__restrict__ g_normal, float *__restrict__ g_alpha) {
   __shared__ float s_red[4];
-  const int b = blockIdx.z;
-  const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = blockIdx.y * 8 + (threadIdx.x >> 5);
   const size_t HW = (size_t)H * W;
+  float loss = 0.0f;
+  // a workgroup walks 32x8 pixel tiles (image, ty, tx) with stride gridDim.x: ONE atomic on the loss word per
+  // workgroup (4096 same-address atomics were most of this kernel's 67 us)
+  const int tiles_x = (W + 31) / 32, tiles_y = (H + 7) / 8;
+  for (int tile = blockIdx.x; tile < tiles_x * tiles_y * n_images; tile += gridDim.x) {
+  const int b = tile / (tiles_x * tiles_y);
+  const int x = (tile % tiles_x) * 32 + (threadIdx.x & 31), y = ((tile / tiles_x) % tiles_y) * 8 + (threadIdx.x >> 5);
   const float *img = image + (size_t)b * 3 * HW, *dep = DEPTH ? depth + (size_t)b * HW : nullptr;
   const float *nrm = NORMAL ? normal + (size_t)b * 3 * HW : nullptr;
-  float loss = 0.0f;
   if (x < W && y < H) {
     const size_t pix = (size_t)y * W + x;
     const Px P = load_px<DEPTH, NORMAL>(img, dep, nrm, HW, pix);
@@ -134,6 +138,7 @@ __global__ void __launch_bounds__(256) image_loss_kernel(
       for (int k = 0; k < 3; ++k) g_normal[(size_t)b * 3 * HW + k * HW + pix] = gn[k];
     }
   }
+  }  // tiles
   float v = loss;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
@@ -161,11 +166,12 @@ extern "C" int dimo_image_loss(int B, int H, int W, const float *image, const fl
   for (int b = 0; b < LOSS_MAX_B; ++b) prm.w_mse[b] = b < B ? w_mse_host[b] : 0.0f;
   prm.w_mask = w_mask, prm.w_smooth_x = w_smooth_x, prm.w_smooth_y = w_smooth_y;
   prm.w_bilat_x = w_bilat_x, prm.w_bilat_y = w_bilat_y;
-  const dim3 grid((W + 31) / 32, (H + 7) / 8, B), block(256);
+  const long tiles = (long)((W + 31) / 32) * ((H + 7) / 8) * B;
+  const dim3 grid((unsigned)(tiles < 1024 ? tiles : 1024)), block(256);
   const size_t mstride = mask_per_image ? (size_t)H * W : 0;
   ScopedTimer tm(T_LOSS, stream);
 #define DIMO_LAUNCH_LOSS(D, N)                                                                                  \
-  hipLaunchKernelGGL((image_loss_kernel<D, N>), grid, block, 0, stream, H, W, prm, image, depth, normal, alpha, \
+  hipLaunchKernelGGL((image_loss_kernel<D, N>), grid, block, 0, stream, H, W, B, prm, image, depth, normal, alpha, \
                      gt, mask, mstride, ssim_grad, loss_accum, g_image, g_depth, g_normal, g_alpha)
   if (depth && normal) DIMO_LAUNCH_LOSS(true, true);
   else if (depth) DIMO_LAUNCH_LOSS(true, false);

@@ -110,7 +110,7 @@ __device__ __forceinline__ int argmin3(const float *s) {
   return k;
 }
 
-__global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_kernel(
+__device__ __forceinline__ void preprocess_fwd_body(
     int N, int deg, int M, int H, int W, const float *__restrict__ means3D, const float *__restrict__ shs,
     const float *__restrict__ colors_precomp, const float *__restrict__ opacities, const float *__restrict__ scales,
     const float *__restrict__ rotations, const float *__restrict__ cov3D_precomp, float scale_mod,
@@ -236,7 +236,28 @@ __global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_kernel(
 // Backward: sums the per-instance records of the blend backward (contiguous per Gaussian, indexed
 // by emission position -> deterministic, atomic-free), then differentiates conic -> cov2D ->
 // (Sigma, t) -> (scale, quaternion, mean), the perspective projection, depth, SH colour, normal.
-__global__ void __launch_bounds__(PRE_BLOCK) preprocess_bwd_kernel(
+__global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_kernel(
+    int N, int deg, int M, int H, int W, const float *__restrict__ means3D, const float *__restrict__ shs,
+    const float *__restrict__ colors_precomp, const float *__restrict__ opacities, const float *__restrict__ scales,
+    const float *__restrict__ rotations, const float *__restrict__ cov3D_precomp, float scale_mod,
+    const float *__restrict__ Vg, const float *__restrict__ Pg, const float *__restrict__ camg, float tanfovx,
+    float tanfovy, int32_t *__restrict__ radii, Splat *__restrict__ splat, uint16_t *__restrict__ rect,
+    uint32_t *__restrict__ tiles_touched, uint8_t *__restrict__ flags, uint32_t *__restrict__ block_sums) {
+  preprocess_fwd_body(N, deg, M, H, W, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
+                      scale_mod, Vg, Pg, camg, tanfovx, tanfovy, radii, splat, rect, tiles_touched, flags, block_sums);
+}
+// blockIdx.y = render of the batch: degree-0 colour from the shared f_dc, scale/rotation covariance
+__global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_batched_kernel(int N, int H, int W,
+                                                                           const float *__restrict__ f_dc,
+                                                                           float scale_mod, GeomLayout L,
+                                                                           RenderBatch b) {
+  const dimo_render_desc &r = b.r[blockIdx.y];
+  preprocess_fwd_body(N, 0, 1, H, W, r.pts, f_dc, nullptr, r.opac, r.scales, r.rot, nullptr, scale_mod, r.view, r.proj,
+                      r.campos, r.tanfovx, r.tanfovy, r.radii, at<Splat>(r.geom, L.splat), at<uint16_t>(r.geom, L.rect),
+                      at<uint32_t>(r.geom, L.tiles), at<uint8_t>(r.geom, L.flags), at<uint32_t>(r.geom, L.block_sums));
+}
+
+__device__ __forceinline__ void preprocess_bwd_body(
     int N, int deg, int M, int H, int W, uint32_t R_cap, const float *__restrict__ means3D,
     const float *__restrict__ shs, const float *__restrict__ colors_precomp, const float *__restrict__ scales,
     const float *__restrict__ rotations, const float *__restrict__ cov3D_precomp, float scale_mod,
@@ -482,6 +503,61 @@ __global__ void __launch_bounds__(PRE_BLOCK) preprocess_bwd_kernel(
     dL_dscales[3 * i] = dsc[0], dL_dscales[3 * i + 1] = dsc[1], dL_dscales[3 * i + 2] = dsc[2];
     dL_drot[4 * i] = dq[0], dL_drot[4 * i + 1] = dq[1], dL_drot[4 * i + 2] = dq[2], dL_drot[4 * i + 3] = dq[3];
   }
+}
+
+__global__ void __launch_bounds__(PRE_BLOCK) preprocess_bwd_kernel(
+    int N, int deg, int M, int H, int W, uint32_t R_cap, const float *__restrict__ means3D,
+    const float *__restrict__ shs, const float *__restrict__ colors_precomp, const float *__restrict__ scales,
+    const float *__restrict__ rotations, const float *__restrict__ cov3D_precomp, float scale_mod,
+    const float *__restrict__ Vg, const float *__restrict__ Pg, const float *__restrict__ camg, float tanfovx,
+    float tanfovy, const int32_t *__restrict__ radii, const Splat *__restrict__ splat,
+    const uint32_t *__restrict__ offsets, const uint8_t *__restrict__ flags, const SplatGrad *__restrict__ inst_grad,
+    const uint8_t *__restrict__ inst_flag, float *__restrict__ dL_dmeans3D, float *__restrict__ dL_dmeans2D,
+    float *__restrict__ dL_dshs, float *__restrict__ dL_dcolors, float *__restrict__ dL_dopacity,
+    float *__restrict__ dL_dscales, float *__restrict__ dL_drot, float *__restrict__ dL_dcov3D) {
+  preprocess_bwd_body(N, deg, M, H, W, R_cap, means3D, shs, colors_precomp, scales, rotations, cov3D_precomp, scale_mod,
+                      Vg, Pg, camg, tanfovx, tanfovy, radii, splat, offsets, flags, inst_grad, inst_flag, dL_dmeans3D,
+                      dL_dmeans2D, dL_dshs, dL_dcolors, dL_dopacity, dL_dscales, dL_drot, dL_dcov3D);
+}
+__global__ void __launch_bounds__(PRE_BLOCK) preprocess_bwd_batched_kernel(int N, int H, int W, uint32_t R_cap,
+                                                                           const float *__restrict__ f_dc,
+                                                                           float scale_mod, GeomLayout L,
+                                                                           size_t flag_offset, RenderBatch b) {
+  const dimo_render_desc &r = b.r[blockIdx.y];
+  preprocess_bwd_body(N, 0, 1, H, W, R_cap, r.pts, f_dc, nullptr, r.scales, r.rot, nullptr, scale_mod, r.view, r.proj,
+                      r.campos, r.tanfovx, r.tanfovy, r.radii, at<Splat>(r.geom, L.splat),
+                      at<uint32_t>(r.geom, L.offsets), at<uint8_t>(r.geom, L.flags),
+                      reinterpret_cast<const SplatGrad *>(r.bwd_scratch), at<uint8_t>(r.bwd_scratch, flag_offset),
+                      r.g_means3D, r.g_means2D, r.g_shs, nullptr, r.g_opac, r.g_scales, r.g_rot, nullptr);
+}
+
+// scan of tiles_touched for every render of a batch (binning.hip)
+int scan_offsets_batched(int N, const GeomLayout &L, const RenderBatch &b, int n, hipStream_t stream);
+
+int preprocess_forward_batched(const dimo_step_common &c, const RenderBatch &b, int n, hipStream_t stream) {
+  if (n <= 0) return DIMO_OK;
+  GeomLayout L(c.N);
+  if (c.geom_bytes < L.bytes) return DIMO_E_WORKSPACE;
+  const int nb = (c.N + PRE_BLOCK - 1) / PRE_BLOCK;
+  if (nb > 0) {
+    ScopedTimer tm(T_PREPROCESS_FWD, stream);
+    hipLaunchKernelGGL(preprocess_fwd_batched_kernel, dim3(nb, n), dim3(PRE_BLOCK), 0, stream, c.N, c.H, c.W, c.f_dc,
+                       c.scale_modifier, L, b);
+  }
+  ScopedTimer tm(T_SCAN, stream);
+  return scan_offsets_batched(c.N, L, b, n, stream);
+}
+
+int preprocess_backward_batched(const dimo_step_common &c, const RenderBatch &b, int n, hipStream_t stream) {
+  const int nb = (c.N + PRE_BLOCK - 1) / PRE_BLOCK;
+  if (nb == 0 || n <= 0) return DIMO_OK;
+  GeomLayout L(c.N);
+  const uint32_t cap = (uint32_t)(c.R_cap > 0xffffffffLL ? 0xffffffffu : (uint32_t)c.R_cap);
+  ScopedTimer tm(T_PREPROCESS_BWD, stream);
+  hipLaunchKernelGGL(preprocess_bwd_batched_kernel, dim3(nb, n), dim3(PRE_BLOCK), 0, stream, c.N, c.H, c.W, cap,
+                     c.f_dc, c.scale_modifier, L,
+                     align_up((size_t)(c.R_cap > 0 ? c.R_cap : 1) * sizeof(SplatGrad)), b);
+  return check_launch();
 }
 
 }  // namespace dimo

@@ -43,6 +43,10 @@ class StepExecutor:
             raise RuntimeError("StepExecutor needs a GPU (no CPU fallback in the product path)")
         self.L = _lib.lib()
         self.N, self.M, self.H, self.W, self.max_renders, self.device = N, M, H, W, max_renders, device
+        # n_streams: > 0 per-render chains on private streams; 0 batched on the caller's stream; < 0 batched
+        # [first, first+count) ranges round-robin over |n_streams| private streams (see include/dimo_hip.h)
+        self.batched = n_streams <= 0
+        self.ranged = n_streams < 0
         self.handle = self.L.dimo_executor_create(n_streams)
         if not self.handle:
             raise RuntimeError("dimo_executor_create failed")
@@ -50,7 +54,8 @@ class StepExecutor:
         u8 = dict(dtype=torch.uint8, device=device)
         L = self.L
         self.geom_bytes, self.img_bytes = L.dimo_raster_geom_bytes(N), L.dimo_raster_img_bytes(H, W)
-        self.lbs_scratch = torch.empty(L.dimo_deform_backward_scratch_bytes(N, M), **u8)
+        self.lbs_scratch = torch.empty(L.dimo_deform_backward_scratch_bytes(N, M) * (max_renders if self.batched else 1),
+                                       **u8)
         self.slots = []
         for _ in range(max_renders):
             s = dict(pts=torch.empty(N, 3, **f32), rot=torch.empty(N, 4, **f32), scales=torch.empty(N, 3, **f32),
@@ -115,6 +120,11 @@ class StepExecutor:
     def forward(self, n):
         _lib.check(self.L.dimo_executor_forward(self.handle, C.addressof(self.common), n, C.addressof(self.descs),
                                                 _lib.current_stream()), "dimo_executor_forward")
+
+    def forward_range(self, first, count):
+        _lib.check(self.L.dimo_executor_forward_range(self.handle, C.addressof(self.common), first, count,
+                                                      C.addressof(self.descs), _lib.current_stream()),
+                   "dimo_executor_forward_range")
 
     def join(self, first, count):
         _lib.check(self.L.dimo_executor_join(self.handle, first, count, _lib.current_stream()), "dimo_executor_join")

@@ -277,9 +277,11 @@ class Trainer:
             import os
             self._exec = StepExecutor(g._xyz.shape[0], g._c_xyz.shape[0], c.resolution, c.resolution,
                                       max(n_renders, 8), cap, self.device,
-                                      # 3 private streams + the caller's = the 4 hardware queues HIP exposes;
-                                      # measured on MI355X: 2 -> 1377, 3 -> 1513, 4 -> 1237, 8 -> 1338 frames/s
-                                      n_streams=int(os.environ.get("DIMO_EXEC_STREAMS", "3")))
+                                      # 0 = batched: every stage is one launch over all renders of the step.
+                                      # k > 0 = per-render chains on k private streams (3 + the caller's = the 4
+                                      # hardware queues HIP exposes; 2 -> 1377, 3 -> 1513, 4 -> 1237 frames/s
+                                      # before the batched mode existed)
+                                      n_streams=int(os.environ.get("DIMO_EXEC_STREAMS", "-2")))
         self._exec.resize_capacity(cap)
         return self._exec
 
@@ -336,7 +338,11 @@ class Trainer:
                 d.out_normal = (normal.data_ptr() + b * 3 * HW4) if normal is not None else None
                 d.out_alpha = alpha.data_ptr() + b * HW4
                 i += 1
-        ex.forward(n)
+        if ex.ranged:  # one batch per motion, on alternating private streams
+            for m, trs in by_motion.items():
+                ex.forward_range(first[m], len(trs))
+        else:
+            ex.forward(n)
         for w_ in ex.total_words(n):
             self.renderer.capacity.track(w_)
 
@@ -370,15 +376,20 @@ class Trainer:
                 d.g_color, d.g_alpha = gi.data_ptr() + b * 3 * HW4, ga.data_ptr() + b * HW4
                 d.g_depth = (gd.data_ptr() + b * HW4) if gd is not None else None
                 d.g_normal = (gn.data_ptr() + b * 3 * HW4) if gn is not None else None
-            ex.backward_launch(first[m], B)  # overlaps with the next motion's losses on this stream
+            if ex.ranged or not ex.batched:
+                ex.backward_launch(first[m], B)  # overlaps with the next motion's losses on this stream
             if g.vae_latent:  # KL term of this motion (main_train_dimo.py:355-360): tiny, autograd
                 mu, lv = g._mu[m], g._log_var[m]
                 kl = c.lambda_kl * (-0.5 * torch.sum(1 + lv - mu.pow(2) - lv.exp()))
                 kl.backward()
                 loss_accum += kl.detach()
         self._mark("losses+launch")
-        for m, trs in by_motion.items():
-            ex.backward_accumulate(first[m], len(trs))
+        if ex.batched and not ex.ranged:
+            ex.backward_launch(0, n)
+            ex.backward_accumulate(0, n)
+        else:
+            for m, trs in by_motion.items():
+                ex.backward_accumulate(first[m], len(trs))
         self._mark("raster_bwd+skinning_bwd")
         # TimeNet backward for all renders at once
         if mine and fused_tn:

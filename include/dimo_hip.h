@@ -266,6 +266,12 @@ typedef struct {
   float *g_means3D, *g_means2D, *g_shs, *g_opac, *g_scales, *g_rot;
 } dimo_render_desc;
 
+/* n_streams > 0: per-render chains on that many private streams (render i on stream i % n).
+ * n_streams == 0: batched -- every stage is ONE launch over all renders of the call (blockIdx.y = render), on the
+ *                 caller's stream.
+ * n_streams < 0: batched ranges -- each [first, first+count) range is one batch; ranges go round-robin over
+ *                |n_streams| private streams (one motion's renders per range: its losses overlap the other
+ *                motions' rendering). */
 void *dimo_executor_create(int n_streams);
 void dimo_executor_destroy(void *executor);
 /* forward chains of renders [0, n_renders) on the private streams (after everything enqueued on main_stream so
@@ -273,6 +279,9 @@ void dimo_executor_destroy(void *executor);
  * can run while the other motions are still rendering */
 int dimo_executor_forward(void *executor, const dimo_step_common *common, int n_renders,
                           const dimo_render_desc *renders, void *main_stream);
+/* the same for renders [first, first+count) only (`renders` is still the whole array) */
+int dimo_executor_forward_range(void *executor, const dimo_step_common *common, int first, int count,
+                                const dimo_render_desc *renders, void *main_stream);
 int dimo_executor_join(void *executor, int first, int count, void *main_stream);
 /* rasterizer backward of renders [first, first+count) on their streams (after main_stream's current tail) ... */
 int dimo_executor_backward_launch(void *executor, const dimo_step_common *common, int first, int count,
