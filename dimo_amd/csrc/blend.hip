@@ -25,6 +25,7 @@
 // with P at the bucket start = dL/dout . (checkpointed accumulators) and S from the final accumulators.  T_i is
 // the forward's own product (no division chain), and ~2700 equal-sized items replace ~800 unequal ones.
 #include "common.hpp"
+#include "wave_ops.hpp"
 
 namespace dimo {
 
@@ -199,56 +200,7 @@ __device__ __forceinline__ void blend_fwd_body(
 }
 
 // ---------------------------------------------------------------------------------- backward
-// DPP helpers.  update_dpp(old, src, ctrl, row_mask, bank_mask, bound_ctrl): lane l reads src of the lane the
-// control selects; lanes whose source is out of range keep `old` (= 0 here).
-template <int CTRL>
-__device__ __forceinline__ float dpp_mov(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
-}
-constexpr int DPP_QUAD_XOR1 = 0xB1;  // quad_perm:[1,0,3,2]
-constexpr int DPP_QUAD_XOR2 = 0x4E;  // quad_perm:[2,3,0,1]
-constexpr int DPP_ROW_SHR4 = 0x114;
-constexpr int DPP_ROW_SHR8 = 0x118;
-
-
-// Wave reduction of 16 values per lane down to row sums in ~48 VALU instead of 16 x 6:
-//   step 1 (lane ^ 1): each lane keeps 8 of the 16 values and adds its partner's copy of those;
-//   step 2 (lane ^ 2): keeps 4 of the 8;   steps 3-4 (row_shr 4, 8): plain adds on the 4 survivors.
-// After step 1 slot s (0..7) of a lane with bit0 = b holds value 8b + s; after step 2 slot t (0..3) of a lane
-// with (bit1, bit0) = (c, b) holds value 8b + 4c + t.  Lanes 12..15 of every row end up with the ROW sums.
-__device__ __forceinline__ void butterfly16(const float (&v)[16], int lane, float (&out)[4]) {
-  const bool b0 = lane & 1, b1 = lane & 2;
-  float h[8];
-#pragma unroll
-  for (int s = 0; s < 8; ++s) {
-    const float keep = b0 ? v[8 + s] : v[s];
-    const float send = b0 ? v[s] : v[8 + s];
-    h[s] = keep + dpp_mov<DPP_QUAD_XOR1>(send);
-  }
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const float keep = b1 ? h[4 + t] : h[t];
-    const float send = b1 ? h[t] : h[4 + t];
-    float r = keep + dpp_mov<DPP_QUAD_XOR2>(send);
-    r += dpp_mov<DPP_ROW_SHR4>(r);
-    r += dpp_mov<DPP_ROW_SHR8>(r);  // lanes 12..15 of every row: row sums
-    // Fold the four rows lane-for-lane (lanes 12..15 of each row hold four DIFFERENT quantities, so row_bcast
-    // cannot be used): gfx950's v_permlane16_swap / v_permlane32_swap exchange odd/even rows and the two wave
-    // halves inside the VALU.  Finishing in registers costs ~6 VALU per value but lets ONE conflict-free 4-lane
-    // LDS add replace four 4-way-conflicting ones -- the LDS pipe, not the VALU, was this kernel's busiest unit
-    // (SQ_LDS_IDX_ACTIVE ~ 1.6x SQ_INSTS_VALU).
-    {
-      float a = r, b = r;
-      asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
-      r = a + b;  // rows (0,1) and (2,3) summed, replicated
-      a = r, b = r;
-      asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
-      r = a + b;  // all four rows
-    }
-    out[t] = r;  // valid in lanes 12..15 of every row (identical across rows)
-  }
-}
-
+// (wave reduction helpers: wave_ops.hpp)
 template <bool NORMAL>
 __device__ __forceinline__ void blend_bwd_body(
     int H, int W, int tiles_x, uint32_t R_cap, const uint32_t *__restrict__ ranges,

@@ -9,6 +9,7 @@
 // control-point gradients in per-workgroup LDS (ds_add_f32), writes one partial table per workgroup and a
 // second tiny kernel sums the partials in a fixed order: no global atomics, deterministic.
 #include "common.hpp"
+#include "wave_ops.hpp"
 
 namespace dimo {
 
@@ -136,7 +137,12 @@ __device__ __forceinline__ void lbs_bwd_body(int N, int M, GaussIO g, CtrlTable 
   load_ctrl_to_lds(t, M, s_cp);
   for (int j = threadIdx.x; j < M * CP_STRIDE; j += blockDim.x) s_acc[j] = 0.f;
   __syncthreads();
-  for (int i = blockIdx.x * DEF_BLOCK + threadIdx.x; i < N; i += gridDim.x * DEF_BLOCK) {
+  const int lane = threadIdx.x & 63;
+  // whole waves stay in the loop (the control-point scatter below combines lanes); lanes past N compute on the
+  // last Gaussian and contribute / store nothing
+  for (int base = blockIdx.x * DEF_BLOCK; base < N; base += gridDim.x * DEF_BLOCK) {
+    const bool valid = base + (int)threadIdx.x < N;
+    const int i = valid ? base + (int)threadIdx.x : N - 1;
     const float x0 = g.xyz[3 * i], x1 = g.xyz[3 * i + 1], x2 = g.xyz[3 * i + 2];
     const float4 q0 = *reinterpret_cast<const float4 *>(g.rot + 4 * (size_t)i);
     const float4 dd = *reinterpret_cast<const float4 *>(g.nn_dist + 4 * (size_t)i);
@@ -182,7 +188,7 @@ __device__ __forceinline__ void lbs_bwd_body(int N, int M, GaussIO g, CtrlTable 
     const float gbx = -gw * sx + gx * sw + gy * sz - gz * sy;
     const float gby = -gw * sy - gx * sz + gy * sw + gz * sx;
     const float gbz = -gw * sz + gx * sy - gy * sx + gz * sw;
-    {
+    if (valid) {
       float4 *dst = reinterpret_cast<float4 *>(d_rot_out + 4 * (size_t)i);
       float4 v = make_float4(gbw, gbx, gby, gbz);
       if (ACC) {
@@ -195,10 +201,12 @@ __device__ __forceinline__ void lbs_bwd_body(int N, int M, GaussIO g, CtrlTable 
     const float gp0 = g_xyz[3 * i], gp1 = g_xyz[3 * i + 1], gp2 = g_xyz[3 * i + 2];
     float dx0 = LOCAL_FRAME ? 0.f : gp0, dx1 = LOCAL_FRAME ? 0.f : gp1, dx2 = LOCAL_FRAME ? 0.f : gp2;
     float gwk[DEF_K], sum_wg = 0.f;
+    // this Gaussian's contribution to columns 3..10 of the gradient row of neighbour k (columns 0..2, the gradient
+    // of the control point's position, follow from columns 4..6 after the reduction: see the end of the kernel)
+    float cpg[DEF_K][CP_STRIDE - 3];
 #pragma unroll
     for (int k = 0; k < DEF_K; ++k) {
       const float *cp = s_cp + idx[k] * CP_STRIDE;
-      float *ac = s_acc + idx[k] * CP_STRIDE;
       const float w = wt[k] * invW;
       const float qw = cp[7], qx = cp[8], qy = cp[9], qz = cp[10];
       // d/d(dq) through the blended quaternion
@@ -220,8 +228,7 @@ __device__ __forceinline__ void lbs_bwd_body(int N, int M, GaussIO g, CtrlTable 
         const float rt1 = R[1] * gy0 + R[4] * gy1 + R[7] * gy2;
         const float rt2 = R[2] * gy0 + R[5] * gy1 + R[8] * gy2;
         dx0 += rt0, dx1 += rt1, dx2 += rt2;
-        atomicAdd(ac + 0, gy0 - rt0), atomicAdd(ac + 1, gy1 - rt1), atomicAdd(ac + 2, gy2 - rt2);
-        atomicAdd(ac + 4, gy0), atomicAdd(ac + 5, gy1), atomicAdd(ac + 6, gy2);
+        cpg[k][1] = gy0, cpg[k][2] = gy1, cpg[k][3] = gy2;
         // dL/dR = gy (x - c)^T  -> unit quaternion -> raw quaternion
         const float d00 = gy0 * l0, d01 = gy0 * l1, d02 = gy0 * l2;
         const float d10 = gy1 * l0, d11 = gy1 * l1, d12 = gy1 * l2;
@@ -238,9 +245,9 @@ __device__ __forceinline__ void lbs_bwd_body(int N, int M, GaussIO g, CtrlTable 
         gq_y += (guy - y_ * du) * inv, gq_z += (guz - z_ * du) * inv;
       } else {
         gwt += cp[4] * gp0 + cp[5] * gp1 + cp[6] * gp2;
-        atomicAdd(ac + 4, w * gp0), atomicAdd(ac + 5, w * gp1), atomicAdd(ac + 6, w * gp2);
+        cpg[k][1] = w * gp0, cpg[k][2] = w * gp1, cpg[k][3] = w * gp2;
       }
-      atomicAdd(ac + 7, gq_w), atomicAdd(ac + 8, gq_x), atomicAdd(ac + 9, gq_y), atomicAdd(ac + 10, gq_z);
+      cpg[k][4] = gq_w, cpg[k][5] = gq_x, cpg[k][6] = gq_y, cpg[k][7] = gq_z;
       gwk[k] = gwt;
       sum_wg += w * gwt;
     }
@@ -251,20 +258,44 @@ __device__ __forceinline__ void lbs_bwd_body(int N, int M, GaussIO g, CtrlTable 
       const float g_wt = (W > NORM_EPS) ? (gwk[k] - sum_wg) * invW : 0.f;
       // wt = exp(-d^2/(2 r^2)) + eps ; d(wt)/dr = ex * d^2 / r^3 ; r = exp(lr) -> * r
       const float g_lr = g_wt * ex[k] * dist[k] * dist[k] / (r * r);
-      atomicAdd(s_acc + idx[k] * CP_STRIDE + 3, g_lr);
+      cpg[k][0] = g_lr;
     }
-    const float o = 1.0f / (1.0f + __expf(-g.opacity[i]));
-    const float gop = g_opacity[i] * o * (1.0f - o);
-    const float dxs[3] = {dx0, dx1, dx2};
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      const float gs = g_scales[3 * i + c] * __expf(g.scaling[3 * i + c]);
-      d_xyz_out[3 * i + c] = ACC ? d_xyz_out[3 * i + c] + dxs[c] : dxs[c];
-      d_scaling_out[3 * i + c] = ACC ? d_scaling_out[3 * i + c] + gs : gs;
+    for (int k = 0; k < DEF_K; ++k)
+      wave_scatter_add<CP_STRIDE - 3>(s_acc + 3, CP_STRIDE, idx[k], cpg[k], valid, lane);
+    if (valid) {
+      const float o = 1.0f / (1.0f + __expf(-g.opacity[i]));
+      const float gop = g_opacity[i] * o * (1.0f - o);
+      const float dxs[3] = {dx0, dx1, dx2};
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float gs = g_scales[3 * i + c] * __expf(g.scaling[3 * i + c]);
+        d_xyz_out[3 * i + c] = ACC ? d_xyz_out[3 * i + c] + dxs[c] : dxs[c];
+        d_scaling_out[3 * i + c] = ACC ? d_scaling_out[3 * i + c] + gs : gs;
+      }
+      d_opacity_out[i] = ACC ? d_opacity_out[i] + gop : gop;
     }
-    d_opacity_out[i] = ACC ? d_opacity_out[i] + gop : gop;
   }
   __syncthreads();
+  // Gradient of the control point's position (columns 0..2): sum_i (gy_i - R^T gy_i) = S - R^T S with S = the summed
+  // dL/dy of columns 4..6 -- R depends on the control point only, so three of the eleven LDS atomics per
+  // (Gaussian, neighbour) are replaced by one 3x3 product per control point and workgroup (linear in S: exact for
+  // the per-workgroup partial sums too).
+  if (LOCAL_FRAME) {
+    for (int m = threadIdx.x; m < M; m += blockDim.x) {
+      const float *cp = s_cp + m * CP_STRIDE;
+      float *ac = s_acc + m * CP_STRIDE;
+      const float qw = cp[7], qx = cp[8], qy = cp[9], qz = cp[10];
+      const float inv = 1.0f / sqrtf(qw * qw + qx * qx + qy * qy + qz * qz);
+      float R[9];
+      quat_R(qw * inv, qx * inv, qy * inv, qz * inv, R);
+      const float s0 = ac[4], s1 = ac[5], s2 = ac[6];
+      ac[0] = s0 - (R[0] * s0 + R[3] * s1 + R[6] * s2);
+      ac[1] = s1 - (R[1] * s0 + R[4] * s1 + R[7] * s2);
+      ac[2] = s2 - (R[2] * s0 + R[5] * s1 + R[8] * s2);
+    }
+    __syncthreads();
+  }
   float *dst = partials + (size_t)blockIdx.x * M * CP_STRIDE;
   for (int j = threadIdx.x; j < M * CP_STRIDE; j += blockDim.x) dst[j] = s_acc[j];
 }
