@@ -33,7 +33,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 NFEAT = 7
 TIMED = ["preprocess_fwd", "scan", "emit", "sort", "ranges", "blend_fwd", "blend_bwd", "preprocess_bwd", "knn",
-         "ssim_fwd", "ssim_bwd", "deform_fwd", "deform_bwd", "image_loss", "adam", "timenet_fwd", "timenet_bwd", "tile_sort"]
+         "ssim_fwd", "ssim_bwd", "deform_fwd", "deform_bwd", "image_loss", "adam", "timenet_fwd", "timenet_bwd", "place"]
 
 
 def make_trainer(device, rank, world, num_pts, resolution, per_gpu=(2, 2, 2), capacity=True):

@@ -15,10 +15,10 @@ extern "C" int dimo_raster_geom_layout(int N, size_t out[6]) {
   out[0] = L.splat, out[1] = L.rect, out[2] = L.tiles, out[3] = L.offsets, out[4] = L.flags, out[5] = L.total;
   return DIMO_OK;
 }
-extern "C" int dimo_raster_bin_layout(int64_t R_cap, int H, int W, size_t out[5]) {
+extern "C" int dimo_raster_bin_layout(int64_t R_cap, int H, int W, size_t out[3]) {
   if (!out || R_cap < 0 || H <= 0 || W <= 0) return DIMO_E_ARG;
   BinLayout L(R_cap, H, W);
-  out[0] = L.keys_a, out[1] = L.vals_a, out[2] = L.keys_b, out[3] = L.vals_b, out[4] = L.ranges;
+  out[0] = L.keys_b, out[1] = L.vals_b, out[2] = L.ranges;
   return DIMO_OK;
 }
 extern "C" int dimo_raster_img_layout(int H, int W, size_t out[2]) {
@@ -58,7 +58,7 @@ bool take_event(hipEvent_t *e) {
 }
 const char *const g_names[TIMED_COUNT] = {"preprocess_fwd", "scan", "emit",     "sort",     "ranges",  "blend_fwd",
                                           "blend_bwd",      "preprocess_bwd", "knn", "dist2", "ssim_fwd", "ssim_bwd",
-                                          "deform_fwd",     "deform_bwd", "image_loss", "adam", "timenet_fwd", "timenet_bwd", "tile_sort"};
+                                          "deform_fwd",     "deform_bwd", "image_loss", "adam", "timenet_fwd", "timenet_bwd", "place"};
 }  // namespace
 
 ScopedTimer::ScopedTimer(int id, hipStream_t s) : id_(id), stream_(s), a_(nullptr), b_(nullptr) {

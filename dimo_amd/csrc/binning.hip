@@ -1,13 +1,17 @@
-// Tile binning: scan of tiles_touched, key emission, sort of (tile | fp32 depth bits) keys with the Gaussian id
-// as payload, and tile ranges.  The sorted arrays equal a stable LSD radix sort over the whole key (the published
-// rasterizer's cub::DeviceRadixSort), but are produced in two steps that fit the machine better: stable radix
-// passes over the TILE bits only (2 passes at 512^2 instead of 6 over 42 bits -- every pass is three launches
-// whose cost is latency, not bandwidth: the instance arrays live in L2), then one workgroup per tile orders its
-// segment by (depth bits, Gaussian id) with a bitonic network in LDS.  The radix passes keep the emission order
-// (ascending Gaussian id) inside a tile, so (depth, id) is exactly the stable order.
+// Tile binning: produces, per tile, the list of Gaussians that touch it in (depth, id) order -- bit for bit the
+// arrays a stable radix sort of the (tile | fp32 depth bits) keys of all (Gaussian, tile) instances yields (the
+// published rasterizer's cub::DeviceRadixSort) -- without ever sorting the instances:
+//   1. the N Gaussians of the frame are sorted by their 32 depth bits (stable LSD radix, 4 passes over N keys;
+//      culled Gaussians carry the key 0xffffffff and no tiles);
+//   2. ORDERED FILTERS cut that list first into per-supertile lists, then every supertile list into the lists of
+//      its tiles (count pass, scan, fill pass per level: see "placement" below).  A filter keeps the input order,
+//      so every tile list comes out in (depth, id) order, and all writes are long contiguous runs.
+// A frame has ~10x fewer Gaussians than instances (1e5 vs 1e6 at the benchmark configuration): sorting the
+// Gaussians and filtering replaces 6 radix passes over the instances (first version), later 2 passes + a per-tile
+// LDS sort, each a chain of launches whose cost was latency rather than bandwidth.
 //
-// All kernels read the live instance count R from device memory (geom.total[0]) and are launched
-// over the CAPACITY R_cap, so the whole chain is enqueued without a host round trip.
+// Everything reads live counts from device memory (geom.total) and is sized by capacities, so the whole chain is
+// enqueued without a host round trip.
 #include "common.hpp"
 
 namespace dimo {
@@ -15,7 +19,7 @@ namespace dimo {
 // ------------------------------------------------------------------------------------ scan
 // Exclusive scan of the per-block sums (nb <= a few thousand) by one workgroup; writes the
 // grand total R to total[0] and clears the overflow flag total[1].
-__device__ __forceinline__ void scan_block_sums_body(int nb, uint32_t *__restrict__ sums,
+__device__ __forceinline__ void scan_block_sums_body(int nb, int N, uint32_t *__restrict__ sums,
                                                      uint32_t *__restrict__ total) {
   __shared__ uint32_t wave_tot[16];
   __shared__ uint32_t carry_s;
@@ -46,14 +50,16 @@ __device__ __forceinline__ void scan_block_sums_body(int nb, uint32_t *__restric
     total[0] = carry_s;
     total[1] = 0;
     total[2] = 0;
-    total[3] = 0;
+    total[3] = (uint32_t)N;  // element count of the depth sort
   }
 }
 
 // offsets[i] = inclusive scan of tiles_touched (block prefix + in-block scan)
+// ... and the input of the depth sort: key = depth bits (0xffffffff for a Gaussian without tiles), value = id
 __device__ __forceinline__ void write_offsets_body(int N, const uint32_t *__restrict__ tiles,
                                                    const uint32_t *__restrict__ block_prefix,
-                                                   uint32_t *__restrict__ offsets) {
+                                                   uint32_t *__restrict__ offsets, const Splat *__restrict__ splat,
+                                                   uint64_t *__restrict__ nkeys, uint32_t *__restrict__ nvals) {
   __shared__ uint32_t wave_tot[PRE_BLOCK / 64];
   const int i = blockIdx.x * PRE_BLOCK + threadIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -68,36 +74,11 @@ __device__ __forceinline__ void write_offsets_body(int N, const uint32_t *__rest
   __syncthreads();
   uint32_t off = block_prefix[blockIdx.x];
   for (int w = 0; w < wave; ++w) off += wave_tot[w];
-  if (i < N) offsets[i] = off + inc;
-}
-
-// ------------------------------------------------------------------------------------ emission
-// One thread per Gaussian: writes its (key, id) run at [offsets[i-1], offsets[i]).
-// key = (tile_id << 32) | depth bits; emission order = tile y, then tile x.
-__device__ __forceinline__ void emit_keys_body(int N, int tiles_x, uint32_t R_cap, const Splat *__restrict__ splat,
-                                               const uint16_t *__restrict__ rect,
-                                               const uint32_t *__restrict__ offsets, uint32_t *__restrict__ total,
-                                               uint64_t *__restrict__ keys, uint32_t *__restrict__ vals) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= N) return;
-  const uint32_t hi = offsets[i];
-  uint32_t off = i == 0 ? 0u : offsets[i - 1];
-  if (hi == off) return;
-  if (hi > R_cap) {  // capacity overflow: flag it, never write out of bounds
-    total[1] = 1;
-    if (off >= R_cap) return;
+  if (i < N) {
+    offsets[i] = off + inc;
+    nkeys[i] = v ? (uint64_t)__float_as_uint(splat[i].depth) : 0xffffffffull;
+    nvals[i] = (uint32_t)i;
   }
-  const uint2 rc = *reinterpret_cast<const uint2 *>(rect + 4 * (size_t)i);
-  const int x0 = rc.x & 0xffff, y0 = rc.x >> 16, x1 = rc.y & 0xffff, y1 = rc.y >> 16;
-  const uint32_t dbits = __float_as_uint(splat[i].depth);
-  for (int y = y0; y < y1; ++y)
-    for (int x = x0; x < x1; ++x) {
-      if (off < R_cap) {
-        keys[off] = ((uint64_t)(uint32_t)(y * tiles_x + x) << 32) | dbits;
-        vals[off] = (uint32_t)i;
-      }
-      ++off;
-    }
 }
 
 // ------------------------------------------------------------------------------------ radix sort
@@ -230,199 +211,257 @@ __device__ __forceinline__ void radix_scatter_body(
   }
 }
 
-// ------------------------------------------------------------------------------------ ranges
-__device__ __forceinline__ void clear_ranges_body(int T, uint32_t *__restrict__ ranges,
-                                                  uint32_t *__restrict__ work_count) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < 2 * T) ranges[i] = 0;
-  if (i == 0) *work_count = 0;  // the blend forward queues the backward's (tile, bucket) items behind it
-}
-__device__ __forceinline__ void tile_ranges_body(const uint64_t *__restrict__ keys,
-                                                 const uint32_t *__restrict__ total, uint32_t R_cap,
-                                                 uint32_t *__restrict__ ranges) {
-  const uint32_t R = min(total[0], R_cap);
-  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= R) return;
-  const uint32_t tile = (uint32_t)(keys[i] >> 32);
-  if (i == 0)
-    ranges[2 * tile] = 0;
-  else {
-    const uint32_t prev = (uint32_t)(keys[i - 1] >> 32);
-    if (prev != tile) {
-      ranges[2 * prev + 1] = i;
-      ranges[2 * tile] = i;
-    }
+// ------------------------------------------------------------------------------------ placement
+// From the depth-ordered Gaussian list to the per-tile lists with ORDERED FILTERS, two levels deep, so that every
+// output is written as long contiguous runs (a first version placed each instance with an 8-byte scattered write:
+// 15 M partial-line L2 misses per step, 220 us):
+//   level 1: the image is cut into <= 256 supertiles of SS x SS tiles; the depth-ordered list is cut into segments
+//            of 256; one wave per segment tests its Gaussians against every supertile (ballot / popcount give the
+//            order-preserving ranks) -- a count pass, a scan over the segments, a fill pass -> per-supertile lists
+//            of (Gaussian id, depth bits), still in depth order; list starts are aligned to 256 entries so that
+//   level 2: every 256-entry window of the level-1 array belongs to one supertile; one wave per window filters it
+//            against the <= 64 tiles of that supertile -- count, scan over the supertile's windows, tile starts,
+//            fill -> the final (key, value) lists.
+struct BinGrid {
+  int tiles_x, tiles_y, ss_shift, stx, sty, NS;  // supertile edge = 1 << ss_shift tiles, stx * sty = NS supertiles
+};
+constexpr int SEG = 256;        // list entries per wave (both levels)
+constexpr int MAX_SUPER = 256;  // supertiles (4 counters per lane at level 1)
+
+// level-1 metadata in the bin workspace (uint32): [0, 256) list length, [256, 512) list start (multiple of SEG),
+// [512] number of level-2 windows, [1024, ...) supertile of every window
+constexpr int META_LEN = 0, META_START = MAX_SUPER, META_NWIN = 2 * MAX_SUPER, META_WIN = 4 * MAX_SUPER;
+
+template <bool FILL>
+__device__ __forceinline__ void level1_body(int N, BinGrid gi, const uint32_t *__restrict__ perm,
+                                            const uint64_t *__restrict__ nkeys, const uint16_t *__restrict__ rect,
+                                            uint32_t *__restrict__ cnt1, const uint32_t *__restrict__ meta,
+                                            uint2 *__restrict__ l1list, size_t l1cap) {
+  const int seg = blockIdx.x, lane = threadIdx.x;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  uint32_t *row = cnt1 + (size_t)seg * MAX_SUPER;
+  uint32_t c[MAX_SUPER / 64];
+#pragma unroll
+  for (int q = 0; q < MAX_SUPER / 64; ++q) {
+    const int sidx = q * 64 + lane;
+    c[q] = (FILL && sidx < gi.NS) ? meta[META_START + sidx] + row[sidx] : 0u;
   }
-  if (i == R - 1) ranges[2 * tile + 1] = R;
-}
-
-// ------------------------------------------------------------------------------------ per-tile depth sort
-// One workgroup per tile orders the tile's segment by the 32 depth bits (stable, so ties keep the ascending
-// Gaussian id the radix passes over the tile bits left them in).  Segments of up to TS_CAP instances -- all of
-// them in practice -- are sorted in LDS with the same wave-ballot counting scatter as the global passes, 8 bits
-// at a time, skipping digits every key of the tile agrees on (view-space depths of one tile share their exponent
-// byte).  Linear in the segment length: the few crowded tiles do not leave a long tail behind.
-constexpr int TS_CAP = 4096;
-constexpr int TS_ITEMS = TS_CAP / 256;
-constexpr size_t TS_LDS_BYTES = 2 * TS_CAP * sizeof(uint64_t) + 4 * RADIX * sizeof(uint32_t);
-
-// Oversized segments fall back to a bitonic network on the global arrays (slow, exact).  "Mirror" form: every
-// compare-exchange moves the smaller element down, so an arbitrary length n behaves as if padded with +inf --
-// pairs whose upper index is >= n are skipped.
-template <class CmpSwap>
-__device__ __forceinline__ void bitonic_network(uint32_t n, CmpSwap cmp_swap) {
-  uint32_t np2 = 1;
-  while (np2 < n) np2 <<= 1;
-  const uint32_t half = np2 >> 1;
-  for (uint32_t k = 2; k <= np2; k <<= 1) {
-    for (uint32_t p = threadIdx.x; p < half; p += blockDim.x) {  // mirror step
-      const uint32_t blk = p / (k >> 1), l = p % (k >> 1);
-      const uint32_t lo = blk * k + l, hi = blk * k + k - 1 - l;
-      if (hi < n) cmp_swap(lo, hi);
-    }
-    __syncthreads();
-    for (uint32_t j = k >> 2; j > 0; j >>= 1) {
-      for (uint32_t p = threadIdx.x; p < half; p += blockDim.x) {
-        const uint32_t lo = (p / j) * 2 * j + (p % j), hi = lo + j;
-        if (hi < n) cmp_swap(lo, hi);
+  for (int it = 0; it < SEG / 64; ++it) {
+    const int k = seg * SEG + it * 64 + lane;
+    const bool valid = k < N;
+    const uint32_t g = perm[valid ? k : N - 1];
+    const uint2 rc = *reinterpret_cast<const uint2 *>(rect + 4 * (size_t)g);
+    const int x0 = rc.x & 0xffff, y0 = rc.x >> 16, x1 = rc.y & 0xffff, y1 = rc.y >> 16;
+    const bool some = valid && x1 > x0 && y1 > y0;
+    const int sx0 = x0 >> gi.ss_shift, sx1 = (x1 - 1) >> gi.ss_shift;
+    const int sy0 = y0 >> gi.ss_shift, sy1 = (y1 - 1) >> gi.ss_shift;
+    const uint32_t dbits = FILL ? (uint32_t)nkeys[valid ? k : N - 1] : 0u;
+    if (__ballot(some) == 0) continue;
+    int sx = 0, sy = 0;  // supertile (sx, sy) of index q * 64 + sl, advanced incrementally (wave-uniform)
+#pragma unroll
+    for (int q = 0; q < MAX_SUPER / 64; ++q) {
+      if (q * 64 >= gi.NS) break;
+      for (int sl = 0; sl < 64 && q * 64 + sl < gi.NS; ++sl) {
+        const bool cov = some && sx >= sx0 && sx <= sx1 && sy >= sy0 && sy <= sy1;
+        const unsigned long long bal = __ballot(cov);
+        if (++sx == gi.stx) sx = 0, ++sy;
+        if (bal == 0) continue;
+        if (FILL) {
+          const uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)c[q], sl);
+          const size_t pos = (size_t)off + (uint32_t)__popcll(bal & lt);
+          if (cov && pos < l1cap) l1list[pos] = make_uint2(g, dbits);
+        }
+        c[q] += lane == sl ? (uint32_t)__popcll(bal) : 0u;
       }
-      __syncthreads();
     }
+  }
+  if (!FILL) {
+#pragma unroll
+    for (int q = 0; q < MAX_SUPER / 64; ++q) row[q * 64 + lane] = c[q];
   }
 }
 
-__device__ __forceinline__ void tile_depth_sort_body(const uint32_t *__restrict__ ranges, uint64_t *__restrict__ keys,
-                                                     uint32_t *__restrict__ vals) {
-  extern __shared__ uint64_t ts_smem[];
-  __shared__ uint32_t wtot[4];
-  __shared__ uint32_t diff_s;
-  const uint32_t tile = blockIdx.x;
-  const uint32_t beg = ranges[2 * tile], end = ranges[2 * tile + 1];
-  if (end <= beg + 1) return;
-  const uint32_t n = end - beg;
-  if (n > TS_CAP) {
-    uint64_t *k = keys + beg;
-    uint32_t *v = vals + beg;
-    bitonic_network(n, [&](uint32_t lo, uint32_t hi) {
-      const uint64_t ka = k[lo], kb = k[hi];
-      const uint32_t va = v[lo], vb = v[hi];
-      if (kb < ka || (kb == ka && vb < va)) k[lo] = kb, k[hi] = ka, v[lo] = vb, v[hi] = va;
-    });
-    return;
+// one workgroup of 4 x MAX_SUPER threads: thread (part, s) scans its quarter of column s of cnt1 down the segments
+// (a local sum first, then the exclusive values in place: four quarters and 16 loads in flight per thread instead
+// of one 391-step dependent walk, which was 70 us of pure latency), then the list starts (aligned to SEG) and the
+// window -> supertile table
+constexpr int L1_PARTS = 4;
+__device__ __forceinline__ void level1_scan_body(int nseg, int NS, uint32_t *__restrict__ cnt1,
+                                                 uint32_t *__restrict__ meta, size_t max_windows) {
+  __shared__ uint32_t s_part[L1_PARTS][MAX_SUPER];
+  __shared__ uint32_t s_scan[MAX_SUPER];
+  const int sidx = threadIdx.x & (MAX_SUPER - 1), part = threadIdx.x / MAX_SUPER;
+  const int per = (nseg + L1_PARTS - 1) / L1_PARTS;
+  const int b_lo = min(nseg, part * per), b_hi = min(nseg, b_lo + per);
+  uint32_t *p = cnt1 + sidx;
+  uint32_t sum = 0;
+  for (int b0 = b_lo; b0 < b_hi; b0 += 16) {
+    uint32_t v[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = b0 + j < b_hi ? p[(size_t)(b0 + j) * MAX_SUPER] : 0u;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) sum += v[j];
   }
-  uint64_t *src = ts_smem, *dst = ts_smem + TS_CAP;  // composites (depth bits << 32 | Gaussian id)
-  uint32_t(*cnt)[RADIX] = reinterpret_cast<uint32_t(*)[RADIX]>(ts_smem + 2 * TS_CAP);
+  s_part[part][sidx] = sum;
+  __syncthreads();
+  uint32_t run = 0, len = 0;
+#pragma unroll
+  for (int q = 0; q < L1_PARTS; ++q) {
+    run += q < part ? s_part[q][sidx] : 0u;
+    len += s_part[q][sidx];
+  }
+  for (int b0 = b_lo; b0 < b_hi; b0 += 16) {
+    uint32_t v[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = b0 + j < b_hi ? p[(size_t)(b0 + j) * MAX_SUPER] : 0u;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      if (b0 + j < b_hi) p[(size_t)(b0 + j) * MAX_SUPER] = run;
+      run += v[j];
+    }
+  }
+  if (sidx >= NS) len = 0;
+  const uint32_t padded = (len + SEG - 1) / SEG * SEG;
+  if (part == 0) s_scan[sidx] = padded;
+  __syncthreads();
+  for (int o = 1; o < MAX_SUPER; o <<= 1) {  // Hillis-Steele inclusive scan of the padded lengths
+    const uint32_t add = (part == 0 && sidx >= o) ? s_scan[sidx - o] : 0u;
+    __syncthreads();
+    if (part == 0) s_scan[sidx] += add;
+    __syncthreads();
+  }
+  if (part != 0) return;
+  const uint32_t start = s_scan[sidx] - padded;
+  meta[META_LEN + sidx] = len;
+  meta[META_START + sidx] = start;
+  if (sidx == MAX_SUPER - 1) meta[META_NWIN] = (uint32_t)min((size_t)(s_scan[sidx] / SEG), max_windows);
+  for (uint32_t w = start / SEG; w < (start + padded) / SEG; ++w)
+    if (w < max_windows) meta[META_WIN + w] = (uint32_t)sidx;
+}
+
+template <bool FILL>
+__device__ __forceinline__ void level2_body(BinGrid gi, uint32_t R_cap, const uint32_t *__restrict__ meta,
+                                            const uint2 *__restrict__ l1list, size_t l1cap,
+                                            const uint16_t *__restrict__ rect, uint32_t *__restrict__ cnt2,
+                                            const uint32_t *__restrict__ tstart, uint64_t *__restrict__ keys,
+                                            uint32_t *__restrict__ vals) {
+  const int lane = threadIdx.x;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  const uint32_t n_win = meta[META_NWIN];
+  const int ss = 1 << gi.ss_shift, ntile = ss * ss;
+  for (uint32_t w = blockIdx.x; w < n_win; w += gridDim.x) {
+    const int sidx = (int)meta[META_WIN + w];
+    const int tx0 = (sidx % gi.stx) << gi.ss_shift, ty0 = (sidx / gi.stx) << gi.ss_shift;
+    const size_t pend = min((size_t)meta[META_START + sidx] + meta[META_LEN + sidx], l1cap);
+    // lane j owns tile j of the supertile: its count (count pass) or its next free slot (fill pass)
+    const int my_tx = tx0 + (lane & (ss - 1)), my_ty = ty0 + (lane >> gi.ss_shift);
+    const bool my_in = lane < ntile && my_tx < gi.tiles_x && my_ty < gi.tiles_y;
+    uint32_t c = 0;
+    if (FILL && my_in) c = tstart[my_ty * gi.tiles_x + my_tx] + cnt2[(size_t)w * 64 + lane];
+    for (int it = 0; it < SEG / 64; ++it) {
+      const size_t p = (size_t)w * SEG + it * 64 + lane;
+      const bool valid = p < pend;
+      uint2 en = l1list[valid ? p : 0];
+      if (!valid) en = make_uint2(0u, 0u);  // an unwritten slot may hold anything
+      const uint2 rc = *reinterpret_cast<const uint2 *>(rect + 4 * (size_t)en.x);
+      const int x0 = rc.x & 0xffff, y0 = rc.x >> 16, x1 = rc.y & 0xffff, y1 = rc.y >> 16;
+      if (__ballot(valid) == 0) break;
+      for (int j = 0; j < ntile; ++j) {
+        const int tx = tx0 + (j & (ss - 1)), ty = ty0 + (j >> gi.ss_shift);
+        if (tx >= gi.tiles_x || ty >= gi.tiles_y) continue;
+        const bool cov = valid && tx >= x0 && tx < x1 && ty >= y0 && ty < y1;
+        const unsigned long long bal = __ballot(cov);
+        if (bal == 0) continue;
+        if (FILL) {
+          const uint32_t pos = (uint32_t)__builtin_amdgcn_readlane((int)c, j) + (uint32_t)__popcll(bal & lt);
+          if (cov && pos < R_cap) {
+            keys[pos] = ((uint64_t)(uint32_t)(ty * gi.tiles_x + tx) << 32) | en.y;
+            vals[pos] = en.x;
+          }
+        }
+        c += lane == j ? (uint32_t)__popcll(bal) : 0u;
+      }
+    }
+    if (!FILL) cnt2[(size_t)w * 64 + lane] = c;
+  }
+}
+
+// one wave per supertile, lane j = tile j of it: exclusive scan of cnt2[window][j] down the supertile's windows
+// (in place), tile totals
+__device__ __forceinline__ void level2_scan_body(BinGrid gi, const uint32_t *__restrict__ meta,
+                                                 uint32_t *__restrict__ cnt2, uint32_t *__restrict__ totals) {
+  const int sidx = blockIdx.x, lane = threadIdx.x;
+  const int ss = 1 << gi.ss_shift;
+  const int tx = ((sidx % gi.stx) << gi.ss_shift) + (lane & (ss - 1));
+  const int ty = ((sidx / gi.stx) << gi.ss_shift) + (lane >> gi.ss_shift);
+  const uint32_t n_win = meta[META_NWIN];
+  const uint32_t w0 = meta[META_START + sidx] / SEG;
+  const uint32_t w1 = min(w0 + (meta[META_LEN + sidx] + SEG - 1) / SEG, n_win);
+  uint32_t run = 0;
+  for (uint32_t w = w0; w < w1; ++w) {
+    const uint32_t v = cnt2[(size_t)w * 64 + lane];
+    cnt2[(size_t)w * 64 + lane] = run;
+    run += v;
+  }
+  if (lane < ss * ss && tx < gi.tiles_x && ty < gi.tiles_y) totals[ty * gi.tiles_x + tx] = run;
+}
+
+// one workgroup: tile starts = exclusive scan of the tile totals (left in totals[]), tile ranges clamped to the
+// instance capacity, overflow flag, and the backward's work counter cleared for the blend forward behind it
+__device__ __forceinline__ void tile_starts_body(int T, uint32_t R_cap, uint32_t *__restrict__ totals,
+                                                 uint32_t *__restrict__ ranges, uint32_t *__restrict__ total,
+                                                 uint32_t *__restrict__ work_count) {
+  __shared__ uint32_t wave_tot[16];
+  __shared__ uint32_t carry_s;
+  if (threadIdx.x == 0) carry_s = 0, *work_count = 0;
+  __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (threadIdx.x == 0) diff_s = 0;
-  __syncthreads();
-  {
-    const uint32_t first = (uint32_t)keys[beg];
-    uint32_t diff = 0;
-    for (uint32_t i = threadIdx.x; i < n; i += 256) {
-      const uint32_t d = (uint32_t)keys[beg + i];
-      src[i] = ((uint64_t)d << 32) | vals[beg + i];
-      diff |= d ^ first;
+  for (int base = 0; base < T; base += 1024) {
+    const int t = base + threadIdx.x;
+    const uint32_t v = t < T ? totals[t] : 0u;
+    uint32_t inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t u = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += u;
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) diff |= __shfl_xor(diff, o, 64);
-    if (lane == 0 && diff) atomicOr(&diff_s, diff);
-  }
-  __syncthreads();
-  const uint32_t diff = diff_s;
-  const uint32_t chunk = (((n + 3) >> 2) + 63) & ~63u;  // contiguous elements per wave, a multiple of 64
-  const int nitems = (int)(chunk >> 6);                 // <= TS_ITEMS
-  const unsigned long long lt_mask = (1ull << lane) - 1ull;
-  for (int pass = 0; pass < 4; ++pass) {
-    if (((diff >> (8 * pass)) & 0xffu) == 0) continue;  // every key of the tile has the same digit
-    const int shift = 32 + 8 * pass;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) cnt[w][threadIdx.x] = 0;
+    if (lane == 63) wave_tot[wave] = inc;
     __syncthreads();
-    uint64_t k[TS_ITEMS];
-    uint32_t rank[TS_ITEMS];
-#pragma unroll
-    for (int j = 0; j < TS_ITEMS; ++j) {
-      if (j < nitems) {
-        const uint32_t idx = wave * chunk + j * 64 + lane;
-        const bool valid = idx < n;
-        k[j] = valid ? src[idx] : ~0ull;
-        const uint32_t d = digit_of(k[j], shift);
-        unsigned long long peers = __ballot(valid);
-#pragma unroll
-        for (int b = 0; b < RADIX_BITS; ++b) {
-          const unsigned long long bal = __ballot((d >> b) & 1u);
-          peers &= ((d >> b) & 1u) ? bal : ~bal;
-        }
-        const uint32_t before = (uint32_t)__popcll(peers & lt_mask);
-        uint32_t prev = 0;
-        if (valid && before == 0) {
-          prev = cnt[wave][d];
-          cnt[wave][d] = prev + (uint32_t)__popcll(peers);
-        }
-        const int leader = __ffsll((long long)peers) - 1;
-        prev = __shfl(prev, leader < 0 ? 0 : leader, 64);
-        rank[j] = prev + before;
-      }
+    uint32_t off = carry_s;
+    for (int w = 0; w < wave; ++w) off += wave_tot[w];
+    if (t < T) {
+      const uint32_t start = off + inc - v;
+      totals[t] = start;
+      // an empty tile reports (0, 0) like the published identifyTileRanges leaves it
+      ranges[2 * t] = v ? min(start, R_cap) : 0u, ranges[2 * t + 1] = v ? min(start + v, R_cap) : 0u;
+      if (start + v > R_cap) total[1] = 1;  // capacity overflow: flagged, never written out of bounds
     }
     __syncthreads();
-    {  // thread d: exclusive scan of the digit totals, then the per-wave bases of digit d
-      const uint32_t c0 = cnt[0][threadIdx.x], c1 = cnt[1][threadIdx.x], c2 = cnt[2][threadIdx.x],
-                     c3 = cnt[3][threadIdx.x];
-      const uint32_t tot = c0 + c1 + c2 + c3;
-      uint32_t inc = tot;
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t t = __shfl_up(inc, o, 64);
-        if (lane >= o) inc += t;
-      }
-      if (lane == 63) wtot[wave] = inc;
-      __syncthreads();
-      uint32_t run = inc - tot;
-      for (int w = 0; w < wave; ++w) run += wtot[w];
-      cnt[0][threadIdx.x] = run, run += c0;
-      cnt[1][threadIdx.x] = run, run += c1;
-      cnt[2][threadIdx.x] = run, run += c2;
-      cnt[3][threadIdx.x] = run;
-    }
+    if (threadIdx.x == 1023) carry_s = off + inc;
     __syncthreads();
-#pragma unroll
-    for (int j = 0; j < TS_ITEMS; ++j) {
-      if (j < nitems) {
-        const uint32_t idx = wave * chunk + j * 64 + lane;
-        if (idx < n) dst[cnt[wave][digit_of(k[j], shift)] + rank[j]] = k[j];
-      }
-    }
-    __syncthreads();
-    uint64_t *t = src;
-    src = dst, dst = t;
-  }
-  const uint64_t tbits = (uint64_t)tile << 32;
-  for (uint32_t i = threadIdx.x; i < n; i += 256) {
-    const uint64_t c = src[i];
-    keys[beg + i] = tbits | (c >> 32);
-    vals[beg + i] = (uint32_t)c;
   }
 }
 
 // ------------------------------------------------------------------------------------ kernel entry points
 // Every stage exists as a single-render kernel (the C-ABI calls) and as a batched one whose blockIdx.y selects the
-// render of a RenderBatch (the native step executor: one launch per stage for all renders of a step).
-__global__ void __launch_bounds__(1024) scan_block_sums_kernel(int nb, uint32_t *__restrict__ sums,
+// render of a RenderBatch (the native step executor: one launch per stage for all renders of a range).
+struct BinPtrs {  // byte offsets into the geometry (g_) and bin (b_) workspaces
+  size_t g_total, g_rect, g_perm, g_nkeys, g_cnt1;
+  size_t b_meta, b_l1, b_cnt2, b_totals, b_ranges, b_work, b_keys, b_vals;
+  size_t l1cap, max_windows;
+};
+
+__global__ void __launch_bounds__(1024) scan_block_sums_kernel(int nb, int N, uint32_t *__restrict__ sums,
                                                                uint32_t *__restrict__ total) {
-  scan_block_sums_body(nb, sums, total);
+  scan_block_sums_body(nb, N, sums, total);
 }
 __global__ void __launch_bounds__(PRE_BLOCK) write_offsets_kernel(int N, const uint32_t *__restrict__ tiles,
                                                                   const uint32_t *__restrict__ block_prefix,
-                                                                  uint32_t *__restrict__ offsets) {
-  write_offsets_body(N, tiles, block_prefix, offsets);
-}
-__global__ void __launch_bounds__(256) emit_keys_kernel(int N, int tiles_x, uint32_t R_cap,
-                                                        const Splat *__restrict__ splat,
-                                                        const uint16_t *__restrict__ rect,
-                                                        const uint32_t *__restrict__ offsets,
-                                                        uint32_t *__restrict__ total, uint64_t *__restrict__ keys,
-                                                        uint32_t *__restrict__ vals) {
-  emit_keys_body(N, tiles_x, R_cap, splat, rect, offsets, total, keys, vals);
+                                                                  uint32_t *__restrict__ offsets,
+                                                                  const Splat *__restrict__ splat,
+                                                                  uint64_t *__restrict__ nkeys,
+                                                                  uint32_t *__restrict__ nvals) {
+  write_offsets_body(N, tiles, block_prefix, offsets, splat, nkeys, nvals);
 }
 __global__ void __launch_bounds__(SORT_BLOCK) radix_hist_kernel(const uint64_t *__restrict__ keys,
                                                                 const uint32_t *__restrict__ total, uint32_t R_cap,
@@ -439,144 +478,183 @@ __global__ void __launch_bounds__(SORT_BLOCK) radix_scatter_kernel(
     uint32_t num_blocks, const uint32_t *__restrict__ hist) {
   radix_scatter_body(keys_in, vals_in, keys_out, vals_out, total, R_cap, shift, num_blocks, hist);
 }
-__global__ void __launch_bounds__(256) clear_ranges_kernel(int T, uint32_t *__restrict__ ranges,
-                                                           uint32_t *__restrict__ work_count) {
-  clear_ranges_body(T, ranges, work_count);
+
+// placement stages: `geom` / `bin` are the workspaces of the render (blockIdx.y picks it in the batched launches)
+template <bool FILL>
+__device__ __forceinline__ void level1_stage(int N, BinGrid gi, const BinPtrs &o, void *geom, void *bin) {
+  level1_body<FILL>(N, gi, at<uint32_t>(geom, o.g_perm), at<uint64_t>(geom, o.g_nkeys), at<uint16_t>(geom, o.g_rect),
+                    at<uint32_t>(geom, o.g_cnt1), at<uint32_t>(bin, o.b_meta), at<uint2>(bin, o.b_l1), o.l1cap);
 }
-__global__ void __launch_bounds__(256) tile_ranges_kernel(const uint64_t *__restrict__ keys,
-                                                          const uint32_t *__restrict__ total, uint32_t R_cap,
-                                                          uint32_t *__restrict__ ranges) {
-  tile_ranges_body(keys, total, R_cap, ranges);
+template <bool FILL>
+__device__ __forceinline__ void level2_stage(BinGrid gi, uint32_t R_cap, const BinPtrs &o, void *geom, void *bin) {
+  level2_body<FILL>(gi, R_cap, at<uint32_t>(bin, o.b_meta), at<uint2>(bin, o.b_l1), o.l1cap,
+                    at<uint16_t>(geom, o.g_rect), at<uint32_t>(bin, o.b_cnt2), at<uint32_t>(bin, o.b_totals),
+                    at<uint64_t>(bin, o.b_keys), at<uint32_t>(bin, o.b_vals));
 }
-__global__ void __launch_bounds__(256) tile_depth_sort_kernel(const uint32_t *__restrict__ ranges,
-                                                              uint64_t *__restrict__ keys,
-                                                              uint32_t *__restrict__ vals) {
-  tile_depth_sort_body(ranges, keys, vals);
+template <bool FILL>
+__global__ void __launch_bounds__(64) level1_kernel(int N, BinGrid gi, BinPtrs o, void *geom, void *bin) {
+  level1_stage<FILL>(N, gi, o, geom, bin);
+}
+__global__ void __launch_bounds__(L1_PARTS *MAX_SUPER) level1_scan_kernel(int nseg, int NS, BinPtrs o, void *geom, void *bin) {
+  level1_scan_body(nseg, NS, at<uint32_t>(geom, o.g_cnt1), at<uint32_t>(bin, o.b_meta), o.max_windows);
+}
+template <bool FILL>
+__global__ void __launch_bounds__(64) level2_kernel(BinGrid gi, uint32_t R_cap, BinPtrs o, void *geom, void *bin) {
+  level2_stage<FILL>(gi, R_cap, o, geom, bin);
+}
+__global__ void __launch_bounds__(64) level2_scan_kernel(BinGrid gi, BinPtrs o, void *bin) {
+  level2_scan_body(gi, at<uint32_t>(bin, o.b_meta), at<uint32_t>(bin, o.b_cnt2), at<uint32_t>(bin, o.b_totals));
+}
+__global__ void __launch_bounds__(1024) tile_starts_kernel(int T, uint32_t R_cap, BinPtrs o, void *geom, void *bin) {
+  tile_starts_body(T, R_cap, at<uint32_t>(bin, o.b_totals), at<uint32_t>(bin, o.b_ranges),
+                   at<uint32_t>(geom, o.g_total), at<uint32_t>(bin, o.b_work));
 }
 
-__global__ void __launch_bounds__(1024) scan_block_sums_batched_kernel(int nb, GeomLayout L, RenderBatch b) {
+__global__ void __launch_bounds__(1024) scan_block_sums_batched_kernel(int nb, int N, GeomLayout L, RenderBatch b) {
   void *geom = b.r[blockIdx.y].geom;
-  scan_block_sums_body(nb, at<uint32_t>(geom, L.block_sums), at<uint32_t>(geom, L.total));
+  scan_block_sums_body(nb, N, at<uint32_t>(geom, L.block_sums), at<uint32_t>(geom, L.total));
 }
 __global__ void __launch_bounds__(PRE_BLOCK) write_offsets_batched_kernel(int N, GeomLayout L, RenderBatch b) {
   void *geom = b.r[blockIdx.y].geom;
-  write_offsets_body(N, at<uint32_t>(geom, L.tiles), at<uint32_t>(geom, L.block_sums), at<uint32_t>(geom, L.offsets));
+  write_offsets_body(N, at<uint32_t>(geom, L.tiles), at<uint32_t>(geom, L.block_sums), at<uint32_t>(geom, L.offsets),
+                     at<Splat>(geom, L.splat), at<uint64_t>(geom, L.nkeys_a), at<uint32_t>(geom, L.nvals_a));
 }
-__global__ void __launch_bounds__(256) emit_keys_batched_kernel(int N, int tiles_x, uint32_t R_cap, GeomLayout L,
-                                                                size_t keys_off, size_t vals_off, RenderBatch b) {
-  const dimo_render_desc &r = b.r[blockIdx.y];
-  emit_keys_body(N, tiles_x, R_cap, at<Splat>(r.geom, L.splat), at<uint16_t>(r.geom, L.rect),
-                 at<uint32_t>(r.geom, L.offsets), at<uint32_t>(r.geom, L.total), at<uint64_t>(r.bin, keys_off),
-                 at<uint32_t>(r.bin, vals_off));
-}
-__global__ void __launch_bounds__(SORT_BLOCK) radix_hist_batched_kernel(size_t keys_off, size_t total_off,
-                                                                        uint32_t R_cap, int shift,
-                                                                        uint32_t num_blocks, size_t hist_off,
+__global__ void __launch_bounds__(SORT_BLOCK) radix_hist_batched_kernel(GeomLayout L, size_t keys_off, uint32_t cap,
+                                                                        int shift, uint32_t num_blocks,
                                                                         RenderBatch b) {
-  const dimo_render_desc &r = b.r[blockIdx.y];
-  radix_hist_body(at<uint64_t>(r.bin, keys_off), at<uint32_t>(r.geom, total_off), R_cap, shift, num_blocks,
-                  at<uint32_t>(r.bin, hist_off));
+  void *geom = b.r[blockIdx.y].geom;
+  radix_hist_body(at<uint64_t>(geom, keys_off), at<uint32_t>(geom, L.total) + 3, cap, shift, num_blocks,
+                  at<uint32_t>(geom, L.nhist));
 }
-__global__ void __launch_bounds__(256) radix_rowscan_batched_kernel(uint32_t num_blocks, size_t hist_off,
-                                                                    RenderBatch b) {
-  radix_rowscan_body(num_blocks, at<uint32_t>(b.r[blockIdx.y].bin, hist_off));
+__global__ void __launch_bounds__(256) radix_rowscan_batched_kernel(GeomLayout L, uint32_t num_blocks, RenderBatch b) {
+  radix_rowscan_body(num_blocks, at<uint32_t>(b.r[blockIdx.y].geom, L.nhist));
 }
-__global__ void __launch_bounds__(SORT_BLOCK) radix_scatter_batched_kernel(size_t kin, size_t vin, size_t kout,
-                                                                           size_t vout, size_t total_off,
-                                                                           uint32_t R_cap, int shift,
-                                                                           uint32_t num_blocks, size_t hist_off,
+__global__ void __launch_bounds__(SORT_BLOCK) radix_scatter_batched_kernel(GeomLayout L, size_t kin, size_t vin,
+                                                                           size_t kout, size_t vout, uint32_t cap,
+                                                                           int shift, uint32_t num_blocks,
                                                                            RenderBatch b) {
-  const dimo_render_desc &r = b.r[blockIdx.y];
-  radix_scatter_body(at<uint64_t>(r.bin, kin), at<uint32_t>(r.bin, vin), at<uint64_t>(r.bin, kout),
-                     at<uint32_t>(r.bin, vout), at<uint32_t>(r.geom, total_off), R_cap, shift, num_blocks,
-                     at<uint32_t>(r.bin, hist_off));
+  void *geom = b.r[blockIdx.y].geom;
+  radix_scatter_body(at<uint64_t>(geom, kin), at<uint32_t>(geom, vin), at<uint64_t>(geom, kout),
+                     at<uint32_t>(geom, vout), at<uint32_t>(geom, L.total) + 3, cap, shift, num_blocks,
+                     at<uint32_t>(geom, L.nhist));
 }
-__global__ void __launch_bounds__(256) clear_ranges_batched_kernel(int T, size_t ranges_off, size_t work_off,
-                                                                   RenderBatch b) {
+template <bool FILL>
+__global__ void __launch_bounds__(64) level1_batched_kernel(int N, BinGrid gi, BinPtrs o, RenderBatch b) {
+  level1_stage<FILL>(N, gi, o, b.r[blockIdx.y].geom, b.r[blockIdx.y].bin);
+}
+__global__ void __launch_bounds__(L1_PARTS *MAX_SUPER) level1_scan_batched_kernel(int nseg, int NS, BinPtrs o, RenderBatch b) {
+  level1_scan_body(nseg, NS, at<uint32_t>(b.r[blockIdx.y].geom, o.g_cnt1), at<uint32_t>(b.r[blockIdx.y].bin, o.b_meta),
+                   o.max_windows);
+}
+template <bool FILL>
+__global__ void __launch_bounds__(64) level2_batched_kernel(BinGrid gi, uint32_t R_cap, BinPtrs o, RenderBatch b) {
+  level2_stage<FILL>(gi, R_cap, o, b.r[blockIdx.y].geom, b.r[blockIdx.y].bin);
+}
+__global__ void __launch_bounds__(64) level2_scan_batched_kernel(BinGrid gi, BinPtrs o, RenderBatch b) {
   void *bin = b.r[blockIdx.y].bin;
-  clear_ranges_body(T, at<uint32_t>(bin, ranges_off), at<uint32_t>(bin, work_off));
+  level2_scan_body(gi, at<uint32_t>(bin, o.b_meta), at<uint32_t>(bin, o.b_cnt2), at<uint32_t>(bin, o.b_totals));
 }
-__global__ void __launch_bounds__(256) tile_ranges_batched_kernel(size_t keys_off, size_t total_off, uint32_t R_cap,
-                                                                  size_t ranges_off, RenderBatch b) {
+__global__ void __launch_bounds__(1024) tile_starts_batched_kernel(int T, uint32_t R_cap, BinPtrs o, RenderBatch b) {
   const dimo_render_desc &r = b.r[blockIdx.y];
-  tile_ranges_body(at<uint64_t>(r.bin, keys_off), at<uint32_t>(r.geom, total_off), R_cap,
-                   at<uint32_t>(r.bin, ranges_off));
-}
-__global__ void __launch_bounds__(256) tile_depth_sort_batched_kernel(size_t ranges_off, size_t keys_off,
-                                                                      size_t vals_off, RenderBatch b) {
-  void *bin = b.r[blockIdx.y].bin;
-  tile_depth_sort_body(at<uint32_t>(bin, ranges_off), at<uint64_t>(bin, keys_off), at<uint32_t>(bin, vals_off));
+  tile_starts_body(T, R_cap, at<uint32_t>(r.bin, o.b_totals), at<uint32_t>(r.bin, o.b_ranges),
+                   at<uint32_t>(r.geom, o.g_total), at<uint32_t>(r.bin, o.b_work));
 }
 
-int scan_block_sums(int nb, uint32_t *block_sums, uint32_t *total, hipStream_t stream) {
-  hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(1024), 0, stream, nb, block_sums, total);
+// ------------------------------------------------------------------------------------ host side
+constexpr int DEPTH_PASSES = 32 / RADIX_BITS;  // even: the sorted pair ends up in nkeys_a / nvals_a again
+static_assert(DEPTH_PASSES % 2 == 0, "ping-pong must end in the _a buffers");
+constexpr int L2_GRID = 2048;  // persistent waves over the level-2 windows (their number is only known on device)
+
+// supertile edge: the smallest power of two that leaves <= 64 supertiles, else <= MAX_SUPER; edge <= 8 (64 tiles
+// per supertile = one lane each at level 2)
+static bool make_grid(const BinLayout &B, BinGrid &gi) {
+  gi.tiles_x = B.tiles_x, gi.tiles_y = B.tiles_y;
+  for (int limit : {64, MAX_SUPER})
+    for (int sh = 0; sh <= 3; ++sh) {
+      const int ss = 1 << sh;
+      const int stx = (B.tiles_x + ss - 1) / ss, sty = (B.tiles_y + ss - 1) / ss;
+      if (stx * sty <= limit) {
+        gi.ss_shift = sh, gi.stx = stx, gi.sty = sty, gi.NS = stx * sty;
+        return true;
+      }
+    }
+  return false;
+}
+
+static BinPtrs make_ptrs(const GeomLayout &G, const BinLayout &B) {
+  BinPtrs o;
+  o.g_total = G.total, o.g_rect = G.rect, o.g_perm = G.nvals_a, o.g_nkeys = G.nkeys_a, o.g_cnt1 = G.cnt1;
+  o.b_meta = B.meta, o.b_l1 = B.l1list, o.b_cnt2 = B.cnt2, o.b_totals = B.totals, o.b_ranges = B.ranges;
+  o.b_work = B.work, o.b_keys = B.keys_b, o.b_vals = B.vals_b;
+  o.l1cap = B.l1cap, o.max_windows = B.max_windows;
+  return o;
+}
+
+int scan_block_sums(int nb, int N, uint32_t *block_sums, uint32_t *total, hipStream_t stream) {
+  hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(1024), 0, stream, nb, N, block_sums, total);
   return check_launch();
 }
 
-int write_offsets(int N, const uint32_t *tiles, const uint32_t *block_sums, uint32_t *offsets, hipStream_t stream) {
+int write_offsets(int N, const void *geom_c, hipStream_t stream) {
   const int nb = (N + PRE_BLOCK - 1) / PRE_BLOCK;
   if (nb == 0) return DIMO_OK;
-  hipLaunchKernelGGL(write_offsets_kernel, dim3(nb), dim3(PRE_BLOCK), 0, stream, N, tiles, block_sums, offsets);
+  GeomLayout L(N);
+  void *geom = const_cast<void *>(geom_c);
+  hipLaunchKernelGGL(write_offsets_kernel, dim3(nb), dim3(PRE_BLOCK), 0, stream, N, at<uint32_t>(geom, L.tiles),
+                     at<uint32_t>(geom, L.block_sums), at<uint32_t>(geom, L.offsets), at<Splat>(geom, L.splat),
+                     at<uint64_t>(geom, L.nkeys_a), at<uint32_t>(geom, L.nvals_a));
   return check_launch();
 }
 
-// keys_a/vals_a receive the emission and stay intact; passes ping-pong between the scratch pair
-// (keys_c/vals_c) and the sorted pair (keys_b/vals_b) so that the last pass always lands in keys_b.
-int bin_instances(int N, int H, int W, int64_t R_cap, const void *geom, void *bin, hipStream_t stream) {
+int bin_instances(int N, int H, int W, int64_t R_cap, const void *geom_c, void *bin, hipStream_t stream) {
   GeomLayout G(N);
   BinLayout B(R_cap, H, W);
+  BinGrid gi;
+  if (!make_grid(B, gi)) return DIMO_E_ARG;  // more than MAX_SUPER * 64 tiles
+  void *geom = const_cast<void *>(geom_c);  // sort scratch and the overflow flag live in the geometry workspace
   const uint32_t cap = (uint32_t)B.cap;
-  uint32_t *total = const_cast<uint32_t *>(at<uint32_t>(geom, G.total));
-  uint64_t *keys_u = at<uint64_t>(bin, B.keys_a), *keys_s = at<uint64_t>(bin, B.keys_b);
-  uint32_t *vals_u = at<uint32_t>(bin, B.vals_a), *vals_s = at<uint32_t>(bin, B.vals_b);
-  uint64_t *keys_c = at<uint64_t>(bin, B.keys_c);
-  uint32_t *vals_c = at<uint32_t>(bin, B.vals_c);
-  uint32_t *ranges = at<uint32_t>(bin, B.ranges), *hist = at<uint32_t>(bin, B.hist);
-  const int tile_bits = key_bits(B.T) - 32;  // the radix passes cover the tile id only
-  const int passes = (tile_bits + RADIX_BITS - 1) / RADIX_BITS;
-
+  const BinPtrs o = make_ptrs(G, B);
+  uint32_t *total = at<uint32_t>(geom, G.total);
   if (N > 0) {
+    ScopedTimer tm(T_SORT, stream);
+    const uint32_t nblk = (uint32_t)G.sort_blocks;
+    uint32_t *hist = at<uint32_t>(geom, G.nhist);
+    for (int p = 0; p < DEPTH_PASSES; ++p) {
+      const bool a2b = (p & 1) == 0;
+      const uint64_t *kin = at<uint64_t>(geom, a2b ? G.nkeys_a : G.nkeys_b);
+      const uint32_t *vin = at<uint32_t>(geom, a2b ? G.nvals_a : G.nvals_b);
+      uint64_t *kout = at<uint64_t>(geom, a2b ? G.nkeys_b : G.nkeys_a);
+      uint32_t *vout = at<uint32_t>(geom, a2b ? G.nvals_b : G.nvals_a);
+      hipLaunchKernelGGL(radix_hist_kernel, dim3(nblk), dim3(SORT_BLOCK), 0, stream, kin, total + 3, (uint32_t)N,
+                         p * RADIX_BITS, nblk, hist);
+      hipLaunchKernelGGL(radix_rowscan_kernel, dim3(RADIX / 4), dim3(256), 0, stream, nblk, hist);
+      hipLaunchKernelGGL(radix_scatter_kernel, dim3(nblk), dim3(SORT_BLOCK), 0, stream, kin, vin, kout, vout,
+                         total + 3, (uint32_t)N, p * RADIX_BITS, nblk, hist);
+    }
+  }
+  const int nseg = (int)G.nseg1;
+  {
     ScopedTimer tm(T_EMIT, stream);
-    hipLaunchKernelGGL(emit_keys_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, N, B.tiles_x, cap,
-                       at<Splat>(geom, G.splat), at<uint16_t>(geom, G.rect), at<uint32_t>(geom, G.offsets), total,
-                       keys_u, vals_u);
+    if (N > 0) hipLaunchKernelGGL(level1_kernel<false>, dim3(nseg), dim3(64), 0, stream, N, gi, o, geom, bin);
+    hipLaunchKernelGGL(level1_scan_kernel, dim3(1), dim3(L1_PARTS * MAX_SUPER), 0, stream, N > 0 ? nseg : 0, gi.NS, o, geom, bin);
+    if (N > 0) hipLaunchKernelGGL(level1_kernel<true>, dim3(nseg), dim3(64), 0, stream, N, gi, o, geom, bin);
   }
-  const uint32_t nblk = (uint32_t)B.sort_blocks;
-  const uint64_t *kin = keys_u;
-  const uint32_t *vin = vals_u;
-  ScopedTimer *sort_tm = new ScopedTimer(T_SORT, stream);
-  for (int p = 0; p < passes; ++p) {
-    const bool to_sorted = ((passes - 1 - p) & 1) == 0;
-    uint64_t *kout = to_sorted ? keys_s : keys_c;
-    uint32_t *vout = to_sorted ? vals_s : vals_c;
-    const int shift = 32 + p * RADIX_BITS;
-    hipLaunchKernelGGL(radix_hist_kernel, dim3(nblk), dim3(SORT_BLOCK), 0, stream, kin, total, cap, shift, nblk, hist);
-    hipLaunchKernelGGL(radix_rowscan_kernel, dim3(RADIX / 4), dim3(256), 0, stream, nblk, hist);
-    hipLaunchKernelGGL(radix_scatter_kernel, dim3(nblk), dim3(SORT_BLOCK), 0, stream, kin, vin, kout, vout, total, cap,
-                       shift, nblk, hist);
-    kin = kout, vin = vout;
-  }
-  delete sort_tm;
   {
     ScopedTimer tm(T_RANGES, stream);
-    hipLaunchKernelGGL(clear_ranges_kernel, dim3((2 * B.T + 255) / 256), dim3(256), 0, stream, B.T, ranges,
-                       at<uint32_t>(bin, B.work));
-    hipLaunchKernelGGL(tile_ranges_kernel, dim3((cap + 255) / 256), dim3(256), 0, stream, keys_s, total, cap, ranges);
+    hipLaunchKernelGGL(level2_kernel<false>, dim3(L2_GRID), dim3(64), 0, stream, gi, cap, o, geom, bin);
+    hipLaunchKernelGGL(level2_scan_kernel, dim3(gi.NS), dim3(64), 0, stream, gi, o, bin);
+    hipLaunchKernelGGL(tile_starts_kernel, dim3(1), dim3(1024), 0, stream, B.T, cap, o, geom, bin);
   }
   {
     ScopedTimer tm(T_TILE_SORT, stream);
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(tile_depth_sort_kernel),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                       (int)TS_LDS_BYTES);
-    (void)attr;
-    hipLaunchKernelGGL(tile_depth_sort_kernel, dim3(B.T), dim3(256), TS_LDS_BYTES, stream, ranges, keys_s, vals_s);
+    hipLaunchKernelGGL(level2_kernel<true>, dim3(L2_GRID), dim3(64), 0, stream, gi, cap, o, geom, bin);
   }
   return check_launch();
 }
 
 int scan_offsets_batched(int N, const GeomLayout &L, const RenderBatch &b, int n, hipStream_t stream) {
   const int nb = (N + PRE_BLOCK - 1) / PRE_BLOCK;
-  hipLaunchKernelGGL(scan_block_sums_batched_kernel, dim3(1, n), dim3(1024), 0, stream, nb, L, b);
+  hipLaunchKernelGGL(scan_block_sums_batched_kernel, dim3(1, n), dim3(1024), 0, stream, nb, N, L, b);
   if (nb > 0) hipLaunchKernelGGL(write_offsets_batched_kernel, dim3(nb, n), dim3(PRE_BLOCK), 0, stream, N, L, b);
   return check_launch();
 }
@@ -585,46 +663,42 @@ int bin_instances_batched(const dimo_step_common &c, const RenderBatch &b, int n
   if (n <= 0) return DIMO_OK;
   GeomLayout G(c.N);
   BinLayout B(c.R_cap, c.H, c.W);
-  if (c.bin_bytes < B.bytes) return DIMO_E_WORKSPACE;
+  BinGrid gi;
+  if (!make_grid(B, gi)) return DIMO_E_ARG;
+  if (c.bin_bytes < B.bytes || c.geom_bytes < G.bytes) return DIMO_E_WORKSPACE;
   const uint32_t cap = (uint32_t)B.cap;
-  const int tile_bits = key_bits(B.T) - 32;
-  const int passes = (tile_bits + RADIX_BITS - 1) / RADIX_BITS;
+  const BinPtrs o = make_ptrs(G, B);
   if (c.N > 0) {
-    ScopedTimer tm(T_EMIT, stream);
-    hipLaunchKernelGGL(emit_keys_batched_kernel, dim3((c.N + 255) / 256, n), dim3(256), 0, stream, c.N, B.tiles_x, cap,
-                       G, B.keys_a, B.vals_a, b);
-  }
-  const uint32_t nblk = (uint32_t)B.sort_blocks;
-  size_t kin = B.keys_a, vin = B.vals_a;
-  {
     ScopedTimer tm(T_SORT, stream);
-    for (int p = 0; p < passes; ++p) {
-      const bool to_sorted = ((passes - 1 - p) & 1) == 0;
-      const size_t kout = to_sorted ? B.keys_b : B.keys_c, vout = to_sorted ? B.vals_b : B.vals_c;
-      const int shift = 32 + p * RADIX_BITS;
-      hipLaunchKernelGGL(radix_hist_batched_kernel, dim3(nblk, n), dim3(SORT_BLOCK), 0, stream, kin, G.total, cap,
-                         shift, nblk, B.hist, b);
-      hipLaunchKernelGGL(radix_rowscan_batched_kernel, dim3(RADIX / 4, n), dim3(256), 0, stream, nblk, B.hist, b);
-      hipLaunchKernelGGL(radix_scatter_batched_kernel, dim3(nblk, n), dim3(SORT_BLOCK), 0, stream, kin, vin, kout,
-                         vout, G.total, cap, shift, nblk, B.hist, b);
-      kin = kout, vin = vout;
+    const uint32_t nblk = (uint32_t)G.sort_blocks;
+    for (int p = 0; p < DEPTH_PASSES; ++p) {
+      const bool a2b = (p & 1) == 0;
+      const size_t kin = a2b ? G.nkeys_a : G.nkeys_b, vin = a2b ? G.nvals_a : G.nvals_b;
+      const size_t kout = a2b ? G.nkeys_b : G.nkeys_a, vout = a2b ? G.nvals_b : G.nvals_a;
+      hipLaunchKernelGGL(radix_hist_batched_kernel, dim3(nblk, n), dim3(SORT_BLOCK), 0, stream, G, kin,
+                         (uint32_t)c.N, p * RADIX_BITS, nblk, b);
+      hipLaunchKernelGGL(radix_rowscan_batched_kernel, dim3(RADIX / 4, n), dim3(256), 0, stream, G, nblk, b);
+      hipLaunchKernelGGL(radix_scatter_batched_kernel, dim3(nblk, n), dim3(SORT_BLOCK), 0, stream, G, kin, vin, kout,
+                         vout, (uint32_t)c.N, p * RADIX_BITS, nblk, b);
     }
+  }
+  const int nseg = (int)G.nseg1;
+  {
+    ScopedTimer tm(T_EMIT, stream);
+    if (c.N > 0) hipLaunchKernelGGL(level1_batched_kernel<false>, dim3(nseg, n), dim3(64), 0, stream, c.N, gi, o, b);
+    hipLaunchKernelGGL(level1_scan_batched_kernel, dim3(1, n), dim3(L1_PARTS * MAX_SUPER), 0, stream, c.N > 0 ? nseg : 0, gi.NS,
+                       o, b);
+    if (c.N > 0) hipLaunchKernelGGL(level1_batched_kernel<true>, dim3(nseg, n), dim3(64), 0, stream, c.N, gi, o, b);
   }
   {
     ScopedTimer tm(T_RANGES, stream);
-    hipLaunchKernelGGL(clear_ranges_batched_kernel, dim3((2 * B.T + 255) / 256, n), dim3(256), 0, stream, B.T,
-                       B.ranges, B.work, b);
-    hipLaunchKernelGGL(tile_ranges_batched_kernel, dim3((cap + 255) / 256, n), dim3(256), 0, stream, B.keys_b, G.total,
-                       cap, B.ranges, b);
+    hipLaunchKernelGGL(level2_batched_kernel<false>, dim3(L2_GRID, n), dim3(64), 0, stream, gi, cap, o, b);
+    hipLaunchKernelGGL(level2_scan_batched_kernel, dim3(gi.NS, n), dim3(64), 0, stream, gi, o, b);
+    hipLaunchKernelGGL(tile_starts_batched_kernel, dim3(1, n), dim3(1024), 0, stream, B.T, cap, o, b);
   }
   {
     ScopedTimer tm(T_TILE_SORT, stream);
-    static const hipError_t attr =
-        hipFuncSetAttribute(reinterpret_cast<const void *>(tile_depth_sort_batched_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)TS_LDS_BYTES);
-    (void)attr;
-    hipLaunchKernelGGL(tile_depth_sort_batched_kernel, dim3(B.T, n), dim3(256), TS_LDS_BYTES, stream, B.ranges,
-                       B.keys_b, B.vals_b, b);
+    hipLaunchKernelGGL(level2_batched_kernel<true>, dim3(L2_GRID, n), dim3(64), 0, stream, gi, cap, o, b);
   }
   return check_launch();
 }

@@ -48,8 +48,17 @@ __host__ __device__ inline size_t align_up(size_t x, size_t a = ALIGN) { return 
 
 constexpr int PRE_BLOCK = 256;  // Gaussians per preprocess block (also the scan granule)
 
+constexpr int SORT_BLOCK = 256;
+constexpr int SORT_ITEMS = 16;
+constexpr int SORT_TILE = SORT_BLOCK * SORT_ITEMS;  // keys per sort block
+constexpr int RADIX_BITS = 8;
+constexpr int RADIX = 1 << RADIX_BITS;
+
 struct GeomLayout {
-  size_t splat, rect, tiles, offsets, flags, total, block_sums, bytes;
+  size_t splat, rect, tiles, offsets, flags, total, block_sums;
+  size_t nkeys_a, nvals_a, nkeys_b, nvals_b, nhist;  // depth sort of the Gaussians (binning.hip)
+  size_t cnt1;                                       // level-1 filter counters [segments of 256][256 supertiles]
+  size_t bytes, sort_blocks, nseg1;
   __host__ explicit GeomLayout(int N) {
     size_t n = (size_t)(N > 0 ? N : 1);
     size_t o = 0;
@@ -58,38 +67,42 @@ struct GeomLayout {
     tiles = o, o = align_up(o + n * sizeof(uint32_t));
     offsets = o, o = align_up(o + n * sizeof(uint32_t));
     flags = o, o = align_up(o + n);
-    total = o, o = align_up(o + 4 * sizeof(uint32_t));
+    total = o, o = align_up(o + 4 * sizeof(uint32_t));  // R, overflow flag, 0, N
     size_t nb = (n + PRE_BLOCK - 1) / PRE_BLOCK;
     block_sums = o, o = align_up(o + (nb + 1) * sizeof(uint32_t));
+    sort_blocks = (n + SORT_TILE - 1) / SORT_TILE;
+    nkeys_a = o, o = align_up(o + n * sizeof(uint64_t));
+    nvals_a = o, o = align_up(o + n * sizeof(uint32_t));
+    nkeys_b = o, o = align_up(o + n * sizeof(uint64_t));
+    nvals_b = o, o = align_up(o + n * sizeof(uint32_t));
+    nhist = o, o = align_up(o + ((size_t)RADIX * (sort_blocks + 1)) * sizeof(uint32_t));
+    nseg1 = (n + 255) / 256;
+    cnt1 = o, o = align_up(o + nseg1 * 256 * sizeof(uint32_t));
     bytes = o;
   }
 };
 
 constexpr int BUCKET = 64;       // list entries per backward work item
 constexpr int CKPT_FLOATS = 9;   // T, 7 accumulated features, accumulated weight
-constexpr int SORT_BLOCK = 256;
-constexpr int SORT_ITEMS = 16;
-constexpr int SORT_TILE = SORT_BLOCK * SORT_ITEMS;  // keys per sort block
-constexpr int RADIX_BITS = 8;
-constexpr int RADIX = 1 << RADIX_BITS;
-
 struct BinLayout {
-  size_t keys_a, vals_a, keys_b, vals_b, keys_c, vals_c, ranges, hist, ckpt, work, bytes;
+  size_t keys_b, vals_b, ranges, totals, meta, l1list, cnt2, ckpt, work, bytes;
   int tiles_x, tiles_y, T;
-  size_t cap, sort_blocks, ckpt_slots;
+  size_t cap, ckpt_slots, l1cap, max_windows;
   __host__ BinLayout(int64_t R_cap, int H, int W) {
     cap = (size_t)(R_cap > 0 ? R_cap : 1);
     tiles_x = (W + TILE - 1) / TILE, tiles_y = (H + TILE - 1) / TILE, T = tiles_x * tiles_y;
-    sort_blocks = (cap + SORT_TILE - 1) / SORT_TILE;
     size_t o = 0;
-    keys_a = o, o = align_up(o + cap * sizeof(uint64_t));
-    vals_a = o, o = align_up(o + cap * sizeof(uint32_t));
     keys_b = o, o = align_up(o + cap * sizeof(uint64_t));
     vals_b = o, o = align_up(o + cap * sizeof(uint32_t));
-    keys_c = o, o = align_up(o + cap * sizeof(uint64_t));
-    vals_c = o, o = align_up(o + cap * sizeof(uint32_t));
     ranges = o, o = align_up(o + (size_t)T * 2 * sizeof(uint32_t));
-    hist = o, o = align_up(o + ((size_t)RADIX * (sort_blocks + 1)) * sizeof(uint32_t));
+    totals = o, o = align_up(o + (size_t)T * sizeof(uint32_t));  // tile total, then tile start
+    // placement (binning.hip): per-supertile lists of (id, depth) -- at most one entry per instance, every list
+    // start rounded up to a 256-entry window --, per-window tile counters, and the level-1 metadata
+    l1cap = (cap + 255) / 256 * 256 + 256 * 256;
+    max_windows = l1cap / 256;
+    l1list = o, o = align_up(o + l1cap * 2 * sizeof(uint32_t));
+    cnt2 = o, o = align_up(o + max_windows * 64 * sizeof(uint32_t));
+    meta = o, o = align_up(o + (4 * 256 + max_windows) * sizeof(uint32_t));
     // blend checkpoints: per (tile, bucket of BUCKET list entries) the 256 pixels' compositing state at the
     // bucket's first entry -- slot (lo_tile / BUCKET + tile + bucket), see blend.hip; work: [0] = item count,
     // then one word (tile << 12 | bucket) per bucket some pixel of the tile reaches
@@ -176,8 +189,8 @@ int blend_forward_batched(const dimo_step_common &c, const RenderBatch &b, int n
 int blend_backward_batched(const dimo_step_common &c, const RenderBatch &b, int n, hipStream_t stream);
 
 // ---- internal (C++ linkage) entry points shared between translation units ---------------------
-int scan_block_sums(int nb, uint32_t *block_sums, uint32_t *total, hipStream_t stream);
-int write_offsets(int N, const uint32_t *tiles, const uint32_t *block_sums, uint32_t *offsets, hipStream_t stream);
+int scan_block_sums(int nb, int N, uint32_t *block_sums, uint32_t *total, hipStream_t stream);
+int write_offsets(int N, const void *geom, hipStream_t stream);
 int bin_instances(int N, int H, int W, int64_t R_cap, const void *geom, void *bin, hipStream_t stream);
 int preprocess_backward_launch(int N, int sh_degree, int M, int H, int W, int64_t R_cap, const float *means3D,
                                const float *shs, const float *colors_precomp, const float *scales,

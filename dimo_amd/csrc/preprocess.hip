@@ -591,10 +591,9 @@ extern "C" int dimo_raster_preprocess_forward(int N, int sh_degree, int M, int H
                        at<uint32_t>(geom, L.block_sums));
   }
   ScopedTimer *scan_tm = new ScopedTimer(T_SCAN, stream);
-  int rc = scan_block_sums(nb, at<uint32_t>(geom, L.block_sums), at<uint32_t>(geom, L.total), stream);
+  int rc = scan_block_sums(nb, N, at<uint32_t>(geom, L.block_sums), at<uint32_t>(geom, L.total), stream);
   if (rc) return rc;
-  rc = write_offsets(N, at<uint32_t>(geom, L.tiles), at<uint32_t>(geom, L.block_sums),
-                          at<uint32_t>(geom, L.offsets), stream);
+  rc = write_offsets(N, geom, stream);
   delete scan_tm;
   if (rc) return rc;
   if (R_host) {

@@ -165,15 +165,24 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   if (n >= g.N) return;
   const float bv = bias ? bias[n] : 0.f;
   const bool masked = g.mask && n >= g.mask_from_col;
+  // gather the ReLU mask / the old C values of all 16 rows first (unconditional loads from clamped rows): a load
+  // inside the per-row branch made the compiler wait for each one in turn -- 16 serial L2 round trips, which is why
+  // the dgrad launches took twice the time of the forward ones
+  float mk[16], old[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = min(mb + (r & 3) + 8 * (r >> 2), g.M - 1);
+    mk[r] = masked ? g.mask[(size_t)m * g.ldmask + n] : 1.0f;
+    old[r] = g.accumulate ? C[(size_t)m * g.ldc + n] : 0.0f;
+  }
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int m = mb + (r & 3) + 8 * (r >> 2);
     if (m >= g.M) continue;
     float v = acc[r] + bv;
     if (g.relu) v = fmaxf(v, 0.f);
-    if (masked && !(g.mask[(size_t)m * g.ldmask + n] > 0.f)) v = 0.f;
-    float *dst = C + (size_t)m * g.ldc + n;
-    *dst = g.accumulate ? *dst + v : v;
+    if (!(mk[r] > 0.f)) v = 0.f;
+    C[(size_t)m * g.ldc + n] = old[r] + v;
   }
 }
 

@@ -314,7 +314,7 @@ def inspect_state(ctx_tensors, N, H, W, r_cap):
     """Test helper: views of the inspectable workspace sub-buffers (see include/dimo_hip.h)."""
     L = _lib.lib()
     geom, bin_ws, img_ws = ctx_tensors
-    go, bo, io = (C.c_size_t * 6)(), (C.c_size_t * 5)(), (C.c_size_t * 2)()
+    go, bo, io = (C.c_size_t * 6)(), (C.c_size_t * 3)(), (C.c_size_t * 2)()
     L.dimo_raster_geom_layout(N, go)
     L.dimo_raster_bin_layout(r_cap, H, W, bo)
     L.dimo_raster_img_layout(H, W, io)
@@ -332,11 +332,9 @@ def inspect_state(ctx_tensors, N, H, W, r_cap):
         offsets=view(geom, go[3], n * 4, torch.int32)[:N],
         flags=view(geom, go[4], n, torch.uint8)[:N],
         total=total,
-        keys_unsorted=view(bin_ws, bo[0], r_cap * 8, torch.int64),
-        vals_unsorted=view(bin_ws, bo[1], r_cap * 4, torch.int32),
-        keys_sorted=view(bin_ws, bo[2], r_cap * 8, torch.int64),
-        vals_sorted=view(bin_ws, bo[3], r_cap * 4, torch.int32),
-        ranges=view(bin_ws, bo[4], T * 8, torch.int32).view(T, 2),
+        keys_sorted=view(bin_ws, bo[0], r_cap * 8, torch.int64),
+        vals_sorted=view(bin_ws, bo[1], r_cap * 4, torch.int32),
+        ranges=view(bin_ws, bo[2], T * 8, torch.int32).view(T, 2),
         final_T=view(img_ws, io[0], H * W * 4, torch.float32).view(H, W),
         n_contrib=view(img_ws, io[1], H * W * 4, torch.int32).view(H, W),
     )

@@ -49,8 +49,8 @@ const char *dimo_last_error(void);
  * stream it is launched on.  dimo_timing_read synchronises the device and returns the summed
  * duration and launch count of one group: "preprocess_fwd" "scan" "emit" "sort" "ranges" "blend_fwd"
  * "blend_bwd" "preprocess_bwd" "knn" "dist2" "ssim_fwd" "ssim_bwd" "deform_fwd" "deform_bwd" "image_loss" "adam"
- * "timenet_fwd" "timenet_bwd" "tile_sort" ("sort" = the radix passes over the tile bits, "tile_sort" = the per-tile
- * depth ordering).
+ * "timenet_fwd" "timenet_bwd" "place" ("sort" = depth sort of the Gaussians, "emit" = per-chunk tile counts,
+ * "ranges" = column scan + tile ranges, "place" = placement of the instances).
  * dimo_timing_enable(1) clears earlier records; returns the previous state.  dimo_timing_select restricts the
  * instrumentation to a comma-separated list of groups (NULL or "": all) -- two event records per launch are not
  * free, a throughput run that only needs one kernel's duration selects that kernel. */
@@ -61,7 +61,7 @@ int dimo_timing_read(const char *name, double *total_ms, int64_t *launches);
 /* ------------------------------------------------------------------ rasterizer workspaces
  * geom : per-Gaussian state written by preprocess (splat records, tile rects, tiles_touched,
  *        offsets, flags, block sums).  Needed by backward.
- * bin  : tile-instance state (unsorted/sorted keys and values, tile ranges, sort scratch).
+ * bin  : tile-instance state (sorted keys and values, tile ranges, placement counters, blend checkpoints).
  *        Sized for a CAPACITY R_cap >= R (number of (Gaussian, tile) instances).  Needed by backward.
  * img  : per-pixel state (final transmittance, n_contrib).  Needed by backward.
  */
@@ -74,12 +74,12 @@ size_t dimo_raster_img_bytes(int H, int W);
  *       [1] rect  uint16[N][4] = (xmin ymin xmax ymax) in tiles     [2] tiles_touched uint32[N]
  *       [3] offsets uint32[N] (inclusive scan)                      [4] flags uint8[N] (bit c = SH channel c clamped)
  *       [5] total  uint32[4]  = (R, overflow flag, 0, 0)
- * bin : [0] keys_unsorted uint64[R_cap] [1] vals_unsorted uint32[R_cap] [2] keys_sorted uint64[R_cap]
- *       [3] vals_sorted uint32[R_cap]   [4] ranges uint32[T][2]
+ * bin : [0] keys_sorted uint64[R_cap]   [1] vals_sorted uint32[R_cap]   [2] ranges uint32[T][2]
+ *       (the instances are placed straight into their sorted slots: there is no unsorted emission to look at)
  * img : [0] final_T float[H*W]          [1] n_contrib uint32[H*W]
  */
 int dimo_raster_geom_layout(int N, size_t out_offsets[6]);
-int dimo_raster_bin_layout(int64_t R_cap, int H, int W, size_t out_offsets[5]);
+int dimo_raster_bin_layout(int64_t R_cap, int H, int W, size_t out_offsets[3]);
 int dimo_raster_img_layout(int H, int W, size_t out_offsets[2]);
 
 /*
@@ -101,8 +101,9 @@ int dimo_raster_preprocess_forward(int N, int sh_degree, int M, int H, int W, co
                                    int64_t *R_host, void *stream);
 
 /*
- * Stage 2+3: key emission, stable radix sort on (tile | fp32 depth bits), tile ranges, and
- * front-to-back alpha compositing.
+ * Stage 2+3: per-tile instance lists in the order of a stable radix sort on (tile | fp32 depth bits) -- depth sort
+ * of the Gaussians, then placement of the instances by counting (dimo_amd/csrc/binning.hip) --, tile ranges, and
+ * front-to-back alpha compositing.  At most 32768 tiles.
  *   bg[3] device pointer.  out_color[3,H,W] out_depth[1,H,W] out_normal[3,H,W]|NULL out_alpha[1,H,W].
  *   out_normal == NULL selects the 4-output (diff_gaussian_rasterization) flavour.
  */
