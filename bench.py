@@ -193,14 +193,21 @@ def main():
             pol.check()
         P = args.resolution * args.resolution
         bwd_ms, bwd_n = timing["blend_bwd"]
-        alg_bytes = (28 + 4 * NFEAT) * R + (8 * (NFEAT + 1) + 8) * P + (24 + 4 * NFEAT) * V
+        # the step executor launches the blend backward once per BATCH of renders (one motion's renders in the
+        # default mode): a launch moves the algorithmic bytes of all of them
+        rpl = renders / max(bwd_n, 1)
+        alg_render = (28 + 4 * NFEAT) * R + (8 * (NFEAT + 1) + 8) * P + (24 + 4 * NFEAT) * V
+        alg_bytes = alg_render * rpl
         avg_s = (bwd_ms / max(bwd_n, 1)) * 1e-3
         achieved = alg_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_blend_bwd.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                pj = json.load(open(pmc))
+                traffic = pj.get("hbm_bytes_per_launch")
+                if traffic is not None and pj.get("renders_per_launch"):  # scale to this run's batch size
+                    traffic = traffic * rpl / pj["renders_per_launch"]
             except Exception:
                 traffic = None
         res = {
@@ -215,17 +222,18 @@ def main():
                                    f"(2 motions x 2 views x 2 frames per GPU)",
                        "renders_per_step": int(renders_total / args.steps), "parallelism": f"dp{world}",
                        "R_tile_instances": R, "V_visible": V},
-            "roofline": {"bound": "hbm", "kernel": "blend_bwd_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": alg_bytes, "avg_ms": bwd_ms / max(bwd_n, 1),
-                         "launches": bwd_n,
-                         "isolated": {"avg_ms": iso_ms / max(iso_n, 1), "launches": iso_n,
-                                      "achieved": alg_bytes / (iso_ms / max(iso_n, 1) * 1e-3) / 1e9 if iso_ms else None,
-                                      "frac": alg_bytes / (iso_ms / max(iso_n, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS
+            "roofline": {"bound": "hbm", "kernel": "blend_bwd_batched_kernel", "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": alg_bytes, "renders_per_launch": rpl,
+                         "avg_ms": bwd_ms / max(bwd_n, 1), "launches": bwd_n,
+                         "isolated": {"avg_ms": iso_ms / max(iso_n, 1), "launches": iso_n, "renders_per_launch": 1,
+                                      "achieved": alg_render / (iso_ms / max(iso_n, 1) * 1e-3) / 1e9 if iso_ms else None,
+                                      "frac": alg_render / (iso_ms / max(iso_n, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS
                                       if iso_ms else None,
-                                      "what": "same kernel with nothing else on the device (the timed region "
-                                              "overlaps several renders on separate streams)"},
-                         "note": "tile blend is FP32-VALU/LDS bound, not HBM bound (each 64-B record is reused by 256 "
+                                      "what": "single-render kernel (blend_bwd_kernel, the C-ABI path) with nothing "
+                                              "else on the device; in the timed region two batches overlap on two "
+                                              "streams"},
+                         "note": "tile blend is FP32-VALU bound, not HBM bound (each 64-B record is reused by 256 "
                                  "pixels); the HBM fraction is reported as required, see DESIGN.md"},
             "kernels_ms_per_launch": {k: (v[0] / v[1] if v[1] else None) for k, v in timing_all.items()},
             "kernels_ms_per_launch_isolated": {k: (v[0] / v[1] if v[1] else None) for k, v in timing_iso.items()},

@@ -49,7 +49,7 @@ __host__ __device__ inline size_t align_up(size_t x, size_t a = ALIGN) { return 
 constexpr int PRE_BLOCK = 256;  // Gaussians per preprocess block (also the scan granule)
 
 constexpr int SORT_BLOCK = 256;
-constexpr int SORT_ITEMS = 16;
+constexpr int SORT_ITEMS = 4;   // 1024 keys per block: the sort runs over the ~1e5 Gaussians of a frame, many small blocks fill the chip
 constexpr int SORT_TILE = SORT_BLOCK * SORT_ITEMS;  // keys per sort block
 constexpr int RADIX_BITS = 8;
 constexpr int RADIX = 1 << RADIX_BITS;

@@ -1,6 +1,6 @@
 """Summarises rocprofv3 --pmc counter CSVs (one pass per counter) into profiles/pmc_blend_bwd.json.
 
-usage: pmc_summarise.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json>
+usage: pmc_summarise.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> [renders per launch]
 FETCH_SIZE / WRITE_SIZE are in KiB (rocprofv3).  Per MI355X_MICROARCH.md (HBM section) FETCH_SIZE on gfx950 reports
 half of the bytes of a wide coalesced streaming read; the 1 GiB calibration copy in the same run measures the actual
 factor for this environment, which is then applied to the kernel of interest."""
@@ -20,6 +20,7 @@ def per_kernel(path, counter):
 
 def main():
     f, w, out = sys.argv[1:4]
+    renders_per_launch = float(sys.argv[4]) if len(sys.argv) > 4 else 4.0  # pmc_probe: one motion (4 renders) per batch
     fetch, write = per_kernel(f, "FETCH_SIZE"), per_kernel(w, "WRITE_SIZE")
     find = lambda d, pat: next((v for k, v in d.items() if pat in k), [])
     mean = lambda xs: sum(xs) / len(xs) if xs else None
@@ -32,8 +33,8 @@ def main():
     kf = (GiB_KiB / cal_f) if cal_f else 2.0
     kw = (GiB_KiB / cal_w) if cal_w else 1.0
     res["calibration"]["fetch_factor"], res["calibration"]["write_factor"] = kf, kw
-    for name, pat in (("blend_bwd", "blend_bwd_kernel"), ("blend_fwd", "blend_fwd_kernel"),
-                      ("preprocess_bwd", "preprocess_bwd_kernel"), ("radix_scatter", "radix_scatter_kernel")):
+    for name, pat in (("blend_bwd", "blend_bwd_batched_kernel"), ("blend_fwd", "blend_fwd_batched_kernel"),
+                      ("preprocess_bwd", "preprocess_bwd_batched_kernel"), ("level2_fill", "level2_batched_kernel<true>")):
         fk, wk = mean(find(fetch, pat)), mean(find(write, pat))
         if fk is None or wk is None:
             continue
@@ -41,6 +42,7 @@ def main():
                      "hbm_bytes_per_launch": (fk * kf + wk * kw) * 1024.0}
     if "blend_bwd" in res:
         res["hbm_bytes_per_launch"] = res["blend_bwd"]["hbm_bytes_per_launch"]
+        res["renders_per_launch"] = renders_per_launch
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res))
 
