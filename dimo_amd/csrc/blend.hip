@@ -306,15 +306,8 @@ __device__ __forceinline__ void blend_bwd_body(
         v[6] = w * dp[0], v[7] = w * dp[1], v[8] = w * dp[2], v[9] = w * dp[3];
         if (NORMAL) v[10] = w * dp[4], v[11] = w * dp[5], v[12] = w * dp[6];
       }
-      float red[4];
-      butterfly16(v, lane, red);
-      // lanes 60..63 hold the wave sums; lane (60 + q) owns values 8*(q&1) + 4*(q>>1) + t, t = 0..3
-      if (lane >= 60) {
-        const int q = lane & 3;
-        const int base = 8 * (q & 1) + 4 * (q >> 1);
-#pragma unroll
-        for (int t4 = 0; t4 < 4; ++t4) atomicAdd(&s_acc[j][base + t4], red[t4]);
-      }
+      const float tot = butterfly16(v, lane);  // lanes 0..15: the wave total of value butterfly16_slot(lane)
+      if (lane < 16 && butterfly16_slot(lane) < 13) atomicAdd(&s_acc[j][butterfly16_slot(lane)], tot);
     }
     __syncthreads();
     if ((int)threadIdx.x < count) {

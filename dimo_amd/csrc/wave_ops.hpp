@@ -16,14 +16,29 @@ constexpr int DPP_ROW_SHR4 = 0x114;
 constexpr int DPP_ROW_SHR8 = 0x118;
 
 
-// Wave reduction of 16 values per lane down to row sums in ~48 VALU instead of 16 x 6:
-//   step 1 (lane ^ 1): each lane keeps 8 of the 16 values and adds its partner's copy of those;
-//   step 2 (lane ^ 2): keeps 4 of the 8;   steps 3-4 (row_shr 4, 8): plain adds on the 4 survivors.
-// After step 1 slot s (0..7) of a lane with bit0 = b holds value 8b + s; after step 2 slot t (0..3) of a lane
-// with (bit1, bit0) = (c, b) holds value 8b + 4c + t.  Lanes 12..15 of every row end up with the ROW sums.
-__device__ __forceinline__ void butterfly16(const float (&v)[16], int lane, float (&out)[4]) {
-  const bool b0 = lane & 1, b1 = lane & 2;
-  float h[8];
+// Wave reduction of 16 values per lane in halving steps: at step s the lanes whose bit s differs exchange the half
+// of their values the partner is going to keep, so every step costs half of the previous one
+//   lane ^ 1 (quad_perm)  16 -> 8 values per lane      lane ^ 2 (quad_perm)  8 -> 4
+//   lane ^ 4 (row_shl/shr:4 on alternating banks) 4 -> 2    lane ^ 8 (row_ror:8)  2 -> 1
+// and the last value is folded over the four 16-lane rows with gfx950's v_permlane16_swap / v_permlane32_swap.
+// Every lane ends up with the WAVE total of value  8 b0 + 4 b1 + 2 b2 + b3  (b_i = bit i of its lane number):
+// lanes 0..15 hold the 16 totals, so ONE 16-lane conflict-free LDS add stores them.  ~60 VALU instead of the
+// 16 x 6 of a plain butterfly (a first version stopped halving after two steps and finished four values per
+// lane: 76 VALU, eight permlane swaps with their s_nop padding, four LDS adds).
+constexpr int DPP_ROW_SHL4 = 0x104;
+constexpr int DPP_ROW_ROR8 = 0x128;
+__device__ __forceinline__ float dpp_xor4(float v) {
+  const int x = __builtin_bit_cast(int, v);
+  int t = __builtin_amdgcn_update_dpp(0, x, DPP_ROW_SHL4, 0xf, 0x5, false);  // banks 0, 2 read lane + 4
+  t = __builtin_amdgcn_update_dpp(t, x, DPP_ROW_SHR4, 0xf, 0xa, false);      // banks 1, 3 read lane - 4
+  return __builtin_bit_cast(float, t);
+}
+__device__ __forceinline__ int butterfly16_slot(int lane) {
+  return 8 * (lane & 1) + 4 * ((lane >> 1) & 1) + 2 * ((lane >> 2) & 1) + ((lane >> 3) & 1);
+}
+__device__ __forceinline__ float butterfly16(const float (&v)[16], int lane) {
+  const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
+  float h[8], q[4], p[2];
 #pragma unroll
   for (int s = 0; s < 8; ++s) {
     const float keep = b0 ? v[8 + s] : v[s];
@@ -34,24 +49,21 @@ __device__ __forceinline__ void butterfly16(const float (&v)[16], int lane, floa
   for (int t = 0; t < 4; ++t) {
     const float keep = b1 ? h[4 + t] : h[t];
     const float send = b1 ? h[t] : h[4 + t];
-    float r = keep + dpp_mov<DPP_QUAD_XOR2>(send);
-    r += dpp_mov<DPP_ROW_SHR4>(r);
-    r += dpp_mov<DPP_ROW_SHR8>(r);  // lanes 12..15 of every row: row sums
-    // Fold the four rows lane-for-lane (lanes 12..15 of each row hold four DIFFERENT quantities, so row_bcast
-    // cannot be used): gfx950's v_permlane16_swap / v_permlane32_swap exchange odd/even rows and the two wave
-    // halves inside the VALU.  Finishing in registers costs ~6 VALU per value but lets ONE conflict-free 4-lane
-    // LDS add replace four 4-way-conflicting ones -- the LDS pipe, not the VALU, was this kernel's busiest unit
-    // (SQ_LDS_IDX_ACTIVE ~ 1.6x SQ_INSTS_VALU).
-    {
-      float a = r, b = r;
-      asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
-      r = a + b;  // rows (0,1) and (2,3) summed, replicated
-      a = r, b = r;
-      asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
-      r = a + b;  // all four rows
-    }
-    out[t] = r;  // valid in lanes 12..15 of every row (identical across rows)
+    q[t] = keep + dpp_mov<DPP_QUAD_XOR2>(send);
   }
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const float keep = b2 ? q[2 + u] : q[u];
+    const float send = b2 ? q[u] : q[2 + u];
+    p[u] = keep + dpp_xor4(send);
+  }
+  float r = (b3 ? p[1] : p[0]) + dpp_mov<DPP_ROW_ROR8>(b3 ? p[0] : p[1]);  // row total of this lane's value
+  float a = r, b = r;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+  r = a + b;  // rows (0,1) and (2,3) summed, replicated
+  a = r, b = r;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+  return a + b;  // all four rows
 }
 
 
