@@ -96,6 +96,19 @@ def shard(items, rank, world):
     return items[lo:hi]
 
 
+class _LazyLoss:
+    """Loss of a direct-pipeline step, kept as the device scalars the kernels produced."""
+
+    def __init__(self, loss_accum, ssim_terms):
+        self.loss_accum, self.ssim_terms = loss_accum, ssim_terms
+
+    def value(self):
+        loss = self.loss_accum[0]
+        for ssum, lam, numel in self.ssim_terms:
+            loss = loss + lam * (1 - ssum[0] / numel)
+        return loss
+
+
 class Trainer:
     def __init__(self, cfg: TrainConfig, renderer, rank=0, world_size=1, process_group=None,
                  ssim_fn: Optional[Callable] = None, knn_fn: Optional[Callable] = None, targets=None, direct=None):
@@ -118,7 +131,7 @@ class Trainer:
         self._np_rng = np.random.default_rng(cfg.seed)
         renderer.gaussians.training_setup(cfg)
         self.optimizer = renderer.gaussians.optimizer
-        self.last_loss = None
+        self._last_loss = None
         self._consts = {}
         self._deform_batch = None
         self._exec = None
@@ -139,6 +152,14 @@ class Trainer:
         if self.direct and renderer.capacity is None:
             from .rasterizer import CapacityPolicy
             renderer.capacity = CapacityPolicy(initial=max(1 << 20, 40 * cfg.num_pts))
+
+    @property
+    def last_loss(self):
+        """Loss of the last step (0-d tensor) or None."""
+        loss = self._last_loss
+        if isinstance(loss, _LazyLoss):
+            loss = self._last_loss = loss.value()
+        return loss.detach() if loss is not None else None
 
     # ------------------------------------------------------------------ pieces of train_step
     def find_knn(self, k=4):
@@ -402,10 +423,9 @@ class Trainer:
         elif mine:
             torch.autograd.backward([dxyz_all, dquat_all], [g_dxyz, g_dquat])
         self._mark("timenet_bwd")
-        loss = loss_accum[0]
-        for ssum, lam, numel in ssim_terms:
-            loss = loss + lam * (1 - ssum[0] / numel)
-        return loss
+        # the scalar loss is only read for logging: it is assembled from these parts when `last_loss` is looked at
+        # (a dozen 4-us elementwise launches per step otherwise)
+        return _LazyLoss(loss_accum, ssim_terms)
 
     def _mark(self, name):
         if self.marks is not None:
@@ -447,12 +467,15 @@ class Trainer:
             # no host sync at all: the overflow words of this step's renders become a device-side skip flag that
             # travels through the all-reduce; the host looks at them one step later (CapacityPolicy.poll)
             tot = cap.collect_async() if cap is not None else None
-            if tot is not None:
-                g.grad_flag.copy_(tot[:, 1].max().to(torch.float32))
-            else:
-                g.grad_flag.zero_()
-            self.all_reduce_grads()
-            self.optimizer.step(skip_flags=g.grad_flag.view(torch.int32), zero_grad=True)
+            if self.world > 1:  # the flag rides in the tail of the gradient bucket through the all-reduce
+                if tot is not None:
+                    g.grad_flag.copy_(tot[:, 1].max().to(torch.float32))
+                else:
+                    g.grad_flag.zero_()
+                self.all_reduce_grads()
+                self.optimizer.step(skip_flags=g.grad_flag.view(torch.int32), zero_grad=True)
+            else:  # one rank: Adam reads the renders' (R, overflow) words directly
+                self.optimizer.step(skip_flags=tot, zero_grad=True)
             self._mark("allreduce+adam")
         else:
             if cap is not None and not cap.check():  # host sync; parameters are still untouched
@@ -461,5 +484,5 @@ class Trainer:
             self.all_reduce_grads()
             self.optimizer.step()
             g.zero_grad()
-        self.last_loss = loss.detach() if loss is not None else None
+        self._last_loss = loss
         return len(mine)
