@@ -11,6 +11,10 @@
  *   dimo_dist2         simple_knn._C.distCUDA2                       renderer/latent_gs_renderer.py:17,426
  *   dimo_ssim_*        fused_ssim.fused_ssim / src.loss.ssim         main_test_dimo.py:29,979 ; src/loss.py:132-175
  *   dimo_deform_*      the LBS block of Renderer.render              renderer/latent_gs_renderer.py:1187-1219
+ *   dimo_timenet_*     TimeNet.forward / its autograd backward       renderer/latent_gs_renderer.py:184-245 ; src/pos_enc.py:6-54
+ *   dimo_image_loss    the loss assembly of GUI.train_step            main_train_dimo.py:325-380 ; src/loss.py:178-243
+ *   dimo_flat_adam_step torch.optim.Adam over the 12 groups           renderer/latent_gs_renderer.py:460-476
+ *   dimo_executor_*    the render loop of GUI.train_step (forward, mirrored backward)  main_train_dimo.py:276-318,415
  *
  * Conventions
  *   - every pointer is a DEVICE pointer unless the name ends in _host; the library never
