@@ -90,3 +90,56 @@ def test_direct_pipeline_equals_autograd_pipeline(vae):
     assert rel < 1e-4, rel
     # and a real step moves the parameters identically enough
     assert torch.isfinite(gb).all()
+
+
+def _dp_gpu_worker(rank, world, port, out):
+    import os
+    import torch.distributed as dist
+    from dimo_amd.rasterizer import CapacityPolicy
+    from dimo_amd.renderer import Renderer
+    from dimo_amd.synth import init_synthetic_model
+    from dimo_amd.trainer import TrainConfig, Trainer
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    cfg = TrainConfig(num_pts=4000, num_cpts=64, num_motions=6, num_frames=6, num_views=4, motions_per_step=2 * world,
+                      views_per_step=2, frames_per_step=1, resolution=96)
+    rd = Renderer(sh_degree=0, num_latent_code=cfg.num_motions, add_normal=True, device="cuda",
+                  capacity=CapacityPolicy(initial=1 << 18))
+    init_synthetic_model(rd, cfg.num_pts, cfg.num_cpts, seed=0, num_latent=cfg.num_motions)
+    tr = Trainer(cfg, rd, rank=rank, world_size=world)
+    assert tr.direct and tr._flat_adam
+    counts = [tr.train_step() for _ in range(3)]
+    torch.cuda.synchronize()
+    torch.save(dict(params=rd.gaussians.flat_params.cpu(), counts=counts, skipped=tr.skipped_steps,
+                    loss=float(tr.last_loss)), f"{out}/rank{rank}.pt")
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_direct_pipeline_data_parallel_two_ranks_on_one_device(tmp_path):
+    """The world > 1 code path of the HIP pipeline (flat bucket + overflow flag through the all-reduce, FlatAdam
+    with the device skip flag) with two ranks sharing cuda:0 over gloo: replicas stay identical and match the
+    single-process step on the union of the triples."""
+    import os
+    import torch.multiprocessing as mp
+    from dimo_amd.rasterizer import CapacityPolicy
+    from dimo_amd.renderer import Renderer
+    from dimo_amd.synth import init_synthetic_model
+    from dimo_amd.trainer import TrainConfig, Trainer
+    port = 23500 + (os.getpid() % 2000)
+    mp.spawn(_dp_gpu_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a, b = torch.load(f"{tmp_path}/rank0.pt"), torch.load(f"{tmp_path}/rank1.pt")
+    assert a["counts"] == [4, 4, 4] and b["counts"] == [4, 4, 4] and a["skipped"] == b["skipped"] == 0
+    assert torch.equal(a["params"], b["params"]), "replicas diverged"
+    cfg = TrainConfig(num_pts=4000, num_cpts=64, num_motions=6, num_frames=6, num_views=4, motions_per_step=4,
+                      views_per_step=2, frames_per_step=1, resolution=96)
+    rd = Renderer(sh_degree=0, num_latent_code=cfg.num_motions, add_normal=True, device="cuda",
+                  capacity=CapacityPolicy(initial=1 << 18))
+    init_synthetic_model(rd, cfg.num_pts, cfg.num_cpts, seed=0, num_latent=cfg.num_motions)
+    single = Trainer(cfg, rd)
+    for _ in range(3):
+        single.train_step()
+    p = rd.gaussians.flat_params.cpu()
+    rel = (p - a["params"]).abs().sum() / p.abs().sum()
+    assert rel < 1e-4, rel
