@@ -10,10 +10,10 @@
 //             epilogue -> ONE grouped split-K wgrad launch for every weight and bias (HW fp32 atomics straight into
 //             the flat gradient bucket) -> embedding backward (control points, latent rows).
 //
-// GEMM core: v_mfma_f32_32x32x2_f32 (exact fp32, k-ordered fma chain), 64x64 block tile, 4 waves of 32x32, K staged
-// through LDS 64 deep in [k][m] order (operand reads are then one ds_read_b32 per lane, conflict-free), register
-// prefetch of the next K stage.  The f32 MFMA issues at the vector rate (64 cycles / instruction), so the floor
-// of a 2048x256x256 layer is 128 workgroups x 3.4 us of MFMA issue; HBM and LDS traffic are far from binding.
+// GEMM core: v_mfma_f32_16x16x4_f32 (exact fp32, k-ordered fma chain), 32x64 block tile, 4 waves of 16x32, K staged
+// through LDS 64 deep in [k][m] order (operand reads are one ds_read_b32 per lane), register prefetch of the next K
+// stage.  The f32 MFMA issues at the vector rate, so the floor of a 2048x256x256 layer is 1.7 us of MFMA issue
+// with every SIMD of the chip busy; HBM and LDS traffic are far from binding, global-load latency is what remains.
 #include <hip/hip_runtime.h>
 
 #include "common.hpp"
@@ -23,36 +23,36 @@ using namespace dimo;
 
 namespace {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int BM = 64, BN = 64, BK = 64, LDT = 65;
+constexpr int BM = 32, BN = 64, BK = 64, LDT = 65;
 constexpr int MAX_LAYERS = DIMO_TIMENET_MAX_LAYERS;
 constexpr int MAX_PAIRS = DIMO_TIMENET_MAX_PAIRS;
-constexpr int STAGE = BM * BK / 256;  // operand elements per thread per K stage
 
 // ---- operand staging -------------------------------------------------------------------------------------------
-// A K stage is a 64 x 64 block of each operand, kept in LDS as S[k][m] (LDT = 65: both the transposing store of a
-// k-contiguous source and the row store of an m-contiguous one hit 64 distinct banks; the MFMA operand read
-// S[k + lane/32][m0 + lane%32] is one conflict-free ds_read_b32).  KC (k contiguous): element (r, k) at
-// src[r * ld + k]; otherwise (r contiguous) at src[k * ld + r].  Either way 64 lanes read 256 contiguous bytes.
-// Deep stages on purpose: one workgroup per CU and one wave per SIMD means nothing hides a global load except the
-// 32 MFMAs (2048 cycles) of the stage in flight -- with 16-deep stages the chain was load-latency bound (15 us per
-// 2048x256x256 layer instead of 4).
-// `vec`: 16-byte loads along the contiguous dimension (pointer 16-B aligned, ld and the contiguous extent
-// multiples of 4) -- a quarter of the load instructions, which is what bounds these GEMMs: one dword load per lane
-// moves 256 B per wave-instruction and the CU's load path (not HBM, not the MFMA pipe) was the limit.
+// A K stage is a ROWS x 64 block of an operand (ROWS = 32 output rows for A, 64 output columns for B), kept in LDS
+// as S[k][m] (LDT = 65: the transposing store of a k-contiguous source and the row store of an m-contiguous one
+// spread over the banks; the MFMA operand read S[k + lane/16][m0 + lane%16] is one ds_read_b32).  KC (k
+// contiguous): element (r, k) at src[r * ld + k]; otherwise (r contiguous) at src[k * ld + r].
+// Deep stages on purpose: with one or two workgroups per CU nothing hides a global load except the MFMAs of the
+// stage in flight -- with 16-deep stages the chain was load-latency bound.
+// VEC: 16-byte loads along the contiguous dimension (pointer 16-B aligned, ld and the contiguous extent multiples
+// of 4) -- a quarter of the load instructions.
 // Loads are UNCONDITIONAL from clamped addresses and the out-of-range lanes are zeroed when the stage is stored
 // to LDS (`ok` bit per load): a branch around each load makes the compiler drain vmcnt at every join, which
 // serialises the prefetch with the MFMAs it is supposed to hide under.
-template <bool KC, bool VEC>
+template <int ROWS, bool KC, bool VEC>
 __device__ __forceinline__ uint32_t load_stage(const float *__restrict__ src, int ld, int rows, int r0, int k0,
-                                               int kend, float (&v)[STAGE]) {
+                                               int kend, float (&v)[ROWS / 4]) {
+  constexpr int PER = ROWS / 4;  // elements per thread
   uint32_t ok = 0;
   if (VEC) {
-    const int q = (threadIdx.x & 15) * 4, h = threadIdx.x >> 4;
+    constexpr int NQ = KC ? 16 : ROWS / 4;  // quads along the contiguous dimension
+    constexpr int STEP = 256 / NQ;          // threads stacked along the other one
+    const int q = (threadIdx.x % NQ) * 4, h = threadIdx.x / NQ;
 #pragma unroll
-    for (int e = 0; e < STAGE / 4; ++e) {
-      const int r = r0 + (KC ? h + 16 * e : q), k = k0 + (KC ? q : h + 16 * e);
+    for (int e = 0; e < PER / 4; ++e) {
+      const int r = r0 + (KC ? h + STEP * e : q), k = k0 + (KC ? q : h + STEP * e);
       ok |= (uint32_t)(r < rows && k < kend) << e;
       const int rc = min(r, rows - (KC ? 1 : 4)), kc = min(k, kend - (KC ? 4 : 1));
       const float4 x = *reinterpret_cast<const float4 *>(src + (KC ? (size_t)rc * ld + kc : (size_t)kc * ld + rc));
@@ -60,73 +60,89 @@ __device__ __forceinline__ uint32_t load_stage(const float *__restrict__ src, in
     }
     return ok;
   }
-  const int lo = threadIdx.x & 63, hi = threadIdx.x >> 6;
+  constexpr int NL = KC ? 64 : ROWS;  // lanes along the contiguous dimension
+  constexpr int STEP = 256 / NL;
+  const int lo = threadIdx.x % NL, hi = threadIdx.x / NL;
 #pragma unroll
-  for (int e = 0; e < STAGE; ++e) {
-    const int r = r0 + (KC ? hi + 4 * e : lo), k = k0 + (KC ? lo : hi + 4 * e);
+  for (int e = 0; e < PER; ++e) {
+    const int r = r0 + (KC ? hi + STEP * e : lo), k = k0 + (KC ? lo : hi + STEP * e);
     ok |= (uint32_t)(r < rows && k < kend) << e;
     const int rc = min(r, rows - 1), kc = min(k, kend - 1);
     v[e] = src[KC ? (size_t)rc * ld + kc : (size_t)kc * ld + rc];
   }
   return ok;
 }
-template <bool KC, bool VEC>
-__device__ __forceinline__ void store_stage(float (*S)[LDT], uint32_t ok, const float (&v)[STAGE]) {
-  if (VEC) {  // banks (k + m) % 64: 16 quads x 4 rows of a wave cover all 64 for each j
-    const int q = (threadIdx.x & 15) * 4, h = threadIdx.x >> 4;
+template <int ROWS, bool KC, bool VEC>
+__device__ __forceinline__ void store_stage(float (*S)[LDT], uint32_t ok, const float (&v)[ROWS / 4]) {
+  constexpr int PER = ROWS / 4;
+  if (VEC) {
+    constexpr int NQ = KC ? 16 : ROWS / 4;
+    constexpr int STEP = 256 / NQ;
+    const int q = (threadIdx.x % NQ) * 4, h = threadIdx.x / NQ;
 #pragma unroll
-    for (int e = 0; e < STAGE / 4; ++e)
+    for (int e = 0; e < PER / 4; ++e)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float x = ((ok >> e) & 1u) ? v[4 * e + j] : 0.f;
         if (KC)
-          S[q + j][h + 16 * e] = x;
+          S[q + j][h + STEP * e] = x;
         else
-          S[h + 16 * e][q + j] = x;
+          S[h + STEP * e][q + j] = x;
       }
     return;
   }
-  const int lo = threadIdx.x & 63, hi = threadIdx.x >> 6;
+  constexpr int NL = KC ? 64 : ROWS;
+  constexpr int STEP = 256 / NL;
+  const int lo = threadIdx.x % NL, hi = threadIdx.x / NL;
 #pragma unroll
-  for (int e = 0; e < STAGE; ++e) {
+  for (int e = 0; e < PER; ++e) {
     const float x = ((ok >> e) & 1u) ? v[e] : 0.f;
     if (KC)
-      S[lo][hi + 4 * e] = x;
+      S[lo][hi + STEP * e] = x;
     else
-      S[hi + 4 * e][lo] = x;
+      S[hi + STEP * e][lo] = x;
   }
 }
 
-// acc (32x32 per wave) += A[m0.., kbeg..kend) * B[kbeg..kend), n0..); bias_sum += this thread's share of the column
-// sums of A (column threadIdx % 64, k rows (threadIdx / 64) * 16 .. + 16 of every stage)
+// Workgroup tile 32 x 64, wave tile 16 x 32 = two v_mfma_f32_16x16x4_f32 accumulators: 2048 x 256 outputs are 256
+// workgroups x 4 waves = one wave per SIMD of the whole chip (64 x 64 tiles of 32x32x2 MFMAs filled half of it and
+// took twice as long per layer).
+struct Acc {
+  f32x4 c0, c1;  // columns wn .. wn+15 and wn+16 .. wn+31; lane l, reg r: row 4 (l / 16) + r, column l % 16
+};
+
+// acc += A[m0.., kbeg..kend) * B[kbeg..kend), n0..); bias_sum += this thread's share of the column sums of A
+// (column threadIdx % 32, k rows (threadIdx / 32) * 8 .. + 8 of every stage)
 template <bool A_KC, bool B_KC, bool BIAS_SUM, bool VEC>
 __device__ __forceinline__ void gemm_segment(const float *__restrict__ A, int lda, const float *__restrict__ B,
                                              int ldb, int M, int N, int m0, int n0, int kbeg, int kend,
-                                             float (*As)[LDT], float (*Bs)[LDT], f32x16 &acc, float &bias_sum) {
+                                             float (*As)[LDT], float (*Bs)[LDT], Acc &acc, float &bias_sum) {
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+  const int wm = (wave >> 1) * 16, wn = (wave & 1) * 32;
   const int nk = (kend - kbeg + BK - 1) / BK;
-  float ra[STAGE], rb[STAGE];
-  uint32_t oka = load_stage<A_KC, VEC>(A, lda, M, m0, kbeg, kend, ra);
-  uint32_t okb = load_stage<B_KC, VEC>(B, ldb, N, n0, kbeg, kend, rb);
+  float ra[BM / 4], rb[BN / 4];
+  uint32_t oka = load_stage<BM, A_KC, VEC>(A, lda, M, m0, kbeg, kend, ra);
+  uint32_t okb = load_stage<BN, B_KC, VEC>(B, ldb, N, n0, kbeg, kend, rb);
   for (int it = 0; it < nk; ++it) {
     __syncthreads();  // the previous stage (or segment) has been consumed
-    store_stage<A_KC, VEC>(As, oka, ra);
-    store_stage<B_KC, VEC>(Bs, okb, rb);
+    store_stage<BM, A_KC, VEC>(As, oka, ra);
+    store_stage<BN, B_KC, VEC>(Bs, okb, rb);
     __syncthreads();
     if (it + 1 < nk) {  // in flight under this stage's MFMAs
-      oka = load_stage<A_KC, VEC>(A, lda, M, m0, kbeg + (it + 1) * BK, kend, ra);
-      okb = load_stage<B_KC, VEC>(B, ldb, N, n0, kbeg + (it + 1) * BK, kend, rb);
+      oka = load_stage<BM, A_KC, VEC>(A, lda, M, m0, kbeg + (it + 1) * BK, kend, ra);
+      okb = load_stage<BN, B_KC, VEC>(B, ldb, N, n0, kbeg + (it + 1) * BK, kend, rb);
     }
-#pragma unroll 8
-    for (int kk = 0; kk < BK; kk += 2) {
-      const float a = As[kk + (lane >> 5)][wm + (lane & 31)];
-      const float b = Bs[kk + (lane >> 5)][wn + (lane & 31)];
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+#pragma unroll 4
+    for (int kk = 0; kk < BK; kk += 4) {
+      const float a = As[kk + (lane >> 4)][wm + (lane & 15)];
+      const float b0 = Bs[kk + (lane >> 4)][wn + (lane & 15)];
+      const float b1 = Bs[kk + (lane >> 4)][wn + 16 + (lane & 15)];
+      acc.c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b0, acc.c0, 0, 0, 0);
+      acc.c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b1, acc.c1, 0, 0, 0);
     }
     if (BIAS_SUM) {
 #pragma unroll
-      for (int kk = 0; kk < 16; ++kk) bias_sum += As[wave * 16 + kk][lane];
+      for (int kk = 0; kk < 8; ++kk) bias_sum += As[(t >> 5) * 8 + kk][t & 31];
     }
   }
 }
@@ -150,9 +166,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   __shared__ float As[BK][LDT], Bs[BK][LDT];
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
   const bool alt = blockIdx.z == 1;
-  f32x16 acc;
+  Acc acc;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  for (int i = 0; i < 4; ++i) acc.c0[i] = 0.f, acc.c1[i] = 0.f;
   float unused = 0.f;
   for (int s = 0; s < g.nseg; ++s)
     gemm_segment<A_KC, B_KC, false, VEC>(g.A[s], g.lda[s], (alt && s == 0) ? g.B_alt : g.B[s], g.ldb[s], g.M, g.N,
@@ -160,29 +176,37 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   const float *bias = alt ? g.bias_alt : g.bias;
   float *C = alt ? g.C_alt : g.C;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int n = n0 + (wave & 1) * 32 + (lane & 31);
-  const int mb = m0 + (wave >> 1) * 32 + 4 * (lane >> 5);
-  if (n >= g.N) return;
-  const float bv = bias ? bias[n] : 0.f;
-  const bool masked = g.mask && n >= g.mask_from_col;
-  // gather the ReLU mask / the old C values of all 16 rows first (unconditional loads from clamped rows): a load
-  // inside the per-row branch made the compiler wait for each one in turn -- 16 serial L2 round trips, which is why
-  // the dgrad launches took twice the time of the forward ones
-  float mk[16], old[16];
+  const int mb = m0 + (wave >> 1) * 16 + 4 * (lane >> 4);
+  // gather the ReLU mask / the old C values first (unconditional loads from clamped positions): a load inside the
+  // per-element branch made the compiler wait for each one in turn -- serial L2 round trips that doubled the time
+  // of the dgrad launches
+  float mk[8], old[8], bv[2];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int m = min(mb + (r & 3) + 8 * (r >> 2), g.M - 1);
-    mk[r] = masked ? g.mask[(size_t)m * g.ldmask + n] : 1.0f;
-    old[r] = g.accumulate ? C[(size_t)m * g.ldc + n] : 0.0f;
+  for (int h = 0; h < 2; ++h) {
+    const int n = n0 + (wave & 1) * 32 + 16 * h + (lane & 15);
+    const int nc = min(n, g.N - 1);
+    bv[h] = bias ? bias[nc] : 0.f;
+    const bool masked = g.mask && n >= g.mask_from_col;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = min(mb + r, g.M - 1);
+      mk[4 * h + r] = masked ? g.mask[(size_t)m * g.ldmask + nc] : 1.0f;
+      old[4 * h + r] = g.accumulate ? C[(size_t)m * g.ldc + nc] : 0.0f;
+    }
   }
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int m = mb + (r & 3) + 8 * (r >> 2);
-    if (m >= g.M) continue;
-    float v = acc[r] + bv;
-    if (g.relu) v = fmaxf(v, 0.f);
-    if (!(mk[r] > 0.f)) v = 0.f;
-    C[(size_t)m * g.ldc + n] = old[r] + v;
+  for (int h = 0; h < 2; ++h) {
+    const int n = n0 + (wave & 1) * 32 + 16 * h + (lane & 15);
+    if (n >= g.N) continue;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = mb + r;
+      if (m >= g.M) continue;
+      float v = (h ? acc.c1[r] : acc.c0[r]) + bv[h];
+      if (g.relu) v = fmaxf(v, 0.f);
+      if (!(mk[4 * h + r] > 0.f)) v = 0.f;
+      C[(size_t)m * g.ldc + n] = old[4 * h + r] + v;
+    }
   }
 }
 
@@ -208,9 +232,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs g) {
   const int m0 = tm * BM, n0 = tn * BN;
   const int kbeg = blockIdx.y * g.kchunk, kend = min(g.rows, kbeg + g.kchunk);
   if (kbeg >= kend) return;
-  f32x16 acc;
+  Acc acc;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  for (int i = 0; i < 4; ++i) acc.c0[i] = 0.f, acc.c1[i] = 0.f;
   float bsum = 0.f;
   if (p.vec) {
     if (tn == 0)
@@ -221,14 +245,15 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs g) {
     gemm_segment<false, false, true, false>(p.dZ, p.ld_dz, p.X, p.ld_x, p.M, p.N, m0, n0, kbeg, kend, As, Bs, acc, bsum);
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (tn == 0 && p.gbias && m0 + lane < p.M) unsafeAtomicAdd(p.gbias + m0 + lane, bsum);
-  const int n = n0 + (wave & 1) * 32 + (lane & 31);
-  const int mb = m0 + (wave >> 1) * 32 + 4 * (lane >> 5);
-  if (n >= p.N) return;
+  if (tn == 0 && p.gbias && m0 + (int)(threadIdx.x & 31) < p.M) unsafeAtomicAdd(p.gbias + m0 + (threadIdx.x & 31), bsum);
+  const int mb = m0 + (wave >> 1) * 16 + 4 * (lane >> 4);
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int m = mb + (r & 3) + 8 * (r >> 2);
-    if (m < p.M) unsafeAtomicAdd(p.gW + (size_t)m * p.ld_w + n, acc[r]);
+  for (int h = 0; h < 2; ++h) {
+    const int n = n0 + (wave & 1) * 32 + 16 * h + (lane & 15);
+    if (n >= p.N) continue;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (mb + r < p.M) unsafeAtomicAdd(p.gW + (size_t)(mb + r) * p.ld_w + n, h ? acc.c1[r] : acc.c0[r]);
   }
 }
 
