@@ -237,47 +237,86 @@ __device__ __forceinline__ void level1_body(int N, BinGrid gi, const uint32_t *_
                                             const uint64_t *__restrict__ nkeys, const uint16_t *__restrict__ rect,
                                             uint32_t *__restrict__ cnt1, const uint32_t *__restrict__ meta,
                                             uint2 *__restrict__ l1list, size_t l1cap) {
+  // per supertile: the segment's count so far (count pass) or its next free slot (fill pass); one wave per block
+  __shared__ uint32_t s_cnt[MAX_SUPER];
   const int seg = blockIdx.x, lane = threadIdx.x;
   const unsigned long long lt = (1ull << lane) - 1ull;
   uint32_t *row = cnt1 + (size_t)seg * MAX_SUPER;
-  uint32_t c[MAX_SUPER / 64];
 #pragma unroll
   for (int q = 0; q < MAX_SUPER / 64; ++q) {
     const int sidx = q * 64 + lane;
-    c[q] = (FILL && sidx < gi.NS) ? meta[META_START + sidx] + row[sidx] : 0u;
+    s_cnt[sidx] = (FILL && sidx < gi.NS) ? meta[META_START + sidx] + row[sidx] : 0u;
   }
+  int nbits = 0;
+  while ((1 << nbits) < gi.NS) ++nbits;
+  // all loads of the segment first (id -> rectangle is a dependent gather: four of them in flight, not in turn)
+  uint32_t g_[SEG / 64], d_[SEG / 64];
+  uint2 rc_[SEG / 64];
+#pragma unroll
   for (int it = 0; it < SEG / 64; ++it) {
-    const int k = seg * SEG + it * 64 + lane;
-    const bool valid = k < N;
-    const uint32_t g = perm[valid ? k : N - 1];
-    const uint2 rc = *reinterpret_cast<const uint2 *>(rect + 4 * (size_t)g);
+    const int k = min(seg * SEG + it * 64 + lane, N - 1);
+    g_[it] = perm[k];
+    d_[it] = FILL ? (uint32_t)nkeys[k] : 0u;
+  }
+#pragma unroll
+  for (int it = 0; it < SEG / 64; ++it) rc_[it] = *reinterpret_cast<const uint2 *>(rect + 4 * (size_t)g_[it]);
+#pragma unroll
+  for (int it = 0; it < SEG / 64; ++it) {
+    const bool valid = seg * SEG + it * 64 + lane < N;
+    const uint32_t g = g_[it], dbits = d_[it];
+    const uint2 rc = rc_[it];
     const int x0 = rc.x & 0xffff, y0 = rc.x >> 16, x1 = rc.y & 0xffff, y1 = rc.y >> 16;
     const bool some = valid && x1 > x0 && y1 > y0;
     const int sx0 = x0 >> gi.ss_shift, sx1 = (x1 - 1) >> gi.ss_shift;
     const int sy0 = y0 >> gi.ss_shift, sy1 = (y1 - 1) >> gi.ss_shift;
-    const uint32_t dbits = FILL ? (uint32_t)nkeys[valid ? k : N - 1] : 0u;
     if (__ballot(some) == 0) continue;
-    int sx = 0, sy = 0;  // supertile (sx, sy) of index q * 64 + sl, advanced incrementally (wave-uniform)
-#pragma unroll
-    for (int q = 0; q < MAX_SUPER / 64; ++q) {
-      if (q * 64 >= gi.NS) break;
-      for (int sl = 0; sl < 64 && q * 64 + sl < gi.NS; ++sl) {
-        const bool cov = some && sx >= sx0 && sx <= sx1 && sy >= sy0 && sy <= sy1;
-        const unsigned long long bal = __ballot(cov);
-        if (++sx == gi.stx) sx = 0, ++sy;
-        if (bal == 0) continue;
-        if (FILL) {
-          const uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)c[q], sl);
-          const size_t pos = (size_t)off + (uint32_t)__popcll(bal & lt);
-          if (cov && pos < l1cap) l1list[pos] = make_uint2(g, dbits);
+    if (__ballot(some && (sx1 - sx0 >= 2 || sy1 - sy0 >= 2)) == 0) {
+      // Fast path (every rectangle spans at most 2 x 2 supertiles): a Gaussian then has at most ONE supertile of
+      // each (column parity, row parity) class, and a supertile belongs to one class -- so four rounds, in each of
+      // which the lanes naming the same supertile are grouped by ballots over the id bits and ranked by lane, keep
+      // the list order per supertile.  ~50 instructions per round instead of one ballot per supertile (64+).
+      for (int cls = 0; cls < 4; ++cls) {
+        const int sx = sx0 + (((cls & 1) ^ sx0) & 1), sy = sy0 + (((cls >> 1) ^ sy0) & 1);
+        const bool has = some && sx <= sx1 && sy <= sy1;
+        const int sidx = has ? sy * gi.stx + sx : 0;
+        unsigned long long peers = __ballot(has);
+        if (peers == 0) continue;
+        for (int bit = 0; bit < nbits; ++bit) {
+          const unsigned long long bal = __ballot((sidx >> bit) & 1);
+          peers &= ((sidx >> bit) & 1) ? bal : ~bal;
         }
-        c[q] += lane == sl ? (uint32_t)__popcll(bal) : 0u;
+        const int leader = has ? __ffsll((long long)peers) - 1 : lane;
+        uint32_t base = 0;
+        if (has && lane == leader) {
+          base = s_cnt[sidx];
+          s_cnt[sidx] = base + (uint32_t)__popcll(peers);
+        }
+        if (FILL) {
+          base = (uint32_t)__shfl((int)base, leader, 64);
+          const size_t pos = (size_t)base + (uint32_t)__popcll(peers & lt);
+          if (has && pos < l1cap) l1list[pos] = make_uint2(g, dbits);
+        }
       }
+      continue;
+    }
+    // general path: some rectangle of this group is larger -- one ballot per supertile
+    int sx = 0, sy = 0;
+    for (int sidx = 0; sidx < gi.NS; ++sidx) {
+      const bool cov = some && sx >= sx0 && sx <= sx1 && sy >= sy0 && sy <= sy1;
+      const unsigned long long bal = __ballot(cov);
+      if (++sx == gi.stx) sx = 0, ++sy;
+      if (bal == 0) continue;
+      const uint32_t base = s_cnt[sidx];
+      if (FILL) {
+        const size_t pos = (size_t)base + (uint32_t)__popcll(bal & lt);
+        if (cov && pos < l1cap) l1list[pos] = make_uint2(g, dbits);
+      }
+      if (lane == 0) s_cnt[sidx] = base + (uint32_t)__popcll(bal);
     }
   }
   if (!FILL) {
 #pragma unroll
-    for (int q = 0; q < MAX_SUPER / 64; ++q) row[q * 64 + lane] = c[q];
+    for (int q = 0; q < MAX_SUPER / 64; ++q) row[q * 64 + lane] = s_cnt[q * 64 + lane];
   }
 }
 
@@ -358,12 +397,20 @@ __device__ __forceinline__ void level2_body(BinGrid gi, uint32_t R_cap, const ui
     const bool my_in = lane < ntile && my_tx < gi.tiles_x && my_ty < gi.tiles_y;
     uint32_t c = 0;
     if (FILL && my_in) c = tstart[my_ty * gi.tiles_x + my_tx] + cnt2[(size_t)w * 64 + lane];
+    uint2 en_[SEG / 64], rc_[SEG / 64];
+#pragma unroll
+    for (int it = 0; it < SEG / 64; ++it) {
+      const size_t p = (size_t)w * SEG + it * 64 + lane;
+      en_[it] = l1list[p < pend ? p : 0];
+      if (!(p < pend)) en_[it] = make_uint2(0u, 0u);  // an unwritten slot may hold anything
+    }
+#pragma unroll
+    for (int it = 0; it < SEG / 64; ++it) rc_[it] = *reinterpret_cast<const uint2 *>(rect + 4 * (size_t)en_[it].x);
+#pragma unroll
     for (int it = 0; it < SEG / 64; ++it) {
       const size_t p = (size_t)w * SEG + it * 64 + lane;
       const bool valid = p < pend;
-      uint2 en = l1list[valid ? p : 0];
-      if (!valid) en = make_uint2(0u, 0u);  // an unwritten slot may hold anything
-      const uint2 rc = *reinterpret_cast<const uint2 *>(rect + 4 * (size_t)en.x);
+      const uint2 en = en_[it], rc = rc_[it];
       const int x0 = rc.x & 0xffff, y0 = rc.x >> 16, x1 = rc.y & 0xffff, y1 = rc.y >> 16;
       if (__ballot(valid) == 0) break;
       for (int j = 0; j < ntile; ++j) {
