@@ -1,0 +1,163 @@
+"""Densification, pruning and optimizer surgery of the canonical Gaussians -- the reference's
+`GaussianModel.densify_and_prune / densify_and_clone / densify_and_split / prune / prune_points / reset_opacity /
+add_densification_stats` (renderer/latent_gs_renderer.py:571-574,652-924), with the same semantics including their
+quirks (documented where they matter), on the flat parameter bucket.
+
+MI355X-first difference.  The reference rebuilds six `nn.Parameter`s and their Adam state tensor by tensor, three
+times per `densify_and_prune` (clone, split, prune).  Here every operation only edits a small *plan* -- for each
+surviving row of the new model the old row it comes from, whether its Adam moments start at zero, and the few
+values that are overwritten -- and the flat parameter / gradient / moment buckets are rebuilt ONCE at the end by
+gathers (`GaussianModel.rebuild`).  The Adam step counter carries over, as `cat_tensors_to_optimizer` keeps it.
+
+Replica consistency: the only random draw (`densify_and_split`) uses the global torch generator of the model's
+device, exactly like the reference's `torch.normal`; data-parallel ranks seed it identically (`Trainer`).
+"""
+import torch
+
+from .deform import build_rotation
+
+PER_GAUSSIAN = ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation")
+
+
+class _Plan:
+    """Rows of the model being built: `src` = source row in the CURRENT model, `fresh` = Adam moments start at
+    zero, `values` = name -> tensor [rows, ...] of the parameter values (gathered lazily)."""
+
+    def __init__(self, model):
+        self.m = model
+        n = model._xyz.shape[0]
+        dev = model._xyz.device
+        self.src = torch.arange(n, device=dev)
+        self.fresh = torch.zeros(n, dtype=torch.bool, device=dev)
+        self.values = {k: p.detach() for k, p in model.per_gaussian().items()}
+
+    @property
+    def n(self):
+        return self.src.shape[0]
+
+    def append(self, src_rows, new_values):
+        """Appends rows copied from the plan's rows `src_rows` (moments zero) with the given values."""
+        self.src = torch.cat([self.src, self.src[src_rows]])
+        self.fresh = torch.cat([self.fresh, torch.ones(src_rows.shape[0], dtype=torch.bool, device=self.src.device)])
+        for k in self.values:
+            self.values[k] = torch.cat([self.values[k], new_values[k]], dim=0)
+
+    def keep(self, mask):
+        self.src, self.fresh = self.src[mask], self.fresh[mask]
+        for k in self.values:
+            self.values[k] = self.values[k][mask]
+
+    def scaling_act(self):
+        return torch.exp(self.values["scaling"])
+
+    def opacity_act(self):
+        return torch.sigmoid(self.values["opacity"])
+
+
+class DensifyMixin:
+    """Mixed into `GaussianModel`."""
+
+    # ------------------------------------------------------------------ statistics
+    def add_densification_stats(self, viewspace_point_tensor, update_filter):
+        """latent_gs_renderer.py:922-924.  `viewspace_point_tensor`: a tensor with `.grad` [N, 3] (the autograd
+        path) or the gradient tensor itself (the direct pipeline's `g_means2D`)."""
+        g = getattr(viewspace_point_tensor, "grad", None)
+        if g is None:
+            g = viewspace_point_tensor
+        self.xyz_gradient_accum[update_filter] += torch.norm(g[update_filter, :2], dim=-1, keepdim=True)
+        self.denom[update_filter] += 1
+
+    def update_max_radii(self, radii, visibility_filter):
+        """main_train_dimo.py:431."""
+        self.max_radii2D[visibility_filter] = torch.max(self.max_radii2D[visibility_filter],
+                                                        radii[visibility_filter].to(self.max_radii2D.dtype))
+
+    # ------------------------------------------------------------------ plan steps (no parameter is touched)
+    def _plan_clone(self, plan, grads, grad_threshold, scene_extent):
+        """latent_gs_renderer.py:856-874."""
+        sel = torch.norm(grads, dim=-1) >= grad_threshold
+        sel = torch.logical_and(sel, torch.max(plan.scaling_act(), dim=1).values <= self.percent_dense * scene_extent)
+        rows = sel.nonzero(as_tuple=True)[0]
+        plan.append(rows, {k: v[rows] for k, v in plan.values.items()})
+
+    def _plan_split(self, plan, grads, grad_threshold, scene_extent, N=2):
+        """latent_gs_renderer.py:826-854 (grads are those of BEFORE the clone, zero-padded for the clones)."""
+        n_init = plan.n
+        padded = torch.zeros(n_init, device=grads.device)
+        padded[:grads.shape[0]] = grads.squeeze()
+        sel = padded >= grad_threshold
+        sel = torch.logical_and(sel, torch.max(plan.scaling_act(), dim=1).values > self.percent_dense * scene_extent)
+        rows = sel.nonzero(as_tuple=True)[0]
+        sc = plan.scaling_act()[rows]
+        stds = sc.repeat(N, 1)
+        means = torch.zeros((stds.size(0), 3), device=stds.device)
+        samples = torch.normal(mean=means, std=stds)
+        rots = build_rotation(plan.values["rotation"][rows]).repeat(N, 1, 1)
+        new = {
+            "xyz": torch.bmm(rots, samples.unsqueeze(-1)).squeeze(-1) + plan.values["xyz"][rows].repeat(N, 1),
+            "scaling": torch.log(sc.repeat(N, 1) / (0.8 * N)),
+            "rotation": plan.values["rotation"][rows].repeat(N, 1),
+            "f_dc": plan.values["f_dc"][rows].repeat(N, 1, 1),
+            "f_rest": plan.values["f_rest"][rows].repeat(N, 1, 1),
+            "opacity": plan.values["opacity"][rows].repeat(N, 1),
+        }
+        plan.append(rows.repeat(N), new)
+        keep = torch.cat([~sel, torch.ones(N * rows.shape[0], dtype=torch.bool, device=sel.device)])
+        plan.keep(keep)
+
+    def _plan_prune(self, plan, min_opacity, extent, max_screen_size, max_radii2D):
+        """latent_gs_renderer.py:883-889 / 892-900."""
+        mask = (plan.opacity_act() < min_opacity).squeeze(-1)
+        if max_screen_size:
+            big_vs = max_radii2D > max_screen_size
+            big_ws = plan.scaling_act().max(dim=1).values > 0.1 * extent
+            mask = torch.logical_or(torch.logical_or(mask, big_vs), big_ws)
+        plan.keep(~mask)
+        return mask
+
+    # ------------------------------------------------------------------ the reference's entry points
+    @torch.no_grad()
+    def densify_and_prune(self, max_grad, min_opacity, extent, max_screen_size):
+        """latent_gs_renderer.py:876-890.  Quirk kept: `densification_postfix` zeroes `max_radii2D` (and the
+        gradient statistics) when the clones are appended, so the screen-size criterion of the final prune never
+        fires here -- only the opacity and world-size criteria do."""
+        grads = self.xyz_gradient_accum / self.denom
+        grads[grads.isnan()] = 0.0
+        plan = _Plan(self)
+        self._plan_clone(plan, grads, max_grad, extent)
+        self._plan_split(plan, grads, max_grad, extent)
+        self._plan_prune(plan, min_opacity, extent, max_screen_size, torch.zeros(plan.n, device=plan.src.device))
+        self.rebuild(plan)
+        n = self._xyz.shape[0]
+        self.xyz_gradient_accum = torch.zeros((n, 1), device=self.device)
+        self.denom = torch.zeros((n, 1), device=self.device)
+        self.max_radii2D = torch.zeros(n, device=self.device)
+
+    @torch.no_grad()
+    def prune(self, min_opacity, extent, max_screen_size=None):
+        """latent_gs_renderer.py:892-902 (stage s2, main_train_dimo.py:439-443)."""
+        plan = _Plan(self)
+        self._plan_prune(plan, min_opacity, extent, max_screen_size, self.max_radii2D)
+        self._finish_prune(plan)
+
+    @torch.no_grad()
+    def prune_points(self, mask):
+        """latent_gs_renderer.py:719-733: removes the rows where `mask` is True."""
+        plan = _Plan(self)
+        plan.keep(~mask)
+        self._finish_prune(plan)
+
+    def _finish_prune(self, plan):
+        src = plan.src
+        self.rebuild(plan)
+        self.xyz_gradient_accum = self.xyz_gradient_accum[src]
+        self.denom = self.denom[src]
+        self.max_radii2D = self.max_radii2D[src]
+
+    @torch.no_grad()
+    def reset_opacity(self):
+        """latent_gs_renderer.py:571-574: opacity = min(opacity, 0.01), its Adam moments zeroed."""
+        plan = _Plan(self)
+        op = plan.opacity_act()
+        plan.values["opacity"] = self.inverse_opacity_activation(torch.min(op, torch.ones_like(op) * 0.01))
+        self.rebuild(plan, zero_moments=("opacity",))

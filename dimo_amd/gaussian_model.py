@@ -11,7 +11,8 @@ fp32 parameter buffer and every `.grad` a view into one flat gradient buffer
 (`flat_params` / `flat_grads`), so data-parallel training all-reduces ONE contiguous bucket
 over RCCL/xGMI with no packing copy, and zeroing gradients is a single memset.
 
-Out of scope here: densify / prune / optimizer surgery, PLY and .pth I/O.
+Densify / prune / optimizer surgery live in densify.py, PLY and .pth I/O in ply_io.py (SURVEY.md 8f row 3);
+both are mixed into `GaussianModel`.
 """
 import math
 from typing import NamedTuple
@@ -56,13 +57,17 @@ def get_expon_lr_func(lr_init, lr_final, lr_delay_steps=0, lr_delay_mult=1.0, ma
     return helper
 
 
+from .densify import PER_GAUSSIAN, DensifyMixin  # noqa: E402
+from .ply_io import PlyMixin  # noqa: E402
+
+
 class BasicPointCloud(NamedTuple):
     points: np.ndarray
     colors: np.ndarray
     normals: np.ndarray
 
 
-class GaussianModel:
+class GaussianModel(DensifyMixin, PlyMixin):
     def __init__(self, sh_degree: int, num_latent_code: int = 1, latent_code_dim: int = 32, vae_latent: bool = False,
                  device=None, dist2_fn=None):
         self.device = torch.device(device if device is not None else ("cuda" if torch.cuda.is_available() else "cpu"))
@@ -229,21 +234,96 @@ class GaussianModel:
         self.flat_params, self.flat_grads = flat, grads
         return flat, grads
 
-    def training_setup(self, training_args, fused=None):
-        self.percent_dense = training_args.percent_dense
-        n = self._xyz.shape[0]
-        self.xyz_gradient_accum = torch.zeros((n, 1), device=self.device)
-        self.denom = torch.zeros((n, 1), device=self.device)
+    # ------------------------------------------------------------------ optimizer surgery (densify / prune)
+    def per_gaussian(self):
+        """The six per-Gaussian parameter tensors by the reference's optimizer group names."""
+        return dict(xyz=self._xyz, f_dc=self._features_dc, f_rest=self._features_rest, opacity=self._opacity,
+                    scaling=self._scaling, rotation=self._rotation)
+
+    def _moments(self, p):
+        """(exp_avg, exp_avg_sq, step) of parameter p, shaped like p; None before the first step of torch Adam."""
+        opt = self.optimizer
+        if type(opt).__name__ == "FlatAdam":
+            off = (p.data_ptr() - self.flat_params.data_ptr()) // 4
+            n = p.numel()
+            return (opt.exp_avg[off:off + n].view(p.shape), opt.exp_avg_sq[off:off + n].view(p.shape), opt.step_count)
+        st = opt.state.get(p, None)
+        if not st:
+            return None
+        return st["exp_avg"], st["exp_avg_sq"], st["step"]
+
+    def rebuild(self, plan, zero_moments=()):
+        """Applies a densify.py plan: new per-Gaussian parameters (values from the plan), Adam moments gathered
+        from the plan's source rows (zero for fresh rows / the `zero_moments` groups), everything else carried over;
+        ONE rebuild of the flat parameter / gradient / moment buckets."""
+        assert self.optimizer is not None, "training_setup first"
+        old = self.per_gaussian()
+        new_moments, carried = {}, {}
+        for k, p in old.items():
+            mo = self._moments(p)
+            if mo is None:
+                continue
+            m, v = mo[0][plan.src].clone(), mo[1][plan.src].clone()
+            m[plan.fresh], v[plan.fresh] = 0, 0
+            if k in zero_moments:
+                m.zero_(), v.zero_()
+            new_moments[k] = (m, v, mo[2])
+        per_ids = {id(p) for p in old.values()}
+        for grp in self.optimizer.param_groups:
+            for p in grp["params"]:
+                if id(p) not in per_ids:
+                    mo = self._moments(p)
+                    if mo is not None:
+                        carried[id(p)] = (mo[0].clone(), mo[1].clone(), mo[2])
+        lrs = {grp["name"]: grp["lr"] for grp in self.optimizer.param_groups}
+        step_count = getattr(self.optimizer, "step_count", None)
+        P = lambda t: nn.Parameter(t.detach().clone().contiguous().requires_grad_(True))
+        v = plan.values
+        self._xyz, self._features_dc, self._features_rest = P(v["xyz"]), P(v["f_dc"]), P(v["f_rest"])
+        self._opacity, self._scaling, self._rotation = P(v["opacity"]), P(v["scaling"]), P(v["rotation"])
+        self._make_optimizer(self._training_args, self._fused)
+        for grp in self.optimizer.param_groups:
+            grp["lr"] = lrs.get(grp["name"], grp["lr"])
+        if step_count is not None:
+            self.optimizer.step_count = step_count
+        new = self.per_gaussian()
+        with torch.no_grad():
+            for grp in self.optimizer.param_groups:
+                for p in grp["params"]:
+                    key = next((k for k, q in new.items() if q is p), None)
+                    src = new_moments.get(key) if key is not None else carried.get(id(p))
+                    if src is None:
+                        continue
+                    if type(self.optimizer).__name__ == "FlatAdam":
+                        m, s2, _ = self._moments(p)
+                        m.copy_(src[0]), s2.copy_(src[1])
+                    else:
+                        step = src[2]
+                        self.optimizer.state[p] = {"step": step.clone() if torch.is_tensor(step) else step,
+                                                   "exp_avg": src[0], "exp_avg_sq": src[1]}
+        self.neighbor_dists = self.neighbor_indices = None  # per-Gaussian KNN results are stale
+
+    def _make_optimizer(self, training_args, fused):
         groups = self.param_groups(training_args)
         groups = [g for g in groups if all(p.numel() > 0 for p in g["params"])]
         self.flatten_parameters(groups)
-        if fused is None:
-            fused = "flat" if self.device.type == "cuda" else False
         if fused == "flat":  # one HIP launch over the flat bucket (dimo_amd/csrc/adam.hip)
             from .flat_adam import FlatAdam
             self.optimizer = FlatAdam(groups, self.flat_params, self.flat_grads, eps=1e-15)
         else:
             self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15, **({"fused": True} if fused else {}))
+
+    def training_setup(self, training_args, fused=None):
+        self.percent_dense = training_args.percent_dense
+        n = self._xyz.shape[0]
+        self.xyz_gradient_accum = torch.zeros((n, 1), device=self.device)
+        self.denom = torch.zeros((n, 1), device=self.device)
+        if fused is None:
+            fused = "flat" if self.device.type == "cuda" else False
+        self._training_args, self._fused = training_args, fused
+        if self.max_radii2D.shape[0] != n:
+            self.max_radii2D = torch.zeros(n, device=self.device)
+        self._make_optimizer(training_args, fused)
         self.lr_setup(training_args)
 
     def zero_grad(self):

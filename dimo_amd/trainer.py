@@ -80,6 +80,17 @@ class TrainConfig:
     c_position_lr_final: float = 0.000002
     c_position_lr_delay_mult: float = 0.02
     r_lr: float = 0.01
+    # densification / pruning schedule (configs/train_config.yaml:79-88; main_train_dimo.py:426-443)
+    density_start_iter: int = 100
+    density_end_iter: int = 1000
+    density_end_iter_s2: int = 5000
+    densification_interval: int = 100
+    densification_interval_s2: int = 1000
+    opacity_reset_interval: int = 200000
+    densify_grad_threshold: float = 0.01
+    densify_opacity_threshold_s1: float = 0.01
+    densify_opacity_threshold_s2: float = 0.01
+    init_type: str = "ag"
     seed: int = 0
     stage: str = "s2"
 
@@ -130,7 +141,6 @@ class Trainer:
         self._py_rng = random.Random(cfg.seed)
         self._np_rng = np.random.default_rng(cfg.seed)
         renderer.gaussians.training_setup(cfg)
-        self.optimizer = renderer.gaussians.optimizer
         self._last_loss = None
         self._consts = {}
         self._deform_batch = None
@@ -152,6 +162,11 @@ class Trainer:
         if self.direct and renderer.capacity is None:
             from .rasterizer import CapacityPolicy
             renderer.capacity = CapacityPolicy(initial=max(1 << 20, 40 * cfg.num_pts))
+
+    @property
+    def optimizer(self):
+        """Always the model's CURRENT optimizer (densification / pruning rebuild it)."""
+        return self.renderer.gaussians.optimizer
 
     @property
     def last_loss(self):
@@ -274,8 +289,10 @@ class Trainer:
         loss = None
         by_motion = {}
         deforms = self.batched_deform(mine) if self.stage >= "s2" else {}
+        self._last_out = None
         for (m, v, f) in mine:
             out = self.render_triple(m, v, f, deform=deforms.get((m, v, f)))
+            self._last_out = out
             gt, mask = self.targets.get(m, v, f)
             w = 1.0 if (v == 0 or f == 0) else 0.5  # reference view / frame weighting (main_train_dimo.py:334)
             rec = by_motion.setdefault(m, ([], [], [], []))
@@ -294,7 +311,7 @@ class Trainer:
         from .executor import StepExecutor
         g, c = self.renderer.gaussians, self.cfg
         cap = self.renderer.capacity.next_capacity()
-        if self._exec is None or self._exec.max_renders < n_renders:
+        if self._exec is None or self._exec.max_renders < n_renders or self._exec.N != g._xyz.shape[0]:
             import os
             self._exec = StepExecutor(g._xyz.shape[0], g._c_xyz.shape[0], c.resolution, c.resolution,
                                       max(n_renders, 8), cap, self.device,
@@ -485,4 +502,26 @@ class Trainer:
             self.optimizer.step()
             g.zero_grad()
         self._last_loss = loss
+        self.densify_schedule()
         return len(mine)
+
+    def densify_schedule(self):
+        """Densification / pruning of the reference's two stages (main_train_dimo.py:426-443), after the optimizer
+        step.  Deterministic in the parameters (and the shared torch seed for the split draws): replicas stay equal."""
+        c, g = self.cfg, self.renderer.gaussians
+        if self.stage == "s1":
+            fps_iter = getattr(c, "FPS_iter", 1000)
+            if self.step % fps_iter >= c.density_start_iter and self.step <= c.density_end_iter:
+                out = getattr(self, "_last_out", None)
+                if out is not None and out["viewspace_points"].grad is not None:
+                    vis = out["visibility_filter"]
+                    g.update_max_radii(out["radii"], vis)
+                    g.add_densification_stats(out["viewspace_points"], vis)
+                if self.step % c.densification_interval == 0:
+                    g.densify_and_prune(c.densify_grad_threshold, min_opacity=c.densify_opacity_threshold_s1, extent=4,
+                                        max_screen_size=1)
+                if self.step % c.opacity_reset_interval == 0:
+                    g.reset_opacity()
+        elif self.stage == "s2" and self.step < c.density_end_iter_s2:
+            if self.step % c.densification_interval_s2 == 0 and c.init_type == "ag":
+                g.prune(min_opacity=c.densify_opacity_threshold_s2, extent=4, max_screen_size=1)
