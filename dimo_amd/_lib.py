@@ -48,6 +48,7 @@ _SIGNATURES = {
                                        c_ptr, C.c_size_t, c_ptr]),
     "dimo_timenet_backward": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_ptr, c_ptr, C.c_void_p, C.c_void_p, c_ptr,
                                         c_ptr, c_ptr, C.c_size_t, c_ptr]),
+    "dimo_farthest_point_sample": (C.c_int, [C.c_int, C.c_int, c_ptr, c_ptr, c_ptr, c_ptr]),
     "dimo_executor_create": (C.c_void_p, [C.c_int]),
     "dimo_executor_destroy": (None, [C.c_void_p]),
     "dimo_executor_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),

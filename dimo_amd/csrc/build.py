@@ -24,6 +24,7 @@ SOURCES = {
     "image_loss.hip": [],
     "adam.hip": [],
     "timenet.hip": [],
+    "fps.hip": ["-ffp-contract=off"],
     "executor.hip": [],
 }
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-fast-math", "-Wall", "-Wno-unused-function"]

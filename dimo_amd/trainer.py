@@ -91,6 +91,15 @@ class TrainConfig:
     densify_opacity_threshold_s1: float = 0.01
     densify_opacity_threshold_s2: float = 0.01
     init_type: str = "ag"
+    # regularisers (configs/train_config.yaml:57-65).  Off by default: BASELINE.json's metric is quoted without them
+    use_arap: bool = False
+    arap_start_iter_s1: int = 1000
+    arap_end_iter_s2: int = 2000
+    lambda_arap: float = 10.0
+    add_ga: bool = False
+    ga_chamfer: bool = True
+    lambda_ga1: float = 10.0
+    lambda_ga2: float = 10000.0
     seed: int = 0
     stage: str = "s2"
 
@@ -277,6 +286,18 @@ class Trainer:
             loss = loss + c.lambda_bilateral * share * compute_bilateral_normal_smoothness_loss(normal, img_hwc)
         return loss
 
+    def regularizer_loss(self, m):
+        """ARAP term of one motion (main_train_dimo.py:374-384); None when switched off / outside its window."""
+        c = self.cfg
+        if not c.use_arap:
+            return None
+        if (self.stage == "s1" and self.step > c.arap_start_iter_s1) or \
+                (self.stage == "s2" and self.step < c.arap_end_iter_s2):
+            from .regularizers import arap_loss_v2
+            err, _ = arap_loss_v2(self.renderer.gaussians, stage=self.stage, latent_index=m)
+            return c.lambda_arap * err
+        return None
+
     def all_reduce_grads(self):
         """ONE collective per step: the flat gradient bucket (+ its 4-float tail carrying the overflow flag)."""
         if self.world > 1:
@@ -302,6 +323,9 @@ class Trainer:
             if g.vae_latent:
                 mu, lv = g._mu[m], g._log_var[m]
                 lm = lm + c.lambda_kl * (-0.5 * torch.sum(1 + lv - mu.pow(2) - lv.exp()))
+            reg = self.regularizer_loss(m)
+            if reg is not None:
+                lm = lm + reg
             loss = lm if loss is None else loss + lm
         if loss is not None:
             loss.backward()
@@ -421,6 +445,10 @@ class Trainer:
                 kl = c.lambda_kl * (-0.5 * torch.sum(1 + lv - mu.pow(2) - lv.exp()))
                 kl.backward()
                 loss_accum += kl.detach()
+            reg = self.regularizer_loss(m)  # ARAP on the control points: its own small autograd graph
+            if reg is not None:
+                reg.backward()
+                loss_accum += reg.detach()
         self._mark("losses+launch")
         if ex.batched and not ex.ranged:
             ex.backward_launch(0, n)

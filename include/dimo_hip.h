@@ -15,6 +15,7 @@
  *   dimo_image_loss    the loss assembly of GUI.train_step            main_train_dimo.py:325-380 ; src/loss.py:178-243
  *   dimo_flat_adam_step torch.optim.Adam over the 12 groups           renderer/latent_gs_renderer.py:460-476
  *   dimo_executor_*    the render loop of GUI.train_step (forward, mirrored backward)  main_train_dimo.py:276-318,415
+ *   dimo_farthest_point_sample  pytorch3d.ops.sample_farthest_points   main_train_dimo.py:511-515
  *
  * Conventions
  *   - every pointer is a DEVICE pointer unless the name ends in _host; the library never
@@ -234,6 +235,13 @@ int dimo_timenet_forward(const dimo_timenet_desc *net, int P, int M, const float
 int dimo_timenet_backward(const dimo_timenet_desc *net, int P, int M, const float *g_d_xyz, const float *g_d_rot,
                           const float *times_host, const int *latent_rows_host, float *g_c_xyz,
                           float *g_latent_table, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------ farthest point sampling (stage s1, every FPS_iter)
+ * pytorch3d.ops.sample_farthest_points(points[1,N,3], K) with the default fixed start (main_train_dimo.py:511-515):
+ * out_idx[0] = 0, then K-1 times the point with the largest squared distance to the selected set (lowest index among
+ * equals).  min_dist_scratch: N floats.  One workgroup; K sequential rounds. */
+int dimo_farthest_point_sample(int N, int K, const float *xyz, float *min_dist_scratch, int64_t *out_idx,
+                               void *stream);
 
 /* ------------------------------------------------------------------ native step executor
  * Runs the per-render kernel chains of one training step (main_train_dimo.py:276-318 forward, the mirrored

@@ -364,3 +364,52 @@ def densify_fixture():
 densify_fixture()
 print("densify done")
 
+
+
+# ----------------------------------------------------------------------------- 9. ARAP regulariser
+# utils/deform_utils.py: cal_connectivity_from_points_v2 (:115-141), estimate_rotation (:161-197), cal_arap_error
+# (:208-236) on a small node sequence.  pytorch3d is absent: its ball_query is replaced by a restatement of its
+# documented behaviour (the first K points of p2, in index order, with squared distance < radius^2; idx padded with
+# -1, dists with 0) -- the only un-pinned piece of this fixture.
+def arap_fixture():
+    from utils import deform_utils as DU
+
+    def ball_query(p1, p2, K, radius):
+        T_, N1 = p1.shape[0], p1.shape[1]
+        d2 = ((p1[:, :, None, :] - p2[:, None, :, :]) ** 2).sum(-1)
+        idx = torch.full((T_, N1, K), -1, dtype=torch.long)
+        dist = torch.zeros(T_, N1, K)
+        for t in range(T_):
+            for i in range(N1):
+                hit = torch.nonzero(d2[t, i] < radius * radius).flatten()[:K]
+                idx[t, i, :len(hit)] = hit
+                dist[t, i, :len(hit)] = d2[t, i, hit]
+        return dist, idx, None
+
+    class _NN:  # ops.ball_query(...) returns a 3-tuple whose third item is sliced: hand back a sliceable dummy
+        def __getitem__(self, k):
+            return self
+
+    DU.ops.ball_query = lambda p1, p2, K, radius: ball_query(p1, p2, K, radius)[:2] + (_NN(),)
+    gg = torch.Generator().manual_seed(21)
+    T_, Nv = 4, 60
+    base = (torch.rand(Nv, 3, generator=gg) - 0.5) * 0.3
+    pts = base[None] + 0.01 * torch.randn(T_, Nv, 3, generator=gg)
+    # a rotation-like deformation on top, different per time
+    for t in range(T_):
+        a = 0.15 * t
+        rot = torch.tensor([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]], dtype=torch.float32)
+        pts[t] = pts[t] @ rot.T
+    pts = pts.clone().requires_grad_(True)
+    ii, jj, nn_, _ = DU.cal_connectivity_from_points_v2(pts.detach(), K=10)
+    err = DU.cal_arap_error(pts, ii, jj, nn_)
+    err.backward()
+    with torch.no_grad():
+        rot1 = DU.estimate_rotation(pts[0].detach(), pts[1].detach(), ii, jj, nn_, K=10,
+                                    weight=torch.zeros(Nv, 10).index_put_((ii, nn_), torch.tensor(1.0)))
+    save("arap.npz", pts=n(pts).copy(), ii=n(ii).copy(), jj=n(jj).copy(), nn=n(nn_).copy(), error=n(err).copy(),
+         g_pts=n(pts.grad).copy(), rot1=n(rot1).copy(), radius=np.array(0.1), K=np.array(10))
+
+
+arap_fixture()
+print("arap done")

@@ -63,14 +63,14 @@ def test_image_loss_kernel_vs_reference_assembly(B, H, W, share, dn):
         assert rel <= 1e-4, (name, rel.item())
 
 
-@pytest.mark.parametrize("vae", [False, True])
-def test_direct_pipeline_equals_autograd_pipeline(vae):
+@pytest.mark.parametrize("vae,arap", [(False, False), (True, False), (False, True)])
+def test_direct_pipeline_equals_autograd_pipeline(vae, arap):
     from dimo_amd.rasterizer import CapacityPolicy
     from dimo_amd.renderer import Renderer
     from dimo_amd.synth import init_synthetic_model
     from dimo_amd.trainer import TrainConfig, Trainer
     cfg = TrainConfig(num_pts=5000, num_cpts=64, num_motions=4, num_frames=6, num_views=4, motions_per_step=2,
-                      views_per_step=2, frames_per_step=2, resolution=128, vae_latent=vae)
+                      views_per_step=2, frames_per_step=2, resolution=128, vae_latent=vae, use_arap=arap)
     res = []
     for direct in (False, True):
         rd = Renderer(sh_degree=0, num_latent_code=cfg.num_motions, add_normal=True, device="cuda", vae_latent=vae,
