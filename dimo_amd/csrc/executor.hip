@@ -80,7 +80,11 @@ extern "C" void *dimo_executor_create(int n_streams) {
   for (int i = 0; i < S; ++i) {
     hipStream_t s;
     hipEvent_t e;
-    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess ||
+    // LOWEST priority: the caller's stream carries the step's critical path (losses, skinning backward, TimeNet);
+    // its kernels should win the workgroup slots against the other motion's batch when both are runnable
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    if (hipStreamCreateWithPriority(&s, hipStreamNonBlocking, prio_lo) != hipSuccess ||
         hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
       delete ex;
       return nullptr;
