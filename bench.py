@@ -30,6 +30,7 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+FP32_VALU_PEAK = 157.3e12  # MI355X_MICROARCH.md: peak FP32 (vector)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 NFEAT = 7
 TIMED = ["preprocess_fwd", "scan", "emit", "sort", "ranges", "blend_fwd", "blend_bwd", "preprocess_bwd", "knn",
@@ -85,8 +86,8 @@ def cpu_baseline(num_pts, resolution, renders=20):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--num-pts", type=int, default=100000)
     ap.add_argument("--resolution", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -150,6 +151,16 @@ def main():
     else:
         renders_total = float(renders)
     timing = read_timing()
+    # step latency distribution (median + p10/p90), one device sync per step, outside the timed region
+    lat = []
+    for _ in range(min(args.steps, 50)):
+        barrier()
+        t1 = time.perf_counter()
+        tr.train_step()
+        torch.cuda.synchronize()
+        lat.append(1e3 * (time.perf_counter() - t1))
+    lat.sort()
+    pct = lambda q: lat[min(len(lat) - 1, int(q * len(lat)))]
     L.dimo_timing_select(None)
     L.dimo_timing_enable(1)
     for _ in range(3):
@@ -235,6 +246,16 @@ def main():
                                               "streams"},
                          "note": "tile blend is FP32-VALU bound, not HBM bound (each 64-B record is reused by 256 "
                                  "pixels); the HBM fraction is reported as required, see DESIGN.md"},
+            "synced_step_ms": {"median": pct(0.5), "p10": pct(0.1), "p90": pct(0.9), "steps": len(lat),
+                               "what": "one step at a time with a device sync after each (no overlap of the host "
+                                       "enqueue with the previous step), outside the timed region"},
+            # pixel-Gaussian interactions I = sum over tiles of len * 256, against the FP32 vector peak
+            "interactions": {"per_render": R * 256, "blend_bwd_per_s": R * 256 / (avg_s / rpl) if avg_s > 0 else None,
+                             "blend_fwd_per_s": (R * 256 / (timing_all["blend_fwd"][0] / timing_all["blend_fwd"][1]
+                                                            * 1e-3 / rpl) if timing_all["blend_fwd"][1] else None),
+                             "fp32_vector_peak_flops": FP32_VALU_PEAK,
+                             "note": "list entries x 256 pixels; culling and saturation skip most of them, so the "
+                                     "rate is an upper-bound style figure, not executed FLOPs"},
             "kernels_ms_per_launch": {k: (v[0] / v[1] if v[1] else None) for k, v in timing_all.items()},
             "kernels_ms_per_launch_isolated": {k: (v[0] / v[1] if v[1] else None) for k, v in timing_iso.items()},
         }

@@ -176,9 +176,17 @@ class ScopedTimer {
 // The executor's descriptors travel BY VALUE in the kernel arguments (8 x 256 B), blockIdx.y selects the render:
 // one launch per stage for all renders of a step instead of one per render and stage.
 constexpr int MAX_BATCH = 8;
+// Renders of a batch that share their TimeNet rows (same (motion, frame) pair, different cameras) share the skinned
+// Gaussians: they form a deformation GROUP.  The skinning forward runs once per group (the members' pts / rot /
+// scales / opac pointers are redirected to the leader's buffers when the batch is filled) and the skinning backward,
+// linear in the rasterizer gradients, runs once on their sum.
 struct RenderBatch {
   dimo_render_desc r[MAX_BATCH];
+  int n_groups;
+  unsigned char leader[MAX_BATCH];   // group -> its first render
+  unsigned char members[MAX_BATCH];  // group -> bitmask of its renders (leader included)
 };
+void group_deformations(RenderBatch &b, int n);
 int lbs_forward_batched(const dimo_step_common &c, const RenderBatch &b, int n, hipStream_t stream);
 size_t lbs_backward_batched_scratch_bytes(int N, int M, int n);
 int lbs_backward_batched(const dimo_step_common &c, const RenderBatch &b, int n, hipStream_t stream);

@@ -113,11 +113,12 @@ __global__ void __launch_bounds__(DEF_BLOCK) lbs_fwd_kernel(int N, int M, GaussI
                                                             float *__restrict__ out_opacity) {
   lbs_fwd_body<LOCAL_FRAME>(N, M, g, t, out_xyz, out_rot, out_scales, out_opacity);
 }
-// blockIdx.y = render of the batch (every render skins the same canonical Gaussians with its own TimeNet rows)
+// blockIdx.y = deformation group of the batch (every group skins the same canonical Gaussians with its own TimeNet
+// rows; the renders of a group read the leader's buffers)
 template <bool LOCAL_FRAME>
 __global__ void __launch_bounds__(DEF_BLOCK) lbs_fwd_batched_kernel(int N, int M, GaussIO g, const float *c_xyz,
                                                                     const float *c_lr, RenderBatch b) {
-  const dimo_render_desc &r = b.r[blockIdx.y];
+  const dimo_render_desc &r = b.r[b.leader[blockIdx.y]];
   lbs_fwd_body<LOCAL_FRAME>(N, M, g, CtrlTable{c_xyz, c_lr, r.d_xyz, r.d_rot}, r.pts, r.rot, r.scales, r.opac);
 }
 
@@ -125,12 +126,47 @@ __global__ void __launch_bounds__(DEF_BLOCK) lbs_fwd_batched_kernel(int N, int M
 // of all its renders straight into the flat gradient bucket).
 // The batched launch runs this in place (outputs over the inputs of the same Gaussian, each element read before
 // it is written by its own thread), hence no __restrict__ on the eight per-Gaussian arrays.
-template <bool LOCAL_FRAME, bool ACC>
+// EXTRA adds the rasterizer gradients of the other renders of a deformation group to the leader's (the backward is
+// linear in them); NoExtra for a single render.
+struct NoExtra {
+  __device__ __forceinline__ void rot(size_t, float4 &) const {}
+  __device__ __forceinline__ void vec3(int, size_t, float &, float &, float &) const {}
+  __device__ __forceinline__ void opac(size_t, float &) const {}
+};
+struct GroupExtra {
+  const RenderBatch &b;
+  unsigned others;  // bitmask of the group's renders without the leader
+  __device__ __forceinline__ void rot(size_t i, float4 &v) const {
+#pragma unroll
+    for (int j = 1; j < MAX_BATCH; ++j)
+      if ((others >> j) & 1u) {
+        const float4 t = *reinterpret_cast<const float4 *>(b.r[j].g_rot + 4 * i);
+        v.x += t.x, v.y += t.y, v.z += t.z, v.w += t.w;
+      }
+  }
+  // which = 0: g_means3D, 1: g_scales
+  __device__ __forceinline__ void vec3(int which, size_t i, float &a, float &c, float &d) const {
+#pragma unroll
+    for (int j = 1; j < MAX_BATCH; ++j)
+      if ((others >> j) & 1u) {
+        const float *p = (which == 0 ? b.r[j].g_means3D : b.r[j].g_scales) + 3 * i;
+        a += p[0], c += p[1], d += p[2];
+      }
+  }
+  __device__ __forceinline__ void opac(size_t i, float &v) const {
+#pragma unroll
+    for (int j = 1; j < MAX_BATCH; ++j)
+      if ((others >> j) & 1u) v += b.r[j].g_opac[i];
+  }
+};
+
+template <bool LOCAL_FRAME, bool ACC, class EXTRA>
 __device__ __forceinline__ void lbs_bwd_body(int N, int M, GaussIO g, CtrlTable t, const float *g_xyz,
                                              const float *g_rot, const float *g_scales, const float *g_opacity,
                                              float *d_xyz_out, float *d_rot_out, float *d_scaling_out,
                                              float *d_opacity_out,
-                                             float *__restrict__ partials /* [gridDim.x][M][CP_STRIDE] */) {
+                                             float *__restrict__ partials /* [gridDim.x][M][CP_STRIDE] */,
+                                             const EXTRA extra) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float *s_cp = smem;                    // control-point table
   float *s_acc = smem + M * CP_STRIDE;   // control-point gradient accumulators
@@ -175,7 +211,8 @@ __device__ __forceinline__ void lbs_bwd_body(int N, int M, GaussIO g, CtrlTable 
     const float inv_n = 1.0f / nrm;
     const float uw = ow * inv_n, ux = ox * inv_n, uy = oy * inv_n, uz = oz * inv_n;
     // normalisation backward
-    const float4 go = *reinterpret_cast<const float4 *>(g_rot + 4 * (size_t)i);
+    float4 go = *reinterpret_cast<const float4 *>(g_rot + 4 * (size_t)i);
+    extra.rot((size_t)i, go);
     const float dotg = uw * go.x + ux * go.y + uy * go.z + uz * go.w;
     const float gw = (go.x - uw * dotg) * inv_n, gx = (go.y - ux * dotg) * inv_n;
     const float gy = (go.z - uy * dotg) * inv_n, gz = (go.w - uz * dotg) * inv_n;
@@ -198,7 +235,8 @@ __device__ __forceinline__ void lbs_bwd_body(int N, int M, GaussIO g, CtrlTable 
       *dst = v;
     }
 
-    const float gp0 = g_xyz[3 * i], gp1 = g_xyz[3 * i + 1], gp2 = g_xyz[3 * i + 2];
+    float gp0 = g_xyz[3 * i], gp1 = g_xyz[3 * i + 1], gp2 = g_xyz[3 * i + 2];
+    extra.vec3(0, (size_t)i, gp0, gp1, gp2);
     float dx0 = LOCAL_FRAME ? 0.f : gp0, dx1 = LOCAL_FRAME ? 0.f : gp1, dx2 = LOCAL_FRAME ? 0.f : gp2;
     float gwk[DEF_K], sum_wg = 0.f;
     // this Gaussian's contribution to columns 3..10 of the gradient row of neighbour k (columns 0..2, the gradient
@@ -265,11 +303,15 @@ __device__ __forceinline__ void lbs_bwd_body(int N, int M, GaussIO g, CtrlTable 
       wave_scatter_add<CP_STRIDE - 3>(s_acc + 3, CP_STRIDE, idx[k], cpg[k], valid, lane);
     if (valid) {
       const float o = 1.0f / (1.0f + __expf(-g.opacity[i]));
-      const float gop = g_opacity[i] * o * (1.0f - o);
+      float gopac = g_opacity[i];
+      extra.opac((size_t)i, gopac);
+      const float gop = gopac * o * (1.0f - o);
       const float dxs[3] = {dx0, dx1, dx2};
+      float gsc[3] = {g_scales[3 * i], g_scales[3 * i + 1], g_scales[3 * i + 2]};
+      extra.vec3(1, (size_t)i, gsc[0], gsc[1], gsc[2]);
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        const float gs = g_scales[3 * i + c] * __expf(g.scaling[3 * i + c]);
+        const float gs = gsc[c] * __expf(g.scaling[3 * i + c]);
         d_xyz_out[3 * i + c] = ACC ? d_xyz_out[3 * i + c] + dxs[c] : dxs[c];
         d_scaling_out[3 * i + c] = ACC ? d_scaling_out[3 * i + c] + gs : gs;
       }
@@ -307,31 +349,33 @@ __global__ void __launch_bounds__(DEF_BLOCK) lbs_bwd_kernel(
     float *__restrict__ d_rot_out, float *__restrict__ d_scaling_out, float *__restrict__ d_opacity_out,
     float *__restrict__ partials) {
   lbs_bwd_body<LOCAL_FRAME, ACC>(N, M, g, t, g_xyz, g_rot, g_scales, g_opacity, d_xyz_out, d_rot_out, d_scaling_out,
-                                 d_opacity_out, partials);
+                                 d_opacity_out, partials, NoExtra{});
 }
-// blockIdx.y = render.  Per-Gaussian gradients are written IN PLACE over the render's rasterizer gradients
-// (g_means3D -> d xyz, g_rot -> d rotation, g_scales -> d scaling, g_opac -> d opacity: same shapes);
-// accumulate_batched_kernel then folds the renders into the shared gradient views in a fixed order.
+// blockIdx.y = deformation group.  Per-Gaussian gradients are written IN PLACE over the LEADER's rasterizer
+// gradients (g_means3D -> d xyz, g_rot -> d rotation, g_scales -> d scaling, g_opac -> d opacity: same shapes);
+// accumulate_batched_kernel then folds the leaders into the shared gradient views in a fixed order.
 template <bool LOCAL_FRAME>
 __global__ void __launch_bounds__(DEF_BLOCK) lbs_bwd_batched_kernel(int N, int M, GaussIO g, const float *c_xyz,
                                                                     const float *c_lr, RenderBatch b,
                                                                     float *__restrict__ partials) {
-  const dimo_render_desc &r = b.r[blockIdx.y];
+  const int lead = b.leader[blockIdx.y];
+  const dimo_render_desc &r = b.r[lead];
   lbs_bwd_body<LOCAL_FRAME, false>(N, M, g, CtrlTable{c_xyz, c_lr, r.d_xyz, r.d_rot}, r.g_means3D, r.g_rot,
                                    r.g_scales, r.g_opac, r.g_means3D, r.g_rot, r.g_scales, r.g_opac,
-                                   partials + (size_t)blockIdx.y * gridDim.x * M * CP_STRIDE);
+                                   partials + (size_t)blockIdx.y * gridDim.x * M * CP_STRIDE,
+                                   GroupExtra{b, b.members[blockIdx.y] & ~(1u << lead)});
 }
 
-// Batched control-point reduction: one thread owns output j of EVERY render (renders that share a (motion, frame)
-// pair share their TimeNet gradient rows, and all share the control points), so the adds are ordered.
-__global__ void __launch_bounds__(256) lbs_reduce_batched_kernel(int M, int nblocks, int n_renders,
+// Batched control-point reduction: one thread owns output j of EVERY group (all share the control points), so the
+// adds are ordered.
+__global__ void __launch_bounds__(256) lbs_reduce_batched_kernel(int M, int nblocks, int n_groups,
                                                                  const float *__restrict__ partials,
                                                                  float *d_c_xyz, float *d_c_lr, RenderBatch b) {
   __shared__ float s_part[16][17];
   const int jj = threadIdx.x & 15, chunk = threadIdx.x >> 4;
   const int j = blockIdx.x * 16 + jj;
   const int m = j / CP_STRIDE, c = j % CP_STRIDE;
-  for (int r = 0; r < n_renders; ++r) {
+  for (int r = 0; r < n_groups; ++r) {
     const float *p = partials + (size_t)r * nblocks * M * CP_STRIDE;
     float s = 0.f;
     if (j < M * CP_STRIDE)
@@ -346,14 +390,15 @@ __global__ void __launch_bounds__(256) lbs_reduce_batched_kernel(int M, int nblo
       float *dst;
       if (c < 3) dst = d_c_xyz + 3 * m + c;
       else if (c == 3) dst = d_c_lr + m;
-      else if (c < 7) dst = b.r[r].g_d_xyz + 3 * m + (c - 4);
-      else dst = b.r[r].g_d_rot + 4 * m + (c - 7);
+      else if (c < 7) dst = b.r[b.leader[r]].g_d_xyz + 3 * m + (c - 4);
+      else dst = b.r[b.leader[r]].g_d_rot + 4 * m + (c - 7);
       *dst += s;
     }
   }
 }
 
-// dst[i] += sum_r src_r[i] for the five per-Gaussian gradient arrays of a batch (fixed render order)
+// dst[i] += sum_r src_r[i] for the five per-Gaussian gradient arrays of a batch (fixed order): the skinning
+// backward left the first four in the group leaders' buffers, the colour gradient is per render
 __global__ void __launch_bounds__(256) accumulate_batched_kernel(int N, int n_renders, RenderBatch b, float *g_xyz,
                                                                  float *g_rotation, float *g_scaling,
                                                                  float *g_opacity, float *g_f_dc) {
@@ -370,7 +415,10 @@ __global__ void __launch_bounds__(256) accumulate_batched_kernel(int N, int n_re
   else if (i < 11 * n) dst = g_opacity, k = i - 10 * n, which = 3;
   else dst = g_f_dc, k = i - 11 * n, which = 4;
   float s = dst[k];
+  unsigned leaders = 0;
+  for (int q = 0; q < b.n_groups; ++q) leaders |= 1u << b.leader[q];
   for (int r = 0; r < n_renders; ++r) {
+    if (which != 4 && !((leaders >> r) & 1u)) continue;
     const dimo_render_desc &d = b.r[r];
     const float *src = which == 0 ? d.g_means3D : which == 1 ? d.g_rot : which == 2 ? d.g_scales
                        : which == 3 ? d.g_opac : d.g_shs;
@@ -444,6 +492,25 @@ inline void allow_big_lds() {
 }
 
 // ---- batched host entry points (native step executor) ------------------------------------------------------------
+void group_deformations(RenderBatch &b, int n) {
+  b.n_groups = 0;
+  for (int i = 0; i < MAX_BATCH; ++i) b.leader[i] = 0, b.members[i] = 0;
+  for (int i = 0; i < n; ++i) {
+    int q = 0;
+    for (; q < b.n_groups; ++q) {
+      const dimo_render_desc &l = b.r[b.leader[q]];
+      if (l.d_xyz == b.r[i].d_xyz && l.d_rot == b.r[i].d_rot && l.g_d_xyz == b.r[i].g_d_xyz &&
+          l.g_d_rot == b.r[i].g_d_rot)
+        break;
+    }
+    if (q == b.n_groups) b.leader[b.n_groups++] = (unsigned char)i;
+    b.members[q] |= (unsigned char)(1u << i);
+    const dimo_render_desc &l = b.r[b.leader[q]];
+    b.r[i].pts = l.pts, b.r[i].rot = l.rot, b.r[i].scales = l.scales, b.r[i].opac = l.opac;
+  }
+  for (int i = n; i < MAX_BATCH; ++i) b.r[i] = b.r[n - 1];  // padding entries follow the redirected last render
+}
+
 int lbs_forward_batched(const dimo_step_common &c, const RenderBatch &b, int n, hipStream_t stream) {
   if (c.N <= 0 || n <= 0) return DIMO_OK;
   GaussIO g{c.xyz, c.rotation, c.scaling, c.opacity, c.nn_dist, c.nn_idx};
@@ -451,12 +518,12 @@ int lbs_forward_batched(const dimo_step_common &c, const RenderBatch &b, int n, 
   allow_big_lds();
   ScopedTimer tm(T_DEFORM_FWD, stream);
   // the control-point table is re-built per workgroup: fewer, fatter workgroups per render when batching
-  const int grid = max(1, deform_grid(c.N) / (n > 1 ? 2 : 1));
+  const int grid = max(1, deform_grid(c.N) / (b.n_groups > 1 ? 2 : 1));
   if (c.local_frame)
-    hipLaunchKernelGGL(lbs_fwd_batched_kernel<true>, dim3(grid, n), dim3(DEF_BLOCK), lds, stream, c.N, c.M, g, c.c_xyz,
+    hipLaunchKernelGGL(lbs_fwd_batched_kernel<true>, dim3(grid, b.n_groups), dim3(DEF_BLOCK), lds, stream, c.N, c.M, g, c.c_xyz,
                        c.c_log_radius, b);
   else
-    hipLaunchKernelGGL(lbs_fwd_batched_kernel<false>, dim3(grid, n), dim3(DEF_BLOCK), lds, stream, c.N, c.M, g,
+    hipLaunchKernelGGL(lbs_fwd_batched_kernel<false>, dim3(grid, b.n_groups), dim3(DEF_BLOCK), lds, stream, c.N, c.M, g,
                        c.c_xyz, c.c_log_radius, b);
   return check_launch();
 }
@@ -471,17 +538,17 @@ int lbs_backward_batched(const dimo_step_common &c, const RenderBatch &b, int n,
   GaussIO g{c.xyz, c.rotation, c.scaling, c.opacity, c.nn_dist, c.nn_idx};
   const size_t lds = 2 * (size_t)c.M * CP_STRIDE * sizeof(float);
   allow_big_lds();
-  const int grid = max(1, deform_grid(c.N) / (n > 1 ? 2 : 1));
+  const int grid = max(1, deform_grid(c.N) / (b.n_groups > 1 ? 2 : 1));
   float *partials = reinterpret_cast<float *>(c.lbs_scratch);
   ScopedTimer tm(T_DEFORM_BWD, stream);
   if (c.local_frame)
-    hipLaunchKernelGGL(lbs_bwd_batched_kernel<true>, dim3(grid, n), dim3(DEF_BLOCK), lds, stream, c.N, c.M, g, c.c_xyz,
+    hipLaunchKernelGGL(lbs_bwd_batched_kernel<true>, dim3(grid, b.n_groups), dim3(DEF_BLOCK), lds, stream, c.N, c.M, g, c.c_xyz,
                        c.c_log_radius, b, partials);
   else
-    hipLaunchKernelGGL(lbs_bwd_batched_kernel<false>, dim3(grid, n), dim3(DEF_BLOCK), lds, stream, c.N, c.M, g,
+    hipLaunchKernelGGL(lbs_bwd_batched_kernel<false>, dim3(grid, b.n_groups), dim3(DEF_BLOCK), lds, stream, c.N, c.M, g,
                        c.c_xyz, c.c_log_radius, b, partials);
-  hipLaunchKernelGGL(lbs_reduce_batched_kernel, dim3((c.M * CP_STRIDE + 15) / 16), dim3(256), 0, stream, c.M, grid, n,
-                     partials, c.g_c_xyz, c.g_c_log_radius, b);
+  hipLaunchKernelGGL(lbs_reduce_batched_kernel, dim3((c.M * CP_STRIDE + 15) / 16), dim3(256), 0, stream, c.M, grid,
+                     b.n_groups, partials, c.g_c_xyz, c.g_c_log_radius, b);
   const size_t total = 14 * (size_t)c.N;
   hipLaunchKernelGGL(accumulate_batched_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, c.N, n, b,
                      c.g_xyz, c.g_rotation, c.g_scaling, c.g_opacity, c.g_f_dc);

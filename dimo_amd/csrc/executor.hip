@@ -112,6 +112,7 @@ extern "C" void dimo_executor_destroy(void *h) {
 
 static void fill_batch(RenderBatch &b, const dimo_render_desc *d, int n) {
   for (int i = 0; i < MAX_BATCH; ++i) b.r[i] = d[i < n ? i : n - 1];
+  group_deformations(b, n);
 }
 
 static int ensure_events(Executor *ex, int n) {

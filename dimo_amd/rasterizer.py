@@ -240,6 +240,21 @@ def raster_backward(st: RasterState, g_color, g_depth, g_normal, g_alpha, out=No
     return out
 
 
+def _checked(stage, st, tensors):
+    """`raster_settings.debug` (latent_gs_renderer.py:1145): checked mode.  The published extensions snapshot the
+    arguments and re-raise when a launch fails; here the call is synchronised (so an asynchronous fault surfaces at
+    the stage that caused it, as a RuntimeError), the tile-instance capacity flag is read back, and every output is
+    checked to be finite."""
+    torch.cuda.synchronize(st.means3D.device)
+    tot = _total_view(st.geom, st.N).cpu()
+    if int(tot[1]) != 0 or int(tot[0]) > st.r_cap:
+        raise RuntimeError(f"rasterizer {stage}: {int(tot[0])} tile instances exceed the workspace capacity "
+                           f"{st.r_cap} (the render was truncated)")
+    for name, t in tensors.items():
+        if t is not None and not bool(torch.isfinite(t).all()):
+            raise RuntimeError(f"rasterizer {stage}: non-finite values in `{name}`")
+
+
 class _Rasterize(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, settings,
@@ -247,6 +262,8 @@ class _Rasterize(torch.autograd.Function):
         color, depth, normal, alpha, radii, st = raster_forward(
             means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, settings, with_normal,
             capacity)
+        if settings.debug:
+            _checked("forward", st, dict(image=color, depth=depth, normal=normal, alpha=alpha))
         ctx.st = st
         ctx.r_cap = st.r_cap
         ctx.opacity_shape = opacities.shape
@@ -266,6 +283,8 @@ class _Rasterize(torch.autograd.Function):
             g_color, g_depth, g_alpha, _ = grads
             g_normal = None
         g = raster_backward(st, g_color, g_depth, g_normal, g_alpha)
+        if st.settings.debug:
+            _checked("backward", st, {k: v for k, v in g.items() if not k.startswith("_")})
         return (g["means3D"], g["means2D"], g.get("shs"), g.get("colors"), g["opacities"].view(ctx.opacity_shape),
                 g.get("scales"), g.get("rotations"), g.get("cov3D"), None, None, None)
 

@@ -234,6 +234,38 @@ def test_capacity_policy_async_and_overflow():
     assert small.check() and torch.equal(res3["color"], exact["color"])
 
 
+def test_debug_flag_is_a_checked_mode():
+    """`raster_settings.debug` (latent_gs_renderer.py:1145): errors surface as RuntimeError at the stage that caused
+    them -- a truncated render (capacity too small) and non-finite outputs -- and never as an abort."""
+    from dimo_amd import rasterizer as rz
+    from dimo_amd.rasterizer import CapacityPolicy
+    d = _dev()
+    cam = camera_np(10.0, W=64, H=64)
+    sc = random_scene(500, seed=4, scale=0.05)
+    t = {k: torch.tensor(np.asarray(v), dtype=torch.float32, device=d) for k, v in sc.items()}
+    st = _settings(cam, (0, 0, 0), 0)._replace(debug=True)
+    args = lambda tt: (tt["means3D"], torch.zeros_like(tt["means3D"]), tt["shs"], None, tt["opacities"], tt["scales"],
+                       tt["rotations"], None, st, True)
+    rz._Rasterize.apply(*args(t), None)  # clean inputs pass
+    with pytest.raises(RuntimeError, match="capacity"):
+        rz._Rasterize.apply(*args(t), CapacityPolicy(initial=16))
+    colors = torch.rand(500, 3, device=d)
+    colors[:50] = float("nan")  # (NaN SH coefficients would be clamped away by max(colour + 0.5, 0), as upstream)
+    with pytest.raises(RuntimeError, match="non-finite"):
+        rz._Rasterize.apply(t["means3D"], torch.zeros_like(t["means3D"]), None, colors, t["opacities"], t["scales"],
+                            t["rotations"], None, st, True, None)
+
+
+@pytest.mark.parametrize("N,R,scale", [(50_000, 256, 0.02), (100_000, 512, 0.012), (200_000, 1024, 0.008)])
+def test_baseline_config_sizes_against_the_oracle(N, R, scale):
+    """BASELINE.json's C2 / C3 / C5 shapes (50k @ 256^2, 100k @ 512^2, 200k @ 1024^2): the C oracle finishes these in
+    seconds, so the full comparison -- bit-exact integer stages, 1e-4 L1 images and gradients -- runs at full size."""
+    cam = camera_np(40.0, elevation=5, W=R, H=R)
+    sc = random_scene(N, seed=N + 7, scale=scale, anisotropy=0.3)
+    _check_forward(sc, cam, (0.0, 0.0, 0.0), 0)
+    _check_backward(sc, cam, (0.0, 0.0, 0.0), 0, GRADS_SH)
+
+
 def test_full_size_properties_100k_512():
     """BASELINE config size (100k Gaussians, 512^2): size-independent properties instead of the oracle."""
     cam = camera_np(40.0, W=512, H=512)
