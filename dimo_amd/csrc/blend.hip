@@ -11,9 +11,10 @@
 // and only visits the records that can touch its 64 pixels.  The box is conservative, so results are
 // unchanged; at ~1e5 small splats per frame it removes most of the per-record rejection tests.
 //
-// Backward is free of global atomics: per (tile, instance) sums are reduced inside the workgroup
-// (DPP butterfly over the wave -> LDS) and written as ONE 64-byte record per instance at the
+// Backward is free of global atomics: per (tile, instance) sums are reduced inside the wave
+// (halving DPP butterfly -> LDS) and written as ONE 64-byte record per instance at the
 // instance's emission position, so that the per-Gaussian kernel can sum a contiguous run.
+// In the backward a wave owns a whole tile (four pixels per lane, one per quadrant): see blend_bwd_body.
 //
 // Backward work items are BUCKETS of 64 consecutive list entries, not tiles.  A tile's list is a sequential
 // recurrence (transmittance), a trained scene saturates after ~160 of ~1200 entries on average but after 550 on
@@ -26,12 +27,13 @@
 // the forward's own product (no division chain), and ~2700 equal-sized items replace ~800 unequal ones.
 #include "common.hpp"
 #include "wave_ops.hpp"
+#include <cstdlib>
 
 namespace dimo {
 
 constexpr int BLEND_BLOCK = 256;
 constexpr int BATCH = 256;
-constexpr int BWD_GRID = 4096;  // persistent workgroups looping over the (tile, bucket) items
+constexpr int BWD_GRID = 16384;  // persistent single-wave workgroups looping over the (tile, bucket) items
 
 __device__ __forceinline__ void pixel_of_thread(int tile_x, int tile_y, int &px, int &py) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -200,7 +202,20 @@ __device__ __forceinline__ void blend_fwd_body(
 
 // ---------------------------------------------------------------------------------- backward
 // (wave reduction helpers: wave_ops.hpp)
-template <bool NORMAL>
+//
+// ONE WAVE per (tile, bucket) item, four pixels per lane -- lane l owns pixel l of EACH 8x8 quadrant.  The 13
+// per-(record) sums are then accumulated over a lane's four pixels in registers and cross the wave ONCE per record
+// (one halving butterfly + one plain 16-lane LDS store: the wave is the only writer of its item), while quadrant
+// culling stays wave-uniform: a quadrant the record cannot reach, or whose pixels all stopped earlier, is skipped by
+// a scalar branch.  The previous layout (one workgroup per item, one wave per quadrant) paid the ~60-instruction
+// reduction once per visited QUADRANT -- 2.3 times per record on the C3 workload, more than the ~45 instructions of
+// the per-pixel evaluation itself.
+//
+// QPW = quadrants per wave: 4 -> one wave per item (the batched launches of the step executor, >= 10^4 items in
+// flight); 1 or 2 -> 4 or 2 waves per item, each with its own visit list and LDS float atomics into the shared
+// sums (a single render has ~2700 items for 1024 SIMDs: one wave per SIMD is latency bound, 0.185 ms against
+// 0.129 ms with four waves per item).
+template <bool NORMAL, int QPW>
 __device__ __forceinline__ void blend_bwd_body(
     int H, int W, int tiles_x, uint32_t R_cap, const uint32_t *__restrict__ ranges,
     const uint32_t *__restrict__ vals_sorted, const Splat *__restrict__ splat, const uint16_t *__restrict__ rect,
@@ -215,8 +230,10 @@ __device__ __forceinline__ void blend_bwd_body(
   __shared__ float s_nz[BUCKET];
   __shared__ uint32_t s_emit[BUCKET];
   __shared__ uint32_t s_mask[BUCKET];
-  __shared__ uint16_t s_list[BLEND_BLOCK / 64][BUCKET];
+  constexpr int WAVES = 4 / QPW;
+  __shared__ uint16_t s_list[WAVES][BUCKET];
   __shared__ float s_acc[BUCKET][16];
+  static_assert(BUCKET == 64, "one staged record per lane of the first wave");
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const size_t HW = (size_t)H * W;
@@ -228,95 +245,152 @@ __device__ __forceinline__ void blend_bwd_body(
     const int tile_x = tile % tiles_x, tile_y = tile / tiles_x;
     const uint32_t lo = ranges[2 * tile], hi = ranges[2 * tile + 1];
     const int count = (int)min((uint32_t)BUCKET, hi - lo - blo);
-    int px, py;
-    pixel_of_thread(tile_x, tile_y, px, py);
-    const bool inside = px < W && py < H;
-    const float pxf = (float)px, pyf = (float)py;
-    const size_t pix = (size_t)py * W + px;
+    const int bx = tile_x * TILE + (lane & 7), by = tile_y * TILE + (lane >> 3);
+    const float bxf = (float)bx, byf = (float)by;
+    const float *const ck_item = ckpt + ((size_t)(lo / BUCKET) + tile + blo / BUCKET) * (CKPT_FLOATS * TILE * TILE);
 
-    const uint32_t last = inside ? n_contrib[pix] : 0u;
-    float T = 0.0f, P = 0.0f, S = 0.0f;
-    float dp[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // dL/d{r,g,b,depth,nx,ny,nz,alpha} at this pixel
-    if (last > blo) {
-      if (dL_dcolor) dp[0] = dL_dcolor[pix], dp[1] = dL_dcolor[HW + pix], dp[2] = dL_dcolor[2 * HW + pix];
-      if (dL_ddepth) dp[3] = dL_ddepth[pix];
-      if (NORMAL && dL_dnormal) dp[4] = dL_dnormal[pix], dp[5] = dL_dnormal[HW + pix], dp[6] = dL_dnormal[2 * HW + pix];
-      if (dL_dalpha) dp[7] = dL_dalpha[pix];
-      const float *c = ckpt + ((size_t)(lo / BUCKET) + tile + blo / BUCKET) * (CKPT_FLOATS * TILE * TILE) + threadIdx.x;
-      T = c[0];
-      P = dp[7] * c[8 * TILE * TILE];
-      S = dp[7] * final_acc[7 * HW + pix] + final_T[pix] * (bg[0] * dp[0] + bg[1] * dp[1] + bg[2] * dp[2]);
+    // per-quadrant pixel state.  Every load is unconditional (clamped pixel index, substitute pointer for an absent
+    // gradient image) and the predicates are applied afterwards with selects: a branch around a load makes the
+    // compiler drain the whole memory queue at the join, which put ~16 dependent round trips in front of every item.
+    uint32_t last[QPW], deepest[QPW];
+    float T[QPW], SP[QPW], dp[QPW][8];  // SP = S - P: what the entries behind the current one still add
+    const float *const pc = dL_dcolor ? dL_dcolor : final_T, *const pd = dL_ddepth ? dL_ddepth : final_T;
+    const float *const pn = (NORMAL && dL_dnormal) ? dL_dnormal : final_T, *const pa = dL_dalpha ? dL_dalpha : final_T;
+    const float kc = dL_dcolor ? 1.0f : 0.0f, kd = dL_ddepth ? 1.0f : 0.0f;
+    const float kn = (NORMAL && dL_dnormal) ? 1.0f : 0.0f, ka = dL_dalpha ? 1.0f : 0.0f;
+    // 32-bit element offsets from wave-uniform base pointers (SGPR base + VGPR offset addressing: a 64-bit address
+    // pair per load is what overflowed the register file here)
+    const uint32_t HW32 = (uint32_t)HW;
+    const uint32_t HWc = dL_dcolor ? HW32 : 0u, HWn = (NORMAL && dL_dnormal) ? HW32 : 0u;
+    const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
+#pragma unroll
+    for (int q = 0; q < QPW; ++q) {
+      const int quad = wave * QPW + q;
+      const int px = bx + (quad & 1) * 8, py = by + (quad >> 1) * 8;
+      const bool inside = px < W && py < H;
+      const uint32_t pix = inside ? (uint32_t)py * (uint32_t)W + (uint32_t)px : 0u;
+      const uint32_t nc = n_contrib[pix];
+      const float *c = ck_item + (uint32_t)(quad * 64 + lane);  // the forward's thread index = quadrant * 64 + lane
+      float cv[9], fa[8];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) cv[k] = c[k * TILE * TILE];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) fa[k] = final_acc[(uint32_t)k * HW32 + pix];
+      const float fT = final_T[pix];
+      dp[q][0] = kc * pc[pix], dp[q][1] = kc * pc[HWc + pix], dp[q][2] = kc * pc[2u * HWc + pix];
+      dp[q][3] = kd * pd[pix];
+      dp[q][4] = kn * pn[pix], dp[q][5] = kn * pn[HWn + pix], dp[q][6] = kn * pn[2u * HWn + pix];
+      dp[q][7] = ka * pa[pix];
+      last[q] = inside ? nc : 0u;
+      const bool need = last[q] > blo;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) dp[q][k] = need ? dp[q][k] : 0.0f;
+      float P = dp[q][7] * cv[8];
+      float S = dp[q][7] * fa[7] + fT * (bg0 * dp[q][0] + bg1 * dp[q][1] + bg2 * dp[q][2]);
 #pragma unroll
       for (int k = 0; k < (NORMAL ? 7 : 4); ++k) {
-        P += dp[k] * c[(1 + k) * TILE * TILE];
-        S += dp[k] * final_acc[k * HW + pix];
+        P += dp[q][k] * cv[1 + k];
+        S += dp[q][k] * fa[k];
       }
-    }
-    // deepest entry any pixel of this wave still looks at
-    uint32_t wlast = last;
+      T[q] = need ? cv[0] : 0.0f;
+      SP[q] = need ? S - P : 0.0f;
+      // deepest entry any pixel of this quadrant still looks at (wave-uniform)
+      uint32_t m = last[q];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) wlast = max(wlast, (uint32_t)__shfl_xor((int)wlast, o, 64));
+      for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
+      deepest[q] = (uint32_t)__builtin_amdgcn_readfirstlane((int)m);
+      // one quadrant's ~27 loads in flight at a time: hoisting all four above the first use spills 48 registers
+      if (QPW == 4) __builtin_amdgcn_sched_barrier(0);
+    }
+    uint32_t wlast = deepest[0];
+#pragma unroll
+    for (int q = 1; q < QPW; ++q) wlast = max(wlast, deepest[q]);
 
     __syncthreads();  // previous item fully consumed
-    if ((int)threadIdx.x < count) {
-      const uint32_t g = vals_sorted[lo + blo + threadIdx.x];
+    if (wave == 0 && lane < count) {
+      const uint32_t g = vals_sorted[lo + blo + lane];
       const float4 *rp = reinterpret_cast<const float4 *>(splat + g);
       const float4 a = rp[0], b = rp[1];
-      s_geo[threadIdx.x] = a;
-      s_col[threadIdx.x] = b;
-      s_aux[threadIdx.x] = rp[2];
-      if (NORMAL) s_nz[threadIdx.x] = rp[3].x;
-      s_mask[threadIdx.x] = quadrant_mask(a.x, a.y, a.z, a.w, b.x, b.y, tile_x, tile_y);
+      s_geo[lane] = a;
+      s_col[lane] = b;
+      s_aux[lane] = rp[2];
+      if (NORMAL) s_nz[lane] = rp[3].x;
+      s_mask[lane] = quadrant_mask(a.x, a.y, a.z, a.w, b.x, b.y, tile_x, tile_y);
       const uint2 rc = *reinterpret_cast<const uint2 *>(rect + 4 * (size_t)g);
       const int x0 = rc.x & 0xffff, y0 = rc.x >> 16, x1 = rc.y & 0xffff;
-      s_emit[threadIdx.x] = (g == 0 ? 0u : offsets[g - 1]) + (uint32_t)((tile_y - y0) * (x1 - x0) + (tile_x - x0));
+      s_emit[lane] = (g == 0 ? 0u : offsets[g - 1]) + (uint32_t)((tile_y - y0) * (x1 - x0) + (tile_x - x0));
     }
-    reinterpret_cast<float4 *>(&s_acc[0][0])[threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < QPW; ++k)
+      reinterpret_cast<float4 *>(&s_acc[0][0])[k * (64 * WAVES) + threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
-    const int mine = compact_for_wave(s_mask, s_list[wave], count, wave, lane);
+    // ascending list of the records that can reach any pixel of this wave's quadrants
+    constexpr uint32_t QBITS = ((1u << QPW) - 1u);
+    int mine;
+    {
+      const bool hit = lane < count && ((s_mask[lane] >> (wave * QPW)) & QBITS) != 0u;
+      const unsigned long long bal = __ballot(hit);
+      if (hit) s_list[wave][__popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)lane;
+      mine = __popcll(bal);
+    }
+    __syncthreads();
 
-    // (no software pipelining here, unlike the forward: this loop is VALU-issue bound and the prefetch of the
-    // feature record for visits that turn out inactive cost more than the hidden latency returned: 142 -> 155 us)
     for (int t = 0; t < mine; ++t) {
       const int j = __builtin_amdgcn_readfirstlane((int)s_list[wave][t]);
-      if (blo + (uint32_t)j >= wlast) break;  // the list is ascending: nothing further reaches this wave
+      const uint32_t pos = blo + (uint32_t)j;
+      if (pos >= wlast) break;  // the list is ascending: nothing further reaches this tile
+      const uint32_t qm = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_mask[j]) >> (wave * QPW);
       const float4 g = s_geo[j];
       const float4 c = s_col[j];
-      const float dx = g.x - pxf, dy = g.y - pyf;
-      const float power = -0.5f * (g.z * dx * dx + c.x * dy * dy) - g.w * dx * dy;
-      const float G = __expf(power);
-      const float alpha = fminf(ALPHA_MAX, c.y * G);
-      const bool active = (blo + (uint32_t)j < last) && power <= 0.0f && alpha >= ALPHA_MIN;
-      if (__ballot(active) == 0) continue;  // wave-uniform skip
+      const float4 a = s_aux[j];
+      const float nz = NORMAL ? s_nz[j] : 0.0f;
+      const float dx0 = g.x - bxf - (float)(((wave * QPW) & 1) * 8), dy0 = g.y - byf - (float)(((wave * QPW) >> 1) * 8);
       float v[16];
 #pragma unroll
       for (int k = 0; k < 16; ++k) v[k] = 0.0f;
-      if (active) {
-        const float4 a = s_aux[j];
-        const float w = alpha * T;
-        float D = dp[7] + c.z * dp[0] + c.w * dp[1] + a.x * dp[2] + a.y * dp[3];
-        if (NORMAL) D += a.z * dp[4] + a.w * dp[5] + s_nz[j] * dp[6];
-        P += D * w;
-        const float dL_dalpha_i = D * T - (S - P) * __builtin_amdgcn_rcpf(1.0f - alpha);
-        T *= 1.0f - alpha;
-        const float gg = G * c.y * dL_dalpha_i;  // g = G * dL/dG, dL/dG = opacity * dL/dalpha
-        v[0] = gg, v[1] = gg * dx, v[2] = gg * dy;
-        v[3] = v[1] * dx, v[4] = v[1] * dy, v[5] = v[2] * dy;
-        v[6] = w * dp[0], v[7] = w * dp[1], v[8] = w * dp[2], v[9] = w * dp[3];
-        if (NORMAL) v[10] = w * dp[4], v[11] = w * dp[5], v[12] = w * dp[6];
+      bool any = false;
+#pragma unroll
+      for (int q = 0; q < QPW; ++q) {
+        if (!((qm >> q) & 1u) || pos >= deepest[q]) continue;  // wave-uniform
+        // (QPW = 2: wave 0 owns the top quadrants 0, 1 and wave 1 the bottom ones, so q only moves along x)
+        const float dx = dx0 - (float)((q & 1) * 8), dy = dy0 - (float)((QPW == 4 ? (q >> 1) : 0) * 8);
+        const float power = -0.5f * (g.z * dx * dx + c.x * dy * dy) - g.w * dx * dy;
+        const float G = __expf(power);
+        const float alpha = fminf(ALPHA_MAX, c.y * G);
+        const bool active = pos < last[q] && power <= 0.0f && alpha >= ALPHA_MIN;
+        if (__ballot(active) == 0) continue;  // wave-uniform skip
+        any = true;
+        if (active) {
+          const float w = alpha * T[q];
+          float D = dp[q][7] + c.z * dp[q][0] + c.w * dp[q][1] + a.x * dp[q][2] + a.y * dp[q][3];
+          if (NORMAL) D += a.z * dp[q][4] + a.w * dp[q][5] + nz * dp[q][6];
+          SP[q] -= D * w;
+          const float dL_dalpha_i = D * T[q] - SP[q] * __builtin_amdgcn_rcpf(1.0f - alpha);
+          T[q] *= 1.0f - alpha;
+          const float gg = G * c.y * dL_dalpha_i;  // g = G * dL/dG, dL/dG = opacity * dL/dalpha
+          const float gx = gg * dx, gy = gg * dy;
+          v[0] += gg, v[1] += gx, v[2] += gy;
+          v[3] += gx * dx, v[4] += gx * dy, v[5] += gy * dy;
+          v[6] += w * dp[q][0], v[7] += w * dp[q][1], v[8] += w * dp[q][2], v[9] += w * dp[q][3];
+          if (NORMAL) v[10] += w * dp[q][4], v[11] += w * dp[q][5], v[12] += w * dp[q][6];
+        }
       }
+      if (!any) continue;
       const float tot = butterfly16(v, lane);  // lanes 0..15: the wave total of value butterfly16_slot(lane)
-      if (lane < 16 && butterfly16_slot(lane) < 13) atomicAdd(&s_acc[j][butterfly16_slot(lane)], tot);
+      if (lane < 16) {
+        if (QPW == 4) s_acc[j][butterfly16_slot(lane)] = tot;  // this wave is the only writer of record j
+        else atomicAdd(&s_acc[j][butterfly16_slot(lane)], tot);
+      }
     }
     __syncthreads();
-    if ((int)threadIdx.x < count) {
-      const uint32_t e = s_emit[threadIdx.x];
-      const float4 *src = reinterpret_cast<const float4 *>(&s_acc[threadIdx.x][0]);
+    if (wave == 0 && lane < count) {
+      const uint32_t e = s_emit[lane];
+      const float4 *src = reinterpret_cast<const float4 *>(&s_acc[lane][0]);
       const float4 r0 = src[0], r1 = src[1], r2 = src[2], r3 = src[3];
-      const bool any = r0.x != 0.f || r0.y != 0.f || r0.z != 0.f || r0.w != 0.f || r1.x != 0.f || r1.y != 0.f ||
-                       r1.z != 0.f || r1.w != 0.f || r2.x != 0.f || r2.y != 0.f || r2.z != 0.f || r2.w != 0.f ||
-                       r3.x != 0.f;
-      if (e < R_cap && any) {
+      const bool nonzero = r0.x != 0.f || r0.y != 0.f || r0.z != 0.f || r0.w != 0.f || r1.x != 0.f || r1.y != 0.f ||
+                           r1.z != 0.f || r1.w != 0.f || r2.x != 0.f || r2.y != 0.f || r2.z != 0.f || r2.w != 0.f ||
+                           r3.x != 0.f;
+      if (e < R_cap && nonzero) {
         float4 *dst = reinterpret_cast<float4 *>(inst_grad + e);
         dst[0] = r0, dst[1] = r1, dst[2] = r2, dst[3] = r3;
         inst_flag[e] = 1;
@@ -336,8 +410,8 @@ __global__ void __launch_bounds__(BLEND_BLOCK) blend_fwd_kernel(
   blend_fwd_body<NORMAL>(H, W, tiles_x, ranges, vals_sorted, splat, bg, out_color, out_depth, out_normal, out_alpha,
                          final_T, n_contrib, final_acc, ckpt, work);
 }
-template <bool NORMAL>
-__global__ void __launch_bounds__(BLEND_BLOCK) blend_bwd_kernel(
+template <bool NORMAL, int QPW>
+__global__ void __launch_bounds__(256 / QPW, QPW == 4 ? 3 : 4) blend_bwd_kernel(
     int H, int W, int tiles_x, uint32_t R_cap, const uint32_t *__restrict__ ranges,
     const uint32_t *__restrict__ vals_sorted, const Splat *__restrict__ splat, const uint16_t *__restrict__ rect,
     const uint32_t *__restrict__ offsets, const float *__restrict__ bg, const float *__restrict__ final_T,
@@ -345,7 +419,7 @@ __global__ void __launch_bounds__(BLEND_BLOCK) blend_bwd_kernel(
     const uint32_t *__restrict__ work, const float *__restrict__ dL_dcolor, const float *__restrict__ dL_ddepth,
     const float *__restrict__ dL_dnormal, const float *__restrict__ dL_dalpha, SplatGrad *__restrict__ inst_grad,
     uint8_t *__restrict__ inst_flag) {
-  blend_bwd_body<NORMAL>(H, W, tiles_x, R_cap, ranges, vals_sorted, splat, rect, offsets, bg, final_T, n_contrib,
+  blend_bwd_body<NORMAL, QPW>(H, W, tiles_x, R_cap, ranges, vals_sorted, splat, rect, offsets, bg, final_T, n_contrib,
                          final_acc, ckpt, work, dL_dcolor, dL_ddepth, dL_dnormal, dL_dalpha, inst_grad, inst_flag);
 }
 
@@ -366,12 +440,12 @@ __global__ void __launch_bounds__(BLEND_BLOCK) blend_fwd_batched_kernel(int H, i
                          r.out_alpha, at<float>(r.img, o.final_T), at<uint32_t>(r.img, o.n_contrib),
                          at<float>(r.img, o.final_acc), at<float>(r.bin, o.ckpt), at<uint32_t>(r.bin, o.work));
 }
-template <bool NORMAL>
-__global__ void __launch_bounds__(BLEND_BLOCK) blend_bwd_batched_kernel(int H, int W, int tiles_x, uint32_t R_cap,
+template <bool NORMAL, int QPW>
+__global__ void __launch_bounds__(256 / QPW, QPW == 4 ? 3 : 4) blend_bwd_batched_kernel(int H, int W, int tiles_x, uint32_t R_cap,
                                                                         const float *__restrict__ bg, BlendOffsets o,
                                                                         RenderBatch b) {
   const dimo_render_desc &r = b.r[blockIdx.y];
-  blend_bwd_body<NORMAL>(H, W, tiles_x, R_cap, at<uint32_t>(r.bin, o.ranges), at<uint32_t>(r.bin, o.vals),
+  blend_bwd_body<NORMAL, QPW>(H, W, tiles_x, R_cap, at<uint32_t>(r.bin, o.ranges), at<uint32_t>(r.bin, o.vals),
                          at<Splat>(r.geom, o.splat), at<uint16_t>(r.geom, o.rect), at<uint32_t>(r.geom, o.offsets), bg,
                          at<float>(r.img, o.final_T), at<uint32_t>(r.img, o.n_contrib), at<float>(r.img, o.final_acc),
                          at<float>(r.bin, o.ckpt), at<uint32_t>(r.bin, o.work), r.g_color, r.g_depth,
@@ -384,6 +458,17 @@ __global__ void __launch_bounds__(256) clear_flags_batched_kernel(uint32_t R_cap
   const uint32_t R = min(*at<uint32_t>(r.geom, o.total), R_cap);
   const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 16;
   if (i < R) *reinterpret_cast<uint4 *>(at<uint8_t>(r.bwd_scratch, o.flag) + i) = make_uint4(0, 0, 0, 0);
+}
+
+// quadrants per wave of the backward for a launch over n renders (DIMO_BWD_QPW overrides, for experiments)
+static int bwd_quadrants_per_wave(int n) {
+  static const int forced = [] {
+    const char *e = getenv("DIMO_BWD_QPW");
+    const int v = e ? atoi(e) : 0;
+    return (v == 1 || v == 2 || v == 4) ? v : 0;
+  }();
+  if (forced) return forced;
+  return n >= 2 ? 4 : 2;
 }
 
 static BlendOffsets blend_offsets(const GeomLayout &G, const BinLayout &B, const ImgLayout &I) {
@@ -423,13 +508,23 @@ int blend_backward_batched(const dimo_step_common &c, const RenderBatch &b, int 
   ScopedTimer tm(T_BLEND_BWD, stream);
   hipLaunchKernelGGL(clear_flags_batched_kernel, dim3((unsigned)((B.cap / 16 + 255) / 256 + 1), n), dim3(256), 0,
                      stream, cap, o, b);
-  const int grid = (BWD_GRID + n - 1) / n < 512 ? 512 : (BWD_GRID + n - 1) / n;
-  if (c.with_normal)
-    hipLaunchKernelGGL(blend_bwd_batched_kernel<true>, dim3(grid, n), dim3(BLEND_BLOCK), 0, stream, c.H, c.W,
-                       B.tiles_x, cap, c.bg, o, b);
-  else
-    hipLaunchKernelGGL(blend_bwd_batched_kernel<false>, dim3(grid, n), dim3(BLEND_BLOCK), 0, stream, c.H, c.W,
-                       B.tiles_x, cap, c.bg, o, b);
+  // one wave per item when the batch supplies enough items to fill the chip, two waves per item for a lone render
+  const int qpw = bwd_quadrants_per_wave(n);
+  const int want = BWD_GRID * qpw / 4;
+  const int grid = (want + n - 1) / n < 2048 ? 2048 : (want + n - 1) / n;
+#define DIMO_LAUNCH_BWD_BATCHED(NORMAL, QPW)                                                                         \
+  hipLaunchKernelGGL((blend_bwd_batched_kernel<NORMAL, QPW>), dim3(grid, n), dim3(256 / QPW), 0, stream, c.H, c.W,   \
+                     B.tiles_x, cap, c.bg, o, b)
+  if (c.with_normal) {
+    if (qpw == 4) DIMO_LAUNCH_BWD_BATCHED(true, 4);
+    else if (qpw == 2) DIMO_LAUNCH_BWD_BATCHED(true, 2);
+    else DIMO_LAUNCH_BWD_BATCHED(true, 1);
+  } else {
+    if (qpw == 4) DIMO_LAUNCH_BWD_BATCHED(false, 4);
+    else if (qpw == 2) DIMO_LAUNCH_BWD_BATCHED(false, 2);
+    else DIMO_LAUNCH_BWD_BATCHED(false, 1);
+  }
+#undef DIMO_LAUNCH_BWD_BATCHED
   return check_launch();
 }
 
@@ -505,18 +600,24 @@ extern "C" int dimo_raster_backward(int N, int sh_degree, int M, int H, int W, i
   if (N > 0) {
     ScopedTimer tm(T_BLEND_BWD, stream);
     if (hipMemsetAsync(inst_flag, 0, B.cap, stream) != hipSuccess) return DIMO_E_LAUNCH;
-    if (dL_dnormal)
-      hipLaunchKernelGGL(blend_bwd_kernel<true>, dim3(BWD_GRID), dim3(BLEND_BLOCK), 0, stream, H, W, B.tiles_x, cap,
-                         at<uint32_t>(bin, B.ranges), at<uint32_t>(bin, B.vals_b), at<Splat>(geom, G.splat),
-                         at<uint16_t>(geom, G.rect), at<uint32_t>(geom, G.offsets), bg, at<float>(img, I.final_T),
-                         at<uint32_t>(img, I.n_contrib), at<float>(img, I.final_acc), at<float>(bin, B.ckpt),
-                         at<uint32_t>(bin, B.work), dL_dcolor, dL_ddepth, dL_dnormal, dL_dalpha, inst, inst_flag);
-    else
-      hipLaunchKernelGGL(blend_bwd_kernel<false>, dim3(BWD_GRID), dim3(BLEND_BLOCK), 0, stream, H, W, B.tiles_x, cap,
-                         at<uint32_t>(bin, B.ranges), at<uint32_t>(bin, B.vals_b), at<Splat>(geom, G.splat),
-                         at<uint16_t>(geom, G.rect), at<uint32_t>(geom, G.offsets), bg, at<float>(img, I.final_T),
-                         at<uint32_t>(img, I.n_contrib), at<float>(img, I.final_acc), at<float>(bin, B.ckpt),
-                         at<uint32_t>(bin, B.work), dL_dcolor, dL_ddepth, dL_dnormal, dL_dalpha, inst, inst_flag);
+    const int qpw = bwd_quadrants_per_wave(1);
+#define DIMO_LAUNCH_BWD(NORMAL, QPW)                                                                                 \
+  hipLaunchKernelGGL((blend_bwd_kernel<NORMAL, QPW>), dim3(BWD_GRID * QPW / 4), dim3(256 / QPW), 0, stream, H, W,    \
+                     B.tiles_x, cap, at<uint32_t>(bin, B.ranges), at<uint32_t>(bin, B.vals_b),                       \
+                     at<Splat>(geom, G.splat), at<uint16_t>(geom, G.rect), at<uint32_t>(geom, G.offsets), bg,        \
+                     at<float>(img, I.final_T), at<uint32_t>(img, I.n_contrib), at<float>(img, I.final_acc),         \
+                     at<float>(bin, B.ckpt), at<uint32_t>(bin, B.work), dL_dcolor, dL_ddepth, dL_dnormal, dL_dalpha, \
+                     inst, inst_flag)
+    if (dL_dnormal) {
+      if (qpw == 4) DIMO_LAUNCH_BWD(true, 4);
+      else if (qpw == 2) DIMO_LAUNCH_BWD(true, 2);
+      else DIMO_LAUNCH_BWD(true, 1);
+    } else {
+      if (qpw == 4) DIMO_LAUNCH_BWD(false, 4);
+      else if (qpw == 2) DIMO_LAUNCH_BWD(false, 2);
+      else DIMO_LAUNCH_BWD(false, 1);
+    }
+#undef DIMO_LAUNCH_BWD
     int rc = check_launch();
     if (rc) return rc;
   }

@@ -169,6 +169,10 @@ def test_executor_modes_agree(monkeypatch):
         res[mode] = (tr.last_loss.item(), g.flat_grads.clone(), g._xyz.grad.clone(), g._c_xyz.grad.clone())
     for mode in ("0", "-2"):
         assert abs(res[mode][0] - res["3"][0]) <= 1e-6 * abs(res["3"][0])
-        assert torch.allclose(res[mode][2], res["3"][2], rtol=1e-5, atol=1e-8), mode   # per-Gaussian: fixed order
+        # per-Gaussian gradients: the batched modes sum the two views of a (motion, frame) pair before the skinning
+        # backward and reduce a tile's pixels in one wave instead of two, so only the summation order differs
+        ref = res["3"][2]
+        assert torch.allclose(res[mode][2], ref, rtol=1e-3, atol=1e-5 * float(ref.abs().max())), mode
+        assert (res[mode][2] - ref).abs().sum() / ref.abs().sum() < 1e-5, mode
         rel = (res[mode][1] - res["3"][1]).abs().sum() / res["3"][1].abs().sum()
         assert rel < 1e-5, (mode, rel)
