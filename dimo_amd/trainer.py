@@ -373,7 +373,11 @@ class Trainer:
             dxyz_all, dquat_all, pair_of = self._deform_batch  # [P,M,3], [P,M,4], triple -> row
             dxyz_c, dquat_c = dxyz_all.detach().contiguous(), dquat_all.detach().contiguous()
         self._mark("timenet_fwd")
-        g_dxyz, g_dquat = torch.zeros_like(dxyz_c), torch.zeros_like(dquat_c)  # accumulated by the skinning backward
+        # accumulated by the skinning backward; one zero-fill for both and for the loss accumulator
+        o_q = (dxyz_c.numel() + 3) // 4 * 4  # 16-byte aligned start of the quaternion rows
+        zeroed = torch.zeros(o_q + dquat_c.numel() + 4, **f32)
+        g_dxyz = zeroed[:dxyz_c.numel()].view_as(dxyz_c)
+        g_dquat = zeroed[o_q:o_q + dquat_c.numel()].view_as(dquat_c)
         by_motion = {}
         for t in mine:
             by_motion.setdefault(t[0], []).append(t)
@@ -408,15 +412,18 @@ class Trainer:
         for w_ in ex.total_words(n):
             self.renderer.capacity.track(w_)
 
-        loss_accum = torch.zeros(1, **f32)
+        loss_accum = zeroed[-4:-3]
         ssim_terms, keep = [], []
+        # the target batches are gathered while the renders are still in flight (before the joins below)
+        gathered = {}
+        for m, trs in by_motion.items():
+            gts = [self.targets.get(*t) for t in trs]
+            gathered[m] = (torch.stack([x[0] for x in gts]), gts[0][1])
         for m, trs in by_motion.items():
             B = len(trs)
             img, depth, normal, alpha = bufs[m]
             ex.join(first[m], B)  # only this motion's renders: the other motions keep rendering underneath
-            gts = [self.targets.get(*t) for t in trs]
-            gt = torch.stack([x[0] for x in gts])
-            mask = gts[0][1]
+            gt, mask = gathered[m]
             share = B / n_img
             # SSIM on the clamped render; its gradient image feeds the loss kernel
             ssum = torch.empty(1, **f32)
