@@ -43,6 +43,7 @@ _SIGNATURES = {
     "dimo_deform_backward": (C.c_int, [C.c_int] * 4 + [c_ptr] * 22 + [c_ptr, C.c_size_t, c_ptr]),
     "dimo_ssim_forward": (C.c_int, [C.c_int] * 5 + [c_ptr] * 5),
     "dimo_ssim_backward": (C.c_int, [C.c_int] * 5 + [c_ptr] * 6),
+    "dimo_ssim_forward_backward": (C.c_int, [C.c_int] * 5 + [c_ptr] * 6),
     "dimo_timenet_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
     "dimo_timenet_forward": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_ptr, C.c_void_p, c_ptr, C.c_void_p, c_ptr, c_ptr,
                                        c_ptr, C.c_size_t, c_ptr]),

@@ -198,6 +198,132 @@ __global__ void __launch_bounds__(256) ssim_bwd_kernel(int H, int W, int n_plane
   }
 }
 
+
+// ---- forward value + gradient in ONE launch ----------------------------------------------------------------------
+// The training loss needs both the SSIM mean and dL/dimg1 of every batch, and the gradient's upstream factor is a
+// constant (-lambda / numel), so nothing forces the three derivative planes through HBM (3 planes written, then read
+// back with their halos: 76 MB per 4 x 3 x 512^2 batch).  A workgroup computes the window statistics on the 42x42
+// halo of its 32x32 tile from a 52x52 input halo (2.6x the pixels, all VALU), keeps the derivative planes in LDS,
+// and applies the window a second time.  Positions outside the image carry zero derivatives (the zero padding of
+// the backward convolution).
+constexpr int IS = HS + 2 * SR;  // 52: input halo edge
+__global__ void __launch_bounds__(256) ssim_fused_kernel(int H, int W, int n_planes, int clamp1, Window win,
+                                                         const float *__restrict__ img1,
+                                                         const float *__restrict__ img2,
+                                                         const float *__restrict__ dL_dmean, float inv_numel,
+                                                         float *__restrict__ ssim_sum, float *__restrict__ dL_dimg1) {
+  __shared__ float s_x[IS][IS + 1];
+  __shared__ float s_y[IS][IS + 1];
+  __shared__ float s_h[IS][HS + 1];      // horizontally filtered map (52 x 42); reused as 42 x 32 in the second pass
+  __shared__ float s_p[3][HS][HS + 1];   // derivative planes on the halo
+  __shared__ float s_red[4];
+  const int tid = threadIdx.x;
+  const int tiles_x = (W + TS - 1) / TS, tiles_y = (H + TS - 1) / TS;
+  const int total_tiles = tiles_x * tiles_y * n_planes;
+  const float scale = dL_dmean[0] * inv_numel;
+  // first pass, horizontal: 52 rows x 3 groups of 14 columns; vertical: 42 columns x 6 groups of 7 rows
+  const bool h1 = tid < IS * 3;
+  const int h1_row = h1 ? tid / 3 : 0, h1_c0 = (tid % 3) * 14;
+  const bool v1 = tid < HS * 6;
+  const int v1_c = v1 ? tid % HS : 0, v1_r0 = v1 ? (tid / HS) * 7 : 0;
+  // second pass (as ssim_bwd_kernel): horizontal 42 rows x 4 groups of 8; vertical column c, rows r0 .. r0 + 3
+  const bool h2 = tid < HS * (TS / 8);
+  const int h2_row = h2 ? tid / (TS / 8) : 0, h2_c0 = (tid % (TS / 8)) * 8;
+  const int c = tid & (TS - 1), r0 = (tid >> 5) * 4;
+  float m_acc = 0.0f;
+  for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
+    const int plane = tile / (tiles_x * tiles_y);
+    const int x0 = (tile % tiles_x) * TS, y0 = ((tile / tiles_x) % tiles_y) * TS;
+    const float *p1 = img1 + (size_t)plane * H * W;
+    const float *p2 = img2 + (size_t)plane * H * W;
+    __syncthreads();  // the previous tile's LDS has been consumed
+    for (int t = tid; t < IS * IS; t += 256) {
+      const int hy = t / IS, hx = t - hy * IS;
+      const int gy = y0 + hy - 2 * SR, gx = x0 + hx - 2 * SR;
+      const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+      const size_t o = in ? (size_t)gy * W + gx : 0;
+      const float a = p1[o], b = p2[o];
+      s_x[hy][hx] = in ? maybe_clamp(a, clamp1) : 0.0f;
+      s_y[hy][hx] = in ? b : 0.0f;
+    }
+    __syncthreads();
+    float x[24], y[24];
+#pragma unroll
+    for (int i = 0; i < 24; ++i) x[i] = s_x[h1_row][h1_c0 + i], y[i] = s_y[h1_row][h1_c0 + i];
+    float st[5][7];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {  // maps: x, y, x^2, y^2, x y
+      if (h1) {
+        float v[24], o[14];
+#pragma unroll
+        for (int i = 0; i < 24; ++i) v[i] = q == 0 ? x[i] : q == 1 ? y[i] : q == 2 ? x[i] * x[i] : q == 3 ? y[i] * y[i] : x[i] * y[i];
+        taps<14, 24>(win, v, o);
+#pragma unroll
+        for (int i = 0; i < 14; ++i) s_h[h1_row][h1_c0 + i] = o[i];
+      }
+      __syncthreads();
+      float col[17];
+#pragma unroll
+      for (int i = 0; i < 17; ++i) col[i] = s_h[v1_r0 + i][v1_c];
+      taps<7, 17>(win, col, st[q]);
+      __syncthreads();
+    }
+    if (v1) {
+      const int gx = x0 + v1_c - SR;
+#pragma unroll
+      for (int i = 0; i < 7; ++i) {
+        const int hy = v1_r0 + i, gy = y0 + hy - SR;
+        const bool in = gx >= 0 && gx < W && gy >= 0 && gy < H;
+        const float mu1 = st[0][i], mu2 = st[1][i], e11 = st[2][i], e22 = st[3][i], e12 = st[4][i];
+        const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
+        const float s1 = e11 - mu1_sq, s2 = e22 - mu2_sq, s12 = e12 - mu12;
+        const float A1 = 2.0f * mu12 + SSIM_C1, A2 = 2.0f * s12 + SSIM_C2;
+        const float B1 = mu1_sq + mu2_sq + SSIM_C1, B2 = s1 + s2 + SSIM_C2;
+        const float inv = 1.0f / (B1 * B2);
+        const float m = A1 * A2 * inv;
+        const bool own = hy >= SR && hy < SR + TS && v1_c >= SR && v1_c < SR + TS;  // this tile's 32 x 32 outputs
+        if (in && own) m_acc += m;
+        s_p[0][hy][v1_c] = in ? (2.0f * mu2 * (A2 - A1) - m * 2.0f * mu1 * (B2 - B1)) * inv : 0.0f;
+        s_p[1][hy][v1_c] = in ? -m / B2 : 0.0f;
+        s_p[2][hy][v1_c] = in ? 2.0f * A1 * inv : 0.0f;
+      }
+    }
+    float g[3][4];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      __syncthreads();  // s_p complete (q = 0) / s_h free again
+      if (h2) {
+        float v[18], o[8];
+#pragma unroll
+        for (int i = 0; i < 18; ++i) v[i] = s_p[q][h2_row][h2_c0 + i];
+        taps<8, 18>(win, v, o);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s_h[h2_row][h2_c0 + i] = o[i];
+      }
+      __syncthreads();
+      float col[14];
+#pragma unroll
+      for (int i = 0; i < 14; ++i) col[i] = s_h[r0 + i][c];
+      taps<4, 14>(win, col, g[q]);
+    }
+    const int gx = x0 + c;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int gy = y0 + r0 + i;
+      if (gx < W && gy < H) {
+        const float xv = s_x[r0 + i + 2 * SR][c + 2 * SR], yv = s_y[r0 + i + 2 * SR][c + 2 * SR];
+        dL_dimg1[(size_t)plane * H * W + (size_t)gy * W + gx] = (g[0][i] + 2.0f * xv * g[1][i] + yv * g[2][i]) * scale;
+      }
+    }
+  }  // tiles
+  float v = m_acc;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  if ((tid & 63) == 0) s_red[tid >> 6] = v;
+  __syncthreads();
+  if (tid == 0) atomicAdd(ssim_sum, s_red[0] + s_red[1] + s_red[2] + s_red[3]);
+}
+
 }  // namespace dimo
 
 using namespace dimo;
@@ -234,5 +360,24 @@ extern "C" int dimo_ssim_backward(int B, int C, int H, int W, int clamp_img1, co
   ScopedTimer tm(T_SSIM_BWD, stream);
   hipLaunchKernelGGL(ssim_bwd_kernel, grid, block, 0, stream, H, W, (int)planes, clamp_img1, win, img1, img2, partials,
                      (size_t)planes * H * W, dL_dmean, 1.0f / (float)((double)planes * H * W), dL_dimg1);
+  return check_launch();
+}
+
+extern "C" int dimo_ssim_forward_backward(int B, int C, int H, int W, int clamp_img1, const float *img1,
+                                          const float *img2, const float *dL_dmean, float *ssim_sum, float *dL_dimg1,
+                                          void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  clear_errors();
+  if (B < 0 || C < 0 || H <= 0 || W <= 0 || !ssim_sum) return DIMO_E_ARG;
+  if (hipMemsetAsync(ssim_sum, 0, sizeof(float), stream) != hipSuccess) return DIMO_E_LAUNCH;
+  const long planes = (long)B * C;
+  if (planes == 0) return DIMO_OK;
+  if (!img1 || !img2 || !dL_dmean || !dL_dimg1 || planes > 65535) return DIMO_E_ARG;
+  static const Window win = make_window();
+  const long tiles = (long)((W + TS - 1) / TS) * ((H + TS - 1) / TS) * planes;
+  const dim3 grid((unsigned)(tiles < 4096 ? tiles : 4096)), block(256);
+  ScopedTimer tm(T_SSIM_FWD, stream);
+  hipLaunchKernelGGL(ssim_fused_kernel, grid, block, 0, stream, H, W, (int)planes, clamp_img1, win, img1, img2,
+                     dL_dmean, 1.0f / (float)((double)planes * H * W), ssim_sum, dL_dimg1);
   return check_launch();
 }

@@ -427,13 +427,11 @@ class Trainer:
             share = B / n_img
             # SSIM on the clamped render; its gradient image feeds the loss kernel
             ssum = torch.empty(1, **f32)
-            partials = torch.empty(3, B, 3, H, W, **f32)
-            _lib.check(L.dimo_ssim_forward(B, 3, H, W, 1, _lib.ptr(img), _lib.ptr(gt), _lib.ptr(ssum),
-                                           _lib.ptr(partials), stream), "dimo_ssim_forward")
             coef = self._const(-c.lambda_ssim * share)
             ssim_grad = torch.empty(B, 3, H, W, **f32)
-            _lib.check(L.dimo_ssim_backward(B, 3, H, W, 1, _lib.ptr(img), _lib.ptr(gt), _lib.ptr(partials),
-                                            _lib.ptr(coef), _lib.ptr(ssim_grad), stream), "dimo_ssim_backward")
+            _lib.check(L.dimo_ssim_forward_backward(B, 3, H, W, 1, _lib.ptr(img), _lib.ptr(gt), _lib.ptr(coef),
+                                                    _lib.ptr(ssum), _lib.ptr(ssim_grad), stream),
+                       "dimo_ssim_forward_backward")
             ssim_terms.append((ssum, c.lambda_ssim * share, float(B * 3 * H * W)))
             w_mse = [c.lambda_mse * (1.0 if (v == 0 or f == 0) else 0.5) / (3 * H * W) for (_m, v, f) in trs]
             gi, gd, gn, ga = fused_image_loss(img, depth if c.add_depth else None, normal if c.add_normal else None,

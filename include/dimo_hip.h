@@ -153,6 +153,12 @@ int dimo_ssim_forward(int B, int C, int H, int W, int clamp_img1, const float *i
 int dimo_ssim_backward(int B, int C, int H, int W, int clamp_img1, const float *img1, const float *img2,
                        const float *partials, const float *dL_dmean /* 1 float, device */, float *dL_dimg1,
                        void *stream);
+/* Value and gradient in one launch (the training loss always needs both, main_train_dimo.py:343 + :415): ssim_sum as
+ * dimo_ssim_forward, dL_dimg1 as dimo_ssim_backward with upstream dL_dmean -- the derivative planes never leave the
+ * chip (each workgroup recomputes them on its tile's halo). */
+int dimo_ssim_forward_backward(int B, int C, int H, int W, int clamp_img1, const float *img1, const float *img2,
+                               const float *dL_dmean /* 1 float, device */, float *ssim_sum, float *dL_dimg1,
+                               void *stream);
 
 /* ------------------------------------------------------------------ fused image losses + their gradients
  * One motion's batch of B <= 64 renders (main_train_dimo.py:331-372, src/loss.py:64-106):

@@ -82,6 +82,27 @@ def test_ssim_against_torch_conv(shape):
     assert (gs - gr).abs().sum() / gr.abs().sum() < 1e-3
 
 
+@pytest.mark.parametrize("shape,clamp", [((4, 3, 96, 130), 1), ((2, 3, 512, 512), 0), ((1, 1, 7, 9), 1)])
+def test_ssim_one_launch_equals_forward_then_backward(shape, clamp):
+    """dimo_ssim_forward_backward (derivative planes kept on chip) against dimo_ssim_forward + dimo_ssim_backward."""
+    from dimo_amd import _lib
+    L, st = _lib.lib(), _lib.current_stream()
+    B, C, H, W = shape
+    g = torch.Generator().manual_seed(H)
+    a = (torch.rand(shape, generator=g) * 1.4 - 0.2).cuda()  # some values outside [0, 1]: the clamp path matters
+    b = torch.rand(shape, generator=g).cuda()
+    coef = torch.tensor([-0.37], device="cuda")
+    s2, part, g2 = torch.empty(1, device="cuda"), torch.empty(3, *shape, device="cuda"), torch.empty(shape, device="cuda")
+    _lib.check(L.dimo_ssim_forward(B, C, H, W, clamp, _lib.ptr(a), _lib.ptr(b), _lib.ptr(s2), _lib.ptr(part), st), "f")
+    _lib.check(L.dimo_ssim_backward(B, C, H, W, clamp, _lib.ptr(a), _lib.ptr(b), _lib.ptr(part), _lib.ptr(coef),
+                                    _lib.ptr(g2), st), "b")
+    s1, g1 = torch.empty(1, device="cuda"), torch.empty(shape, device="cuda")
+    _lib.check(L.dimo_ssim_forward_backward(B, C, H, W, clamp, _lib.ptr(a), _lib.ptr(b), _lib.ptr(coef), _lib.ptr(s1),
+                                            _lib.ptr(g1), st), "fb")
+    assert abs(s1.item() - s2.item()) <= 1e-5 * abs(s2.item())
+    assert (g1 - g2).abs().max() <= 1e-6 * g2.abs().max() + 1e-12
+
+
 def test_flat_adam_matches_torch_adam_and_skip_flag():
     """FlatAdam (one HIP launch over the flat bucket) vs torch.optim.Adam with per-group learning rates."""
     from dimo_amd.flat_adam import FlatAdam
