@@ -11,14 +11,65 @@
 
 namespace dimo {
 
-constexpr int KNN_BLOCK = 256;
-constexpr int KNN_CHUNK = 2048;  // reference points staged per LDS round (24 KiB)
+constexpr int KNN_BLOCK = 64;     // one wave per workgroup: 1563 workgroups for 1e5 queries keep 256 CUs evenly loaded
+constexpr int KNN_CHUNK = 1024;   // reference points staged per LDS round (16 KiB as float4)
+
+// K = 4 (DIMO's setting): the four best (distance, index) pairs live as four 64-bit keys
+//     key = (bits of d2) << 32 | index
+// reinterpreted as doubles.  d2 >= 0, so the float's bit pattern orders like the number, the index in the low word
+// breaks ties towards the lower index (the reference's strict '<' in ascending index order), and every such pattern
+// is a finite non-negative double (a zero distance gives a subnormal, which v_min/max_f64 order correctly; f64
+// denormals are never flushed on gfx9).  Inserting a candidate is then a branch-free 7-instruction min/max chain
+// instead of a divergent compare-and-swap ladder.
+__global__ void __launch_bounds__(KNN_BLOCK) knn4_kernel(int M, int N, int k, const float *__restrict__ ref,
+                                                         const float *__restrict__ query, float *__restrict__ dist,
+                                                         int64_t *__restrict__ idx) {
+  __shared__ float4 s_ref[KNN_CHUNK];
+  const int i = blockIdx.x * KNN_BLOCK + threadIdx.x;
+  float qx = 0, qy = 0, qz = 0;
+  if (i < N) qx = query[3 * i], qy = query[3 * i + 1], qz = query[3 * i + 2];
+  const double empty = __longlong_as_double((long long)(((unsigned long long)__float_as_uint(INFINITY) << 32) | 0xffffffffull));
+  double b0 = empty, b1 = empty, b2 = empty, b3 = empty;
+  for (int base = 0; base < M; base += KNN_CHUNK) {
+    const int cnt = min(KNN_CHUNK, M - base);
+    __syncthreads();
+    for (int t = threadIdx.x; t < cnt; t += KNN_BLOCK) {
+      const float *r = ref + (size_t)(base + t) * 3;
+      s_ref[t] = make_float4(r[0], r[1], r[2], 0.0f);
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int m = 0; m < cnt; ++m) {
+      const float4 c = s_ref[m];
+      const float dx = qx - c.x, dy = qy - c.y, dz = qz - c.z;
+      const float d2 = dx * dx + dy * dy + dz * dz;
+      const double key = __hiloint2double((int)__float_as_uint(d2), base + m);
+      const double r0 = fmax(b0, key);
+      b0 = fmin(b0, key);
+      const double r1 = fmax(b1, r0);
+      b1 = fmin(b1, r0);
+      const double r2 = fmax(b2, r1);
+      b2 = fmin(b2, r1);
+      b3 = fmin(b3, r2);
+    }
+  }
+  if (i < N) {
+    const double b[4] = {b0, b1, b2, b3};
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (j < k) {
+        const int lo = __double2loint(b[j]);
+        dist[(size_t)i * k + j] = sqrtf(__uint_as_float((unsigned)__double2hiint(b[j])));
+        idx[(size_t)i * k + j] = (int64_t)(lo == -1 && __double2hiint(b[j]) == (int)__float_as_uint(INFINITY) ? -1 : lo);
+      }
+  }
+}
 
 template <int K>
 __global__ void __launch_bounds__(KNN_BLOCK) knn_kernel(int M, int N, int k, const float *__restrict__ ref,
                                                         const float *__restrict__ query, float *__restrict__ dist,
                                                         int64_t *__restrict__ idx) {
-  __shared__ float s_ref[KNN_CHUNK * 3];
+  __shared__ float4 s_ref[KNN_CHUNK];
   const int i = blockIdx.x * KNN_BLOCK + threadIdx.x;
   float qx = 0, qy = 0, qz = 0;
   if (i < N) qx = query[3 * i], qy = query[3 * i + 1], qz = query[3 * i + 2];
@@ -30,10 +81,14 @@ __global__ void __launch_bounds__(KNN_BLOCK) knn_kernel(int M, int N, int k, con
   for (int base = 0; base < M; base += KNN_CHUNK) {
     const int cnt = min(KNN_CHUNK, M - base);
     __syncthreads();
-    for (int t = threadIdx.x; t < cnt * 3; t += KNN_BLOCK) s_ref[t] = ref[(size_t)base * 3 + t];
+    for (int t = threadIdx.x; t < cnt; t += KNN_BLOCK) {
+      const float *r = ref + (size_t)(base + t) * 3;
+      s_ref[t] = make_float4(r[0], r[1], r[2], 0.0f);
+    }
     __syncthreads();
     for (int m = 0; m < cnt; ++m) {
-      const float dx = qx - s_ref[3 * m], dy = qy - s_ref[3 * m + 1], dz = qz - s_ref[3 * m + 2];
+      const float4 c = s_ref[m];
+      const float dx = qx - c.x, dy = qy - c.y, dz = qz - c.z;
       const float d2 = dx * dx + dy * dy + dz * dz;
       if (d2 < bd[K - 1]) {
         // insertion keeping ascending order; strict '<' => ties keep the lower index first
@@ -102,7 +157,7 @@ extern "C" int dimo_knn(int M, int N, int k, const float *ref, const float *quer
   const dim3 grid((N + KNN_BLOCK - 1) / KNN_BLOCK), block(KNN_BLOCK);
   ScopedTimer tm(T_KNN, stream);
   if (k <= 4)
-    hipLaunchKernelGGL(knn_kernel<4>, grid, block, 0, stream, M, N, k, ref, query, dist, idx);
+    hipLaunchKernelGGL(knn4_kernel, grid, block, 0, stream, M, N, k, ref, query, dist, idx);
   else if (k <= 8)
     hipLaunchKernelGGL(knn_kernel<8>, grid, block, 0, stream, M, N, k, ref, query, dist, idx);
   else
