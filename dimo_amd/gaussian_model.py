@@ -231,6 +231,13 @@ class GaussianModel(DensifyMixin, PlyMixin):
                 p.data = flat[o:o + n].view(p.shape)
                 p.grad = grads[o:o + n].view(p.shape)
                 o += pad4(n)
+        # the per-Gaussian groups lead the bucket: [0, flat_split) is final as soon as the last skinning backward has
+        # accumulated, before the TimeNet backward runs (Trainer overlaps that part's all-reduce with it)
+        self.flat_split = 0
+        for g in groups:
+            if g.get("name") not in ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation"):
+                break
+            self.flat_split += sum(pad4(p.numel()) for p in g["params"] if p.numel() > 0)
         self.flat_params, self.flat_grads = flat, grads
         return flat, grads
 

@@ -299,9 +299,28 @@ class Trainer:
         return None
 
     def all_reduce_grads(self):
-        """ONE collective per step: the flat gradient bucket (+ its 4-float tail carrying the overflow flag)."""
+        """The step's collective: the flat gradient bucket (+ its 4-float tail carrying the overflow flag), SUM.
+        When `all_reduce_point_grads_async` already sent the per-Gaussian head of the bucket (5.6 of 8.2 MB at
+        N = 100 k) under the TimeNet backward, only the tail is left here."""
         if self.world > 1:
-            dist.all_reduce(self.renderer.gaussians.flat_grads_ext, op=dist.ReduceOp.SUM, group=self.pg)
+            ext = self.renderer.gaussians.flat_grads_ext
+            pending, self._pending_ar = getattr(self, "_pending_ar", None), None
+            if pending is not None:
+                work, split = pending
+                dist.all_reduce(ext[split:], op=dist.ReduceOp.SUM, group=self.pg)
+                work.wait()
+            else:
+                dist.all_reduce(ext, op=dist.ReduceOp.SUM, group=self.pg)
+
+    def all_reduce_point_grads_async(self):
+        """Starts the all-reduce of the per-Gaussian gradients (the head of the bucket) as soon as the last skinning
+        backward has accumulated into them; it runs on the collective library's stream while this stream goes on
+        with the TimeNet backward.  `all_reduce_grads` completes the step's reduction."""
+        g = self.renderer.gaussians
+        split = getattr(g, "flat_split", 0)
+        if self.world > 1 and self._flat_adam and split > 0:
+            work = dist.all_reduce(g.flat_grads_ext[:split], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+            self._pending_ar = (work, split)
 
     # ------------------------------------------------------------------ forward + backward, two ways
     def _forward_backward_autograd(self, mine, n_img):
@@ -462,6 +481,7 @@ class Trainer:
             for m, trs in by_motion.items():
                 ex.backward_accumulate(first[m], len(trs))
         self._mark("raster_bwd+skinning_bwd")
+        self.all_reduce_point_grads_async()
         # TimeNet backward for all renders at once
         if mine and fused_tn:
             if lat is not None:  # VAE latents: re-parameterised rows, their gradient continues through autograd
