@@ -16,6 +16,9 @@
 // with every SIMD of the chip busy; HBM and LDS traffic are far from binding, global-load latency is what remains.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+#include <type_traits>
+
 #include "common.hpp"
 #include "../../include/dimo_hip.h"
 
@@ -379,11 +382,256 @@ __global__ void head_out_bwd_kernel(int rows, int Wd, const float *__restrict__ 
   dzr[idx] = hr[idx] > 0.f ? vr : 0.f;
 }
 
+// ---- the whole forward in ONE launch (W = 256 nets) -------------------------------------------------------------
+// Activation-stationary: a workgroup (8 waves) owns 16 rows and walks them through every layer; the activations stay
+// in LDS (written to the workspace as well, for the backward), only the weights stream in, straight from L2 into the
+// MFMA B operand.  128 workgroups x 8 waves = one wave per SIMD of the chip for the 2048-row step batch, and the
+// chain of D + 3 dependent launches (each a global-load -> LDS -> barrier -> MFMA pipeline that starts cold) becomes
+// one.
+//
+// Operand mapping of v_mfma_f32_16x16x4_f32 (A[m = lane % 16][k = lane / 16], B[k = lane / 16][n = lane % 16]): for a
+// block of 16 k values, lane (kq, m) fetches ONE float4 X[m][k0 + 4 kq .. + 3] from LDS and lane (kq, n) ONE float4
+// W[n][k0 + 4 kq .. + 3] from global memory; component i of both feeds MFMA i of the block, which therefore contracts
+// k0 + {i, 4 + i, 8 + i, 12 + i} -- a permutation of the block's k values, i.e. the same sum.
+constexpr int FR = 16;           // rows per workgroup
+constexpr int FW = 256;          // hidden width: 8 waves x 32 columns
+constexpr int FH_LD = FW + 4;    // leading dimensions of the LDS tiles: 4 x odd floats (16-byte rows, spread banks)
+constexpr int FE_MAX = 128;      // embedding columns kept in LDS (zero padded: FPF whole blocks, see embed_blocks)
+constexpr int FC_LD = FE_MAX + 4;
+constexpr int FPF = 8;           // weight blocks in flight per wave; every layer's block count is a multiple of it,
+                                 // so the register ring lines up across layer boundaries
+__host__ __device__ constexpr int embed_blocks(int) { return FE_MAX / 16; }  // one whole chunk (fused_chunk)
+static_assert((FE_MAX / 16) % FPF == 0, "the embedding chunk is a whole number of rings");
+static_assert((FW / 16) % FPF == 0, "hidden blocks per layer must be a multiple of the ring depth");
+
+struct FusedArgs {
+  int R, Mc, E, CAT, D, skip, pts_freqs, time_freqs, latent_dim;
+  const float *c_xyz, *latent_table;
+  const float *W[MAX_LAYERS], *b[MAX_LAYERS];
+  const float *Wp[MAX_LAYERS];  // packed copies of the hidden layers' weights (pack_weights_kernel)
+  float *cat, *act[MAX_LAYERS], *hp, *hr, *d_xyz, *d_rot;
+  int act_ld[MAX_LAYERS];
+  PairTable pt;
+};
+
+// Packed weights: the B operand of one (16 columns x 16 k) MFMA block is 64 lanes x float4; stored in that order
+// (block (nt, kb) at ((nt * nkb + kb) * 64 + lane) float4s) a wave's load is ONE contiguous KiB.  Straight from the
+// row-major matrix the same load touches 16 rows 1 KiB (or 1.4 KiB) apart -- a handful of L2 channels for the
+// whole chip, which reads the same weights at the same time; the layers then ran at the speed of those channels
+// (9 us per 256 x 256 layer, fused or not).  Segments ([embedding | hidden] of the skip layer) are padded to whole
+// 16-k blocks with zeros.  Repacked every step (the weights have just been updated): 0.7 M floats.
+struct PackJob {
+  const float *W;   // [256][ldw]
+  float *out;
+  int ldw, E_seg, H_seg, nkb;  // columns of the embedding / hidden segment, k blocks per column tile
+};
+struct PackArgs {
+  PackJob job[MAX_LAYERS];
+  int njobs;
+};
+__global__ __launch_bounds__(256) void pack_weights_kernel(PackArgs a) {
+  const PackJob &j = a.job[blockIdx.y];
+  const int nE = j.E_seg ? embed_blocks(j.E_seg) : 0;
+  const int total = (FW / 16) * j.nkb * 64;  // float4s
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const int lane = i & 63, blk = i >> 6;
+    const int kb = blk % j.nkb, nt = blk / j.nkb;
+    const int kq = lane >> 4, mn = lane & 15;
+    // column of this float4 inside its segment, and the segment's first column / length
+    const bool emb = kb < nE;
+    const int kseg = 16 * (emb ? kb : kb - nE) + 4 * kq;
+    const int seg0 = emb ? 0 : j.E_seg, seglen = emb ? j.E_seg : j.H_seg;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (kseg + 3 < seglen) v = *reinterpret_cast<const float4 *>(j.W + (size_t)(nt * 16 + mn) * j.ldw + seg0 + kseg);
+    reinterpret_cast<float4 *>(j.out)[i] = v;
+  }
+}
+
+// The layers of the fused forward as one stream of weight blocks per wave: the FPF-deep register ring of B operands
+// runs ACROSS layer boundaries (the first blocks of layer l + 1 are requested before layer l's epilogue and barrier:
+// weights do not depend on activations), so a layer never starts with a cold memory pipeline.
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() is a workgroup-scope fence over ALL address spaces:
+// on gfx9 that is s_waitcnt vmcnt(0) as well, i.e. every layer would wait for its activation stores to reach L2 and
+// for the NEXT layer's prefetched weights before any wave may go on.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+struct WaveWeights {
+  const float4 *w0, *w1;  // this lane's float4 of block 0 of the wave's two column tiles
+  int nE, nkb;            // embedding blocks (A from the embedding tile), blocks in all
+};
+__device__ __forceinline__ WaveWeights wave_weights(const float *packed, int E, bool use_embed, bool use_hidden,
+                                                    int wave, int lane) {
+  WaveWeights w;
+  w.nE = use_embed ? embed_blocks(E) : 0;
+  w.nkb = w.nE + (use_hidden ? FW / 16 : 0);
+  w.w0 = reinterpret_cast<const float4 *>(packed) + (size_t)(2 * wave) * w.nkb * 64 + lane;
+  w.w1 = w.w0 + (size_t)w.nkb * 64;
+  return w;
+}
+__device__ __forceinline__ void prefetch_blocks(const WaveWeights &w, float4 (&q0)[FPF], float4 (&q1)[FPF]) {
+#pragma unroll
+  for (int u = 0; u < FPF; ++u) {
+    const int blk = min(u, w.nkb - 1);
+    q0[u] = w.w0[blk * 64], q1[u] = w.w1[blk * 64];
+  }
+}
+
+// One CHUNK of LEN weight blocks (LEN a multiple of FPF, fully unrolled so that every register of the ring has a
+// static index and the compiler counts the loads in flight exactly -- with a runtime block loop it re-synchronised
+// the whole ring, s_waitcnt vmcnt(0), at every trip): acc += X[16 x 16 LEN] * W^T.  Ring slots 0 .. FPF-1 hold
+// blocks 0 .. FPF-1 of this chunk on entry; consumed slots are refilled with the rest of the chunk and then with the
+// first FPF blocks of the NEXT chunk of the stream (n0 / n1), so they hold those on exit.
+template <int LEN>
+__device__ __forceinline__ void fused_chunk(const float *xa /* this lane's A pointer at the chunk's first column */,
+                                            const float4 *__restrict__ w0, const float4 *__restrict__ w1,
+                                            const float4 *__restrict__ n0, const float4 *__restrict__ n1,
+                                            float4 (&q0)[FPF], float4 (&q1)[FPF], f32x4 &c0, f32x4 &c1) {
+  static_assert(LEN % FPF == 0, "chunks are whole rings");
+  float4 a_next = *reinterpret_cast<const float4 *>(xa);
+#pragma unroll
+  for (int blk = 0; blk < LEN; ++blk) {
+    const int u = blk % FPF;
+    const float4 a = a_next;
+    if (blk + 1 < LEN) a_next = *reinterpret_cast<const float4 *>(xa + 16 * (blk + 1));
+    const float4 p0 = q0[u], p1 = q1[u];
+    if (blk + FPF < LEN) q0[u] = w0[(blk + FPF) * 64], q1[u] = w1[(blk + FPF) * 64];
+    else q0[u] = n0[(blk + FPF - LEN) * 64], q1[u] = n1[(blk + FPF - LEN) * 64];
+    c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, p0.x, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, p1.x, c1, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, p0.y, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, p1.y, c1, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, p0.z, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, p1.z, c1, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, p0.w, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, p1.w, c1, 0, 0, 0);
+  }
+}
+
+// acc = [embed | hidden] (LDS tiles, zero padded to whole chunks) * W^T for the wave's 32 columns: an embedding chunk
+// (layer 0 and the layer after the skip) and / or a hidden chunk; the ring runs on into the next layer's weights (wn)
+__device__ __forceinline__ void fused_matmul(const float *s_c, const float *s_in, const WaveWeights &w,
+                                             const WaveWeights &wn, float4 (&q0)[FPF], float4 (&q1)[FPF], f32x4 &c0,
+                                             f32x4 &c1, int lane) {
+  const int kq = lane >> 4, mn = lane & 15;
+  constexpr int EB = FE_MAX / 16, HB = FW / 16;
+  const bool hidden = w.nkb > w.nE;
+  if (w.nE) {
+    const float4 *n0 = hidden ? w.w0 + EB * 64 : wn.w0, *n1 = hidden ? w.w1 + EB * 64 : wn.w1;
+    fused_chunk<EB>(s_c + mn * FC_LD + 4 * kq, w.w0, w.w1, n0, n1, q0, q1, c0, c1);
+  }
+  if (hidden)
+    fused_chunk<HB>(s_in + mn * FH_LD + 4 * kq, w.w0 + w.nE * 64, w.w1 + w.nE * 64, wn.w0, wn.w1, q0, q1, c0, c1);
+}
+
+// relu(acc + bias) -> LDS tile + workspace
+__device__ __forceinline__ void fused_epilogue(const f32x4 &c0, const f32x4 &c1, float b0, float b1, float *s_out,
+                                               float *__restrict__ gout, int ld_out, int row0, int R, int lane,
+                                               int wave) {
+  const int kq = lane >> 4, mn = lane & 15, n0 = wave * 32;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int m = 4 * kq + r;
+    const float v0 = fmaxf(c0[r] + b0, 0.f), v1 = fmaxf(c1[r] + b1, 0.f);
+    s_out[m * FH_LD + n0 + mn] = v0;
+    s_out[m * FH_LD + n0 + 16 + mn] = v1;
+    if (row0 + m < R) {
+      gout[(size_t)(row0 + m) * ld_out + n0 + mn] = v0;
+      gout[(size_t)(row0 + m) * ld_out + n0 + 16 + mn] = v1;
+    }
+  }
+}
+
+__global__ __launch_bounds__(512) void timenet_fwd_fused_kernel(FusedArgs g) {
+  __shared__ __attribute__((aligned(16))) float s_c[FR * FC_LD];
+  __shared__ __attribute__((aligned(16))) float s_h[2][FR * FH_LD];
+  __shared__ float s_wo[7 * FW];  // the 3 + 4 rows of the head output layers (read 16 x per workgroup at the very end)
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int row0 = blockIdx.x * FR;
+  for (int e = t; e < 7 * FW; e += 512) s_wo[e] = e < 3 * FW ? g.W[g.D + 1][e] : g.W[g.D + 3][e - 3 * FW];
+  float4 q0[FPF], q1[FPF];
+  WaveWeights w = wave_weights(g.Wp[0], g.E, true, false, wave, lane);
+  prefetch_blocks(w, q0, q1);  // in flight under the embedding
+  // embedding of the 16 rows (same arithmetic as embed_kernel) -> LDS (zero padded) and the workspace
+  const int npts = 6 * g.pts_freqs, ntime = 2 * g.time_freqs;
+  for (int e = t; e < FR * FE_MAX; e += 512) {
+    const int m = e / FE_MAX, col = e % FE_MAX;
+    const int row = min(row0 + m, g.R - 1);
+    const int p = row / g.Mc, cp = row % g.Mc;
+    float v = 0.f;
+    if (col < npts) {
+      const int f = col / 6, wd = col % 6;
+      const float x = g.c_xyz[cp * 3 + (wd % 3)] * exp2f((float)f);
+      v = wd < 3 ? sinf(x) : cosf(x);
+    } else if (col < npts + ntime) {
+      const int c = col - npts, f = c >> 1;
+      const float x = g.pt.time[p] * exp2f((float)f);
+      v = (c & 1) ? cosf(x) : sinf(x);
+    } else if (col < g.E) {
+      v = g.latent_table[(size_t)g.pt.latent_row[p] * g.latent_dim + (col - npts - ntime)];
+    }
+    s_c[m * FC_LD + col] = v;
+    if (col < g.E && row0 + m < g.R) g.cat[(size_t)(row0 + m) * g.CAT + col] = v;
+  }
+  __syncthreads();
+  int cur = 0;  // s_h[cur] holds the input of the next hidden layer
+  // layer sequence: deformnet 0 .. D-1, then the two head hidden layers (both read h[D-1])
+  for (int step = 0; step < g.D + 2; ++step) {
+    const bool head = step >= g.D;
+    const int li = head ? g.D + 2 * (step - g.D) : step;
+    f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
+    // (requested before the matmul: after it they would be a full memory round trip on the critical path)
+    const float bias0 = g.b[li][wave * 32 + (lane & 15)], bias1 = g.b[li][wave * 32 + 16 + (lane & 15)];
+    WaveWeights wn = w;  // (after the last layer the ring refills with clamped repeats of its own blocks)
+    if (step + 1 < g.D + 2) {
+      const int ns = step + 1, nli = ns >= g.D ? g.D + 2 * (ns - g.D) : ns;
+      wn = wave_weights(g.Wp[nli], g.E, ns < g.D && ns - 1 == g.skip, true, wave, lane);
+    }
+    fused_matmul(s_c, s_h[cur], w, wn, q0, q1, c0, c1, lane);
+    w = wn;
+    if (!head) {
+      fused_epilogue(c0, c1, bias0, bias1, s_h[cur ^ 1], g.act[li], g.act_ld[li], row0, g.R, lane, wave);
+      cur ^= 1;
+      lds_barrier();
+      continue;
+    }
+    // head hidden layer -> s_h[cur ^ 1]; its 3 / 4 output columns are wave dot products (two rows per wave, the
+    // arithmetic of head_out_kernel)
+    const int hd = step - g.D;
+    fused_epilogue(c0, c1, bias0, bias1, s_h[cur ^ 1], hd ? g.hr : g.hp, FW, row0, g.R, lane, wave);
+    lds_barrier();
+    const float *Wo = s_wo + (hd ? 3 * FW : 0), *bo = g.b[li + 1];
+    const int nout = hd ? 4 : 3;
+    for (int rr = 0; rr < 2; ++rr) {
+      const int m = 2 * wave + rr;
+      const float *x = s_h[cur ^ 1] + m * FH_LD;
+      float a[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int c = lane; c < FW; c += 64) {
+        const float xv = x[c];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (i < nout) a[i] = fmaf(xv, Wo[i * FW + c], a[i]);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (i < nout) a[i] = wave_sum(a[i]);
+      if (lane == 0 && row0 + m < g.R) {
+        float *dst = hd ? g.d_rot + (size_t)(row0 + m) * 4 : g.d_xyz + (size_t)(row0 + m) * 3;
+        for (int i = 0; i < nout; ++i) dst[i] = a[i] + bo[i];
+      }
+    }
+    lds_barrier();  // s_h[cur ^ 1] is overwritten by the second head
+  }
+}
+
 // ---- host side -------------------------------------------------------------------------------------------------
 struct Plan {
   int D, Wd, skip, E, CAT, rows;
   // float offsets into the workspace
   size_t cat, g_cat, hp, hr, dzp, dzr, act[MAX_LAYERS], dz[MAX_LAYERS], total;
+  size_t packed[MAX_LAYERS];  // packed forward weights of layer l (fused forward only; 0 floats otherwise)
+  int nkb[MAX_LAYERS];
 };
 
 bool make_plan(const dimo_timenet_desc *d, int rows, Plan &pl) {
@@ -407,6 +655,17 @@ bool make_plan(const dimo_timenet_desc *d, int rows, Plan &pl) {
       pl.act[l] = pl.cat + pl.E, pl.dz[l] = pl.g_cat + pl.E;
     } else {
       pl.act[l] = take(R * pl.Wd), pl.dz[l] = take(R * pl.Wd);
+    }
+  }
+  for (int l = 0; l < d->D + 4; ++l) pl.packed[l] = 0, pl.nkb[l] = 0;
+  if (pl.Wd == 256) {  // FW (the fused forward's shape class; see fused_forward_ok)
+    const int nE = embed_blocks(pl.E), nH = 256 / 16;
+    for (int l = 0; l < d->D + 4; ++l) {
+      const bool hidden_layer = l < d->D || l == d->D || l == d->D + 2;
+      if (!hidden_layer) continue;
+      const bool use_embed = l == 0 || (l < d->D && l - 1 == d->skip), use_hidden = l > 0;
+      pl.nkb[l] = (use_embed ? nE : 0) + (use_hidden ? nH : 0);
+      pl.packed[l] = take((size_t)256 * pl.nkb[l] * 16);
     }
   }
   pl.total = o;
@@ -443,6 +702,16 @@ void launch_gemm(const GemmArgs &g, int z, hipStream_t s) {
     gemm_kernel<A_KC, B_KC, false><<<grid, 256, 0, s>>>(g);
 }
 
+// the one-launch forward handles the reference's shape class: width 256, at most one skip, embedding <= 112 columns,
+// every operand 16-byte aligned with row lengths that are multiples of 4
+bool fused_forward_ok(const dimo_timenet_desc *d, const Plan &pl) {
+  if (getenv("DIMO_TIMENET_UNFUSED")) return false;
+  if (pl.Wd != FW || pl.E > FE_MAX || (pl.E & 3) || pl.E < 4 || d->D + 4 > MAX_LAYERS) return false;
+  for (int l = 0; l < d->D + 4; ++l)
+    if ((reinterpret_cast<uintptr_t>(d->weight[l]) & 15) != 0) return false;
+  return true;
+}
+
 bool fill_pairs(int P, const float *times, const int *rows, PairTable &pt) {
   if (P > MAX_PAIRS) return false;
   for (int p = 0; p < P; ++p) pt.time[p] = times[p], pt.latent_row[p] = rows ? rows[p] : p;
@@ -476,6 +745,36 @@ extern "C" int dimo_timenet_forward(const dimo_timenet_desc *d, int P, int M, co
   ScopedTimer timer(T_TIMENET_FWD, s);
   float *ws = static_cast<float *>(workspace);
   const int R = pl.rows;
+  if (fused_forward_ok(d, pl)) {
+    FusedArgs g = {};
+    g.R = R, g.Mc = M, g.E = pl.E, g.CAT = pl.CAT, g.D = d->D, g.skip = d->skip, g.pts_freqs = d->pts_freqs;
+    g.time_freqs = d->time_freqs, g.latent_dim = d->latent_dim, g.c_xyz = c_xyz, g.latent_table = latent_table;
+    for (int l = 0; l < d->D + 4; ++l) g.W[l] = d->weight[l], g.b[l] = d->bias[l];
+    g.cat = ws + pl.cat, g.hp = ws + pl.hp, g.hr = ws + pl.hr, g.d_xyz = d_xyz, g.d_rot = d_rot;
+    for (int l = 0; l < d->D; ++l) g.act[l] = ws + pl.act[l], g.act_ld[l] = act_ld(pl, l);
+    g.pt = pt;
+    PackArgs pa = {};
+    for (int l = 0; l < d->D + 4; ++l) {
+      if (!pl.nkb[l]) continue;
+      const bool use_embed = l == 0 || (l < d->D && l - 1 == d->skip), use_hidden = l > 0;
+      PackJob &j = pa.job[pa.njobs++];
+      j.W = d->weight[l], j.out = ws + pl.packed[l], j.E_seg = use_embed ? pl.E : 0, j.H_seg = use_hidden ? FW : 0;
+      j.ldw = j.E_seg + j.H_seg, j.nkb = pl.nkb[l];
+      g.Wp[l] = ws + pl.packed[l];
+    }
+    pack_weights_kernel<<<dim3(16, pa.njobs), 256, 0, s>>>(pa);
+    // 128 workgroups for 256 CUs: ask for enough LDS that two of them cannot share a CU (4 waves per SIMD would
+    // halve each workgroup's MFMA rate while the other half of the chip idles)
+    static const bool once = [] {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(timenet_fwd_fused_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+      return true;
+    }();
+    (void)once;
+    const int spread = getenv("DIMO_TIMENET_NOSPREAD") ? 0 : 48 * 1024;
+    timenet_fwd_fused_kernel<<<(R + FR - 1) / FR, 512, spread, s>>>(g);
+    return check_launch();
+  }
   {
     const int n = R * pl.E;
     embed_kernel<<<(n + 255) / 256, 256, 0, s>>>(P, M, pl.E, pl.CAT, d->pts_freqs, d->time_freqs, d->latent_dim,
