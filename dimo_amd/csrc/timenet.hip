@@ -1,7 +1,12 @@
 // TimeNet (renderer/latent_gs_renderer.py:184-245) forward and backward for a whole training step's batch of
 // (motion, frame) pairs as a short chain of fp32 MFMA GEMMs -- rows = pairs x control points (2048 at the
 // benchmark configuration), widths 104 / 256 / 360.  PyTorch's eager version of the same MLP is ~190 launches of
-// 2-20 us kernels per step (1.4 ms of a 4.7 ms step); here forward is D + 3 launches and backward D + 5.
+// 2-20 us kernels per step (1.4 ms of a 4.7 ms step).  Two implementations:
+//   * the reference's shape class (width 256, <= 1 skip, embedding <= 128 columns): the whole forward is ONE launch
+//     and the whole dgrad chain ONE launch (timenet_fwd_fused_kernel / timenet_bwd_fused_kernel below: a workgroup
+//     walks 16 rows through every layer, activations in LDS, packed weights streamed through a register ring),
+//     followed by the grouped wgrad and the embedding backward;
+//   * any other shape: one GEMM launch per layer (forward D + 3 launches, backward D + 5):
 //
 //   forward : embed (NeRF positional encoding of control points and time + latent, src/pos_enc.py:6-54)
 //             -> D x [Y = relu(X W^T + b)]   (the skip layer writes beside the embedding: the concat is free)
@@ -447,9 +452,6 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(PackArgs a) {
   }
 }
 
-// The layers of the fused forward as one stream of weight blocks per wave: the FPF-deep register ring of B operands
-// runs ACROSS layer boundaries (the first blocks of layer l + 1 are requested before layer l's epilogue and barrier:
-// weights do not depend on activations), so a layer never starts with a cold memory pipeline.
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() is a workgroup-scope fence over ALL address spaces:
 // on gfx9 that is s_waitcnt vmcnt(0) as well, i.e. every layer would wait for its activation stores to reach L2 and
 // for the NEXT layer's prefetched weights before any wave may go on.
@@ -457,6 +459,9 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// The layers of the fused forward as one stream of weight blocks per wave: the FPF-deep register ring of B operands
+// runs ACROSS layer boundaries (weights do not depend on activations), so a layer never starts with a cold memory
+// pipeline.
 struct WaveWeights {
   const float4 *w0, *w1;  // this lane's float4 of block 0 of the wave's two column tiles
   int nE, nkb;            // embedding blocks (A from the embedding tile), blocks in all
@@ -483,7 +488,9 @@ __device__ __forceinline__ void prefetch_blocks(const WaveWeights &w, float4 (&q
 // the whole ring, s_waitcnt vmcnt(0), at every trip): acc += X[16 x 16 LEN] * W^T.  Ring slots 0 .. FPF-1 hold
 // blocks 0 .. FPF-1 of this chunk on entry; consumed slots are refilled with the rest of the chunk and then with the
 // first FPF blocks of the NEXT chunk of the stream (n0 / n1), so they hold those on exit.
-template <int LEN>
+// NT / NTN: column tiles per wave of this chunk / of the next one (2: the wave's 32 columns; 1: a 16-column tile of
+// the 128 embedding columns in the backward -- q1 / c1 are then left alone).
+template <int LEN, int NT = 2, int NTN = 2>
 __device__ __forceinline__ void fused_chunk(const float *xa /* this lane's A pointer at the chunk's first column */,
                                             const float4 *__restrict__ w0, const float4 *__restrict__ w1,
                                             const float4 *__restrict__ n0, const float4 *__restrict__ n1,
@@ -496,16 +503,21 @@ __device__ __forceinline__ void fused_chunk(const float *xa /* this lane's A poi
     const float4 a = a_next;
     if (blk + 1 < LEN) a_next = *reinterpret_cast<const float4 *>(xa + 16 * (blk + 1));
     const float4 p0 = q0[u], p1 = q1[u];
-    if (blk + FPF < LEN) q0[u] = w0[(blk + FPF) * 64], q1[u] = w1[(blk + FPF) * 64];
-    else q0[u] = n0[(blk + FPF - LEN) * 64], q1[u] = n1[(blk + FPF - LEN) * 64];
+    if (blk + FPF < LEN) {
+      q0[u] = w0[(blk + FPF) * 64];
+      if (NT == 2) q1[u] = w1[(blk + FPF) * 64];
+    } else {
+      q0[u] = n0[(blk + FPF - LEN) * 64];
+      if (NTN == 2) q1[u] = n1[(blk + FPF - LEN) * 64];
+    }
     c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, p0.x, c0, 0, 0, 0);
-    c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, p1.x, c1, 0, 0, 0);
+    if (NT == 2) c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, p1.x, c1, 0, 0, 0);
     c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, p0.y, c0, 0, 0, 0);
-    c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, p1.y, c1, 0, 0, 0);
+    if (NT == 2) c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, p1.y, c1, 0, 0, 0);
     c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, p0.z, c0, 0, 0, 0);
-    c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, p1.z, c1, 0, 0, 0);
+    if (NT == 2) c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, p1.z, c1, 0, 0, 0);
     c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, p0.w, c0, 0, 0, 0);
-    c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, p1.w, c1, 0, 0, 0);
+    if (NT == 2) c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, p1.w, c1, 0, 0, 0);
   }
 }
 
@@ -625,6 +637,163 @@ __global__ __launch_bounds__(512) void timenet_fwd_fused_kernel(FusedArgs g) {
   }
 }
 
+// ---- the dgrad chain in ONE launch (same shape class) ------------------------------------------------------------
+// Mirrors the forward: a workgroup owns 16 rows; dZ of the layer above stays in LDS (and goes to the workspace for the
+// weight gradients), the TRANSPOSED weights stream through the same register ring.  Sequence of matmuls per workgroup
+// (D = 8, skip = 4):  [dZp Wp0 + dZr Wr0] -> dZ7 ; dZ7 W7 -> dZ6 ; dZ6 W6 -> dZ5 ; dZ5 W5[:, E:] -> dZ4 and
+// dZ5 W5[:, :E] -> gE ; dZ4 W4 -> dZ3 ; ... ; dZ1 W1 -> dZ0 ; dZ0 W0 -> gE (accumulated in registers, written once).
+// Every hidden product is masked by the ReLU of the layer it enters (saved activation > 0).
+//
+// Packed transposed block (jt, nb), lane (kq, mn): float4 { W[16 nb + 4 kq + i][col0 + 16 jt + mn] }, i = 0..3
+// (zero for columns past `ncols`): the contraction now runs over the ROWS of W.
+struct PackTJob {
+  const float *W;
+  float *out;
+  int ldw, col0, ncols, ntiles;
+};
+struct PackTArgs {
+  PackTJob job[MAX_LAYERS + 2];
+  int njobs;
+};
+__global__ __launch_bounds__(256) void pack_weights_t_kernel(PackTArgs a) {
+  const PackTJob &j = a.job[blockIdx.y];
+  const int total = j.ntiles * (FW / 16) * 64;  // float4s
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const int lane = i & 63, blk = i >> 6;
+    const int nb = blk % (FW / 16), jt = blk / (FW / 16);
+    const int kq = lane >> 4, mn = lane & 15;
+    const int col = 16 * jt + mn, row = 16 * nb + 4 * kq;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (col < j.ncols) {
+      const float *p = j.W + (size_t)row * j.ldw + j.col0 + col;
+      v = make_float4(p[0], p[j.ldw], p[2 * (size_t)j.ldw], p[3 * (size_t)j.ldw]);
+    }
+    reinterpret_cast<float4 *>(j.out)[i] = v;
+  }
+}
+
+struct FusedBwdArgs {
+  int R, E, CAT, D, skip;
+  const float *g_d_xyz, *g_d_rot, *Wp1, *Wr1, *hp, *hr;
+  float *dzp, *dzr, *g_cat;
+  const float *Tp[MAX_LAYERS];                  // packed transposed hidden-column weights of layer l (heads: D, D + 2)
+  const float *TpE[MAX_LAYERS];                 // packed transposed embedding-column weights (layer 0, layer skip + 1)
+  const float *mask[MAX_LAYERS];                // saved activation of layer l (ReLU mask of dZ[l])
+  float *dz[MAX_LAYERS];
+  int ld[MAX_LAYERS];                           // leading dimension of mask[l] / dz[l]
+};
+
+// (acc) * (mask > 0) -> LDS tile + workspace
+__device__ __forceinline__ void fused_bwd_epilogue(const f32x4 &c0, const f32x4 &c1, const float (&mk)[8], float *s_out,
+                                                   float *__restrict__ gout, int ld_out, int row0, int R, int lane,
+                                                   int wave) {
+  const int kq = lane >> 4, mn = lane & 15, n0 = wave * 32;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int m = 4 * kq + r;
+    const float v0 = mk[r] > 0.f ? c0[r] : 0.f, v1 = mk[4 + r] > 0.f ? c1[r] : 0.f;
+    s_out[m * FH_LD + n0 + mn] = v0;
+    s_out[m * FH_LD + n0 + 16 + mn] = v1;
+    if (row0 + m < R) {
+      gout[(size_t)(row0 + m) * ld_out + n0 + mn] = v0;
+      gout[(size_t)(row0 + m) * ld_out + n0 + 16 + mn] = v1;
+    }
+  }
+}
+
+__global__ __launch_bounds__(512) void timenet_bwd_fused_kernel(FusedBwdArgs g) {
+  __shared__ __attribute__((aligned(16))) float s_d[3][FR * FH_LD];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int kq = lane >> 4, mn = lane & 15;
+  const int row0 = blockIdx.x * FR;
+  constexpr int HB = FW / 16;
+  // this lane's float4 of block 0 of the wave's tiles in a packed matrix with 16 (hidden) / 8 (embedding) tiles
+  auto hidden_w0 = [&](const float *packed) {
+    return reinterpret_cast<const float4 *>(packed) + (size_t)(2 * wave) * HB * 64 + lane;
+  };
+  auto embed_w0 = [&](const float *packed) {
+    return reinterpret_cast<const float4 *>(packed) + (size_t)wave * HB * 64 + lane;
+  };
+  float4 q0[FPF], q1[FPF];
+  {  // first ring: the head's first chunk (dZp Wp0)
+    const float4 *w0 = hidden_w0(g.Tp[g.D]), *w1 = w0 + HB * 64;
+#pragma unroll
+    for (int u = 0; u < FPF; ++u) q0[u] = w0[u * 64], q1[u] = w1[u * 64];
+  }
+  // dZp = (g_d_xyz Wp1) * (hp > 0), dZr = (g_d_rot Wr1) * (hr > 0)   (head_out_bwd_kernel's arithmetic)
+  for (int e = t; e < FR * FW; e += 512) {
+    const int m = e / FW, c = e % FW;
+    const int row = min(row0 + m, g.R - 1);
+    float vp = 0.f, vr = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) vp = fmaf(g.g_d_xyz[row * 3 + i], g.Wp1[i * FW + c], vp);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) vr = fmaf(g.g_d_rot[row * 4 + i], g.Wr1[i * FW + c], vr);
+    vp = g.hp[(size_t)row * FW + c] > 0.f ? vp : 0.f;
+    vr = g.hr[(size_t)row * FW + c] > 0.f ? vr : 0.f;
+    s_d[0][m * FH_LD + c] = vp;
+    s_d[1][m * FH_LD + c] = vr;
+    if (row0 + m < g.R) g.dzp[(size_t)(row0 + m) * FW + c] = vp, g.dzr[(size_t)(row0 + m) * FW + c] = vr;
+  }
+  lds_barrier();
+  const float *xa0 = s_d[0] + mn * FH_LD + 4 * kq;  // A pointers of the three tiles
+  auto xa = [&](int tile) { return xa0 + tile * (FR * FH_LD); };
+  auto load_mask = [&](int l, float (&mk)[8]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const size_t row = (size_t)min(row0 + 4 * kq + r, g.R - 1) * g.ld[l];
+      mk[r] = g.mask[l][row + wave * 32 + mn], mk[4 + r] = g.mask[l][row + wave * 32 + 16 + mn];
+    }
+  };
+  f32x4 cE = {0.f, 0.f, 0.f, 0.f}, unused = {0.f, 0.f, 0.f, 0.f};
+  int cur;
+  {  // head: dZ[D-1] = (dZp Wp0 + dZr Wr0) * (h[D-1] > 0)
+    float mk[8];
+    load_mask(g.D - 1, mk);
+    f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
+    const float4 *wp = hidden_w0(g.Tp[g.D]), *wr = hidden_w0(g.Tp[g.D + 2]), *wn = hidden_w0(g.Tp[g.D - 1]);
+    fused_chunk<HB>(xa(0), wp, wp + HB * 64, wr, wr + HB * 64, q0, q1, c0, c1);
+    fused_chunk<HB>(xa(1), wr, wr + HB * 64, wn, wn + HB * 64, q0, q1, c0, c1);
+    fused_bwd_epilogue(c0, c1, mk, s_d[2], g.dz[g.D - 1], g.ld[g.D - 1], row0, g.R, lane, wave);
+    cur = 2;
+    lds_barrier();
+  }
+  for (int l = g.D - 1; l >= 1; --l) {  // dZ[l-1] = (dZ[l] W_l[:, hidden columns]) * (h[l-1] > 0)
+    float mk[8];
+    load_mask(l - 1, mk);
+    f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
+    const float4 *w = hidden_w0(g.Tp[l]);
+    const bool with_embed = l - 1 == g.skip;  // this layer also read the embedding: gE += dZ[l] W_l[:, :E]
+    // what the ring runs on into: this layer's embedding chunk, the next layer's hidden chunk, or (l == 1) layer
+    // 0's embedding chunk
+    const float4 *e = with_embed ? embed_w0(g.TpE[l]) : nullptr;
+    const float4 *nx = l > 1 ? hidden_w0(g.Tp[l - 1]) : embed_w0(g.TpE[0]);
+    if (with_embed) {
+      fused_chunk<HB, 2, 1>(xa(cur), w, w + HB * 64, e, e, q0, q1, c0, c1);
+      if (l > 1) fused_chunk<HB, 1, 2>(xa(cur), e, e, nx, nx + HB * 64, q0, q1, cE, unused);
+      else fused_chunk<HB, 1, 1>(xa(cur), e, e, nx, nx, q0, q1, cE, unused);
+    } else if (l > 1) {
+      fused_chunk<HB, 2, 2>(xa(cur), w, w + HB * 64, nx, nx + HB * 64, q0, q1, c0, c1);
+    } else {
+      fused_chunk<HB, 2, 1>(xa(cur), w, w + HB * 64, nx, nx, q0, q1, c0, c1);
+    }
+    const int out = (cur + 1) % 3;
+    fused_bwd_epilogue(c0, c1, mk, s_d[out], g.dz[l - 1], g.ld[l - 1], row0, g.R, lane, wave);
+    cur = out;
+    lds_barrier();
+  }
+  {  // gE += dZ[0] W_0 ; the embedding gradient leaves the chip once
+    const float4 *e = embed_w0(g.TpE[0]);
+    fused_chunk<HB, 1, 1>(xa(cur), e, e, e, e, q0, q1, cE, unused);
+    const int col = 16 * wave + mn;
+    if (col < g.E) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (row0 + 4 * kq + r < g.R) g.g_cat[(size_t)(row0 + 4 * kq + r) * g.CAT + col] = cE[r];
+    }
+  }
+}
+
 // ---- host side -------------------------------------------------------------------------------------------------
 struct Plan {
   int D, Wd, skip, E, CAT, rows;
@@ -632,6 +801,8 @@ struct Plan {
   size_t cat, g_cat, hp, hr, dzp, dzr, act[MAX_LAYERS], dz[MAX_LAYERS], total;
   size_t packed[MAX_LAYERS];  // packed forward weights of layer l (fused forward only; 0 floats otherwise)
   int nkb[MAX_LAYERS];
+  size_t packed_t[MAX_LAYERS], packed_te[MAX_LAYERS];  // packed transposed weights (fused backward): hidden / embedding columns
+  bool has_t[MAX_LAYERS], has_te[MAX_LAYERS];
 };
 
 bool make_plan(const dimo_timenet_desc *d, int rows, Plan &pl) {
@@ -666,6 +837,15 @@ bool make_plan(const dimo_timenet_desc *d, int rows, Plan &pl) {
       const bool use_embed = l == 0 || (l < d->D && l - 1 == d->skip), use_hidden = l > 0;
       pl.nkb[l] = (use_embed ? nE : 0) + (use_hidden ? nH : 0);
       pl.packed[l] = take((size_t)256 * pl.nkb[l] * 16);
+    }
+  }
+  for (int l = 0; l < d->D + 4; ++l) pl.has_t[l] = pl.has_te[l] = false, pl.packed_t[l] = pl.packed_te[l] = 0;
+  if (pl.Wd == 256) {
+    for (int l = 0; l < d->D + 4; ++l) {
+      const bool hidden_in = (l >= 1 && l < d->D) || l == d->D || l == d->D + 2;  // layers with a hidden-width input
+      const bool embed_in = l == 0 || (l < d->D && l - 1 == d->skip);
+      if (hidden_in) pl.has_t[l] = true, pl.packed_t[l] = take((size_t)256 * 256);
+      if (embed_in) pl.has_te[l] = true, pl.packed_te[l] = take((size_t)128 * 256);
     }
   }
   pl.total = o;
@@ -820,13 +1000,43 @@ extern "C" int dimo_timenet_backward(const dimo_timenet_desc *d, int P, int M, c
   ScopedTimer timer(T_TIMENET_BWD, s);
   float *ws = static_cast<float *>(workspace);
   const int R = pl.rows, D = d->D, Wd = pl.Wd;
-  {
+  const bool fused = fused_forward_ok(d, pl) && !getenv("DIMO_TIMENET_UNFUSED_BWD");
+  if (fused) {
+    PackTArgs pa = {};
+    FusedBwdArgs g = {};
+    g.R = R, g.E = pl.E, g.CAT = pl.CAT, g.D = D, g.skip = pl.skip;
+    g.g_d_xyz = g_d_xyz, g.g_d_rot = g_d_rot, g.Wp1 = d->weight[D + 1], g.Wr1 = d->weight[D + 3];
+    g.hp = ws + pl.hp, g.hr = ws + pl.hr, g.dzp = ws + pl.dzp, g.dzr = ws + pl.dzr, g.g_cat = ws + pl.g_cat;
+    for (int l = 0; l < D + 4; ++l) {
+      const int K = l == 0 ? pl.E : (l < D && l - 1 == pl.skip ? pl.CAT : Wd);  // row length of weight[l]
+      if (pl.has_t[l]) {
+        PackTJob &j = pa.job[pa.njobs++];
+        j.W = d->weight[l], j.out = ws + pl.packed_t[l], j.ldw = K, j.col0 = K - Wd, j.ncols = Wd, j.ntiles = 16;
+        g.Tp[l] = j.out;
+      }
+      if (pl.has_te[l]) {
+        PackTJob &j = pa.job[pa.njobs++];
+        j.W = d->weight[l], j.out = ws + pl.packed_te[l], j.ldw = K, j.col0 = 0, j.ncols = pl.E, j.ntiles = 8;
+        g.TpE[l] = j.out;
+      }
+    }
+    for (int l = 0; l < D; ++l) g.mask[l] = ws + pl.act[l], g.dz[l] = ws + pl.dz[l], g.ld[l] = act_ld(pl, l);
+    pack_weights_t_kernel<<<dim3(16, pa.njobs), 256, 0, s>>>(pa);
+    static const bool once = [] {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(timenet_bwd_fused_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+      return true;
+    }();
+    (void)once;
+    timenet_bwd_fused_kernel<<<(R + FR - 1) / FR, 512, 0, s>>>(g);
+  }
+  if (!fused) {
     const int n = R * Wd;
     head_out_bwd_kernel<<<(n + 255) / 256, 256, 0, s>>>(R, Wd, g_d_xyz, g_d_rot, ws + pl.hp, ws + pl.hr,
                                                         d->weight[D + 1], d->weight[D + 3], ws + pl.dzp,
                                                         ws + pl.dzr);
   }
-  {  // dZ[D-1] = (dZp Wp0 + dZr Wr0) * (h[D-1] > 0)
+  if (!fused) {  // dZ[D-1] = (dZp Wp0 + dZr Wr0) * (h[D-1] > 0)
     GemmArgs g = {};
     g.nseg = 2;
     g.A[0] = ws + pl.dzp, g.A[1] = ws + pl.dzr, g.lda[0] = g.lda[1] = Wd, g.K[0] = g.K[1] = Wd;
@@ -835,7 +1045,7 @@ extern "C" int dimo_timenet_backward(const dimo_timenet_desc *d, int P, int M, c
     g.mask = ws + pl.act[D - 1], g.ldmask = act_ld(pl, D - 1);
     launch_gemm<true, false>(g, 1, s);
   }
-  for (int l = D - 1; l >= 0; --l) {  // gradient of layer l's input
+  for (int l = D - 1; l >= 0 && !fused; --l) {  // gradient of layer l's input
     GemmArgs g = {};
     size_t in_off;
     int in_ld, K;
