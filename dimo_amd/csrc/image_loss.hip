@@ -106,24 +106,19 @@ __global__ void __launch_bounds__(256) image_loss_kernel(
     const float em = a - mask[(size_t)b * mask_stride + pix];
     loss += prm.w_mask * em * em;
     g_alpha[(size_t)b * HW + pix] = 2.0f * prm.w_mask * em;
-    // stencil terms
+    // stencil terms.  The four neighbours are loaded UNCONDITIONALLY (clamped to the pixel itself at the image
+    // border, where the pair's weights are zero): a branch around each neighbour's loads made the compiler wait for
+    // them one after the other -- four dependent memory round trips per pixel.
     if (DEPTH || NORMAL) {
-      if (x + 1 < W) {
-        const Px Q = load_px<DEPTH, NORMAL>(img, dep, nrm, HW, pix + 1);
-        loss += pair_term<DEPTH, NORMAL>(P, Q, 1.0f, prm.w_smooth_x, prm.w_bilat_x, gc, gd, gn);
-      }
-      if (y + 1 < H) {
-        const Px Q = load_px<DEPTH, NORMAL>(img, dep, nrm, HW, pix + W);
-        loss += pair_term<DEPTH, NORMAL>(P, Q, 1.0f, prm.w_smooth_y, prm.w_bilat_y, gc, gd, gn);
-      }
-      if (x > 0) {
-        const Px Q = load_px<DEPTH, NORMAL>(img, dep, nrm, HW, pix - 1);
-        (void)pair_term<DEPTH, NORMAL>(Q, P, -1.0f, prm.w_smooth_x, prm.w_bilat_x, gc, gd, gn);
-      }
-      if (y > 0) {
-        const Px Q = load_px<DEPTH, NORMAL>(img, dep, nrm, HW, pix - W);
-        (void)pair_term<DEPTH, NORMAL>(Q, P, -1.0f, prm.w_smooth_y, prm.w_bilat_y, gc, gd, gn);
-      }
+      const bool vr = x + 1 < W, vd = y + 1 < H, vl = x > 0, vu = y > 0;
+      const Px QR = load_px<DEPTH, NORMAL>(img, dep, nrm, HW, vr ? pix + 1 : pix);
+      const Px QD = load_px<DEPTH, NORMAL>(img, dep, nrm, HW, vd ? pix + W : pix);
+      const Px QL = load_px<DEPTH, NORMAL>(img, dep, nrm, HW, vl ? pix - 1 : pix);
+      const Px QU = load_px<DEPTH, NORMAL>(img, dep, nrm, HW, vu ? pix - W : pix);
+      loss += pair_term<DEPTH, NORMAL>(P, QR, 1.0f, vr ? prm.w_smooth_x : 0.0f, vr ? prm.w_bilat_x : 0.0f, gc, gd, gn);
+      loss += pair_term<DEPTH, NORMAL>(P, QD, 1.0f, vd ? prm.w_smooth_y : 0.0f, vd ? prm.w_bilat_y : 0.0f, gc, gd, gn);
+      (void)pair_term<DEPTH, NORMAL>(QL, P, -1.0f, vl ? prm.w_smooth_x : 0.0f, vl ? prm.w_bilat_x : 0.0f, gc, gd, gn);
+      (void)pair_term<DEPTH, NORMAL>(QU, P, -1.0f, vu ? prm.w_smooth_y : 0.0f, vu ? prm.w_bilat_y : 0.0f, gc, gd, gn);
     }
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
