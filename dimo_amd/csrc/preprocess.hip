@@ -279,11 +279,20 @@ __device__ __forceinline__ void preprocess_bwd_body(
   float dsc[3] = {0, 0, 0}, dq[4] = {0, 0, 0, 0}, dSig[6] = {0, 0, 0, 0, 0, 0};
   float dfeat[NFEAT] = {0, 0, 0, 0, 0, 0, 0};
   const bool visible = radii[i] > 0;
+  // the Gaussian's own inputs are requested before the gather loop (they are only needed after it)
+  uint32_t lo = offsets[i == 0 ? 0 : i - 1], hi = offsets[i];
+  const Splat sp = splat[i];
+  const float p[3] = {means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2]};
+  float q[4] = {1, 0, 0, 0}, s[3] = {0, 0, 0};
+  if (!cov3D_precomp) {  // (kernel-uniform)
+    q[0] = rotations[4 * i], q[1] = rotations[4 * i + 1], q[2] = rotations[4 * i + 2], q[3] = rotations[4 * i + 3];
+    s[0] = scales[3 * i], s[1] = scales[3 * i + 1], s[2] = scales[3 * i + 2];
+  }
 
   if (visible) {
     // ---- gather the instance records
     float m0 = 0, mx = 0, my = 0, mxx = 0, mxy = 0, myy = 0;
-    uint32_t lo = i == 0 ? 0u : offsets[i - 1], hi = offsets[i];
+    lo = i == 0 ? 0u : lo;
     lo = min(lo, R_cap), hi = min(hi, R_cap);
     // Eight instances per round, every load of the round issued before the first use: the flags first, then the four
     // float4s of each record -- from the record when its flag is set (an instance no pixel reached has no record),
@@ -314,7 +323,6 @@ __device__ __forceinline__ void preprocess_bwd_body(
         }
       }
     }
-    const Splat sp = splat[i];
     // moments -> gradients of (pixel mean, conic, opacity)
     const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
     dm2d[0] = -(sp.A * mx + sp.B * my) * ddelx_dx;
@@ -323,14 +331,11 @@ __device__ __forceinline__ void preprocess_bwd_body(
     dop = (m0 != 0.0f) ? m0 / sp.opacity : 0.0f;
 
     const float fx = (float)W / (2.0f * tanfovx), fy = (float)H / (2.0f * tanfovy);
-    const float p[3] = {means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2]};
-    float c6[6], R[9], q[4] = {1, 0, 0, 0}, s[3] = {0, 0, 0};
+    float c6[6], R[9];
     if (cov3D_precomp) {
 #pragma unroll
       for (int k = 0; k < 6; ++k) c6[k] = cov3D_precomp[6 * i + k];
     } else {
-      q[0] = rotations[4 * i], q[1] = rotations[4 * i + 1], q[2] = rotations[4 * i + 2], q[3] = rotations[4 * i + 3];
-      s[0] = scales[3 * i], s[1] = scales[3 * i + 1], s[2] = scales[3 * i + 2];
       quat_to_R(q, R);
       cov3d_from_scale_rot(s, scale_mod, R, c6);
     }
