@@ -371,29 +371,39 @@ __global__ void __launch_bounds__(DEF_BLOCK) lbs_bwd_batched_kernel(int N, int M
 __global__ void __launch_bounds__(256) lbs_reduce_batched_kernel(int M, int nblocks, int n_groups,
                                                                  const float *__restrict__ partials,
                                                                  float *d_c_xyz, float *d_c_lr, RenderBatch b) {
-  __shared__ float s_part[16][17];
+  // Thread (jj, chunk) sums the tables chunk, chunk + 16, ... of output j for every group; all of a group's loads
+  // (<= 16 per thread, unconditional from clamped table indices) are issued before the first add.  The kernel is a
+  // few hundred workgroups of pure memory latency on the step's critical path: a loop with one load in flight took
+  // 90 us next to the other motion's blend kernels.
+  __shared__ float s_part[MAX_BATCH][16][17];
   const int jj = threadIdx.x & 15, chunk = threadIdx.x >> 4;
   const int j = blockIdx.x * 16 + jj;
-  const int m = j / CP_STRIDE, c = j % CP_STRIDE;
+  const int jc = min(j, M * CP_STRIDE - 1);
+  const int m = jc / CP_STRIDE, c = jc % CP_STRIDE;
   for (int r = 0; r < n_groups; ++r) {
-    const float *p = partials + (size_t)r * nblocks * M * CP_STRIDE;
+    const float *p = partials + (size_t)r * nblocks * M * CP_STRIDE + jc;
     float s = 0.f;
-    if (j < M * CP_STRIDE)
-      for (int k = chunk; k < nblocks; k += 16) s += p[(size_t)k * M * CP_STRIDE + j];
-    __syncthreads();
-    s_part[chunk][jj] = s;
-    __syncthreads();
-    if (chunk == 0 && j < M * CP_STRIDE) {
-      s = 0.f;
+    for (int k0 = chunk; k0 < nblocks; k0 += 16 * 16) {
+      float v[16];
 #pragma unroll
-      for (int k = 0; k < 16; ++k) s += s_part[k][jj];
-      float *dst;
-      if (c < 3) dst = d_c_xyz + 3 * m + c;
-      else if (c == 3) dst = d_c_lr + m;
-      else if (c < 7) dst = b.r[b.leader[r]].g_d_xyz + 3 * m + (c - 4);
-      else dst = b.r[b.leader[r]].g_d_rot + 4 * m + (c - 7);
-      *dst += s;
+      for (int it = 0; it < 16; ++it) v[it] = p[(size_t)min(k0 + 16 * it, nblocks - 1) * M * CP_STRIDE];
+#pragma unroll
+      for (int it = 0; it < 16; ++it) s += (k0 + 16 * it < nblocks) ? v[it] : 0.f;
     }
+    s_part[r][chunk][jj] = s;
+  }
+  __syncthreads();
+  if (chunk != 0 || j >= M * CP_STRIDE) return;
+  for (int r = 0; r < n_groups; ++r) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += s_part[r][k][jj];
+    float *dst;
+    if (c < 3) dst = d_c_xyz + 3 * m + c;
+    else if (c == 3) dst = d_c_lr + m;
+    else if (c < 7) dst = b.r[b.leader[r]].g_d_xyz + 3 * m + (c - 4);
+    else dst = b.r[b.leader[r]].g_d_rot + 4 * m + (c - 7);
+    *dst += s;
   }
 }
 

@@ -369,7 +369,11 @@ extern "C" int dimo_ssim_forward_backward(int B, int C, int H, int W, int clamp_
   hipStream_t stream = (hipStream_t)stream_;
   clear_errors();
   if (B < 0 || C < 0 || H <= 0 || W <= 0 || !ssim_sum) return DIMO_E_ARG;
-  if (hipMemsetAsync(ssim_sum, 0, sizeof(float), stream) != hipSuccess) return DIMO_E_LAUNCH;
+  // bit 1 of clamp_img1: the caller zeroed *ssim_sum together with its other accumulators (a 4-byte memset is a
+  // launch of its own on the step's critical path)
+  const bool prezeroed = (clamp_img1 & 2) != 0;
+  clamp_img1 &= 1;
+  if (!prezeroed && hipMemsetAsync(ssim_sum, 0, sizeof(float), stream) != hipSuccess) return DIMO_E_LAUNCH;
   const long planes = (long)B * C;
   if (planes == 0) return DIMO_OK;
   if (!img1 || !img2 || !dL_dmean || !dL_dimg1 || planes > 65535) return DIMO_E_ARG;

@@ -394,7 +394,8 @@ class Trainer:
         self._mark("timenet_fwd")
         # accumulated by the skinning backward; one zero-fill for both and for the loss accumulator
         o_q = (dxyz_c.numel() + 3) // 4 * 4  # 16-byte aligned start of the quaternion rows
-        zeroed = torch.zeros(o_q + dquat_c.numel() + 4, **f32)
+        n_motions = len({t[0] for t in mine})
+        zeroed = torch.zeros(o_q + dquat_c.numel() + 4 + n_motions, **f32)
         g_dxyz = zeroed[:dxyz_c.numel()].view_as(dxyz_c)
         g_dquat = zeroed[o_q:o_q + dquat_c.numel()].view_as(dquat_c)
         by_motion = {}
@@ -431,7 +432,8 @@ class Trainer:
         for w_ in ex.total_words(n):
             self.renderer.capacity.track(w_)
 
-        loss_accum = zeroed[-4:-3]
+        loss_accum = zeroed[o_q + dquat_c.numel():o_q + dquat_c.numel() + 1]
+        ssums = zeroed[o_q + dquat_c.numel() + 4:]
         ssim_terms, keep = [], []
         # the target batches are gathered while the renders are still in flight (before the joins below)
         gathered = {}
@@ -445,10 +447,10 @@ class Trainer:
             gt, mask = gathered[m]
             share = B / n_img
             # SSIM on the clamped render; its gradient image feeds the loss kernel
-            ssum = torch.empty(1, **f32)
+            ssum = ssums[len(ssim_terms):len(ssim_terms) + 1]  # zeroed with the step's other accumulators
             coef = self._const(-c.lambda_ssim * share)
             ssim_grad = torch.empty(B, 3, H, W, **f32)
-            _lib.check(L.dimo_ssim_forward_backward(B, 3, H, W, 1, _lib.ptr(img), _lib.ptr(gt), _lib.ptr(coef),
+            _lib.check(L.dimo_ssim_forward_backward(B, 3, H, W, 1 | 2, _lib.ptr(img), _lib.ptr(gt), _lib.ptr(coef),
                                                     _lib.ptr(ssum), _lib.ptr(ssim_grad), stream),
                        "dimo_ssim_forward_backward")
             ssim_terms.append((ssum, c.lambda_ssim * share, float(B * 3 * H * W)))

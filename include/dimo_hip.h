@@ -155,7 +155,8 @@ int dimo_ssim_backward(int B, int C, int H, int W, int clamp_img1, const float *
                        void *stream);
 /* Value and gradient in one launch (the training loss always needs both, main_train_dimo.py:343 + :415): ssim_sum as
  * dimo_ssim_forward, dL_dimg1 as dimo_ssim_backward with upstream dL_dmean -- the derivative planes never leave the
- * chip (each workgroup recomputes them on its tile's halo). */
+ * chip (each workgroup recomputes them on its tile's halo).  clamp_img1 bit 1 (value 2): *ssim_sum is already zero
+ * (the caller cleared it with its other accumulators), skip the memset. */
 int dimo_ssim_forward_backward(int B, int C, int H, int W, int clamp_img1, const float *img1, const float *img2,
                                const float *dL_dmean /* 1 float, device */, float *ssim_sum, float *dL_dimg1,
                                void *stream);
