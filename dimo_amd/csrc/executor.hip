@@ -267,6 +267,31 @@ extern "C" int dimo_executor_backward_launch(void *h, const dimo_step_common *c,
   return DIMO_OK;
 }
 
+// Batched ranges only.  The private stream the range starting at render `first` runs on (null without one): the
+// caller may enqueue that range's loss kernels THERE, behind its forward, instead of joining the caller's stream --
+// a motion's whole chain (forward, losses, rasterizer backward) then needs no cross-stream event until the skinning
+// backward, and dimo_executor_backward_launch_in_order continues it.
+extern "C" void *dimo_executor_range_stream(void *h, int first) {
+  Executor *ex = reinterpret_cast<Executor *>(h);
+  if (!ex || !ex->batched || ex->streams.empty() || first < 0 || first >= (int)ex->range_stream.size()) return nullptr;
+  const int si = ex->range_stream[first];
+  return si >= 0 ? (void *)ex->streams[si] : nullptr;
+}
+extern "C" int dimo_executor_backward_launch_in_order(void *h, const dimo_step_common *c, int first, int count,
+                                                      const dimo_render_desc *d) {
+  Executor *ex = reinterpret_cast<Executor *>(h);
+  if (!ex || !c || first < 0 || count < 0 || (count > 0 && !d)) return DIMO_E_ARG;
+  if (count == 0) return DIMO_OK;
+  if (!ex->batched || ex->streams.empty() || first + count > (int)ex->render_done.size()) return DIMO_E_ARG;
+  const int si = ex->range_stream[first];
+  if (si < 0) return DIMO_E_ARG;
+  clear_errors();
+  hipStream_t s = ex->streams[si];
+  const int rc = batched_backward_raster(c, d, first, count, s);
+  if (rc) return rc;
+  return hipEventRecord(ex->render_done[first], s) == hipSuccess ? DIMO_OK : DIMO_E_LAUNCH;
+}
+
 // On the caller's stream: wait for the rasterizer backward of renders [first, first + count), then the skinning
 // backward accumulating into the shared gradient views (g_f_dc += g_shs included).
 extern "C" int dimo_executor_backward_accumulate(void *h, const dimo_step_common *c, int first, int count,

@@ -134,6 +134,15 @@ class StepExecutor:
                                                         C.addressof(self.descs), _lib.current_stream()),
                    "dimo_executor_backward_launch")
 
+    def range_stream(self, first):
+        """Raw handle of the private stream of the batched range starting at `first` (None if there is none)."""
+        return self.L.dimo_executor_range_stream(self.handle, first) or None
+
+    def backward_launch_in_order(self, first, count):
+        _lib.check(self.L.dimo_executor_backward_launch_in_order(self.handle, C.addressof(self.common), first, count,
+                                                                 C.addressof(self.descs)),
+                   "dimo_executor_backward_launch_in_order")
+
     def backward_accumulate(self, first, count):
         _lib.check(self.L.dimo_executor_backward_accumulate(self.handle, C.addressof(self.common), first, count,
                                                             C.addressof(self.descs), _lib.current_stream()),

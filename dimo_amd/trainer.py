@@ -164,6 +164,7 @@ class Trainer:
         self.marks = None  # set to [] to collect (name, torch.cuda.Event) phase marks on the main stream
         self.skipped_steps = 0
         self._flat_adam = type(self.optimizer).__name__ == "FlatAdam"
+        self._inorder_losses = os.environ.get("DIMO_INORDER_LOSSES", "1") == "1"
         # direct HIP pipeline: GPU, stage s2, degree-0 colour (DIMO's configuration), product rasterizer
         self.direct = (direct if direct is not None else True) and self.device.type == "cuda" \
             and cfg.stage >= "s2" and cfg.sh_degree == 0 and renderer._rasterizer_factory is None \
@@ -424,6 +425,22 @@ class Trainer:
                 d.out_normal = (normal.data_ptr() + b * 3 * HW4) if normal is not None else None
                 d.out_alpha = alpha.data_ptr() + b * HW4
                 i += 1
+        # the target batches are gathered before the renders are launched: the private streams fork from this
+        # stream, so whatever is enqueued here so far is visible to the loss kernels they run
+        gathered = {}
+        for m, trs in by_motion.items():
+            gts = [self.targets.get(*t) for t in trs]
+            gathered[m] = (torch.stack([x[0] for x in gts]), gts[0][1])
+            self._const(-c.lambda_ssim * (len(trs) / n_img))
+        # ... and every buffer the loss kernels write is allocated here, BEFORE the forks: memory handed out later could
+        # be a block whose last use is a kernel still pending on this stream, which a private stream would not wait for
+        loss_bufs = {}
+        for m, trs in by_motion.items():
+            img, depth, normal, alpha = bufs[m]
+            loss_bufs[m] = (torch.empty_like(img), torch.empty_like(img),
+                            torch.empty_like(depth) if c.add_depth else None,
+                            torch.empty_like(normal) if (c.add_normal and normal is not None) else None,
+                            torch.empty_like(alpha))
         if ex.ranged:  # one batch per motion, on alternating private streams
             for m, trs in by_motion.items():
                 ex.forward_range(first[m], len(trs))
@@ -435,36 +452,38 @@ class Trainer:
         loss_accum = zeroed[o_q + dquat_c.numel():o_q + dquat_c.numel() + 1]
         ssums = zeroed[o_q + dquat_c.numel() + 4:]
         ssim_terms, keep = [], []
-        # the target batches are gathered while the renders are still in flight (before the joins below)
-        gathered = {}
-        for m, trs in by_motion.items():
-            gts = [self.targets.get(*t) for t in trs]
-            gathered[m] = (torch.stack([x[0] for x in gts]), gts[0][1])
         for m, trs in by_motion.items():
             B = len(trs)
             img, depth, normal, alpha = bufs[m]
-            ex.join(first[m], B)  # only this motion's renders: the other motions keep rendering underneath
+            # batched ranges: this motion's losses and rasterizer backward continue ON ITS OWN STREAM, in order behind
+            # its renders (no cross-stream event until the skinning backward); otherwise join this stream
+            own = ex.range_stream(first[m]) if (ex.ranged and self._inorder_losses) else None
+            if own is None:
+                ex.join(first[m], B)  # only this motion's renders: the other motions keep rendering underneath
+            stream_m = own if own is not None else stream
             gt, mask = gathered[m]
             share = B / n_img
             # SSIM on the clamped render; its gradient image feeds the loss kernel
             ssum = ssums[len(ssim_terms):len(ssim_terms) + 1]  # zeroed with the step's other accumulators
             coef = self._const(-c.lambda_ssim * share)
-            ssim_grad = torch.empty(B, 3, H, W, **f32)
+            ssim_grad, *grad_out = loss_bufs[m]
             _lib.check(L.dimo_ssim_forward_backward(B, 3, H, W, 1 | 2, _lib.ptr(img), _lib.ptr(gt), _lib.ptr(coef),
-                                                    _lib.ptr(ssum), _lib.ptr(ssim_grad), stream),
+                                                    _lib.ptr(ssum), _lib.ptr(ssim_grad), stream_m),
                        "dimo_ssim_forward_backward")
             ssim_terms.append((ssum, c.lambda_ssim * share, float(B * 3 * H * W)))
             w_mse = [c.lambda_mse * (1.0 if (v == 0 or f == 0) else 0.5) / (3 * H * W) for (_m, v, f) in trs]
             gi, gd, gn, ga = fused_image_loss(img, depth if c.add_depth else None, normal if c.add_normal else None,
                                               alpha, gt, mask, w_mse, loss_weights(c, B, n_img, H, W), ssim_grad,
-                                              loss_accum)
-            keep.append((gi, gd, gn, ga))
+                                              loss_accum, out=tuple(grad_out), stream=stream_m)
+            keep.append((gi, gd, gn, ga, ssim_grad))
             for b in range(B):
                 d = ex.descs[first[m] + b]
                 d.g_color, d.g_alpha = gi.data_ptr() + b * 3 * HW4, ga.data_ptr() + b * HW4
                 d.g_depth = (gd.data_ptr() + b * HW4) if gd is not None else None
                 d.g_normal = (gn.data_ptr() + b * 3 * HW4) if gn is not None else None
-            if ex.ranged or not ex.batched:
+            if own is not None:
+                ex.backward_launch_in_order(first[m], B)
+            elif ex.ranged or not ex.batched:
                 ex.backward_launch(first[m], B)  # overlaps with the next motion's losses on this stream
             if g.vae_latent:  # KL term of this motion (main_train_dimo.py:355-360): tiny, autograd
                 mu, lv = g._mu[m], g._log_var[m]

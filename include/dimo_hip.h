@@ -306,6 +306,12 @@ int dimo_executor_join(void *executor, int first, int count, void *main_stream);
 /* rasterizer backward of renders [first, first+count) on their streams (after main_stream's current tail) ... */
 int dimo_executor_backward_launch(void *executor, const dimo_step_common *common, int first, int count,
                                   const dimo_render_desc *renders, void *main_stream);
+/* batched ranges (n_streams < 0): the private stream of the range that starts at render `first` (NULL if none), so
+ * that the caller can enqueue the range's loss kernels behind its forward without a cross-stream join, and the
+ * rasterizer backward continuing on that stream (no fork from a caller stream) */
+void *dimo_executor_range_stream(void *executor, int first);
+int dimo_executor_backward_launch_in_order(void *executor, const dimo_step_common *common, int first, int count,
+                                           const dimo_render_desc *renders);
 /* ... and, on main_stream, per render: wait for it, g_f_dc += g_shs, skinning backward (accumulate) */
 int dimo_executor_backward_accumulate(void *executor, const dimo_step_common *common, int first, int count,
                                       const dimo_render_desc *renders, void *main_stream);
