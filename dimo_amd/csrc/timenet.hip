@@ -943,16 +943,7 @@ extern "C" int dimo_timenet_forward(const dimo_timenet_desc *d, int P, int M, co
       g.Wp[l] = ws + pl.packed[l];
     }
     pack_weights_kernel<<<dim3(16, pa.njobs), 256, 0, s>>>(pa);
-    // 128 workgroups for 256 CUs: ask for enough LDS that two of them cannot share a CU (4 waves per SIMD would
-    // halve each workgroup's MFMA rate while the other half of the chip idles)
-    static const bool once = [] {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(timenet_fwd_fused_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-      return true;
-    }();
-    (void)once;
-    const int spread = getenv("DIMO_TIMENET_NOSPREAD") ? 0 : 48 * 1024;
-    timenet_fwd_fused_kernel<<<(R + FR - 1) / FR, 512, spread, s>>>(g);
+    timenet_fwd_fused_kernel<<<(R + FR - 1) / FR, 512, 0, s>>>(g);
     return check_launch();
   }
   {
@@ -1022,12 +1013,6 @@ extern "C" int dimo_timenet_backward(const dimo_timenet_desc *d, int P, int M, c
     }
     for (int l = 0; l < D; ++l) g.mask[l] = ws + pl.act[l], g.dz[l] = ws + pl.dz[l], g.ld[l] = act_ld(pl, l);
     pack_weights_t_kernel<<<dim3(16, pa.njobs), 256, 0, s>>>(pa);
-    static const bool once = [] {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(timenet_bwd_fused_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-      return true;
-    }();
-    (void)once;
     timenet_bwd_fused_kernel<<<(R + FR - 1) / FR, 512, 0, s>>>(g);
   }
   if (!fused) {

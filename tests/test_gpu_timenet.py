@@ -66,6 +66,9 @@ def _close(got, ref, name, tol=1e-4):
     (8, 256, (4,), 32, 3, 203),   # ragged rows, a latent row used twice
     (3, 64, (), 8, 2, 70),        # no skip, narrow
     (4, 128, (1,), 0, 1, 33),     # no latent code
+    (4, 256, (1,), 0, 2, 40),     # one-launch path: early skip, no latent code (72 embedding columns)
+    (3, 256, (), 8, 1, 17),       # one-launch path: no skip layer, a single partial 16-row block
+    (2, 256, (0,), 16, 2, 64),    # one-launch path: the skip right after the first layer
 ])
 def test_timenet_forward_backward_matches_float64_autograd(D, W, skips, L, P, M):
     from dimo_amd.fused_timenet import FusedTimeNet
