@@ -92,6 +92,30 @@ def test_direct_pipeline_equals_autograd_pipeline(vae, arap):
     assert torch.isfinite(gb).all()
 
 
+def test_direct_pipeline_ragged_tiles_and_three_view_groups():
+    """72^2 images (4.5 tiles per side: the last tile row / column is partial) and three views of ONE (motion,
+    frame) pair per motion (a deformation group of three renders): direct pipeline == autograd pipeline."""
+    from dimo_amd.rasterizer import CapacityPolicy
+    from dimo_amd.renderer import Renderer
+    from dimo_amd.synth import init_synthetic_model
+    from dimo_amd.trainer import TrainConfig, Trainer
+    cfg = TrainConfig(num_pts=3000, num_cpts=40, num_motions=3, num_frames=5, num_views=5, motions_per_step=2,
+                      views_per_step=3, frames_per_step=1, resolution=72)
+    res = []
+    for direct in (False, True):
+        rd = Renderer(sh_degree=0, num_latent_code=cfg.num_motions, add_normal=True, device="cuda",
+                      capacity=CapacityPolicy(initial=1 << 18) if direct else None)
+        init_synthetic_model(rd, cfg.num_pts, cfg.num_cpts, seed=3, num_latent=cfg.num_motions)
+        tr = Trainer(cfg, rd, direct=direct)
+        tr.optimizer.step = lambda *a, **k: None
+        rd.gaussians.zero_grad = lambda: None
+        tr.train_step(tr.sample())
+        res.append((tr.last_loss.item(), rd.gaussians.flat_grads.clone()))
+    (la, ga), (lb, gb) = res
+    assert abs(la - lb) <= 1e-5 * abs(la), (la, lb)
+    assert (ga - gb).abs().sum() / ga.abs().sum() < 1e-4
+
+
 def _dp_gpu_worker(rank, world, port, out):
     import os
     import torch.distributed as dist
