@@ -41,23 +41,38 @@ __device__ __forceinline__ void pixel_of_thread(int tile_x, int tile_y, int &px,
   py = tile_y * TILE + (wave >> 1) * 8 + (lane >> 3);
 }
 
-// 4-bit mask of the tile's 8x8 quadrants (bit = wave index) that the alpha >= 1/255 region of a splat
-// can reach.  Conservative: the threshold radius is inflated and half a pixel is added on each side.
+// 4-bit mask of the tile's 8x8 quadrants (bit = wave index) that the alpha >= 1/255 region of a splat can reach:
+//     alpha >= 1/255  <=>  q(d) = A dx^2 + 2 B dx dy + C dy^2 <= tau = 2 ln(255 opacity),
+// so a quadrant is reachable iff the minimum of the convex form q over its pixel-centre rectangle is <= tau.  That
+// minimum is 0 if the centre lies inside, else it sits on one of the four edges (a clamped 1-D minimiser each).
+// Conservative: tau carries slack for the exp / log rounding of the kernels' own test.  (A first version tested the
+// ellipse's bounding box: a quarter of the quadrant visits it let through had no active pixel -- the box corners.)
+__device__ __forceinline__ float edge_min(float P, float Q, float R, float fixed, float lo, float hi) {
+  // min over t in [lo, hi] of P fixed^2 + 2 Q fixed t + R t^2   (R > 0)
+  const float t = fminf(fmaxf(-Q * fixed / R, lo), hi);
+  return P * fixed * fixed + 2.0f * Q * fixed * t + R * t * t;
+}
+__device__ __forceinline__ bool rect_reach(float A, float B, float C, float tau, float u0, float u1, float v0,
+                                           float v1) {
+  if (u0 <= 0.0f && u1 >= 0.0f && v0 <= 0.0f && v1 >= 0.0f) return true;
+  const float m = fminf(fminf(edge_min(A, B, C, u0, v0, v1), edge_min(A, B, C, u1, v0, v1)),
+                        fminf(edge_min(C, B, A, v0, u0, u1), edge_min(C, B, A, v1, u0, u1)));
+  return m <= tau;
+}
 __device__ __forceinline__ uint32_t quadrant_mask(float gx, float gy, float A, float B, float C, float opacity,
                                                   int tile_x, int tile_y) {
   if (!(opacity * 255.0f >= 1.0f)) return 0u;  // alpha = min(.99, o * G) with G <= 1 can never reach 1/255
   const float det = A * C - B * B;
-  if (!(det > 0.0f)) return 0xfu;  // degenerate conic: no culling
-  const float tau = 2.0f * __logf(opacity * 255.0f) * 1.02f + 0.05f;  // d_M^2 bound with slack for exp/log rounding
-  const float inv_det = 1.0f / det;
-  const float hx = sqrtf(tau * C * inv_det) + 0.5f, hy = sqrtf(tau * A * inv_det) + 0.5f;
-  const float x0 = (float)(tile_x * TILE), y0 = (float)(tile_y * TILE);
-  const bool left = gx - hx <= x0 + 7.0f && gx + hx >= x0;
-  const bool right = gx - hx <= x0 + 15.0f && gx + hx >= x0 + 8.0f;
-  const bool top = gy - hy <= y0 + 7.0f && gy + hy >= y0;
-  const bool bottom = gy - hy <= y0 + 15.0f && gy + hy >= y0 + 8.0f;
-  return (uint32_t)(left && top) | ((uint32_t)(right && top) << 1) | ((uint32_t)(left && bottom) << 2) |
-         ((uint32_t)(right && bottom) << 3);
+  if (!(det > 0.0f) || !(A > 0.0f) || !(C > 0.0f)) return 0xfu;  // degenerate conic: no culling
+  const float tau = 2.0f * __logf(opacity * 255.0f) * 1.02f + 0.05f;  // bound on q with slack for exp/log rounding
+  // pixel centres of the quadrants relative to the splat centre, half a pixel of margin on each side
+  const float x0 = (float)(tile_x * TILE) - gx, y0 = (float)(tile_y * TILE) - gy;
+  const float ul0 = x0 - 0.5f, ul1 = x0 + 7.5f, ur0 = x0 + 7.5f, ur1 = x0 + 15.5f;
+  const float vt0 = y0 - 0.5f, vt1 = y0 + 7.5f, vb0 = y0 + 7.5f, vb1 = y0 + 15.5f;
+  return (uint32_t)rect_reach(A, B, C, tau, ul0, ul1, vt0, vt1) |
+         ((uint32_t)rect_reach(A, B, C, tau, ur0, ur1, vt0, vt1) << 1) |
+         ((uint32_t)rect_reach(A, B, C, tau, ul0, ul1, vb0, vb1) << 2) |
+         ((uint32_t)rect_reach(A, B, C, tau, ur0, ur1, vb0, vb1) << 3);
 }
 
 // Every wave builds the ascending list of batch entries whose mask has its bit set.  Returns the count.
@@ -249,6 +264,26 @@ __device__ __forceinline__ void blend_bwd_body(
     const float bxf = (float)bx, byf = (float)by;
     const float *const ck_item = ckpt + ((size_t)(lo / BUCKET) + tile + blo / BUCKET) * (CKPT_FLOATS * TILE * TILE);
 
+    __syncthreads();  // previous item fully consumed
+    if (wave == 0 && lane < count) {
+      const uint32_t g = vals_sorted[lo + blo + lane];
+      const float4 *rp = reinterpret_cast<const float4 *>(splat + g);
+      const float4 a = rp[0], b = rp[1];
+      s_geo[lane] = a;
+      s_col[lane] = b;
+      s_aux[lane] = rp[2];
+      if (NORMAL) s_nz[lane] = rp[3].x;
+      s_mask[lane] = quadrant_mask(a.x, a.y, a.z, a.w, b.x, b.y, tile_x, tile_y);
+      const uint2 rc = *reinterpret_cast<const uint2 *>(rect + 4 * (size_t)g);
+      const int x0 = rc.x & 0xffff, y0 = rc.x >> 16, x1 = rc.y & 0xffff;
+      s_emit[lane] = (g == 0 ? 0u : offsets[g - 1]) + (uint32_t)((tile_y - y0) * (x1 - x0) + (tile_x - x0));
+    }
+#pragma unroll
+    for (int k = 0; k < QPW; ++k)
+      reinterpret_cast<float4 *>(&s_acc[0][0])[k * (64 * WAVES) + threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
+    // (the records are staged BEFORE the pixel state is loaded: the quadrant tests need registers, and with the four
+    // quadrants' state already live they spilled)
+    __builtin_amdgcn_sched_barrier(0);
     // per-quadrant pixel state.  Every load is unconditional (clamped pixel index, substitute pointer for an absent
     // gradient image) and the predicates are applied afterwards with selects: a branch around a load makes the
     // compiler drain the whole memory queue at the join, which put ~16 dependent round trips in front of every item.
@@ -306,23 +341,6 @@ __device__ __forceinline__ void blend_bwd_body(
 #pragma unroll
     for (int q = 1; q < QPW; ++q) wlast = max(wlast, deepest[q]);
 
-    __syncthreads();  // previous item fully consumed
-    if (wave == 0 && lane < count) {
-      const uint32_t g = vals_sorted[lo + blo + lane];
-      const float4 *rp = reinterpret_cast<const float4 *>(splat + g);
-      const float4 a = rp[0], b = rp[1];
-      s_geo[lane] = a;
-      s_col[lane] = b;
-      s_aux[lane] = rp[2];
-      if (NORMAL) s_nz[lane] = rp[3].x;
-      s_mask[lane] = quadrant_mask(a.x, a.y, a.z, a.w, b.x, b.y, tile_x, tile_y);
-      const uint2 rc = *reinterpret_cast<const uint2 *>(rect + 4 * (size_t)g);
-      const int x0 = rc.x & 0xffff, y0 = rc.x >> 16, x1 = rc.y & 0xffff;
-      s_emit[lane] = (g == 0 ? 0u : offsets[g - 1]) + (uint32_t)((tile_y - y0) * (x1 - x0) + (tile_x - x0));
-    }
-#pragma unroll
-    for (int k = 0; k < QPW; ++k)
-      reinterpret_cast<float4 *>(&s_acc[0][0])[k * (64 * WAVES) + threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
     // ascending list of the records that can reach any pixel of this wave's quadrants
     constexpr uint32_t QBITS = ((1u << QPW) - 1u);
