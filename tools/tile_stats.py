@@ -53,11 +53,17 @@ for t in range(1024):
     A, B, C_, o = e[:, 2], e[:, 3], e[:, 4], e[:, 5]
     det = A * C_ - B * B
     tau = 2.0 * torch.log(torch.clamp(o * 255.0, min=1e-9)) * 1.02 + 0.05
-    hx = torch.sqrt(torch.clamp(tau * C_ / det, min=0)) + 0.5; hy = torch.sqrt(torch.clamp(tau * A / det, min=0)) + 0.5
-    x0, y0 = tx * 16.0, ty * 16.0
-    left = (e[:, 0] - hx <= x0 + 7) & (e[:, 0] + hx >= x0); right = (e[:, 0] - hx <= x0 + 15) & (e[:, 0] + hx >= x0 + 8)
-    top = (e[:, 1] - hy <= y0 + 7) & (e[:, 1] + hy >= y0); bot = (e[:, 1] - hy <= y0 + 15) & (e[:, 1] + hy >= y0 + 8)
-    qm = torch.stack([left & top, right & top, left & bot, right & bot], 1) & (o * 255.0 >= 1.0)[:, None]  # [L,4]
+    x0, y0 = tx * 16.0 - e[:, 0], ty * 16.0 - e[:, 1]
+    def edge_min(P, Q, R, fixed, lo_, hi_):
+        tt = torch.minimum(torch.maximum(-Q * fixed / R, lo_), hi_)
+        return P * fixed * fixed + 2 * Q * fixed * tt + R * tt * tt
+    def reach(u0, u1, v0, v1):
+        inside = (u0 <= 0) & (u1 >= 0) & (v0 <= 0) & (v1 >= 0)
+        m = torch.minimum(torch.minimum(edge_min(A, B, C_, u0, v0, v1), edge_min(A, B, C_, u1, v0, v1)),
+                          torch.minimum(edge_min(C_, B, A, v0, u0, u1), edge_min(C_, B, A, v1, u0, u1)))
+        return inside | (m <= tau)
+    ul, ur, vt, vb = (x0 - 0.5, x0 + 7.5), (x0 + 7.5, x0 + 15.5), (y0 - 0.5, y0 + 7.5), (y0 + 7.5, y0 + 15.5)
+    qm = torch.stack([reach(*ul, *vt), reach(*ur, *vt), reach(*ul, *vb), reach(*ur, *vb)], 1) & (o * 255.0 >= 1.0)[:, None]
     qm = qm | (det <= 0)[:, None]
     tot["R"] += hi - lo
     for q in range(4):
