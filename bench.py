@@ -221,14 +221,17 @@ def main():
                     traffic = traffic * rpl / pj["renders_per_launch"]
             except Exception:
                 traffic = None
+        shape_name = {(100000, 512): "C3", (50000, 256): "C2 shape", (200000, 1024): "C5 shape"}.get(
+            (args.num_pts, args.resolution), "custom")
         res = {
-            "metric": "train-step frames/sec @100k Gaussians 512^2 (renders through deform+raster fwd+bwd+losses+Adam)",
+            "metric": f"train-step frames/sec @{args.num_pts // 1000}k Gaussians {args.resolution}^2 (renders through "
+                      f"deform+raster fwd+bwd+losses+Adam)",
             "value": renders_total / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic (seeded Gaussians initialised as the reference does, random-init TimeNet, "
                     "random targets; no dataset/LPIPS weights offline; LPIPS/ARAP/GA/KL terms excluded)",
-            "config": {"workload": f"C3: {args.num_pts} Gaussians, 512 control points, {args.resolution}^2, stage s2, "
+            "config": {"workload": f"{shape_name}: {args.num_pts} Gaussians, 512 control points, {args.resolution}^2, stage s2, "
                                    f"diff_gauss flavour (rgb+depth+normal+alpha), 8 renders/GPU/step "
                                    f"(2 motions x 2 views x 2 frames per GPU)",
                        "renders_per_step": int(renders_total / args.steps), "parallelism": f"dp{world}",
