@@ -92,6 +92,8 @@ class TrainConfig:
     densify_opacity_threshold_s2: float = 0.01
     init_type: str = "ag"
     # regularisers (configs/train_config.yaml:57-65).  Off by default: BASELINE.json's metric is quoted without them
+    use_lpips: bool = False   # main_train_dimo.py:339-341 (needs the metric's weights: dimo_amd/lpips_vgg.py)
+    lambda_lpips: float = 1000.0  # configs/train_config.yaml:44
     use_arap: bool = False
     arap_start_iter_s1: int = 1000
     arap_end_iter_s2: int = 2000
@@ -285,7 +287,20 @@ class Trainer:
         if c.add_normal:
             normal = torch.stack([o["normal"] for o in outs]).permute(0, 2, 3, 1)
             loss = loss + c.lambda_bilateral * share * compute_bilateral_normal_smoothness_loss(normal, img_hwc)
+        if c.use_lpips:
+            loss = loss + c.lambda_lpips * share * self.lpips_metric()(img, gt).mean()
         return loss
+
+    def lpips_metric(self):
+        """The LPIPS module of `use_lpips` (main_train_dimo.py:150).  Assign `trainer.lpips` a module carrying the
+        published weights; without one a fixed random-weight instance stands in (the wiring, not the metric)."""
+        if getattr(self, "lpips", None) is None:
+            from .lpips_vgg import LPIPS
+            gen = torch.random.get_rng_state()
+            torch.manual_seed(1234)
+            self.lpips = LPIPS().to(self.device)
+            torch.random.set_rng_state(gen)
+        return self.lpips
 
     def regularizer_loss(self, m):
         """ARAP term of one motion (main_train_dimo.py:374-384); None when switched off / outside its window."""
@@ -457,7 +472,7 @@ class Trainer:
             img, depth, normal, alpha = bufs[m]
             # batched ranges: this motion's losses and rasterizer backward continue ON ITS OWN STREAM, in order behind
             # its renders (no cross-stream event until the skinning backward); otherwise join this stream
-            own = ex.range_stream(first[m]) if (ex.ranged and self._inorder_losses) else None
+            own = ex.range_stream(first[m]) if (ex.ranged and self._inorder_losses and not c.use_lpips) else None
             if own is None:
                 ex.join(first[m], B)  # only this motion's renders: the other motions keep rendering underneath
             stream_m = own if own is not None else stream
@@ -476,6 +491,12 @@ class Trainer:
                                               alpha, gt, mask, w_mse, loss_weights(c, B, n_img, H, W), ssim_grad,
                                               loss_accum, out=tuple(grad_out), stream=stream_m)
             keep.append((gi, gd, gn, ga, ssim_grad))
+            if c.use_lpips:  # torch (MIOpen) on this stream, on the clamped render; its gradient joins the image's
+                x = img.detach().clamp(0.0, 1.0).requires_grad_(True)
+                lp = c.lambda_lpips * share * self.lpips_metric()(x, gt).mean()
+                (g_lp,) = torch.autograd.grad(lp, x)
+                gi.add_(g_lp * ((img >= 0.0) & (img <= 1.0)))
+                loss_accum += lp.detach()
             for b in range(B):
                 d = ex.descs[first[m] + b]
                 d.g_color, d.g_alpha = gi.data_ptr() + b * 3 * HW4, ga.data_ptr() + b * HW4

@@ -116,6 +116,30 @@ def test_direct_pipeline_ragged_tiles_and_three_view_groups():
     assert (ga - gb).abs().sum() / ga.abs().sum() < 1e-4
 
 
+def test_direct_pipeline_with_lpips_term():
+    """`use_lpips` (main_train_dimo.py:339-341) on the fixed random-weight stand-in: the direct pipeline adds the
+    metric's image gradient to the loss kernel's, and must agree with the autograd pipeline."""
+    from dimo_amd.rasterizer import CapacityPolicy
+    from dimo_amd.renderer import Renderer
+    from dimo_amd.synth import init_synthetic_model
+    from dimo_amd.trainer import TrainConfig, Trainer
+    cfg = TrainConfig(num_pts=2000, num_cpts=32, num_motions=3, num_frames=4, num_views=4, motions_per_step=2,
+                      views_per_step=2, frames_per_step=1, resolution=64, use_lpips=True, lambda_lpips=50.0)
+    res = []
+    for direct in (False, True):
+        rd = Renderer(sh_degree=0, num_latent_code=cfg.num_motions, add_normal=True, device="cuda",
+                      capacity=CapacityPolicy(initial=1 << 17) if direct else None)
+        init_synthetic_model(rd, cfg.num_pts, cfg.num_cpts, seed=2, num_latent=cfg.num_motions)
+        tr = Trainer(cfg, rd, direct=direct)
+        tr.optimizer.step = lambda *a, **k: None
+        rd.gaussians.zero_grad = lambda: None
+        tr.train_step(tr.sample())
+        res.append((tr.last_loss.item(), rd.gaussians.flat_grads.clone()))
+    (la, ga), (lb, gb) = res
+    assert abs(la - lb) <= 1e-4 * abs(la), (la, lb)
+    assert (ga - gb).abs().sum() / ga.abs().sum() < 1e-3  # MIOpen may pick different algorithms for the two graphs
+
+
 def test_direct_pipeline_more_renders_per_motion_than_a_batch():
     """10 renders per motion (5 frames x 2 views): a motion's range is split into launches of at most 8 renders,
     deformation groups must not straddle the split incorrectly.  direct pipeline == autograd pipeline."""
