@@ -52,6 +52,32 @@ def make_trainer(device, rank, world, num_pts, resolution, per_gpu=(2, 2, 2), ca
     return Trainer(cfg, rd, rank=rank, world_size=world), pol
 
 
+def kernel_rooflines(timing_iso, N, V, R, P, C=NFEAT):
+    """name -> algorithmic bytes per render (DESIGN.md section 4 / SURVEY.md 8d formulas), isolated time, GB/s,
+    fraction of the HBM peak.  The blend kernels are FP32-VALU bound (see `roofline.note`); the others stream."""
+    alg = {
+        "deform_fwd": 92 * N,
+        "preprocess_fwd": 56 * N + 77 * V,
+        "scan": 8 * N,
+        "sort": 4 * 24 * N,
+        "emit": 12 * N + 16 * N,           # level 1: (id, rect) in, ~2 N (id, depth) entries out
+        "ranges": 8 * 2 * N + 8 * (P // 256),  # level 2 count + scan + tile starts: the level-1 entries once more
+        "place": 8 * 2 * N + 12 * R,       # level 2 fill: entries in, one (key, value) per instance out
+        "blend_fwd": (28 + 4 * C) * R + 4 * (C + 1) * P + 8 * P,
+        "blend_bwd": (28 + 4 * C) * R + (8 * (C + 1) + 8) * P + (24 + 4 * C) * V,
+        "preprocess_bwd": (24 + 4 * C) * V + 56 * N + 56 * N + 12 * N,
+        "deform_bwd": 200 * N,
+    }
+    out = {}
+    for k, b in alg.items():
+        ms, n = timing_iso.get(k, (0.0, 0))
+        if not n or ms <= 0:
+            continue
+        t = ms / n * 1e-3
+        out[k] = {"algorithmic_bytes": float(b), "ms": ms / n, "GBps": b / t / 1e9, "frac_of_hbm_peak": b / t / 1e9 / HBM_PEAK_GBS}
+    return out
+
+
 def read_timing():
     from dimo_amd import _lib
     L = _lib.lib()
@@ -259,6 +285,9 @@ def main():
                              "fp32_vector_peak_flops": FP32_VALU_PEAK,
                              "note": "list entries x 256 pixels; culling and saturation skip most of them, so the "
                                      "rate is an upper-bound style figure, not executed FLOPs"},
+            # achieved HBM GB/s per kernel against the 8 TB/s peak, from the ALGORITHMIC bytes of
+            # DESIGN.md section 4 and the single-render launches measured alone on the device (timing_iso)
+            "kernel_rooflines": kernel_rooflines(timing_iso, args.num_pts, V, R, P),
             "kernels_ms_per_launch": {k: (v[0] / v[1] if v[1] else None) for k, v in timing_all.items()},
             "kernels_ms_per_launch_isolated": {k: (v[0] / v[1] if v[1] else None) for k, v in timing_iso.items()},
         }

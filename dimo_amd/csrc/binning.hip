@@ -226,97 +226,105 @@ struct BinGrid {
   int tiles_x, tiles_y, ss_shift, stx, sty, NS;  // supertile edge = 1 << ss_shift tiles, stx * sty = NS supertiles
 };
 constexpr int SEG = 256;        // list entries per wave (both levels)
-constexpr int MAX_SUPER = 256;  // supertiles (4 counters per lane at level 1)
+constexpr int MAX_SUPER = 256;  // supertiles (one level-1 thread each)
+static_assert(SEG == MAX_SUPER, "level 1: a workgroup has one thread per entry AND per supertile");
 
 // level-1 metadata in the bin workspace (uint32): [0, 256) list length, [256, 512) list start (multiple of SEG),
 // [512] number of level-2 windows, [1024, ...) supertile of every window
 constexpr int META_LEN = 0, META_START = MAX_SUPER, META_NWIN = 2 * MAX_SUPER, META_WIN = 4 * MAX_SUPER;
 
+// One workgroup (4 waves) per segment of 256 list entries, one wave per 64 of them: the entries of a segment reach a
+// supertile list in (wave, lane) order, so every wave counts its own entries per supertile, an exclusive prefix over
+// the four waves (one thread per supertile) orders them, and the fill pass adds the wave-local rank.  (A first
+// version walked the segment with ONE wave, four rounds of 64 entries chained through the running counts: with only
+// N / 256 waves per render the kernel is pure latency, and that chain was four times longer.)
 template <bool FILL>
 __device__ __forceinline__ void level1_body(int N, BinGrid gi, const uint32_t *__restrict__ perm,
                                             const uint64_t *__restrict__ nkeys, const uint16_t *__restrict__ rect,
                                             uint32_t *__restrict__ cnt1, const uint32_t *__restrict__ meta,
                                             uint2 *__restrict__ l1list, size_t l1cap) {
-  // per supertile: the segment's count so far (count pass) or its next free slot (fill pass); one wave per block
-  __shared__ uint32_t s_cnt[MAX_SUPER];
-  const int seg = blockIdx.x, lane = threadIdx.x;
+  __shared__ uint32_t s_cnt[SEG / 64][MAX_SUPER];  // count pass: per-wave counts; fill pass: per-wave first slots
+  const int seg = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const unsigned long long lt = (1ull << lane) - 1ull;
   uint32_t *row = cnt1 + (size_t)seg * MAX_SUPER;
+  // this thread's supertile: the segment's first slot in its list (fill pass), requested before anything else
+  const int my_s = threadIdx.x;  // SEG == MAX_SUPER == blockDim.x
+  const uint32_t my_base = (FILL && my_s < gi.NS) ? meta[META_START + my_s] + row[my_s] : 0u;
 #pragma unroll
-  for (int q = 0; q < MAX_SUPER / 64; ++q) {
-    const int sidx = q * 64 + lane;
-    s_cnt[sidx] = (FILL && sidx < gi.NS) ? meta[META_START + sidx] + row[sidx] : 0u;
-  }
+  for (int w = 0; w < SEG / 64; ++w) s_cnt[w][threadIdx.x] = 0u;
   int nbits = 0;
   while ((1 << nbits) < gi.NS) ++nbits;
-  // all loads of the segment first (id -> rectangle is a dependent gather: four of them in flight, not in turn)
-  uint32_t g_[SEG / 64], d_[SEG / 64];
-  uint2 rc_[SEG / 64];
+  const int k = seg * SEG + wave * 64 + lane;
+  const bool valid = k < N;
+  const uint32_t g = perm[min(k, N - 1)];
+  const uint32_t dbits = FILL ? (uint32_t)nkeys[min(k, N - 1)] : 0u;
+  const uint2 rc = *reinterpret_cast<const uint2 *>(rect + 4 * (size_t)g);
+  const int x0 = rc.x & 0xffff, y0 = rc.x >> 16, x1 = rc.y & 0xffff, y1 = rc.y >> 16;
+  const bool some = valid && x1 > x0 && y1 > y0;
+  const int sx0 = x0 >> gi.ss_shift, sx1 = (x1 - 1) >> gi.ss_shift;
+  const int sy0 = y0 >> gi.ss_shift, sy1 = (y1 - 1) >> gi.ss_shift;
+  // Fast path (every rectangle of the wave spans at most 2 x 2 supertiles): a Gaussian then has at most ONE
+  // supertile of each (column parity, row parity) class, and a supertile belongs to one class -- so four rounds, in
+  // each of which the lanes naming the same supertile are grouped by ballots over the id bits and ranked by lane,
+  // keep the list order per supertile.  ~50 instructions per round instead of one ballot per supertile (64+).
+  const bool fast = __ballot(some && (sx1 - sx0 >= 2 || sy1 - sy0 >= 2)) == 0;
+  __syncthreads();  // counters cleared
+  int c_sidx[4];
+  uint32_t c_rank[4];
+  bool c_has[4];
+  if (fast) {
 #pragma unroll
-  for (int it = 0; it < SEG / 64; ++it) {
-    const int k = min(seg * SEG + it * 64 + lane, N - 1);
-    g_[it] = perm[k];
-    d_[it] = FILL ? (uint32_t)nkeys[k] : 0u;
-  }
-#pragma unroll
-  for (int it = 0; it < SEG / 64; ++it) rc_[it] = *reinterpret_cast<const uint2 *>(rect + 4 * (size_t)g_[it]);
-#pragma unroll
-  for (int it = 0; it < SEG / 64; ++it) {
-    const bool valid = seg * SEG + it * 64 + lane < N;
-    const uint32_t g = g_[it], dbits = d_[it];
-    const uint2 rc = rc_[it];
-    const int x0 = rc.x & 0xffff, y0 = rc.x >> 16, x1 = rc.y & 0xffff, y1 = rc.y >> 16;
-    const bool some = valid && x1 > x0 && y1 > y0;
-    const int sx0 = x0 >> gi.ss_shift, sx1 = (x1 - 1) >> gi.ss_shift;
-    const int sy0 = y0 >> gi.ss_shift, sy1 = (y1 - 1) >> gi.ss_shift;
-    if (__ballot(some) == 0) continue;
-    if (__ballot(some && (sx1 - sx0 >= 2 || sy1 - sy0 >= 2)) == 0) {
-      // Fast path (every rectangle spans at most 2 x 2 supertiles): a Gaussian then has at most ONE supertile of
-      // each (column parity, row parity) class, and a supertile belongs to one class -- so four rounds, in each of
-      // which the lanes naming the same supertile are grouped by ballots over the id bits and ranked by lane, keep
-      // the list order per supertile.  ~50 instructions per round instead of one ballot per supertile (64+).
-      for (int cls = 0; cls < 4; ++cls) {
-        const int sx = sx0 + (((cls & 1) ^ sx0) & 1), sy = sy0 + (((cls >> 1) ^ sy0) & 1);
-        const bool has = some && sx <= sx1 && sy <= sy1;
-        const int sidx = has ? sy * gi.stx + sx : 0;
-        unsigned long long peers = __ballot(has);
-        if (peers == 0) continue;
-        for (int bit = 0; bit < nbits; ++bit) {
-          const unsigned long long bal = __ballot((sidx >> bit) & 1);
-          peers &= ((sidx >> bit) & 1) ? bal : ~bal;
-        }
-        const int leader = has ? __ffsll((long long)peers) - 1 : lane;
-        uint32_t base = 0;
-        if (has && lane == leader) {
-          base = s_cnt[sidx];
-          s_cnt[sidx] = base + (uint32_t)__popcll(peers);
-        }
-        if (FILL) {
-          base = (uint32_t)__shfl((int)base, leader, 64);
-          const size_t pos = (size_t)base + (uint32_t)__popcll(peers & lt);
-          if (has && pos < l1cap) l1list[pos] = make_uint2(g, dbits);
-        }
+    for (int cls = 0; cls < 4; ++cls) {
+      const int sx = sx0 + (((cls & 1) ^ sx0) & 1), sy = sy0 + (((cls >> 1) ^ sy0) & 1);
+      const bool has = some && sx <= sx1 && sy <= sy1;
+      const int sidx = has ? sy * gi.stx + sx : 0;
+      unsigned long long peers = __ballot(has);
+      for (int bit = 0; bit < nbits; ++bit) {
+        const unsigned long long bal = __ballot((sidx >> bit) & 1);
+        peers &= ((sidx >> bit) & 1) ? bal : ~bal;
       }
-      continue;
+      c_sidx[cls] = sidx, c_has[cls] = has, c_rank[cls] = (uint32_t)__popcll(peers & lt);
+      // one class per supertile: the group's first lane stores the group's size (nobody else writes that counter)
+      if (has && (peers & lt) == 0) s_cnt[wave][sidx] = (uint32_t)__popcll(peers);
     }
-    // general path: some rectangle of this group is larger -- one ballot per supertile
+  } else {  // general path: some rectangle of this wave is larger -- one ballot per supertile
+    int sx = 0, sy = 0;
+    for (int sidx = 0; sidx < gi.NS; ++sidx) {
+      const bool cov = some && sx >= sx0 && sx <= sx1 && sy >= sy0 && sy <= sy1;
+      const unsigned long long bal = __ballot(cov);
+      if (++sx == gi.stx) sx = 0, ++sy;
+      if (bal != 0 && lane == 0) s_cnt[wave][sidx] = (uint32_t)__popcll(bal);
+    }
+  }
+  __syncthreads();
+  {  // thread = supertile: the segment's count (count pass) / each wave's first slot (fill pass)
+    uint32_t run = my_base;
+#pragma unroll
+    for (int w = 0; w < SEG / 64; ++w) {
+      const uint32_t c = s_cnt[w][threadIdx.x];
+      if (FILL) s_cnt[w][threadIdx.x] = run;
+      run += c;
+    }
+    if (!FILL) row[threadIdx.x] = run;
+  }
+  if (!FILL) return;
+  __syncthreads();
+  if (fast) {
+#pragma unroll
+    for (int cls = 0; cls < 4; ++cls) {
+      const size_t pos = (size_t)s_cnt[wave][c_sidx[cls]] + c_rank[cls];
+      if (c_has[cls] && pos < l1cap) l1list[pos] = make_uint2(g, dbits);
+    }
+  } else {
     int sx = 0, sy = 0;
     for (int sidx = 0; sidx < gi.NS; ++sidx) {
       const bool cov = some && sx >= sx0 && sx <= sx1 && sy >= sy0 && sy <= sy1;
       const unsigned long long bal = __ballot(cov);
       if (++sx == gi.stx) sx = 0, ++sy;
       if (bal == 0) continue;
-      const uint32_t base = s_cnt[sidx];
-      if (FILL) {
-        const size_t pos = (size_t)base + (uint32_t)__popcll(bal & lt);
-        if (cov && pos < l1cap) l1list[pos] = make_uint2(g, dbits);
-      }
-      if (lane == 0) s_cnt[sidx] = base + (uint32_t)__popcll(bal);
+      const size_t pos = (size_t)s_cnt[wave][sidx] + (uint32_t)__popcll(bal & lt);
+      if (cov && pos < l1cap) l1list[pos] = make_uint2(g, dbits);
     }
-  }
-  if (!FILL) {
-#pragma unroll
-    for (int q = 0; q < MAX_SUPER / 64; ++q) row[q * 64 + lane] = s_cnt[q * 64 + lane];
   }
 }
 
@@ -539,7 +547,7 @@ __device__ __forceinline__ void level2_stage(BinGrid gi, uint32_t R_cap, const B
                     at<uint64_t>(bin, o.b_keys), at<uint32_t>(bin, o.b_vals));
 }
 template <bool FILL>
-__global__ void __launch_bounds__(64) level1_kernel(int N, BinGrid gi, BinPtrs o, void *geom, void *bin) {
+__global__ void __launch_bounds__(SEG) level1_kernel(int N, BinGrid gi, BinPtrs o, void *geom, void *bin) {
   level1_stage<FILL>(N, gi, o, geom, bin);
 }
 __global__ void __launch_bounds__(L1_PARTS *MAX_SUPER) level1_scan_kernel(int nseg, int NS, BinPtrs o, void *geom, void *bin) {
@@ -586,7 +594,7 @@ __global__ void __launch_bounds__(SORT_BLOCK) radix_scatter_batched_kernel(GeomL
                      at<uint32_t>(geom, L.nhist));
 }
 template <bool FILL>
-__global__ void __launch_bounds__(64) level1_batched_kernel(int N, BinGrid gi, BinPtrs o, RenderBatch b) {
+__global__ void __launch_bounds__(SEG) level1_batched_kernel(int N, BinGrid gi, BinPtrs o, RenderBatch b) {
   level1_stage<FILL>(N, gi, o, b.r[blockIdx.y].geom, b.r[blockIdx.y].bin);
 }
 __global__ void __launch_bounds__(L1_PARTS *MAX_SUPER) level1_scan_batched_kernel(int nseg, int NS, BinPtrs o, RenderBatch b) {
@@ -682,9 +690,9 @@ int bin_instances(int N, int H, int W, int64_t R_cap, const void *geom_c, void *
   const int nseg = (int)G.nseg1;
   {
     ScopedTimer tm(T_EMIT, stream);
-    if (N > 0) hipLaunchKernelGGL(level1_kernel<false>, dim3(nseg), dim3(64), 0, stream, N, gi, o, geom, bin);
+    if (N > 0) hipLaunchKernelGGL(level1_kernel<false>, dim3(nseg), dim3(SEG), 0, stream, N, gi, o, geom, bin);
     hipLaunchKernelGGL(level1_scan_kernel, dim3(1), dim3(L1_PARTS * MAX_SUPER), 0, stream, N > 0 ? nseg : 0, gi.NS, o, geom, bin);
-    if (N > 0) hipLaunchKernelGGL(level1_kernel<true>, dim3(nseg), dim3(64), 0, stream, N, gi, o, geom, bin);
+    if (N > 0) hipLaunchKernelGGL(level1_kernel<true>, dim3(nseg), dim3(SEG), 0, stream, N, gi, o, geom, bin);
   }
   {
     ScopedTimer tm(T_RANGES, stream);
@@ -732,10 +740,10 @@ int bin_instances_batched(const dimo_step_common &c, const RenderBatch &b, int n
   const int nseg = (int)G.nseg1;
   {
     ScopedTimer tm(T_EMIT, stream);
-    if (c.N > 0) hipLaunchKernelGGL(level1_batched_kernel<false>, dim3(nseg, n), dim3(64), 0, stream, c.N, gi, o, b);
+    if (c.N > 0) hipLaunchKernelGGL(level1_batched_kernel<false>, dim3(nseg, n), dim3(SEG), 0, stream, c.N, gi, o, b);
     hipLaunchKernelGGL(level1_scan_batched_kernel, dim3(1, n), dim3(L1_PARTS * MAX_SUPER), 0, stream, c.N > 0 ? nseg : 0, gi.NS,
                        o, b);
-    if (c.N > 0) hipLaunchKernelGGL(level1_batched_kernel<true>, dim3(nseg, n), dim3(64), 0, stream, c.N, gi, o, b);
+    if (c.N > 0) hipLaunchKernelGGL(level1_batched_kernel<true>, dim3(nseg, n), dim3(SEG), 0, stream, c.N, gi, o, b);
   }
   {
     ScopedTimer tm(T_RANGES, stream);
