@@ -386,13 +386,19 @@ __device__ __forceinline__ void level1_scan_body(int nseg, int NS, uint32_t *__r
     if (w < max_windows) meta[META_WIN + w] = (uint32_t)sidx;
 }
 
+// A workgroup (4 waves) per 256-entry window, one wave per 64 entries (same reasoning as level 1: few windows per
+// render, so the per-window chain is the kernel's duration).  Lane j of every wave owns tile j of the supertile.
+// Count pass: each wave's per-tile counts -> cnt2w[window][wave][tile], and the window's totals -> cnt2[window][tile]
+// (level2_scan turns those into the window's first slot per tile).  Fill pass: a wave starts at the window's first
+// slot plus the counts of the waves before it, and ranks its own entries with one ballot per tile.
 template <bool FILL>
 __device__ __forceinline__ void level2_body(BinGrid gi, uint32_t R_cap, const uint32_t *__restrict__ meta,
                                             const uint2 *__restrict__ l1list, size_t l1cap,
                                             const uint16_t *__restrict__ rect, uint32_t *__restrict__ cnt2,
-                                            const uint32_t *__restrict__ tstart, uint64_t *__restrict__ keys,
-                                            uint32_t *__restrict__ vals) {
-  const int lane = threadIdx.x;
+                                            uint32_t *__restrict__ cnt2w, const uint32_t *__restrict__ tstart,
+                                            uint64_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+  __shared__ uint32_t s_c[SEG / 64][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const unsigned long long lt = (1ull << lane) - 1ull;
   const uint32_t n_win = meta[META_NWIN];
   const int ss = 1 << gi.ss_shift, ntile = ss * ss;
@@ -404,23 +410,17 @@ __device__ __forceinline__ void level2_body(BinGrid gi, uint32_t R_cap, const ui
     const int my_tx = tx0 + (lane & (ss - 1)), my_ty = ty0 + (lane >> gi.ss_shift);
     const bool my_in = lane < ntile && my_tx < gi.tiles_x && my_ty < gi.tiles_y;
     uint32_t c = 0;
-    if (FILL && my_in) c = tstart[my_ty * gi.tiles_x + my_tx] + cnt2[(size_t)w * 64 + lane];
-    uint2 en_[SEG / 64], rc_[SEG / 64];
-#pragma unroll
-    for (int it = 0; it < SEG / 64; ++it) {
-      const size_t p = (size_t)w * SEG + it * 64 + lane;
-      en_[it] = l1list[p < pend ? p : 0];
-      if (!(p < pend)) en_[it] = make_uint2(0u, 0u);  // an unwritten slot may hold anything
+    if (FILL && my_in) {
+      c = tstart[my_ty * gi.tiles_x + my_tx] + cnt2[(size_t)w * 64 + lane];
+      for (int v = 0; v < wave; ++v) c += cnt2w[((size_t)w * (SEG / 64) + v) * 64 + lane];
     }
-#pragma unroll
-    for (int it = 0; it < SEG / 64; ++it) rc_[it] = *reinterpret_cast<const uint2 *>(rect + 4 * (size_t)en_[it].x);
-#pragma unroll
-    for (int it = 0; it < SEG / 64; ++it) {
-      const size_t p = (size_t)w * SEG + it * 64 + lane;
-      const bool valid = p < pend;
-      const uint2 en = en_[it], rc = rc_[it];
-      const int x0 = rc.x & 0xffff, y0 = rc.x >> 16, x1 = rc.y & 0xffff, y1 = rc.y >> 16;
-      if (__ballot(valid) == 0) break;
+    const size_t p = (size_t)w * SEG + wave * 64 + lane;
+    const bool valid = p < pend;
+    uint2 en = l1list[valid ? p : 0];
+    if (!valid) en = make_uint2(0u, 0u);  // an unwritten slot may hold anything
+    const uint2 rc = *reinterpret_cast<const uint2 *>(rect + 4 * (size_t)en.x);
+    const int x0 = rc.x & 0xffff, y0 = rc.x >> 16, x1 = rc.y & 0xffff, y1 = rc.y >> 16;
+    if (__ballot(valid) != 0) {
       for (int j = 0; j < ntile; ++j) {
         const int tx = tx0 + (j & (ss - 1)), ty = ty0 + (j >> gi.ss_shift);
         if (tx >= gi.tiles_x || ty >= gi.tiles_y) continue;
@@ -433,11 +433,18 @@ __device__ __forceinline__ void level2_body(BinGrid gi, uint32_t R_cap, const ui
             keys[pos] = ((uint64_t)(uint32_t)(ty * gi.tiles_x + tx) << 32) | en.y;
             vals[pos] = en.x;
           }
+        } else {
+          c += lane == j ? (uint32_t)__popcll(bal) : 0u;
         }
-        c += lane == j ? (uint32_t)__popcll(bal) : 0u;
       }
     }
-    if (!FILL) cnt2[(size_t)w * 64 + lane] = c;
+    if (!FILL) {
+      cnt2w[((size_t)w * (SEG / 64) + wave) * 64 + lane] = c;
+      __syncthreads();  // (the previous window's sums have been read: see the barrier below)
+      s_c[wave][lane] = c;
+      __syncthreads();
+      if (wave == 0) cnt2[(size_t)w * 64 + lane] = s_c[0][lane] + s_c[1][lane] + s_c[2][lane] + s_c[3][lane];
+    }
   }
 }
 
@@ -543,7 +550,8 @@ __device__ __forceinline__ void level1_stage(int N, BinGrid gi, const BinPtrs &o
 template <bool FILL>
 __device__ __forceinline__ void level2_stage(BinGrid gi, uint32_t R_cap, const BinPtrs &o, void *geom, void *bin) {
   level2_body<FILL>(gi, R_cap, at<uint32_t>(bin, o.b_meta), at<uint2>(bin, o.b_l1), o.l1cap,
-                    at<uint16_t>(geom, o.g_rect), at<uint32_t>(bin, o.b_cnt2), at<uint32_t>(bin, o.b_totals),
+                    at<uint16_t>(geom, o.g_rect), at<uint32_t>(bin, o.b_cnt2),
+                    at<uint32_t>(bin, o.b_cnt2) + o.max_windows * 64, at<uint32_t>(bin, o.b_totals),
                     at<uint64_t>(bin, o.b_keys), at<uint32_t>(bin, o.b_vals));
 }
 template <bool FILL>
@@ -554,7 +562,7 @@ __global__ void __launch_bounds__(L1_PARTS *MAX_SUPER) level1_scan_kernel(int ns
   level1_scan_body(nseg, NS, at<uint32_t>(geom, o.g_cnt1), at<uint32_t>(bin, o.b_meta), o.max_windows);
 }
 template <bool FILL>
-__global__ void __launch_bounds__(64) level2_kernel(BinGrid gi, uint32_t R_cap, BinPtrs o, void *geom, void *bin) {
+__global__ void __launch_bounds__(SEG) level2_kernel(BinGrid gi, uint32_t R_cap, BinPtrs o, void *geom, void *bin) {
   level2_stage<FILL>(gi, R_cap, o, geom, bin);
 }
 __global__ void __launch_bounds__(64) level2_scan_kernel(BinGrid gi, BinPtrs o, void *bin) {
@@ -602,7 +610,7 @@ __global__ void __launch_bounds__(L1_PARTS *MAX_SUPER) level1_scan_batched_kerne
                    o.max_windows);
 }
 template <bool FILL>
-__global__ void __launch_bounds__(64) level2_batched_kernel(BinGrid gi, uint32_t R_cap, BinPtrs o, RenderBatch b) {
+__global__ void __launch_bounds__(SEG) level2_batched_kernel(BinGrid gi, uint32_t R_cap, BinPtrs o, RenderBatch b) {
   level2_stage<FILL>(gi, R_cap, o, b.r[blockIdx.y].geom, b.r[blockIdx.y].bin);
 }
 __global__ void __launch_bounds__(64) level2_scan_batched_kernel(BinGrid gi, BinPtrs o, RenderBatch b) {
@@ -696,13 +704,13 @@ int bin_instances(int N, int H, int W, int64_t R_cap, const void *geom_c, void *
   }
   {
     ScopedTimer tm(T_RANGES, stream);
-    hipLaunchKernelGGL(level2_kernel<false>, dim3(L2_GRID), dim3(64), 0, stream, gi, cap, o, geom, bin);
+    hipLaunchKernelGGL(level2_kernel<false>, dim3(L2_GRID), dim3(SEG), 0, stream, gi, cap, o, geom, bin);
     hipLaunchKernelGGL(level2_scan_kernel, dim3(gi.NS), dim3(64), 0, stream, gi, o, bin);
     hipLaunchKernelGGL(tile_starts_kernel, dim3(1), dim3(1024), 0, stream, B.T, cap, o, geom, bin);
   }
   {
     ScopedTimer tm(T_TILE_SORT, stream);
-    hipLaunchKernelGGL(level2_kernel<true>, dim3(L2_GRID), dim3(64), 0, stream, gi, cap, o, geom, bin);
+    hipLaunchKernelGGL(level2_kernel<true>, dim3(L2_GRID), dim3(SEG), 0, stream, gi, cap, o, geom, bin);
   }
   return check_launch();
 }
@@ -747,13 +755,13 @@ int bin_instances_batched(const dimo_step_common &c, const RenderBatch &b, int n
   }
   {
     ScopedTimer tm(T_RANGES, stream);
-    hipLaunchKernelGGL(level2_batched_kernel<false>, dim3(L2_GRID, n), dim3(64), 0, stream, gi, cap, o, b);
+    hipLaunchKernelGGL(level2_batched_kernel<false>, dim3(L2_GRID, n), dim3(SEG), 0, stream, gi, cap, o, b);
     hipLaunchKernelGGL(level2_scan_batched_kernel, dim3(gi.NS, n), dim3(64), 0, stream, gi, o, b);
     hipLaunchKernelGGL(tile_starts_batched_kernel, dim3(1, n), dim3(1024), 0, stream, B.T, cap, o, b);
   }
   {
     ScopedTimer tm(T_TILE_SORT, stream);
-    hipLaunchKernelGGL(level2_batched_kernel<true>, dim3(L2_GRID, n), dim3(64), 0, stream, gi, cap, o, b);
+    hipLaunchKernelGGL(level2_batched_kernel<true>, dim3(L2_GRID, n), dim3(SEG), 0, stream, gi, cap, o, b);
   }
   return check_launch();
 }

@@ -101,7 +101,8 @@ struct BinLayout {
     l1cap = (cap + 255) / 256 * 256 + 256 * 256;
     max_windows = l1cap / 256;
     l1list = o, o = align_up(o + l1cap * 2 * sizeof(uint32_t));
-    cnt2 = o, o = align_up(o + max_windows * 64 * sizeof(uint32_t));
+    // per-window tile counts [max_windows][64], then the same per (window, wave) [max_windows][4][64]
+    cnt2 = o, o = align_up(o + max_windows * 64 * 5 * sizeof(uint32_t));
     meta = o, o = align_up(o + (4 * 256 + max_windows) * sizeof(uint32_t));
     // blend checkpoints: per (tile, bucket of BUCKET list entries) the 256 pixels' compositing state at the
     // bucket's first entry -- slot (lo_tile / BUCKET + tile + bucket), see blend.hip; work: [0] = item count,
