@@ -216,10 +216,10 @@ __device__ __forceinline__ void radix_scatter_body(
 // output is written as long contiguous runs (a first version placed each instance with an 8-byte scattered write:
 // 15 M partial-line L2 misses per step, 220 us):
 //   level 1: the image is cut into <= 256 supertiles of SS x SS tiles; the depth-ordered list is cut into segments
-//            of 256; one wave per segment tests its Gaussians against every supertile (ballot / popcount give the
+//            of 256; a workgroup per segment (a wave per 64 entries) tests its Gaussians against the supertiles (ballot / popcount give the
 //            order-preserving ranks) -- a count pass, a scan over the segments, a fill pass -> per-supertile lists
 //            of (Gaussian id, depth bits), still in depth order; list starts are aligned to 256 entries so that
-//   level 2: every 256-entry window of the level-1 array belongs to one supertile; one wave per window filters it
+//   level 2: every 256-entry window of the level-1 array belongs to one supertile; a workgroup per window filters it
 //            against the <= 64 tiles of that supertile -- count, scan over the supertile's windows, tile starts,
 //            fill -> the final (key, value) lists.
 struct BinGrid {
