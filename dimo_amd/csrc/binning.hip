@@ -225,7 +225,7 @@ __device__ __forceinline__ void radix_scatter_body(
 struct BinGrid {
   int tiles_x, tiles_y, ss_shift, stx, sty, NS;  // supertile edge = 1 << ss_shift tiles, stx * sty = NS supertiles
 };
-constexpr int SEG = 256;        // list entries per wave (both levels)
+constexpr int SEG = 256;        // list entries per workgroup (both levels): 4 waves x 64
 constexpr int MAX_SUPER = 256;  // supertiles (one level-1 thread each)
 static_assert(SEG == MAX_SUPER, "level 1: a workgroup has one thread per entry AND per supertile");
 
