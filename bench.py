@@ -78,6 +78,11 @@ def kernel_rooflines(timing_iso, N, V, R, P, C=NFEAT):
     return out
 
 
+def per_launch(timing, key):
+    ms, n = timing.get(key, (0.0, 0))
+    return ms / n if n else 0.0
+
+
 def read_timing():
     from dimo_amd import _lib
     L = _lib.lib()
@@ -288,6 +293,17 @@ def main():
             # achieved HBM GB/s per kernel against the 8 TB/s peak, from the ALGORITHMIC bytes of
             # DESIGN.md section 4 and the single-render launches measured alone on the device (timing_iso)
             "kernel_rooflines": kernel_rooflines(timing_iso, args.num_pts, V, R, P),
+            # BASELINE.json metric (ii): rasterizer forward / backward device time of ONE render alone on the device
+            # (sum of its kernels' HIP-event times: project, scan, depth sort, placement, blend | blend, projection)
+            "raster_ms_per_render_isolated": {
+                "forward": sum(per_launch(timing_iso, k) for k in
+                               ("preprocess_fwd", "scan", "sort", "emit", "ranges", "place", "blend_fwd")),
+                "backward": sum(per_launch(timing_iso, k) for k in ("blend_bwd", "preprocess_bwd"))},
+            "raster_ms_per_render_batched": {
+                "forward": sum(per_launch(timing_all, k) for k in
+                               ("preprocess_fwd", "scan", "sort", "emit", "ranges", "place", "blend_fwd")) / max(rpl, 1),
+                "backward": sum(per_launch(timing_all, k) for k in ("blend_bwd", "preprocess_bwd")) / max(rpl, 1),
+                "what": "per render of a batched launch in the timed schedule (two motions' batches share the chip)"},
             "kernels_ms_per_launch": {k: (v[0] / v[1] if v[1] else None) for k, v in timing_all.items()},
             "kernels_ms_per_launch_isolated": {k: (v[0] / v[1] if v[1] else None) for k, v in timing_iso.items()},
         }
