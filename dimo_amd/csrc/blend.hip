@@ -265,7 +265,37 @@ __device__ __forceinline__ void blend_bwd_body(
     const float *const ck_item = ckpt + ((size_t)(lo / BUCKET) + tile + blo / BUCKET) * (CKPT_FLOATS * TILE * TILE);
 
     __syncthreads();  // previous item fully consumed
-    if (wave == 0 && lane < count) {
+    // QPW == 4 (one wave per item): the records are staged COMPACTED -- record number rank-among-the-reachable goes
+    // to slot rank, with its original list position in the high bits of the mask word -- so the visit loop reads slot
+    // t directly instead of chasing an index list (two dependent LDS round trips per record, ~250 cycles of a
+    // latency-bound loop); every lane keeps its own rank / emission slot in registers for the epilogue.
+    uint32_t my_emit = 0;
+    int my_rank = 0, mine = 0;
+    bool my_hit = false;
+    if (QPW == 4) {
+      float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra, rc4 = ra;
+      float rnz = 0.0f;
+      uint32_t qmask = 0;
+      if (lane < count) {
+        const uint32_t g = vals_sorted[lo + blo + lane];
+        const float4 *rp = reinterpret_cast<const float4 *>(splat + g);
+        ra = rp[0], rb = rp[1], rc4 = rp[2];
+        if (NORMAL) rnz = rp[3].x;
+        qmask = quadrant_mask(ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, tile_x, tile_y);
+        const uint2 rc = *reinterpret_cast<const uint2 *>(rect + 4 * (size_t)g);
+        const int x0 = rc.x & 0xffff, y0 = rc.x >> 16, x1 = rc.y & 0xffff;
+        my_emit = (g == 0 ? 0u : offsets[g - 1]) + (uint32_t)((tile_y - y0) * (x1 - x0) + (tile_x - x0));
+      }
+      my_hit = qmask != 0u;
+      const unsigned long long bal = __ballot(my_hit);
+      my_rank = __popcll(bal & ((1ull << lane) - 1ull));
+      mine = __popcll(bal);
+      if (my_hit) {
+        s_geo[my_rank] = ra, s_col[my_rank] = rb, s_aux[my_rank] = rc4;
+        if (NORMAL) s_nz[my_rank] = rnz;
+        s_mask[my_rank] = qmask | ((uint32_t)lane << 8);
+      }
+    } else if (wave == 0 && lane < count) {
       const uint32_t g = vals_sorted[lo + blo + lane];
       const float4 *rp = reinterpret_cast<const float4 *>(splat + g);
       const float4 a = rp[0], b = rp[1];
@@ -344,8 +374,7 @@ __device__ __forceinline__ void blend_bwd_body(
     __syncthreads();
     // ascending list of the records that can reach any pixel of this wave's quadrants
     constexpr uint32_t QBITS = ((1u << QPW) - 1u);
-    int mine;
-    {
+    if (QPW != 4) {
       const bool hit = lane < count && ((s_mask[lane] >> (wave * QPW)) & QBITS) != 0u;
       const unsigned long long bal = __ballot(hit);
       if (hit) s_list[wave][__popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)lane;
@@ -354,14 +383,22 @@ __device__ __forceinline__ void blend_bwd_body(
     __syncthreads();
 
     for (int t = 0; t < mine; ++t) {
-      const int j = __builtin_amdgcn_readfirstlane((int)s_list[wave][t]);
+      // slot of the record in the staged arrays, its position in the bucket, its quadrant bits
+      int slot, j;
+      uint32_t qm;
+      if (QPW == 4) {
+        const uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_mask[t]);
+        slot = t, j = (int)(m >> 8), qm = m & 0xfu;
+      } else {
+        slot = j = __builtin_amdgcn_readfirstlane((int)s_list[wave][t]);
+        qm = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_mask[j]) >> (wave * QPW);
+      }
       const uint32_t pos = blo + (uint32_t)j;
       if (pos >= wlast) break;  // the list is ascending: nothing further reaches this tile
-      const uint32_t qm = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_mask[j]) >> (wave * QPW);
-      const float4 g = s_geo[j];
-      const float4 c = s_col[j];
-      const float4 a = s_aux[j];
-      const float nz = NORMAL ? s_nz[j] : 0.0f;
+      const float4 g = s_geo[slot];
+      const float4 c = s_col[slot];
+      const float4 a = s_aux[slot];
+      const float nz = NORMAL ? s_nz[slot] : 0.0f;
       const float dx0 = g.x - bxf - (float)(((wave * QPW) & 1) * 8), dy0 = g.y - byf - (float)(((wave * QPW) >> 1) * 8);
       float v[16];
 #pragma unroll
@@ -396,14 +433,14 @@ __device__ __forceinline__ void blend_bwd_body(
       if (!any) continue;
       const float tot = butterfly16(v, lane);  // lanes 0..15: the wave total of value butterfly16_slot(lane)
       if (lane < 16) {
-        if (QPW == 4) s_acc[j][butterfly16_slot(lane)] = tot;  // this wave is the only writer of record j
+        if (QPW == 4) s_acc[slot][butterfly16_slot(lane)] = tot;  // this wave is the only writer of the record
         else atomicAdd(&s_acc[j][butterfly16_slot(lane)], tot);
       }
     }
     __syncthreads();
-    if (wave == 0 && lane < count) {
-      const uint32_t e = s_emit[lane];
-      const float4 *src = reinterpret_cast<const float4 *>(&s_acc[lane][0]);
+    if (QPW == 4 ? my_hit : (wave == 0 && lane < count)) {
+      const uint32_t e = QPW == 4 ? my_emit : s_emit[lane];
+      const float4 *src = reinterpret_cast<const float4 *>(&s_acc[QPW == 4 ? my_rank : lane][0]);
       const float4 r0 = src[0], r1 = src[1], r2 = src[2], r3 = src[3];
       const bool nonzero = r0.x != 0.f || r0.y != 0.f || r0.z != 0.f || r0.w != 0.f || r1.x != 0.f || r1.y != 0.f ||
                            r1.z != 0.f || r1.w != 0.f || r2.x != 0.f || r2.y != 0.f || r2.z != 0.f || r2.w != 0.f ||
