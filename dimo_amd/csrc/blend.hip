@@ -382,21 +382,28 @@ __device__ __forceinline__ void blend_bwd_body(
     }
     __syncthreads();
 
+    // (QPW == 4) the mask word and the geometry of record t + 1 are read from LDS while record t is processed
+    uint32_t m_next = 0;
+    float4 g_next = make_float4(0.f, 0.f, 0.f, 0.f), c_next = g_next;
+    if (QPW == 4 && mine > 0) m_next = s_mask[0], g_next = s_geo[0], c_next = s_col[0];
     for (int t = 0; t < mine; ++t) {
       // slot of the record in the staged arrays, its position in the bucket, its quadrant bits
       int slot, j;
       uint32_t qm;
+      float4 g, c;
       if (QPW == 4) {
-        const uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_mask[t]);
+        const uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane((int)m_next);
         slot = t, j = (int)(m >> 8), qm = m & 0xfu;
+        g = g_next, c = c_next;
+        const int tn = min(t + 1, mine - 1);
+        m_next = s_mask[tn], g_next = s_geo[tn], c_next = s_col[tn];
       } else {
         slot = j = __builtin_amdgcn_readfirstlane((int)s_list[wave][t]);
         qm = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_mask[j]) >> (wave * QPW);
+        g = s_geo[slot], c = s_col[slot];
       }
       const uint32_t pos = blo + (uint32_t)j;
       if (pos >= wlast) break;  // the list is ascending: nothing further reaches this tile
-      const float4 g = s_geo[slot];
-      const float4 c = s_col[slot];
       const float4 a = s_aux[slot];
       const float nz = NORMAL ? s_nz[slot] : 0.0f;
       const float dx0 = g.x - bxf - (float)(((wave * QPW) & 1) * 8), dy0 = g.y - byf - (float)(((wave * QPW) >> 1) * 8);
