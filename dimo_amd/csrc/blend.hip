@@ -210,7 +210,9 @@ __device__ __forceinline__ void blend_fwd_body(
     const uint32_t nb = (deepest + BUCKET - 1) / BUCKET;
     if (nb) {
       const uint32_t base = atomicAdd(work, nb);
-      for (uint32_t b = 0; b < nb; ++b) work[1 + base + b] = ((uint32_t)tile << 12) | b;
+      // (the item carries its tile's list range: one dependent load less in front of every backward item)
+      for (uint32_t b = 0; b < nb; ++b)
+        reinterpret_cast<uint4 *>(work)[1 + base + b] = make_uint4(((uint32_t)tile << 12) | b, lo, hi, 0u);
     }
   }
 }
@@ -254,11 +256,11 @@ __device__ __forceinline__ void blend_bwd_body(
   const size_t HW = (size_t)H * W;
   const uint32_t n_items = work[0];
   for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
-    const uint32_t code = work[1 + item];
+    const uint4 it = reinterpret_cast<const uint4 *>(work)[1 + item];
+    const uint32_t code = it.x, lo = it.y, hi = it.z;
     const int tile = (int)(code >> 12);
     const uint32_t blo = (code & 0xfffu) * BUCKET;
     const int tile_x = tile % tiles_x, tile_y = tile / tiles_x;
-    const uint32_t lo = ranges[2 * tile], hi = ranges[2 * tile + 1];
     const int count = (int)min((uint32_t)BUCKET, hi - lo - blo);
     const int bx = tile_x * TILE + (lane & 7), by = tile_y * TILE + (lane >> 3);
     const float bxf = (float)bx, byf = (float)by;

@@ -109,7 +109,8 @@ struct BinLayout {
     // then one word (tile << 12 | bucket) per bucket some pixel of the tile reaches
     ckpt_slots = cap / BUCKET + (size_t)T + 2;
     ckpt = o, o = align_up(o + ckpt_slots * CKPT_FLOATS * TILE * TILE * sizeof(float));
-    work = o, o = align_up(o + (ckpt_slots + 1) * sizeof(uint32_t));
+    // [0] = item count, [1] unused, then (tile << 12 | bucket, list start, list end, -) per item
+    work = o, o = align_up(o + (4 * ckpt_slots + 4) * sizeof(uint32_t));
     bytes = o;
   }
 };
