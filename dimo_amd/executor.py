@@ -88,6 +88,9 @@ class StepExecutor:
         r_cap = int(r_cap)
         if r_cap == self.r_cap:
             return
+        # the host may be a step ahead of the device, whose queued kernels (on private streams the caching allocator
+        # knows nothing about) still use the old workspaces
+        torch.cuda.synchronize()
         self.r_cap = r_cap
         self.bin_bytes = self.L.dimo_raster_bin_bytes(r_cap, self.H, self.W)
         self.bwd_bytes = self.L.dimo_raster_backward_scratch_bytes(self.N, r_cap)

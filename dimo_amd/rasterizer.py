@@ -94,14 +94,20 @@ class CapacityPolicy:
         self._inflight.append((host, ev))
         return tot
 
-    def poll(self):
-        """Evaluates finished asynchronous copies. Returns the number of steps that had overflowed."""
+    def poll(self, lag=1):
+        """Evaluates the asynchronous copies except the `lag` newest ones.  Returns the number of steps that had
+        overflowed.  Called at the start of a step, lag = 1 leaves the copy of the step just enqueued alone and looks
+        at the one before it, which finished a whole step ago -- the host never waits for the device and can run a
+        full step ahead (with lag = 0 the call is a device sync in disguise: the event of the previous step's
+        renders completes only when that step is all but done).  The device-side skip flag, not this read-back, is
+        what keeps an overflowing step from being applied."""
+        inflight = getattr(self, "_inflight", [])
+        ready, self._inflight = (inflight[:-lag], inflight[-lag:]) if lag > 0 else (inflight, [])
         bad = 0
-        for host, ev in getattr(self, "_inflight", []):
-            ev.synchronize()  # recorded a whole step ago: already complete in steady state
+        for host, ev in ready:
+            ev.synchronize()
             if not self._update(host):
                 bad += 1
-        self._inflight = []
         return bad
 
 

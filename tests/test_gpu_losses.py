@@ -116,6 +116,34 @@ def test_direct_pipeline_ragged_tiles_and_three_view_groups():
     assert (ga - gb).abs().sum() / ga.abs().sum() < 1e-4
 
 
+def test_capacity_overflow_is_skipped_on_device_and_recovered_a_step_later():
+    """An instance capacity that is too small: the overflowing steps must leave the parameters untouched (device-side
+    skip flag), the host -- which reads the counts with a lag of one step and never waits for the device -- raises the
+    capacity, and training then proceeds."""
+    from dimo_amd.rasterizer import CapacityPolicy
+    from dimo_amd.renderer import Renderer
+    from dimo_amd.synth import init_synthetic_model
+    from dimo_amd.trainer import TrainConfig, Trainer
+    cfg = TrainConfig(num_pts=3000, num_cpts=32, num_motions=3, num_frames=4, num_views=4, motions_per_step=2,
+                      views_per_step=2, frames_per_step=1, resolution=64)
+    rd = Renderer(sh_degree=0, num_latent_code=cfg.num_motions, add_normal=True, device="cuda",
+                  capacity=CapacityPolicy(initial=64))
+    init_synthetic_model(rd, cfg.num_pts, cfg.num_cpts, seed=4, num_latent=cfg.num_motions)
+    tr = Trainer(cfg, rd)
+    p0 = rd.gaussians.flat_params.clone()
+    tr.train_step()
+    torch.cuda.synchronize()
+    assert torch.equal(rd.gaussians.flat_params, p0), "an overflowing step was applied"
+    for _ in range(6):
+        tr.train_step()
+    torch.cuda.synchronize()
+    assert tr.skipped_steps >= 1 and rd.capacity.capacity > 64
+    assert not torch.equal(rd.gaussians.flat_params, p0) and torch.isfinite(rd.gaussians.flat_params).all()
+    skipped = tr.skipped_steps
+    tr.train_step(); tr.train_step(); tr.train_step()
+    assert tr.skipped_steps == skipped, "still overflowing after the capacity was raised"
+
+
 def test_direct_pipeline_with_lpips_term():
     """`use_lpips` (main_train_dimo.py:339-341) on the fixed random-weight stand-in: the direct pipeline adds the
     metric's image gradient to the loss kernel's, and must agree with the autograd pipeline."""
