@@ -47,8 +47,17 @@ class FusedTimeNet:
         self._ws, self._shape, self._times, self._rows = None, None, None, None
 
     def _refresh(self, need_grads):
-        l0 = self.layers[0]
-        key = (l0.weight.data_ptr(), l0.weight.grad.data_ptr() if l0.weight.grad is not None else 0, need_grads)
+        """Re-reads the parameter / gradient pointers only when they moved (re-flattened buckets, fresh .grad
+        tensors): in steady state this is two data_ptr() calls per call, not a walk over twenty layers."""
+        l0, ll = self.layers[0], self.layers[-1]
+        if need_grads and (l0.weight.grad is None or ll.bias.grad is None):
+            for lin in self.layers:
+                for t in (lin.weight, lin.bias):
+                    if t.grad is None:
+                        t.grad = torch.zeros_like(t)
+        key = (l0.weight.data_ptr(), ll.bias.data_ptr(),
+               l0.weight.grad.data_ptr() if l0.weight.grad is not None else 0,
+               ll.bias.grad.data_ptr() if ll.bias.grad is not None else 0)
         if key == self._key:
             return
         d = self.desc
@@ -56,13 +65,10 @@ class FusedTimeNet:
             for t in (lin.weight, lin.bias):
                 if t.dtype != torch.float32 or not t.is_contiguous():
                     raise ValueError("TimeNet parameters must be contiguous fp32")
-                if need_grads and t.grad is None:
-                    t.grad = torch.zeros_like(t)
             d.weight[i], d.bias[i] = lin.weight.data_ptr(), lin.bias.data_ptr()
             d.g_weight[i] = lin.weight.grad.data_ptr() if lin.weight.grad is not None else None
             d.g_bias[i] = lin.bias.grad.data_ptr() if lin.bias.grad is not None else None
-        l0 = self.layers[0]
-        self._key = (l0.weight.data_ptr(), l0.weight.grad.data_ptr() if l0.weight.grad is not None else 0, need_grads)
+        self._key = key
 
     def forward(self, c_xyz, times, latent_table, latent_rows=None):
         """c_xyz [M,3]; times: P python floats; latent_table [T,L]; latent_rows: P row indices (None: row p).
