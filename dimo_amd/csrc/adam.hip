@@ -6,7 +6,11 @@
 // update is a single streaming pass: read p, g, m, v / write p, m, v (+ g = 0): 32 bytes per parameter,
 // HBM-bound.  Per-group learning rates come from a small by-value segment table.  An optional device flag
 // (the rasterizer's "instance capacity overflow" word) turns the update into a no-op, so a step whose
-// gradients are invalid is skipped without the host ever waiting for the device.
+// gradients are invalid is skipped without the host ever waiting for the device.  The bias corrections use the
+// number of updates actually APPLIED: the count of skipped launches lives on the device (two words, written
+// alternately so that no block reads the word another block is writing) and is subtracted from the host's launch
+// counter in the kernel -- every data-parallel replica sees the same all-reduced flag, so the replicas' effective
+// step stays equal without the host ever reading the flag.
 #include "common.hpp"
 
 namespace dimo {
@@ -20,11 +24,23 @@ struct AdamSegs {
 
 __global__ void __launch_bounds__(256) flat_adam_kernel(long long n, float *__restrict__ p, float *__restrict__ g,
                                                         float *__restrict__ m, float *__restrict__ v, AdamSegs segs,
-                                                        float beta1, float beta2, float eps, float inv_bc1,
-                                                        float inv_sqrt_bc2, const int *__restrict__ skip_flags,
-                                                        int n_flags, int flag_stride, int zero_grad) {
+                                                        float beta1, float beta2, float eps, long long launch,
+                                                        const int *__restrict__ skip_flags, int n_flags,
+                                                        int flag_stride, int zero_grad, int *__restrict__ skipped) {
   bool skip = false;
   for (int k = 0; k < n_flags; ++k) skip |= skip_flags[(size_t)k * flag_stride] != 0;
+  // effective step = launches so far - launches skipped before this one; this launch reads word (launch & 1) and
+  // writes the other one
+  __shared__ float s_bc[2];
+  const int before = skipped ? skipped[launch & 1] : 0;
+  if (threadIdx.x == 0) {
+    const double t = (double)(launch - before);
+    s_bc[0] = (float)(1.0 / (1.0 - pow((double)beta1, t)));
+    s_bc[1] = (float)(1.0 / sqrt(1.0 - pow((double)beta2, t)));
+    if (skipped && blockIdx.x == 0) skipped[(launch + 1) & 1] = before + (skip ? 1 : 0);
+  }
+  __syncthreads();
+  const float inv_bc1 = s_bc[0], inv_sqrt_bc2 = s_bc[1];
   const long long stride = (long long)gridDim.x * 256 * 4;
   for (long long i0 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4; i0 < n; i0 += stride) {
     if (i0 + 3 < n) {
@@ -72,7 +88,8 @@ using namespace dimo;
 extern "C" int dimo_flat_adam_step(int64_t n, float *params, float *grads, float *exp_avg, float *exp_avg_sq,
                                    int n_segments, const int64_t *segment_end_host, const float *segment_lr_host,
                                    float beta1, float beta2, float eps, int64_t step, const int *skip_flags,
-                                   int n_flags, int flag_stride, int zero_grad, void *stream_) {
+                                   int n_flags, int flag_stride, int zero_grad, int *skipped_launches,
+                                   void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   clear_errors();
   if (n < 0 || n_segments < 1 || n_segments > ADAM_MAX_SEG || step < 1 || n_flags < 0) return DIMO_E_ARG;
@@ -89,13 +106,12 @@ extern "C" int dimo_flat_adam_step(int64_t n, float *params, float *grads, float
     segs.lr[k] = k < n_segments ? segment_lr_host[k] : 0.0f;
   }
   if (segs.end[n_segments - 1] != n) return DIMO_E_ARG;
-  const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
   long long blocks = (n / 4 + 255) / 256;
   if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;
   ScopedTimer tm(T_ADAM, stream);
   hipLaunchKernelGGL(flat_adam_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (long long)n, params, grads,
-                     exp_avg, exp_avg_sq, segs, beta1, beta2, eps, (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)),
-                     skip_flags, n_flags, flag_stride, zero_grad);
+                     exp_avg, exp_avg_sq, segs, beta1, beta2, eps, (long long)step, skip_flags, n_flags, flag_stride,
+                     zero_grad, skipped_launches);
   return check_launch();
 }

@@ -10,7 +10,8 @@ values that are overwritten -- and the flat parameter / gradient / moment bucket
 gathers (`GaussianModel.rebuild`).  The Adam step counter carries over, as `cat_tensors_to_optimizer` keeps it.
 
 Replica consistency: the only random draw (`densify_and_split`) uses the global torch generator of the model's
-device, exactly like the reference's `torch.normal`; data-parallel ranks seed it identically (`Trainer`).
+device, exactly like the reference's `torch.normal`; under data parallelism `Trainer` sets `split_generator`, seeded
+from (seed, step), so that every rank draws the same samples whatever else consumed its global generator.
 """
 import torch
 
@@ -48,7 +49,16 @@ class _Plan:
             self.values[k] = self.values[k][mask]
 
     def scaling_act(self):
-        return torch.exp(self.values["scaling"])
+        """`GaussianModel.get_scaling` on the rows of the plan (latent_gs_renderer.py:341-351): exp(_scaling) once
+        `_r` is empty (stage s2), otherwise exp of the radius `_r` -- shared (1, 1) in stage s1, or one row per
+        Gaussian -- broadcast to three axes."""
+        r = self.m._r
+        if len(r) == 0:
+            return torch.exp(self.values["scaling"])
+        if "r" in self.values:
+            rv = self.values["r"]
+            return torch.exp(rv.repeat(1, 3) if rv.shape[1] == 1 else rv)
+        return torch.exp(r.detach().reshape(1, -1)[:, :1].repeat(self.n, 3))
 
     def opacity_act(self):
         return torch.sigmoid(self.values["opacity"])
@@ -78,7 +88,7 @@ class DensifyMixin:
         sel = torch.norm(grads, dim=-1) >= grad_threshold
         sel = torch.logical_and(sel, torch.max(plan.scaling_act(), dim=1).values <= self.percent_dense * scene_extent)
         rows = sel.nonzero(as_tuple=True)[0]
-        plan.append(rows, {k: v[rows] for k, v in plan.values.items()})
+        plan.append(rows, {k: v[rows] for k, v in plan.values.items()})  # (a per-point `_r` is cloned like the rest)
 
     def _plan_split(self, plan, grads, grad_threshold, scene_extent, N=2):
         """latent_gs_renderer.py:826-854 (grads are those of BEFORE the clone, zero-padded for the clones)."""
@@ -91,7 +101,8 @@ class DensifyMixin:
         sc = plan.scaling_act()[rows]
         stds = sc.repeat(N, 1)
         means = torch.zeros((stds.size(0), 3), device=stds.device)
-        samples = torch.normal(mean=means, std=stds)
+        gen = getattr(self, "split_generator", None)  # data-parallel ranks: Trainer supplies a rank-identical one
+        samples = torch.normal(mean=means, std=stds) if gen is None else torch.normal(mean=means, std=stds, generator=gen)
         rots = build_rotation(plan.values["rotation"][rows]).repeat(N, 1, 1)
         new = {
             "xyz": torch.bmm(rots, samples.unsqueeze(-1)).squeeze(-1) + plan.values["xyz"][rows].repeat(N, 1),
@@ -101,6 +112,8 @@ class DensifyMixin:
             "f_rest": plan.values["f_rest"][rows].repeat(N, 1, 1),
             "opacity": plan.values["opacity"][rows].repeat(N, 1),
         }
+        if "r" in plan.values:  # new_r = new_scaling[:, :r.shape[1]] (latent_gs_renderer.py:846-848)
+            new["r"] = new["scaling"][:, :plan.values["r"].shape[1]]
         plan.append(rows.repeat(N), new)
         keep = torch.cat([~sel, torch.ones(N * rows.shape[0], dtype=torch.bool, device=sel.device)])
         plan.keep(keep)

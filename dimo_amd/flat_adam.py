@@ -22,7 +22,11 @@ class FlatAdam:
         self.flat_params, self.flat_grads = flat_params, flat_grads
         self.exp_avg = torch.zeros_like(flat_params)
         self.exp_avg_sq = torch.zeros_like(flat_params)
-        self.step_count = 0
+        self.launches = 0  # every step() call, applied or skipped on the device
+        self.skipped_host = 0  # skipped launches the host knows of (Trainer: read back with a lag of one step)
+        # the device's own count of skipped launches (two words written alternately, see adam.hip): the bias
+        # corrections use launches - skipped without the host ever reading the overflow flag
+        self._skipped = torch.zeros(2, dtype=torch.int32, device=flat_params.device)
         # groups must tile the bucket in order, at most 3 padding floats (16-byte alignment) between tensors
         # (GaussianModel.flatten_parameters builds it that way); padding is updated with the group it precedes
         base = flat_params.data_ptr()
@@ -42,10 +46,21 @@ class FlatAdam:
         self._ends = (C.c_int64 * len(ends))(*ends)
         self._n_seg = len(ends)
 
+    @property
+    def step_count(self):
+        """Updates actually applied, as far as the host knows (== torch.optim.Adam's `step` state)."""
+        return self.launches - self.skipped_host
+
+    @step_count.setter
+    def step_count(self, value):
+        self.launches = int(value)
+        self.skipped_host = 0
+        self._skipped.zero_()
+
     def step(self, skip_flags=None, zero_grad=False):
         """skip_flags: optional int32 tensor [k, 2] (rasterizer `total` words: R, overflow) -- any non-zero
         overflow word turns this step into a no-op on the device."""
-        self.step_count += 1
+        self.launches += 1
         lrs = (C.c_float * self._n_seg)(*[float(g["lr"]) for g in self.param_groups])
         b1, b2 = self.defaults["betas"]
         if skip_flags is not None and skip_flags.numel() > 0:
@@ -58,8 +73,9 @@ class FlatAdam:
             fptr, nfl, fstride = None, 0, 1
         _lib.check(_lib.lib().dimo_flat_adam_step(
             self.flat_params.numel(), _lib.ptr(self.flat_params), _lib.ptr(self.flat_grads), _lib.ptr(self.exp_avg),
-            _lib.ptr(self.exp_avg_sq), self._n_seg, self._ends, lrs, b1, b2, self.defaults["eps"], self.step_count,
-            fptr, nfl, fstride, int(bool(zero_grad)), _lib.current_stream()), "dimo_flat_adam_step")
+            _lib.ptr(self.exp_avg_sq), self._n_seg, self._ends, lrs, b1, b2, self.defaults["eps"], self.launches,
+            fptr, nfl, fstride, int(bool(zero_grad)), _lib.ptr(self._skipped), _lib.current_stream()),
+            "dimo_flat_adam_step")
 
     def zero_grad(self, set_to_none=False):
         self.flat_grads.zero_()

@@ -244,8 +244,16 @@ class GaussianModel(DensifyMixin, PlyMixin):
     # ------------------------------------------------------------------ optimizer surgery (densify / prune)
     def per_gaussian(self):
         """The six per-Gaussian parameter tensors by the reference's optimizer group names."""
-        return dict(xyz=self._xyz, f_dc=self._features_dc, f_rest=self._features_rest, opacity=self._opacity,
-                    scaling=self._scaling, rotation=self._rotation)
+        d = dict(xyz=self._xyz, f_dc=self._features_dc, f_rest=self._features_rest, opacity=self._opacity,
+                 scaling=self._scaling, rotation=self._rotation)
+        if self.r_is_per_point():  # a per-point `_r` is pruned / extended with the Gaussians (group "r")
+            d["r"] = self._r
+        return d
+
+    def r_is_per_point(self):
+        """The reference extends / prunes `_r` with the Gaussians only when it has one row per Gaussian
+        (latent_gs_renderer.py:701,727,847,869); the shared (1, 1) radius of stage s1 is left alone."""
+        return len(self._r) > 0 and self._r.dim() == 2 and self._r.shape[0] == self._xyz.shape[0] and self._r.shape[0] > 1
 
     def _moments(self, p):
         """(exp_avg, exp_avg_sq, step) of parameter p, shaped like p; None before the first step of torch Adam."""
@@ -283,16 +291,19 @@ class GaussianModel(DensifyMixin, PlyMixin):
                     if mo is not None:
                         carried[id(p)] = (mo[0].clone(), mo[1].clone(), mo[2])
         lrs = {grp["name"]: grp["lr"] for grp in self.optimizer.param_groups}
-        step_count = getattr(self.optimizer, "step_count", None)
+        old_opt = self.optimizer
         P = lambda t: nn.Parameter(t.detach().clone().contiguous().requires_grad_(True))
         v = plan.values
         self._xyz, self._features_dc, self._features_rest = P(v["xyz"]), P(v["f_dc"]), P(v["f_rest"])
         self._opacity, self._scaling, self._rotation = P(v["opacity"]), P(v["scaling"]), P(v["rotation"])
+        if "r" in v:
+            self._r = P(v["r"])
         self._make_optimizer(self._training_args, self._fused)
         for grp in self.optimizer.param_groups:
             grp["lr"] = lrs.get(grp["name"], grp["lr"])
-        if step_count is not None:
-            self.optimizer.step_count = step_count
+        if type(old_opt).__name__ == "FlatAdam":  # launch counter and the device's skipped-launch words carry over
+            o = self.optimizer
+            o.launches, o.skipped_host, o._skipped = old_opt.launches, old_opt.skipped_host, old_opt._skipped
         new = self.per_gaussian()
         with torch.no_grad():
             for grp in self.optimizer.param_groups:

@@ -8,17 +8,20 @@ import torch
 from . import _lib
 
 
-def loss_weights(cfg, n_local, n_img, H, W):
+def loss_weights(cfg, n_local, n_img, H, W, depth_on=None, normal_on=None):
     """Folds lambda, the 1/numel of each mean-type term and this rank's share n_local/n_img of the motion's
-    images into per-element weights (see Trainer.motion_loss for the autograd formulation)."""
+    images into per-element weights (see Trainer.motion_loss for the autograd formulation).  `depth_on` /
+    `normal_on` override cfg.add_depth / cfg.add_normal (the terms start after depth/normal_reg_start_iter)."""
     share = n_local / n_img
     B = n_local
+    depth_on = cfg.add_depth if depth_on is None else depth_on
+    normal_on = cfg.add_normal if normal_on is None else normal_on
     return dict(
         w_mask=cfg.lambda_mask * share / (B * H * W),
-        w_smooth_x=(cfg.lambda_smooth * share / (B * H * (W - 1))) if cfg.add_depth and W > 1 else 0.0,
-        w_smooth_y=(cfg.lambda_smooth * share / (B * (H - 1) * W)) if cfg.add_depth and H > 1 else 0.0,
-        w_bilat_x=(cfg.lambda_bilateral * share / (3 * B * H * (W - 1))) if cfg.add_normal and W > 1 else 0.0,
-        w_bilat_y=(cfg.lambda_bilateral * share / (3 * B * (H - 1) * W)) if cfg.add_normal and H > 1 else 0.0,
+        w_smooth_x=(cfg.lambda_smooth * share / (B * H * (W - 1))) if depth_on and W > 1 else 0.0,
+        w_smooth_y=(cfg.lambda_smooth * share / (B * (H - 1) * W)) if depth_on and H > 1 else 0.0,
+        w_bilat_x=(cfg.lambda_bilateral * share / (3 * B * H * (W - 1))) if normal_on and W > 1 else 0.0,
+        w_bilat_y=(cfg.lambda_bilateral * share / (3 * B * (H - 1) * W)) if normal_on and H > 1 else 0.0,
     )
 
 

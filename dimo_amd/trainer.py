@@ -57,8 +57,10 @@ class TrainConfig:
     lambda_ssim: float = 500.0
     lambda_mask: float = 500.0
     add_depth: bool = True
+    depth_reg_start_iter: int = 200   # the term is on for step > this (main_train_dimo.py:362)
     lambda_smooth: float = 100.0
     add_normal: bool = True
+    normal_reg_start_iter: int = 200  # main_train_dimo.py:368
     lambda_bilateral: float = 0.05
     lambda_kl: float = 0.05
     # optimizer
@@ -91,6 +93,7 @@ class TrainConfig:
     densify_opacity_threshold_s1: float = 0.01
     densify_opacity_threshold_s2: float = 0.01
     init_type: str = "ag"
+    FPS_iter: int = 1000  # stage s1: farthest-point down-sampling to num_cpts every FPS_iter steps
     # regularisers (configs/train_config.yaml:57-65).  Off by default: BASELINE.json's metric is quoted without them
     use_lpips: bool = False   # main_train_dimo.py:339-341 (needs the metric's weights: dimo_amd/lpips_vgg.py)
     lambda_lpips: float = 1000.0  # configs/train_config.yaml:44
@@ -121,11 +124,13 @@ def shard(items, rank, world):
 class _LazyLoss:
     """Loss of a direct-pipeline step, kept as the device scalars the kernels produced."""
 
-    def __init__(self, loss_accum, ssim_terms):
-        self.loss_accum, self.ssim_terms = loss_accum, ssim_terms
+    def __init__(self, loss_accum, ssim_terms, extra=None):
+        self.loss_accum, self.ssim_terms, self.extra = loss_accum, ssim_terms, extra
 
     def value(self):
         loss = self.loss_accum[0]
+        if self.extra is not None:  # KL / ARAP / GA scalars (main stream; kept apart from the kernels' atomic adds)
+            loss = loss + self.extra
         for ssum, lam, numel in self.ssim_terms:
             loss = loss + lam * (1 - ssum[0] / numel)
         return loss
@@ -133,7 +138,8 @@ class _LazyLoss:
 
 class Trainer:
     def __init__(self, cfg: TrainConfig, renderer, rank=0, world_size=1, process_group=None,
-                 ssim_fn: Optional[Callable] = None, knn_fn: Optional[Callable] = None, targets=None, direct=None):
+                 ssim_fn: Optional[Callable] = None, knn_fn: Optional[Callable] = None, targets=None, direct=None,
+                 fps_fn: Optional[Callable] = None):
         self.cfg, self.renderer = cfg, renderer
         self.rank, self.world, self.pg = rank, world_size, process_group
         self.device = renderer.device
@@ -144,6 +150,8 @@ class Trainer:
         if knn_fn is None:
             from .knn_cuda import knn_points as knn_fn  # HIP, GPU only
         self.ssim, self.knn = ssim_fn, knn_fn
+        self._fps_fn = fps_fn  # stage s1 down-sampling; default: the HIP kernel behind regularizers.sample_farthest_points
+        self.cpts_s1 = None    # [motions, frames, M, 3]: control-point trajectories cached at stage-s2 step 0 (GA term)
         self.cams = CameraCache(fovy_deg=cfg.fovy, device=self.device)
         self.azimuths = default_azimuths(cfg.num_views)
         self.source_time = frame_times(cfg.num_frames)
@@ -152,6 +160,10 @@ class Trainer:
         self._py_rng = random.Random(cfg.seed)
         self._np_rng = np.random.default_rng(cfg.seed)
         renderer.gaussians.training_setup(cfg)
+        if cfg.stage == "s1":  # prepare_train_s1 (main_train_dimo.py:464-469): the control points do not train in s1
+            for grp in renderer.gaussians.optimizer.param_groups:
+                if grp["name"] in ("c_radius", "c_xyz"):
+                    grp["lr"] = 0.0
         self._last_loss = None
         self._consts = {}
         self._deform_batch = None
@@ -193,6 +205,20 @@ class Trainer:
         g = self.renderer.gaussians
         d, i = self.knn(g._c_xyz.detach(), g._xyz.detach(), k)
         g.neighbor_dists, g.neighbor_indices = d, i
+
+    def fps(self, num_pts):
+        """`GUI.FPS` (main_train_dimo.py:511-515): stage-s1 down-sampling of the Gaussians to `num_pts` by farthest
+        point sampling.  Quirk kept: the reference hands the INDEX tensor to `prune_points(mask)`, whose `~mask` on
+        int64 is a bitwise not (-i-1), so the rows that survive are N-1-idx, in sampling order."""
+        g = self.renderer.gaussians
+        if g._xyz.shape[0] == 0:
+            return
+        if self._fps_fn is not None:
+            idxs = self._fps_fn(g._xyz.detach(), num_pts)
+        else:
+            from .regularizers import sample_farthest_points
+            idxs = sample_farthest_points(g._xyz.detach()[None], num_pts)[1][0]
+        g.prune_points(idxs.to(torch.int64))
 
     def sample(self) -> List[Tuple[int, int, int]]:
         c = self.cfg
@@ -281,14 +307,76 @@ class Trainer:
         alpha = torch.stack([o["alpha"] for o in outs])
         loss = loss + c.lambda_mask * share * ((alpha - torch.stack(masks)) ** 2).mean()
         img_hwc = img.permute(0, 2, 3, 1)
-        if c.add_depth:
+        depth_on, normal_on = self._reg_on()
+        if depth_on:
             depth = torch.stack([o["depth"] for o in outs]).permute(0, 2, 3, 1)
             loss = loss + c.lambda_smooth * share * compute_edge_aware_smoothness_loss(depth, img_hwc)
-        if c.add_normal:
+        if normal_on:
             normal = torch.stack([o["normal"] for o in outs]).permute(0, 2, 3, 1)
             loss = loss + c.lambda_bilateral * share * compute_bilateral_normal_smoothness_loss(normal, img_hwc)
         if c.use_lpips:
             loss = loss + c.lambda_lpips * share * self.lpips_metric()(img, gt).mean()
+        return loss
+
+    def _reg_on(self):
+        """(depth smoothness on, normal smoothness on) at the current step (main_train_dimo.py:362,368)."""
+        c = self.cfg
+        return (c.add_depth and self.step > c.depth_reg_start_iter,
+                c.add_normal and self.renderer.add_normal and self.step > c.normal_reg_start_iter)
+
+    # ------------------------------------------------------------------ geometry-anchor term (stage s2)
+    @torch.no_grad()
+    def cache_cpts_s1(self):
+        """main_train_dimo.py:231-244: at stage-s2 step 0 the control-point trajectory of every (motion, frame) is
+        frozen as the anchor of the geometry-anchor ("GA") term.  One batched TimeNet call instead of 51 x 21."""
+        g, c = self.renderer.gaussians, self.cfg
+        M = g._c_xyz.shape[0]
+        out = torch.empty(c.num_motions, c.num_frames, M, 3, dtype=torch.float32, device=self.device)
+        times = torch.tensor(self.source_time, dtype=torch.float32, device=self.device)[:, None, None].expand(-1, M, 1)
+        for m in range(c.num_motions):
+            lat = g.latent_code(m)[None, None, :].expand(c.num_frames, M, -1)
+            dxyz, _ = g._timenet(g._c_xyz[None], times, lat, t_apply=True)
+            out[m] = g._c_xyz[None] + dxyz
+        self.cpts_s1 = out
+
+    def _ga_active(self):
+        return self.cfg.add_ga and self.stage == "s2" and self.cpts_s1 is not None
+
+    def ga_loss(self, cpts, m, f):
+        """GA term of ONE render (the reference adds it per (motion, view, frame) render, main_train_dimo.py:295-303)."""
+        from .regularizers import geometry_anchor_loss
+        c = self.cfg
+        return geometry_anchor_loss(cpts, self.cpts_s1[m, f], c.ga_chamfer, c.lambda_ga1, c.lambda_ga2)
+
+    def _ga_direct(self, mine, pair_of, dxyz_c, g_dxyz):
+        """GA term of the direct pipeline: closed-form gradient for all (motion, frame) pairs of the step at once
+        (chamfer: 2 (p - nn(p)) per control point; L1: sign / numel), weighted by the number of local renders that
+        show the pair, added to the TimeNet output gradient and to `_c_xyz.grad`.  Returns the loss scalar."""
+        g, c = self.renderer.gaussians, self.cfg
+        pairs, counts = {}, {}
+        for (m, v, f) in mine:
+            p = pair_of[(m, v, f)]
+            pairs[p] = (m, f)
+            counts[p] = counts.get(p, 0) + 1
+        rows = sorted(pairs)
+        idx = torch.tensor(rows, device=self.device)
+        cnt = torch.tensor([float(counts[p]) for p in rows], device=self.device)
+        ori = torch.stack([self.cpts_s1[pairs[p][0], pairs[p][1]] for p in rows])  # [P, M, 3]
+        cp = g._c_xyz.detach()[None] + dxyz_c[idx]
+        if c.ga_chamfer:
+            d2 = torch.cdist(cp, ori).square()
+            dmin, nn = d2.min(dim=2)
+            near = torch.gather(ori, 1, nn[..., None].expand(-1, -1, 3))
+            # the minimum is recomputed from the gathered points (cdist's expansion loses digits for close pairs)
+            diff = cp - near
+            loss = c.lambda_ga1 * (cnt * diff.square().sum(dim=(1, 2))).sum()
+            grad = (2.0 * c.lambda_ga1) * cnt[:, None, None] * diff
+        else:
+            diff = cp - ori
+            loss = c.lambda_ga2 * (cnt * diff.abs().mean(dim=(1, 2))).sum()
+            grad = (c.lambda_ga2 / diff[0].numel()) * cnt[:, None, None] * torch.sign(diff)
+        g_dxyz.index_add_(0, idx, grad)
+        g._c_xyz.grad.add_(grad.sum(dim=0))
         return loss
 
     def lpips_metric(self):
@@ -349,21 +437,31 @@ class Trainer:
         for (m, v, f) in mine:
             out = self.render_triple(m, v, f, deform=deforms.get((m, v, f)))
             self._last_out = out
+            if self._ga_active():
+                ga = self.ga_loss(out["cpts_t"], m, f)
+                loss = ga if loss is None else loss + ga
             gt, mask = self.targets.get(m, v, f)
             w = 1.0 if (v == 0 or f == 0) else 0.5  # reference view / frame weighting (main_train_dimo.py:334)
             rec = by_motion.setdefault(m, ([], [], [], []))
             rec[0].append(out), rec[1].append(gt), rec[2].append(mask), rec[3].append(w)
         for m, (outs, gts, masks, ws) in by_motion.items():
             lm = self.motion_loss(outs, gts, masks, ws, n_img)
+            # per-motion terms (KL, ARAP) carry this rank's share of the motion's images, like the mean-type image
+            # terms: a motion whose renders are split over ranks is then counted once by the SUM all-reduce
+            share = len(outs) / n_img
             if g.vae_latent:
                 mu, lv = g._mu[m], g._log_var[m]
-                lm = lm + c.lambda_kl * (-0.5 * torch.sum(1 + lv - mu.pow(2) - lv.exp()))
+                lm = lm + share * c.lambda_kl * (-0.5 * torch.sum(1 + lv - mu.pow(2) - lv.exp()))
             reg = self.regularizer_loss(m)
             if reg is not None:
-                lm = lm + reg
+                lm = lm + share * reg
             loss = lm if loss is None else loss + lm
         if loss is not None:
             loss.backward()
+        out = self._last_out
+        self._last_stats = None
+        if out is not None and out["viewspace_points"].grad is not None:
+            self._last_stats = (out["radii"], out["viewspace_points"].grad)
         return loss
 
     def _executor(self, n_renders):
@@ -445,16 +543,18 @@ class Trainer:
         gathered = {}
         for m, trs in by_motion.items():
             gts = [self.targets.get(*t) for t in trs]
-            gathered[m] = (torch.stack([x[0] for x in gts]), gts[0][1])
+            # one mask per image (source_masks[motion][view][frame], main_train_dimo.py:284): [B, 1, H, W]
+            gathered[m] = (torch.stack([x[0] for x in gts]), torch.stack([x[1] for x in gts]))
             self._const(-c.lambda_ssim * (len(trs) / n_img))
         # ... and every buffer the loss kernels write is allocated here, BEFORE the forks: memory handed out later could
         # be a block whose last use is a kernel still pending on this stream, which a private stream would not wait for
+        depth_on, normal_on = self._reg_on()
         loss_bufs = {}
         for m, trs in by_motion.items():
             img, depth, normal, alpha = bufs[m]
             loss_bufs[m] = (torch.empty_like(img), torch.empty_like(img),
-                            torch.empty_like(depth) if c.add_depth else None,
-                            torch.empty_like(normal) if (c.add_normal and normal is not None) else None,
+                            torch.empty_like(depth) if depth_on else None,
+                            torch.empty_like(normal) if (normal_on and normal is not None) else None,
                             torch.empty_like(alpha))
         if ex.ranged:  # one batch per motion, on alternating private streams
             for m, trs in by_motion.items():
@@ -465,6 +565,11 @@ class Trainer:
             self.renderer.capacity.track(w_)
 
         loss_accum = zeroed[o_q + dquat_c.numel():o_q + dquat_c.numel() + 1]
+        # scalars produced on THIS stream (KL, ARAP, GA, LPIPS): summed apart from `loss_accum`, which the private
+        # streams' kernels add to atomically
+        extra = torch.zeros((), **f32)
+        if self._ga_active():
+            extra = extra + self._ga_direct(mine, pair_of, dxyz_c, g_dxyz)
         ssums = zeroed[o_q + dquat_c.numel() + 4:]
         ssim_terms, keep = [], []
         for m, trs in by_motion.items():
@@ -487,8 +592,9 @@ class Trainer:
                        "dimo_ssim_forward_backward")
             ssim_terms.append((ssum, c.lambda_ssim * share, float(B * 3 * H * W)))
             w_mse = [c.lambda_mse * (1.0 if (v == 0 or f == 0) else 0.5) / (3 * H * W) for (_m, v, f) in trs]
-            gi, gd, gn, ga = fused_image_loss(img, depth if c.add_depth else None, normal if c.add_normal else None,
-                                              alpha, gt, mask, w_mse, loss_weights(c, B, n_img, H, W), ssim_grad,
+            gi, gd, gn, ga = fused_image_loss(img, depth if depth_on else None, normal if normal_on else None,
+                                              alpha, gt, mask, w_mse,
+                                              loss_weights(c, B, n_img, H, W, depth_on, normal_on), ssim_grad,
                                               loss_accum, out=tuple(grad_out), stream=stream_m)
             keep.append((gi, gd, gn, ga, ssim_grad))
             if c.use_lpips:  # torch (MIOpen) on this stream, on the clamped render; its gradient joins the image's
@@ -496,7 +602,7 @@ class Trainer:
                 lp = c.lambda_lpips * share * self.lpips_metric()(x, gt).mean()
                 (g_lp,) = torch.autograd.grad(lp, x)
                 gi.add_(g_lp * ((img >= 0.0) & (img <= 1.0)))
-                loss_accum += lp.detach()
+                extra = extra + lp.detach()
             for b in range(B):
                 d = ex.descs[first[m] + b]
                 d.g_color, d.g_alpha = gi.data_ptr() + b * 3 * HW4, ga.data_ptr() + b * HW4
@@ -508,13 +614,14 @@ class Trainer:
                 ex.backward_launch(first[m], B)  # overlaps with the next motion's losses on this stream
             if g.vae_latent:  # KL term of this motion (main_train_dimo.py:355-360): tiny, autograd
                 mu, lv = g._mu[m], g._log_var[m]
-                kl = c.lambda_kl * (-0.5 * torch.sum(1 + lv - mu.pow(2) - lv.exp()))
+                kl = share * c.lambda_kl * (-0.5 * torch.sum(1 + lv - mu.pow(2) - lv.exp()))
                 kl.backward()
-                loss_accum += kl.detach()
+                extra = extra + kl.detach()
             reg = self.regularizer_loss(m)  # ARAP on the control points: its own small autograd graph
             if reg is not None:
+                reg = share * reg
                 reg.backward()
-                loss_accum += reg.detach()
+                extra = extra + reg.detach()
         self._mark("losses+launch")
         if ex.batched and not ex.ranged:
             ex.backward_launch(0, n)
@@ -537,7 +644,7 @@ class Trainer:
         self._mark("timenet_bwd")
         # the scalar loss is only read for logging: it is assembled from these parts when `last_loss` is looked at
         # (a dozen 4-us elementwise launches per step otherwise)
-        return _LazyLoss(loss_accum, ssim_terms)
+        return _LazyLoss(loss_accum, ssim_terms, extra)
 
     def _mark(self, name):
         if self.marks is not None:
@@ -557,18 +664,33 @@ class Trainer:
         """Runs one optimisation step; returns the number of renders THIS rank performed."""
         g = self.renderer.gaussians
         cap = self.renderer.capacity
+        c = self.cfg
         if self._flat_adam and cap is not None:
             bad = cap.poll()  # last step's instance counts (copied asynchronously)
-            if bad:  # that update was skipped on the device; the capacity bound has been raised
+            if bad:  # that update was skipped on the device; the capacity bound has been raised.  The optimizer's
+                # bias corrections do not depend on this read-back: the device counts its own skipped launches
+                # (adam.hip), identically on every replica because the flag travels through the all-reduce
                 self.skipped_steps += bad
-                self.optimizer.step_count -= bad
+                self.optimizer.skipped_host += bad
+        if self.stage == "s1" and self.step % c.FPS_iter == 0:  # main_train_dimo.py:227-228
+            self.fps(c.num_cpts)
+        if self.stage == "s2" and self.step == 0 and c.add_ga and self.cpts_s1 is None:  # main_train_dimo.py:231-244
+            self.cache_cpts_s1()
         self.step += 1
         g.update_learning_rate(self.step, self.stage)
+        if self.stage == "s2" and self.step < 1000:  # main_train_dimo.py:250-253
+            for grp in self.optimizer.param_groups:
+                if grp["name"] == "xyz":
+                    grp["lr"] = 0.0002
         if self.stage >= "s2":
             self.find_knn(k=4)
         if triples is None:
             triples = self.sample()
         mine = shard(triples, self.rank, self.world)
+        # the rank whose slice ends with the step's LAST triple: its last render feeds the s1 densification statistics
+        n_t = len(triples)
+        self._stats_owner = max((r for r in range(self.world) if (n_t * (r + 1)) // self.world > (n_t * r) // self.world),
+                                default=0)
         n_img = max(1, len(triples) // max(1, len({t[0] for t in triples})))  # images per motion (b^2)
 
         if self.direct:
@@ -600,19 +722,42 @@ class Trainer:
         self.densify_schedule()
         return len(mine)
 
+    def _densification_stats(self):
+        """main_train_dimo.py:429-431: the statistics come from `out` of the step's LAST render only (the reference's
+        loop variable), so under data parallelism the rank that owns the last triple contributes and the others add
+        zeros: all-reduce(SUM) of (gradient norm, count), all-reduce(MAX) of the radii -- every replica
+        then holds exactly the single-process statistics and densifies identically."""
+        g = self.renderer.gaussians
+        N = g._xyz.shape[0]
+        stats = torch.zeros(N, 2, dtype=torch.float32, device=self.device)
+        radii = torch.zeros(N, dtype=torch.float32, device=self.device)
+        last = getattr(self, "_last_stats", None)
+        if last is not None and self.rank == getattr(self, "_stats_owner", 0):
+            r, g2d = last  # radii [N] int32, gradient of the screen-space means [N, 3]
+            vis = r > 0
+            stats[vis, 0] = torch.norm(g2d[vis, :2], dim=-1)
+            stats[vis, 1] = 1.0
+            radii[vis] = r[vis].to(radii.dtype)
+        if self.world > 1:
+            dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=self.pg)
+            dist.all_reduce(radii, op=dist.ReduceOp.MAX, group=self.pg)
+        g.xyz_gradient_accum += stats[:, :1]
+        g.denom += stats[:, 1:2]
+        g.max_radii2D = torch.max(g.max_radii2D, radii)
+        self._last_stats = None
+
     def densify_schedule(self):
         """Densification / pruning of the reference's two stages (main_train_dimo.py:426-443), after the optimizer
         step.  Deterministic in the parameters (and the shared torch seed for the split draws): replicas stay equal."""
         c, g = self.cfg, self.renderer.gaussians
         if self.stage == "s1":
-            fps_iter = getattr(c, "FPS_iter", 1000)
+            fps_iter = c.FPS_iter
             if self.step % fps_iter >= c.density_start_iter and self.step <= c.density_end_iter:
-                out = getattr(self, "_last_out", None)
-                if out is not None and out["viewspace_points"].grad is not None:
-                    vis = out["visibility_filter"]
-                    g.update_max_radii(out["radii"], vis)
-                    g.add_densification_stats(out["viewspace_points"], vis)
+                self._densification_stats()
                 if self.step % c.densification_interval == 0:
+                    if self.world > 1:  # rank-identical split draws, whatever else consumed the global generator
+                        g.split_generator = torch.Generator(device=self.device).manual_seed(
+                            (c.seed * 1_000_003 + self.step) & 0x7FFFFFFF)
                     g.densify_and_prune(c.densify_grad_threshold, min_opacity=c.densify_opacity_threshold_s1, extent=4,
                                         max_screen_size=1)
                 if self.step % c.opacity_reset_interval == 0:

@@ -208,11 +208,14 @@ int dimo_deform_backward(int N, int M, int local_frame, int accumulate, const fl
  * n_segments contiguous ranges [segment_end[k-1], segment_end[k]) with learning rate segment_lr[k] (HOST arrays,
  * passed by value, n_segments <= 32, segment_end[n_segments-1] == n).  step = 1-based step count (bias correction).
  * skip_flags: optional device ints (n_flags of them, flag_stride ints apart); if any is non-zero the update is a
- * no-op (used with the rasterizer's capacity-overflow word).  zero_grad != 0 clears grads in the same pass. */
+ * no-op (used with the rasterizer's capacity-overflow word).  zero_grad != 0 clears grads in the same pass.
+ * skipped_launches: optional 2 device ints, zero-initialised by the caller and owned by this function afterwards:
+ * the number of no-op launches so far, kept on the device so that the bias corrections use the number of updates
+ * actually applied (step - skipped) without a host read-back; `step` must then count EVERY launch (1, 2, 3, ...). */
 int dimo_flat_adam_step(int64_t n, float *params, float *grads, float *exp_avg, float *exp_avg_sq, int n_segments,
                         const int64_t *segment_end_host, const float *segment_lr_host, float beta1, float beta2,
                         float eps, int64_t step, const int *skip_flags, int n_flags, int flag_stride, int zero_grad,
-                        void *stream);
+                        int *skipped_launches, void *stream);
 
 /* ------------------------------------------------------------------ TimeNet (the deformation MLP)
  * renderer/latent_gs_renderer.py:184-245 (`TimeNet.forward` with t_apply: one time per batch entry) for a whole

@@ -30,6 +30,11 @@ def dist2_cpu(pts):
     return torch.from_numpy(ro.dist2(pts.detach().cpu().numpy()))
 
 
+def fps_cpu(xyz, K):
+    from oracle.regularizers_ref import farthest_point_sample_ref
+    return torch.from_numpy(farthest_point_sample_ref(xyz.detach().numpy(), min(int(K), xyz.shape[0])))
+
+
 def make_cpu_trainer(cfg, rank=0, world=1, pg=None, regime="trained"):
     from dimo_amd.renderer import Renderer
     from dimo_amd.synth import init_synthetic_model
@@ -38,4 +43,8 @@ def make_cpu_trainer(cfg, rank=0, world=1, pg=None, regime="trained"):
                   num_latent_code=cfg.num_motions, latent_code_dim=cfg.latent_code_dim, add_normal=cfg.add_normal,
                   vae_latent=cfg.vae_latent, device="cpu", rasterizer_factory=OracleRasterizer, dist2_fn=dist2_cpu)
     init_synthetic_model(rd, cfg.num_pts, cfg.num_cpts, seed=cfg.seed, regime=regime, num_latent=cfg.num_motions)
-    return Trainer(cfg, rd, rank=rank, world_size=world, process_group=pg, ssim_fn=ssim_ref, knn_fn=knn_cpu)
+    if cfg.stage == "s1":  # the shared log-radius create_from_pcd makes (renderer/latent_gs_renderer.py:449-451)
+        g = rd.gaussians
+        g._r = torch.nn.Parameter(g._scaling.detach().mean() * torch.ones(1, 1))
+    return Trainer(cfg, rd, rank=rank, world_size=world, process_group=pg, ssim_fn=ssim_ref, knn_fn=knn_cpu,
+                   fps_fn=fps_cpu)

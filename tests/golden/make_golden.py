@@ -116,7 +116,12 @@ def sg(t):  # strided sample of a big gradient
     return n(t).reshape(-1)[::GRAD_STRIDE]
 
 
+ONLY = set(sys.argv[1:])  # e.g. `python tests/golden/make_golden.py densify_r.npz`: rewrite only these files
+
+
 def save(name, **arrs):
+    if ONLY and name not in ONLY:
+        return
     np.savez_compressed(os.path.join(OUT, name), **{k: np.asarray(v) for k, v in arrs.items()})
     print("wrote", name, len(arrs), "arrays")
 
@@ -363,6 +368,94 @@ def densify_fixture():
 
 densify_fixture()
 print("densify done")
+
+
+# ----------------------------------------------------------------------------- 8b. stage-s1 densification
+# The same entry points in the configuration stage s1 actually runs them in: `_r` is the shared (1, 1) log-radius that
+# create_from_pcd makes, so get_scaling = exp(_r) for every Gaussian (renderer/latent_gs_renderer.py:341-351) and the
+# clone / split selection, the split's sample stds, new_scaling and the world-size prune all use it instead of
+# `_scaling`.  Two radii: above percent_dense * extent (every selected point is split) and below it (cloned).  Plus
+# GUI.FPS's call `prune_points(idxs)` with an INDEX tensor (main_train_dimo.py:511-515), whose `~mask` is a bitwise not.
+def densify_r_fixture():
+    from dimo_amd.trainer import TrainConfig
+    opt = TrainConfig()
+    res = {}
+    names = ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation")
+    for case, radius in (("split", 0.05), ("clone", 0.03)):
+        torch.manual_seed(11)
+        Ng, Mc, L = 300, 300, 3
+        rd = R.Renderer(sh_degree=0, white_background=True, radius=2, num_latent_code=L, latent_code_dim=32,
+                        add_normal=True)
+        gm = rd.gaussians
+        P = lambda t: torch.nn.Parameter(t.clone().requires_grad_(True))
+        gm._xyz = P((torch.rand(Ng, 3) - 0.5) * 0.8)
+        gm._features_dc = P(torch.randn(Ng, 1, 3) * 0.3)
+        gm._features_rest = P(torch.zeros(Ng, 0, 3))
+        gm._scaling = P(torch.log(torch.rand(Ng, 3) * 0.12 + 0.004))
+        gm._rotation = P(torch.randn(Ng, 4))
+        gm._opacity = P(torch.randn(Ng, 1) * 2.5)
+        gm._c_xyz = P((torch.rand(Mc, 3) - 0.5) * 0.8)
+        gm._c_radius = P(torch.log(torch.rand(Mc, 1) * 0.1 + 0.05))
+        gm._r = P(torch.log(torch.tensor([[radius]])))
+        gm._latent_codes = P(torch.randn(L, 32))
+        gm.spatial_lr_scale = 1.0
+        gm.max_radii2D = torch.zeros(Ng)
+        gm.training_setup(opt)
+        per_gauss = dict(xyz=gm._xyz, f_dc=gm._features_dc, f_rest=gm._features_rest, opacity=gm._opacity,
+                         scaling=gm._scaling, rotation=gm._rotation)
+        if case == "split":
+            for k, p in per_gauss.items():
+                res[f"init.{k}"] = n(p).copy()
+        gg = torch.Generator().manual_seed(9)
+        for it in range(2):
+            for k, p in per_gauss.items():
+                p.grad = torch.randn(p.shape, generator=gg) * 0.01
+                if case == "split":
+                    res[f"grad{it}.{k}"] = n(p.grad).copy()
+            gm._r.grad = torch.full((1, 1), 0.02 * (it + 1))
+            for grp in gm.optimizer.param_groups:
+                if grp["name"] not in names + ("r",):
+                    for q in grp["params"]:
+                        q.grad = None
+            gm.optimizer.step()
+        accum, denom = torch.rand(Ng, 1, generator=gg) * 0.05, torch.randint(0, 3, (Ng, 1), generator=gg).float()
+        gm.xyz_gradient_accum, gm.denom = accum.clone(), denom.clone()
+        gm.max_radii2D = torch.rand(Ng, generator=gg) * 3
+        if case == "split":
+            res["accum"], res["denom"], res["max_radii2D"] = n(accum), n(denom), n(gm.max_radii2D)
+        res[f"{case}.r_before"] = n(gm._r).copy()
+
+        def snap(tag):
+            for grp in gm.optimizer.param_groups:
+                if grp["name"] in names + ("r",):
+                    q = grp["params"][0]
+                    st = gm.optimizer.state.get(q, None)
+                    res[f"{tag}.{grp['name']}"] = n(q).copy()
+                    res[f"{tag}.exp_avg.{grp['name']}"] = n(st["exp_avg"]).copy()
+                    res[f"{tag}.exp_avg_sq.{grp['name']}"] = n(st["exp_avg_sq"]).copy()
+                    res[f"{tag}.step.{grp['name']}"] = np.array(float(st["step"]))
+            res[f"{tag}.accum"], res[f"{tag}.denom"] = n(gm.xyz_gradient_accum).copy(), n(gm.denom).copy()
+            res[f"{tag}.max_radii2D"] = n(gm.max_radii2D).copy()
+
+        torch.manual_seed(78)
+        gm.densify_and_prune(opt.densify_grad_threshold, min_opacity=opt.densify_opacity_threshold_s1, extent=4,
+                             max_screen_size=1)
+        snap(f"{case}.densified")
+        if case == "split":  # GUI.FPS hands prune_points an index tensor
+            idxs = torch.tensor([5, 0, 17, 3, 40, 41, 2], dtype=torch.int64)
+            gm.xyz_gradient_accum = torch.arange(gm._xyz.shape[0], dtype=torch.float32)[:, None].clone()
+            gm.prune_points(idxs)
+            res["fps.idxs"] = n(idxs)
+            snap("fps")
+    res["radii"] = np.array([0.05, 0.03])
+    res["seed_split"] = np.array(78)
+    res["thresholds"] = np.array([opt.densify_grad_threshold, opt.densify_opacity_threshold_s1, 4.0, 1.0,
+                                  opt.percent_dense])
+    save("densify_r.npz", **res)
+
+
+densify_r_fixture()
+print("densify_r done")
 
 
 

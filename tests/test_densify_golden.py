@@ -84,6 +84,50 @@ def test_densify_prune_reset_match_reference():
     assert not torch.equal(before, g._xyz.detach())
 
 
+def _model_r(gold, radius):
+    from torch import nn
+    g, cfg = _model(gold)
+    g._r = nn.Parameter(torch.log(torch.tensor([[radius]], dtype=torch.float32)).requires_grad_(True))
+    return g, cfg
+
+
+@pytest.mark.parametrize("case,radius", [("split", 0.05), ("clone", 0.03)])
+def test_stage_s1_densification_uses_the_shared_radius(case, radius):
+    """Stage s1 (the only stage that densifies): `_r` is the shared (1, 1) log-radius, get_scaling = exp(_r), and the
+    clone / split selection, the split's stds and new_scaling and the world-size prune follow it
+    (renderer/latent_gs_renderer.py:341-351,826-890).  Golden: the reference's own GaussianModel with `_r` set."""
+    gold = np.load(os.path.join(GOLD, "densify_r.npz"))
+    g, cfg = _model_r(gold, radius)
+    g.training_setup(cfg)
+    assert "r" in [grp["name"] for grp in g.optimizer.param_groups]
+    for it in range(2):
+        g.zero_grad()
+        for k, p in g.per_gaussian().items():
+            if p.numel():
+                p.grad.copy_(torch.tensor(gold[f"grad{it}.{k}"]))
+        g._r.grad.fill_(0.02 * (it + 1))
+        g.optimizer.step()
+    np.testing.assert_allclose(g._r.detach().numpy(), gold[f"{case}.r_before"], rtol=1e-6)
+    g.xyz_gradient_accum, g.denom = torch.tensor(gold["accum"]), torch.tensor(gold["denom"])
+    g.max_radii2D = torch.tensor(gold["max_radii2D"])
+    thr = gold["thresholds"]
+    torch.manual_seed(int(gold["seed_split"]))
+    g.densify_and_prune(float(thr[0]), min_opacity=float(thr[1]), extent=float(thr[2]), max_screen_size=float(thr[3]))
+    _check(g, gold, f"{case}.densified")
+    # the shared radius and its Adam state are untouched by the surgery
+    np.testing.assert_allclose(g._r.detach().numpy(), gold[f"{case}.densified.r"], rtol=1e-6)
+    m, v, step = g._moments(g._r)
+    np.testing.assert_allclose(m.numpy(), gold[f"{case}.densified.exp_avg.r"], rtol=1e-5)
+    np.testing.assert_allclose(v.numpy(), gold[f"{case}.densified.exp_avg_sq.r"], rtol=1e-5)
+    assert g._xyz.shape[0] != 300
+    if case == "split":
+        # GUI.FPS (main_train_dimo.py:511-515) hands prune_points an INDEX tensor: ~idx = -idx-1 selects rows N-1-idx
+        g.xyz_gradient_accum = torch.arange(g._xyz.shape[0], dtype=torch.float32)[:, None].clone()
+        g.prune_points(torch.tensor(gold["fps.idxs"]))
+        assert g._xyz.shape[0] == len(gold["fps.idxs"])
+        _check(g, gold, "fps")
+
+
 def test_prune_points_keeps_other_groups_and_their_moments():
     gold = np.load(os.path.join(GOLD, "densify.npz"))
     g, cfg = _model(gold)

@@ -86,6 +86,7 @@ def test_train_step_gpu_matches_cpu_oracle_pipeline():
     rd = Renderer(sh_degree=0, num_latent_code=cfg.num_motions, add_normal=True, device="cuda")
     init_synthetic_model(rd, cfg.num_pts, cfg.num_cpts, seed=cfg.seed, num_latent=cfg.num_motions)
     gpu = Trainer(cfg, rd)
+    cpu.step = gpu.step = 300  # past depth/normal_reg_start_iter: every image term is on
     p0 = cpu.renderer.gaussians.flat_params.clone()
     assert torch.allclose(p0, rd.gaussians.flat_params.cpu(), atol=2e-6)  # log(sqrt(dist2)) rounds per device
     # gradients of the first step (before Adam's sign-like normalisation amplifies rounding)

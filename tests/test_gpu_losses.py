@@ -77,6 +77,7 @@ def test_direct_pipeline_equals_autograd_pipeline(vae, arap):
                       capacity=CapacityPolicy(initial=1 << 19) if direct else None)
         init_synthetic_model(rd, cfg.num_pts, cfg.num_cpts, seed=0, num_latent=cfg.num_motions)
         tr = Trainer(cfg, rd, direct=direct)
+        tr.step = 300  # past depth/normal_reg_start_iter: every image term is on
         assert tr.direct == direct
         tr.optimizer.step = lambda *a, **k: None
         rd.gaussians.zero_grad = lambda: None
@@ -90,6 +91,58 @@ def test_direct_pipeline_equals_autograd_pipeline(vae, arap):
     assert rel < 1e-4, rel
     # and a real step moves the parameters identically enough
     assert torch.isfinite(gb).all()
+
+
+class _MaskedTargets:
+    """Targets whose mask differs per (view, frame), like source_masks[motion][view][frame] (main_train_dimo.py:284)."""
+
+    def __init__(self, res):
+        self.res = res
+        self._cache = {}
+
+    def get(self, m, v, f):
+        key = (m, v, f)
+        if key not in self._cache:
+            gen = torch.Generator().manual_seed(1000 * m + 10 * v + f)
+            img = torch.rand(3, self.res, self.res, generator=gen)
+            yy, xx = torch.meshgrid(torch.arange(self.res), torch.arange(self.res), indexing="ij")
+            cx, cy = self.res * (0.3 + 0.1 * v), self.res * (0.35 + 0.08 * f)
+            mask = (((xx - cx) ** 2 + (yy - cy) ** 2) <= (0.25 * self.res) ** 2).float()[None]
+            self._cache[key] = (img.cuda(), mask.cuda())
+        return self._cache[key]
+
+
+@pytest.mark.parametrize("ga", [None, "chamfer", "l1"])
+def test_direct_pipeline_per_image_masks_and_geometry_anchor(ga):
+    """(a) every image of a motion's batch is compared with ITS OWN mask (a shared synthetic mask hid a bug here);
+    (b) the geometry-anchor term of stage s2 (main_train_dimo.py:231-244,295-303), chamfer and L1 flavours, with its
+    step-0 control-point cache: direct pipeline == autograd pipeline."""
+    from dimo_amd.rasterizer import CapacityPolicy
+    from dimo_amd.renderer import Renderer
+    from dimo_amd.synth import init_synthetic_model
+    from dimo_amd.trainer import TrainConfig, Trainer
+    cfg = TrainConfig(num_pts=4000, num_cpts=64, num_motions=4, num_frames=6, num_views=4, motions_per_step=2,
+                      views_per_step=2, frames_per_step=2, resolution=96, add_ga=ga is not None,
+                      ga_chamfer=ga == "chamfer")
+    res = []
+    for direct in (False, True):
+        rd = Renderer(sh_degree=0, num_latent_code=cfg.num_motions, add_normal=True, device="cuda",
+                      capacity=CapacityPolicy(initial=1 << 19) if direct else None)
+        init_synthetic_model(rd, cfg.num_pts, cfg.num_cpts, seed=0, num_latent=cfg.num_motions)
+        tr = Trainer(cfg, rd, direct=direct, targets=_MaskedTargets(cfg.resolution))
+        tr.optimizer.step = lambda *a, **k: None
+        rd.gaussians.zero_grad = lambda: None
+        if ga is not None:  # the cache of step 0, then moved: at step 0 itself the anchors coincide with the points
+            tr.cache_cpts_s1()
+            assert tr.cpts_s1.shape == (cfg.num_motions, cfg.num_frames, cfg.num_cpts, 3)
+            tr.cpts_s1 += 0.02 * torch.randn(tr.cpts_s1.shape, generator=torch.Generator().manual_seed(3)).cuda()
+        tr.step = 300
+        tr.train_step(tr.sample())
+        res.append((tr.last_loss.item(), rd.gaussians.flat_grads.clone(), rd.gaussians._c_xyz.grad.clone()))
+    (la, ga_, ca), (lb, gb, cb) = res
+    assert abs(la - lb) <= 1e-5 * abs(la), (la, lb)
+    assert (ga_ - gb).abs().sum() / ga_.abs().sum() < 1e-4
+    assert (ca - cb).abs().sum() / ca.abs().sum() < 1e-4
 
 
 def test_direct_pipeline_ragged_tiles_and_three_view_groups():
@@ -107,6 +160,7 @@ def test_direct_pipeline_ragged_tiles_and_three_view_groups():
                       capacity=CapacityPolicy(initial=1 << 18) if direct else None)
         init_synthetic_model(rd, cfg.num_pts, cfg.num_cpts, seed=3, num_latent=cfg.num_motions)
         tr = Trainer(cfg, rd, direct=direct)
+        tr.step = 300  # past depth/normal_reg_start_iter: every image term is on
         tr.optimizer.step = lambda *a, **k: None
         rd.gaussians.zero_grad = lambda: None
         tr.train_step(tr.sample())
@@ -159,6 +213,7 @@ def test_direct_pipeline_with_lpips_term():
                       capacity=CapacityPolicy(initial=1 << 17) if direct else None)
         init_synthetic_model(rd, cfg.num_pts, cfg.num_cpts, seed=2, num_latent=cfg.num_motions)
         tr = Trainer(cfg, rd, direct=direct)
+        tr.step = 300  # past depth/normal_reg_start_iter: every image term is on
         tr.optimizer.step = lambda *a, **k: None
         rd.gaussians.zero_grad = lambda: None
         tr.train_step(tr.sample())
@@ -183,6 +238,7 @@ def test_direct_pipeline_more_renders_per_motion_than_a_batch():
                       capacity=CapacityPolicy(initial=1 << 17) if direct else None)
         init_synthetic_model(rd, cfg.num_pts, cfg.num_cpts, seed=5, num_latent=cfg.num_motions)
         tr = Trainer(cfg, rd, direct=direct)
+        tr.step = 300  # past depth/normal_reg_start_iter: every image term is on
         tr.optimizer.step = lambda *a, **k: None
         rd.gaussians.zero_grad = lambda: None
         assert tr.train_step(tr.sample()) == 20
@@ -208,6 +264,7 @@ def _dp_gpu_worker(rank, world, port, out):
                   capacity=CapacityPolicy(initial=1 << 18))
     init_synthetic_model(rd, cfg.num_pts, cfg.num_cpts, seed=0, num_latent=cfg.num_motions)
     tr = Trainer(cfg, rd, rank=rank, world_size=world)
+    tr.step = 300
     assert tr.direct and tr._flat_adam
     counts = [tr.train_step() for _ in range(3)]
     torch.cuda.synchronize()
@@ -238,6 +295,7 @@ def test_direct_pipeline_data_parallel_two_ranks_on_one_device(tmp_path):
                   capacity=CapacityPolicy(initial=1 << 18))
     init_synthetic_model(rd, cfg.num_pts, cfg.num_cpts, seed=0, num_latent=cfg.num_motions)
     single = Trainer(cfg, rd)
+    single.step = 300
     for _ in range(3):
         single.train_step()
     p = rd.gaussians.flat_params.cpu()
@@ -261,6 +319,7 @@ def test_executor_modes_agree(monkeypatch):
                       capacity=CapacityPolicy(initial=1 << 19))
         init_synthetic_model(rd, cfg.num_pts, cfg.num_cpts, seed=0, num_latent=cfg.num_motions)
         tr = Trainer(cfg, rd)
+        tr.step = 300
         tr.optimizer.step = lambda *a, **k: None
         tr.train_step(tr.sample())
         torch.cuda.synchronize()

@@ -63,6 +63,37 @@ def test_loss_is_partition_invariant_and_sum_reduced():
     assert rel < 1e-5, rel
 
 
+def test_per_motion_terms_are_counted_once_when_a_motion_is_split_over_ranks():
+    """KL (VAE latents) and the geometry-anchor term with ONE motion's four renders split over two ranks: the SUM of
+    the ranks' gradients must equal the single-process gradients (the KL term used to be added once per rank)."""
+    cfg = small_cfg(motions_per_step=1, views_per_step=2, frames_per_step=2, resolution=48, num_pts=300,
+                    vae_latent=True, add_ga=True)
+    triples = make_cpu_trainer(cfg).sample()
+    assert len({t[0] for t in triples}) == 1 and len(triples) == 4
+    grads, losses = [], []
+    for world in (1, 2):
+        acc, loss = None, 0.0
+        for rank in range(world):
+            t2 = make_cpu_trainer(cfg, rank=rank, world=world)
+            t2.all_reduce_grads = lambda: None
+            g = t2.renderer.gaussians
+            t2.optimizer.step = lambda: None
+            g.zero_grad = lambda: None
+            with torch.no_grad():  # std = exp(-15): the per-render eps draws (global generator) do not matter
+                g._log_var.fill_(-30.0)
+            t2.cache_cpts_s1()
+            t2.cpts_s1 += 0.02 * torch.randn(t2.cpts_s1.shape, generator=torch.Generator().manual_seed(3))
+            t2.step = 300
+            t2.train_step(triples)
+            acc = g.flat_grads.clone() if acc is None else acc + g.flat_grads
+            loss += float(t2.last_loss)
+        grads.append(acc)
+        losses.append(loss)
+    assert abs(losses[0] - losses[1]) <= 1e-5 * abs(losses[0]), losses
+    rel = (grads[0] - grads[1]).abs().sum() / grads[0].abs().sum()
+    assert rel < 1e-5, rel
+
+
 def test_shard_covers_everything():
     items = list(range(10))
     for world in (1, 2, 3, 4, 8, 16):
@@ -95,3 +126,78 @@ def test_data_parallel_two_ranks_gloo(tmp_path):
     p = single.renderer.gaussians.flat_params
     rel = (p - a["params"]).abs().sum() / p.abs().sum()
     assert rel < 1e-4, rel
+
+
+def _s1_cfg():
+    # stage s1: FPS down to num_cpts at step 0, statistics from step 1 on, densify at steps 2 and 4
+    return small_cfg(stage="s1", num_pts=300, num_cpts=48, motions_per_step=2, views_per_step=1, frames_per_step=1,
+                     resolution=48, density_start_iter=1, densification_interval=2, densify_grad_threshold=1e-9,
+                     position_lr_max_steps=500)
+
+
+def _s1_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    tr = make_cpu_trainer(_s1_cfg(), rank=rank, world=world, regime="init")
+    g = tr.renderer.gaussians
+    torch.manual_seed(100 + rank)  # the ranks' global generators differ: the split draws must not depend on them
+    sizes = []
+    for _ in range(5):
+        tr.train_step()
+        sizes.append(g._xyz.shape[0])
+    torch.save(dict(params=g.flat_params.clone(), sizes=sizes, accum=g.xyz_gradient_accum.clone(),
+                    denom=g.denom.clone(), radii=g.max_radii2D.clone()), f"{out}/rank{rank}.pt")
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_stage_s1_data_parallel_densification_keeps_replicas_identical(tmp_path):
+    """SURVEY 8e / renderer/latent_gs_renderer.py:838,922-924: under data parallelism the densification statistics
+    are all-reduced (SUM for the gradient norms and counts, MAX for the radii) and the split draws come from a
+    rank-identical generator, so two gloo ranks train stage s1 ACROSS two densify_and_prune calls with equal Gaussian
+    counts and bit-identical parameters -- and the counts equal the single-process run on the same triples."""
+    port = 25500 + (os.getpid() % 2000)
+    mp.spawn(_s1_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a, b = torch.load(f"{tmp_path}/rank0.pt"), torch.load(f"{tmp_path}/rank1.pt")
+    assert a["sizes"] == b["sizes"], (a["sizes"], b["sizes"])
+    assert a["sizes"][0] == 48 and a["sizes"][-1] != 48, a["sizes"]  # FPS at step 0, then densified
+    assert torch.equal(a["params"], b["params"]), "replicas diverged"
+    for k in ("accum", "denom", "radii"):
+        assert torch.equal(a[k], b[k]), k
+    single = make_cpu_trainer(_s1_cfg(), regime="init")
+    sizes = []
+    for _ in range(5):
+        single.train_step()
+        sizes.append(single.renderer.gaussians._xyz.shape[0])
+    assert sizes[:2] == a["sizes"][:2]  # identical up to the first densification (the split draws differ after it)
+
+
+def test_stage_s1_fps_and_lr_rules():
+    tr = make_cpu_trainer(_s1_cfg(), regime="init")
+    g = tr.renderer.gaussians
+    lrs = {grp["name"]: grp["lr"] for grp in tr.optimizer.param_groups}
+    assert lrs["c_xyz"] == 0.0 and lrs["c_radius"] == 0.0 and "r" in lrs  # prepare_train_s1
+    xyz0 = g._xyz.detach().clone()
+    from oracle.regularizers_ref import farthest_point_sample_ref
+    idx = farthest_point_sample_ref(xyz0.numpy(), 48)
+    tr.fps(48)
+    # the reference's `prune_points(idxs)` keeps rows N-1-idx (bitwise not of an index tensor), in sampling order
+    assert torch.equal(g._xyz.detach(), xyz0[300 - 1 - torch.from_numpy(idx)])
+
+
+def test_stage_s2_schedule_rules():
+    """main_train_dimo.py:250-253 (xyz lr pinned to 2e-4 while step < 1000 in s2) and :362,368 (the depth / normal
+    smoothness terms start after step 200)."""
+    cfg = small_cfg(motions_per_step=1, resolution=32, num_pts=200)
+    tr = make_cpu_trainer(cfg)
+    tr.train_step()
+    lr = {grp["name"]: grp["lr"] for grp in tr.optimizer.param_groups}
+    assert lr["xyz"] == 0.0002 and tr._reg_on() == (False, False)
+    tr.step = 200
+    tr.train_step()
+    assert tr._reg_on() == (True, True)
+    tr.step = 999
+    tr.train_step()
+    lr = {grp["name"]: grp["lr"] for grp in tr.optimizer.param_groups}
+    assert lr["xyz"] != 0.0002 and abs(lr["xyz"] - tr.renderer.gaussians.xyz_scheduler_args(1000)) < 1e-12

@@ -3,13 +3,17 @@
     pmc_sq_summarise.py <csv> [pattern ...]                                   (prints one line per pattern)
     pmc_sq_summarise.py --json out.json --csv a.csv b.csv ... -- pattern ...  (merged passes + derived figures)
 
-Derived (per launch, MI355X: 256 CUs x 4 SIMD-32, a wave64 VALU instruction occupies its SIMD for 2 cycles;
-SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* are in quad-cycles summed over waves -- MI355X_MICROARCH.md):
-  valu_issue_frac   = 2 * SQ_INSTS_VALU / (1024 * GRBM_GUI_ACTIVE)      share of the chip's VALU issue slots used
+Derived (per launch, MI355X: 256 CUs x 4 SIMDs; GRBM_GUI_ACTIVE comes back SUMMED over the 8 XCDs, so the kernel's
+cycle count is a eighth of it; a wave64 VALU instruction occupies its SIMD for 2 cycles if it is an fma / mul / add /
+mov / and / or on VGPR operands, 4 for cmp / min / max / cndmask / shifts / cvt / any DPP or SGPR-operand form, 8 for
+exp / rcp / sqrt / log -- profiles/r02_valu_issue_rates.txt; SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* are in
+quad-cycles summed over waves -- MI355X_MICROARCH.md):
+  valu_issue_frac   = 2 * SQ_INSTS_VALU / (1024 * cycles)   LOWER bound of the VALU pipe's busy share (all 2-cycle)
+  valu_busy_quad    = 4 * SQ_ACTIVE_INST_VALU / (1024 * cycles)   the same with every instruction priced at 4 cycles
   wave_active_valu  = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES              share of a wave's life spent issuing VALU
   wave_wait_any     = SQ_WAIT_ANY / SQ_WAVE_CYCLES                      parked on s_waitcnt / barrier
   wave_wait_inst    = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES                 ready but not issued (pipe / dependency stall)
-  waves_per_simd    = 4 * SQ_WAVE_CYCLES / (1024 * GRBM_GUI_ACTIVE)     achieved occupancy
+  waves_per_simd    = 4 * SQ_WAVE_CYCLES / (1024 * cycles)              achieved occupancy
   lds_conflict_frac = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE
 """
 import csv
@@ -42,9 +46,13 @@ def main():
         m = {k: sum(v) / len(v) for k, v in d.items()}
         m["launches"] = len(next(iter(d.values())))
         g, wc = m.get("GRBM_GUI_ACTIVE"), m.get("SQ_WAVE_CYCLES")
+        g = g / 8.0 if g else g  # summed over the 8 XCDs
         der = {}
         if g and "SQ_INSTS_VALU" in m:
             der["valu_issue_frac"] = 2.0 * m["SQ_INSTS_VALU"] / (1024.0 * g)
+            der["kernel_cycles"] = g
+        if g and "SQ_ACTIVE_INST_VALU" in m:
+            der["valu_busy_quad"] = 4.0 * m["SQ_ACTIVE_INST_VALU"] / (1024.0 * g)
         if wc:
             for name, key in (("wave_active_valu", "SQ_ACTIVE_INST_VALU"), ("wave_active_any", "SQ_ACTIVE_INST_ANY"),
                               ("wave_wait_any", "SQ_WAIT_ANY"), ("wave_wait_inst", "SQ_WAIT_INST_ANY"),
