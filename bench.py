@@ -49,7 +49,11 @@ def make_trainer(device, rank, world, num_pts, resolution, per_gpu=(2, 2, 2), ca
     rd = Renderer(sh_degree=0, white_background=True, radius=cfg.radius, num_latent_code=cfg.num_motions,
                   latent_code_dim=cfg.latent_code_dim, add_normal=True, device=device, capacity=pol)
     init_synthetic_model(rd, cfg.num_pts, cfg.num_cpts, seed=0, regime="trained", num_latent=cfg.num_motions)
-    return Trainer(cfg, rd, rank=rank, world_size=world), pol
+    tr = Trainer(cfg, rd, rank=rank, world_size=world)
+    # steady state of the schedule: past depth/normal_reg_start_iter (200) every image term is on (10 600 of the
+    # reference's 10 000 + 2 800 iterations run that way), past step 1000 the s2 xyz lr rule no longer applies
+    tr.step = 1000
+    return tr, pol
 
 
 def kernel_rooflines(timing_iso, N, V, R, P, C=NFEAT):

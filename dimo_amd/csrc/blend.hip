@@ -33,7 +33,8 @@ namespace dimo {
 
 constexpr int BLEND_BLOCK = 256;
 constexpr int BATCH = 256;
-constexpr int BWD_GRID = 16384;  // persistent single-wave workgroups looping over the (tile, bucket) items
+constexpr int BWD_GRID = 16384;  // single-wave workgroups striding over the work items (most get one)
+constexpr int BWD_WAVES_PER_SIMD = 4;  // register budget of the backward: 128 VGPRs
 
 __device__ __forceinline__ void pixel_of_thread(int tile_x, int tile_y, int &px, int &py) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -97,7 +98,7 @@ __device__ __forceinline__ void blend_fwd_body(
     const Splat *__restrict__ splat, const float *__restrict__ bg, float *__restrict__ out_color,
     float *__restrict__ out_depth, float *__restrict__ out_normal, float *__restrict__ out_alpha,
     float *__restrict__ final_T, uint32_t *__restrict__ n_contrib, float *__restrict__ final_acc,
-    float *__restrict__ ckpt, uint32_t *__restrict__ work) {
+    float *__restrict__ ckpt, uint32_t *__restrict__ work, uint32_t chain) {
   __shared__ uint32_t s_last[BLEND_BLOCK / 64];
   __shared__ float4 s_geo[BATCH];   // x y A B
   __shared__ float4 s_col[BATCH];   // C opacity r g
@@ -155,7 +156,10 @@ __device__ __forceinline__ void blend_fwd_body(
       raw_next = (int)s_list[wave][min(t + 2, mine - 1)];
       gn = s_geo[jn], cn = s_col[jn], an = s_aux[jn];
       if (NORMAL) nzn = s_nz[jn];
+      // the state at the first entry of every bucket that STARTS A CHAIN of the backward (every `chain`-th bucket;
+      // not bucket 0, whose state is T = 1 and empty sums)
       for (const uint32_t eb = ((start - lo) + (uint32_t)j) / BUCKET; next_ck <= eb; ++next_ck) {
+        if (next_ck == 0u || next_ck % chain != 0u) continue;
         float *ck = ck_base + (size_t)next_ck * (CKPT_FLOATS * TILE * TILE);
         ck[0] = T;
 #pragma unroll
@@ -199,7 +203,7 @@ __device__ __forceinline__ void blend_fwd_body(
     }
     out_alpha[pix] = wsum;
   }
-  // queue one backward item per bucket some pixel of this tile reaches
+  // queue one backward item per chain of `chain` buckets some pixel of this tile reaches
   uint32_t m = last;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
@@ -209,257 +213,241 @@ __device__ __forceinline__ void blend_fwd_body(
     const uint32_t deepest = max(max(s_last[0], s_last[1]), max(s_last[2], s_last[3]));
     const uint32_t nb = (deepest + BUCKET - 1) / BUCKET;
     if (nb) {
-      const uint32_t base = atomicAdd(work, nb);
-      // (the item carries its tile's list range: one dependent load less in front of every backward item)
-      for (uint32_t b = 0; b < nb; ++b)
-        reinterpret_cast<uint4 *>(work)[1 + base + b] = make_uint4(((uint32_t)tile << 12) | b, lo, hi, 0u);
+      const uint32_t ni = (nb + chain - 1) / chain;
+      const uint32_t base = atomicAdd(work, ni);
+      // (tile << 12 | first bucket, list start, list end, buckets in the chain): the item carries its tile's list
+      // range, one dependent load less in front of every backward item
+      for (uint32_t i = 0; i < ni; ++i)
+        reinterpret_cast<uint4 *>(work)[1 + base + i] =
+            make_uint4(((uint32_t)tile << 12) | (i * chain), lo, hi, min(chain, nb - i * chain));
     }
   }
 }
 
 // ---------------------------------------------------------------------------------- backward
-// (wave reduction helpers: wave_ops.hpp)
+// (wave reduction: wave_ops.hpp)
 //
-// ONE WAVE per (tile, bucket) item, four pixels per lane -- lane l owns pixel l of EACH 8x8 quadrant.  The 13
-// per-(record) sums are then accumulated over a lane's four pixels in registers and cross the wave ONCE per record
-// (one halving butterfly + one plain 16-lane LDS store: the wave is the only writer of its item), while quadrant
-// culling stays wave-uniform: a quadrant the record cannot reach, or whose pixels all stopped earlier, is skipped by
-// a scalar branch.  The previous layout (one workgroup per item, one wave per quadrant) paid the ~60-instruction
-// reduction once per visited QUADRANT -- 2.3 times per record on the C3 workload, more than the ~45 instructions of
-// the per-pixel evaluation itself.
+// ONE WAVE per work item, four pixels per lane -- lane l owns pixel l of EACH 8x8 quadrant of the tile.  The 13
+// per-record sums are accumulated over a lane's four pixels in registers and cross the wave ONCE per record (one
+// halving reduction + one plain 16-lane LDS store: the wave is the only writer of its item), while quadrant culling
+// stays wave-uniform: a quadrant the record cannot reach, or whose pixels all stopped earlier, is skipped by a scalar
+// branch.
 //
-// QPW = quadrants per wave: 4 -> one wave per item (the batched launches of the step executor, >= 10^4 items in
-// flight); 1 or 2 -> 4 or 2 waves per item, each with its own visit list and LDS float atomics into the shared
-// sums (a single render has ~2700 items for 1024 SIMDs: one wave per SIMD is latency bound, 0.185 ms against
-// 0.129 ms with four waves per item).
-template <bool NORMAL, int QPW>
-__device__ __forceinline__ void blend_bwd_body(
-    int H, int W, int tiles_x, uint32_t R_cap, const uint32_t *__restrict__ ranges,
-    const uint32_t *__restrict__ vals_sorted, const Splat *__restrict__ splat, const uint16_t *__restrict__ rect,
-    const uint32_t *__restrict__ offsets, const float *__restrict__ bg, const float *__restrict__ final_T,
-    const uint32_t *__restrict__ n_contrib, const float *__restrict__ final_acc, const float *__restrict__ ckpt,
-    const uint32_t *__restrict__ work, const float *__restrict__ dL_dcolor, const float *__restrict__ dL_ddepth,
-    const float *__restrict__ dL_dnormal, const float *__restrict__ dL_dalpha, SplatGrad *__restrict__ inst_grad,
-    uint8_t *__restrict__ inst_flag) {
-  __shared__ float4 s_geo[BUCKET];
-  __shared__ float4 s_col[BUCKET];
-  __shared__ float4 s_aux[BUCKET];
-  __shared__ float s_nz[BUCKET];
-  __shared__ uint32_t s_emit[BUCKET];
-  __shared__ uint32_t s_mask[BUCKET];
-  constexpr int WAVES = 4 / QPW;
-  __shared__ uint16_t s_list[WAVES][BUCKET];
-  __shared__ float s_acc[BUCKET][16];
-  static_assert(BUCKET == 64, "one staged record per lane of the first wave");
+// A work item is a CHAIN of up to `chain` consecutive buckets of one tile (bucket = BUCKET list entries): the pixel
+// state (transmittance, the running sums, the 8 gradient values of each of the lane's four pixels) is loaded once
+// per item and carried through the chain in registers.  Only a chain that does not start at the head of the list
+// reads a checkpoint; round 1 ran one bucket per item and re-read ~112 B of state per pixel for every bucket
+// (1.86x the algorithmic traffic, SQ_WAIT_ANY a third of a wave's life).
+//
+// The per-pixel evaluation is predicated (selects on alpha and on g), not branched: with half of a quadrant's lanes
+// inactive a branch saves no issue slot, and every `if` on a vector condition costs a VALU -> SALU round trip.
+// Instruction classes are chosen by their measured issue cost (profiles/r02_valu_issue_rates.txt).
+struct BwdView {  // one render's buffers as the backward sees them
+  const uint32_t *vals;
+  const Splat *splat;
+  const uint16_t *rect;
+  const uint32_t *offsets;
+  const float *final_T;
+  const uint32_t *n_contrib;
+  const float *final_acc;
+  const float *ckpt;
+  const uint32_t *work;
+  const float *dL_dcolor, *dL_ddepth, *dL_dnormal, *dL_dalpha;
+  SplatGrad *inst_grad;
+  uint8_t *inst_flag;
+};
 
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const size_t HW = (size_t)H * W;
-  const uint32_t n_items = work[0];
-  for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
-    const uint4 it = reinterpret_cast<const uint4 *>(work)[1 + item];
-    const uint32_t code = it.x, lo = it.y, hi = it.z;
-    const int tile = (int)(code >> 12);
-    const uint32_t blo = (code & 0xfffu) * BUCKET;
-    const int tile_x = tile % tiles_x, tile_y = tile / tiles_x;
-    const int count = (int)min((uint32_t)BUCKET, hi - lo - blo);
-    const int bx = tile_x * TILE + (lane & 7), by = tile_y * TILE + (lane >> 3);
-    const float bxf = (float)bx, byf = (float)by;
-    const float *const ck_item = ckpt + ((size_t)(lo / BUCKET) + tile + blo / BUCKET) * (CKPT_FLOATS * TILE * TILE);
+template <bool NORMAL>
+__device__ __forceinline__ void blend_bwd_item(int H, int W, int tiles_x, uint32_t R_cap, const float *__restrict__ bg,
+                                               const BwdView &r, uint4 it, float4 *s_geo, float4 *s_col, float4 *s_aux,
+                                               float *s_nz, uint32_t *s_mask, float (*s_acc)[16]) {
+  const int lane = threadIdx.x;
+  const uint32_t HW32 = (uint32_t)H * (uint32_t)W;
+  const uint32_t code = it.x, lo = it.y, hi = it.z;
+  const int tile = (int)(code >> 12);
+  const uint32_t b0 = code & 0xfffu, nbk = it.w;
+  const int tile_x = tile % tiles_x, tile_y = tile / tiles_x;
+  const int bx = tile_x * TILE + (lane & 7), by = tile_y * TILE + (lane >> 3);
+  const float bxf = (float)bx, byf = (float)by;
 
-    __syncthreads();  // previous item fully consumed
-    // QPW == 4 (one wave per item): the records are staged COMPACTED -- record number rank-among-the-reachable goes
-    // to slot rank, with its original list position in the high bits of the mask word -- so the visit loop reads slot
-    // t directly instead of chasing an index list (two dependent LDS round trips per record, ~250 cycles of a
-    // latency-bound loop); every lane keeps its own rank / emission slot in registers for the epilogue.
-    uint32_t my_emit = 0;
-    int my_rank = 0, mine = 0;
-    bool my_hit = false;
-    if (QPW == 4) {
-      float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra, rc4 = ra;
-      float rnz = 0.0f;
-      uint32_t qmask = 0;
-      if (lane < count) {
-        const uint32_t g = vals_sorted[lo + blo + lane];
-        const float4 *rp = reinterpret_cast<const float4 *>(splat + g);
-        ra = rp[0], rb = rp[1], rc4 = rp[2];
-        if (NORMAL) rnz = rp[3].x;
-        qmask = quadrant_mask(ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, tile_x, tile_y);
-        const uint2 rc = *reinterpret_cast<const uint2 *>(rect + 4 * (size_t)g);
-        const int x0 = rc.x & 0xffff, y0 = rc.x >> 16, x1 = rc.y & 0xffff;
-        my_emit = (g == 0 ? 0u : offsets[g - 1]) + (uint32_t)((tile_y - y0) * (x1 - x0) + (tile_x - x0));
-      }
-      my_hit = qmask != 0u;
-      const unsigned long long bal = __ballot(my_hit);
-      my_rank = __popcll(bal & ((1ull << lane) - 1ull));
-      mine = __popcll(bal);
-      if (my_hit) {
-        s_geo[my_rank] = ra, s_col[my_rank] = rb, s_aux[my_rank] = rc4;
-        if (NORMAL) s_nz[my_rank] = rnz;
-        s_mask[my_rank] = qmask | ((uint32_t)lane << 8);
-      }
-    } else if (wave == 0 && lane < count) {
-      const uint32_t g = vals_sorted[lo + blo + lane];
-      const float4 *rp = reinterpret_cast<const float4 *>(splat + g);
-      const float4 a = rp[0], b = rp[1];
-      s_geo[lane] = a;
-      s_col[lane] = b;
-      s_aux[lane] = rp[2];
-      if (NORMAL) s_nz[lane] = rp[3].x;
-      s_mask[lane] = quadrant_mask(a.x, a.y, a.z, a.w, b.x, b.y, tile_x, tile_y);
-      const uint2 rc = *reinterpret_cast<const uint2 *>(rect + 4 * (size_t)g);
-      const int x0 = rc.x & 0xffff, y0 = rc.x >> 16, x1 = rc.y & 0xffff;
-      s_emit[lane] = (g == 0 ? 0u : offsets[g - 1]) + (uint32_t)((tile_y - y0) * (x1 - x0) + (tile_x - x0));
-    }
+  // ---- pixel state of the lane's four pixels at the head of the chain.  Every load is unconditional (clamped pixel
+  // index, substitute pointer for an absent gradient image) and the predicates are applied afterwards with selects:
+  // a branch around a load makes the compiler drain the whole memory queue at the join.
+  uint32_t last[4], deepest[4];
+  float T[4], SP[4], dp[4][8];  // SP = S - P: what the entries behind the current one still add
+  const float *const pc = r.dL_dcolor ? r.dL_dcolor : r.final_T, *const pd = r.dL_ddepth ? r.dL_ddepth : r.final_T;
+  const float *const pn = (NORMAL && r.dL_dnormal) ? r.dL_dnormal : r.final_T;
+  const float *const pa = r.dL_dalpha ? r.dL_dalpha : r.final_T;
+  const float kc = r.dL_dcolor ? 1.0f : 0.0f, kd = r.dL_ddepth ? 1.0f : 0.0f;
+  const float kn = (NORMAL && r.dL_dnormal) ? 1.0f : 0.0f, ka = r.dL_dalpha ? 1.0f : 0.0f;
+  const uint32_t HWc = r.dL_dcolor ? HW32 : 0u, HWn = (NORMAL && r.dL_dnormal) ? HW32 : 0u;
+  const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
+  const bool head = b0 == 0u;  // the chain starts at the head of the list: T = 1, nothing accumulated yet
+  const float *const ck_item = r.ckpt + ((size_t)(lo / BUCKET) + tile + b0) * (CKPT_FLOATS * TILE * TILE);
+  const uint32_t blo0 = b0 * BUCKET;
 #pragma unroll
-    for (int k = 0; k < QPW; ++k)
-      reinterpret_cast<float4 *>(&s_acc[0][0])[k * (64 * WAVES) + threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
-    // (the records are staged BEFORE the pixel state is loaded: the quadrant tests need registers, and with the four
-    // quadrants' state already live they spilled)
-    __builtin_amdgcn_sched_barrier(0);
-    // per-quadrant pixel state.  Every load is unconditional (clamped pixel index, substitute pointer for an absent
-    // gradient image) and the predicates are applied afterwards with selects: a branch around a load makes the
-    // compiler drain the whole memory queue at the join, which put ~16 dependent round trips in front of every item.
-    uint32_t last[QPW], deepest[QPW];
-    float T[QPW], SP[QPW], dp[QPW][8];  // SP = S - P: what the entries behind the current one still add
-    const float *const pc = dL_dcolor ? dL_dcolor : final_T, *const pd = dL_ddepth ? dL_ddepth : final_T;
-    const float *const pn = (NORMAL && dL_dnormal) ? dL_dnormal : final_T, *const pa = dL_dalpha ? dL_dalpha : final_T;
-    const float kc = dL_dcolor ? 1.0f : 0.0f, kd = dL_ddepth ? 1.0f : 0.0f;
-    const float kn = (NORMAL && dL_dnormal) ? 1.0f : 0.0f, ka = dL_dalpha ? 1.0f : 0.0f;
-    // 32-bit element offsets from wave-uniform base pointers (SGPR base + VGPR offset addressing: a 64-bit address
-    // pair per load is what overflowed the register file here)
-    const uint32_t HW32 = (uint32_t)HW;
-    const uint32_t HWc = dL_dcolor ? HW32 : 0u, HWn = (NORMAL && dL_dnormal) ? HW32 : 0u;
-    const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
+  for (int q = 0; q < 4; ++q) {
+    const int px = bx + (q & 1) * 8, py = by + (q >> 1) * 8;
+    const bool inside = px < W && py < H;
+    const uint32_t pix = inside ? (uint32_t)py * (uint32_t)W + (uint32_t)px : 0u;
+    const uint32_t nc = r.n_contrib[pix];
+    float fa[8];
 #pragma unroll
-    for (int q = 0; q < QPW; ++q) {
-      const int quad = wave * QPW + q;
-      const int px = bx + (quad & 1) * 8, py = by + (quad >> 1) * 8;
-      const bool inside = px < W && py < H;
-      const uint32_t pix = inside ? (uint32_t)py * (uint32_t)W + (uint32_t)px : 0u;
-      const uint32_t nc = n_contrib[pix];
-      const float *c = ck_item + (uint32_t)(quad * 64 + lane);  // the forward's thread index = quadrant * 64 + lane
-      float cv[9], fa[8];
+    for (int k = 0; k < 8; ++k) fa[k] = r.final_acc[(uint32_t)k * HW32 + pix];
+    const float fT = r.final_T[pix];
+    dp[q][0] = kc * pc[pix], dp[q][1] = kc * pc[HWc + pix], dp[q][2] = kc * pc[2u * HWc + pix];
+    dp[q][3] = kd * pd[pix];
+    dp[q][4] = kn * pn[pix], dp[q][5] = kn * pn[HWn + pix], dp[q][6] = kn * pn[2u * HWn + pix];
+    dp[q][7] = ka * pa[pix];
+    last[q] = inside ? nc : 0u;
+    const bool need = last[q] > blo0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) dp[q][k] = need ? dp[q][k] : 0.0f;
+    float S = dp[q][7] * fa[7] + fT * (bg0 * dp[q][0] + bg1 * dp[q][1] + bg2 * dp[q][2]);
+#pragma unroll
+    for (int k = 0; k < (NORMAL ? 7 : 4); ++k) S += dp[q][k] * fa[k];
+    float P = 0.0f, Tq = 1.0f;
+    if (!head) {  // wave-uniform
+      const float *c = ck_item + (uint32_t)(q * 64 + lane);  // the forward's thread index = quadrant * 64 + lane
+      float cv[9];
 #pragma unroll
       for (int k = 0; k < 9; ++k) cv[k] = c[k * TILE * TILE];
+      P = dp[q][7] * cv[8];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) fa[k] = final_acc[(uint32_t)k * HW32 + pix];
-      const float fT = final_T[pix];
-      dp[q][0] = kc * pc[pix], dp[q][1] = kc * pc[HWc + pix], dp[q][2] = kc * pc[2u * HWc + pix];
-      dp[q][3] = kd * pd[pix];
-      dp[q][4] = kn * pn[pix], dp[q][5] = kn * pn[HWn + pix], dp[q][6] = kn * pn[2u * HWn + pix];
-      dp[q][7] = ka * pa[pix];
-      last[q] = inside ? nc : 0u;
-      const bool need = last[q] > blo;
-#pragma unroll
-      for (int k = 0; k < 8; ++k) dp[q][k] = need ? dp[q][k] : 0.0f;
-      float P = dp[q][7] * cv[8];
-      float S = dp[q][7] * fa[7] + fT * (bg0 * dp[q][0] + bg1 * dp[q][1] + bg2 * dp[q][2]);
-#pragma unroll
-      for (int k = 0; k < (NORMAL ? 7 : 4); ++k) {
-        P += dp[q][k] * cv[1 + k];
-        S += dp[q][k] * fa[k];
-      }
-      T[q] = need ? cv[0] : 0.0f;
-      SP[q] = need ? S - P : 0.0f;
-      // deepest entry any pixel of this quadrant still looks at (wave-uniform)
-      uint32_t m = last[q];
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
-      deepest[q] = (uint32_t)__builtin_amdgcn_readfirstlane((int)m);
-      // one quadrant's ~27 loads in flight at a time: hoisting all four above the first use spills 48 registers
-      if (QPW == 4) __builtin_amdgcn_sched_barrier(0);
+      for (int k = 0; k < (NORMAL ? 7 : 4); ++k) P += dp[q][k] * cv[1 + k];
+      Tq = cv[0];
     }
-    uint32_t wlast = deepest[0];
+    T[q] = need ? Tq : 0.0f;
+    SP[q] = need ? S - P : 0.0f;
+    // deepest entry any pixel of this quadrant still looks at (wave-uniform)
+    uint32_t m = last[q];
 #pragma unroll
-    for (int q = 1; q < QPW; ++q) wlast = max(wlast, deepest[q]);
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
+    deepest[q] = (uint32_t)__builtin_amdgcn_readfirstlane((int)m);
+    // one quadrant's loads in flight at a time: hoisting all four above the first use spills
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  const uint32_t wlast = max(max(deepest[0], deepest[1]), max(deepest[2], deepest[3]));
 
-    __syncthreads();
-    // ascending list of the records that can reach any pixel of this wave's quadrants
-    constexpr uint32_t QBITS = ((1u << QPW) - 1u);
-    if (QPW != 4) {
-      const bool hit = lane < count && ((s_mask[lane] >> (wave * QPW)) & QBITS) != 0u;
-      const unsigned long long bal = __ballot(hit);
-      if (hit) s_list[wave][__popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)lane;
-      mine = __popcll(bal);
+  for (uint32_t bk = 0; bk < nbk; ++bk) {
+    const uint32_t blo = blo0 + bk * BUCKET;
+    if (blo >= wlast) break;  // no pixel of the tile looks this deep
+    const int count = (int)min((uint32_t)BUCKET, hi - lo - blo);
+    // ---- stage the bucket's records COMPACTED: the records some quadrant can reach, in list order, slot = rank;
+    // every lane keeps the rank / emission slot of the record it staged for the epilogue
+    float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra, rc4 = ra;
+    float rnz = 0.0f;
+    uint32_t qmask = 0, my_emit = 0;
+    if (lane < count) {
+      const uint32_t g = r.vals[lo + blo + lane];
+      const float4 *rp = reinterpret_cast<const float4 *>(r.splat + g);
+      ra = rp[0], rb = rp[1], rc4 = rp[2];
+      if (NORMAL) rnz = rp[3].x;
+      qmask = quadrant_mask(ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, tile_x, tile_y);
+      const uint2 rc = *reinterpret_cast<const uint2 *>(r.rect + 4 * (size_t)g);
+      const int x0 = rc.x & 0xffff, y0 = rc.x >> 16, x1 = rc.y & 0xffff;
+      my_emit = (g == 0 ? 0u : r.offsets[g - 1]) + (uint32_t)((tile_y - y0) * (x1 - x0) + (tile_x - x0));
     }
+    const bool my_hit = qmask != 0u;
+    const unsigned long long bal = __ballot(my_hit);
+    const int my_rank = __popcll(bal & ((1ull << lane) - 1ull));
+    const int mine = __popcll(bal);
+    __syncthreads();  // the previous bucket's epilogue has read s_acc
+    if (my_hit) {
+      s_geo[my_rank] = ra, s_col[my_rank] = rb, s_aux[my_rank] = rc4;
+      if (NORMAL) s_nz[my_rank] = rnz;
+      s_mask[my_rank] = qmask | ((uint32_t)lane << 8);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      reinterpret_cast<float4 *>(&s_acc[0][0])[k * 64 + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
 
-    // (QPW == 4) the mask word and the geometry of record t + 1 are read from LDS while record t is processed
+    // the mask word and the geometry of record t + 1 are read from LDS while record t is processed
     uint32_t m_next = 0;
     float4 g_next = make_float4(0.f, 0.f, 0.f, 0.f), c_next = g_next;
-    if (QPW == 4 && mine > 0) m_next = s_mask[0], g_next = s_geo[0], c_next = s_col[0];
+    if (mine > 0) m_next = s_mask[0], g_next = s_geo[0], c_next = s_col[0];
     for (int t = 0; t < mine; ++t) {
-      // slot of the record in the staged arrays, its position in the bucket, its quadrant bits
-      int slot, j;
-      uint32_t qm;
-      float4 g, c;
-      if (QPW == 4) {
-        const uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane((int)m_next);
-        slot = t, j = (int)(m >> 8), qm = m & 0xfu;
-        g = g_next, c = c_next;
-        const int tn = min(t + 1, mine - 1);
-        m_next = s_mask[tn], g_next = s_geo[tn], c_next = s_col[tn];
-      } else {
-        slot = j = __builtin_amdgcn_readfirstlane((int)s_list[wave][t]);
-        qm = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_mask[j]) >> (wave * QPW);
-        g = s_geo[slot], c = s_col[slot];
-      }
-      const uint32_t pos = blo + (uint32_t)j;
+      const uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane((int)m_next);
+      const uint32_t pos = blo + (m >> 8), qm = m & 0xfu;
+      const float4 g = g_next, c = c_next;
+      const int tn = min(t + 1, mine - 1);
+      m_next = s_mask[tn], g_next = s_geo[tn], c_next = s_col[tn];
       if (pos >= wlast) break;  // the list is ascending: nothing further reaches this tile
-      const float4 a = s_aux[slot];
-      const float nz = NORMAL ? s_nz[slot] : 0.0f;
-      const float dx0 = g.x - bxf - (float)(((wave * QPW) & 1) * 8), dy0 = g.y - byf - (float)(((wave * QPW) >> 1) * 8);
+      const float4 a = s_aux[t];
+      const float nz = NORMAL ? s_nz[t] : 0.0f;
+      const float dx0 = g.x - bxf, dy0 = g.y - byf;
       float v[16];
 #pragma unroll
       for (int k = 0; k < 16; ++k) v[k] = 0.0f;
       bool any = false;
 #pragma unroll
-      for (int q = 0; q < QPW; ++q) {
+      for (int q = 0; q < 4; ++q) {
         if (!((qm >> q) & 1u) || pos >= deepest[q]) continue;  // wave-uniform
-        // (QPW = 2: wave 0 owns the top quadrants 0, 1 and wave 1 the bottom ones, so q only moves along x)
-        const float dx = dx0 - (float)((q & 1) * 8), dy = dy0 - (float)((QPW == 4 ? (q >> 1) : 0) * 8);
+        any = true;
+        const float dx = dx0 - (float)((q & 1) * 8), dy = dy0 - (float)((q >> 1) * 8);
         const float power = -0.5f * (g.z * dx * dx + c.x * dy * dy) - g.w * dx * dy;
         const float G = __expf(power);
         const float alpha = fminf(ALPHA_MAX, c.y * G);
         const bool active = pos < last[q] && power <= 0.0f && alpha >= ALPHA_MIN;
-        if (__ballot(active) == 0) continue;  // wave-uniform skip
-        any = true;
-        if (active) {
-          const float w = alpha * T[q];
-          float D = dp[q][7] + c.z * dp[q][0] + c.w * dp[q][1] + a.x * dp[q][2] + a.y * dp[q][3];
-          if (NORMAL) D += a.z * dp[q][4] + a.w * dp[q][5] + nz * dp[q][6];
-          SP[q] -= D * w;
-          const float dL_dalpha_i = D * T[q] - SP[q] * __builtin_amdgcn_rcpf(1.0f - alpha);
-          T[q] *= 1.0f - alpha;
-          const float gg = G * c.y * dL_dalpha_i;  // g = G * dL/dG, dL/dG = opacity * dL/dalpha
-          const float gx = gg * dx, gy = gg * dy;
-          v[0] += gg, v[1] += gx, v[2] += gy;
-          v[3] += gx * dx, v[4] += gx * dy, v[5] += gy * dy;
-          v[6] += w * dp[q][0], v[7] += w * dp[q][1], v[8] += w * dp[q][2], v[9] += w * dp[q][3];
-          if (NORMAL) v[10] += w * dp[q][4], v[11] += w * dp[q][5], v[12] += w * dp[q][6];
-        }
+        const float ae = active ? alpha : 0.0f;
+        const float w = ae * T[q];
+        float D = dp[q][7] + c.z * dp[q][0] + c.w * dp[q][1] + a.x * dp[q][2] + a.y * dp[q][3];
+        if (NORMAL) D += a.z * dp[q][4] + a.w * dp[q][5] + nz * dp[q][6];
+        SP[q] -= D * w;
+        const float oma = 1.0f - ae;
+        const float dL_dalpha_i = D * T[q] - SP[q] * __builtin_amdgcn_rcpf(oma);
+        T[q] *= oma;
+        float gg = G * c.y * dL_dalpha_i;  // g = G * dL/dG, dL/dG = opacity * dL/dalpha
+        gg = active ? gg : 0.0f;           // (a select, not a product: G of a rejected lane may be inf)
+        const float gx = gg * dx, gy = gg * dy;
+        v[0] += gg, v[1] += gx, v[2] += gy;
+        v[3] += gx * dx, v[4] += gx * dy, v[5] += gy * dy;
+        v[6] += w * dp[q][0], v[7] += w * dp[q][1], v[8] += w * dp[q][2], v[9] += w * dp[q][3];
+        if (NORMAL) v[10] += w * dp[q][4], v[11] += w * dp[q][5], v[12] += w * dp[q][6];
       }
       if (!any) continue;
-      const float tot = butterfly16(v, lane);  // lanes 0..15: the wave total of value butterfly16_slot(lane)
-      if (lane < 16) {
-        if (QPW == 4) s_acc[slot][butterfly16_slot(lane)] = tot;  // this wave is the only writer of the record
-        else atomicAdd(&s_acc[j][butterfly16_slot(lane)], tot);
-      }
+      const float tot = wave_reduce16(v);  // lane l: the wave total of value reduce16_slot(l)
+      if ((lane & 3) == 0) s_acc[t][reduce16_slot(lane)] = tot;  // this wave is the only writer of the record
     }
     __syncthreads();
-    if (QPW == 4 ? my_hit : (wave == 0 && lane < count)) {
-      const uint32_t e = QPW == 4 ? my_emit : s_emit[lane];
-      const float4 *src = reinterpret_cast<const float4 *>(&s_acc[QPW == 4 ? my_rank : lane][0]);
+    if (my_hit) {
+      const float4 *src = reinterpret_cast<const float4 *>(&s_acc[my_rank][0]);
       const float4 r0 = src[0], r1 = src[1], r2 = src[2], r3 = src[3];
       const bool nonzero = r0.x != 0.f || r0.y != 0.f || r0.z != 0.f || r0.w != 0.f || r1.x != 0.f || r1.y != 0.f ||
                            r1.z != 0.f || r1.w != 0.f || r2.x != 0.f || r2.y != 0.f || r2.z != 0.f || r2.w != 0.f ||
                            r3.x != 0.f;
-      if (e < R_cap && nonzero) {
-        float4 *dst = reinterpret_cast<float4 *>(inst_grad + e);
+      if (my_emit < R_cap && nonzero) {
+        float4 *dst = reinterpret_cast<float4 *>(r.inst_grad + my_emit);
         dst[0] = r0, dst[1] = r1, dst[2] = r2, dst[3] = r3;
-        inst_flag[e] = 1;
+        r.inst_flag[my_emit] = 1;
       }
     }
+  }
+}
+
+// Items are taken in REVERSE queue order: the forward queues a tile's items when the tile finishes, so the long
+// lists -- the long items -- sit at the end of the queue, and the hardware's in-order workgroup dispatch over
+// blockIdx turns "longest first" into a dynamic LPT schedule without a single atomic.  Virtual item v = blockIdx.x,
+// + gridDim.x, ...: render v % n, that render's (count - 1 - v / n)-th item, so the renders of a batch interleave.
+template <bool NORMAL, class VIEW>
+__device__ __forceinline__ void blend_bwd_loop(int H, int W, int tiles_x, uint32_t R_cap, const float *__restrict__ bg,
+                                               int n, VIEW view) {
+  __shared__ float4 s_geo[BUCKET];
+  __shared__ float4 s_col[BUCKET];
+  __shared__ float4 s_aux[BUCKET];
+  __shared__ float s_nz[BUCKET];
+  __shared__ uint32_t s_mask[BUCKET];
+  __shared__ float s_acc[BUCKET][16];
+  static_assert(BUCKET == 64, "one staged record per lane");
+  uint32_t most = 0;
+  for (int i = 0; i < n; ++i) most = max(most, view(i).work[0]);
+  for (uint32_t v = blockIdx.x; v < most * (uint32_t)n; v += gridDim.x) {
+    const BwdView r = view((int)(v % (uint32_t)n));
+    const uint32_t local = v / (uint32_t)n, n_items = r.work[0];
+    if (local >= n_items) continue;
+    const uint4 it = reinterpret_cast<const uint4 *>(r.work)[1 + (n_items - 1 - local)];
+    blend_bwd_item<NORMAL>(H, W, tiles_x, R_cap, bg, r, it, s_geo, s_col, s_aux, s_nz, s_mask, s_acc);
   }
 }
 
@@ -470,24 +458,22 @@ __global__ void __launch_bounds__(BLEND_BLOCK) blend_fwd_kernel(
     const Splat *__restrict__ splat, const float *__restrict__ bg, float *__restrict__ out_color,
     float *__restrict__ out_depth, float *__restrict__ out_normal, float *__restrict__ out_alpha,
     float *__restrict__ final_T, uint32_t *__restrict__ n_contrib, float *__restrict__ final_acc,
-    float *__restrict__ ckpt, uint32_t *__restrict__ work) {
+    float *__restrict__ ckpt, uint32_t *__restrict__ work, uint32_t chain) {
   blend_fwd_body<NORMAL>(H, W, tiles_x, ranges, vals_sorted, splat, bg, out_color, out_depth, out_normal, out_alpha,
-                         final_T, n_contrib, final_acc, ckpt, work);
+                         final_T, n_contrib, final_acc, ckpt, work, chain);
 }
-template <bool NORMAL, int QPW>
-__global__ void __launch_bounds__(256 / QPW, QPW == 4 ? 3 : 4) blend_bwd_kernel(
-    int H, int W, int tiles_x, uint32_t R_cap, const uint32_t *__restrict__ ranges,
-    const uint32_t *__restrict__ vals_sorted, const Splat *__restrict__ splat, const uint16_t *__restrict__ rect,
-    const uint32_t *__restrict__ offsets, const float *__restrict__ bg, const float *__restrict__ final_T,
-    const uint32_t *__restrict__ n_contrib, const float *__restrict__ final_acc, const float *__restrict__ ckpt,
-    const uint32_t *__restrict__ work, const float *__restrict__ dL_dcolor, const float *__restrict__ dL_ddepth,
-    const float *__restrict__ dL_dnormal, const float *__restrict__ dL_dalpha, SplatGrad *__restrict__ inst_grad,
-    uint8_t *__restrict__ inst_flag) {
-  blend_bwd_body<NORMAL, QPW>(H, W, tiles_x, R_cap, ranges, vals_sorted, splat, rect, offsets, bg, final_T, n_contrib,
-                         final_acc, ckpt, work, dL_dcolor, dL_ddepth, dL_dnormal, dL_dalpha, inst_grad, inst_flag);
+struct SingleView {
+  BwdView v;
+  __device__ __forceinline__ const BwdView &operator()(int) const { return v; }
+};
+template <bool NORMAL>
+__global__ void __launch_bounds__(64, BWD_WAVES_PER_SIMD) blend_bwd_kernel(int H, int W, int tiles_x, uint32_t R_cap,
+                                                                            const float *__restrict__ bg, SingleView sv) {
+  blend_bwd_loop<NORMAL>(H, W, tiles_x, R_cap, bg, 1, sv);
 }
 
-// Batched entry points (native step executor): blockIdx.y = render of the batch.
+// Batched entry points (native step executor): blockIdx.y = render of the batch (forward); the backward interleaves
+// the renders' items over a one-dimensional grid.
 struct BlendOffsets {
   size_t splat, rect, offsets, total;           // geom
   size_t ranges, vals, ckpt, work;              // bin
@@ -497,24 +483,34 @@ struct BlendOffsets {
 template <bool NORMAL>
 __global__ void __launch_bounds__(BLEND_BLOCK) blend_fwd_batched_kernel(int H, int W, int tiles_x,
                                                                         const float *__restrict__ bg, BlendOffsets o,
-                                                                        RenderBatch b) {
+                                                                        uint32_t chain, RenderBatch b) {
   const dimo_render_desc &r = b.r[blockIdx.y];
   blend_fwd_body<NORMAL>(H, W, tiles_x, at<uint32_t>(r.bin, o.ranges), at<uint32_t>(r.bin, o.vals),
                          at<Splat>(r.geom, o.splat), bg, r.out_color, r.out_depth, NORMAL ? r.out_normal : nullptr,
                          r.out_alpha, at<float>(r.img, o.final_T), at<uint32_t>(r.img, o.n_contrib),
-                         at<float>(r.img, o.final_acc), at<float>(r.bin, o.ckpt), at<uint32_t>(r.bin, o.work));
+                         at<float>(r.img, o.final_acc), at<float>(r.bin, o.ckpt), at<uint32_t>(r.bin, o.work), chain);
 }
-template <bool NORMAL, int QPW>
-__global__ void __launch_bounds__(256 / QPW, QPW == 4 ? 3 : 4) blend_bwd_batched_kernel(int H, int W, int tiles_x, uint32_t R_cap,
-                                                                        const float *__restrict__ bg, BlendOffsets o,
-                                                                        RenderBatch b) {
-  const dimo_render_desc &r = b.r[blockIdx.y];
-  blend_bwd_body<NORMAL, QPW>(H, W, tiles_x, R_cap, at<uint32_t>(r.bin, o.ranges), at<uint32_t>(r.bin, o.vals),
-                         at<Splat>(r.geom, o.splat), at<uint16_t>(r.geom, o.rect), at<uint32_t>(r.geom, o.offsets), bg,
-                         at<float>(r.img, o.final_T), at<uint32_t>(r.img, o.n_contrib), at<float>(r.img, o.final_acc),
-                         at<float>(r.bin, o.ckpt), at<uint32_t>(r.bin, o.work), r.g_color, r.g_depth,
-                         NORMAL ? r.g_normal : nullptr, r.g_alpha, reinterpret_cast<SplatGrad *>(r.bwd_scratch),
-                         at<uint8_t>(r.bwd_scratch, o.flag));
+template <bool NORMAL>
+struct BatchView {
+  const RenderBatch &b;
+  const BlendOffsets &o;
+  __device__ __forceinline__ BwdView operator()(int i) const {
+    const dimo_render_desc &r = b.r[i];
+    return BwdView{at<uint32_t>(r.bin, o.vals),      at<Splat>(r.geom, o.splat),       at<uint16_t>(r.geom, o.rect),
+                   at<uint32_t>(r.geom, o.offsets),  at<float>(r.img, o.final_T),      at<uint32_t>(r.img, o.n_contrib),
+                   at<float>(r.img, o.final_acc),    at<float>(r.bin, o.ckpt),         at<uint32_t>(r.bin, o.work),
+                   r.g_color,                        r.g_depth,                        NORMAL ? r.g_normal : nullptr,
+                   r.g_alpha,                        reinterpret_cast<SplatGrad *>(r.bwd_scratch),
+                   at<uint8_t>(r.bwd_scratch, o.flag)};
+  }
+};
+template <bool NORMAL>
+__global__ void __launch_bounds__(64, BWD_WAVES_PER_SIMD) blend_bwd_batched_kernel(int H, int W, int tiles_x,
+                                                                                    uint32_t R_cap,
+                                                                                    const float *__restrict__ bg,
+                                                                                    BlendOffsets o, int n,
+                                                                                    RenderBatch b) {
+  blend_bwd_loop<NORMAL>(H, W, tiles_x, R_cap, bg, n, BatchView<NORMAL>{b, o});
 }
 // clears the "record written" flags of the instances a render actually has ([0, R), 16 bytes per thread)
 __global__ void __launch_bounds__(256) clear_flags_batched_kernel(uint32_t R_cap, BlendOffsets o, RenderBatch b) {
@@ -524,15 +520,17 @@ __global__ void __launch_bounds__(256) clear_flags_batched_kernel(uint32_t R_cap
   if (i < R) *reinterpret_cast<uint4 *>(at<uint8_t>(r.bwd_scratch, o.flag) + i) = make_uint4(0, 0, 0, 0);
 }
 
-// quadrants per wave of the backward for a launch over n renders (DIMO_BWD_QPW overrides, for experiments)
-static int bwd_quadrants_per_wave(int n) {
+// Buckets per backward item.  A lone render has ~2700 buckets for 4096 wave slots: one bucket per item keeps the
+// chip as full as it gets; a batch of renders supplies >= 10^4 and chains two (DIMO_BWD_CHAIN overrides, for
+// experiments; the forward and the backward of a render must use the same value, so it is fixed per process).
+static uint32_t bwd_chain(int n) {
   static const int forced = [] {
-    const char *e = getenv("DIMO_BWD_QPW");
+    const char *e = getenv("DIMO_BWD_CHAIN");
     const int v = e ? atoi(e) : 0;
-    return (v == 1 || v == 2 || v == 4) ? v : 0;
+    return (v >= 1 && v <= 64) ? v : 0;
   }();
-  if (forced) return forced;
-  return n >= 2 ? 4 : 2;
+  if (forced) return (uint32_t)forced;
+  return n >= 2 ? 2u : 1u;
 }
 
 static BlendOffsets blend_offsets(const GeomLayout &G, const BinLayout &B, const ImgLayout &I) {
@@ -551,13 +549,14 @@ int blend_forward_batched(const dimo_step_common &c, const RenderBatch &b, int n
   ImgLayout I(c.H, c.W);
   if (c.bin_bytes < B.bytes || c.img_bytes < I.bytes) return DIMO_E_WORKSPACE;
   const BlendOffsets o = blend_offsets(G, B, I);
+  const uint32_t chain = bwd_chain(n);
   ScopedTimer tm(T_BLEND_FWD, stream);
   if (c.with_normal)
     hipLaunchKernelGGL(blend_fwd_batched_kernel<true>, dim3(B.T, n), dim3(BLEND_BLOCK), 0, stream, c.H, c.W, B.tiles_x,
-                       c.bg, o, b);
+                       c.bg, o, chain, b);
   else
     hipLaunchKernelGGL(blend_fwd_batched_kernel<false>, dim3(B.T, n), dim3(BLEND_BLOCK), 0, stream, c.H, c.W,
-                       B.tiles_x, c.bg, o, b);
+                       B.tiles_x, c.bg, o, chain, b);
   return check_launch();
 }
 
@@ -572,23 +571,13 @@ int blend_backward_batched(const dimo_step_common &c, const RenderBatch &b, int 
   ScopedTimer tm(T_BLEND_BWD, stream);
   hipLaunchKernelGGL(clear_flags_batched_kernel, dim3((unsigned)((B.cap / 16 + 255) / 256 + 1), n), dim3(256), 0,
                      stream, cap, o, b);
-  // one wave per item when the batch supplies enough items to fill the chip, two waves per item for a lone render
-  const int qpw = bwd_quadrants_per_wave(n);
-  const int want = BWD_GRID * qpw / 4;
-  const int grid = (want + n - 1) / n < 2048 ? 2048 : (want + n - 1) / n;
-#define DIMO_LAUNCH_BWD_BATCHED(NORMAL, QPW)                                                                         \
-  hipLaunchKernelGGL((blend_bwd_batched_kernel<NORMAL, QPW>), dim3(grid, n), dim3(256 / QPW), 0, stream, c.H, c.W,   \
-                     B.tiles_x, cap, c.bg, o, b)
-  if (c.with_normal) {
-    if (qpw == 4) DIMO_LAUNCH_BWD_BATCHED(true, 4);
-    else if (qpw == 2) DIMO_LAUNCH_BWD_BATCHED(true, 2);
-    else DIMO_LAUNCH_BWD_BATCHED(true, 1);
-  } else {
-    if (qpw == 4) DIMO_LAUNCH_BWD_BATCHED(false, 4);
-    else if (qpw == 2) DIMO_LAUNCH_BWD_BATCHED(false, 2);
-    else DIMO_LAUNCH_BWD_BATCHED(false, 1);
-  }
-#undef DIMO_LAUNCH_BWD_BATCHED
+  // (the chain length is the one the forward of this batch used: bwd_chain(n) is a function of n only)
+  if (c.with_normal)
+    hipLaunchKernelGGL(blend_bwd_batched_kernel<true>, dim3(BWD_GRID), dim3(64), 0, stream, c.H, c.W, B.tiles_x, cap,
+                       c.bg, o, n, b);
+  else
+    hipLaunchKernelGGL(blend_bwd_batched_kernel<false>, dim3(BWD_GRID), dim3(64), 0, stream, c.H, c.W, B.tiles_x, cap,
+                       c.bg, o, n, b);
   return check_launch();
 }
 
@@ -617,12 +606,29 @@ extern "C" int dimo_raster_render_forward(int N, int H, int W, int64_t R_cap, co
     hipLaunchKernelGGL(blend_fwd_kernel<true>, dim3(B.T), dim3(BLEND_BLOCK), 0, stream, H, W, B.tiles_x, ranges, vals,
                        splat, bg, out_color, out_depth, out_normal, out_alpha, at<float>(img, I.final_T),
                        at<uint32_t>(img, I.n_contrib), at<float>(img, I.final_acc), at<float>(bin, B.ckpt),
-                       at<uint32_t>(bin, B.work));
+                       at<uint32_t>(bin, B.work), bwd_chain(1));
   else
     hipLaunchKernelGGL(blend_fwd_kernel<false>, dim3(B.T), dim3(BLEND_BLOCK), 0, stream, H, W, B.tiles_x, ranges,
                        vals, splat, bg, out_color, out_depth, out_normal, out_alpha, at<float>(img, I.final_T),
                        at<uint32_t>(img, I.n_contrib), at<float>(img, I.final_acc), at<float>(bin, B.ckpt),
-                       at<uint32_t>(bin, B.work));
+                       at<uint32_t>(bin, B.work), bwd_chain(1));
+  return check_launch();
+}
+
+// Diagnostic: the wave reduction of the backward on caller-supplied data (in: 64 lanes x 16 floats, lane-major;
+// out: 16 wave totals).  Lets a test pin the DPP / permlane sequence of wave_ops.hpp against a plain sum.
+__global__ void __launch_bounds__(64) wave_reduce16_selftest_kernel(const float *__restrict__ in, float *__restrict__ out) {
+  float v[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) v[k] = in[threadIdx.x * 16 + k];
+  const float tot = dimo::wave_reduce16(v);
+  if ((threadIdx.x & 3) == 0) out[dimo::reduce16_slot(threadIdx.x)] = tot;
+}
+extern "C" int dimo_selftest_wave_reduce16(const float *in, float *out, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  clear_errors();
+  if (!in || !out) return DIMO_E_ARG;
+  hipLaunchKernelGGL(wave_reduce16_selftest_kernel, dim3(1), dim3(64), 0, stream, in, out);
   return check_launch();
 }
 
@@ -664,24 +670,14 @@ extern "C" int dimo_raster_backward(int N, int sh_degree, int M, int H, int W, i
   if (N > 0) {
     ScopedTimer tm(T_BLEND_BWD, stream);
     if (hipMemsetAsync(inst_flag, 0, B.cap, stream) != hipSuccess) return DIMO_E_LAUNCH;
-    const int qpw = bwd_quadrants_per_wave(1);
-#define DIMO_LAUNCH_BWD(NORMAL, QPW)                                                                                 \
-  hipLaunchKernelGGL((blend_bwd_kernel<NORMAL, QPW>), dim3(BWD_GRID * QPW / 4), dim3(256 / QPW), 0, stream, H, W,    \
-                     B.tiles_x, cap, at<uint32_t>(bin, B.ranges), at<uint32_t>(bin, B.vals_b),                       \
-                     at<Splat>(geom, G.splat), at<uint16_t>(geom, G.rect), at<uint32_t>(geom, G.offsets), bg,        \
-                     at<float>(img, I.final_T), at<uint32_t>(img, I.n_contrib), at<float>(img, I.final_acc),         \
-                     at<float>(bin, B.ckpt), at<uint32_t>(bin, B.work), dL_dcolor, dL_ddepth, dL_dnormal, dL_dalpha, \
-                     inst, inst_flag)
-    if (dL_dnormal) {
-      if (qpw == 4) DIMO_LAUNCH_BWD(true, 4);
-      else if (qpw == 2) DIMO_LAUNCH_BWD(true, 2);
-      else DIMO_LAUNCH_BWD(true, 1);
-    } else {
-      if (qpw == 4) DIMO_LAUNCH_BWD(false, 4);
-      else if (qpw == 2) DIMO_LAUNCH_BWD(false, 2);
-      else DIMO_LAUNCH_BWD(false, 1);
-    }
-#undef DIMO_LAUNCH_BWD
+    SingleView sv{BwdView{at<uint32_t>(bin, B.vals_b), at<Splat>(geom, G.splat), at<uint16_t>(geom, G.rect),
+                          at<uint32_t>(geom, G.offsets), at<float>(img, I.final_T), at<uint32_t>(img, I.n_contrib),
+                          at<float>(img, I.final_acc), at<float>(bin, B.ckpt), at<uint32_t>(bin, B.work), dL_dcolor,
+                          dL_ddepth, dL_dnormal, dL_dalpha, inst, inst_flag}};
+    if (dL_dnormal)
+      hipLaunchKernelGGL(blend_bwd_kernel<true>, dim3(BWD_GRID), dim3(64), 0, stream, H, W, B.tiles_x, cap, bg, sv);
+    else
+      hipLaunchKernelGGL(blend_bwd_kernel<false>, dim3(BWD_GRID), dim3(64), 0, stream, H, W, B.tiles_x, cap, bg, sv);
     int rc = check_launch();
     if (rc) return rc;
   }

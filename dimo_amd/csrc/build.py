@@ -17,7 +17,10 @@ SOURCES = {
     "api.hip": [],
     "preprocess.hip": ["-ffp-contract=off"],
     "binning.hip": [],
-    "blend.hip": [],
+    # the SLP vectoriser turns the per-pixel maths into v_pk_*_f32 + v_mov shuffles: a packed op issues in the time of
+    # its two scalar halves on gfx950 (profiles/r02_valu_issue_rates.txt), so the packing only adds the moves
+    # (150-187 -> 116 issue cycles per quadrant visit of the backward)
+    "blend.hip": ["-fno-slp-vectorize"],
     "knn.hip": ["-ffp-contract=off"],
     "ssim.hip": [],
     "deform.hip": [],

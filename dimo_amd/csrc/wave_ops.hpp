@@ -16,54 +16,51 @@ constexpr int DPP_ROW_SHR4 = 0x114;
 constexpr int DPP_ROW_SHR8 = 0x118;
 
 
-// Wave reduction of 16 values per lane in halving steps: at step s the lanes whose bit s differs exchange the half
-// of their values the partner is going to keep, so every step costs half of the previous one
-//   lane ^ 1 (quad_perm)  16 -> 8 values per lane      lane ^ 2 (quad_perm)  8 -> 4
-//   lane ^ 4 (row_shl/shr:4 on alternating banks) 4 -> 2    lane ^ 8 (row_ror:8)  2 -> 1
-// and the last value is folded over the four 16-lane rows with gfx950's v_permlane16_swap / v_permlane32_swap.
-// Every lane ends up with the WAVE total of value  8 b0 + 4 b1 + 2 b2 + b3  (b_i = bit i of its lane number):
-// lanes 0..15 hold the 16 totals, so ONE 16-lane conflict-free LDS add stores them.  ~60 VALU instead of the
-// 16 x 6 of a plain butterfly (a first version stopped halving after two steps and finished four values per
-// lane: 76 VALU, eight permlane swaps with their s_nop padding, four LDS adds).
-constexpr int DPP_ROW_SHL4 = 0x104;
-constexpr int DPP_ROW_ROR8 = 0x128;
-__device__ __forceinline__ float dpp_xor4(float v) {
-  const int x = __builtin_bit_cast(int, v);
-  int t = __builtin_amdgcn_update_dpp(0, x, DPP_ROW_SHL4, 0xf, 0x5, false);  // banks 0, 2 read lane + 4
-  t = __builtin_amdgcn_update_dpp(t, x, DPP_ROW_SHR4, 0xf, 0xa, false);      // banks 1, 3 read lane - 4
-  return __builtin_bit_cast(float, t);
+// Wave reduction of 16 values per lane in halving steps: at every step a lane exchanges, with the lane whose number
+// differs in one bit, the half of its values the partner is going to keep, so a step costs half of the previous one.
+// Priced with the measured gfx950 issue rates (profiles/r02_valu_issue_rates.txt: v_cndmask / any DPP form 4 cycles
+// per wave64 instruction, v_add 2, v_permlane*_swap 8) the order of the bits matters:
+//   lane ^ 8   16 -> 8   v_add_f32_dpp row_ror:8, bank_mask selects the banks that keep the low / the high value:
+//   lane ^ 4    8 -> 4   (row_shl:4 / row_shr:4)    TWO masked DPP adds per output, no v_cndmask      64 + 32 cycles
+//   lane ^ 32   4 -> 2   v_permlane32_swap + v_add  (a swap moves both halves at once)                      20
+//   lane ^ 16   2 -> 1   v_permlane16_swap + v_add                                                          10
+//   lane ^ 1, lane ^ 2   plain quad_perm DPP adds on the one remaining value                                 8
+// = 134 cycles.  (Round 1 halved over the low bits first, where only quad_perm reaches and every output costs two
+// v_cndmask + a DPP add: 216 cycles.)  Lane l ends with the WAVE total of value reduce16_slot(l); the four lanes
+// l & ~3 .. l | 3 hold the same one, so the 16 lanes with (l & 3) == 0 store the 16 totals.
+// All in one asm block, in place on v[0..15]: the hazard recogniser does not look into inline asm, so the wait
+// states (VALU write -> DPP / permlane read: 2) are spelled out where fewer than two instructions separate them.
+__device__ __forceinline__ int reduce16_slot(int lane) {
+  return 8 * ((lane >> 3) & 1) + 4 * ((lane >> 2) & 1) + 2 * ((lane >> 5) & 1) + ((lane >> 4) & 1);
 }
-__device__ __forceinline__ int butterfly16_slot(int lane) {
-  return 8 * (lane & 1) + 4 * ((lane >> 1) & 1) + 2 * ((lane >> 2) & 1) + ((lane >> 3) & 1);
-}
-__device__ __forceinline__ float butterfly16(const float (&v)[16], int lane) {
-  const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
-  float h[8], q[4], p[2];
-#pragma unroll
-  for (int s = 0; s < 8; ++s) {
-    const float keep = b0 ? v[8 + s] : v[s];
-    const float send = b0 ? v[s] : v[8 + s];
-    h[s] = keep + dpp_mov<DPP_QUAD_XOR1>(send);
-  }
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const float keep = b1 ? h[4 + t] : h[t];
-    const float send = b1 ? h[t] : h[4 + t];
-    q[t] = keep + dpp_mov<DPP_QUAD_XOR2>(send);
-  }
-#pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    const float keep = b2 ? q[2 + u] : q[u];
-    const float send = b2 ? q[u] : q[2 + u];
-    p[u] = keep + dpp_xor4(send);
-  }
-  float r = (b3 ? p[1] : p[0]) + dpp_mov<DPP_ROW_ROR8>(b3 ? p[0] : p[1]);  // row total of this lane's value
-  float a = r, b = r;
-  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
-  r = a + b;  // rows (0,1) and (2,3) summed, replicated
-  a = r, b = r;
-  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
-  return a + b;  // all four rows
+__device__ __forceinline__ float wave_reduce16(float (&v)[16]) {
+#define DIMO_RA(s, h) "v_add_f32_dpp %" #s ", %" #s ", %" #s " row_ror:8 row_mask:0xf bank_mask:0x3\n\t" \
+                      "v_add_f32_dpp %" #s ", %" #h ", %" #h " row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+#define DIMO_RB(t, u) "v_add_f32_dpp %" #t ", %" #t ", %" #t " row_shl:4 row_mask:0xf bank_mask:0x5\n\t" \
+                      "v_add_f32_dpp %" #t ", %" #u ", %" #u " row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+  asm volatile(
+      "s_nop 1\n\t"
+      DIMO_RA(0, 8) DIMO_RA(1, 9) DIMO_RA(2, 10) DIMO_RA(3, 11) DIMO_RA(4, 12) DIMO_RA(5, 13) DIMO_RA(6, 14) DIMO_RA(7, 15)
+      DIMO_RB(0, 4) DIMO_RB(1, 5) DIMO_RB(2, 6) DIMO_RB(3, 7)
+      "s_nop 1\n\t"
+      "v_permlane32_swap_b32 %0, %2\n\t"
+      "v_permlane32_swap_b32 %1, %3\n\t"
+      "s_nop 1\n\t"
+      "v_add_f32 %0, %0, %2\n\t"
+      "v_add_f32 %1, %1, %3\n\t"
+      "s_nop 1\n\t"
+      "v_permlane16_swap_b32 %0, %1\n\t"
+      "s_nop 1\n\t"
+      "v_add_f32 %0, %0, %1\n\t"
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %1, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7])
+      : "v"(v[8]), "v"(v[9]), "v"(v[10]), "v"(v[11]), "v"(v[12]), "v"(v[13]), "v"(v[14]), "v"(v[15]));
+#undef DIMO_RA
+#undef DIMO_RB
+  return v[0];
 }
 
 

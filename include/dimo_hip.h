@@ -217,6 +217,10 @@ int dimo_flat_adam_step(int64_t n, float *params, float *grads, float *exp_avg, 
                         float eps, int64_t step, const int *skip_flags, int n_flags, int flag_stride, int zero_grad,
                         int *skipped_launches, void *stream);
 
+/* Diagnostic (no reference counterpart): the 64-lane x 16-value wave reduction the rasterizer backward uses
+ * (csrc/wave_ops.hpp), run on caller data.  in: 64 x 16 floats (lane-major), out: 16 floats = the column sums. */
+int dimo_selftest_wave_reduce16(const float *in, float *out, void *stream);
+
 /* ------------------------------------------------------------------ TimeNet (the deformation MLP)
  * renderer/latent_gs_renderer.py:184-245 (`TimeNet.forward` with t_apply: one time per batch entry) for a whole
  * step's batch of P (motion, frame) pairs x M control points, forward and backward as fp32 MFMA GEMM chains.

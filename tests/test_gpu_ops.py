@@ -147,3 +147,20 @@ def test_flat_adam_matches_torch_adam_and_skip_flag():
     opt.step(skip_flags=flag, zero_grad=True)
     assert torch.equal(flat, before[0]) and torch.equal(opt.exp_avg, before[1]) and torch.equal(opt.exp_avg_sq, before[2])
     assert torch.count_nonzero(grads[:total]) == 0
+
+
+def test_wave_reduce16_of_the_blend_backward():
+    """The 64-lane x 16-value halving reduction (DPP row_ror / row_shl / row_shr with bank masks, v_permlane32/16_swap,
+    quad_perm: csrc/wave_ops.hpp) against a plain float64 column sum, on values of mixed sign and magnitude."""
+    from dimo_amd import _lib
+    g = torch.Generator().manual_seed(7)
+    for trial in range(4):
+        x = torch.randn(64, 16, generator=g) * (10.0 ** torch.randint(-3, 3, (64, 16), generator=g).float())
+        if trial == 0:
+            x = torch.arange(64 * 16, dtype=torch.float32).reshape(64, 16)  # every (lane, value) distinguishable
+        xd = x.cuda().contiguous()
+        out = torch.full((16,), float("nan"), device="cuda")
+        _lib.check(_lib.lib().dimo_selftest_wave_reduce16(_lib.ptr(xd), _lib.ptr(out), _lib.current_stream()), "selftest")
+        want = x.double().sum(0)
+        got = out.cpu().double()
+        assert torch.allclose(got, want, rtol=1e-5, atol=1e-5 * float(x.abs().sum(0).max())), (trial, got, want)

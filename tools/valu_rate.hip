@@ -97,6 +97,21 @@ KERNEL(k_rfl, I_RFL)
 KERNEL(k_rowshr, I_ROWSHR)
 KERNEL(k_waveshr, I_WAVESHR)
 
+// permlane swaps: four independent register pairs, 32 swaps per iteration (operands last written 4 swaps earlier)
+#define SWAP4(OP) OP " %0, %1\n\t" OP " %2, %3\n\t" OP " %4, %5\n\t" OP " %6, %7\n\t"
+#define SWAPBODY(OP)                                                                                       \
+  asm volatile(SWAP4(OP) SWAP4(OP) SWAP4(OP) SWAP4(OP) SWAP4(OP) SWAP4(OP) SWAP4(OP) SWAP4(OP)             \
+               : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7))
+#define SWAPKERNEL(NAME, OP)                                                                   \
+  __global__ void __launch_bounds__(256) NAME(float *out, float xin, float yin) {              \
+    float a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5,   \
+          a6 = a0 + 6, a7 = a0 + 7;                                                            \
+    for (int i = 0; i < ITERS; ++i) SWAPBODY(OP);                                              \
+    out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + xin + yin;  \
+  }
+SWAPKERNEL(k_swap32, "v_permlane32_swap_b32")
+SWAPKERNEL(k_swap16, "v_permlane16_swap_b32")
+
 // packed fp32: 4 accumulator pairs
 __global__ void __launch_bounds__(256) k_pkfma(float *out, float xin, float yin) {
   typedef float f2 __attribute__((ext_vector_type(2)));
@@ -169,6 +184,8 @@ int main() {
     run("readfirstlane", k_rfl, w, out, ghz);
     run("dpp_row_shr1", k_rowshr, w, out, ghz);
     run("dpp_wave_shr1", k_waveshr, w, out, ghz);
+    run("permlane32_swap", k_swap32, w, out, ghz);
+    run("permlane16_swap", k_swap16, w, out, ghz);
   }
   return 0;
 }
