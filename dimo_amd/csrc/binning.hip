@@ -469,13 +469,13 @@ __device__ __forceinline__ void level2_scan_body(BinGrid gi, const uint32_t *__r
 }
 
 // one workgroup: tile starts = exclusive scan of the tile totals (left in totals[]), tile ranges clamped to the
-// instance capacity, overflow flag, and the backward's work counter cleared for the blend forward behind it
+// instance capacity, overflow flag, and the backward's three work counters cleared for the blend forward behind it
 __device__ __forceinline__ void tile_starts_body(int T, uint32_t R_cap, uint32_t *__restrict__ totals,
                                                  uint32_t *__restrict__ ranges, uint32_t *__restrict__ total,
                                                  uint32_t *__restrict__ work_count) {
   __shared__ uint32_t wave_tot[16];
   __shared__ uint32_t carry_s;
-  if (threadIdx.x == 0) carry_s = 0, *work_count = 0;
+  if (threadIdx.x == 0) carry_s = 0, work_count[0] = 0, work_count[1] = 0, work_count[2] = 0;
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int base = 0; base < T; base += 1024) {

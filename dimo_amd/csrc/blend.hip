@@ -213,13 +213,21 @@ __device__ __forceinline__ void blend_fwd_body(
     const uint32_t deepest = max(max(s_last[0], s_last[1]), max(s_last[2], s_last[3]));
     const uint32_t nb = (deepest + BUCKET - 1) / BUCKET;
     if (nb) {
+      // Three queues by the chain's position in its list -- head, second, deeper: [1, 1 + T), [1 + T, 1 + 2 T),
+      // [1 + 2 T, ...) of the uint4 array, counts in work[0..2].  The head chains see every pixel of the tile and are
+      // the expensive ones; the backward takes all heads first, the sparse deep chains fill the tail of the launch.
+      // Item = (tile << 12 | first bucket, list start, list end, buckets in the chain): it carries its tile's list
+      // range, one dependent load less in front of every backward item.
       const uint32_t ni = (nb + chain - 1) / chain;
-      const uint32_t base = atomicAdd(work, ni);
-      // (tile << 12 | first bucket, list start, list end, buckets in the chain): the item carries its tile's list
-      // range, one dependent load less in front of every backward item
-      for (uint32_t i = 0; i < ni; ++i)
-        reinterpret_cast<uint4 *>(work)[1 + base + i] =
-            make_uint4(((uint32_t)tile << 12) | (i * chain), lo, hi, min(chain, nb - i * chain));
+      const uint32_t T = gridDim.x;
+      uint4 *const q = reinterpret_cast<uint4 *>(work) + 1;
+      q[atomicAdd(work, 1u)] = make_uint4(((uint32_t)tile << 12), lo, hi, min(chain, nb));
+      if (ni > 1) q[T + atomicAdd(work + 1, 1u)] = make_uint4(((uint32_t)tile << 12) | chain, lo, hi, min(chain, nb - chain));
+      if (ni > 2) {
+        const uint32_t base = atomicAdd(work + 2, ni - 2);
+        for (uint32_t i = 2; i < ni; ++i)
+          q[2 * T + base + (i - 2)] = make_uint4(((uint32_t)tile << 12) | (i * chain), lo, hi, min(chain, nb - i * chain));
+      }
     }
   }
 }
@@ -242,6 +250,14 @@ __device__ __forceinline__ void blend_fwd_body(
 // The per-pixel evaluation is predicated (selects on alpha and on g), not branched: with half of a quadrant's lanes
 // inactive a branch saves no issue slot, and every `if` on a vector condition costs a VALU -> SALU round trip.
 // Instruction classes are chosen by their measured issue cost (profiles/r02_valu_issue_rates.txt).
+// Optional per-item trace of the backward (diagnostics; compiled in with -DDIMO_BWD_TRACE -- build.py does that when
+// the environment has DIMO_BWD_TRACE=1 -- and then off unless dimo_debug_blend_trace set a buffer): 4 x u64 per
+// item -- s_memrealtime (the chip-wide 100 MHz clock) at its start and end, (XCC id << 56 | render << 48 | item code), (records visited << 48 | quadrant visits <<
+// 32 | HW_ID) -- appended with one atomic per item.
+__device__ unsigned long long *g_bwd_trace = nullptr;
+__device__ unsigned int g_bwd_trace_cap = 0;
+__device__ unsigned int g_bwd_trace_n = 0;
+
 struct BwdView {  // one render's buffers as the backward sees them
   const uint32_t *vals;
   const Splat *splat;
@@ -260,8 +276,15 @@ struct BwdView {  // one render's buffers as the backward sees them
 template <bool NORMAL>
 __device__ __forceinline__ void blend_bwd_item(int H, int W, int tiles_x, uint32_t R_cap, const float *__restrict__ bg,
                                                const BwdView &r, uint4 it, float4 *s_geo, float4 *s_col, float4 *s_aux,
-                                               float *s_nz, uint32_t *s_mask, float (*s_acc)[16]) {
+                                               float *s_nz, uint32_t *s_mask, float (*s_acc)[16], int render) {
   const int lane = threadIdx.x;
+#ifdef DIMO_BWD_TRACE
+  unsigned long long *const trace = g_bwd_trace;
+#else
+  unsigned long long *const trace = nullptr;  // (everything below that depends on it folds away)
+#endif
+  const unsigned long long t_start = trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
+  uint32_t n_rec = 0, n_quad = 0;
   const uint32_t HW32 = (uint32_t)H * (uint32_t)W;
   const uint32_t code = it.x, lo = it.y, hi = it.z;
   const int tile = (int)(code >> 12);
@@ -363,19 +386,23 @@ __device__ __forceinline__ void blend_bwd_item(int H, int W, int tiles_x, uint32
       reinterpret_cast<float4 *>(&s_acc[0][0])[k * 64 + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
 
-    // the mask word and the geometry of record t + 1 are read from LDS while record t is processed
+    // record t + 1 (mask word and all 13 floats) is read from LDS while record t is processed
     uint32_t m_next = 0;
-    float4 g_next = make_float4(0.f, 0.f, 0.f, 0.f), c_next = g_next;
-    if (mine > 0) m_next = s_mask[0], g_next = s_geo[0], c_next = s_col[0];
+    float4 g_next = make_float4(0.f, 0.f, 0.f, 0.f), c_next = g_next, a_next = g_next;
+    float nz_next = 0.0f;
+    if (mine > 0) {
+      m_next = s_mask[0], g_next = s_geo[0], c_next = s_col[0], a_next = s_aux[0];
+      if (NORMAL) nz_next = s_nz[0];
+    }
     for (int t = 0; t < mine; ++t) {
       const uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane((int)m_next);
       const uint32_t pos = blo + (m >> 8), qm = m & 0xfu;
-      const float4 g = g_next, c = c_next;
+      const float4 g = g_next, c = c_next, a = a_next;
+      const float nz = nz_next;
       const int tn = min(t + 1, mine - 1);
-      m_next = s_mask[tn], g_next = s_geo[tn], c_next = s_col[tn];
+      m_next = s_mask[tn], g_next = s_geo[tn], c_next = s_col[tn], a_next = s_aux[tn];
+      if (NORMAL) nz_next = s_nz[tn];
       if (pos >= wlast) break;  // the list is ascending: nothing further reaches this tile
-      const float4 a = s_aux[t];
-      const float nz = NORMAL ? s_nz[t] : 0.0f;
       const float dx0 = g.x - bxf, dy0 = g.y - byf;
       float v[16];
 #pragma unroll
@@ -385,6 +412,7 @@ __device__ __forceinline__ void blend_bwd_item(int H, int W, int tiles_x, uint32
       for (int q = 0; q < 4; ++q) {
         if (!((qm >> q) & 1u) || pos >= deepest[q]) continue;  // wave-uniform
         any = true;
+        ++n_quad;
         const float dx = dx0 - (float)((q & 1) * 8), dy = dy0 - (float)((q >> 1) * 8);
         const float power = -0.5f * (g.z * dx * dx + c.x * dy * dy) - g.w * dx * dy;
         const float G = __expf(power);
@@ -407,6 +435,7 @@ __device__ __forceinline__ void blend_bwd_item(int H, int W, int tiles_x, uint32
         if (NORMAL) v[10] += w * dp[q][4], v[11] += w * dp[q][5], v[12] += w * dp[q][6];
       }
       if (!any) continue;
+      ++n_rec;
       const float tot = wave_reduce16(v);  // lane l: the wave total of value reduce16_slot(l)
       if ((lane & 3) == 0) s_acc[t][reduce16_slot(lane)] = tot;  // this wave is the only writer of the record
     }
@@ -424,12 +453,26 @@ __device__ __forceinline__ void blend_bwd_item(int H, int W, int tiles_x, uint32
       }
     }
   }
+  if (trace && lane == 0) {
+    const unsigned int at_ = atomicAdd(&g_bwd_trace_n, 1u);
+    if (at_ < g_bwd_trace_cap) {
+      unsigned int hw, xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      unsigned long long *t = trace + 4ull * at_;
+      t[0] = t_start, t[1] = __builtin_amdgcn_s_memrealtime();
+      t[2] = ((unsigned long long)(xcc & 0xfu) << 56) | ((unsigned long long)render << 48) | code;
+      t[3] = ((unsigned long long)n_rec << 48) | ((unsigned long long)n_quad << 32) | hw;
+    }
+  }
 }
 
-// Items are taken in REVERSE queue order: the forward queues a tile's items when the tile finishes, so the long
-// lists -- the long items -- sit at the end of the queue, and the hardware's in-order workgroup dispatch over
-// blockIdx turns "longest first" into a dynamic LPT schedule without a single atomic.  Virtual item v = blockIdx.x,
-// + gridDim.x, ...: render v % n, that render's (count - 1 - v / n)-th item, so the renders of a batch interleave.
+// Items are taken class by class from the BACK -- the deep chains, then the second ones, then the heads (see the
+// forward's queues) -- in the hardware's in-order workgroup dispatch over blockIdx: no atomics.  Measured on the C3
+// batch: deep-first 196-203 us per launch, heads-first 200-223 us (the sparse deep items are latency bound and mix
+// well with the VALU-bound heads when they start together; started last they leave the chip half idle).  Virtual
+// item v = blockIdx.x, + gridDim.x, ...: render v % n, that render's (v / n)-th item from the back, so the renders of
+// a batch interleave.
 template <bool NORMAL, class VIEW>
 __device__ __forceinline__ void blend_bwd_loop(int H, int W, int tiles_x, uint32_t R_cap, const float *__restrict__ bg,
                                                int n, VIEW view) {
@@ -440,14 +483,21 @@ __device__ __forceinline__ void blend_bwd_loop(int H, int W, int tiles_x, uint32
   __shared__ uint32_t s_mask[BUCKET];
   __shared__ float s_acc[BUCKET][16];
   static_assert(BUCKET == 64, "one staged record per lane");
+  const uint32_t T = (uint32_t)tiles_x * (uint32_t)((H + TILE - 1) / TILE);
   uint32_t most = 0;
-  for (int i = 0; i < n; ++i) most = max(most, view(i).work[0]);
+  for (int i = 0; i < n; ++i) {
+    const uint32_t *w = view(i).work;
+    most = max(most, w[0] + w[1] + w[2]);
+  }
   for (uint32_t v = blockIdx.x; v < most * (uint32_t)n; v += gridDim.x) {
     const BwdView r = view((int)(v % (uint32_t)n));
-    const uint32_t local = v / (uint32_t)n, n_items = r.work[0];
-    if (local >= n_items) continue;
-    const uint4 it = reinterpret_cast<const uint4 *>(r.work)[1 + (n_items - 1 - local)];
-    blend_bwd_item<NORMAL>(H, W, tiles_x, R_cap, bg, r, it, s_geo, s_col, s_aux, s_nz, s_mask, s_acc);
+    const uint32_t local = v / (uint32_t)n, c0 = r.work[0], c1 = r.work[1], c2 = r.work[2];
+    if (local >= c0 + c1 + c2) continue;
+    const uint32_t l2 = c0 + c1 + c2 - 1 - local;
+    const uint32_t slot = l2 < c0 ? l2 : (l2 < c0 + c1 ? T + (l2 - c0) : 2u * T + (l2 - c0 - c1));
+    const uint4 it = reinterpret_cast<const uint4 *>(r.work)[1 + slot];
+    blend_bwd_item<NORMAL>(H, W, tiles_x, R_cap, bg, r, it, s_geo, s_col, s_aux, s_nz, s_mask, s_acc,
+                           (int)(v % (uint32_t)n));
   }
 }
 
@@ -520,9 +570,11 @@ __global__ void __launch_bounds__(256) clear_flags_batched_kernel(uint32_t R_cap
   if (i < R) *reinterpret_cast<uint4 *>(at<uint8_t>(r.bwd_scratch, o.flag) + i) = make_uint4(0, 0, 0, 0);
 }
 
-// Buckets per backward item.  A lone render has ~2700 buckets for 4096 wave slots: one bucket per item keeps the
-// chip as full as it gets; a batch of renders supplies >= 10^4 and chains two (DIMO_BWD_CHAIN overrides, for
-// experiments; the forward and the backward of a render must use the same value, so it is fixed per process).
+// Buckets per backward item.  Measured on the C3 batch (4 renders, ~10^4 buckets for 4096 wave slots): 189 / 231 /
+// 245 / 273 us per launch at 1 / 2 / 3 / 4 buckets per item -- what a longer chain saves in state loads it loses
+// several times over in the tail of the launch (fewer, longer items), so the default is one bucket per item and the
+// head bucket (no checkpoint to read) is where the traffic saving comes from.  DIMO_BWD_CHAIN overrides, for
+// experiments; the forward and the backward of a render must use the same value, so it is fixed per process.
 static uint32_t bwd_chain(int n) {
   static const int forced = [] {
     const char *e = getenv("DIMO_BWD_CHAIN");
@@ -530,7 +582,8 @@ static uint32_t bwd_chain(int n) {
     return (v >= 1 && v <= 64) ? v : 0;
   }();
   if (forced) return (uint32_t)forced;
-  return n >= 2 ? 2u : 1u;
+  (void)n;
+  return 1u;
 }
 
 static BlendOffsets blend_offsets(const GeomLayout &G, const BinLayout &B, const ImgLayout &I) {
@@ -613,6 +666,23 @@ extern "C" int dimo_raster_render_forward(int N, int H, int W, int64_t R_cap, co
                        at<uint32_t>(img, I.n_contrib), at<float>(img, I.final_acc), at<float>(bin, B.ckpt),
                        at<uint32_t>(bin, B.work), bwd_chain(1));
   return check_launch();
+}
+
+// Diagnostic: per-item trace of the blend backward (see g_bwd_trace).  buffer = device memory for `capacity` records
+// of 4 x u64, or null to switch the trace off; returns the number of records written since the last call.
+extern "C" int64_t dimo_debug_blend_trace(void *buffer, int64_t capacity) {
+#ifndef DIMO_BWD_TRACE
+  if (buffer) return DIMO_E_ARG;  // not compiled in
+#endif
+  unsigned int n = 0, zero = 0, cap = (unsigned int)(capacity > 0 ? capacity : 0);
+  unsigned long long *p = reinterpret_cast<unsigned long long *>(buffer);
+  if (hipDeviceSynchronize() != hipSuccess) return DIMO_E_LAUNCH;
+  if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_bwd_trace_n), sizeof(n)) != hipSuccess) return DIMO_E_LAUNCH;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_bwd_trace_n), &zero, sizeof(zero)) != hipSuccess ||
+      hipMemcpyToSymbol(HIP_SYMBOL(g_bwd_trace_cap), &cap, sizeof(cap)) != hipSuccess ||
+      hipMemcpyToSymbol(HIP_SYMBOL(g_bwd_trace), &p, sizeof(p)) != hipSuccess)
+    return DIMO_E_LAUNCH;
+  return (int64_t)n;
 }
 
 // Diagnostic: the wave reduction of the backward on caller-supplied data (in: 64 lanes x 16 floats, lane-major;

@@ -30,6 +30,8 @@ SOURCES = {
     "fps.hip": ["-ffp-contract=off"],
     "executor.hip": [],
 }
+if os.environ.get("DIMO_BWD_TRACE") == "1":  # per-item trace of the blend backward (tools/bwd_trace.py)
+    SOURCES["blend.hip"] = SOURCES["blend.hip"] + ["-DDIMO_BWD_TRACE"]
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
 
 

@@ -109,8 +109,9 @@ struct BinLayout {
     // then one word (tile << 12 | bucket) per bucket some pixel of the tile reaches
     ckpt_slots = cap / BUCKET + (size_t)T + 2;
     ckpt = o, o = align_up(o + ckpt_slots * CKPT_FLOATS * TILE * TILE * sizeof(float));
-    // [0] = item count, [1] unused, then (tile << 12 | bucket, list start, list end, -) per item
-    work = o, o = align_up(o + (4 * ckpt_slots + 4) * sizeof(uint32_t));
+    // [0..2] = item counts of the three queues (head / second / deeper chains), then 16-byte items: heads at
+    // [1, 1 + T), seconds at [1 + T, 1 + 2 T), the rest behind (blend.hip)
+    work = o, o = align_up(o + (4 * (ckpt_slots + 2 * (size_t)T) + 8) * sizeof(uint32_t));
     bytes = o;
   }
 };

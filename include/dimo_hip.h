@@ -220,6 +220,11 @@ int dimo_flat_adam_step(int64_t n, float *params, float *grads, float *exp_avg, 
 /* Diagnostic (no reference counterpart): the 64-lane x 16-value wave reduction the rasterizer backward uses
  * (csrc/wave_ops.hpp), run on caller data.  in: 64 x 16 floats (lane-major), out: 16 floats = the column sums. */
 int dimo_selftest_wave_reduce16(const float *in, float *out, void *stream);
+/* Diagnostic: per-work-item trace of the blend backward.  buffer: device memory for `capacity` records of 4 x uint64
+ * (s_memrealtime = 100 MHz ticks at start, at end, XCC << 56 | render << 48 | item code, records << 48 | quadrant visits << 32 | HW_ID), or NULL to
+ * switch it off.  Synchronises the device; returns the number of records written since the previous call, or
+ * DIMO_E_ARG when the library was built without -DDIMO_BWD_TRACE (the default). */
+int64_t dimo_debug_blend_trace(void *buffer, int64_t capacity);
 
 /* ------------------------------------------------------------------ TimeNet (the deformation MLP)
  * renderer/latent_gs_renderer.py:184-245 (`TimeNet.forward` with t_apply: one time per batch entry) for a whole
