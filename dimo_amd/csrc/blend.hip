@@ -105,7 +105,6 @@ __device__ __forceinline__ void blend_fwd_body(
   __shared__ float4 s_aux[BATCH];   // b depth nx ny
   __shared__ float s_nz[BATCH];
   __shared__ uint32_t s_mask[BATCH];
-  __shared__ uint16_t s_list[BLEND_BLOCK / 64][BATCH];
 
   const int tile = blockIdx.x;
   const int tile_x = tile % tiles_x, tile_y = tile / tiles_x;
@@ -123,10 +122,33 @@ __device__ __forceinline__ void blend_fwd_body(
   // checkpoint slots of this tile: (lo / BUCKET + tile) + bucket -- strictly increasing with the tile index and
   // never overlapping (ceil(len / BUCKET) <= floor((lo + len) / BUCKET) - floor(lo / BUCKET) + 1)
   float *const ck_base = ckpt + ((size_t)(lo / BUCKET) + tile) * (CKPT_FLOATS * TILE * TILE) + threadIdx.x;
-  uint32_t next_ck = 0;  // first bucket whose start state this wave has not stored yet (wave-uniform)
+
+  // One visit: the rejection tests of the published loop as ONE predicate and selects (per-lane `continue`s cost as
+  // many scalar instructions -- exec save / restore, branches -- as there were vector ones).  `done` needs no test of
+  // its own: a finished pixel has Tw = 0, so its products vanish and test_T < T_STOP keeps it from being added.
+  float Tw = done ? 0.0f : 1.0f;  // working transmittance: T while the pixel is alive, 0 once it has stopped
+#define DIMO_VISIT(G, C, A, NZ, POS)                                                              \
+  {                                                                                               \
+    const float dx = G.x - pxf, dy = G.y - pyf;                                                   \
+    const float power = -0.5f * (G.z * dx * dx + C.x * dy * dy) - G.w * dx * dy;                  \
+    const float alpha = fminf(ALPHA_MAX, C.y * __expf(power));                                    \
+    const float test_T = Tw * (1.0f - alpha);                                                     \
+    const bool hit = power <= 0.0f && alpha >= ALPHA_MIN;                                         \
+    const bool add = hit && !(test_T < T_STOP);                                                   \
+    const float w = add ? alpha * Tw : 0.0f;                                                      \
+    acc[0] += C.z * w, acc[1] += C.w * w, acc[2] += A.x * w, acc[3] += A.y * w;                   \
+    if (NORMAL) acc[4] += A.z * w, acc[5] += A.w * w, acc[6] += NZ * w;                           \
+    wsum += w;                                                                                    \
+    T = add ? test_T : T;                                                                         \
+    last = add ? (POS) + 1u : last;                                                               \
+    Tw = hit ? (add ? test_T : 0.0f) : Tw;                                                        \
+  }
+#define DIMO_LOAD(G, C, A, NZ, J) \
+  G = s_geo[J], C = s_col[J], A = s_aux[J]; \
+  if (NORMAL) NZ = s_nz[J];
 
   for (uint32_t start = lo; start < hi; start += BATCH) {
-    if (__syncthreads_count(done) == BLEND_BLOCK) break;
+    if (__syncthreads_count(Tw == 0.0f) == BLEND_BLOCK) break;
     const uint32_t idx = start + threadIdx.x;
     if (idx < hi) {
       const float4 *rp = reinterpret_cast<const float4 *>(splat + vals_sorted[idx]);
@@ -139,52 +161,58 @@ __device__ __forceinline__ void blend_fwd_body(
     }
     __syncthreads();
     const int count = (int)min((uint32_t)BATCH, hi - start);
-    const int mine = compact_for_wave(s_mask, s_list[wave], count, wave, lane);
-    // Software pipeline over the wave's list: the index of visit t+2 and the record of visit t+1 are in flight
-    // from LDS while visit t computes (index -> readfirstlane -> record is a dependent two-hop chain otherwise
-    // paid in full on every visit of this sequential loop).
-    int raw_next = (int)s_list[wave][mine > 1 ? 1 : 0];
-    int jn = mine > 0 ? __builtin_amdgcn_readfirstlane((int)s_list[wave][0]) : 0;
-    float4 gn = s_geo[jn], cn = s_col[jn], an = s_aux[jn];
-    float nzn = NORMAL ? s_nz[jn] : 0.0f;
-    for (int t = 0; t < mine; ++t) {
-      if (__ballot(!done) == 0) break;  // whole wave finished
-      const int j = jn;
-      const float4 g = gn, c = cn, a = an;
-      const float nz = nzn;
-      jn = __builtin_amdgcn_readfirstlane(raw_next);
-      raw_next = (int)s_list[wave][min(t + 2, mine - 1)];
-      gn = s_geo[jn], cn = s_col[jn], an = s_aux[jn];
-      if (NORMAL) nzn = s_nz[jn];
+    // The batch is walked in four chunks of 64 records = the backward's buckets.  The records of a chunk that can
+    // reach this wave's quadrant are the set bits of ONE ballot; the visit loop pulls them off with scalar bit
+    // operations (round 1 compacted an index list through LDS and chased it with readfirstlane: two dependent LDS
+    // round trips in front of every visit).  Two register sets alternate, the record of the next visit is in flight
+    // from LDS while the current one computes.
+#pragma unroll 1
+    for (int ch = 0; ch < BATCH / 64; ++ch) {
+      const int jb = ch * 64;
+      if (jb >= count) break;
+      if (__builtin_amdgcn_ballot_w64(Tw != 0.0f) == 0ull) break;  // every pixel of the quadrant has stopped
       // the state at the first entry of every bucket that STARTS A CHAIN of the backward (every `chain`-th bucket;
       // not bucket 0, whose state is T = 1 and empty sums)
-      for (const uint32_t eb = ((start - lo) + (uint32_t)j) / BUCKET; next_ck <= eb; ++next_ck) {
-        if (next_ck == 0u || next_ck % chain != 0u) continue;
-        float *ck = ck_base + (size_t)next_ck * (CKPT_FLOATS * TILE * TILE);
+      const uint32_t bucket = (start - lo) / BUCKET + (uint32_t)ch;
+      if (bucket != 0u && bucket % chain == 0u) {
+        float *ck = ck_base + (size_t)bucket * (CKPT_FLOATS * TILE * TILE);
         ck[0] = T;
 #pragma unroll
         for (int k = 0; k < NFEAT; ++k) ck[(1 + k) * TILE * TILE] = acc[k];
         ck[8 * TILE * TILE] = wsum;
       }
-      // Predicated visit: the rejection tests of the published loop are one predicate, one wave-level skip and
-      // selects.  Per-lane `continue`s cost as many scalar instructions (exec save / restore, branches) as there
-      // were vector ones; in the batched launches, which are issue bound, this form is 6 % faster.
-      const float dx = g.x - pxf, dy = g.y - pyf;
-      const float power = -0.5f * (g.z * dx * dx + c.x * dy * dy) - g.w * dx * dy;
-      const float alpha = fminf(ALPHA_MAX, c.y * __expf(power));
-      const float test_T = T * (1.0f - alpha);
-      const bool hit = !done && power <= 0.0f && alpha >= ALPHA_MIN;
-      if (__ballot(hit) == 0) continue;
-      const bool add = hit && !(test_T < T_STOP);
-      done = done || (hit && !add);
-      const float w = add ? alpha * T : 0.0f;
-      acc[0] += c.z * w, acc[1] += c.w * w, acc[2] += a.x * w, acc[3] += a.y * w;
-      if (NORMAL) acc[4] += a.z * w, acc[5] += a.w * w, acc[6] += nz * w;
-      wsum += w;
-      T = add ? test_T : T;
-      last = add ? (start - lo) + (uint32_t)j + 1u : last;
+      const int j_lane = jb + lane;
+      unsigned long long bits = __builtin_amdgcn_ballot_w64(j_lane < count && ((s_mask[j_lane] >> wave) & 1u));
+      if (bits == 0ull) continue;
+      const uint32_t pos0 = (start - lo) + (uint32_t)jb;
+      float4 g0, c0, a0, g1, c1, a1;
+      float nz0 = 0.0f, nz1 = 0.0f;
+      int j0 = __builtin_ctzll(bits), j1 = 0;
+      bits &= bits - 1ull;
+      DIMO_LOAD(g0, c0, a0, nz0, jb + j0)
+      while (true) {
+        const bool more1 = bits != 0ull;
+        if (more1) {
+          j1 = __builtin_ctzll(bits);
+          bits &= bits - 1ull;
+          DIMO_LOAD(g1, c1, a1, nz1, jb + j1)
+        }
+        DIMO_VISIT(g0, c0, a0, nz0, pos0 + (uint32_t)j0)
+        if (!more1) break;
+        const bool more0 = bits != 0ull;
+        if (more0) {
+          j0 = __builtin_ctzll(bits);
+          bits &= bits - 1ull;
+          DIMO_LOAD(g0, c0, a0, nz0, jb + j0)
+        }
+        DIMO_VISIT(g1, c1, a1, nz1, pos0 + (uint32_t)j1)
+        if (!more0) break;
+        if (__builtin_amdgcn_ballot_w64(Tw != 0.0f) == 0ull) break;  // checked once per two visits
+      }
     }
   }
+#undef DIMO_VISIT
+#undef DIMO_LOAD
   if (inside) {
     const size_t HW = (size_t)H * W, pix = (size_t)py * W + px;
     final_T[pix] = T;

@@ -4,6 +4,6 @@ rm -rf /tmp/kp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/k
 python - <<'EOF'
 import csv, glob
 f = glob.glob("/tmp/kp/**/*kernel_stats.csv", recursive=True)[0]
-for r in list(csv.DictReader(open(f)))[:16]:
+for r in list(csv.DictReader(open(f)))[:24]:
     print(r["Name"][:64].ljust(66), r["Calls"].rjust(5), "%9.1f us" % (float(r["AverageNs"]) / 1e3))
 EOF
