@@ -414,59 +414,72 @@ __device__ __forceinline__ void blend_bwd_item(int H, int W, int tiles_x, uint32
       reinterpret_cast<float4 *>(&s_acc[0][0])[k * 64 + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
 
-    // record t + 1 (mask word and all 13 floats) is read from LDS while record t is processed
-    uint32_t m_next = 0;
-    float4 g_next = make_float4(0.f, 0.f, 0.f, 0.f), c_next = g_next, a_next = g_next;
-    float nz_next = 0.0f;
-    if (mine > 0) {
-      m_next = s_mask[0], g_next = s_geo[0], c_next = s_col[0], a_next = s_aux[0];
-      if (NORMAL) nz_next = s_nz[0];
+    // Two register sets alternate (the loop is unrolled by two): the record of visit t + 1 -- mask word and all 13
+    // floats -- is read from LDS into the idle set while visit t computes from the other, with no copies at the
+    // back edge (a rotating single set cost 12 v_mov per record).
+#define DIMO_BWD_LOAD(M, G, C, A, NZ, TT)                      \
+  {                                                            \
+    const int tt_ = min((TT), mine - 1);                       \
+    M = s_mask[tt_], G = s_geo[tt_], C = s_col[tt_], A = s_aux[tt_]; \
+    if (NORMAL) NZ = s_nz[tt_];                                \
+  }
+#define DIMO_BWD_RECORD(M, G, C, A, NZ, TT)                                                                        \
+  {                                                                                                                \
+    const uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane((int)M);                                           \
+    const uint32_t pos = blo + (m >> 8), qm = m & 0xfu;                                                            \
+    const float dx0 = G.x - bxf, dy0 = G.y - byf;                                                                  \
+    float v[16];                                                                                                   \
+    _Pragma("unroll") for (int k = 0; k < 16; ++k) {                                                               \
+      v[k] = 0.0f;                                                                                                 \
+      if (k < (NORMAL ? 13 : 10)) asm volatile("" : "+v"(v[k])); /* every quadrant accumulates the same way */      \
+    }                                                                                                              \
+    bool any = false;                                                                                              \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                                \
+      if (!((qm >> q) & 1u) || pos >= deepest[q]) continue; /* wave-uniform */                                      \
+      any = true;                                                                                                  \
+      ++n_quad;                                                                                                    \
+      const float dx = dx0 - (float)((q & 1) * 8), dy = dy0 - (float)((q >> 1) * 8);                               \
+      const float power = -0.5f * (G.z * dx * dx + C.x * dy * dy) - G.w * dx * dy;                                 \
+      const float Gs = __expf(power);                                                                              \
+      const float alpha = fminf(ALPHA_MAX, C.y * Gs);                                                              \
+      const bool active = pos < last[q] && power <= 0.0f && alpha >= ALPHA_MIN;                                    \
+      const float ae = active ? alpha : 0.0f;                                                                      \
+      const float w = ae * T[q];                                                                                   \
+      float D = dp[q][7] + C.z * dp[q][0] + C.w * dp[q][1] + A.x * dp[q][2] + A.y * dp[q][3];                      \
+      if (NORMAL) D += A.z * dp[q][4] + A.w * dp[q][5] + NZ * dp[q][6];                                            \
+      SP[q] -= D * w;                                                                                              \
+      const float oma = 1.0f - ae;                                                                                 \
+      const float dL_dalpha_i = D * T[q] - SP[q] * __builtin_amdgcn_rcpf(oma);                                     \
+      T[q] *= oma;                                                                                                 \
+      float gg = Gs * C.y * dL_dalpha_i; /* g = G * dL/dG, dL/dG = opacity * dL/dalpha */                           \
+      gg = active ? gg : 0.0f;           /* (a select, not a product: G of a rejected lane may be inf) */            \
+      const float gx = gg * dx, gy = gg * dy;                                                                      \
+      v[0] += gg, v[1] += gx, v[2] += gy;                                                                          \
+      v[3] += gx * dx, v[4] += gx * dy, v[5] += gy * dy;                                                           \
+      v[6] += w * dp[q][0], v[7] += w * dp[q][1], v[8] += w * dp[q][2], v[9] += w * dp[q][3];                      \
+      if (NORMAL) v[10] += w * dp[q][4], v[11] += w * dp[q][5], v[12] += w * dp[q][6];                             \
+    }                                                                                                              \
+    if (any) {                                                                                                     \
+      ++n_rec;                                                                                                     \
+      const float tot = wave_reduce16(v); /* lane l: the wave total of value reduce16_slot(l) */                    \
+      if ((lane & 3) == 0) s_acc[(TT)][reduce16_slot(lane)] = tot; /* this wave is the only writer of the record */ \
+    } else if (pos >= wlast) {                                                                                     \
+      break; /* the list is ascending: nothing further reaches this tile */                                         \
+    }                                                                                                              \
+  }
+    uint32_t m0 = 0, m1 = 0;
+    float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), c0 = g0, a0 = g0, g1 = g0, c1 = g0, a1 = g0;
+    float nz0 = 0.0f, nz1 = 0.0f;
+    if (mine > 0) DIMO_BWD_LOAD(m0, g0, c0, a0, nz0, 0)
+    for (int t = 0; t < mine; t += 2) {
+      DIMO_BWD_LOAD(m1, g1, c1, a1, nz1, t + 1)
+      DIMO_BWD_RECORD(m0, g0, c0, a0, nz0, t)
+      if (t + 1 >= mine) break;
+      DIMO_BWD_LOAD(m0, g0, c0, a0, nz0, t + 2)
+      DIMO_BWD_RECORD(m1, g1, c1, a1, nz1, t + 1)
     }
-    for (int t = 0; t < mine; ++t) {
-      const uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane((int)m_next);
-      const uint32_t pos = blo + (m >> 8), qm = m & 0xfu;
-      const float4 g = g_next, c = c_next, a = a_next;
-      const float nz = nz_next;
-      const int tn = min(t + 1, mine - 1);
-      m_next = s_mask[tn], g_next = s_geo[tn], c_next = s_col[tn], a_next = s_aux[tn];
-      if (NORMAL) nz_next = s_nz[tn];
-      if (pos >= wlast) break;  // the list is ascending: nothing further reaches this tile
-      const float dx0 = g.x - bxf, dy0 = g.y - byf;
-      float v[16];
-#pragma unroll
-      for (int k = 0; k < 16; ++k) v[k] = 0.0f;
-      bool any = false;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        if (!((qm >> q) & 1u) || pos >= deepest[q]) continue;  // wave-uniform
-        any = true;
-        ++n_quad;
-        const float dx = dx0 - (float)((q & 1) * 8), dy = dy0 - (float)((q >> 1) * 8);
-        const float power = -0.5f * (g.z * dx * dx + c.x * dy * dy) - g.w * dx * dy;
-        const float G = __expf(power);
-        const float alpha = fminf(ALPHA_MAX, c.y * G);
-        const bool active = pos < last[q] && power <= 0.0f && alpha >= ALPHA_MIN;
-        const float ae = active ? alpha : 0.0f;
-        const float w = ae * T[q];
-        float D = dp[q][7] + c.z * dp[q][0] + c.w * dp[q][1] + a.x * dp[q][2] + a.y * dp[q][3];
-        if (NORMAL) D += a.z * dp[q][4] + a.w * dp[q][5] + nz * dp[q][6];
-        SP[q] -= D * w;
-        const float oma = 1.0f - ae;
-        const float dL_dalpha_i = D * T[q] - SP[q] * __builtin_amdgcn_rcpf(oma);
-        T[q] *= oma;
-        float gg = G * c.y * dL_dalpha_i;  // g = G * dL/dG, dL/dG = opacity * dL/dalpha
-        gg = active ? gg : 0.0f;           // (a select, not a product: G of a rejected lane may be inf)
-        const float gx = gg * dx, gy = gg * dy;
-        v[0] += gg, v[1] += gx, v[2] += gy;
-        v[3] += gx * dx, v[4] += gx * dy, v[5] += gy * dy;
-        v[6] += w * dp[q][0], v[7] += w * dp[q][1], v[8] += w * dp[q][2], v[9] += w * dp[q][3];
-        if (NORMAL) v[10] += w * dp[q][4], v[11] += w * dp[q][5], v[12] += w * dp[q][6];
-      }
-      if (!any) continue;
-      ++n_rec;
-      const float tot = wave_reduce16(v);  // lane l: the wave total of value reduce16_slot(l)
-      if ((lane & 3) == 0) s_acc[t][reduce16_slot(lane)] = tot;  // this wave is the only writer of the record
-    }
+#undef DIMO_BWD_LOAD
+#undef DIMO_BWD_RECORD
     __syncthreads();
     if (my_hit) {
       const float4 *src = reinterpret_cast<const float4 *>(&s_acc[my_rank][0]);
