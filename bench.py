@@ -37,28 +37,35 @@ TIMED = ["preprocess_fwd", "scan", "emit", "sort", "ranges", "blend_fwd", "blend
          "ssim_fwd", "ssim_bwd", "deform_fwd", "deform_bwd", "image_loss", "adam", "timenet_fwd", "timenet_bwd", "place"]
 
 
-def make_trainer(device, rank, world, num_pts, resolution, per_gpu=(2, 2, 2), capacity=True):
+def make_trainer(device, rank, world, num_pts, resolution, per_gpu=(2, 2, 2), capacity=True, global_batch=None,
+                 direct=None):
+    """per_gpu = (motions, views, frames) per GPU and step (weak scaling: the step's motion count grows with the
+    world size); global_batch = the reference's `batch_size` b for a FIXED step of 2b x b x b renders sharded over
+    the ranks (strong scaling; main_train_dimo.py:266-281: b = 2 -> 16 renders, b = 4 -> 128)."""
     from dimo_amd.rasterizer import CapacityPolicy
     from dimo_amd.renderer import Renderer
     from dimo_amd.synth import init_synthetic_model
     from dimo_amd.trainer import TrainConfig, Trainer
-    m, v, f = per_gpu
-    cfg = TrainConfig(num_pts=num_pts, resolution=resolution, motions_per_step=min(51, m * world), views_per_step=v,
-                      frames_per_step=f)
+    if global_batch:
+        m, v, f = min(51, 2 * global_batch), global_batch, global_batch
+    else:
+        m, v, f = min(51, per_gpu[0] * world), per_gpu[1], per_gpu[2]
+    cfg = TrainConfig(num_pts=num_pts, resolution=resolution, motions_per_step=m, views_per_step=v, frames_per_step=f)
     pol = CapacityPolicy(initial=max(1 << 20, 40 * num_pts)) if capacity else None
     rd = Renderer(sh_degree=0, white_background=True, radius=cfg.radius, num_latent_code=cfg.num_motions,
                   latent_code_dim=cfg.latent_code_dim, add_normal=True, device=device, capacity=pol)
     init_synthetic_model(rd, cfg.num_pts, cfg.num_cpts, seed=0, regime="trained", num_latent=cfg.num_motions)
-    tr = Trainer(cfg, rd, rank=rank, world_size=world)
+    tr = Trainer(cfg, rd, rank=rank, world_size=world, direct=direct)
     # steady state of the schedule: past depth/normal_reg_start_iter (200) every image term is on (10 600 of the
     # reference's 10 000 + 2 800 iterations run that way), past step 1000 the s2 xyz lr rule no longer applies
     tr.step = 1000
     return tr, pol
 
 
-def kernel_rooflines(timing_iso, N, V, R, P, C=NFEAT):
-    """name -> algorithmic bytes per render (DESIGN.md section 4 / SURVEY.md 8d formulas), isolated time, GB/s,
-    fraction of the HBM peak.  The blend kernels are FP32-VALU bound (see `roofline.note`); the others stream."""
+def kernel_rooflines(timing_iso, N, V, R, P, C=NFEAT, renders_per_launch=1.0):
+    """name -> algorithmic bytes per render (DESIGN.md section 4 / SURVEY.md 8d formulas), time per launch, GB/s,
+    fraction of the HBM peak -- from the BATCHED launches of the timed schedule when `renders_per_launch` > 1 (a
+    launch then moves that many renders' bytes).  The blend kernels are FP32-VALU bound (see `roofline.note`)."""
     alg = {
         "deform_fwd": 92 * N,
         "preprocess_fwd": 56 * N + 77 * V,
@@ -78,7 +85,10 @@ def kernel_rooflines(timing_iso, N, V, R, P, C=NFEAT):
         if not n or ms <= 0:
             continue
         t = ms / n * 1e-3
-        out[k] = {"algorithmic_bytes": float(b), "ms": ms / n, "GBps": b / t / 1e9, "frac_of_hbm_peak": b / t / 1e9 / HBM_PEAK_GBS}
+        # the skinning kernels run once per (motion, frame) GROUP of a batch: two views share a group in this workload
+        b = b * (renders_per_launch / 2.0 if (k.startswith("deform") and renders_per_launch > 1) else renders_per_launch)
+        out[k] = {"algorithmic_bytes_per_launch": float(b), "ms": ms / n, "GBps": b / t / 1e9,
+                  "frac_of_hbm_peak": b / t / 1e9 / HBM_PEAK_GBS}
     return out
 
 
@@ -126,6 +136,12 @@ def main():
     ap.add_argument("--num-pts", type=int, default=100000)
     ap.add_argument("--resolution", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-dropin", action="store_true", help="skip the drop-in (autograd) path's frames/s")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for the tests)")
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="strong scaling: the reference's batch_size b -> a FIXED step of 2b x b x b renders (b = 2: 16, "
+                         "b = 4: 128) sharded over the ranks, instead of 8 renders per GPU")
+    ap.add_argument("--per-gpu", default="2,2,2", help="weak scaling: motions,views,frames per GPU and step")
     ap.add_argument("--sync-exact", action="store_true", help="size sort buffers by reading R back (one sync per render)")
     args = ap.parse_args()
 
@@ -137,15 +153,22 @@ def main():
             sys.exit(f"--gpus {args.gpus} needs a torch.distributed.run launch with --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the product path has no CPU fallback)")
+    local = local % torch.cuda.device_count()  # (several ranks may share a device under --backend gloo)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     from dimo_amd import _lib
     L = _lib.lib()
-    tr, pol = make_trainer(device, rank, world, args.num_pts, args.resolution, capacity=not args.sync_exact)
+    per_gpu = tuple(int(x) for x in args.per_gpu.split(","))
+    tr, pol = make_trainer(device, rank, world, args.num_pts, args.resolution, per_gpu=per_gpu,
+                           capacity=not args.sync_exact, global_batch=args.global_batch or None)
+    tr.time_allreduce = world > 1  # event pairs around the step's collective: its EXPOSED time on this stream
 
     def barrier():
         if world > 1:
@@ -154,6 +177,8 @@ def main():
 
     for _ in range(args.warmup):
         tr.train_step()
+    skipped_warmup = tr.skipped_steps
+    tr.allreduce_events = []
     # a full (generation-2) Python GC pass walks every object torch created at import time: ~45 ms, i.e. ten
     # training steps, whenever it happens to fall into the timed region.  Long-running training loops park the
     # start-up objects in the permanent generation for the same reason.
@@ -173,6 +198,9 @@ def main():
             trace.append(time.perf_counter() - t0)
     barrier()
     elapsed = time.perf_counter() - t0
+    skipped_timed = tr.skipped_steps - skipped_warmup  # (read with a lag of one step: the last step is not in yet)
+    ar_ms = [a.elapsed_time(b) for a, b in tr.allreduce_events] if getattr(tr, "allreduce_events", None) else []
+    tr.time_allreduce = False
     if trace is not None:
         print("step-end host times (ms):", " ".join(f"{1e3 * x:.2f}" for x in trace), f"| total {1e3 * elapsed:.2f}",
               f"skipped={tr.skipped_steps}", file=sys.stderr)
@@ -186,6 +214,7 @@ def main():
     else:
         renders_total = float(renders)
     timing = read_timing()
+    torch.cuda.reset_peak_memory_stats(device)
     # step latency distribution (median + p10/p90), one device sync per step, outside the timed region
     lat = []
     for _ in range(min(args.steps, 50)):
@@ -203,6 +232,8 @@ def main():
     barrier()
     L.dimo_timing_enable(0)
     timing_all = read_timing()
+    skipped_total = tr.skipped_steps
+    peak_mem = torch.cuda.max_memory_allocated(device)
 
     if rank == 0:
         # measured R (tile instances) and V (visible Gaussians) of this workload, outside the timed region
@@ -247,6 +278,17 @@ def main():
         avg_s = (bwd_ms / max(bwd_n, 1)) * 1e-3
         achieved = alg_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
         traffic = None
+        valu = None
+        sqf = os.path.join(ROOT, "profiles", "sq_blend.json")
+        if os.path.exists(sqf):  # SQ counters of a rocprofv3 --pmc run of this workload (tools/pmc_sq.sh), not live
+            try:
+                d = json.load(open(sqf)).get("blend_bwd_batched", {}).get("derived", {})
+                valu = {"valu_busy_at_4_cycles_per_inst": d.get("valu_busy_quad"),
+                        "valu_busy_at_2_cycles_per_inst": d.get("valu_issue_frac"),
+                        "waves_per_simd": d.get("waves_per_simd"), "source": "profiles/sq_blend.json (rocprofv3 --pmc, "
+                        "separate run of tools/pmc_probe.py)"}
+            except Exception:
+                valu = None
         pmc = os.path.join(ROOT, "profiles", "pmc_blend_bwd.json")
         if os.path.exists(pmc):
             try:
@@ -263,18 +305,33 @@ def main():
                       f"deform+raster fwd+bwd+losses+Adam)",
             "value": renders_total / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "scaling": "strong" if args.global_batch else "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic (seeded Gaussians initialised as the reference does, random-init TimeNet, "
                     "random targets; no dataset/LPIPS weights offline; LPIPS/ARAP/GA/KL terms excluded)",
             "config": {"workload": f"{shape_name}: {args.num_pts} Gaussians, 512 control points, {args.resolution}^2, stage s2, "
-                                   f"diff_gauss flavour (rgb+depth+normal+alpha), 8 renders/GPU/step "
-                                   f"(2 motions x 2 views x 2 frames per GPU)",
+                                   f"diff_gauss flavour (rgb+depth+normal+alpha), "
+                                   + (f"a fixed step of {tr.cfg.motions_per_step} x {tr.cfg.views_per_step} x "
+                                      f"{tr.cfg.frames_per_step} renders sharded over the ranks (batch_size "
+                                      f"{args.global_batch})" if args.global_batch else
+                                      f"{per_gpu[0] * per_gpu[1] * per_gpu[2]} renders/GPU/step ({per_gpu[0]} motions x "
+                                      f"{per_gpu[1]} views x {per_gpu[2]} frames per GPU)")
+                                   + ", schedule step 1000+ (every image term on)",
                        "renders_per_step": int(renders_total / args.steps), "parallelism": f"dp{world}",
-                       "R_tile_instances": R, "V_visible": V},
+                       "R_tile_instances": R, "V_visible": V,
+                       "instance_capacity": int(pol.capacity) if pol is not None else None,
+                       "hbm_peak_allocated_GB": peak_mem / 1e9},
+            # a step whose renders overflowed the instance capacity is skipped on the device (Adam no-op) but its
+            # renders are still counted above: this must read 0 for `value` to be a training rate
+            "skipped_steps": {"timed_region": skipped_timed, "whole_run": skipped_total},
+            "allreduce_exposed_ms_per_step": (sum(ar_ms) / len(ar_ms)) if ar_ms else (0.0 if world == 1 else None),
             "roofline": {"bound": "hbm", "kernel": "blend_bwd_batched_kernel", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "renders_per_launch": rpl,
                          "avg_ms": bwd_ms / max(bwd_n, 1), "launches": bwd_n,
+                         "traffic_source": "profiles/pmc_blend_bwd.json: FETCH_SIZE / WRITE_SIZE of separate rocprofv3 "
+                                           "--pmc passes over tools/pmc_probe.py, calibrated on a 1 GiB copy; scaled to "
+                                           "this run's renders per launch" if traffic is not None else None,
+                         "valu": valu,
                          "isolated": {"avg_ms": iso_ms / max(iso_n, 1), "launches": iso_n, "renders_per_launch": 1,
                                       "achieved": alg_render / (iso_ms / max(iso_n, 1) * 1e-3) / 1e9 if iso_ms else None,
                                       "frac": alg_render / (iso_ms / max(iso_n, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS
@@ -295,8 +352,10 @@ def main():
                              "note": "list entries x 256 pixels; culling and saturation skip most of them, so the "
                                      "rate is an upper-bound style figure, not executed FLOPs"},
             # achieved HBM GB/s per kernel against the 8 TB/s peak, from the ALGORITHMIC bytes of
-            # DESIGN.md section 4 and the single-render launches measured alone on the device (timing_iso)
-            "kernel_rooflines": kernel_rooflines(timing_iso, args.num_pts, V, R, P),
+            # DESIGN.md section 4 and (a) the BATCHED launches the step really runs, (b) single-render launches
+            # measured alone on the device
+            "kernel_rooflines": kernel_rooflines(timing_all, args.num_pts, V, R, P, renders_per_launch=rpl),
+            "kernel_rooflines_isolated": kernel_rooflines(timing_iso, args.num_pts, V, R, P),
             # BASELINE.json metric (ii): rasterizer forward / backward device time of ONE render alone on the device
             # (sum of its kernels' HIP-event times: project, scan, depth sort, placement, blend | blend, projection)
             "raster_ms_per_render_isolated": {
@@ -311,6 +370,29 @@ def main():
             "kernels_ms_per_launch": {k: (v[0] / v[1] if v[1] else None) for k, v in timing_all.items()},
             "kernels_ms_per_launch_isolated": {k: (v[0] / v[1] if v[1] else None) for k, v in timing_iso.items()},
         }
+        if world == 1 and not args.no_dropin:
+            # what a maintainer gets who only swaps the imports: the reference-shaped step --
+            # Renderer.render per triple through the GaussianRasterizer autograd module, torch losses, one backward
+            try:
+                del tr
+                torch.cuda.empty_cache()
+                tr2, _ = make_trainer(device, 0, 1, args.num_pts, args.resolution, per_gpu=per_gpu, capacity=False,
+                                      direct=False)
+                for _ in range(3):
+                    tr2.train_step()
+                torch.cuda.synchronize()
+                k2 = 10
+                t2 = time.perf_counter()
+                n2 = sum(tr2.train_step() for _ in range(k2))
+                torch.cuda.synchronize()
+                res["dropin_frames_per_s"] = n2 / (time.perf_counter() - t2)
+                res["dropin_what"] = ("same C3 step through the drop-in surface only: Renderer.render + "
+                                      "GaussianRasterizerNormal (autograd, one launch chain and one R read-back per render), "
+                                      "PyTorch TimeNet and losses (fused SSIM op), FlatAdam; %d steps" % k2)
+                del tr2
+            except Exception as e:
+                res["dropin_frames_per_s"] = None
+                res["dropin_what"] = f"failed: {e!r}"
         if world == 1 and not args.no_cpu_baseline:
             try:
                 res["cpu_baseline"] = cpu_baseline(args.num_pts, args.resolution)

@@ -177,6 +177,8 @@ class Trainer:
         self._fused_tn = None
         self.marks = None  # set to [] to collect (name, torch.cuda.Event) phase marks on the main stream
         self.skipped_steps = 0
+        self.time_allreduce = False  # bench.py: event pairs around the step's collective (exposed time)
+        self.allreduce_events = []
         self._flat_adam = type(self.optimizer).__name__ == "FlatAdam"
         self._inorder_losses = os.environ.get("DIMO_INORDER_LOSSES", "1") == "1"
         # direct HIP pipeline: GPU, stage s2, degree-0 colour (DIMO's configuration), product rasterizer
@@ -706,7 +708,14 @@ class Trainer:
                     g.grad_flag.copy_(tot[:, 1].max().to(torch.float32))
                 else:
                     g.grad_flag.zero_()
+                timed = getattr(self, "time_allreduce", False) and self.device.type == "cuda"
+                if timed:  # exposed time of the collective on this stream (bench.py reports the mean)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
                 self.all_reduce_grads()
+                if timed:
+                    e1.record()
+                    self.allreduce_events.append((e0, e1))
                 self.optimizer.step(skip_flags=g.grad_flag.view(torch.int32), zero_grad=True)
             else:  # one rank: Adam reads the renders' (R, overflow) words directly
                 self.optimizer.step(skip_flags=tot, zero_grad=True)

@@ -1,0 +1,54 @@
+"""bench.py's own code paths on the GPU box: the world > 1 branch (two ranks on ONE device over gloo -- the driver's
+8-GPU run uses the same code with RCCL), the strong-scaling mode, and the fields the record must carry."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(cmd):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+SMALL = ["--steps", "4", "--warmup", "3", "--num-pts", "20000", "--resolution", "128", "--no-cpu-baseline"]
+
+
+@pytest.mark.timeout(1200)
+@pytest.mark.parametrize("strong", [False, True])
+def test_bench_two_ranks_on_one_device(strong):
+    port = 24500 + (os.getpid() % 2000) + int(strong)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "2", "--backend", "gloo", "--no-dropin"] + SMALL
+    if strong:
+        cmd += ["--global-batch", "2"]
+    r = _run(cmd)
+    assert r["n_gpus"] == 2 and r["steps"] == 4 and r["higher_is_better"] is True
+    assert r["scaling"] == ("strong" if strong else "weak")
+    assert r["config"]["renders_per_step"] == 16  # 2 x 8 per GPU (weak) or the fixed 4 x 2 x 2 step (strong)
+    assert r["skipped_steps"] == {"timed_region": 0, "whole_run": 0}
+    assert r["allreduce_exposed_ms_per_step"] is not None and r["allreduce_exposed_ms_per_step"] >= 0.0
+    assert r["value"] > 0 and abs(r["value"] - 16 * 1e3 / r["ms_per_step"]) < 1e-6 * r["value"]
+    assert r["roofline"]["bound"] in ("hbm", "mfma") and r["roofline"]["achieved"] > 0
+
+
+@pytest.mark.timeout(1200)
+def test_bench_single_rank_record_fields():
+    r = _run([sys.executable, "bench.py"] + SMALL)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "skipped_steps", "dropin_frames_per_s",
+                "kernel_rooflines"):
+        assert key in r, key
+    assert r["n_gpus"] == 1 and r["dtype"] == "f32" and "workload" in r["config"]
+    assert r["dropin_frames_per_s"] and r["dropin_frames_per_s"] < r["value"]
+    assert r["skipped_steps"]["whole_run"] == 0
+    assert r["kernel_rooflines"]["blend_bwd"]["ms"] > 0
