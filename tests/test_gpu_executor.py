@@ -168,3 +168,21 @@ def test_batched_executor_single_stream_mode_small(monkeypatch):
     assert ex.batched and not ex.ranged
     for o in outs:
         _check_render(o, f_dc, bg, 128, 128)
+
+
+@pytest.mark.timeout(1800)
+@pytest.mark.parametrize("chain", ["2", "3"])
+def test_chained_buckets_mode_against_the_oracle(chain):
+    """DIMO_BWD_CHAIN > 1: a backward item walks several consecutive buckets with the pixel state in registers and
+    the forward stores checkpoints only at chain starts.  The variable is read once per process, so the oracle
+    comparisons (single render at 100k / 512^2 and the batched executor at 50k / 256^2) run in a child process."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DIMO_BWD_CHAIN=chain)
+    p = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "tests/test_gpu_raster.py",
+                        "tests/test_gpu_executor.py", "-k",
+                        "(baseline_config_sizes and 100000) or (batched_executor_kernels and 50000)"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=1500)
+    assert p.returncode == 0 and " passed" in p.stdout, p.stdout[-3000:] + p.stderr[-2000:]
