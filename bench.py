@@ -393,6 +393,39 @@ def main():
             except Exception as e:
                 res["dropin_frames_per_s"] = None
                 res["dropin_what"] = f"failed: {e!r}"
+        if world == 1 and not args.no_dropin:
+            # stage s1 (2 800 of the reference's 12 800 iterations, run_train_latent.sh:12): num_cpts Gaussians (what
+            # FPS leaves), the TimeNet evaluated on them, every scale = exp(_r) -- same step shape, HIP pipeline
+            try:
+                from dimo_amd.rasterizer import CapacityPolicy
+                from dimo_amd.renderer import Renderer
+                from dimo_amd.synth import init_synthetic_model
+                from dimo_amd.trainer import TrainConfig, Trainer
+                c1 = TrainConfig(num_pts=512, resolution=args.resolution, motions_per_step=per_gpu[0],
+                                 views_per_step=per_gpu[1], frames_per_step=per_gpu[2], stage="s1", FPS_iter=10 ** 9,
+                                 position_lr_max_steps=500)
+                rd1 = Renderer(sh_degree=0, white_background=True, radius=c1.radius, num_latent_code=c1.num_motions,
+                               add_normal=True, device=device, capacity=CapacityPolicy(initial=1 << 22))
+                init_synthetic_model(rd1, c1.num_pts, c1.num_cpts, seed=0, regime="trained", num_latent=c1.num_motions)
+                g1 = rd1.gaussians
+                g1._r = torch.nn.Parameter(torch.full((1, 1), -3.2, device=device))  # exp(-3.2) = 0.04: blobs of a 512-point shape
+                t1 = Trainer(c1, rd1)
+                t1.step = 1100  # full resolution, past the density window
+                for _ in range(5):
+                    t1.train_step()
+                torch.cuda.synchronize()
+                k1 = 20
+                ts = time.perf_counter()
+                n1 = sum(t1.train_step() for _ in range(k1))
+                torch.cuda.synchronize()
+                res["s1_frames_per_s"] = n1 / (time.perf_counter() - ts)
+                res["s1_what"] = ("stage s1 on the HIP pipeline (direct=%s): 512 Gaussians of radius exp(_r) = 0.04, TimeNet "
+                                  "on the Gaussians, %d renders/step at %d^2, %d steps; skipped %d"
+                                  % (t1.direct, n1 // k1, args.resolution, k1, t1.skipped_steps))
+                del t1, rd1
+            except Exception as e:
+                res["s1_frames_per_s"] = None
+                res["s1_what"] = f"failed: {e!r}"
         if world == 1 and not args.no_cpu_baseline:
             try:
                 res["cpu_baseline"] = cpu_baseline(args.num_pts, args.resolution)

@@ -521,7 +521,82 @@ void group_deformations(RenderBatch &b, int n) {
   for (int i = n; i < MAX_BATCH; ++i) b.r[i] = b.r[n - 1];  // padding entries follow the redirected last render
 }
 
+// ---- stage s1: direct deformation (renderer/latent_gs_renderer.py:1176-1177, 1211-1212, get_scaling :341-351) ------
+// The TimeNet moves every Gaussian itself: pts = xyz + d_xyz[i], rotation = normalize(rotation), scale = exp(_r) on
+// all three axes (the shared (1, 1) log-radius), opacity = sigmoid.  One thread per Gaussian, blockIdx.y = group.
+__global__ void __launch_bounds__(256) s1_fwd_batched_kernel(int N, const float *__restrict__ xyz,
+                                                             const float *__restrict__ rotation,
+                                                             const float *__restrict__ opacity,
+                                                             const float *__restrict__ log_r, RenderBatch b) {
+  const dimo_render_desc &r = b.r[b.leader[blockIdx.y]];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  const float s = __expf(log_r[0]);
+  r.pts[3 * i] = xyz[3 * i] + r.d_xyz[3 * i];
+  r.pts[3 * i + 1] = xyz[3 * i + 1] + r.d_xyz[3 * i + 1];
+  r.pts[3 * i + 2] = xyz[3 * i + 2] + r.d_xyz[3 * i + 2];
+  const float4 q = *reinterpret_cast<const float4 *>(rotation + 4 * (size_t)i);
+  const float inv_n = 1.0f / fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-12f);
+  *reinterpret_cast<float4 *>(r.rot + 4 * (size_t)i) = make_float4(q.x * inv_n, q.y * inv_n, q.z * inv_n, q.w * inv_n);
+  r.scales[3 * i] = s, r.scales[3 * i + 1] = s, r.scales[3 * i + 2] = s;
+  r.opac[i] = 1.0f / (1.0f + __expf(-opacity[i]));
+}
+// Backward, in place over the LEADER's rasterizer gradients like lbs_bwd_batched_kernel (accumulate_batched_kernel
+// then folds the leaders into the shared gradient views): d xyz = sum of the group's g_means3D, which is also the
+// gradient of this pair's TimeNet output row; normalize / sigmoid backward; the radius gradient is reduced per
+// workgroup and added atomically (a single float, N <= a few thousand in this stage).
+__global__ void __launch_bounds__(256) s1_bwd_batched_kernel(int N, const float *__restrict__ rotation,
+                                                             const float *__restrict__ opacity,
+                                                             const float *__restrict__ log_r, float *g_log_r,
+                                                             RenderBatch b) {
+  __shared__ float s_red[4];
+  const int lead = b.leader[blockIdx.y];
+  const dimo_render_desc &r = b.r[lead];
+  const unsigned others = b.members[blockIdx.y] & ~(1u << lead);
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  float gr = 0.0f;
+  if (i < N) {
+    float gx = r.g_means3D[3 * i], gy = r.g_means3D[3 * i + 1], gz = r.g_means3D[3 * i + 2];
+    float4 gq = *reinterpret_cast<const float4 *>(r.g_rot + 4 * (size_t)i);
+    float gs = r.g_scales[3 * i] + r.g_scales[3 * i + 1] + r.g_scales[3 * i + 2];
+    float go = r.g_opac[i];
+    for (unsigned m = others; m; m &= m - 1) {
+      const dimo_render_desc &o = b.r[__ffs(m) - 1];
+      gx += o.g_means3D[3 * i], gy += o.g_means3D[3 * i + 1], gz += o.g_means3D[3 * i + 2];
+      const float4 t = *reinterpret_cast<const float4 *>(o.g_rot + 4 * (size_t)i);
+      gq.x += t.x, gq.y += t.y, gq.z += t.z, gq.w += t.w;
+      gs += o.g_scales[3 * i] + o.g_scales[3 * i + 1] + o.g_scales[3 * i + 2];
+      go += o.g_opac[i];
+    }
+    r.g_d_xyz[3 * i] += gx, r.g_d_xyz[3 * i + 1] += gy, r.g_d_xyz[3 * i + 2] += gz;
+    r.g_means3D[3 * i] = gx, r.g_means3D[3 * i + 1] = gy, r.g_means3D[3 * i + 2] = gz;
+    const float4 q = *reinterpret_cast<const float4 *>(rotation + 4 * (size_t)i);
+    const float nrm = fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-12f), inv_n = 1.0f / nrm;
+    const float ux = q.x * inv_n, uy = q.y * inv_n, uz = q.z * inv_n, uw = q.w * inv_n;
+    const float dot = ux * gq.x + uy * gq.y + uz * gq.z + uw * gq.w;
+    *reinterpret_cast<float4 *>(r.g_rot + 4 * (size_t)i) =
+        make_float4((gq.x - ux * dot) * inv_n, (gq.y - uy * dot) * inv_n, (gq.z - uz * dot) * inv_n, (gq.w - uw * dot) * inv_n);
+    r.g_scales[3 * i] = 0.0f, r.g_scales[3 * i + 1] = 0.0f, r.g_scales[3 * i + 2] = 0.0f;  // `_scaling` is unused in s1
+    const float sg = 1.0f / (1.0f + __expf(-opacity[i]));
+    r.g_opac[i] = go * sg * (1.0f - sg);
+    gr = gs * __expf(log_r[0]);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) gr += __shfl_down(gr, o, 64);
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = gr;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(g_log_r, s_red[0] + s_red[1] + s_red[2] + s_red[3]);
+}
+
 int lbs_forward_batched(const dimo_step_common &c, const RenderBatch &b, int n, hipStream_t stream) {
+  if (c.stage1) {
+    if (c.N <= 0 || n <= 0) return DIMO_OK;
+    if (!c.log_r) return DIMO_E_ARG;
+    ScopedTimer tm(T_DEFORM_FWD, stream);
+    hipLaunchKernelGGL(s1_fwd_batched_kernel, dim3((c.N + 255) / 256, b.n_groups), dim3(256), 0, stream, c.N, c.xyz,
+                       c.rotation, c.opacity, c.log_r, b);
+    return check_launch();
+  }
   if (c.N <= 0 || n <= 0) return DIMO_OK;
   GaussIO g{c.xyz, c.rotation, c.scaling, c.opacity, c.nn_dist, c.nn_idx};
   const size_t lds = (size_t)c.M * CP_STRIDE * sizeof(float);
@@ -544,6 +619,16 @@ size_t lbs_backward_batched_scratch_bytes(int N, int M, int n) {
 
 int lbs_backward_batched(const dimo_step_common &c, const RenderBatch &b, int n, hipStream_t stream) {
   if (c.N <= 0 || n <= 0) return DIMO_OK;
+  if (c.stage1) {
+    if (!c.log_r || !c.g_log_r) return DIMO_E_ARG;
+    ScopedTimer tm(T_DEFORM_BWD, stream);
+    hipLaunchKernelGGL(s1_bwd_batched_kernel, dim3((c.N + 255) / 256, b.n_groups), dim3(256), 0, stream, c.N,
+                       c.rotation, c.opacity, c.log_r, c.g_log_r, b);
+    const size_t total = 14 * (size_t)c.N;
+    hipLaunchKernelGGL(accumulate_batched_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, c.N, n,
+                       b, c.g_xyz, c.g_rotation, c.g_scaling, c.g_opacity, c.g_f_dc);
+    return check_launch();
+  }
   if (c.lbs_scratch_bytes < lbs_backward_batched_scratch_bytes(c.N, c.M, n)) return DIMO_E_WORKSPACE;
   GaussIO g{c.xyz, c.rotation, c.scaling, c.opacity, c.nn_dist, c.nn_idx};
   const size_t lds = 2 * (size_t)c.M * CP_STRIDE * sizeof(float);

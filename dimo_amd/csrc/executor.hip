@@ -25,6 +25,9 @@ typedef struct {
   float *g_xyz, *g_rotation, *g_scaling, *g_opacity, *g_f_dc, *g_c_xyz, *g_c_log_radius;
   void *lbs_scratch;
   size_t lbs_scratch_bytes, geom_bytes, bin_bytes, img_bytes, bwd_scratch_bytes;
+  int stage1;            // stage s1: direct deformation (see include/dimo_hip.h)
+  const float *log_r;
+  float *g_log_r;
 } dimo_step_common;
 
 typedef struct {
@@ -190,6 +193,7 @@ extern "C" int dimo_executor_forward_range(void *h, const dimo_step_common *c, i
     if (rc) return rc;
     return hipEventRecord(ex->fwd_done[first], s) == hipSuccess ? DIMO_OK : DIMO_E_LAUNCH;
   }
+  if (c->stage1) return DIMO_E_ARG;  // stage s1 runs in the batched modes only
   rc = fork_from_main(ex, main);
   if (rc) return rc;
   for (int i = first; i < first + count; ++i) {

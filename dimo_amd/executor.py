@@ -23,7 +23,8 @@ class StepCommon(C.Structure):
                 ("g_xyz", _fp), ("g_rotation", _fp), ("g_scaling", _fp), ("g_opacity", _fp), ("g_f_dc", _fp),
                 ("g_c_xyz", _fp), ("g_c_log_radius", _fp),
                 ("lbs_scratch", _vp), ("lbs_scratch_bytes", C.c_size_t), ("geom_bytes", C.c_size_t),
-                ("bin_bytes", C.c_size_t), ("img_bytes", C.c_size_t), ("bwd_scratch_bytes", C.c_size_t)]
+                ("bin_bytes", C.c_size_t), ("img_bytes", C.c_size_t), ("bwd_scratch_bytes", C.c_size_t),
+                ("stage1", C.c_int), ("log_r", _fp), ("g_log_r", _fp)]
 
 
 class RenderDesc(C.Structure):
@@ -106,14 +107,20 @@ class StepExecutor:
         from .rasterizer import _total_view
         return [_total_view(self.slots[i]["geom"], self.N) for i in range(n)]
 
-    def set_common(self, g, bg, with_normal, local_frame=True, scale_modifier=1.0):
+    def set_common(self, g, bg, with_normal, local_frame=True, scale_modifier=1.0, stage1=False):
+        """stage1: direct deformation (stage s1) -- d_xyz of a render is [N, 3], scales = exp(g._r)."""
         c = self.common
+        c.stage1 = int(bool(stage1))
+        c.log_r = _lib.ptr(g._r) if stage1 else None
+        c.g_log_r = _lib.ptr(g._r.grad) if stage1 else None
         c.N, c.M, c.H, c.W = self.N, self.M, self.H, self.W
         c.with_normal, c.local_frame, c.R_cap = int(with_normal), int(local_frame), self.r_cap
         p = _lib.ptr
         c.xyz, c.rotation, c.scaling, c.opacity, c.f_dc = p(g._xyz), p(g._rotation), p(g._scaling), p(g._opacity), p(g._features_dc)
         c.c_xyz, c.c_log_radius = p(g._c_xyz), p(g._c_radius)
-        c.nn_dist, c.nn_idx, c.bg = p(g.neighbor_dists), p(g.neighbor_indices), p(bg)
+        c.nn_dist = p(g.neighbor_dists) if not stage1 else None
+        c.nn_idx = p(g.neighbor_indices) if not stage1 else None
+        c.bg = p(bg)
         c.scale_modifier = float(scale_modifier)
         c.g_xyz, c.g_rotation, c.g_scaling, c.g_opacity = p(g._xyz.grad), p(g._rotation.grad), p(g._scaling.grad), p(g._opacity.grad)
         c.g_f_dc, c.g_c_xyz, c.g_c_log_radius = p(g._features_dc.grad), p(g._c_xyz.grad), p(g._c_radius.grad)

@@ -48,6 +48,9 @@ class TrainConfig:
     views_per_step: int = 2
     frames_per_step: int = 2
     resolution: int = 512
+    # main_train_dimo.py:261: renders (and the targets, resampled bilinearly) at 128^2 while step < 300, 256^2 while
+    # step < 450, full size afterwards -- never above `resolution`
+    progressive_resolution: bool = True
     # camera
     radius: float = 2
     fovy: float = 33.9
@@ -152,6 +155,7 @@ class Trainer:
         self.ssim, self.knn = ssim_fn, knn_fn
         self._fps_fn = fps_fn  # stage s1 down-sampling; default: the HIP kernel behind regularizers.sample_farthest_points
         self.cpts_s1 = None    # [motions, frames, M, 3]: control-point trajectories cached at stage-s2 step 0 (GA term)
+        self._resampled = {}   # targets at the reduced render sizes of the first 450 steps
         self.cams = CameraCache(fovy_deg=cfg.fovy, device=self.device)
         self.azimuths = default_azimuths(cfg.num_views)
         self.source_time = frame_times(cfg.num_frames)
@@ -181,10 +185,13 @@ class Trainer:
         self.allreduce_events = []
         self._flat_adam = type(self.optimizer).__name__ == "FlatAdam"
         self._inorder_losses = os.environ.get("DIMO_INORDER_LOSSES", "1") == "1"
-        # direct HIP pipeline: GPU, stage s2, degree-0 colour (DIMO's configuration), product rasterizer
+        # direct HIP pipeline: GPU, degree-0 colour (DIMO's configuration), product rasterizer; stage s2 (skinning by
+        # <= 1800 control points, `_r` retired) or stage s1 (the TimeNet moves the Gaussians, shared (1, 1) radius `_r`)
+        g0 = renderer.gaussians
+        stage_ok = (cfg.stage >= "s2" and len(g0._r) == 0 and g0._c_xyz.shape[0] <= 1800) or \
+                   (cfg.stage == "s1" and tuple(g0._r.shape) == (1, 1))
         self.direct = (direct if direct is not None else True) and self.device.type == "cuda" \
-            and cfg.stage >= "s2" and cfg.sh_degree == 0 and renderer._rasterizer_factory is None \
-            and len(renderer.gaussians._r) == 0 and renderer.gaussians._c_xyz.shape[0] <= 1800
+            and stage_ok and cfg.sh_degree == 0 and renderer._rasterizer_factory is None
         if self.direct and renderer.capacity is None:
             from .rasterizer import CapacityPolicy
             renderer.capacity = CapacityPolicy(initial=max(1 << 20, 40 * cfg.num_pts))
@@ -222,6 +229,31 @@ class Trainer:
             idxs = sample_farthest_points(g._xyz.detach()[None], num_pts)[1][0]
         g.prune_points(idxs.to(torch.int64))
 
+    def render_resolution(self):
+        """Render size of the current step (main_train_dimo.py:261)."""
+        c = self.cfg
+        if not c.progressive_resolution:
+            return c.resolution
+        return min(c.resolution, 128 if self.step < 300 else (256 if self.step < 450 else 512))
+
+    def target(self, m, v, f):
+        """(image [3, r, r], mask [1, r, r]) of a triple at the step's render size (bilinear, align_corners=False:
+        main_train_dimo.py:307-313)."""
+        img, mask = self.targets.get(m, v, f)
+        r = self.render_resolution()
+        if img.shape[-1] != r or img.shape[-2] != r:
+            key = (m, v, f, r)
+            hit = self._resampled.get(key)
+            if hit is None:
+                F = torch.nn.functional
+                hit = (F.interpolate(img[None], (r, r), mode="bilinear", align_corners=False)[0],
+                       F.interpolate(mask[None], (r, r), mode="bilinear", align_corners=False)[0])
+                if len(self._resampled) > 4096:
+                    self._resampled.clear()
+                self._resampled[key] = hit
+            return hit
+        return img, mask
+
     def sample(self) -> List[Tuple[int, int, int]]:
         c = self.cfg
         frames = self._py_rng.sample(range(c.num_frames), c.frames_per_step)
@@ -231,7 +263,8 @@ class Trainer:
 
     def render_triple(self, m, v, f, deform=None):
         c = self.cfg
-        cam = self.cams.get(c.elevation, self.azimuths[v], c.radius, c.resolution, c.resolution)
+        r = self.render_resolution()
+        cam = self.cams.get(c.elevation, self.azimuths[v], c.radius, r, r)
         return self.renderer.render(cam, time=self.source_time[f], stage=self.stage, latent_index=m, deform=deform)
 
     def batched_deform(self, triples):
@@ -269,7 +302,8 @@ class Trainer:
             table, rows = (lat.detach().contiguous() if pairs else g._mu), None
         else:
             lat, table, rows = None, g._latent_codes, [p[0] for p in pairs]
-        dxyz, dquat = self._fused_tn.forward(g._c_xyz, times, table, rows)
+        pts = g._xyz if self.stage == "s1" else g._c_xyz  # s1: the MLP is evaluated on the Gaussians themselves
+        dxyz, dquat = self._fused_tn.forward(pts.detach().contiguous(), times, table, rows)
         return dxyz, dquat, {(m, v, f): pairs.index(key(m, v, f)) for (m, v, f) in triples}, lat
 
     def _timenet_batched(self, pts, times, lat):
@@ -442,7 +476,7 @@ class Trainer:
             if self._ga_active():
                 ga = self.ga_loss(out["cpts_t"], m, f)
                 loss = ga if loss is None else loss + ga
-            gt, mask = self.targets.get(m, v, f)
+            gt, mask = self.target(m, v, f)
             w = 1.0 if (v == 0 or f == 0) else 0.5  # reference view / frame weighting (main_train_dimo.py:334)
             rec = by_motion.setdefault(m, ([], [], [], []))
             rec[0].append(out), rec[1].append(gt), rec[2].append(mask), rec[3].append(w)
@@ -470,9 +504,11 @@ class Trainer:
         from .executor import StepExecutor
         g, c = self.renderer.gaussians, self.cfg
         cap = self.renderer.capacity.next_capacity()
-        if self._exec is None or self._exec.max_renders < n_renders or self._exec.N != g._xyz.shape[0]:
+        res = self.render_resolution()
+        if self._exec is None or self._exec.max_renders < n_renders or self._exec.N != g._xyz.shape[0] \
+                or self._exec.H != res:
             import os
-            self._exec = StepExecutor(g._xyz.shape[0], g._c_xyz.shape[0], c.resolution, c.resolution,
+            self._exec = StepExecutor(g._xyz.shape[0], g._c_xyz.shape[0], res, res,
                                       max(n_renders, 8), cap, self.device,
                                       # 0 = batched: every stage is one launch over all renders of the step.
                                       # k > 0 = per-render chains on k private streams (3 + the caller's = the 4
@@ -494,13 +530,16 @@ class Trainer:
         from .image_loss import fused_image_loss, loss_weights
         c, g, L = self.cfg, self.renderer.gaussians, _lib.lib()
         dev, stream = self.device, _lib.current_stream()
-        H = W = c.resolution
+        H = W = self.render_resolution()
         f32 = dict(dtype=torch.float32, device=dev)
         n = len(mine)
         ex = self._executor(n)
-        ex.set_common(g, self.renderer.bg_color, self.renderer.add_normal)
+        s1 = self.stage == "s1"
+        ex.set_common(g, self.renderer.bg_color, self.renderer.add_normal, stage1=s1)
         self._mark("start")
-        fused_tn = self.fused_timenet and len(g._timenet.skips) <= 1
+        fused_tn = (self.fused_timenet or s1) and len(g._timenet.skips) <= 1
+        if s1 and not fused_tn:
+            raise RuntimeError("the stage-s1 direct pipeline needs the fused TimeNet (one skip connection)")
         if fused_tn:
             dxyz_c, dquat_c, pair_of, lat = self._fused_deform(mine)
         else:
@@ -544,7 +583,7 @@ class Trainer:
         # stream, so whatever is enqueued here so far is visible to the loss kernels they run
         gathered = {}
         for m, trs in by_motion.items():
-            gts = [self.targets.get(*t) for t in trs]
+            gts = [self.target(*t) for t in trs]
             # one mask per image (source_masks[motion][view][frame], main_train_dimo.py:284): [B, 1, H, W]
             gathered[m] = (torch.stack([x[0] for x in gts]), torch.stack([x[1] for x in gts]))
             self._const(-c.lambda_ssim * (len(trs) / n_img))
@@ -633,14 +672,21 @@ class Trainer:
                 ex.backward_accumulate(first[m], len(trs))
         self._mark("raster_bwd+skinning_bwd")
         self.all_reduce_point_grads_async()
-        # TimeNet backward for all renders at once
+        # the s1 densification statistics come from the step's last render (main_train_dimo.py:429-431)
+        self._last_stats = None
+        if s1 and n > 0:
+            last_slot = ex.slots[n - 1]
+            self._last_stats = (last_slot["radii"], last_slot["g_means2D"])
+        # TimeNet backward for all renders at once; the gradient w.r.t. its input points goes to the control points
+        # (s2) or to the Gaussians themselves (s1)
+        g_pts = g._xyz.grad if s1 else g._c_xyz.grad
         if mine and fused_tn:
             if lat is not None:  # VAE latents: re-parameterised rows, their gradient continues through autograd
                 g_lat = torch.zeros_like(lat)
-                self._fused_tn.backward(g_dxyz, g_dquat, g._c_xyz.grad, g_lat)
+                self._fused_tn.backward(g_dxyz, g_dquat, g_pts, g_lat)
                 lat.backward(g_lat)
             else:
-                self._fused_tn.backward(g_dxyz, g_dquat, g._c_xyz.grad, g._latent_codes.grad)
+                self._fused_tn.backward(g_dxyz, g_dquat, g_pts, g._latent_codes.grad)
         elif mine:
             torch.autograd.backward([dxyz_all, dquat_all], [g_dxyz, g_dquat])
         self._mark("timenet_bwd")

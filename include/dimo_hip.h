@@ -283,6 +283,12 @@ typedef struct {
   float *g_xyz, *g_rotation, *g_scaling, *g_opacity, *g_f_dc, *g_c_xyz, *g_c_log_radius;
   void *lbs_scratch;
   size_t lbs_scratch_bytes, geom_bytes, bin_bytes, img_bytes, bwd_scratch_bytes;
+  /* stage s1 (renderer/latent_gs_renderer.py:1176-1177,1211-1212): the TimeNet moves every Gaussian itself --
+   * d_xyz of a render is [N,3] (d_rot unused), pts = xyz + d_xyz, rotation = normalize(rotation), every scale =
+   * exp(log_r[0]) (the shared radius `_r`, get_scaling :341-351); no control points, no KNN.  0 = stage s2 skinning */
+  int stage1;
+  const float *log_r;
+  float *g_log_r;
 } dimo_step_common;
 
 typedef struct {

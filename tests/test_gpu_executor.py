@@ -41,7 +41,8 @@ def _run_batched(N, res, renders_per_motion, n_motions, seed=0, streams="-2", mo
         monkeypatch.setenv("DIMO_EXEC_STREAMS", streams)
     n = renders_per_motion * n_motions
     cfg = TrainConfig(num_pts=N, num_cpts=512, num_motions=max(4, n_motions), resolution=res,
-                      motions_per_step=n_motions, views_per_step=2, frames_per_step=max(1, renders_per_motion // 2))
+                      motions_per_step=n_motions, views_per_step=2, frames_per_step=max(1, renders_per_motion // 2),
+                      progressive_resolution=False)
     rd = Renderer(sh_degree=0, num_latent_code=cfg.num_motions, add_normal=True, device="cuda",
                   capacity=CapacityPolicy(initial=max(1 << 20, 40 * N)))
     init_synthetic_model(rd, cfg.num_pts, cfg.num_cpts, seed=seed, num_latent=cfg.num_motions)

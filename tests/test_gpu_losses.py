@@ -335,3 +335,103 @@ def test_executor_modes_agree(monkeypatch):
         assert (res[mode][2] - ref).abs().sum() / ref.abs().sum() < 1e-5, mode
         rel = (res[mode][1] - res["3"][1]).abs().sum() / res["3"][1].abs().sum()
         assert rel < 1e-5, (mode, rel)
+
+
+def _s1_trainer(cfg, direct, seed=0):
+    from dimo_amd.rasterizer import CapacityPolicy
+    from dimo_amd.renderer import Renderer
+    from dimo_amd.synth import init_synthetic_model
+    from dimo_amd.trainer import Trainer
+    rd = Renderer(sh_degree=0, num_latent_code=cfg.num_motions, add_normal=True, device="cuda",
+                  capacity=CapacityPolicy(initial=1 << 20) if direct else None)
+    init_synthetic_model(rd, cfg.num_pts, cfg.num_cpts, seed=seed, num_latent=cfg.num_motions)
+    g = rd.gaussians
+    # the shared log-radius create_from_pcd makes for stage s1 (renderer/latent_gs_renderer.py:449-451)
+    g._r = torch.nn.Parameter(g._scaling.detach().mean() * torch.ones(1, 1, device="cuda"))
+    tr = Trainer(cfg, rd, direct=direct)
+    assert tr.direct == direct
+    return tr, rd
+
+
+def test_stage_s1_direct_pipeline_equals_autograd_pipeline():
+    """Stage s1 (renderer/latent_gs_renderer.py:1176-1177, 1211-1212): the TimeNet moves every Gaussian itself and
+    every scale is exp(_r).  HIP path (dimo_timenet_forward on the N Gaussians, s1 deformation kernels, batched
+    rasterizer, fused losses) == the reference-shaped autograd path, including d loss / d _r, and the densification
+    statistics source (radii, d loss / d means2D of the step's last render)."""
+    from dimo_amd.trainer import TrainConfig
+    cfg = TrainConfig(num_pts=1500, num_cpts=64, num_motions=4, num_frames=6, num_views=4, motions_per_step=2,
+                      views_per_step=2, frames_per_step=2, resolution=96, stage="s1", FPS_iter=10 ** 9,
+                      density_end_iter=0)  # (outside the density window: the statistics source stays readable)
+    res = []
+    for direct in (False, True):
+        tr, rd = _s1_trainer(cfg, direct)
+        tr.optimizer.step = lambda *a, **k: None
+        rd.gaussians.zero_grad = lambda: None
+        tr.step = 300
+        tr.train_step(tr.sample())
+        torch.cuda.synchronize()
+        g = rd.gaussians
+        radii, g2d = tr._last_stats
+        res.append((tr.last_loss.item(), g.flat_grads.clone(), g._r.grad.clone(), g._xyz.grad.clone(),
+                    radii.clone(), g2d.clone()))
+    (la, ga, ra, xa, rada, g2a), (lb, gb, rb, xb, radb, g2b) = res
+    assert abs(la - lb) <= 1e-5 * abs(la), (la, lb)
+    assert (ga - gb).abs().sum() / ga.abs().sum() < 1e-4
+    assert abs(float(ra) - float(rb)) <= 1e-4 * abs(float(ra)) and float(ra) != 0.0
+    assert (xa - xb).abs().sum() / xa.abs().sum() < 1e-4
+    assert torch.equal(rada, radb)
+    assert (g2a - g2b).abs().sum() / g2a.abs().sum() < 1e-4
+
+
+def test_stage_s1_trains_across_fps_and_densification_on_the_hip_path():
+    """FPS at step 0 (num_pts -> num_cpts Gaussians), densification statistics from the executor's last slot, two
+    densify_and_prune calls (the flat buckets, FlatAdam moments, executor slots and the fused TimeNet follow the
+    changing Gaussian count), all without leaving the HIP pipeline."""
+    from dimo_amd.trainer import TrainConfig
+    cfg = TrainConfig(num_pts=2000, num_cpts=96, num_motions=3, num_frames=6, num_views=4, motions_per_step=2,
+                      views_per_step=2, frames_per_step=1, resolution=64, stage="s1", density_start_iter=1,
+                      densification_interval=2, densify_grad_threshold=1e-9, position_lr_max_steps=500)
+    tr, rd = _s1_trainer(cfg, True, seed=1)
+    g = rd.gaussians
+    sizes, losses = [], []
+    for _ in range(6):
+        tr.train_step()
+        sizes.append(g._xyz.shape[0])
+        losses.append(float(tr.last_loss))
+    torch.cuda.synchronize()
+    assert sizes[0] == 96 and sizes[-1] != 96, sizes
+    assert tr.direct and tr._exec.N == sizes[-1] or tr._exec.N == sizes[-2]
+    assert all(np.isfinite(losses)) and torch.isfinite(g.flat_params).all()
+    assert tr.skipped_steps == 0
+
+
+def test_direct_pipeline_follows_the_progressive_resolution():
+    """main_train_dimo.py:261: 128^2 -> 256^2 at step 300: the executor's slots, the camera cache and the resampled
+    targets follow the render size; direct pipeline == autograd pipeline on both sides of the change."""
+    from dimo_amd.rasterizer import CapacityPolicy
+    from dimo_amd.renderer import Renderer
+    from dimo_amd.synth import init_synthetic_model
+    from dimo_amd.trainer import TrainConfig, Trainer
+    cfg = TrainConfig(num_pts=3000, num_cpts=48, num_motions=3, num_frames=5, num_views=4, motions_per_step=2,
+                      views_per_step=2, frames_per_step=1, resolution=256)
+    res = []
+    for direct in (False, True):
+        rd = Renderer(sh_degree=0, num_latent_code=cfg.num_motions, add_normal=True, device="cuda",
+                      capacity=CapacityPolicy(initial=1 << 19) if direct else None)
+        init_synthetic_model(rd, cfg.num_pts, cfg.num_cpts, seed=0, num_latent=cfg.num_motions)
+        tr = Trainer(cfg, rd, direct=direct)
+        tr.optimizer.step = lambda *a, **k: None
+        sizes = []
+        tr.step = 298
+        for _ in range(2):  # steps 299 (128^2) and 300 (256^2)
+            rd.gaussians.zero_grad()
+            tr.train_step(tr.sample())
+            sizes.append(tr.render_resolution())
+            res.append((direct, tr.last_loss.item(), rd.gaussians.flat_grads.clone()))
+        assert sizes == [128, 256]
+        if direct:
+            assert tr._exec.H == 256
+    for i in range(2):
+        (_, la, ga), (_, lb, gb) = res[i], res[2 + i]
+        assert abs(la - lb) <= 1e-5 * abs(la), (i, la, lb)
+        assert (ga - gb).abs().sum() / ga.abs().sum() < 1e-4, i

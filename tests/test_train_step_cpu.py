@@ -201,3 +201,23 @@ def test_stage_s2_schedule_rules():
     tr.train_step()
     lr = {grp["name"]: grp["lr"] for grp in tr.optimizer.param_groups}
     assert lr["xyz"] != 0.0002 and abs(lr["xyz"] - tr.renderer.gaussians.xyz_scheduler_args(1000)) < 1e-12
+
+
+def test_progressive_render_resolution_rule():
+    """main_train_dimo.py:261,307-313: 128^2 while step < 300, 256^2 while step < 450, then full size; the targets are
+    resampled bilinearly to the render size."""
+    cfg = small_cfg(motions_per_step=1, resolution=512, num_pts=50)
+    tr = make_cpu_trainer(cfg)
+    got = []
+    for step in (1, 299, 300, 449, 450, 5000):
+        tr.step = step
+        got.append(tr.render_resolution())
+    assert got == [128, 128, 256, 256, 512, 512]
+    tr.step = 10
+    img, mask = tr.target(0, 1, 2)
+    full, fmask = tr.targets.get(0, 1, 2)
+    assert img.shape == (3, 128, 128) and mask.shape == (1, 128, 128) and full.shape == (3, 512, 512)
+    want = torch.nn.functional.interpolate(full[None], (128, 128), mode="bilinear", align_corners=False)[0]
+    assert torch.equal(img, want)
+    cfg2 = small_cfg(motions_per_step=1, resolution=96, num_pts=50)
+    assert make_cpu_trainer(cfg2).render_resolution() == 96  # never above the configured size
