@@ -207,16 +207,21 @@ __global__ void __launch_bounds__(256) ssim_bwd_kernel(int H, int W, int n_plane
 // and applies the window a second time.  Positions outside the image carry zero derivatives (the zero padding of
 // the backward convolution).
 constexpr int IS = HS + 2 * SR;  // 52: input halo edge
-__global__ void __launch_bounds__(256) ssim_fused_kernel(int H, int W, int n_planes, int clamp1, Window win,
+__global__ void __launch_bounds__(256, 3) ssim_fused_kernel(int H, int W, int n_planes, int clamp1, Window win,
                                                          const float *__restrict__ img1,
                                                          const float *__restrict__ img2,
                                                          const float *__restrict__ dL_dmean, float inv_numel,
                                                          float *__restrict__ ssim_sum, float *__restrict__ dL_dimg1) {
-  __shared__ float s_x[IS][IS + 1];
-  __shared__ float s_y[IS][IS + 1];
+  // 31 KB of LDS per workgroup (53 KB in round 1: three workgroups then owned ALL of a CU's LDS, and in the
+  // two-stream schedule no blend workgroup of the other motion could join them on that CU -- the kernel showed 200+ us
+  // there against 77 us alone).  The derivative planes live over the input planes, which are dead once every thread
+  // has taken its 24 x / y values into registers; x and y of the tile's own pixels are re-read from global at the end.
+  __shared__ float s_xy[2][IS][IS + 1];
   __shared__ float s_h[IS][HS + 1];      // horizontally filtered map (52 x 42); reused as 42 x 32 in the second pass
-  __shared__ float s_p[3][HS][HS + 1];   // derivative planes on the halo
   __shared__ float s_red[4];
+  static_assert(3 * HS * (HS + 1) <= 2 * IS * (IS + 1), "derivative planes must fit over the input planes");
+  float (*s_x)[IS + 1] = s_xy[0], (*s_y)[IS + 1] = s_xy[1];
+  float (*s_p)[HS][HS + 1] = reinterpret_cast<float (*)[HS][HS + 1]>(&s_xy[0][0][0]);  // derivative planes on the halo
   const int tid = threadIdx.x;
   const int tiles_x = (W + TS - 1) / TS, tiles_y = (H + TS - 1) / TS;
   const int total_tiles = tiles_x * tiles_y * n_planes;
@@ -311,8 +316,9 @@ __global__ void __launch_bounds__(256) ssim_fused_kernel(int H, int W, int n_pla
     for (int i = 0; i < 4; ++i) {
       const int gy = y0 + r0 + i;
       if (gx < W && gy < H) {
-        const float xv = s_x[r0 + i + 2 * SR][c + 2 * SR], yv = s_y[r0 + i + 2 * SR][c + 2 * SR];
-        dL_dimg1[(size_t)plane * H * W + (size_t)gy * W + gx] = (g[0][i] + 2.0f * xv * g[1][i] + yv * g[2][i]) * scale;
+        const size_t o = (size_t)gy * W + gx;
+        const float xv = maybe_clamp(p1[o], clamp1), yv = p2[o];
+        dL_dimg1[(size_t)plane * H * W + o] = (g[0][i] + 2.0f * xv * g[1][i] + yv * g[2][i]) * scale;
       }
     }
   }  // tiles

@@ -16,6 +16,7 @@ if "--no-calibration" not in sys.argv:
         dst = src.clone()  # vectorized copy kernel: 1 GiB in, 1 GiB out
     torch.cuda.synchronize()
 tr, pol = bench.make_trainer(dev, 0, 1, 100000, 512)
-for _ in range(4):
+steps = int(sys.argv[sys.argv.index("--steps") + 1]) if "--steps" in sys.argv else 4
+for _ in range(steps):
     tr.train_step()
 torch.cuda.synchronize()

@@ -15,5 +15,5 @@ for q in queues:
 for q in queues:
     print("--- queue", q)
     for s, e, n, _ in [x for x in step if x[3] == q]:
-        if e - s > 40000:
+        if e - s > (0 if len(sys.argv) > 2 else 15000):
             print(f"  {(s-t0)/1e3:8.1f} us  +{(e-s)/1e3:6.1f}  {n}")
