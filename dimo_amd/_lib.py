@@ -65,7 +65,7 @@ _SIGNATURES = {
     "dimo_selftest_wave_reduce16": (C.c_int, [c_ptr, c_ptr, c_ptr]),
     "dimo_debug_blend_trace": (C.c_int64, [c_ptr, C.c_int64]),
     "dimo_image_loss": (C.c_int, [C.c_int] * 3 + [c_ptr] * 6 + [C.c_int, C.POINTER(C.c_float)] + [C.c_float] * 5
-                        + [c_ptr] * 7),
+                        + [c_ptr] * 8),
 }
 
 ERRORS = {-1: "DIMO_E_ARG (bad argument)", -2: "DIMO_E_LAUNCH (HIP launch/runtime error)",

@@ -299,6 +299,7 @@ struct BwdView {  // one render's buffers as the backward sees them
   const float *dL_dcolor, *dL_ddepth, *dL_dnormal, *dL_dalpha;
   SplatGrad *inst_grad;
   uint8_t *inst_flag;
+  const float *dot;  // optional: per pixel sum over the channels of gradient x rendered value (= S below)
 };
 
 template <bool NORMAL>
@@ -342,10 +343,6 @@ __device__ __forceinline__ void blend_bwd_item(int H, int W, int tiles_x, uint32
     const bool inside = px < W && py < H;
     const uint32_t pix = inside ? (uint32_t)py * (uint32_t)W + (uint32_t)px : 0u;
     const uint32_t nc = r.n_contrib[pix];
-    float fa[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) fa[k] = r.final_acc[(uint32_t)k * HW32 + pix];
-    const float fT = r.final_T[pix];
     dp[q][0] = kc * pc[pix], dp[q][1] = kc * pc[HWc + pix], dp[q][2] = kc * pc[2u * HWc + pix];
     dp[q][3] = kd * pd[pix];
     dp[q][4] = kn * pn[pix], dp[q][5] = kn * pn[HWn + pix], dp[q][6] = kn * pn[2u * HWn + pix];
@@ -354,9 +351,20 @@ __device__ __forceinline__ void blend_bwd_item(int H, int W, int tiles_x, uint32
     const bool need = last[q] > blo0;
 #pragma unroll
     for (int k = 0; k < 8; ++k) dp[q][k] = need ? dp[q][k] : 0.0f;
-    float S = dp[q][7] * fa[7] + fT * (bg0 * dp[q][0] + bg1 * dp[q][1] + bg2 * dp[q][2]);
+    // S = dL/dout . (final accumulators) + final_T (bg . dL/dcolour) = sum over the channels of gradient x RENDERED
+    // value: the loss kernel hands it over as one plane (4 B per pixel); without it, from the forward's nine planes
+    float S;
+    if (r.dot) {  // wave-uniform
+      S = need ? r.dot[pix] : 0.0f;
+    } else {
+      float fa[8];
 #pragma unroll
-    for (int k = 0; k < (NORMAL ? 7 : 4); ++k) S += dp[q][k] * fa[k];
+      for (int k = 0; k < 8; ++k) fa[k] = r.final_acc[(uint32_t)k * HW32 + pix];
+      const float fT = r.final_T[pix];
+      S = dp[q][7] * fa[7] + fT * (bg0 * dp[q][0] + bg1 * dp[q][1] + bg2 * dp[q][2]);
+#pragma unroll
+      for (int k = 0; k < (NORMAL ? 7 : 4); ++k) S += dp[q][k] * fa[k];
+    }
     float P = 0.0f, Tq = 1.0f;
     if (!head) {  // wave-uniform
       const float *c = ck_item + (uint32_t)(q * 64 + lane);  // the forward's thread index = quadrant * 64 + lane
@@ -592,7 +600,7 @@ struct BatchView {
                    at<float>(r.img, o.final_acc),    at<float>(r.bin, o.ckpt),         at<uint32_t>(r.bin, o.work),
                    r.g_color,                        r.g_depth,                        NORMAL ? r.g_normal : nullptr,
                    r.g_alpha,                        reinterpret_cast<SplatGrad *>(r.bwd_scratch),
-                   at<uint8_t>(r.bwd_scratch, o.flag)};
+                   at<uint8_t>(r.bwd_scratch, o.flag), r.g_dot};
   }
 };
 template <bool NORMAL>
@@ -784,7 +792,7 @@ extern "C" int dimo_raster_backward(int N, int sh_degree, int M, int H, int W, i
     SingleView sv{BwdView{at<uint32_t>(bin, B.vals_b), at<Splat>(geom, G.splat), at<uint16_t>(geom, G.rect),
                           at<uint32_t>(geom, G.offsets), at<float>(img, I.final_T), at<uint32_t>(img, I.n_contrib),
                           at<float>(img, I.final_acc), at<float>(bin, B.ckpt), at<uint32_t>(bin, B.work), dL_dcolor,
-                          dL_ddepth, dL_dnormal, dL_dalpha, inst, inst_flag}};
+                          dL_ddepth, dL_dnormal, dL_dalpha, inst, inst_flag, nullptr}};
     if (dL_dnormal)
       hipLaunchKernelGGL(blend_bwd_kernel<true>, dim3(BWD_GRID), dim3(64), 0, stream, H, W, B.tiles_x, cap, bg, sv);
     else

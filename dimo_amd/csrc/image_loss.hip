@@ -78,7 +78,7 @@ __global__ void __launch_bounds__(256) image_loss_kernel(
     const float *__restrict__ normal, const float *__restrict__ alpha, const float *__restrict__ gt,
     const float *__restrict__ mask, size_t mask_stride, const float *__restrict__ ssim_grad,
     float *__restrict__ loss_out, float *__restrict__ g_image, float *__restrict__ g_depth,
-    float *__restrict__ g_normal, float *__restrict__ g_alpha) {
+    float *__restrict__ g_normal, float *__restrict__ g_alpha, float *__restrict__ g_dot) {
   __shared__ float s_red[4];
   const size_t HW = (size_t)H * W;
   float loss = 0.0f;
@@ -106,6 +106,7 @@ __global__ void __launch_bounds__(256) image_loss_kernel(
     const float em = a - mask[(size_t)b * mask_stride + pix];
     loss += prm.w_mask * em * em;
     g_alpha[(size_t)b * HW + pix] = 2.0f * prm.w_mask * em;
+    float dot = 2.0f * prm.w_mask * em * a;  // sum over the channels of gradient x rendered value (see g_dot)
     // stencil terms.  The four neighbours are loaded UNCONDITIONALLY (clamped to the pixel itself at the image
     // border, where the pair's weights are zero): a branch around each neighbour's loads made the compiler wait for
     // them one after the other -- four dependent memory round trips per pixel.
@@ -125,13 +126,16 @@ __global__ void __launch_bounds__(256) image_loss_kernel(
       float g = gc[k];
       if (ssim_grad) g += ssim_grad[(size_t)b * 3 * HW + k * HW + pix];
       const float raw = img[k * HW + pix];
-      g_image[(size_t)b * 3 * HW + k * HW + pix] = (raw >= 0.0f && raw <= 1.0f) ? g : 0.0f;  // clamp backward
+      g = (raw >= 0.0f && raw <= 1.0f) ? g : 0.0f;  // clamp backward
+      g_image[(size_t)b * 3 * HW + k * HW + pix] = g;
+      dot += g * raw;
     }
-    if (g_depth) g_depth[(size_t)b * HW + pix] = gd;
+    if (g_depth) g_depth[(size_t)b * HW + pix] = gd, dot += gd * P.d;
     if (NORMAL) {
 #pragma unroll
-      for (int k = 0; k < 3; ++k) g_normal[(size_t)b * 3 * HW + k * HW + pix] = gn[k];
+      for (int k = 0; k < 3; ++k) g_normal[(size_t)b * 3 * HW + k * HW + pix] = gn[k], dot += gn[k] * P.n[k];
     }
+    if (g_dot) g_dot[(size_t)b * HW + pix] = dot;
   }
   }  // tiles
   float v = loss;
@@ -150,7 +154,8 @@ extern "C" int dimo_image_loss(int B, int H, int W, const float *image, const fl
                                const float *alpha, const float *gt, const float *mask, int mask_per_image,
                                const float *w_mse_host, float w_mask, float w_smooth_x, float w_smooth_y,
                                float w_bilat_x, float w_bilat_y, const float *ssim_grad, float *loss_accum,
-                               float *g_image, float *g_depth, float *g_normal, float *g_alpha, void *stream_) {
+                               float *g_image, float *g_depth, float *g_normal, float *g_alpha, float *g_dot,
+                               void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   clear_errors();
   if (B < 0 || B > LOSS_MAX_B || H <= 0 || W <= 0) return DIMO_E_ARG;
@@ -167,7 +172,7 @@ extern "C" int dimo_image_loss(int B, int H, int W, const float *image, const fl
   ScopedTimer tm(T_LOSS, stream);
 #define DIMO_LAUNCH_LOSS(D, N)                                                                                  \
   hipLaunchKernelGGL((image_loss_kernel<D, N>), grid, block, 0, stream, H, W, B, prm, image, depth, normal, alpha, \
-                     gt, mask, mstride, ssim_grad, loss_accum, g_image, g_depth, g_normal, g_alpha)
+                     gt, mask, mstride, ssim_grad, loss_accum, g_image, g_depth, g_normal, g_alpha, g_dot)
   if (depth && normal) DIMO_LAUNCH_LOSS(true, true);
   else if (depth) DIMO_LAUNCH_LOSS(true, false);
   else if (normal) DIMO_LAUNCH_LOSS(false, true);

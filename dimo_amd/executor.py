@@ -35,7 +35,7 @@ class RenderDesc(C.Structure):
                 ("pts", _fp), ("rot", _fp), ("scales", _fp), ("opac", _fp), ("radii", _vp),
                 ("geom", _vp), ("bin", _vp), ("img", _vp), ("bwd_scratch", _vp),
                 ("g_means3D", _fp), ("g_means2D", _fp), ("g_shs", _fp), ("g_opac", _fp), ("g_scales", _fp),
-                ("g_rot", _fp)]
+                ("g_rot", _fp), ("g_dot", _fp)]
 
 
 class StepExecutor:

@@ -596,7 +596,7 @@ class Trainer:
             loss_bufs[m] = (torch.empty_like(img), torch.empty_like(img),
                             torch.empty_like(depth) if depth_on else None,
                             torch.empty_like(normal) if (normal_on and normal is not None) else None,
-                            torch.empty_like(alpha))
+                            torch.empty_like(alpha), torch.empty_like(alpha))  # (last: the backward's per-pixel S)
         if ex.ranged:  # one batch per motion, on alternating private streams
             for m, trs in by_motion.items():
                 ex.forward_range(first[m], len(trs))
@@ -627,7 +627,9 @@ class Trainer:
             # SSIM on the clamped render; its gradient image feeds the loss kernel
             ssum = ssums[len(ssim_terms):len(ssim_terms) + 1]  # zeroed with the step's other accumulators
             coef = self._const(-c.lambda_ssim * share)
-            ssim_grad, *grad_out = loss_bufs[m]
+            ssim_grad, *grad_out, g_dot = loss_bufs[m]
+            if c.use_lpips:  # the LPIPS gradient is added to g_image afterwards: S would be stale
+                g_dot = None
             _lib.check(L.dimo_ssim_forward_backward(B, 3, H, W, 1 | 2, _lib.ptr(img), _lib.ptr(gt), _lib.ptr(coef),
                                                     _lib.ptr(ssum), _lib.ptr(ssim_grad), stream_m),
                        "dimo_ssim_forward_backward")
@@ -636,8 +638,8 @@ class Trainer:
             gi, gd, gn, ga = fused_image_loss(img, depth if depth_on else None, normal if normal_on else None,
                                               alpha, gt, mask, w_mse,
                                               loss_weights(c, B, n_img, H, W, depth_on, normal_on), ssim_grad,
-                                              loss_accum, out=tuple(grad_out), stream=stream_m)
-            keep.append((gi, gd, gn, ga, ssim_grad))
+                                              loss_accum, out=tuple(grad_out), stream=stream_m, g_dot=g_dot)
+            keep.append((gi, gd, gn, ga, ssim_grad, g_dot))
             if c.use_lpips:  # torch (MIOpen) on this stream, on the clamped render; its gradient joins the image's
                 x = img.detach().clamp(0.0, 1.0).requires_grad_(True)
                 lp = c.lambda_lpips * share * self.lpips_metric()(x, gt).mean()
@@ -649,6 +651,7 @@ class Trainer:
                 d.g_color, d.g_alpha = gi.data_ptr() + b * 3 * HW4, ga.data_ptr() + b * HW4
                 d.g_depth = (gd.data_ptr() + b * HW4) if gd is not None else None
                 d.g_normal = (gn.data_ptr() + b * 3 * HW4) if gn is not None else None
+                d.g_dot = (g_dot.data_ptr() + b * HW4) if g_dot is not None else None
             if own is not None:
                 ex.backward_launch_in_order(first[m], B)
             elif ex.ranged or not ex.batched:

@@ -169,12 +169,15 @@ int dimo_ssim_forward_backward(int B, int C, int H, int W, int clamp_img1, const
  * g_image/g_depth/g_normal/g_alpha receive dloss/d(raw rasterizer outputs); ssim_grad (optional, [B,3,H,W],
  * w.r.t. the clamped image) is added before the clamp mask.  image[B,3,H,W] depth[B,1,H,W]|NULL
  * normal[B,3,H,W]|NULL alpha[B,1,H,W] gt[B,3,H,W] mask[B,1,H,W] (mask_per_image != 0) or [1,H,W] shared.
- * w_mse_host: B floats on the HOST (passed by value to the kernel).  loss_accum: 1 device float, added to. */
+ * w_mse_host: B floats on the HOST (passed by value to the kernel).  loss_accum: 1 device float, added to.
+ * g_dot (optional, [B,1,H,W]): per pixel sum over the channels of gradient x rendered value -- the rasterizer backward's
+ * "S" (dimo_render_desc.g_dot): with it the blend backward reads 4 bytes per pixel instead of the nine final
+ * accumulator planes. */
 int dimo_image_loss(int B, int H, int W, const float *image, const float *depth, const float *normal,
                     const float *alpha, const float *gt, const float *mask, int mask_per_image,
                     const float *w_mse_host, float w_mask, float w_smooth_x, float w_smooth_y, float w_bilat_x,
                     float w_bilat_y, const float *ssim_grad, float *loss_accum, float *g_image, float *g_depth,
-                    float *g_normal, float *g_alpha, void *stream);
+                    float *g_normal, float *g_alpha, float *g_dot, void *stream);
 
 /* ------------------------------------------------------------------ fused skinning (stage s2 of Renderer.render)
  * One kernel for renderer/latent_gs_renderer.py:1187-1219: LBS weights w_k = L1norm(exp(-d_k^2/(2 r_k^2)) + 1e-7),
@@ -302,6 +305,9 @@ typedef struct {
   int32_t *radii;
   void *geom, *bin, *img, *bwd_scratch;
   float *g_means3D, *g_means2D, *g_shs, *g_opac, *g_scales, *g_rot;
+  /* optional [H,W]: sum over the output channels of (gradient image x rendered image) per pixel, as dimo_image_loss
+   * emits it; NULL: the blend backward forms it from the forward's final accumulators */
+  const float *g_dot;
 } dimo_render_desc;
 
 /* n_streams > 0: per-render chains on that many private streams (render i on stream i % n).

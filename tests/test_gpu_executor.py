@@ -95,6 +95,13 @@ def _run_batched(N, res, renders_per_motion, n_motions, seed=0, streams="-2", mo
             radii=cpu(s["radii"]), cam=cams[i], color=cpu(img[i]), depth=cpu(depth[i]), normal=cpu(normal[i]),
             alpha=cpu(alpha[i]),
             st={k: cpu(v) for k, v in inspect_state((s["geom"], s["bin"], s["img"]), N, H, W, ex.r_cap).items()}))
+    # the optional per-pixel S plane (sum over the channels of gradient x rendered value, what dimo_image_loss emits):
+    # handed to the second half of the renders, the first half lets the kernel form S from the final accumulators
+    dot = ((grads[0] * img).sum(1, keepdim=True) + grads[1] * depth + (grads[2] * normal).sum(1, keepdim=True)
+           + grads[3] * alpha).contiguous()
+    for i in range(n // 2, n):
+        ex.descs[i].g_dot = dot.data_ptr() + i * HW4
+    torch.cuda.synchronize()
     for first in firsts:
         if ex.ranged:
             ex.backward_launch_in_order(first, renders_per_motion)
