@@ -21,11 +21,27 @@ constexpr int KNN_CHUNK = 1024;   // reference points staged per LDS round (16 K
 // is a finite non-negative double (a zero distance gives a subnormal, which v_min/max_f64 order correctly; f64
 // denormals are never flushed on gfx9).  Inserting a candidate is then a branch-free 7-instruction min/max chain
 // instead of a divergent compare-and-swap ladder.
-__global__ void __launch_bounds__(KNN_BLOCK) knn4_kernel(int M, int N, int k, const float *__restrict__ ref,
-                                                         const float *__restrict__ query, float *__restrict__ dist,
-                                                         int64_t *__restrict__ idx) {
+// Four waves share 64 queries: wave w scans every fourth chunk-quarter of the references and keeps its own four
+// best keys; the keys order totally (distance bits, then index), so the four partial lists merge into the same
+// result in any order.  (One wave per 64 queries scanned all 512 references: 1563 waves for 1024 SIMDs, each a
+// dependent chain of 512 x 17 instructions -- 47 us of mostly latency at the head of every training step.)
+constexpr int KNN4_WAVES = 4;
+__device__ __forceinline__ void knn4_insert(double &b0, double &b1, double &b2, double &b3, double key) {
+  const double r0 = fmax(b0, key);
+  b0 = fmin(b0, key);
+  const double r1 = fmax(b1, r0);
+  b1 = fmin(b1, r0);
+  const double r2 = fmax(b2, r1);
+  b2 = fmin(b2, r1);
+  b3 = fmin(b3, r2);
+}
+__global__ void __launch_bounds__(KNN_BLOCK *KNN4_WAVES) knn4_kernel(int M, int N, int k, const float *__restrict__ ref,
+                                                                      const float *__restrict__ query,
+                                                                      float *__restrict__ dist, int64_t *__restrict__ idx) {
   __shared__ float4 s_ref[KNN_CHUNK];
-  const int i = blockIdx.x * KNN_BLOCK + threadIdx.x;
+  __shared__ double s_best[KNN4_WAVES][4][KNN_BLOCK];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = blockIdx.x * KNN_BLOCK + lane;
   float qx = 0, qy = 0, qz = 0;
   if (i < N) qx = query[3 * i], qy = query[3 * i + 1], qz = query[3 * i + 2];
   const double empty = __longlong_as_double((long long)(((unsigned long long)__float_as_uint(INFINITY) << 32) | 0xffffffffull));
@@ -33,26 +49,28 @@ __global__ void __launch_bounds__(KNN_BLOCK) knn4_kernel(int M, int N, int k, co
   for (int base = 0; base < M; base += KNN_CHUNK) {
     const int cnt = min(KNN_CHUNK, M - base);
     __syncthreads();
-    for (int t = threadIdx.x; t < cnt; t += KNN_BLOCK) {
+    for (int t = threadIdx.x; t < cnt; t += KNN_BLOCK * KNN4_WAVES) {
       const float *r = ref + (size_t)(base + t) * 3;
       s_ref[t] = make_float4(r[0], r[1], r[2], 0.0f);
     }
     __syncthreads();
+    const int per = (cnt + KNN4_WAVES - 1) / KNN4_WAVES;
+    const int m0 = wave * per, m1 = min(cnt, m0 + per);
 #pragma unroll 4
-    for (int m = 0; m < cnt; ++m) {
+    for (int m = m0; m < m1; ++m) {
       const float4 c = s_ref[m];
       const float dx = qx - c.x, dy = qy - c.y, dz = qz - c.z;
       const float d2 = dx * dx + dy * dy + dz * dz;
-      const double key = __hiloint2double((int)__float_as_uint(d2), base + m);
-      const double r0 = fmax(b0, key);
-      b0 = fmin(b0, key);
-      const double r1 = fmax(b1, r0);
-      b1 = fmin(b1, r0);
-      const double r2 = fmax(b2, r1);
-      b2 = fmin(b2, r1);
-      b3 = fmin(b3, r2);
+      knn4_insert(b0, b1, b2, b3, __hiloint2double((int)__float_as_uint(d2), base + m));
     }
   }
+  s_best[wave][0][lane] = b0, s_best[wave][1][lane] = b1, s_best[wave][2][lane] = b2, s_best[wave][3][lane] = b3;
+  __syncthreads();
+  if (wave != 0) return;
+#pragma unroll
+  for (int w = 1; w < KNN4_WAVES; ++w)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) knn4_insert(b0, b1, b2, b3, s_best[w][j][lane]);
   if (i < N) {
     const double b[4] = {b0, b1, b2, b3};
 #pragma unroll
@@ -157,7 +175,7 @@ extern "C" int dimo_knn(int M, int N, int k, const float *ref, const float *quer
   const dim3 grid((N + KNN_BLOCK - 1) / KNN_BLOCK), block(KNN_BLOCK);
   ScopedTimer tm(T_KNN, stream);
   if (k <= 4)
-    hipLaunchKernelGGL(knn4_kernel, grid, block, 0, stream, M, N, k, ref, query, dist, idx);
+    hipLaunchKernelGGL(knn4_kernel, grid, dim3(KNN_BLOCK * KNN4_WAVES), 0, stream, M, N, k, ref, query, dist, idx);
   else if (k <= 8)
     hipLaunchKernelGGL(knn_kernel<8>, grid, block, 0, stream, M, N, k, ref, query, dist, idx);
   else
