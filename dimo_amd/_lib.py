@@ -44,6 +44,7 @@ _SIGNATURES = {
     "dimo_ssim_forward": (C.c_int, [C.c_int] * 5 + [c_ptr] * 5),
     "dimo_ssim_backward": (C.c_int, [C.c_int] * 5 + [c_ptr] * 6),
     "dimo_ssim_forward_backward": (C.c_int, [C.c_int] * 5 + [c_ptr] * 6),
+    "dimo_ssim_forward_backward_images": (C.c_int, [C.c_int] * 5 + [c_ptr, C.POINTER(C.c_void_p)] + [c_ptr] * 4),
     "dimo_timenet_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
     "dimo_timenet_forward": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_ptr, C.c_void_p, c_ptr, C.c_void_p, c_ptr, c_ptr,
                                        c_ptr, C.c_size_t, c_ptr]),
@@ -65,7 +66,7 @@ _SIGNATURES = {
     "dimo_selftest_wave_reduce16": (C.c_int, [c_ptr, c_ptr, c_ptr]),
     "dimo_debug_blend_trace": (C.c_int64, [c_ptr, C.c_int64]),
     "dimo_image_loss": (C.c_int, [C.c_int] * 3 + [c_ptr] * 6 + [C.c_int, C.POINTER(C.c_float)] + [C.c_float] * 5
-                        + [c_ptr] * 8),
+                        + [c_ptr] * 7 + [C.POINTER(C.c_void_p)] * 2 + [c_ptr]),
 }
 
 ERRORS = {-1: "DIMO_E_ARG (bad argument)", -2: "DIMO_E_LAUNCH (HIP launch/runtime error)",
@@ -107,6 +108,14 @@ def check(rc, what):
 def ptr(t):
     """Device pointer of a (contiguous) tensor or None."""
     return None if t is None else t.data_ptr()
+
+
+def ptr_array(tensors):
+    """HOST array of the device pointers of a list of contiguous fp32 tensors (for the *_images_host arguments)."""
+    for t in tensors:
+        if not (t.is_cuda and t.is_contiguous() and t.dtype.is_floating_point and t.element_size() == 4):
+            raise ValueError("contiguous fp32 GPU tensors expected")
+    return (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
 
 
 def current_stream():

@@ -19,6 +19,10 @@ struct LossParams {
   float w_mask;             // lambda_mask * share / (B H W)
   float w_smooth_x, w_smooth_y;   // lambda_smooth * share / (B H (W-1)) , / (B (H-1) W)
   float w_bilat_x, w_bilat_y;     // lambda_bilateral * share / (3 B H (W-1)) , / (3 B (H-1) W)
+  // optional per-image base pointers of the targets / masks (null: one contiguous gt / mask tensor): the batch's
+  // targets live in a resident pool, one tensor per image -- no stacking copies at the head of the step
+  const float *gt_image[LOSS_MAX_B];
+  const float *mask_image[LOSS_MAX_B];
 };
 
 struct Px {
@@ -98,12 +102,13 @@ __global__ void __launch_bounds__(256) image_loss_kernel(
     const float wm = prm.w_mse[b];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      const float e = P.c[k] - gt[(size_t)b * 3 * HW + k * HW + pix];
+      const float *gtb = prm.gt_image[b] ? prm.gt_image[b] : gt + (size_t)b * 3 * HW;
+      const float e = P.c[k] - gtb[k * HW + pix];
       loss += wm * e * e;
       gc[k] += 2.0f * wm * e;
     }
     const float a = alpha[(size_t)b * HW + pix];
-    const float em = a - mask[(size_t)b * mask_stride + pix];
+    const float em = a - (prm.mask_image[b] ? prm.mask_image[b][pix] : mask[(size_t)b * mask_stride + pix]);
     loss += prm.w_mask * em * em;
     g_alpha[(size_t)b * HW + pix] = 2.0f * prm.w_mask * em;
     float dot = 2.0f * prm.w_mask * em * a;  // sum over the channels of gradient x rendered value (see g_dot)
@@ -155,15 +160,23 @@ extern "C" int dimo_image_loss(int B, int H, int W, const float *image, const fl
                                const float *w_mse_host, float w_mask, float w_smooth_x, float w_smooth_y,
                                float w_bilat_x, float w_bilat_y, const float *ssim_grad, float *loss_accum,
                                float *g_image, float *g_depth, float *g_normal, float *g_alpha, float *g_dot,
+                               const float *const *gt_images_host, const float *const *mask_images_host,
                                void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   clear_errors();
   if (B < 0 || B > LOSS_MAX_B || H <= 0 || W <= 0) return DIMO_E_ARG;
   if (B == 0) return DIMO_OK;
-  if (!image || !alpha || !gt || !mask || !w_mse_host || !loss_accum || !g_image || !g_alpha) return DIMO_E_ARG;
+  if (!image || !alpha || (!gt && !gt_images_host) || (!mask && !mask_images_host) || !w_mse_host || !loss_accum ||
+      !g_image || !g_alpha)
+    return DIMO_E_ARG;
   if ((depth == nullptr) != (g_depth == nullptr) || (normal == nullptr) != (g_normal == nullptr)) return DIMO_E_ARG;
   LossParams prm;
-  for (int b = 0; b < LOSS_MAX_B; ++b) prm.w_mse[b] = b < B ? w_mse_host[b] : 0.0f;
+  for (int b = 0; b < LOSS_MAX_B; ++b) {
+    prm.w_mse[b] = b < B ? w_mse_host[b] : 0.0f;
+    prm.gt_image[b] = (gt_images_host && b < B) ? gt_images_host[b] : nullptr;
+    prm.mask_image[b] = (mask_images_host && b < B) ? mask_images_host[b] : nullptr;
+    if (b < B && ((gt_images_host && !prm.gt_image[b]) || (mask_images_host && !prm.mask_image[b]))) return DIMO_E_ARG;
+  }
   prm.w_mask = w_mask, prm.w_smooth_x = w_smooth_x, prm.w_smooth_y = w_smooth_y;
   prm.w_bilat_x = w_bilat_x, prm.w_bilat_y = w_bilat_y;
   const long tiles = (long)((W + 31) / 32) * ((H + 7) / 8) * B;

@@ -207,9 +207,16 @@ __global__ void __launch_bounds__(256) ssim_bwd_kernel(int H, int W, int n_plane
 // and applies the window a second time.  Positions outside the image carry zero derivatives (the zero padding of
 // the backward convolution).
 constexpr int IS = HS + 2 * SR;  // 52: input halo edge
+// Optional per-image base pointers of img2 (the targets of a batch live in a resident pool, one tensor per image:
+// stacking them cost two copy kernels per motion at the head of every step).  n == 0: img2 is one contiguous tensor.
+constexpr int SSIM_MAX_IMAGES = 32;
+struct ImagePtrs {
+  int n, channels;
+  const float *p[SSIM_MAX_IMAGES];
+};
 __global__ void __launch_bounds__(256, 3) ssim_fused_kernel(int H, int W, int n_planes, int clamp1, Window win,
                                                          const float *__restrict__ img1,
-                                                         const float *__restrict__ img2,
+                                                         const float *__restrict__ img2, ImagePtrs img2_images,
                                                          const float *__restrict__ dL_dmean, float inv_numel,
                                                          float *__restrict__ ssim_sum, float *__restrict__ dL_dimg1) {
   // 31 KB of LDS per workgroup (53 KB in round 1: three workgroups then owned ALL of a CU's LDS, and in the
@@ -240,7 +247,9 @@ __global__ void __launch_bounds__(256, 3) ssim_fused_kernel(int H, int W, int n_
     const int plane = tile / (tiles_x * tiles_y);
     const int x0 = (tile % tiles_x) * TS, y0 = ((tile / tiles_x) % tiles_y) * TS;
     const float *p1 = img1 + (size_t)plane * H * W;
-    const float *p2 = img2 + (size_t)plane * H * W;
+    const float *p2 = img2_images.n ? img2_images.p[plane / img2_images.channels] +
+                                          (size_t)(plane % img2_images.channels) * H * W
+                                    : img2 + (size_t)plane * H * W;
     __syncthreads();  // the previous tile's LDS has been consumed
     for (int t = tid; t < IS * IS; t += 256) {
       const int hy = t / IS, hx = t - hy * IS;
@@ -369,9 +378,24 @@ extern "C" int dimo_ssim_backward(int B, int C, int H, int W, int clamp_img1, co
   return check_launch();
 }
 
+static int ssim_forward_backward_impl(int B, int C, int H, int W, int clamp_img1, const float *img1, const float *img2,
+                                      const float *const *img2_images_host, const float *dL_dmean, float *ssim_sum,
+                                      float *dL_dimg1, void *stream_);
 extern "C" int dimo_ssim_forward_backward(int B, int C, int H, int W, int clamp_img1, const float *img1,
                                           const float *img2, const float *dL_dmean, float *ssim_sum, float *dL_dimg1,
                                           void *stream_) {
+  return ssim_forward_backward_impl(B, C, H, W, clamp_img1, img1, img2, nullptr, dL_dmean, ssim_sum, dL_dimg1, stream_);
+}
+extern "C" int dimo_ssim_forward_backward_images(int B, int C, int H, int W, int clamp_img1, const float *img1,
+                                                 const float *const *img2_images_host, const float *dL_dmean,
+                                                 float *ssim_sum, float *dL_dimg1, void *stream_) {
+  if (!img2_images_host || B > SSIM_MAX_IMAGES) return DIMO_E_ARG;
+  return ssim_forward_backward_impl(B, C, H, W, clamp_img1, img1, nullptr, img2_images_host, dL_dmean, ssim_sum,
+                                    dL_dimg1, stream_);
+}
+static int ssim_forward_backward_impl(int B, int C, int H, int W, int clamp_img1, const float *img1, const float *img2,
+                                      const float *const *img2_images_host, const float *dL_dmean, float *ssim_sum,
+                                      float *dL_dimg1, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   clear_errors();
   if (B < 0 || C < 0 || H <= 0 || W <= 0 || !ssim_sum) return DIMO_E_ARG;
@@ -382,12 +406,17 @@ extern "C" int dimo_ssim_forward_backward(int B, int C, int H, int W, int clamp_
   if (!prezeroed && hipMemsetAsync(ssim_sum, 0, sizeof(float), stream) != hipSuccess) return DIMO_E_LAUNCH;
   const long planes = (long)B * C;
   if (planes == 0) return DIMO_OK;
-  if (!img1 || !img2 || !dL_dmean || !dL_dimg1 || planes > 65535) return DIMO_E_ARG;
+  if (!img1 || (!img2 && !img2_images_host) || !dL_dmean || !dL_dimg1 || planes > 65535) return DIMO_E_ARG;
+  ImagePtrs ptrs;
+  ptrs.n = img2_images_host ? B : 0, ptrs.channels = C > 0 ? C : 1;
+  for (int b = 0; b < SSIM_MAX_IMAGES; ++b) ptrs.p[b] = (img2_images_host && b < B) ? img2_images_host[b] : nullptr;
+  for (int b = 0; b < ptrs.n; ++b)
+    if (!ptrs.p[b]) return DIMO_E_ARG;
   static const Window win = make_window();
   const long tiles = (long)((W + TS - 1) / TS) * ((H + TS - 1) / TS) * planes;
   const dim3 grid((unsigned)(tiles < 4096 ? tiles : 4096)), block(256);
   ScopedTimer tm(T_SSIM_FWD, stream);
-  hipLaunchKernelGGL(ssim_fused_kernel, grid, block, 0, stream, H, W, (int)planes, clamp_img1, win, img1, img2,
+  hipLaunchKernelGGL(ssim_fused_kernel, grid, block, 0, stream, H, W, (int)planes, clamp_img1, win, img1, img2, ptrs,
                      dL_dmean, 1.0f / (float)((double)planes * H * W), ssim_sum, dL_dimg1);
   return check_launch();
 }

@@ -28,7 +28,8 @@ def loss_weights(cfg, n_local, n_img, H, W, depth_on=None, normal_on=None):
 def fused_image_loss(image, depth, normal, alpha, gt, mask, w_mse, weights, ssim_grad, loss_accum, out=None,
                      stream=None, g_dot=None):
     """image[B,3,H,W] (raw, unclamped) depth[B,1,H,W]|None normal[B,3,H,W]|None alpha[B,1,H,W] gt[B,3,H,W]
-    mask [1,H,W] (shared) or [B,1,H,W]; w_mse: python list of B floats (already divided by 3HW).
+    mask [1,H,W] (shared) or [B,1,H,W] -- or `gt` / `mask` as LISTS of B separate [3,H,W] / [1,H,W] tensors (no
+    stacking copy); w_mse: python list of B floats (already divided by 3HW).
     Adds the loss to `loss_accum` (1 float) and returns (g_image, g_depth|None, g_normal|None, g_alpha).
     `stream`: raw stream handle to launch on (default: torch's current stream).  `g_dot` (optional [B,1,H,W]):
     receives sum_channels(gradient x rendered value) per pixel for the rasterizer backward."""
@@ -42,13 +43,18 @@ def fused_image_loss(image, depth, normal, alpha, gt, mask, w_mse, weights, ssim
         g_normal = new(normal) if normal is not None else None
     else:
         g_image, g_depth, g_normal, g_alpha = out
-    per_image = 1 if (mask.dim() == 4 and mask.shape[0] == B and B > 1) else 0
+    gt_list = mask_list = None
+    if isinstance(gt, (list, tuple)):
+        gt_list, gt = _lib.ptr_array(gt), None
+    if isinstance(mask, (list, tuple)):
+        mask_list, mask = _lib.ptr_array(mask), None
+    per_image = 1 if (mask is not None and mask.dim() == 4 and mask.shape[0] == B and B > 1) else 0
     w_arr = (C.c_float * B)(*w_mse)
     _lib.check(_lib.lib().dimo_image_loss(
         B, H, W, _lib.ptr(image), _lib.ptr(depth), _lib.ptr(normal), _lib.ptr(alpha), _lib.ptr(gt), _lib.ptr(mask),
         per_image, w_arr, weights["w_mask"], weights["w_smooth_x"], weights["w_smooth_y"], weights["w_bilat_x"],
         weights["w_bilat_y"], _lib.ptr(ssim_grad), _lib.ptr(loss_accum), _lib.ptr(g_image), _lib.ptr(g_depth),
-        _lib.ptr(g_normal), _lib.ptr(g_alpha), _lib.ptr(g_dot),
+        _lib.ptr(g_normal), _lib.ptr(g_alpha), _lib.ptr(g_dot), gt_list, mask_list,
         stream if stream is not None else _lib.current_stream()),
         "dimo_image_loss")
     return g_image, g_depth, g_normal, g_alpha

@@ -584,8 +584,9 @@ class Trainer:
         gathered = {}
         for m, trs in by_motion.items():
             gts = [self.target(*t) for t in trs]
-            # one mask per image (source_masks[motion][view][frame], main_train_dimo.py:284): [B, 1, H, W]
-            gathered[m] = (torch.stack([x[0] for x in gts]), torch.stack([x[1] for x in gts]))
+            # one target and one mask per image (source_masks[motion][view][frame], main_train_dimo.py:284), handed to
+            # the loss kernels as pointer lists: the pool's tensors are not stacked (4 copy kernels per step before)
+            gathered[m] = ([x[0].contiguous() for x in gts], [x[1].contiguous() for x in gts])
             self._const(-c.lambda_ssim * (len(trs) / n_img))
         # ... and every buffer the loss kernels write is allocated here, BEFORE the forks: memory handed out later could
         # be a block whose last use is a kernel still pending on this stream, which a private stream would not wait for
@@ -630,9 +631,14 @@ class Trainer:
             ssim_grad, *grad_out, g_dot = loss_bufs[m]
             if c.use_lpips:  # the LPIPS gradient is added to g_image afterwards: S would be stale
                 g_dot = None
-            _lib.check(L.dimo_ssim_forward_backward(B, 3, H, W, 1 | 2, _lib.ptr(img), _lib.ptr(gt), _lib.ptr(coef),
-                                                    _lib.ptr(ssum), _lib.ptr(ssim_grad), stream_m),
-                       "dimo_ssim_forward_backward")
+            if B <= 32:
+                _lib.check(L.dimo_ssim_forward_backward_images(B, 3, H, W, 1 | 2, _lib.ptr(img), _lib.ptr_array(gt),
+                                                               _lib.ptr(coef), _lib.ptr(ssum), _lib.ptr(ssim_grad),
+                                                               stream_m), "dimo_ssim_forward_backward_images")
+            else:
+                _lib.check(L.dimo_ssim_forward_backward(B, 3, H, W, 1 | 2, _lib.ptr(img), _lib.ptr(torch.stack(gt)),
+                                                        _lib.ptr(coef), _lib.ptr(ssum), _lib.ptr(ssim_grad), stream_m),
+                           "dimo_ssim_forward_backward")
             ssim_terms.append((ssum, c.lambda_ssim * share, float(B * 3 * H * W)))
             w_mse = [c.lambda_mse * (1.0 if (v == 0 or f == 0) else 0.5) / (3 * H * W) for (_m, v, f) in trs]
             gi, gd, gn, ga = fused_image_loss(img, depth if depth_on else None, normal if normal_on else None,
@@ -642,7 +648,7 @@ class Trainer:
             keep.append((gi, gd, gn, ga, ssim_grad, g_dot))
             if c.use_lpips:  # torch (MIOpen) on this stream, on the clamped render; its gradient joins the image's
                 x = img.detach().clamp(0.0, 1.0).requires_grad_(True)
-                lp = c.lambda_lpips * share * self.lpips_metric()(x, gt).mean()
+                lp = c.lambda_lpips * share * self.lpips_metric()(x, torch.stack(gt)).mean()
                 (g_lp,) = torch.autograd.grad(lp, x)
                 gi.add_(g_lp * ((img >= 0.0) & (img <= 1.0)))
                 extra = extra + lp.detach()

@@ -160,6 +160,11 @@ int dimo_ssim_backward(int B, int C, int H, int W, int clamp_img1, const float *
 int dimo_ssim_forward_backward(int B, int C, int H, int W, int clamp_img1, const float *img1, const float *img2,
                                const float *dL_dmean /* 1 float, device */, float *ssim_sum, float *dL_dimg1,
                                void *stream);
+/* the same with img2 as B separate [C,H,W] tensors (HOST array of B <= 32 device pointers): the targets of a batch
+ * need not be stacked */
+int dimo_ssim_forward_backward_images(int B, int C, int H, int W, int clamp_img1, const float *img1,
+                                      const float *const *img2_images_host, const float *dL_dmean, float *ssim_sum,
+                                      float *dL_dimg1, void *stream);
 
 /* ------------------------------------------------------------------ fused image losses + their gradients
  * One motion's batch of B <= 64 renders (main_train_dimo.py:331-372, src/loss.py:64-106):
@@ -172,12 +177,15 @@ int dimo_ssim_forward_backward(int B, int C, int H, int W, int clamp_img1, const
  * w_mse_host: B floats on the HOST (passed by value to the kernel).  loss_accum: 1 device float, added to.
  * g_dot (optional, [B,1,H,W]): per pixel sum over the channels of gradient x rendered value -- the rasterizer backward's
  * "S" (dimo_render_desc.g_dot): with it the blend backward reads 4 bytes per pixel instead of the nine final
- * accumulator planes. */
+ * accumulator planes.  gt_images_host / mask_images_host (optional HOST arrays of B device pointers, [3,H,W] /
+ * [1,H,W] each): the batch's targets / masks as separate tensors instead of the contiguous gt / mask (which may then
+ * be NULL). */
 int dimo_image_loss(int B, int H, int W, const float *image, const float *depth, const float *normal,
                     const float *alpha, const float *gt, const float *mask, int mask_per_image,
                     const float *w_mse_host, float w_mask, float w_smooth_x, float w_smooth_y, float w_bilat_x,
                     float w_bilat_y, const float *ssim_grad, float *loss_accum, float *g_image, float *g_depth,
-                    float *g_normal, float *g_alpha, float *g_dot, void *stream);
+                    float *g_normal, float *g_alpha, float *g_dot, const float *const *gt_images_host,
+                    const float *const *mask_images_host, void *stream);
 
 /* ------------------------------------------------------------------ fused skinning (stage s2 of Renderer.render)
  * One kernel for renderer/latent_gs_renderer.py:1187-1219: LBS weights w_k = L1norm(exp(-d_k^2/(2 r_k^2)) + 1e-7),
