@@ -396,7 +396,8 @@ __device__ __forceinline__ void level2_body(BinGrid gi, uint32_t R_cap, const ui
                                             const uint2 *__restrict__ l1list, size_t l1cap,
                                             const uint16_t *__restrict__ rect, uint32_t *__restrict__ cnt2,
                                             uint32_t *__restrict__ cnt2w, const uint32_t *__restrict__ tstart,
-                                            uint64_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+                                            uint64_t *__restrict__ keys, uint32_t *__restrict__ vals,
+                                            uint8_t *__restrict__ grad_flags) {
   __shared__ uint32_t s_c[SEG / 64][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const unsigned long long lt = (1ull << lane) - 1ull;
@@ -432,6 +433,9 @@ __device__ __forceinline__ void level2_body(BinGrid gi, uint32_t R_cap, const ui
           if (cov && pos < R_cap) {
             keys[pos] = ((uint64_t)(uint32_t)(ty * gi.tiles_x + tx) << 32) | en.y;
             vals[pos] = en.x;
+            // the fill pass touches every instance slot [0, R) exactly once: it also clears the backward's "gradient
+            // record written" flags (indexed by emission position, the same range) -- a launch of its own before
+            if (grad_flags) grad_flags[pos] = 0;
           }
         } else {
           c += lane == j ? (uint32_t)__popcll(bal) : 0u;
@@ -548,11 +552,12 @@ __device__ __forceinline__ void level1_stage(int N, BinGrid gi, const BinPtrs &o
                     at<uint32_t>(geom, o.g_cnt1), at<uint32_t>(bin, o.b_meta), at<uint2>(bin, o.b_l1), o.l1cap);
 }
 template <bool FILL>
-__device__ __forceinline__ void level2_stage(BinGrid gi, uint32_t R_cap, const BinPtrs &o, void *geom, void *bin) {
+__device__ __forceinline__ void level2_stage(BinGrid gi, uint32_t R_cap, const BinPtrs &o, void *geom, void *bin,
+                                             uint8_t *grad_flags) {
   level2_body<FILL>(gi, R_cap, at<uint32_t>(bin, o.b_meta), at<uint2>(bin, o.b_l1), o.l1cap,
                     at<uint16_t>(geom, o.g_rect), at<uint32_t>(bin, o.b_cnt2),
                     at<uint32_t>(bin, o.b_cnt2) + o.max_windows * 64, at<uint32_t>(bin, o.b_totals),
-                    at<uint64_t>(bin, o.b_keys), at<uint32_t>(bin, o.b_vals));
+                    at<uint64_t>(bin, o.b_keys), at<uint32_t>(bin, o.b_vals), grad_flags);
 }
 template <bool FILL>
 __global__ void __launch_bounds__(SEG) level1_kernel(int N, BinGrid gi, BinPtrs o, void *geom, void *bin) {
@@ -563,7 +568,7 @@ __global__ void __launch_bounds__(L1_PARTS *MAX_SUPER) level1_scan_kernel(int ns
 }
 template <bool FILL>
 __global__ void __launch_bounds__(SEG) level2_kernel(BinGrid gi, uint32_t R_cap, BinPtrs o, void *geom, void *bin) {
-  level2_stage<FILL>(gi, R_cap, o, geom, bin);
+  level2_stage<FILL>(gi, R_cap, o, geom, bin, nullptr);  // (the C-ABI backward clears its own scratch)
 }
 __global__ void __launch_bounds__(64) level2_scan_kernel(BinGrid gi, BinPtrs o, void *bin) {
   level2_scan_body(gi, at<uint32_t>(bin, o.b_meta), at<uint32_t>(bin, o.b_cnt2), at<uint32_t>(bin, o.b_totals));
@@ -610,8 +615,10 @@ __global__ void __launch_bounds__(L1_PARTS *MAX_SUPER) level1_scan_batched_kerne
                    o.max_windows);
 }
 template <bool FILL>
-__global__ void __launch_bounds__(SEG) level2_batched_kernel(BinGrid gi, uint32_t R_cap, BinPtrs o, RenderBatch b) {
-  level2_stage<FILL>(gi, R_cap, o, b.r[blockIdx.y].geom, b.r[blockIdx.y].bin);
+__global__ void __launch_bounds__(SEG) level2_batched_kernel(BinGrid gi, uint32_t R_cap, BinPtrs o, size_t flag_off,
+                                                             RenderBatch b) {
+  const dimo_render_desc &r = b.r[blockIdx.y];
+  level2_stage<FILL>(gi, R_cap, o, r.geom, r.bin, FILL ? at<uint8_t>(r.bwd_scratch, flag_off) : nullptr);
 }
 __global__ void __launch_bounds__(64) level2_scan_batched_kernel(BinGrid gi, BinPtrs o, RenderBatch b) {
   void *bin = b.r[blockIdx.y].bin;
@@ -729,6 +736,9 @@ int bin_instances_batched(const dimo_step_common &c, const RenderBatch &b, int n
   BinGrid gi;
   if (!make_grid(B, gi)) return DIMO_E_ARG;
   if (c.bin_bytes < B.bytes || c.geom_bytes < G.bytes) return DIMO_E_WORKSPACE;
+  if (c.bwd_scratch_bytes < align_up(B.cap * sizeof(SplatGrad)) + align_up(B.cap)) return DIMO_E_WORKSPACE;
+  for (int i = 0; i < n; ++i)
+    if (!b.r[i].bwd_scratch) return DIMO_E_ARG;  // the fill pass clears the backward's record flags
   const uint32_t cap = (uint32_t)B.cap;
   const BinPtrs o = make_ptrs(G, B);
   if (c.N > 0) {
@@ -755,13 +765,15 @@ int bin_instances_batched(const dimo_step_common &c, const RenderBatch &b, int n
   }
   {
     ScopedTimer tm(T_RANGES, stream);
-    hipLaunchKernelGGL(level2_batched_kernel<false>, dim3(L2_GRID, n), dim3(SEG), 0, stream, gi, cap, o, b);
+    hipLaunchKernelGGL(level2_batched_kernel<false>, dim3(L2_GRID, n), dim3(SEG), 0, stream, gi, cap, o, (size_t)0, b);
     hipLaunchKernelGGL(level2_scan_batched_kernel, dim3(gi.NS, n), dim3(64), 0, stream, gi, o, b);
     hipLaunchKernelGGL(tile_starts_batched_kernel, dim3(1, n), dim3(1024), 0, stream, B.T, cap, o, b);
   }
   {
     ScopedTimer tm(T_TILE_SORT, stream);
-    hipLaunchKernelGGL(level2_batched_kernel<true>, dim3(L2_GRID, n), dim3(SEG), 0, stream, gi, cap, o, b);
+    // (flags of the backward's scratch: [records: cap x 64 B][flags: cap x 1 B], see blend.hip)
+    hipLaunchKernelGGL(level2_batched_kernel<true>, dim3(L2_GRID, n), dim3(SEG), 0, stream, gi, cap, o,
+                       align_up(B.cap * sizeof(SplatGrad)), b);
   }
   return check_launch();
 }

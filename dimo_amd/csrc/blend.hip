@@ -611,14 +611,6 @@ __global__ void __launch_bounds__(64, BWD_WAVES_PER_SIMD) blend_bwd_batched_kern
                                                                                     RenderBatch b) {
   blend_bwd_loop<NORMAL>(H, W, tiles_x, R_cap, bg, n, BatchView<NORMAL>{b, o});
 }
-// clears the "record written" flags of the instances a render actually has ([0, R), 16 bytes per thread)
-__global__ void __launch_bounds__(256) clear_flags_batched_kernel(uint32_t R_cap, BlendOffsets o, RenderBatch b) {
-  const dimo_render_desc &r = b.r[blockIdx.y];
-  const uint32_t R = min(*at<uint32_t>(r.geom, o.total), R_cap);
-  const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 16;
-  if (i < R) *reinterpret_cast<uint4 *>(at<uint8_t>(r.bwd_scratch, o.flag) + i) = make_uint4(0, 0, 0, 0);
-}
-
 // Buckets per backward item.  Measured on the C3 batch (4 renders, ~10^4 buckets for 4096 wave slots): 189 / 231 /
 // 245 / 273 us per launch at 1 / 2 / 3 / 4 buckets per item -- what a longer chain saves in state loads it loses
 // several times over in the tail of the launch (fewer, longer items), so the default is one bucket per item and the
@@ -670,9 +662,8 @@ int blend_backward_batched(const dimo_step_common &c, const RenderBatch &b, int 
   if (c.bwd_scratch_bytes < align_up(B.cap * sizeof(SplatGrad)) + align_up(B.cap)) return DIMO_E_WORKSPACE;
   const BlendOffsets o = blend_offsets(G, B, I);
   const uint32_t cap = (uint32_t)B.cap;
+  // (the "record written" flags were cleared by the placement's fill pass of this batch's forward: binning.hip)
   ScopedTimer tm(T_BLEND_BWD, stream);
-  hipLaunchKernelGGL(clear_flags_batched_kernel, dim3((unsigned)((B.cap / 16 + 255) / 256 + 1), n), dim3(256), 0,
-                     stream, cap, o, b);
   // (the chain length is the one the forward of this batch used: bwd_chain(n) is a function of n only)
   if (c.with_normal)
     hipLaunchKernelGGL(blend_bwd_batched_kernel<true>, dim3(BWD_GRID), dim3(64), 0, stream, c.H, c.W, B.tiles_x, cap,
