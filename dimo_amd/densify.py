@@ -20,6 +20,18 @@ from .deform import build_rotation
 PER_GAUSSIAN = ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation")
 
 
+def morton_order(xyz, bits=10):
+    """Permutation that sorts points along the 3D Morton (Z-order) curve of their bounding box; stable, so equal
+    codes keep their current order and replicas holding equal positions get equal permutations."""
+    lo, hi = xyz.min(dim=0).values, xyz.max(dim=0).values
+    q = ((xyz - lo) / (hi - lo).clamp_min(1e-12) * float((1 << bits) - 1)).to(torch.int64).clamp_(0, (1 << bits) - 1)
+    code = torch.zeros(xyz.shape[0], dtype=torch.int64, device=xyz.device)
+    for b in range(bits):
+        for d in range(3):
+            code |= ((q[:, d] >> b) & 1) << (3 * b + d)
+    return torch.sort(code, stable=True).indices
+
+
 class _Plan:
     """Rows of the model being built: `src` = source row in the CURRENT model, `fresh` = Adam moments start at
     zero, `values` = name -> tensor [rows, ...] of the parameter values (gathered lazily)."""
@@ -166,6 +178,30 @@ class DensifyMixin:
         self.xyz_gradient_accum = self.xyz_gradient_accum[src]
         self.denom = self.denom[src]
         self.max_radii2D = self.max_radii2D[src]
+
+    @torch.no_grad()
+    def sort_spatially(self):
+        """MI355X layout step with no counterpart in the reference (a Gaussian model is a set): stores the Gaussians
+        in Morton order of their canonical positions, so that the 64 Gaussians of a wavefront share control points
+        (the skinning backward's LDS atomics combine inside the wave), reach the same screen tiles (binning) and sit
+        in neighbouring cache lines when the blend kernels gather them.  Parameters, Adam moments and densification
+        statistics move together; returns the permutation (new row -> old row)."""
+        perm = morton_order(self._xyz.detach())
+        if self.optimizer is None:
+            for name in ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation") + \
+                    (("_r",) if self.r_is_per_point() else ()):
+                p = getattr(self, name)
+                setattr(self, name, torch.nn.Parameter(p.detach()[perm].contiguous().requires_grad_(True)))
+            for name in ("xyz_gradient_accum", "denom", "max_radii2D"):
+                t = getattr(self, name, None)
+                if t is not None and t.shape[0] == perm.shape[0]:
+                    setattr(self, name, t[perm])
+            self.neighbor_dists = self.neighbor_indices = None
+            return perm
+        plan = _Plan(self)
+        plan.keep(perm)
+        self._finish_prune(plan)
+        return perm
 
     @torch.no_grad()
     def reset_opacity(self):

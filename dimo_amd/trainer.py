@@ -97,6 +97,8 @@ class TrainConfig:
     densify_opacity_threshold_s2: float = 0.01
     init_type: str = "ag"
     FPS_iter: int = 1000  # stage s1: farthest-point down-sampling to num_cpts every FPS_iter steps
+    # MI355X layout (no reference counterpart): keep the canonical Gaussians in Morton order (densify.py)
+    spatial_sort: bool = True
     # regularisers (configs/train_config.yaml:57-65).  Off by default: BASELINE.json's metric is quoted without them
     use_lpips: bool = False   # main_train_dimo.py:339-341 (needs the metric's weights: dimo_amd/lpips_vgg.py)
     lambda_lpips: float = 1000.0  # configs/train_config.yaml:44
@@ -163,6 +165,8 @@ class Trainer:
         # rank-identical sampling: all three RNGs the reference uses are seeded (it leaves `random` unseeded)
         self._py_rng = random.Random(cfg.seed)
         self._np_rng = np.random.default_rng(cfg.seed)
+        if cfg.spatial_sort:  # Morton order of the canonical Gaussians (densify.py: sort_spatially), kept by densify_schedule
+            renderer.gaussians.sort_spatially()
         renderer.gaussians.training_setup(cfg)
         if cfg.stage == "s1":  # prepare_train_s1 (main_train_dimo.py:464-469): the control points do not train in s1
             for grp in renderer.gaussians.optimizer.param_groups:
@@ -814,6 +818,12 @@ class Trainer:
         """Densification / pruning of the reference's two stages (main_train_dimo.py:426-443), after the optimizer
         step.  Deterministic in the parameters (and the shared torch seed for the split draws): replicas stay equal."""
         c, g = self.cfg, self.renderer.gaussians
+        n_before, opt_before = g._xyz.shape[0], g.optimizer
+        self._densify_schedule(c, g)
+        if c.spatial_sort and g.optimizer is not opt_before and g._xyz.shape[0] != n_before:
+            g.sort_spatially()  # new rows were appended / rows removed: restore the Morton order (one more rebuild)
+
+    def _densify_schedule(self, c, g):
         if self.stage == "s1":
             fps_iter = c.FPS_iter
             if self.step % fps_iter >= c.density_start_iter and self.step <= c.density_end_iter:

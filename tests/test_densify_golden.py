@@ -244,3 +244,38 @@ def test_training_goes_on_across_a_prune():
     torch.cuda.synchronize()
     assert tr._exec.N == n and torch.isfinite(tr.last_loss) and torch.isfinite(g.flat_params).all()
     assert tr.skipped_steps == 0
+
+
+def test_sort_spatially_moves_parameters_moments_and_statistics_together():
+    """The Morton-order layout step (densify.py: sort_spatially) is a pure permutation of the per-Gaussian rows: every
+    parameter, both Adam moments and the densification statistics of a row travel with it, the other groups stay, and
+    the densify that follows gives the same SET of Gaussians as without the sort."""
+    from dimo_amd.densify import morton_order
+    gold = np.load(os.path.join(GOLD, "densify.npz"))
+    g, cfg = _model(gold)
+    g.training_setup(cfg)
+    _two_steps(g, gold)
+    before = {k: (p.detach().clone(), g._moments(p)[0].clone(), g._moments(p)[1].clone())
+              for k, p in g.per_gaussian().items() if p.numel()}
+    stats = (g.xyz_gradient_accum.clone(), g.denom.clone(), g.max_radii2D.clone())
+    c_m = g._moments(g._c_xyz)[0].clone()
+    perm = g.sort_spatially()
+    assert sorted(perm.tolist()) == list(range(perm.shape[0])) and not torch.equal(perm, torch.arange(perm.shape[0]))
+    for k, p in g.per_gaussian().items():
+        if p.numel():
+            assert torch.equal(p.detach(), before[k][0][perm]), k
+            assert torch.equal(g._moments(p)[0], before[k][1][perm]) and torch.equal(g._moments(p)[1], before[k][2][perm]), k
+    assert torch.equal(g.xyz_gradient_accum, stats[0][perm]) and torch.equal(g.denom, stats[1][perm])
+    assert torch.equal(g.max_radii2D, stats[2][perm]) and torch.equal(g._moments(g._c_xyz)[0], c_m)
+    # sorted: neighbours in memory are neighbours in space (mean hop much shorter than between random rows), idempotent
+    x = g._xyz.detach()
+    assert (x[1:] - x[:-1]).norm(dim=1).mean() < 0.6 * (before["xyz"][0][1:] - before["xyz"][0][:-1]).norm(dim=1).mean()
+    assert torch.equal(morton_order(x), torch.arange(x.shape[0]))
+    # a prune after the sort removes the same Gaussians as before it would have
+    g2, _ = _model(gold)
+    g2.training_setup(cfg)
+    _two_steps(g2, gold)
+    g.prune(0.3, 4.0)
+    g2.prune(0.3, 4.0)
+    key = lambda m: sorted(map(tuple, m._xyz.detach().numpy().round(6).tolist()))
+    assert key(g) == key(g2) and 0 < g._xyz.shape[0] < perm.shape[0]
