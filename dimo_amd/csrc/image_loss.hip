@@ -86,8 +86,9 @@ __global__ void __launch_bounds__(256) image_loss_kernel(
   __shared__ float s_red[4];
   const size_t HW = (size_t)H * W;
   float loss = 0.0f;
-  // a workgroup walks 32x8 pixel tiles (image, ty, tx) with stride gridDim.x: ONE atomic on the loss word per
-  // workgroup (4096 same-address atomics were most of this kernel's 67 us)
+  // a workgroup walks 32x8 pixel tiles (image, ty, tx) with stride gridDim.x: ONE atomic per workgroup, spread over
+  // 16 words in 16 cache lines (same-address atomics drain at ~7 ns each: 4096 of them were most of this kernel's
+  // 67 us, 1024 still 4 of 40; with the spread the grid size no longer matters -- 35 us for 8 images = 5 TB/s)
   const int tiles_x = (W + 31) / 32, tiles_y = (H + 7) / 8;
   for (int tile = blockIdx.x; tile < tiles_x * tiles_y * n_images; tile += gridDim.x) {
   const int b = tile / (tiles_x * tiles_y);
@@ -148,7 +149,8 @@ __global__ void __launch_bounds__(256) image_loss_kernel(
   for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
   if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(loss_out, s_red[0] + s_red[1] + s_red[2] + s_red[3]);
+  // 16 accumulator words in 16 cache lines (DIMO_LOSS_WORDS = 16 x 32 floats): the caller sums them
+  if (threadIdx.x == 0) atomicAdd(loss_out + (blockIdx.x & 15) * 32, s_red[0] + s_red[1] + s_red[2] + s_red[3]);
 }
 
 }  // namespace dimo

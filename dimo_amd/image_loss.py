@@ -25,17 +25,22 @@ def loss_weights(cfg, n_local, n_img, H, W, depth_on=None, normal_on=None):
     )
 
 
+LOSS_WORDS = 512  # include/dimo_hip.h: DIMO_LOSS_WORDS
+
+
 def fused_image_loss(image, depth, normal, alpha, gt, mask, w_mse, weights, ssim_grad, loss_accum, out=None,
                      stream=None, g_dot=None):
     """image[B,3,H,W] (raw, unclamped) depth[B,1,H,W]|None normal[B,3,H,W]|None alpha[B,1,H,W] gt[B,3,H,W]
     mask [1,H,W] (shared) or [B,1,H,W] -- or `gt` / `mask` as LISTS of B separate [3,H,W] / [1,H,W] tensors (no
     stacking copy); w_mse: python list of B floats (already divided by 3HW).
-    Adds the loss to `loss_accum` (1 float) and returns (g_image, g_depth|None, g_normal|None, g_alpha).
+    Adds the loss to `loss_accum` (LOSS_WORDS floats; the loss is their sum) and returns (g_image, g_depth|None, g_normal|None, g_alpha).
     `stream`: raw stream handle to launch on (default: torch's current stream).  `g_dot` (optional [B,1,H,W]):
     receives sum_channels(gradient x rendered value) per pixel for the rasterizer backward."""
     if not image.is_cuda:
         raise RuntimeError("dimo_amd.image_loss needs GPU tensors (no CPU fallback in the product path)")
     B, _, H, W = image.shape
+    if loss_accum.numel() < LOSS_WORDS:
+        raise ValueError(f"loss_accum needs {LOSS_WORDS} floats (dimo_hip.h: DIMO_LOSS_WORDS)")
     new = lambda ref: torch.empty_like(ref)
     if out is None:
         g_image, g_alpha = new(image), new(alpha)

@@ -27,6 +27,7 @@ import torch
 import torch.distributed as dist
 
 from .camera import CameraCache
+_LOSS_WORDS = 512  # include/dimo_hip.h: DIMO_LOSS_WORDS (image_loss.py imports the HIP library; keep this module CPU-importable)
 from .losses import compute_bilateral_normal_smoothness_loss, compute_edge_aware_smoothness_loss
 from .synth import SyntheticTargets, default_azimuths, frame_times
 
@@ -133,7 +134,7 @@ class _LazyLoss:
         self.loss_accum, self.ssim_terms, self.extra = loss_accum, ssim_terms, extra
 
     def value(self):
-        loss = self.loss_accum[0]
+        loss = self.loss_accum.sum()
         if self.extra is not None:  # KL / ARAP / GA scalars (main stream; kept apart from the kernels' atomic adds)
             loss = loss + self.extra
         for ssum, lam, numel in self.ssim_terms:
@@ -554,7 +555,7 @@ class Trainer:
         # accumulated by the skinning backward; one zero-fill for both and for the loss accumulator
         o_q = (dxyz_c.numel() + 3) // 4 * 4  # 16-byte aligned start of the quaternion rows
         n_motions = len({t[0] for t in mine})
-        zeroed = torch.zeros(o_q + dquat_c.numel() + 4 + n_motions, **f32)
+        zeroed = torch.zeros(o_q + dquat_c.numel() + _LOSS_WORDS + n_motions, **f32)
         g_dxyz = zeroed[:dxyz_c.numel()].view_as(dxyz_c)
         g_dquat = zeroed[o_q:o_q + dquat_c.numel()].view_as(dquat_c)
         by_motion = {}
@@ -610,13 +611,13 @@ class Trainer:
         for w_ in ex.total_words(n):
             self.renderer.capacity.track(w_)
 
-        loss_accum = zeroed[o_q + dquat_c.numel():o_q + dquat_c.numel() + 1]
+        loss_accum = zeroed[o_q + dquat_c.numel():o_q + dquat_c.numel() + _LOSS_WORDS]
         # scalars produced on THIS stream (KL, ARAP, GA, LPIPS): summed apart from `loss_accum`, which the private
         # streams' kernels add to atomically
         extra = torch.zeros((), **f32)
         if self._ga_active():
             extra = extra + self._ga_direct(mine, pair_of, dxyz_c, g_dxyz)
-        ssums = zeroed[o_q + dquat_c.numel() + 4:]
+        ssums = zeroed[o_q + dquat_c.numel() + _LOSS_WORDS:]
         ssim_terms, keep = [], []
         for m, trs in by_motion.items():
             B = len(trs)

@@ -174,12 +174,15 @@ int dimo_ssim_forward_backward_images(int B, int C, int H, int W, int clamp_img1
  * g_image/g_depth/g_normal/g_alpha receive dloss/d(raw rasterizer outputs); ssim_grad (optional, [B,3,H,W],
  * w.r.t. the clamped image) is added before the clamp mask.  image[B,3,H,W] depth[B,1,H,W]|NULL
  * normal[B,3,H,W]|NULL alpha[B,1,H,W] gt[B,3,H,W] mask[B,1,H,W] (mask_per_image != 0) or [1,H,W] shared.
- * w_mse_host: B floats on the HOST (passed by value to the kernel).  loss_accum: 1 device float, added to.
+ * w_mse_host: B floats on the HOST (passed by value to the kernel).  loss_accum: DIMO_LOSS_WORDS device floats, added
+ * to; the loss is their SUM (the workgroups spread their atomic adds over 16 cache lines: same-address atomics
+ * serialise in the L2 at ~7 ns each, which was a fifth of this kernel's time).
  * g_dot (optional, [B,1,H,W]): per pixel sum over the channels of gradient x rendered value -- the rasterizer backward's
  * "S" (dimo_render_desc.g_dot): with it the blend backward reads 4 bytes per pixel instead of the nine final
  * accumulator planes.  gt_images_host / mask_images_host (optional HOST arrays of B device pointers, [3,H,W] /
  * [1,H,W] each): the batch's targets / masks as separate tensors instead of the contiguous gt / mask (which may then
  * be NULL). */
+#define DIMO_LOSS_WORDS 512
 int dimo_image_loss(int B, int H, int W, const float *image, const float *depth, const float *normal,
                     const float *alpha, const float *gt, const float *mask, int mask_per_image,
                     const float *w_mse_host, float w_mask, float w_smooth_x, float w_smooth_y, float w_bilat_x,

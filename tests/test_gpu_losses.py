@@ -47,11 +47,11 @@ def test_image_loss_kernel_vs_reference_assembly(B, H, W, share, dn):
     coef = torch.tensor([-cfg.lambda_ssim * B / n_img], device="cuda")
     sg = torch.empty(B, 3, H, W, device="cuda")
     _lib.check(L.dimo_ssim_backward(B, 3, H, W, 1, _lib.ptr(img_d), _lib.ptr(gt_d), _lib.ptr(partials), _lib.ptr(coef), _lib.ptr(sg), st), "b")
-    acc = torch.zeros(1, device="cuda")
+    acc = torch.zeros(512, device="cuda")  # DIMO_LOSS_WORDS
     w_mse = [cfg.lambda_mse * w / (3 * H * W) for w in wts]
     gi, gd, gn, ga = fused_image_loss(img_d, dep_d if dn[0] else None, nrm_d if dn[1] else None, alp_d, gt_d, mask_d,
                                       w_mse, loss_weights(cfg, B, n_img, H, W), sg, acc)
-    loss = acc[0].item() + cfg.lambda_ssim * (B / n_img) * (1 - ssum[0].item() / (B * 3 * H * W))
+    loss = acc.sum().item() + cfg.lambda_ssim * (B / n_img) * (1 - ssum[0].item() / (B * 3 * H * W))
     assert abs(loss - ref.item()) <= 2e-5 * abs(ref.item()), (loss, ref.item())
     for got, leaf, name in ((gi, leaves[0], "image"), (gd, leaves[1], "depth"), (gn, leaves[2], "normal"),
                             (ga, leaves[3], "alpha")):

@@ -10,7 +10,7 @@ img, dep, nrm, al = torch.rand(B, 3, H, W, device=d), torch.rand(B, 1, H, W, dev
 gt, mask, sg = torch.rand(B, 3, H, W, device=d), torch.rand(1, H, W, device=d), torch.rand(B, 3, H, W, device=d)
 cfg = SimpleNamespace(lambda_mask=1.0, lambda_smooth=0.1, lambda_bilateral=0.1, add_depth=True, add_normal=True)
 wts = loss_weights(cfg, B, B, H, W)
-acc = torch.zeros(1, device=d)
+acc = torch.zeros(512, device=d)
 out = fused_image_loss(img, dep, nrm, al, gt, mask, [1e-6] * B, wts, sg, acc)
 f = lambda: fused_image_loss(img, dep, nrm, al, gt, mask, [1e-6] * B, wts, sg, acc, out=out)
 for _ in range(10): f()
