@@ -51,6 +51,9 @@ def make_trainer(device, rank, world, num_pts, resolution, per_gpu=(2, 2, 2), ca
     else:
         m, v, f = min(51, per_gpu[0] * world), per_gpu[1], per_gpu[2]
     cfg = TrainConfig(num_pts=num_pts, resolution=resolution, motions_per_step=m, views_per_step=v, frames_per_step=f)
+    # the reference renders at 512^2 from step 450 on whatever the targets' size (main_train_dimo.py:261); a stress
+    # shape above that (BASELINE.json configs[4]: 1024^2) is rendered at ITS size
+    cfg.progressive_resolution = resolution <= 512
     pol = CapacityPolicy(initial=max(1 << 20, 40 * num_pts)) if capacity else None
     rd = Renderer(sh_degree=0, white_background=True, radius=cfg.radius, num_latent_code=cfg.num_motions,
                   latent_code_dim=cfg.latent_code_dim, add_normal=True, device=device, capacity=pol)
@@ -108,7 +111,7 @@ def read_timing():
     return out
 
 
-def cpu_baseline(num_pts, resolution, renders=20):
+def cpu_baseline(num_pts, resolution, renders=16):
     """Same train step on the host cores: product host logic + CPU oracle kernels (kind 'port')."""
     from dimo_amd.trainer import TrainConfig
     from tests.cpu_backend import make_cpu_trainer
@@ -118,7 +121,9 @@ def cpu_baseline(num_pts, resolution, renders=20):
     torch.set_num_threads(cores)
     cfg = TrainConfig(num_pts=num_pts, resolution=resolution, motions_per_step=1, views_per_step=1,
                       frames_per_step=renders)
+    cfg.progressive_resolution = resolution <= 512
     tr = make_cpu_trainer(cfg)
+    tr.step = 1000  # the same point of the schedule as the GPU workload: full render size, every image term on
     t0 = time.time()
     n = tr.train_step()
     dt = time.time() - t0
