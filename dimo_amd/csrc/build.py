@@ -22,7 +22,7 @@ SOURCES = {
     # (150-187 -> 116 issue cycles per quadrant visit of the backward)
     "blend.hip": ["-fno-slp-vectorize"],
     "knn.hip": ["-ffp-contract=off"],
-    "ssim.hip": [],
+    "ssim.hip": ["-fno-slp-vectorize"],  # packed FMAs need register pairs: with the window in VGPRs they spilled
     "deform.hip": [],
     "image_loss.hip": [],
     "adam.hip": [],

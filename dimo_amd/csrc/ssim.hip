@@ -44,6 +44,30 @@ __device__ __forceinline__ float maybe_clamp(float v, int on) { return on ? fmin
 // inputs held in registers (11 x 8 FMAs per map instead of 11 x 8 x (2 LDS reads + FMA)); vertical pass: a thread
 // produces 4 vertically adjacent outputs of one column from 14 values.  The first version read LDS for every tap:
 // it was VALU + LDS bound at 61 us for a 4 x 3 x 512^2 batch against ~8 us of HBM time.
+// The window as six VGPRs (it is symmetric: w[k] == w[10 - k] bit for bit).  As a kernel argument the weights live in
+// SGPRs, and on gfx950 a VALU instruction with an SGPR source issues in 4 cycles instead of 2
+// (profiles/r02_valu_issue_rates.txt): every one of the 11-tap FMAs paid that.  The asm keeps the compiler from
+// folding the copies back into scalar operands.
+struct WindowV {
+  float w[6];
+};
+__device__ __forceinline__ WindowV window_to_vgprs(const Window &win) {
+  WindowV v;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) asm volatile("v_mov_b32 %0, %1" : "=v"(v.w[k]) : "s"(win.w[k]));
+  return v;
+}
+template <int NOUT, int NIN>
+__device__ __forceinline__ void taps(const WindowV &win, const float (&in)[NIN], float (&out)[NOUT]) {
+#pragma unroll
+  for (int o = 0; o < NOUT; ++o) {
+    float a = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 11; ++k) a += win.w[k < 6 ? k : 10 - k] * in[o + k];
+    out[o] = a;
+  }
+}
+
 template <int NOUT, int NIN>
 __device__ __forceinline__ void taps(const Window &win, const float (&in)[NIN], float (&out)[NOUT]) {
 #pragma unroll
@@ -214,20 +238,23 @@ struct ImagePtrs {
   int n, channels;
   const float *p[SSIM_MAX_IMAGES];
 };
-__global__ void __launch_bounds__(256, 3) ssim_fused_kernel(int H, int W, int n_planes, int clamp1, Window win,
+__global__ void __launch_bounds__(256, 4) ssim_fused_kernel(int H, int W, int n_planes, int clamp1, Window win,
                                                          const float *__restrict__ img1,
                                                          const float *__restrict__ img2, ImagePtrs img2_images,
                                                          const float *__restrict__ dL_dmean, float inv_numel,
                                                          float *__restrict__ ssim_sum, float *__restrict__ dL_dimg1) {
   // 31 KB of LDS per workgroup (53 KB in round 1: three workgroups then owned ALL of a CU's LDS, and in the
   // two-stream schedule no blend workgroup of the other motion could join them on that CU -- the kernel showed 200+ us
-  // there against 77 us alone).  The derivative planes live over the input planes, which are dead once every thread
-  // has taken its 24 x / y values into registers; x and y of the tile's own pixels are re-read from global at the end.
+  // there against 77 us alone).  The derivative planes live over the input planes, which are dead once the five maps
+  // are filtered; x and y of the tile's own pixels are re-read from global at the end.  128 VGPRs: FOUR workgroups
+  // per CU (the phases of a tile are short and separated by barriers, so the kernel lives on the other workgroups'
+  // waves: 80 -> 71 us for 8 x 3 x 512^2 against three per CU with x / y held in registers).
   __shared__ float s_xy[2][IS][IS + 1];
   __shared__ float s_h[IS][HS + 1];      // horizontally filtered map (52 x 42); reused as 42 x 32 in the second pass
   __shared__ float s_red[4];
   static_assert(3 * HS * (HS + 1) <= 2 * IS * (IS + 1), "derivative planes must fit over the input planes");
   float (*s_x)[IS + 1] = s_xy[0], (*s_y)[IS + 1] = s_xy[1];
+  const WindowV winv = window_to_vgprs(win);
   float (*s_p)[HS][HS + 1] = reinterpret_cast<float (*)[HS][HS + 1]>(&s_xy[0][0][0]);  // derivative planes on the halo
   const int tid = threadIdx.x;
   const int tiles_x = (W + TS - 1) / TS, tiles_y = (H + TS - 1) / TS;
@@ -261,17 +288,17 @@ __global__ void __launch_bounds__(256, 3) ssim_fused_kernel(int H, int W, int n_
       s_y[hy][hx] = in ? b : 0.0f;
     }
     __syncthreads();
-    float x[24], y[24];
-#pragma unroll
-    for (int i = 0; i < 24; ++i) x[i] = s_x[h1_row][h1_c0 + i], y[i] = s_y[h1_row][h1_c0 + i];
     float st[5][7];
 #pragma unroll
     for (int q = 0; q < 5; ++q) {  // maps: x, y, x^2, y^2, x y
       if (h1) {
         float v[24], o[14];
 #pragma unroll
-        for (int i = 0; i < 24; ++i) v[i] = q == 0 ? x[i] : q == 1 ? y[i] : q == 2 ? x[i] * x[i] : q == 3 ? y[i] * y[i] : x[i] * y[i];
-        taps<14, 24>(win, v, o);
+        for (int i = 0; i < 24; ++i) {  // (re-read from LDS per map: holding x and y cost 48 VGPRs = one wave per SIMD)
+          const float a = (q == 1 || q == 3) ? s_y[h1_row][h1_c0 + i] : s_x[h1_row][h1_c0 + i];
+          v[i] = q < 2 ? a : q < 4 ? a * a : a * s_y[h1_row][h1_c0 + i];
+        }
+        taps<14, 24>(winv, v, o);
 #pragma unroll
         for (int i = 0; i < 14; ++i) s_h[h1_row][h1_c0 + i] = o[i];
       }
@@ -279,7 +306,7 @@ __global__ void __launch_bounds__(256, 3) ssim_fused_kernel(int H, int W, int n_
       float col[17];
 #pragma unroll
       for (int i = 0; i < 17; ++i) col[i] = s_h[v1_r0 + i][v1_c];
-      taps<7, 17>(win, col, st[q]);
+      taps<7, 17>(winv, col, st[q]);
       __syncthreads();
     }
     if (v1) {
@@ -310,7 +337,7 @@ __global__ void __launch_bounds__(256, 3) ssim_fused_kernel(int H, int W, int n_
         float v[18], o[8];
 #pragma unroll
         for (int i = 0; i < 18; ++i) v[i] = s_p[q][h2_row][h2_c0 + i];
-        taps<8, 18>(win, v, o);
+        taps<8, 18>(winv, v, o);
 #pragma unroll
         for (int i = 0; i < 8; ++i) s_h[h2_row][h2_c0 + i] = o[i];
       }
@@ -318,7 +345,7 @@ __global__ void __launch_bounds__(256, 3) ssim_fused_kernel(int H, int W, int n_
       float col[14];
 #pragma unroll
       for (int i = 0; i < 14; ++i) col[i] = s_h[r0 + i][c];
-      taps<4, 14>(win, col, g[q]);
+      taps<4, 14>(winv, col, g[q]);
     }
     const int gx = x0 + c;
 #pragma unroll
