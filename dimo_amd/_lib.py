@@ -36,6 +36,7 @@ _SIGNATURES = {
                              + [C.c_float, C.c_float] + [c_ptr] * 4 + [c_ptr] * 4 + [c_ptr] * 8
                              + [c_ptr, C.c_size_t, c_ptr]),
     "dimo_knn": (C.c_int, [C.c_int, C.c_int, C.c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "dimo_knn_seeded": (C.c_int, [C.c_int, C.c_int, C.c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     "dimo_dist2": (C.c_int, [C.c_int, c_ptr, c_ptr, c_ptr]),
     "dimo_deform_max_ctrl_points": (C.c_int, []),
     "dimo_deform_backward_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int]),

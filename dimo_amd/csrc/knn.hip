@@ -12,7 +12,9 @@
 namespace dimo {
 
 constexpr int KNN_BLOCK = 64;     // one wave per workgroup: 1563 workgroups for 1e5 queries keep 256 CUs evenly loaded
-constexpr int KNN_CHUNK = 1024;   // reference points staged per LDS round (16 KiB as float4)
+constexpr int KNN_CHUNK = 512;    // reference points staged per LDS round (8 KiB as float4: with the 8 KiB of partial lists a
+                                  // workgroup takes 16 KiB, so 8 of them fit a CU and the 1563 workgroups of 1e5 queries are
+                                  // resident at once -- at 24 KiB only 6 were, and a seventh per CU doubled the duration)
 
 // K = 4 (DIMO's setting): the four best (distance, index) pairs live as four 64-bit keys
 //     key = (bits of d2) << 32 | index
@@ -37,7 +39,8 @@ __device__ __forceinline__ void knn4_insert(double &b0, double &b1, double &b2, 
 }
 __global__ void __launch_bounds__(KNN_BLOCK *KNN4_WAVES) knn4_kernel(int M, int N, int k, const float *__restrict__ ref,
                                                                       const float *__restrict__ query,
-                                                                      float *__restrict__ dist, int64_t *__restrict__ idx) {
+                                                                      float *__restrict__ dist, int64_t *__restrict__ idx,
+                                                                      const int64_t *__restrict__ seed) {
   __shared__ float4 s_ref[KNN_CHUNK];
   __shared__ double s_best[KNN4_WAVES][4][KNN_BLOCK];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -46,6 +49,28 @@ __global__ void __launch_bounds__(KNN_BLOCK *KNN4_WAVES) knn4_kernel(int M, int 
   if (i < N) qx = query[3 * i], qy = query[3 * i + 1], qz = query[3 * i + 2];
   const double empty = __longlong_as_double((long long)(((unsigned long long)__float_as_uint(INFINITY) << 32) | 0xffffffffull));
   double b0 = empty, b1 = empty, b2 = empty, b3 = empty;
+  // Seeds (optional): four DISTINCT reference indices per query -- the previous step's neighbours.  The largest of
+  // their distances bounds the query's true fourth-nearest distance from above, so only candidates within it can
+  // enter the list: the result is the same as without seeds whatever the seeds are (stale ones only loosen the
+  // bound; a repeated or out-of-range index switches the bound off for that query).
+  float worst = INFINITY;
+  if (seed && k == 4 && i < N) {
+    const long long s0 = seed[4 * (size_t)i], s1 = seed[4 * (size_t)i + 1], s2 = seed[4 * (size_t)i + 2],
+                    s3 = seed[4 * (size_t)i + 3];
+    const bool ok = s0 >= 0 && s0 < M && s1 >= 0 && s1 < M && s2 >= 0 && s2 < M && s3 >= 0 && s3 < M && s0 != s1 &&
+                    s0 != s2 && s0 != s3 && s1 != s2 && s1 != s3 && s2 != s3;
+    if (ok) {
+      float bound = 0.0f;
+      const long long ss[4] = {s0, s1, s2, s3};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float *r = ref + 3 * (size_t)ss[j];
+        const float dx = qx - r[0], dy = qy - r[1], dz = qz - r[2];
+        bound = fmaxf(bound, dx * dx + dy * dy + dz * dz);  // (a NaN distance is dropped by fmaxf: the bound stays valid
+      }                                                     //  for the finite ones, and NaNs never enter a list anyway)
+      worst = bound;
+    }
+  }
   for (int base = 0; base < M; base += KNN_CHUNK) {
     const int cnt = min(KNN_CHUNK, M - base);
     __syncthreads();
@@ -56,12 +81,34 @@ __global__ void __launch_bounds__(KNN_BLOCK *KNN4_WAVES) knn4_kernel(int M, int 
     __syncthreads();
     const int per = (cnt + KNN4_WAVES - 1) / KNN4_WAVES;
     const int m0 = wave * per, m1 = min(cnt, m0 + per);
-#pragma unroll 4
-    for (int m = m0; m < m1; ++m) {
+    // A candidate can enter a lane's list only if it is not farther than the lane's current bound (the seed bound,
+    // then the fourth best: an equal distance with a higher index loses the key comparison inside the insert): the
+    // 12-instruction f64 insert runs only when some lane of the wave needs it.  With the Gaussians in Morton order
+    // (densify.py: sort_spatially) the 64 queries of a wave share their nearest control points, and with seeds nearly
+    // all of the 512 candidates are rejected by every lane.
+    int m = m0;
+    for (; m + 4 <= m1; m += 4) {  // four candidates' LDS reads in flight, then one uniform test per candidate
+      float4 c[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) c[u] = s_ref[m + u];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float dx = qx - c[u].x, dy = qy - c[u].y, dz = qz - c[u].z;
+        const float d2 = dx * dx + dy * dy + dz * dz;
+        if (__builtin_amdgcn_ballot_w64(d2 <= worst) != 0ull) {
+          knn4_insert(b0, b1, b2, b3, __hiloint2double((int)__float_as_uint(d2), base + m + u));
+          worst = fminf(worst, __uint_as_float((unsigned)__double2hiint(b3)));
+        }
+      }
+    }
+    for (; m < m1; ++m) {
       const float4 c = s_ref[m];
       const float dx = qx - c.x, dy = qy - c.y, dz = qz - c.z;
       const float d2 = dx * dx + dy * dy + dz * dz;
-      knn4_insert(b0, b1, b2, b3, __hiloint2double((int)__float_as_uint(d2), base + m));
+      if (__builtin_amdgcn_ballot_w64(d2 <= worst) != 0ull) {
+        knn4_insert(b0, b1, b2, b3, __hiloint2double((int)__float_as_uint(d2), base + m));
+        worst = fminf(worst, __uint_as_float((unsigned)__double2hiint(b3)));
+      }
     }
   }
   s_best[wave][0][lane] = b0, s_best[wave][1][lane] = b1, s_best[wave][2][lane] = b2, s_best[wave][3][lane] = b3;
@@ -167,6 +214,11 @@ using namespace dimo;
 
 extern "C" int dimo_knn(int M, int N, int k, const float *ref, const float *query, float *dist, int64_t *idx,
                         void *stream_) {
+  return dimo_knn_seeded(M, N, k, ref, query, dist, idx, nullptr, stream_);
+}
+
+extern "C" int dimo_knn_seeded(int M, int N, int k, const float *ref, const float *query, float *dist, int64_t *idx,
+                               const int64_t *seed_idx, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   clear_errors();
   if (M < 0 || N < 0 || k < 1 || k > 16) return DIMO_E_ARG;
@@ -175,7 +227,8 @@ extern "C" int dimo_knn(int M, int N, int k, const float *ref, const float *quer
   const dim3 grid((N + KNN_BLOCK - 1) / KNN_BLOCK), block(KNN_BLOCK);
   ScopedTimer tm(T_KNN, stream);
   if (k <= 4)
-    hipLaunchKernelGGL(knn4_kernel, grid, dim3(KNN_BLOCK * KNN4_WAVES), 0, stream, M, N, k, ref, query, dist, idx);
+    hipLaunchKernelGGL(knn4_kernel, grid, dim3(KNN_BLOCK * KNN4_WAVES), 0, stream, M, N, k, ref, query, dist, idx,
+                       seed_idx);
   else if (k <= 8)
     hipLaunchKernelGGL(knn_kernel<8>, grid, block, 0, stream, M, N, k, ref, query, dist, idx);
   else

@@ -11,16 +11,21 @@ import torch
 from . import _lib
 
 
-def knn_points(ref, query, k):
-    """ref [M,3], query [N,3] (cuda, fp32) -> (dist [N,k], idx [N,k] int64)."""
+def knn_points(ref, query, k, seed=None):
+    """ref [M,3], query [N,3] (cuda, fp32) -> (dist [N,k], idx [N,k] int64).  `seed` (optional, [N,4] int64, k = 4):
+    candidate neighbours per query (the previous step's result) that only prune the search -- same output for any
+    seed values (include/dimo_hip.h: dimo_knn_seeded)."""
     if not (ref.is_cuda and query.is_cuda):
         raise RuntimeError("dimo_amd.knn_cuda needs GPU tensors (no CPU fallback in the product path)")
     ref, query = ref.detach().float().contiguous(), query.detach().float().contiguous()
     M, N = ref.shape[0], query.shape[0]
     dist = torch.empty(N, k, dtype=torch.float32, device=query.device)
     idx = torch.empty(N, k, dtype=torch.int64, device=query.device)
-    _lib.check(_lib.lib().dimo_knn(M, N, k, _lib.ptr(ref), _lib.ptr(query), _lib.ptr(dist), _lib.ptr(idx),
-                                   _lib.current_stream()), "dimo_knn")
+    if seed is not None and not (k == 4 and seed.is_cuda and seed.dtype == torch.int64 and seed.is_contiguous()
+                                 and tuple(seed.shape) == (N, 4)):
+        seed = None
+    _lib.check(_lib.lib().dimo_knn_seeded(M, N, k, _lib.ptr(ref), _lib.ptr(query), _lib.ptr(dist), _lib.ptr(idx),
+                                          _lib.ptr(seed), _lib.current_stream()), "dimo_knn_seeded")
     return dist, idx
 
 

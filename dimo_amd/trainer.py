@@ -156,6 +156,7 @@ class Trainer:
         if knn_fn is None:
             from .knn_cuda import knn_points as knn_fn  # HIP, GPU only
         self.ssim, self.knn = ssim_fn, knn_fn
+        self._knn_seeded = knn_fn.__module__ == "dimo_amd.knn_cuda"  # (a test's CPU stand-in takes no seeds)
         self._fps_fn = fps_fn  # stage s1 down-sampling; default: the HIP kernel behind regularizers.sample_farthest_points
         self.cpts_s1 = None    # [motions, frames, M, 3]: control-point trajectories cached at stage-s2 step 0 (GA term)
         self._resampled = {}   # targets at the reduced render sizes of the first 450 steps
@@ -217,7 +218,10 @@ class Trainer:
     # ------------------------------------------------------------------ pieces of train_step
     def find_knn(self, k=4):
         g = self.renderer.gaussians
-        d, i = self.knn(g._c_xyz.detach(), g._xyz.detach(), k)
+        if self._knn_seeded and g.neighbor_indices is not None:  # last step's neighbours prune this step's search
+            d, i = self.knn(g._c_xyz.detach(), g._xyz.detach(), k, seed=g.neighbor_indices)
+        else:
+            d, i = self.knn(g._c_xyz.detach(), g._xyz.detach(), k)
         g.neighbor_dists, g.neighbor_indices = d, i
 
     def fps(self, num_pts):

@@ -138,6 +138,12 @@ int dimo_raster_backward(int N, int sh_degree, int M, int H, int W, int64_t R_ca
  * dimo_knn: brute-force k nearest reference points (k <= 16) per query; NON-squared distances,
  * ascending; ties -> lowest reference index.  ref[M,3] query[N,3] dist[N,k] idx[N,k] (int64). */
 int dimo_knn(int M, int N, int k, const float *ref, const float *query, float *dist, int64_t *idx, void *stream);
+/* The same with SEEDS (k = 4 only; ignored otherwise): seed_idx[N,4] (int64, may be NULL, may alias idx) holds four
+ * candidate neighbours per query, typically the previous training step's result.  They only prune the search (the
+ * largest seed distance bounds the fourth-nearest distance from above); the output is identical to dimo_knn's for
+ * ANY seed values -- a repeated or out-of-range index just switches the pruning off for that query. */
+int dimo_knn_seeded(int M, int N, int k, const float *ref, const float *query, float *dist, int64_t *idx,
+                    const int64_t *seed_idx, void *stream);
 
 /* dimo_dist2: mean squared distance of each point to its 3 nearest other points. points[N,3] out[N]. */
 int dimo_dist2(int N, const float *points, float *out, void *stream);

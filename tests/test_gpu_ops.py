@@ -26,6 +26,31 @@ def test_knn_bit_exact(M, N, k):
     assert np.array_equal(d[0].cpu().numpy().view(np.uint32), do.view(np.uint32))
 
 
+@pytest.mark.parametrize("M,N", [(512, 20000), (5, 300), (1500, 4097)])
+def test_seeded_knn_gives_the_unseeded_result_for_any_seeds(M, N):
+    """dimo_knn_seeded: the seeds only prune -- good ones (the neighbours before a small move), random ones, and
+    broken ones (repeated, negative, out of range) all give the oracle's bits; ties and exact hits included."""
+    from dimo_amd.knn_cuda import knn_points
+    rng = np.random.default_rng(M * 7 + N)
+    ref = rng.standard_normal((M, 3)).astype(np.float32)
+    q = rng.standard_normal((N, 3)).astype(np.float32)
+    q[: min(N, M) // 2] = ref[: min(N, M) // 2]
+    ref[1] = ref[0]
+    order = np.argsort((q[:, 0] > 0) * 2 + (q[:, 1] > 0))  # some spatial coherence inside the waves
+    q = np.ascontiguousarray(q[order])
+    do, io = ro.knn(ref, q, 4)
+    R, Q = torch.tensor(ref).cuda(), torch.tensor(q).cuda()
+    _, prev = knn_points(R, (Q + 0.01 * torch.randn_like(Q)).contiguous(), 4)
+    bad = torch.randint(0, M, (N, 4), device="cuda")
+    bad[::3, 1] = bad[::3, 0]          # repeated index
+    bad[1::3, 2] = -1                  # negative
+    bad[2::3, 3] = M + 5               # out of range
+    for seed in (prev, torch.randint(0, M, (N, 4), device="cuda"), bad, torch.tensor(io).cuda()):
+        d, i = knn_points(R, Q, 4, seed=seed.contiguous())
+        assert np.array_equal(i.cpu().numpy(), io)
+        assert np.array_equal(d.cpu().numpy().view(np.uint32), do.view(np.uint32))
+
+
 def test_knn_matches_deform_fixture():
     from dimo_amd.knn_cuda import knn_points
     z = np.load(os.path.join(GOLD, "deform_latent.npz"))
