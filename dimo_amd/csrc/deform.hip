@@ -472,6 +472,13 @@ inline int deform_grid(int N) {
   return want < 1 ? 1 : (want > 256 ? 256 : want);
 }
 
+// workgroups per deformation group of a batched launch: `total` over the groups, at most one per DEF_BLOCK Gaussians
+inline int batched_grid(int N, int n_groups, int total) {
+  const int per = (N + DEF_BLOCK - 1) / DEF_BLOCK;
+  const int g = total / (n_groups > 0 ? n_groups : 1);
+  return per < 1 ? 1 : (g < 1 ? 1 : (g < per ? g : per));
+}
+
 // control-point tables larger than the default 64 KiB dynamic-LDS window need the opt-in attribute
 inline void allow_big_lds() {
   static const bool once = [] {
@@ -603,7 +610,8 @@ int lbs_forward_batched(const dimo_step_common &c, const RenderBatch &b, int n, 
   allow_big_lds();
   ScopedTimer tm(T_DEFORM_FWD, stream);
   // the control-point table is re-built per workgroup: fewer, fatter workgroups per render when batching
-  const int grid = max(1, deform_grid(c.N) / (b.n_groups > 1 ? 2 : 1));
+  static const int fwd_total = getenv("DIMO_LBS_FWD_WGS") ? atoi(getenv("DIMO_LBS_FWD_WGS")) : 512;
+  const int grid = batched_grid(c.N, b.n_groups, fwd_total);
   if (c.local_frame)
     hipLaunchKernelGGL(lbs_fwd_batched_kernel<true>, dim3(grid, b.n_groups), dim3(DEF_BLOCK), lds, stream, c.N, c.M, g, c.c_xyz,
                        c.c_log_radius, b);
@@ -613,8 +621,9 @@ int lbs_forward_batched(const dimo_step_common &c, const RenderBatch &b, int n, 
   return check_launch();
 }
 
-size_t lbs_backward_batched_scratch_bytes(int N, int M, int n) {
-  return (size_t)n * align_up((size_t)deform_grid(N) * (size_t)(M > 0 ? M : 1) * CP_STRIDE * sizeof(float));
+size_t lbs_backward_batched_scratch_bytes(int N, int M, int n) {  // (an upper bound for any grouping of the n renders)
+  const size_t per = (size_t)((N > 0 ? N : 1) + DEF_BLOCK - 1) / DEF_BLOCK;
+  return (size_t)n * align_up(per * (size_t)(M > 0 ? M : 1) * CP_STRIDE * sizeof(float));
 }
 
 int lbs_backward_batched(const dimo_step_common &c, const RenderBatch &b, int n, hipStream_t stream) {
@@ -633,7 +642,11 @@ int lbs_backward_batched(const dimo_step_common &c, const RenderBatch &b, int n,
   GaussIO g{c.xyz, c.rotation, c.scaling, c.opacity, c.nn_dist, c.nn_idx};
   const size_t lds = 2 * (size_t)c.M * CP_STRIDE * sizeof(float);
   allow_big_lds();
-  const int grid = max(1, deform_grid(c.N) / (b.n_groups > 1 ? 2 : 1));
+  // 768 = three workgroups (45 KB of LDS, 144 VGPRs) on each of the 256 CUs.  The kernel is a latency chain per wave
+  // (1 700 VALU instructions and 32 LDS-atomic instructions per 64 Gaussians) with N / 64 waves per group in all, so
+  // it wants every CU slot: with 128 workgroups per group (round 1) a launch of two groups ran one wave per SIMD.
+  static const int bwd_total = getenv("DIMO_LBS_WGS") ? atoi(getenv("DIMO_LBS_WGS")) : 768;
+  const int grid = batched_grid(c.N, b.n_groups, bwd_total);
   float *partials = reinterpret_cast<float *>(c.lbs_scratch);
   ScopedTimer tm(T_DEFORM_BWD, stream);
   if (c.local_frame)
@@ -656,8 +669,8 @@ using namespace dimo;
 
 extern "C" int dimo_deform_max_ctrl_points(void) { return (160 * 1024 / 2) / (CP_STRIDE * (int)sizeof(float)); }
 
-extern "C" size_t dimo_deform_backward_scratch_bytes(int N, int M) {
-  return align_up((size_t)deform_grid(N) * (size_t)(M > 0 ? M : 1) * CP_STRIDE * sizeof(float));
+extern "C" size_t dimo_deform_backward_scratch_bytes(int N, int M) {  // one table per DEF_BLOCK Gaussians at most
+  return lbs_backward_batched_scratch_bytes(N, M, 1);
 }
 
 extern "C" int dimo_deform_forward(int N, int M, int local_frame, const float *xyz, const float *rotation,
