@@ -366,34 +366,37 @@ __global__ void __launch_bounds__(DEF_BLOCK) lbs_bwd_batched_kernel(int N, int M
                                    GroupExtra{b, b.members[blockIdx.y] & ~(1u << lead)});
 }
 
-// Batched control-point reduction: one thread owns output j of EVERY group (all share the control points), so the
-// adds are ordered.
-__global__ void __launch_bounds__(256) lbs_reduce_batched_kernel(int M, int nblocks, int n_groups,
-                                                                 const float *__restrict__ partials,
-                                                                 float *d_c_xyz, float *d_c_lr, RenderBatch b) {
-  // Thread (jj, chunk) sums the tables chunk, chunk + 16, ... of output j for every group; all of a group's loads
-  // (<= 16 per thread, unconditional from clamped table indices) are issued before the first add.  The kernel is a
-  // few hundred workgroups of pure memory latency on the step's critical path: a loop with one load in flight took
-  // 90 us next to the other motion's blend kernels.
+// Batched control-point reduction: the sums of a group's partial tables are formed by 16 chunk-threads per output
+// (tables chunk, chunk + 16, ...), up to four groups side by side in the workgroup's third dimension, every load of a
+// thread issued before its first add -- the kernel is a few hundred workgroups of pure memory latency on the step's
+// critical path (a loop with one load in flight took 90 us next to the other motion's blend kernels; groups one
+// after the other in the same threads, 20-30 us once the backward wrote 384 tables per group).  One thread then owns
+// output j of EVERY group, so the adds into the shared control-point gradients are ordered.
+constexpr int RED_GROUPS = 4;   // groups reduced side by side (threadIdx.z)
+constexpr int RED_LOADS = 32;   // tables per chunk-thread and pass: 16 x 32 = 512 tables in one round of loads
+__global__ void __launch_bounds__(256 * RED_GROUPS) lbs_reduce_batched_kernel(int M, int nblocks, int n_groups,
+                                                                              const float *__restrict__ partials,
+                                                                              float *d_c_xyz, float *d_c_lr,
+                                                                              RenderBatch b) {
   __shared__ float s_part[MAX_BATCH][16][17];
-  const int jj = threadIdx.x & 15, chunk = threadIdx.x >> 4;
+  const int jj = threadIdx.x & 15, chunk = threadIdx.x >> 4, zz = threadIdx.z;
   const int j = blockIdx.x * 16 + jj;
   const int jc = min(j, M * CP_STRIDE - 1);
   const int m = jc / CP_STRIDE, c = jc % CP_STRIDE;
-  for (int r = 0; r < n_groups; ++r) {
+  for (int r = zz; r < n_groups; r += RED_GROUPS) {
     const float *p = partials + (size_t)r * nblocks * M * CP_STRIDE + jc;
     float s = 0.f;
-    for (int k0 = chunk; k0 < nblocks; k0 += 16 * 16) {
-      float v[16];
+    for (int k0 = chunk; k0 < nblocks; k0 += 16 * RED_LOADS) {
+      float v[RED_LOADS];
 #pragma unroll
-      for (int it = 0; it < 16; ++it) v[it] = p[(size_t)min(k0 + 16 * it, nblocks - 1) * M * CP_STRIDE];
+      for (int it = 0; it < RED_LOADS; ++it) v[it] = p[(size_t)min(k0 + 16 * it, nblocks - 1) * M * CP_STRIDE];
 #pragma unroll
-      for (int it = 0; it < 16; ++it) s += (k0 + 16 * it < nblocks) ? v[it] : 0.f;
+      for (int it = 0; it < RED_LOADS; ++it) s += (k0 + 16 * it < nblocks) ? v[it] : 0.f;
     }
     s_part[r][chunk][jj] = s;
   }
   __syncthreads();
-  if (chunk != 0 || j >= M * CP_STRIDE) return;
+  if (zz != 0 || chunk != 0 || j >= M * CP_STRIDE) return;
   for (int r = 0; r < n_groups; ++r) {
     float s = 0.f;
 #pragma unroll
@@ -655,8 +658,9 @@ int lbs_backward_batched(const dimo_step_common &c, const RenderBatch &b, int n,
   else
     hipLaunchKernelGGL(lbs_bwd_batched_kernel<false>, dim3(grid, b.n_groups), dim3(DEF_BLOCK), lds, stream, c.N, c.M, g,
                        c.c_xyz, c.c_log_radius, b, partials);
-  hipLaunchKernelGGL(lbs_reduce_batched_kernel, dim3((c.M * CP_STRIDE + 15) / 16), dim3(256), 0, stream, c.M, grid,
-                     b.n_groups, partials, c.g_c_xyz, c.g_c_log_radius, b);
+  hipLaunchKernelGGL(lbs_reduce_batched_kernel, dim3((c.M * CP_STRIDE + 15) / 16),
+                     dim3(256, 1, b.n_groups < RED_GROUPS ? b.n_groups : RED_GROUPS), 0, stream, c.M, grid, b.n_groups,
+                     partials, c.g_c_xyz, c.g_c_log_radius, b);
   const size_t total = 14 * (size_t)c.N;
   hipLaunchKernelGGL(accumulate_batched_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, c.N, n, b,
                      c.g_xyz, c.g_rotation, c.g_scaling, c.g_opacity, c.g_f_dc);
