@@ -281,7 +281,7 @@ __device__ __forceinline__ void blend_fwd_body(
 // Optional per-item trace of the backward (diagnostics; compiled in with -DDIMO_BWD_TRACE -- build.py does that when
 // the environment has DIMO_BWD_TRACE=1 -- and then off unless dimo_debug_blend_trace set a buffer): 4 x u64 per
 // item -- s_memrealtime (the chip-wide 100 MHz clock) at its start and end, (XCC id << 56 | render << 48 | item code), (records visited << 48 | quadrant visits <<
-// 32 | HW_ID) -- appended with one atomic per item.
+// 32 | HW_ID[31:16] | visits that some pixel used) -- appended with one atomic per item.
 __device__ unsigned long long *g_bwd_trace = nullptr;
 __device__ unsigned int g_bwd_trace_cap = 0;
 __device__ unsigned int g_bwd_trace_n = 0;
@@ -313,7 +313,7 @@ __device__ __forceinline__ void blend_bwd_item(int H, int W, int tiles_x, uint32
   unsigned long long *const trace = nullptr;  // (everything below that depends on it folds away)
 #endif
   const unsigned long long t_start = trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
-  uint32_t n_rec = 0, n_quad = 0;
+  uint32_t n_rec = 0, n_quad = 0, n_useful = 0;  // (n_useful: visits in which some pixel took the entry)
   const uint32_t HW32 = (uint32_t)H * (uint32_t)W;
   const uint32_t code = it.x, lo = it.y, hi = it.z;
   const int tile = (int)(code >> 12);
@@ -452,6 +452,7 @@ __device__ __forceinline__ void blend_bwd_item(int H, int W, int tiles_x, uint32
       const float alpha = fminf(ALPHA_MAX, C.y * Gs);                                                              \
       const bool active = pos < last[q] && power <= 0.0f && alpha >= ALPHA_MIN;                                    \
       const float ae = active ? alpha : 0.0f;                                                                      \
+      if (trace && __ballot(active) != 0ull) ++n_useful; /* (trace builds only) */                                 \
       const float w = ae * T[q];                                                                                   \
       float D = dp[q][7] + C.z * dp[q][0] + C.w * dp[q][1] + A.x * dp[q][2] + A.y * dp[q][3];                      \
       if (NORMAL) D += A.z * dp[q][4] + A.w * dp[q][5] + NZ * dp[q][6];                                            \
@@ -511,7 +512,7 @@ __device__ __forceinline__ void blend_bwd_item(int H, int W, int tiles_x, uint32
       unsigned long long *t = trace + 4ull * at_;
       t[0] = t_start, t[1] = __builtin_amdgcn_s_memrealtime();
       t[2] = ((unsigned long long)(xcc & 0xfu) << 56) | ((unsigned long long)render << 48) | code;
-      t[3] = ((unsigned long long)n_rec << 48) | ((unsigned long long)n_quad << 32) | hw;
+      t[3] = ((unsigned long long)n_rec << 48) | ((unsigned long long)n_quad << 32) | (hw & 0xffff0000u) | (n_useful & 0xffffu);
     }
   }
 }

@@ -47,7 +47,10 @@ render = ((t[:, 2] >> np.uint64(48)) & np.uint64(0xff)).astype(np.int64)
 bucket = (t[:, 2] & np.uint64(0xfff)).astype(np.int64)
 n_rec = (t[:, 3] >> np.uint64(48)).astype(np.int64)
 n_quad = ((t[:, 3] >> np.uint64(32)) & np.uint64(0xffff)).astype(np.int64)
-hw = (t[:, 3] & np.uint64(0xffffffff)).astype(np.int64)
+hw = (t[:, 3] & np.uint64(0xffff0000)).astype(np.int64)
+n_useful = (t[:, 3] & np.uint64(0xffff)).astype(np.int64)
+print(f"quadrant visits {n_quad.sum()}, of which some pixel used the entry in {n_useful.sum()} "
+      f"({n_useful.sum() / max(1, n_quad.sum()):.3f}); records {n_rec.sum()}")
 d = end - start
 print(f"{n} items, duration mean {d.mean():.0f} ticks, max {d.max()}")
 for b in range(0, 8):
