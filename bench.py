@@ -73,7 +73,7 @@ def kernel_rooflines(timing_iso, N, V, R, P, C=NFEAT, renders_per_launch=1.0):
         "deform_fwd": 92 * N,
         "preprocess_fwd": 56 * N + 77 * V,
         "scan": 8 * N,
-        "sort": 4 * 24 * N,
+        "sort": 2 * 24 * N,  # bin scatter + in-LDS bin sort (binning.hip): read and write (key, id) twice
         "emit": 12 * N + 16 * N,           # level 1: (id, rect) in, ~2 N (id, depth) entries out
         "ranges": 8 * 2 * N + 8 * (P // 256),  # level 2 count + scan + tile starts: the level-1 entries once more
         "place": 8 * 2 * N + 12 * R,       # level 2 fill: entries in, one (key, value) per instance out

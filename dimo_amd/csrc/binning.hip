@@ -20,10 +20,31 @@ namespace dimo {
 // Exclusive scan of the per-block sums (nb <= a few thousand) by one workgroup; writes the
 // grand total R to total[0] and clears the overflow flag total[1].
 __device__ __forceinline__ void scan_block_sums_body(int nb, int N, uint32_t *__restrict__ sums,
-                                                     uint32_t *__restrict__ total) {
+                                                     uint32_t *__restrict__ total, uint32_t *__restrict__ bk) {
   __shared__ uint32_t wave_tot[16];
   __shared__ uint32_t carry_s;
+  __shared__ uint32_t wave_mn[16], wave_mx[16];
   if (threadIdx.x == 0) carry_s = 0;
+  // the depth sort's bin map (see "depth sort" below): range of the keys over the preprocess blocks, bin width 2^shift
+  // with (max - min) >> shift < number of bins
+  {
+    uint32_t mn = 0xffffffffu, mx = 0u;
+    for (int i = threadIdx.x; i < nb; i += 1024) mn = min(mn, sums[(nb + 1) + i]), mx = max(mx, sums[2 * (nb + 1) + i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      mn = min(mn, (uint32_t)__shfl_down((int)mn, o, 64));
+      mx = max(mx, (uint32_t)__shfl_down((int)mx, o, 64));
+    }
+    if ((threadIdx.x & 63) == 0) wave_mn[threadIdx.x >> 6] = mn, wave_mx[threadIdx.x >> 6] = mx;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t mn = wave_mn[0], mx = wave_mx[0];
+    for (int w = 1; w < 16; ++w) mn = min(mn, wave_mn[w]), mx = max(mx, wave_mx[w]);
+    const uint32_t span = mx >= mn ? mx - mn : 0u;
+    const int nbits = span ? 32 - __clz((int)span) : 0, lg = depth_bins_log2(N);
+    bk[BK_KMIN] = mn, bk[BK_SHIFT] = (uint32_t)(nbits > lg ? nbits - lg : 0);
+  }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int base = 0; base < nb; base += 1024) {
@@ -50,7 +71,7 @@ __device__ __forceinline__ void scan_block_sums_body(int nb, int N, uint32_t *__
     total[0] = carry_s;
     total[1] = 0;
     total[2] = 0;
-    total[3] = (uint32_t)N;  // element count of the depth sort
+    total[3] = 0;  // number of depth-sorted Gaussians (depth_bin_scan writes it)
   }
 }
 
@@ -59,8 +80,12 @@ __device__ __forceinline__ void scan_block_sums_body(int nb, int N, uint32_t *__
 __device__ __forceinline__ void write_offsets_body(int N, const uint32_t *__restrict__ tiles,
                                                    const uint32_t *__restrict__ block_prefix,
                                                    uint32_t *__restrict__ offsets, const Splat *__restrict__ splat,
-                                                   uint64_t *__restrict__ nkeys, uint32_t *__restrict__ nvals) {
+                                                   uint64_t *__restrict__ nkeys, uint32_t *__restrict__ nvals,
+                                                   uint32_t *__restrict__ bk) {
   __shared__ uint32_t wave_tot[PRE_BLOCK / 64];
+  __shared__ uint32_t s_hist[NC_MAX];
+  const int nc = 1 << depth_bins_log2(N);
+  if ((int)threadIdx.x < nc) s_hist[threadIdx.x] = 0u;  // (PRE_BLOCK >= NC_MAX)
   const int i = blockIdx.x * PRE_BLOCK + threadIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t v = i < N ? tiles[i] : 0u;
@@ -76,138 +101,256 @@ __device__ __forceinline__ void write_offsets_body(int N, const uint32_t *__rest
   for (int w = 0; w < wave; ++w) off += wave_tot[w];
   if (i < N) {
     offsets[i] = off + inc;
-    nkeys[i] = v ? (uint64_t)__float_as_uint(splat[i].depth) : 0xffffffffull;
+    const uint32_t key = __float_as_uint(splat[i].depth);
+    nkeys[i] = v ? (uint64_t)key : 0xffffffffull;
     nvals[i] = (uint32_t)i;
-  }
-}
-
-// ------------------------------------------------------------------------------------ radix sort
-// LSD, 8 bits per pass, stable.  Per pass: (1) per-block digit histogram, (2) exclusive scan over
-// (digit-major, block-minor) counts, (3) stable scatter using wave-level match ranking.
-// Key i of a sort block lives at (wave w, item j, lane l) -> index ((w*ITEMS + j)*64 + l): order
-// inside the block is (wave, item, lane), which the ranking below preserves.
-constexpr int SORT_WAVES = SORT_BLOCK / 64;
-
-__device__ __forceinline__ uint32_t digit_of(uint64_t k, int shift) { return (uint32_t)(k >> shift) & (RADIX - 1); }
-
-__device__ __forceinline__ void radix_hist_body(const uint64_t *__restrict__ keys,
-                                                const uint32_t *__restrict__ total, uint32_t R_cap, int shift,
-                                                uint32_t num_blocks, uint32_t *__restrict__ hist) {
-  __shared__ uint32_t h[RADIX];
-  const uint32_t R = min(total[0], R_cap);
-  h[threadIdx.x] = 0;
-  __syncthreads();
-  const uint32_t base = blockIdx.x * SORT_TILE;
-  if (base < R) {
-#pragma unroll
-    for (int j = 0; j < SORT_ITEMS; ++j) {
-      const uint32_t idx = base + j * SORT_BLOCK + threadIdx.x;
-      if (idx < R) atomicAdd(&h[digit_of(keys[idx], shift)], 1u);
-    }
+    if (v) atomicAdd(&s_hist[(key - bk[BK_KMIN]) >> bk[BK_SHIFT]], 1u);  // this block's share of its depth bin
   }
   __syncthreads();
-  hist[(size_t)threadIdx.x * num_blocks + blockIdx.x] = h[threadIdx.x];
+  if ((int)threadIdx.x < nc) bk[BK_HIST + (size_t)blockIdx.x * nc + threadIdx.x] = s_hist[threadIdx.x];
 }
 
-// Row scan: one wave per digit turns hist[d][0..num_blocks) into its exclusive prefix and stores
-// the digit total at hist[RADIX*num_blocks + d].  256 independent waves -> no single-block tail.
-__device__ __forceinline__ void radix_rowscan_body(uint32_t num_blocks, uint32_t *__restrict__ hist) {
-  const int lane = threadIdx.x & 63;
-  const uint32_t d = blockIdx.x * 4 + (threadIdx.x >> 6);
-  uint32_t *row = hist + (size_t)d * num_blocks;
-  uint32_t carry = 0;
-  for (uint32_t base = 0; base < num_blocks; base += 64) {
-    const uint32_t i = base + lane;
-    const uint32_t v = i < num_blocks ? row[i] : 0u;
-    uint32_t inc = v;
+// ------------------------------------------------------------------------------------ depth sort
+// The Gaussians of a frame that touch a tile, ordered by (depth bits, index) -- what a stable sort by the 32 depth bits
+// gives.  A frame has ~1e5 of them: an LSD radix sort was 4 passes x 3 launches of pure launch / ramp latency (99 us
+// per batch of 8 renders), and device-scope atomics (a first bucket sort: 2 per key) are slow on this chip (one
+// counter bump per key cost 27 us per batch).  So, without a single global atomic:
+//   1. preprocess leaves the min / max key per block and scan_block_sums derives the bin map (64 or 256 coarse bins of
+//      width 2^shift over [min, max]: monotone in the key); write_offsets counts each block's keys per bin in LDS;
+//   2. depth_bin_scan (one workgroup): column sums over the blocks -> bin bases, every block's first slot per bin;
+//   3. depth_bin_scatter: a block drops its (key, id) pairs into their bins (LDS cursor per bin: unordered inside);
+//   4. depth_bin_sort: ONE WORKGROUP PER BIN (~1 600 entries at 1e5 Gaussians) sorts its bin in LDS: a counting pass
+//      over 256 sub-bins of the bin's key range, then every entry ranks itself inside its sub-bin (a handful of
+//      entries) by the 64-bit word (key << 32 | id) -- all distinct because the ids are.  A bin that does not fit
+//      (thousands of Gaussians at nearly one depth) is sorted by the same workgroup with nine stable byte passes
+//      through global memory: slow, correct, rare.
+// The result does not depend on the order the LDS atomics resolved in.
+constexpr int BIN_CAP = 6144;      // entries a workgroup sorts in LDS (48 KB)
+constexpr int SUB_BINS = 256;
+constexpr int SUB_MAX = 2048;      // largest sub-bin ranked quadratically
+
+// one workgroup of 1024 threads: thread (part, c) first sums its slice of column c of the [blocks][bins] counts, then
+// (bases known) rewrites the slice as each block's first slot
+__device__ __forceinline__ void depth_bin_scan_body(int N, uint32_t *__restrict__ bk, uint32_t *__restrict__ total) {
+  __shared__ uint32_t s_part[16][NC_MAX];
+  __shared__ uint32_t s_scan[NC_MAX];
+  const int lg = depth_bins_log2(N), nc = 1 << lg, parts = 1024 >> lg;
+  const int nb = (N + PRE_BLOCK - 1) / PRE_BLOCK;
+  const int c = threadIdx.x & (nc - 1), part = threadIdx.x >> lg;
+  const int per = (nb + parts - 1) / parts;
+  const int b_lo = min(nb, part * per), b_hi = min(nb, b_lo + per);
+  uint32_t *p = bk + BK_HIST + c;
+  uint32_t sum = 0;
+  for (int b0 = b_lo; b0 < b_hi; b0 += 16) {
+    uint32_t v[16];
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const uint32_t t = __shfl_up(inc, o, 64);
-      if (lane >= o) inc += t;
-    }
-    if (i < num_blocks) row[i] = carry + inc - v;
-    carry += __shfl(inc, 63, 64);
+    for (int j = 0; j < 16; ++j) v[j] = b0 + j < b_hi ? p[(size_t)(b0 + j) * nc] : 0u;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) sum += v[j];
   }
-  if (lane == 0) hist[(size_t)RADIX * num_blocks + d] = carry;
+  s_part[part][c] = sum;
+  __syncthreads();
+  uint32_t before = 0, len = 0;
+  for (int q = 0; q < parts; ++q) {
+    before += q < part ? s_part[q][c] : 0u;
+    len += s_part[q][c];
+  }
+  if (part == 0) s_scan[c] = len;
+  __syncthreads();
+  for (int o = 1; o < nc; o <<= 1) {  // Hillis-Steele inclusive scan of the bin sizes
+    const uint32_t add = (part == 0 && c >= o) ? s_scan[c - o] : 0u;
+    __syncthreads();
+    if (part == 0) s_scan[c] += add;
+    __syncthreads();
+  }
+  const uint32_t base = s_scan[c] - len;
+  if (part == 0) {
+    bk[BK_BASE + c] = base;
+    if (c == nc - 1) bk[BK_BASE + nc] = s_scan[c], total[3] = s_scan[c];
+  }
+  uint32_t run = base + before;
+  for (int b0 = b_lo; b0 < b_hi; b0 += 16) {
+    uint32_t v[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = b0 + j < b_hi ? p[(size_t)(b0 + j) * nc] : 0u;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      if (b0 + j < b_hi) p[(size_t)(b0 + j) * nc] = run;
+      run += v[j];
+    }
+  }
 }
 
-__device__ __forceinline__ void radix_scatter_body(
-    const uint64_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, uint64_t *__restrict__ keys_out,
-    uint32_t *__restrict__ vals_out, const uint32_t *__restrict__ total, uint32_t R_cap, int shift,
-    uint32_t num_blocks, const uint32_t *__restrict__ hist) {
-  __shared__ uint32_t cnt[SORT_WAVES][RADIX];  // per-wave running digit counts
-  __shared__ uint32_t gbase[RADIX];            // global base of (digit, this block)
-  const uint32_t R = min(total[0], R_cap);
-  const uint32_t base = blockIdx.x * SORT_TILE;
-  if (base >= R) return;
+// blocks of PRE_BLOCK keys, the SAME blocks write_offsets counted
+__device__ __forceinline__ void depth_bin_scatter_body(int N, const uint64_t *__restrict__ keys_in,
+                                                       uint64_t *__restrict__ keys_out,
+                                                       uint32_t *__restrict__ vals_out,
+                                                       const uint32_t *__restrict__ bk) {
+  __shared__ uint32_t s_cur[NC_MAX];
+  const int nc = 1 << depth_bins_log2(N);
+  if ((int)threadIdx.x < nc) s_cur[threadIdx.x] = bk[BK_HIST + (size_t)blockIdx.x * nc + threadIdx.x];
+  __syncthreads();
+  const int idx = blockIdx.x * PRE_BLOCK + (int)threadIdx.x;
+  if (idx >= N) return;
+  const uint64_t k = keys_in[idx];
+  if ((uint32_t)k == 0xffffffffu) return;  // touches no tile: not sorted at all
+  const uint32_t pos = atomicAdd(&s_cur[((uint32_t)k - bk[BK_KMIN]) >> bk[BK_SHIFT]], 1u);
+  keys_out[pos] = k;
+  vals_out[pos] = (uint32_t)idx;
+}
+
+// One stable counting pass of a single workgroup over n (key, id) pairs: digit = byte `byte` of the 9-byte word
+// (id bytes 0..3, key bytes 0..4 -- the last one is zero, a copy pass that makes the number of passes odd).
+__device__ __forceinline__ uint32_t pair_digit(uint64_t k, uint32_t v, int byte) {
+  return byte < 4 ? (v >> (8 * byte)) & 255u : (uint32_t)(k >> (8 * (byte - 4))) & 255u;
+}
+__device__ __forceinline__ void wg_radix_pass(const uint64_t *kin, const uint32_t *vin, uint64_t *kout, uint32_t *vout,
+                                              uint32_t n, int byte, uint32_t *s_run, uint32_t (*s_cnt)[256]) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-  for (int w = 0; w < SORT_WAVES; ++w) cnt[w][threadIdx.x] = 0;
-  {
-    // exclusive scan of the 256 digit totals (thread d owns digit d) + this block's row prefix
-    __shared__ uint32_t wtot[SORT_WAVES];
-    const uint32_t tot = hist[(size_t)RADIX * num_blocks + threadIdx.x];
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  s_run[threadIdx.x] = 0;
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < n; i += SORT_BLOCK) atomicAdd(&s_run[pair_digit(kin[i], vin[i], byte)], 1u);
+  __syncthreads();
+  {  // exclusive scan of the 256 digit counts (thread d owns digit d)
+    const uint32_t tot = s_run[threadIdx.x];
     uint32_t inc = tot;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
       const uint32_t t = __shfl_up(inc, o, 64);
       if (lane >= o) inc += t;
     }
-    if (lane == 63) wtot[wave] = inc;
+    __syncthreads();
+    if (lane == 63) s_cnt[0][wave] = inc;
     __syncthreads();
     uint32_t off = 0;
-    for (int w = 0; w < wave; ++w) off += wtot[w];
-    gbase[threadIdx.x] = off + inc - tot + hist[(size_t)threadIdx.x * num_blocks + blockIdx.x];
+    for (int w = 0; w < wave; ++w) off += s_cnt[0][w];
+    __syncthreads();
+    s_run[threadIdx.x] = off + inc - tot;
   }
-  __syncthreads();
-
-  uint64_t k[SORT_ITEMS];
-  uint32_t v[SORT_ITEMS], rank[SORT_ITEMS];
-  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  for (uint32_t i0 = 0; i0 < n; i0 += SORT_BLOCK) {  // chunks in order: stable
 #pragma unroll
-  for (int j = 0; j < SORT_ITEMS; ++j) {
-    const uint32_t idx = base + (wave * SORT_ITEMS + j) * 64 + lane;
-    const bool valid = idx < R;
-    k[j] = valid ? keys_in[idx] : ~0ull;
-    v[j] = valid ? vals_in[idx] : 0u;
-    const uint32_t d = digit_of(k[j], shift);
-    // lanes of this wave holding the same digit (invalid lanes excluded)
+    for (int w = 0; w < SORT_BLOCK / 64; ++w) s_cnt[w][threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t i = i0 + threadIdx.x;
+    const bool valid = i < n;
+    const uint64_t k = valid ? kin[i] : 0;
+    const uint32_t v = valid ? vin[i] : 0;
+    const uint32_t d = pair_digit(k, v, byte);
     unsigned long long peers = __ballot(valid);
 #pragma unroll
-    for (int b = 0; b < RADIX_BITS; ++b) {
-      const unsigned long long bal = __ballot((d >> b) & 1u);
-      peers &= ((d >> b) & 1u) ? bal : ~bal;
+    for (int bit = 0; bit < 8; ++bit) {
+      const unsigned long long bal = __ballot((d >> bit) & 1u);
+      peers &= ((d >> bit) & 1u) ? bal : ~bal;
     }
-    const uint32_t before = (uint32_t)__popcll(peers & lt_mask);
-    uint32_t prev = 0;
-    if (valid && before == 0) {  // group leader bumps the wave's running count
-      prev = cnt[wave][d];
-      cnt[wave][d] = prev + (uint32_t)__popcll(peers);
-    }
-    const int leader = __ffsll((long long)peers) - 1;
-    prev = __shfl(prev, leader < 0 ? 0 : leader, 64);
-    rank[j] = prev + before;
-  }
-  __syncthreads();
-  // exclusive prefix over waves per digit, folded into the global base
-  {
-    uint32_t run = gbase[threadIdx.x];
+    const uint32_t before = (uint32_t)__popcll(peers & lt);
+    if (valid && before == 0) s_cnt[wave][d] = (uint32_t)__popcll(peers);
+    __syncthreads();
+    {  // thread d: first slot of every wave's entries with digit d, then the running offset moves on
+      uint32_t run = s_run[threadIdx.x];
 #pragma unroll
-    for (int w = 0; w < SORT_WAVES; ++w) {
-      const uint32_t c = cnt[w][threadIdx.x];
-      cnt[w][threadIdx.x] = run;
-      run += c;
+      for (int w = 0; w < SORT_BLOCK / 64; ++w) {
+        const uint32_t cw = s_cnt[w][threadIdx.x];
+        s_cnt[w][threadIdx.x] = run;
+        run += cw;
+      }
+      s_run[threadIdx.x] = run;
     }
+    __syncthreads();
+    if (valid) {
+      const uint32_t pos = s_cnt[wave][d] + before;
+      kout[pos] = k, vout[pos] = v;
+    }
+    __syncthreads();
   }
-  __syncthreads();
+}
+
+__device__ __forceinline__ void depth_bin_sort_body(int N, uint64_t *__restrict__ keys_b, uint32_t *__restrict__ vals_b,
+                                                    uint64_t *__restrict__ keys_a, uint32_t *__restrict__ vals_a,
+                                                    const uint32_t *__restrict__ bk) {
+  __shared__ unsigned long long s_k[BIN_CAP];
+  __shared__ uint32_t s_start[SUB_BINS + 1], s_cur[SUB_BINS];
+  __shared__ uint32_t s_run[256];
+  __shared__ uint32_t s_cnt[SORT_BLOCK / 64][256];
+  __shared__ uint32_t s_big;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t bin = blockIdx.x;
+  if ((int)bin >= (1 << depth_bins_log2(N))) return;
+  const uint32_t base = bk[BK_BASE + bin], n = bk[BK_BASE + bin + 1] - base;
+  if (n == 0) return;
+  const uint32_t shift = bk[BK_SHIFT];
+  const uint32_t klo = bk[BK_KMIN] + (bin << shift);  // smallest key of the bin
+  const uint32_t sub_shift = shift > 8 ? shift - 8 : 0;  // 256 sub-bins over the bin's 2^shift keys
+  bool lds = n <= (uint32_t)BIN_CAP;
+  // the thread's entries, every load issued before the first use (a load -> LDS-atomic loop was one memory round
+  // trip per 256 entries: 42 us for the kernel)
+  constexpr int PER = BIN_CAP / SORT_BLOCK;
+  unsigned long long mine[PER];
+  if (lds) {
 #pragma unroll
-  for (int j = 0; j < SORT_ITEMS; ++j) {
-    const uint32_t idx = base + (wave * SORT_ITEMS + j) * 64 + lane;
-    if (idx < R) {
-      const uint32_t pos = cnt[wave][digit_of(k[j], shift)] + rank[j];
-      keys_out[pos] = k[j];
-      vals_out[pos] = v[j];
+    for (int q = 0; q < PER; ++q) {
+      const uint32_t e = (uint32_t)q * SORT_BLOCK + threadIdx.x, ec = e < n ? e : n - 1;
+      mine[q] = (keys_b[base + ec] << 32) | (unsigned long long)vals_b[base + ec];
     }
+    s_cur[threadIdx.x] = 0u;  // (SORT_BLOCK == SUB_BINS)
+    if (threadIdx.x == 0) s_big = 0u;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < PER; ++q)
+      if ((uint32_t)q * SORT_BLOCK + threadIdx.x < n)
+        atomicAdd(&s_cur[((uint32_t)(mine[q] >> 32) - klo) >> sub_shift], 1u);
+    __syncthreads();
+    {  // exclusive scan of the 256 sub-bin sizes (thread f owns sub-bin f)
+      const uint32_t cnt = s_cur[threadIdx.x];
+      if (cnt > (uint32_t)SUB_MAX) s_big = 1u;
+      uint32_t inc = cnt;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += t;
+      }
+      if (lane == 63) s_run[wave] = inc;
+      __syncthreads();
+      uint32_t off = 0;
+      for (int w = 0; w < wave; ++w) off += s_run[w];
+      s_start[threadIdx.x] = off + inc - cnt;
+      if (threadIdx.x == SORT_BLOCK - 1) s_start[SUB_BINS] = off + inc;
+      __syncthreads();
+      s_cur[threadIdx.x] = s_start[threadIdx.x];
+    }
+    __syncthreads();
+    lds = s_big == 0u;  // (workgroup-uniform)
+  }
+  if (lds) {
+#pragma unroll
+    for (int q = 0; q < PER; ++q)
+      if ((uint32_t)q * SORT_BLOCK + threadIdx.x < n)
+        s_k[atomicAdd(&s_cur[((uint32_t)(mine[q] >> 32) - klo) >> sub_shift], 1u)] = mine[q];
+    __syncthreads();
+    for (uint32_t e = threadIdx.x; e < n; e += SORT_BLOCK) {
+      const unsigned long long c = s_k[e];
+      const uint32_t f = ((uint32_t)(c >> 32) - klo) >> sub_shift;
+      const uint32_t lo = s_start[f], hi = s_start[f + 1];
+      uint32_t r = 0;
+      for (uint32_t t = lo; t < hi; t += 8) {  // eight LDS reads in flight (clamped, masked)
+        unsigned long long v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = s_k[min(t + u, hi - 1)];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) r += (t + u < hi && v[u] < c) ? 1u : 0u;
+      }
+      keys_a[base + lo + r] = c >> 32;
+      vals_a[base + lo + r] = (uint32_t)c;
+    }
+    return;
+  }
+  // nine stable byte passes over (id, key), b -> a -> b ... -> a
+  for (int byte = 0; byte < 9; ++byte) {
+    const bool b2a = (byte & 1) == 0;
+    wg_radix_pass((b2a ? keys_b : keys_a) + base, (b2a ? vals_b : vals_a) + base, (b2a ? keys_a : keys_b) + base,
+                  (b2a ? vals_a : vals_b) + base, n, byte, s_run, s_cnt);
+    __threadfence_block();
+    __syncthreads();
   }
 }
 
@@ -239,7 +382,8 @@ constexpr int META_LEN = 0, META_START = MAX_SUPER, META_NWIN = 2 * MAX_SUPER, M
 // version walked the segment with ONE wave, four rounds of 64 entries chained through the running counts: with only
 // N / 256 waves per render the kernel is pure latency, and that chain was four times longer.)
 template <bool FILL>
-__device__ __forceinline__ void level1_body(int N, BinGrid gi, const uint32_t *__restrict__ perm,
+__device__ __forceinline__ void level1_body(int N_all, const uint32_t *__restrict__ n_sorted, BinGrid gi,
+                                            const uint32_t *__restrict__ perm,
                                             const uint64_t *__restrict__ nkeys, const uint16_t *__restrict__ rect,
                                             uint32_t *__restrict__ cnt1, const uint32_t *__restrict__ meta,
                                             uint2 *__restrict__ l1list, size_t l1cap) {
@@ -254,10 +398,11 @@ __device__ __forceinline__ void level1_body(int N, BinGrid gi, const uint32_t *_
   for (int w = 0; w < SEG / 64; ++w) s_cnt[w][threadIdx.x] = 0u;
   int nbits = 0;
   while ((1 << nbits) < gi.NS) ++nbits;
+  const int N = min(N_all, (int)n_sorted[0]);  // the depth sort holds only the Gaussians that touch a tile
   const int k = seg * SEG + wave * 64 + lane;
   const bool valid = k < N;
-  const uint32_t g = perm[min(k, N - 1)];
-  const uint32_t dbits = FILL ? (uint32_t)nkeys[min(k, N - 1)] : 0u;
+  const uint32_t g = valid ? perm[k] : 0u;
+  const uint32_t dbits = (FILL && valid) ? (uint32_t)nkeys[k] : 0u;
   const uint2 rc = *reinterpret_cast<const uint2 *>(rect + 4 * (size_t)g);
   const int x0 = rc.x & 0xffff, y0 = rc.x >> 16, x1 = rc.y & 0xffff, y1 = rc.y >> 16;
   const bool some = valid && x1 > x0 && y1 > y0;
@@ -518,37 +663,36 @@ struct BinPtrs {  // byte offsets into the geometry (g_) and bin (b_) workspaces
 };
 
 __global__ void __launch_bounds__(1024) scan_block_sums_kernel(int nb, int N, uint32_t *__restrict__ sums,
-                                                               uint32_t *__restrict__ total) {
-  scan_block_sums_body(nb, N, sums, total);
+                                                               uint32_t *__restrict__ total,
+                                                               uint32_t *__restrict__ bk) {
+  scan_block_sums_body(nb, N, sums, total, bk);
 }
 __global__ void __launch_bounds__(PRE_BLOCK) write_offsets_kernel(int N, const uint32_t *__restrict__ tiles,
                                                                   const uint32_t *__restrict__ block_prefix,
                                                                   uint32_t *__restrict__ offsets,
                                                                   const Splat *__restrict__ splat,
                                                                   uint64_t *__restrict__ nkeys,
-                                                                  uint32_t *__restrict__ nvals) {
-  write_offsets_body(N, tiles, block_prefix, offsets, splat, nkeys, nvals);
+                                                                  uint32_t *__restrict__ nvals,
+                                                                  uint32_t *__restrict__ bk) {
+  write_offsets_body(N, tiles, block_prefix, offsets, splat, nkeys, nvals, bk);
 }
-__global__ void __launch_bounds__(SORT_BLOCK) radix_hist_kernel(const uint64_t *__restrict__ keys,
-                                                                const uint32_t *__restrict__ total, uint32_t R_cap,
-                                                                int shift, uint32_t num_blocks,
-                                                                uint32_t *__restrict__ hist) {
-  radix_hist_body(keys, total, R_cap, shift, num_blocks, hist);
+__global__ void __launch_bounds__(1024) depth_bin_scan_kernel(int N, GeomLayout L, void *geom) {
+  depth_bin_scan_body(N, at<uint32_t>(geom, L.bk), at<uint32_t>(geom, L.total));
 }
-__global__ void __launch_bounds__(256) radix_rowscan_kernel(uint32_t num_blocks, uint32_t *__restrict__ hist) {
-  radix_rowscan_body(num_blocks, hist);
+__global__ void __launch_bounds__(PRE_BLOCK) depth_bin_scatter_kernel(int N, GeomLayout L, void *geom) {
+  depth_bin_scatter_body(N, at<uint64_t>(geom, L.nkeys_a), at<uint64_t>(geom, L.nkeys_b), at<uint32_t>(geom, L.nvals_b),
+                         at<uint32_t>(geom, L.bk));
 }
-__global__ void __launch_bounds__(SORT_BLOCK) radix_scatter_kernel(
-    const uint64_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, uint64_t *__restrict__ keys_out,
-    uint32_t *__restrict__ vals_out, const uint32_t *__restrict__ total, uint32_t R_cap, int shift,
-    uint32_t num_blocks, const uint32_t *__restrict__ hist) {
-  radix_scatter_body(keys_in, vals_in, keys_out, vals_out, total, R_cap, shift, num_blocks, hist);
+__global__ void __launch_bounds__(SORT_BLOCK) depth_bin_sort_kernel(int N, GeomLayout L, void *geom) {
+  depth_bin_sort_body(N, at<uint64_t>(geom, L.nkeys_b), at<uint32_t>(geom, L.nvals_b), at<uint64_t>(geom, L.nkeys_a),
+                      at<uint32_t>(geom, L.nvals_a), at<uint32_t>(geom, L.bk));
 }
 
 // placement stages: `geom` / `bin` are the workspaces of the render (blockIdx.y picks it in the batched launches)
 template <bool FILL>
 __device__ __forceinline__ void level1_stage(int N, BinGrid gi, const BinPtrs &o, void *geom, void *bin) {
-  level1_body<FILL>(N, gi, at<uint32_t>(geom, o.g_perm), at<uint64_t>(geom, o.g_nkeys), at<uint16_t>(geom, o.g_rect),
+  level1_body<FILL>(N, at<uint32_t>(geom, o.g_total) + 3, gi, at<uint32_t>(geom, o.g_perm),
+                    at<uint64_t>(geom, o.g_nkeys), at<uint16_t>(geom, o.g_rect),
                     at<uint32_t>(geom, o.g_cnt1), at<uint32_t>(bin, o.b_meta), at<uint2>(bin, o.b_l1), o.l1cap);
 }
 template <bool FILL>
@@ -580,31 +724,27 @@ __global__ void __launch_bounds__(1024) tile_starts_kernel(int T, uint32_t R_cap
 
 __global__ void __launch_bounds__(1024) scan_block_sums_batched_kernel(int nb, int N, GeomLayout L, RenderBatch b) {
   void *geom = b.r[blockIdx.y].geom;
-  scan_block_sums_body(nb, N, at<uint32_t>(geom, L.block_sums), at<uint32_t>(geom, L.total));
+  scan_block_sums_body(nb, N, at<uint32_t>(geom, L.block_sums), at<uint32_t>(geom, L.total), at<uint32_t>(geom, L.bk));
 }
 __global__ void __launch_bounds__(PRE_BLOCK) write_offsets_batched_kernel(int N, GeomLayout L, RenderBatch b) {
   void *geom = b.r[blockIdx.y].geom;
   write_offsets_body(N, at<uint32_t>(geom, L.tiles), at<uint32_t>(geom, L.block_sums), at<uint32_t>(geom, L.offsets),
-                     at<Splat>(geom, L.splat), at<uint64_t>(geom, L.nkeys_a), at<uint32_t>(geom, L.nvals_a));
+                     at<Splat>(geom, L.splat), at<uint64_t>(geom, L.nkeys_a), at<uint32_t>(geom, L.nvals_a),
+                     at<uint32_t>(geom, L.bk));
 }
-__global__ void __launch_bounds__(SORT_BLOCK) radix_hist_batched_kernel(GeomLayout L, size_t keys_off, uint32_t cap,
-                                                                        int shift, uint32_t num_blocks,
-                                                                        RenderBatch b) {
+__global__ void __launch_bounds__(1024) depth_bin_scan_batched_kernel(int N, GeomLayout L, RenderBatch b) {
   void *geom = b.r[blockIdx.y].geom;
-  radix_hist_body(at<uint64_t>(geom, keys_off), at<uint32_t>(geom, L.total) + 3, cap, shift, num_blocks,
-                  at<uint32_t>(geom, L.nhist));
+  depth_bin_scan_body(N, at<uint32_t>(geom, L.bk), at<uint32_t>(geom, L.total));
 }
-__global__ void __launch_bounds__(256) radix_rowscan_batched_kernel(GeomLayout L, uint32_t num_blocks, RenderBatch b) {
-  radix_rowscan_body(num_blocks, at<uint32_t>(b.r[blockIdx.y].geom, L.nhist));
-}
-__global__ void __launch_bounds__(SORT_BLOCK) radix_scatter_batched_kernel(GeomLayout L, size_t kin, size_t vin,
-                                                                           size_t kout, size_t vout, uint32_t cap,
-                                                                           int shift, uint32_t num_blocks,
-                                                                           RenderBatch b) {
+__global__ void __launch_bounds__(PRE_BLOCK) depth_bin_scatter_batched_kernel(int N, GeomLayout L, RenderBatch b) {
   void *geom = b.r[blockIdx.y].geom;
-  radix_scatter_body(at<uint64_t>(geom, kin), at<uint32_t>(geom, vin), at<uint64_t>(geom, kout),
-                     at<uint32_t>(geom, vout), at<uint32_t>(geom, L.total) + 3, cap, shift, num_blocks,
-                     at<uint32_t>(geom, L.nhist));
+  depth_bin_scatter_body(N, at<uint64_t>(geom, L.nkeys_a), at<uint64_t>(geom, L.nkeys_b), at<uint32_t>(geom, L.nvals_b),
+                         at<uint32_t>(geom, L.bk));
+}
+__global__ void __launch_bounds__(SORT_BLOCK) depth_bin_sort_batched_kernel(int N, GeomLayout L, RenderBatch b) {
+  void *geom = b.r[blockIdx.y].geom;
+  depth_bin_sort_body(N, at<uint64_t>(geom, L.nkeys_b), at<uint32_t>(geom, L.nvals_b), at<uint64_t>(geom, L.nkeys_a),
+                      at<uint32_t>(geom, L.nvals_a), at<uint32_t>(geom, L.bk));
 }
 template <bool FILL>
 __global__ void __launch_bounds__(SEG) level1_batched_kernel(int N, BinGrid gi, BinPtrs o, RenderBatch b) {
@@ -631,8 +771,6 @@ __global__ void __launch_bounds__(1024) tile_starts_batched_kernel(int T, uint32
 }
 
 // ------------------------------------------------------------------------------------ host side
-constexpr int DEPTH_PASSES = 32 / RADIX_BITS;  // even: the sorted pair ends up in nkeys_a / nvals_a again
-static_assert(DEPTH_PASSES % 2 == 0, "ping-pong must end in the _a buffers");
 constexpr int L2_GRID = 2048;  // persistent waves over the level-2 windows (their number is only known on device)
 
 // supertile edge: the smallest power of two that leaves <= 64 supertiles, else <= MAX_SUPER; edge <= 8 (64 tiles
@@ -660,8 +798,8 @@ static BinPtrs make_ptrs(const GeomLayout &G, const BinLayout &B) {
   return o;
 }
 
-int scan_block_sums(int nb, int N, uint32_t *block_sums, uint32_t *total, hipStream_t stream) {
-  hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(1024), 0, stream, nb, N, block_sums, total);
+int scan_block_sums(int nb, int N, uint32_t *block_sums, uint32_t *total, uint32_t *bk, hipStream_t stream) {
+  hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(1024), 0, stream, nb, N, block_sums, total, bk);
   return check_launch();
 }
 
@@ -672,7 +810,7 @@ int write_offsets(int N, const void *geom_c, hipStream_t stream) {
   void *geom = const_cast<void *>(geom_c);
   hipLaunchKernelGGL(write_offsets_kernel, dim3(nb), dim3(PRE_BLOCK), 0, stream, N, at<uint32_t>(geom, L.tiles),
                      at<uint32_t>(geom, L.block_sums), at<uint32_t>(geom, L.offsets), at<Splat>(geom, L.splat),
-                     at<uint64_t>(geom, L.nkeys_a), at<uint32_t>(geom, L.nvals_a));
+                     at<uint64_t>(geom, L.nkeys_a), at<uint32_t>(geom, L.nvals_a), at<uint32_t>(geom, L.bk));
   return check_launch();
 }
 
@@ -684,23 +822,12 @@ int bin_instances(int N, int H, int W, int64_t R_cap, const void *geom_c, void *
   void *geom = const_cast<void *>(geom_c);  // sort scratch and the overflow flag live in the geometry workspace
   const uint32_t cap = (uint32_t)B.cap;
   const BinPtrs o = make_ptrs(G, B);
-  uint32_t *total = at<uint32_t>(geom, G.total);
   if (N > 0) {
     ScopedTimer tm(T_SORT, stream);
-    const uint32_t nblk = (uint32_t)G.sort_blocks;
-    uint32_t *hist = at<uint32_t>(geom, G.nhist);
-    for (int p = 0; p < DEPTH_PASSES; ++p) {
-      const bool a2b = (p & 1) == 0;
-      const uint64_t *kin = at<uint64_t>(geom, a2b ? G.nkeys_a : G.nkeys_b);
-      const uint32_t *vin = at<uint32_t>(geom, a2b ? G.nvals_a : G.nvals_b);
-      uint64_t *kout = at<uint64_t>(geom, a2b ? G.nkeys_b : G.nkeys_a);
-      uint32_t *vout = at<uint32_t>(geom, a2b ? G.nvals_b : G.nvals_a);
-      hipLaunchKernelGGL(radix_hist_kernel, dim3(nblk), dim3(SORT_BLOCK), 0, stream, kin, total + 3, (uint32_t)N,
-                         p * RADIX_BITS, nblk, hist);
-      hipLaunchKernelGGL(radix_rowscan_kernel, dim3(RADIX / 4), dim3(256), 0, stream, nblk, hist);
-      hipLaunchKernelGGL(radix_scatter_kernel, dim3(nblk), dim3(SORT_BLOCK), 0, stream, kin, vin, kout, vout,
-                         total + 3, (uint32_t)N, p * RADIX_BITS, nblk, hist);
-    }
+    const unsigned nb = (unsigned)((N + PRE_BLOCK - 1) / PRE_BLOCK), nc = 1u << depth_bins_log2(N);
+    hipLaunchKernelGGL(depth_bin_scan_kernel, dim3(1), dim3(1024), 0, stream, N, G, geom);
+    hipLaunchKernelGGL(depth_bin_scatter_kernel, dim3(nb), dim3(PRE_BLOCK), 0, stream, N, G, geom);
+    hipLaunchKernelGGL(depth_bin_sort_kernel, dim3(nc), dim3(SORT_BLOCK), 0, stream, N, G, geom);
   }
   const int nseg = (int)G.nseg1;
   {
@@ -743,17 +870,10 @@ int bin_instances_batched(const dimo_step_common &c, const RenderBatch &b, int n
   const BinPtrs o = make_ptrs(G, B);
   if (c.N > 0) {
     ScopedTimer tm(T_SORT, stream);
-    const uint32_t nblk = (uint32_t)G.sort_blocks;
-    for (int p = 0; p < DEPTH_PASSES; ++p) {
-      const bool a2b = (p & 1) == 0;
-      const size_t kin = a2b ? G.nkeys_a : G.nkeys_b, vin = a2b ? G.nvals_a : G.nvals_b;
-      const size_t kout = a2b ? G.nkeys_b : G.nkeys_a, vout = a2b ? G.nvals_b : G.nvals_a;
-      hipLaunchKernelGGL(radix_hist_batched_kernel, dim3(nblk, n), dim3(SORT_BLOCK), 0, stream, G, kin,
-                         (uint32_t)c.N, p * RADIX_BITS, nblk, b);
-      hipLaunchKernelGGL(radix_rowscan_batched_kernel, dim3(RADIX / 4, n), dim3(256), 0, stream, G, nblk, b);
-      hipLaunchKernelGGL(radix_scatter_batched_kernel, dim3(nblk, n), dim3(SORT_BLOCK), 0, stream, G, kin, vin, kout,
-                         vout, (uint32_t)c.N, p * RADIX_BITS, nblk, b);
-    }
+    const unsigned nb = (unsigned)((c.N + PRE_BLOCK - 1) / PRE_BLOCK), nc = 1u << depth_bins_log2(c.N);
+    hipLaunchKernelGGL(depth_bin_scan_batched_kernel, dim3(1, n), dim3(1024), 0, stream, c.N, G, b);
+    hipLaunchKernelGGL(depth_bin_scatter_batched_kernel, dim3(nb, n), dim3(PRE_BLOCK), 0, stream, c.N, G, b);
+    hipLaunchKernelGGL(depth_bin_sort_batched_kernel, dim3(nc, n), dim3(SORT_BLOCK), 0, stream, c.N, G, b);
   }
   const int nseg = (int)G.nseg1;
   {

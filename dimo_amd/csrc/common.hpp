@@ -49,14 +49,19 @@ __host__ __device__ inline size_t align_up(size_t x, size_t a = ALIGN) { return 
 constexpr int PRE_BLOCK = 256;  // Gaussians per preprocess block (also the scan granule)
 
 constexpr int SORT_BLOCK = 256;
-constexpr int SORT_ITEMS = 4;   // 1024 keys per block: the sort runs over the ~1e5 Gaussians of a frame, many small blocks fill the chip
-constexpr int SORT_TILE = SORT_BLOCK * SORT_ITEMS;  // keys per sort block
-constexpr int RADIX_BITS = 8;
-constexpr int RADIX = 1 << RADIX_BITS;
+constexpr int SORT_ITEMS = 4;   // 1024 keys per block of the bucket scatter
+constexpr int SORT_TILE = SORT_BLOCK * SORT_ITEMS;
+// Depth sort of a frame's Gaussians (binning.hip): coarse bins over [min, max] of the depth bits, every bin sorted in
+// LDS by one workgroup.  Word offsets inside the `bk` area of the geometry workspace:
+constexpr int NC_MAX = 256;                                          // coarse bins (128 up to 400 k Gaussians, else 256)
+constexpr size_t BK_KMIN = 0, BK_SHIFT = 1;                          // header (4 words): smallest key, log2 bin width
+constexpr size_t BK_BASE = 4;                                        // NC + 1 exclusive prefix sums of the bin sizes
+constexpr size_t BK_HIST = BK_BASE + NC_MAX + 4;                     // [preprocess blocks][NC]: counts, then offsets
+inline __host__ __device__ int depth_bins_log2(int N) { return N <= 400000 ? 7 : 8; }
 
 struct GeomLayout {
   size_t splat, rect, tiles, offsets, flags, total, block_sums;
-  size_t nkeys_a, nvals_a, nkeys_b, nvals_b, nhist;  // depth sort of the Gaussians (binning.hip)
+  size_t nkeys_a, nvals_a, nkeys_b, nvals_b, bk;  // depth sort of the Gaussians (binning.hip)
   size_t cnt1;                                       // level-1 filter counters [segments of 256][256 supertiles]
   size_t bytes, sort_blocks, nseg1;
   __host__ explicit GeomLayout(int N) {
@@ -67,15 +72,16 @@ struct GeomLayout {
     tiles = o, o = align_up(o + n * sizeof(uint32_t));
     offsets = o, o = align_up(o + n * sizeof(uint32_t));
     flags = o, o = align_up(o + n);
-    total = o, o = align_up(o + 4 * sizeof(uint32_t));  // R, overflow flag, 0, N
+    total = o, o = align_up(o + 4 * sizeof(uint32_t));  // R, overflow flag, 0, number of depth-sorted Gaussians
     size_t nb = (n + PRE_BLOCK - 1) / PRE_BLOCK;
-    block_sums = o, o = align_up(o + (nb + 1) * sizeof(uint32_t));
+    // per preprocess block: tiles touched [nb + 1], then min / max of the depth bits of its visible Gaussians
+    block_sums = o, o = align_up(o + 3 * (nb + 1) * sizeof(uint32_t));
     sort_blocks = (n + SORT_TILE - 1) / SORT_TILE;
     nkeys_a = o, o = align_up(o + n * sizeof(uint64_t));
     nvals_a = o, o = align_up(o + n * sizeof(uint32_t));
     nkeys_b = o, o = align_up(o + n * sizeof(uint64_t));
     nvals_b = o, o = align_up(o + n * sizeof(uint32_t));
-    nhist = o, o = align_up(o + ((size_t)RADIX * (sort_blocks + 1)) * sizeof(uint32_t));
+    bk = o, o = align_up(o + (BK_HIST + nb * ((size_t)1 << depth_bins_log2(N))) * sizeof(uint32_t));
     nseg1 = (n + 255) / 256;
     cnt1 = o, o = align_up(o + nseg1 * 256 * sizeof(uint32_t));
     bytes = o;
@@ -200,7 +206,7 @@ int blend_forward_batched(const dimo_step_common &c, const RenderBatch &b, int n
 int blend_backward_batched(const dimo_step_common &c, const RenderBatch &b, int n, hipStream_t stream);
 
 // ---- internal (C++ linkage) entry points shared between translation units ---------------------
-int scan_block_sums(int nb, int N, uint32_t *block_sums, uint32_t *total, hipStream_t stream);
+int scan_block_sums(int nb, int N, uint32_t *block_sums, uint32_t *total, uint32_t *bk, hipStream_t stream);
 int write_offsets(int N, const void *geom, hipStream_t stream);
 int bin_instances(int N, int H, int W, int64_t R_cap, const void *geom, void *bin, hipStream_t stream);
 int preprocess_backward_launch(int N, int sh_degree, int M, int H, int W, int64_t R_cap, const float *means3D,

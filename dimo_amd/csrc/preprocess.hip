@@ -117,7 +117,7 @@ __device__ __forceinline__ void preprocess_fwd_body(
     const float *__restrict__ Vg, const float *__restrict__ Pg, const float *__restrict__ camg, float tanfovx,
     float tanfovy, int32_t *__restrict__ radii, Splat *__restrict__ splat, uint16_t *__restrict__ rect,
     uint32_t *__restrict__ tiles_touched, uint8_t *__restrict__ flags, uint32_t *__restrict__ block_sums) {
-  __shared__ uint32_t wave_sums[PRE_BLOCK / 64];
+  __shared__ uint32_t wave_sums[PRE_BLOCK / 64], wave_min[PRE_BLOCK / 64], wave_max[PRE_BLOCK / 64];
   const int i = blockIdx.x * PRE_BLOCK + threadIdx.x;
   // camera: uniform loads (scalar cache)
   float V[16], P[16], cam[3];
@@ -125,7 +125,7 @@ __device__ __forceinline__ void preprocess_fwd_body(
   for (int k = 0; k < 16; ++k) V[k] = Vg[k], P[k] = Pg[k];
   cam[0] = camg[0], cam[1] = camg[1], cam[2] = camg[2];
 
-  uint32_t my_tiles = 0;
+  uint32_t my_tiles = 0, my_key = 0xffffffffu;  // (key = depth bits of a Gaussian that touches a tile)
   if (i < N) {
     const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
     const float fx = (float)W / (2.0f * tanfovx), fy = (float)H / (2.0f * tanfovy);
@@ -206,6 +206,7 @@ __device__ __forceinline__ void preprocess_fwd_body(
           }
           my_radius = rr;
           my_tiles = (uint32_t)cnt;
+          my_key = __float_as_uint(pv[2]);
           out.x = pix_x, out.y = pix_y, out.A = cA, out.B = cB, out.C = cC, out.opacity = opacities[i];
           out.r = rgb[0], out.g = rgb[1], out.b = rgb[2], out.depth = pv[2];
           out.nx = nv[0], out.ny = nv[1], out.nz = nv[2];
@@ -228,8 +229,21 @@ __device__ __forceinline__ void preprocess_fwd_body(
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
   if ((threadIdx.x & 63) == 0) wave_sums[threadIdx.x >> 6] = v;
+  // ... and the block's range of depth-sort keys (the depth bits of the Gaussians that touch a tile): the sort cuts
+  // [min, max] into buckets (binning.hip)
+  uint32_t kmn = my_key, kmx = my_key == 0xffffffffu ? 0u : my_key;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    kmn = min(kmn, (uint32_t)__shfl_down((int)kmn, o, 64));
+    kmx = max(kmx, (uint32_t)__shfl_down((int)kmx, o, 64));
+  }
+  if ((threadIdx.x & 63) == 0) wave_min[threadIdx.x >> 6] = kmn, wave_max[threadIdx.x >> 6] = kmx;
   __syncthreads();
-  if (threadIdx.x == 0) block_sums[blockIdx.x] = wave_sums[0] + wave_sums[1] + wave_sums[2] + wave_sums[3];
+  if (threadIdx.x == 0) {
+    block_sums[blockIdx.x] = wave_sums[0] + wave_sums[1] + wave_sums[2] + wave_sums[3];
+    block_sums[(gridDim.x + 1) + blockIdx.x] = min(min(wave_min[0], wave_min[1]), min(wave_min[2], wave_min[3]));
+    block_sums[2 * (gridDim.x + 1) + blockIdx.x] = max(max(wave_max[0], wave_max[1]), max(wave_max[2], wave_max[3]));
+  }
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -616,7 +630,8 @@ extern "C" int dimo_raster_preprocess_forward(int N, int sh_degree, int M, int H
                        at<uint32_t>(geom, L.block_sums));
   }
   ScopedTimer *scan_tm = new ScopedTimer(T_SCAN, stream);
-  int rc = scan_block_sums(nb, N, at<uint32_t>(geom, L.block_sums), at<uint32_t>(geom, L.total), stream);
+  int rc = scan_block_sums(nb, N, at<uint32_t>(geom, L.block_sums), at<uint32_t>(geom, L.total), at<uint32_t>(geom, L.bk),
+                           stream);
   if (rc) return rc;
   rc = write_offsets(N, geom, stream);
   delete scan_tm;

@@ -165,6 +165,34 @@ def test_long_tile_lists_with_depth_ties(N):
     assert (o["ranges"][:, 1] - o["ranges"][:, 0]).max() >= 0.9 * N
 
 
+@pytest.mark.parametrize("case", ["one_depth_1500", "one_depth_5000", "slab_and_outliers", "two_depths"])
+def test_depth_sort_bucket_paths(case):
+    """The depth sort cuts [min, max] of the depth bits into 4096 buckets and ranks each on its own (binning.hip):
+    a wave per bucket up to 256 entries, a workgroup in LDS up to 2048, a single-workgroup radix sort above.  Scenes
+    that drive the large-bucket paths -- thousands of Gaussians at ONE depth (order = index), a thin slab next to far
+    outliers, two depths only -- must give the oracle's keys and order bit for bit."""
+    cam = camera_np(0.0, W=96, H=64)
+    if case.startswith("one_depth"):
+        N = int(case.split("_")[-1])
+        sc = random_scene(N, seed=N, scale=0.02)
+        sc["means3D"][:] = sc["means3D"][0]          # one position: one depth, one bucket of N entries
+    elif case == "slab_and_outliers":
+        N = 7000
+        sc = random_scene(N, seed=5, scale=0.02)
+        view = np.asarray(cam["view"], np.float64)   # row-vector convention: p_view = [p 1] @ view
+        axis = view[:3, 2] / np.linalg.norm(view[:3, 2])
+        p = sc["means3D"].astype(np.float64)
+        p -= np.outer(p @ axis, axis) * (1.0 - 1e-5)  # squeeze the cloud to a slab 1e-5 of its depth extent
+        sc["means3D"][:] = p.astype(np.float32)
+        sc["means3D"][:6] += (np.arange(6)[:, None] * 0.6 - 1.5) * axis.astype(np.float32)  # far outliers set the range
+    else:
+        N = 6000
+        sc = random_scene(N, seed=9, scale=0.02)
+        sc["means3D"][: N // 2] = sc["means3D"][0]
+        sc["means3D"][N // 2:] = sc["means3D"][N // 2]
+    _check_forward(sc, cam, (0.2, 0.2, 0.2), 0)
+
+
 def _rel_l1(a, b):
     return np.abs(a - b).sum() / (np.abs(b).sum() + 1e-12)
 
