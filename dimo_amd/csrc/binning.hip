@@ -1,8 +1,8 @@
 // Tile binning: produces, per tile, the list of Gaussians that touch it in (depth, id) order -- bit for bit the
 // arrays a stable radix sort of the (tile | fp32 depth bits) keys of all (Gaussian, tile) instances yields (the
 // published rasterizer's cub::DeviceRadixSort) -- without ever sorting the instances:
-//   1. the N Gaussians of the frame are sorted by their 32 depth bits (stable LSD radix, 4 passes over N keys;
-//      culled Gaussians carry the key 0xffffffff and no tiles);
+//   1. the Gaussians of the frame that touch a tile are sorted by (their 32 depth bits, index): coarse bins over the
+//      key range, each sorted in LDS by one workgroup (see "depth sort" below);
 //   2. ORDERED FILTERS cut that list first into per-supertile lists, then every supertile list into the lists of
 //      its tiles (count pass, scan, fill pass per level: see "placement" below).  A filter keeps the input order,
 //      so every tile list comes out in (depth, id) order, and all writes are long contiguous runs.
