@@ -477,13 +477,19 @@ __device__ __forceinline__ void level1_body(int N_all, const uint32_t *__restric
 // (a local sum first, then the exclusive values in place: four quarters and 16 loads in flight per thread instead
 // of one 391-step dependent walk, which was 70 us of pure latency), then the list starts (aligned to SEG) and the
 // window -> supertile table
-constexpr int L1_PARTS = 4;
+constexpr int L1_PARTS = 4;  // (the workgroup has L1_PARTS * MAX_SUPER = 1024 threads)
 __device__ __forceinline__ void level1_scan_body(int nseg, int NS, uint32_t *__restrict__ cnt1,
                                                  uint32_t *__restrict__ meta, size_t max_windows) {
-  __shared__ uint32_t s_part[L1_PARTS][MAX_SUPER];
+  __shared__ uint32_t s_part[16][MAX_SUPER];
   __shared__ uint32_t s_scan[MAX_SUPER];
-  const int sidx = threadIdx.x & (MAX_SUPER - 1), part = threadIdx.x / MAX_SUPER;
-  const int per = (nseg + L1_PARTS - 1) / L1_PARTS;
+  // columns = the supertiles rounded up to a power of two (>= 64), the 1024 threads split every column's segments
+  // into 1024 / columns parts: 16 parts at 512^2 (64 supertiles) -- four parts over 256 columns walked 98 segments
+  // each, in seven dependent rounds of loads, twice
+  int lg = 6;
+  while ((1 << lg) < NS) ++lg;
+  const int C = 1 << lg, parts = (L1_PARTS * MAX_SUPER) >> lg;
+  const int sidx = threadIdx.x & (C - 1), part = threadIdx.x >> lg;
+  const int per = (nseg + parts - 1) / parts;
   const int b_lo = min(nseg, part * per), b_hi = min(nseg, b_lo + per);
   uint32_t *p = cnt1 + sidx;
   uint32_t sum = 0;
@@ -497,8 +503,7 @@ __device__ __forceinline__ void level1_scan_body(int nseg, int NS, uint32_t *__r
   s_part[part][sidx] = sum;
   __syncthreads();
   uint32_t run = 0, len = 0;
-#pragma unroll
-  for (int q = 0; q < L1_PARTS; ++q) {
+  for (int q = 0; q < parts; ++q) {
     run += q < part ? s_part[q][sidx] : 0u;
     len += s_part[q][sidx];
   }
@@ -516,7 +521,7 @@ __device__ __forceinline__ void level1_scan_body(int nseg, int NS, uint32_t *__r
   const uint32_t padded = (len + SEG - 1) / SEG * SEG;
   if (part == 0) s_scan[sidx] = padded;
   __syncthreads();
-  for (int o = 1; o < MAX_SUPER; o <<= 1) {  // Hillis-Steele inclusive scan of the padded lengths
+  for (int o = 1; o < C; o <<= 1) {  // Hillis-Steele inclusive scan of the padded lengths
     const uint32_t add = (part == 0 && sidx >= o) ? s_scan[sidx - o] : 0u;
     __syncthreads();
     if (part == 0) s_scan[sidx] += add;
@@ -526,7 +531,7 @@ __device__ __forceinline__ void level1_scan_body(int nseg, int NS, uint32_t *__r
   const uint32_t start = s_scan[sidx] - padded;
   meta[META_LEN + sidx] = len;
   meta[META_START + sidx] = start;
-  if (sidx == MAX_SUPER - 1) meta[META_NWIN] = (uint32_t)min((size_t)(s_scan[sidx] / SEG), max_windows);
+  if (sidx == C - 1) meta[META_NWIN] = (uint32_t)min((size_t)(s_scan[sidx] / SEG), max_windows);
   for (uint32_t w = start / SEG; w < (start + padded) / SEG; ++w)
     if (w < max_windows) meta[META_WIN + w] = (uint32_t)sidx;
 }
@@ -609,10 +614,15 @@ __device__ __forceinline__ void level2_scan_body(BinGrid gi, const uint32_t *__r
   const uint32_t w0 = meta[META_START + sidx] / SEG;
   const uint32_t w1 = min(w0 + (meta[META_LEN + sidx] + SEG - 1) / SEG, n_win);
   uint32_t run = 0;
-  for (uint32_t w = w0; w < w1; ++w) {
-    const uint32_t v = cnt2[(size_t)w * 64 + lane];
-    cnt2[(size_t)w * 64 + lane] = run;
-    run += v;
+  for (uint32_t w = w0; w < w1; w += 16) {  // sixteen windows' counts in flight (one at a time: 13 us of latency)
+    uint32_t v[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = w + j < w1 ? cnt2[(size_t)(w + j) * 64 + lane] : 0u;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      if (w + j < w1) cnt2[(size_t)(w + j) * 64 + lane] = run;
+      run += v[j];
+    }
   }
   if (lane < ss * ss && tx < gi.tiles_x && ty < gi.tiles_y) totals[ty * gi.tiles_x + tx] = run;
 }
