@@ -153,6 +153,11 @@ class StepExecutor:
                                                                  C.addressof(self.descs)),
                    "dimo_executor_backward_launch_in_order")
 
+    def backward_launch_joint(self, first, count):
+        _lib.check(self.L.dimo_executor_backward_launch_joint(self.handle, C.addressof(self.common), first, count,
+                                                              C.addressof(self.descs), _lib.current_stream()),
+                   "dimo_executor_backward_launch_joint")
+
     def backward_accumulate(self, first, count):
         _lib.check(self.L.dimo_executor_backward_accumulate(self.handle, C.addressof(self.common), first, count,
                                                             C.addressof(self.descs), _lib.current_stream()),

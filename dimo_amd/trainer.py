@@ -191,6 +191,7 @@ class Trainer:
         self.allreduce_events = []
         self._flat_adam = type(self.optimizer).__name__ == "FlatAdam"
         self._inorder_losses = os.environ.get("DIMO_INORDER_LOSSES", "1") == "1"
+        self._joint_bwd = os.environ.get("DIMO_JOINT_BWD", "1") == "1"
         # direct HIP pipeline: GPU, degree-0 colour (DIMO's configuration), product rasterizer; stage s2 (skinning by
         # <= 1800 control points, `_r` retired) or stage s1 (the TimeNet moves the Gaussians, shared (1, 1) radius `_r`)
         g0 = renderer.gaussians
@@ -667,7 +668,9 @@ class Trainer:
                 d.g_depth = (gd.data_ptr() + b * HW4) if gd is not None else None
                 d.g_normal = (gn.data_ptr() + b * 3 * HW4) if gn is not None else None
                 d.g_dot = (g_dot.data_ptr() + b * HW4) if g_dot is not None else None
-            if own is not None:
+            if own is not None and self._joint_bwd:
+                pass  # one launch chain over all the step's renders, below
+            elif own is not None:
                 ex.backward_launch_in_order(first[m], B)
             elif ex.ranged or not ex.batched:
                 ex.backward_launch(first[m], B)  # overlaps with the next motion's losses on this stream
@@ -682,7 +685,10 @@ class Trainer:
                 reg.backward()
                 extra = extra + reg.detach()
         self._mark("losses+launch")
-        if ex.batched and not ex.ranged:
+        if ex.ranged and self._joint_bwd and self._inorder_losses and not c.use_lpips:
+            ex.backward_launch_joint(0, n)
+            ex.backward_accumulate(0, n)
+        elif ex.batched and not ex.ranged:
             ex.backward_launch(0, n)
             ex.backward_accumulate(0, n)
         else:

@@ -351,6 +351,10 @@ int dimo_executor_backward_launch(void *executor, const dimo_step_common *common
  * that the caller can enqueue the range's loss kernels behind its forward without a cross-stream join, and the
  * rasterizer backward continuing on that stream (no fork from a caller stream) */
 void *dimo_executor_range_stream(void *executor, int first);
+/* Batched ranges only: the rasterizer backward of every range inside [first, first + count) in launches of up to 8
+ * renders on the CALLER's stream, ordered behind what the ranges' private streams hold at the time of the call. */
+int dimo_executor_backward_launch_joint(void *executor, const dimo_step_common *common, int first, int count,
+                                        const dimo_render_desc *descs, void *main_stream);
 int dimo_executor_backward_launch_in_order(void *executor, const dimo_step_common *common, int first, int count,
                                            const dimo_render_desc *renders);
 /* ... and, on main_stream, per render: wait for it, g_f_dc += g_shs, skinning backward (accumulate) */
