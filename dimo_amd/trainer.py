@@ -192,6 +192,7 @@ class Trainer:
         self._flat_adam = type(self.optimizer).__name__ == "FlatAdam"
         self._inorder_losses = os.environ.get("DIMO_INORDER_LOSSES", "1") == "1"
         self._joint_bwd = os.environ.get("DIMO_JOINT_BWD", "1") == "1"
+        self._joint_losses = os.environ.get("DIMO_JOINT_LOSSES", "0") == "1"
         # direct HIP pipeline: GPU, degree-0 colour (DIMO's configuration), product rasterizer; stage s2 (skinning by
         # <= 1800 control points, `_r` retired) or stage s1 (the TimeNet moves the Gaussians, shared (1, 1) radius `_r`)
         g0 = renderer.gaussians
@@ -570,11 +571,16 @@ class Trainer:
         HW4 = H * W * 4
         bufs, first = {}, {}
         i = 0
+        # one allocation per output for ALL renders of the step (a motion's batch is a slice): the joint loss launches
+        # below take the step's images as one tensor
+        img_all, depth_all = torch.empty(n, 3, H, W, **f32), torch.empty(n, 1, H, W, **f32)
+        normal_all = torch.empty(n, 3, H, W, **f32) if self.renderer.add_normal else None
+        alpha_all = torch.empty(n, 1, H, W, **f32)
         for m, trs in by_motion.items():
             B = len(trs)
-            img, depth = torch.empty(B, 3, H, W, **f32), torch.empty(B, 1, H, W, **f32)
-            normal = torch.empty(B, 3, H, W, **f32) if self.renderer.add_normal else None
-            alpha = torch.empty(B, 1, H, W, **f32)
+            img, depth = img_all[i:i + B], depth_all[i:i + B]
+            normal = normal_all[i:i + B] if normal_all is not None else None
+            alpha = alpha_all[i:i + B]
             bufs[m], first[m] = (img, depth, normal, alpha), i
             for b, (_m, v, f) in enumerate(trs):
                 d = ex.descs[i]
@@ -601,13 +607,20 @@ class Trainer:
         # ... and every buffer the loss kernels write is allocated here, BEFORE the forks: memory handed out later could
         # be a block whose last use is a kernel still pending on this stream, which a private stream would not wait for
         depth_on, normal_on = self._reg_on()
-        loss_bufs = {}
-        for m, trs in by_motion.items():
-            img, depth, normal, alpha = bufs[m]
-            loss_bufs[m] = (torch.empty_like(img), torch.empty_like(img),
-                            torch.empty_like(depth) if depth_on else None,
-                            torch.empty_like(normal) if (normal_on and normal is not None) else None,
-                            torch.empty_like(alpha), torch.empty_like(alpha))  # (last: the backward's per-pixel S)
+        loss_all = (torch.empty_like(img_all), torch.empty_like(img_all),
+                    torch.empty_like(depth_all) if depth_on else None,
+                    torch.empty_like(normal_all) if (normal_on and normal_all is not None) else None,
+                    torch.empty_like(alpha_all), torch.empty_like(alpha_all))  # (last: the backward's per-pixel S)
+        loss_bufs = {m: tuple(None if t is None else t[first[m]:first[m] + len(trs)] for t in loss_all)
+                     for m, trs in by_motion.items()}
+        # Joint backward (default): every motion's forward chain and losses run in order on its own stream; THIS stream
+        # then waits for all of them and runs the rasterizer backward as launches over up to 8 of the step's renders
+        # (38 us per render in an 8-render launch against 45-57 in two overlapping launches of four, and the kernel
+        # the roofline is quoted on runs alone).  Joint LOSSES (opt-in, DIMO_JOINT_LOSSES=1: one SSIM and one loss
+        # launch over all images after all forwards) measured slower, 5860 against 6000 frames/s: a motion's losses
+        # overlap the other motion's blend forward in the default.
+        joint_bwd = bool(ex.ranged and self._joint_bwd and self._inorder_losses and not c.use_lpips and n > 0)
+        joint = joint_bwd and self._joint_losses and n <= 32
         if ex.ranged:  # one batch per motion, on alternating private streams
             for m, trs in by_motion.items():
                 ex.forward_range(first[m], len(trs))
@@ -624,8 +637,47 @@ class Trainer:
             extra = extra + self._ga_direct(mine, pair_of, dxyz_c, g_dxyz)
         ssums = zeroed[o_q + dquat_c.numel() + _LOSS_WORDS:]
         ssim_terms, keep = [], []
+        if joint:
+            for m, trs in by_motion.items():
+                ex.join(first[m], len(trs))
+            order = [t for trs in by_motion.values() for t in trs]  # = render index order
+            gt_all = [x for m in by_motion for x in gathered[m][0]]
+            mask_all = [x for m in by_motion for x in gathered[m][1]]
+            share_all = n / n_img
+            ssum = ssums[0:1]
+            ssim_grad, *grad_out, g_dot = loss_all
+            _lib.check(L.dimo_ssim_forward_backward_images(n, 3, H, W, 1 | 2, _lib.ptr(img_all), _lib.ptr_array(gt_all),
+                                                           _lib.ptr(self._const(-c.lambda_ssim * share_all)),
+                                                           _lib.ptr(ssum), _lib.ptr(ssim_grad), stream),
+                       "dimo_ssim_forward_backward_images")
+            ssim_terms.append((ssum, c.lambda_ssim * share_all, float(n * 3 * H * W)))
+            w_mse = [c.lambda_mse * (1.0 if (v == 0 or f == 0) else 0.5) / (3 * H * W) for (_m, v, f) in order]
+            gi, gd, gn, ga = fused_image_loss(img_all, depth_all if depth_on else None,
+                                              normal_all if normal_on else None, alpha_all, gt_all, mask_all, w_mse,
+                                              loss_weights(c, n, n_img, H, W, depth_on, normal_on), ssim_grad,
+                                              loss_accum, out=tuple(grad_out), stream=stream, g_dot=g_dot)
+            keep.append((gi, gd, gn, ga, ssim_grad, g_dot, gt_all, mask_all))
+            for b in range(n):
+                d = ex.descs[b]
+                d.g_color, d.g_alpha = gi.data_ptr() + b * 3 * HW4, ga.data_ptr() + b * HW4
+                d.g_depth = (gd.data_ptr() + b * HW4) if gd is not None else None
+                d.g_normal = (gn.data_ptr() + b * 3 * HW4) if gn is not None else None
+                d.g_dot = (g_dot.data_ptr() + b * HW4) if g_dot is not None else None
         for m, trs in by_motion.items():
             B = len(trs)
+            share = B / n_img
+            if joint:  # only the motion's scalar terms are left (KL, ARAP)
+                if g.vae_latent:
+                    mu, lv = g._mu[m], g._log_var[m]
+                    kl = share * c.lambda_kl * (-0.5 * torch.sum(1 + lv - mu.pow(2) - lv.exp()))
+                    kl.backward()
+                    extra = extra + kl.detach()
+                reg = self.regularizer_loss(m)
+                if reg is not None:
+                    reg = share * reg
+                    reg.backward()
+                    extra = extra + reg.detach()
+                continue
             img, depth, normal, alpha = bufs[m]
             # batched ranges: this motion's losses and rasterizer backward continue ON ITS OWN STREAM, in order behind
             # its renders (no cross-stream event until the skinning backward); otherwise join this stream
@@ -668,7 +720,7 @@ class Trainer:
                 d.g_depth = (gd.data_ptr() + b * HW4) if gd is not None else None
                 d.g_normal = (gn.data_ptr() + b * 3 * HW4) if gn is not None else None
                 d.g_dot = (g_dot.data_ptr() + b * HW4) if g_dot is not None else None
-            if own is not None and self._joint_bwd:
+            if own is not None and joint_bwd:
                 pass  # one launch chain over all the step's renders, below
             elif own is not None:
                 ex.backward_launch_in_order(first[m], B)
@@ -685,7 +737,7 @@ class Trainer:
                 reg.backward()
                 extra = extra + reg.detach()
         self._mark("losses+launch")
-        if ex.ranged and self._joint_bwd and self._inorder_losses and not c.use_lpips:
+        if joint_bwd:
             ex.backward_launch_joint(0, n)
             ex.backward_accumulate(0, n)
         elif ex.batched and not ex.ranged:
