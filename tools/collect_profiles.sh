@@ -17,6 +17,6 @@ for r in rows[:40]:
 PY
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/p2 -o f -- python $GRAFT_REPO_ROOT/tools/pmc_probe.py > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/p3 -o w -- python $GRAFT_REPO_ROOT/tools/pmc_probe.py > /dev/null 2>&1
-python $GRAFT_REPO_ROOT/tools/pmc_summarise.py $(find /tmp/p2 -name "*counter_collection.csv" | head -1) $(find /tmp/p3 -name "*counter_collection.csv" | head -1) $out/${tag}_pmc_fetch_write.json 4
+python $GRAFT_REPO_ROOT/tools/pmc_summarise.py $(find /tmp/p2 -name "*counter_collection.csv" | head -1) $(find /tmp/p3 -name "*counter_collection.csv" | head -1) $out/${tag}_pmc_fetch_write.json 8
 bash $GRAFT_REPO_ROOT/tools/pmc_sq.sh $tag blend_bwd_batched blend_fwd_batched ssim_fused lbs_bwd_batched preprocess_bwd image_loss > $out/${tag}_sq.log 2>&1
 python $GRAFT_REPO_ROOT/bench.py > $out/${tag}_bench_plain.json 2>/dev/null
