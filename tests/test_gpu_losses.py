@@ -435,3 +435,36 @@ def test_direct_pipeline_follows_the_progressive_resolution():
         (_, la, ga), (_, lb, gb) = res[i], res[2 + i]
         assert abs(la - lb) <= 1e-5 * abs(la), (i, la, lb)
         assert (ga - gb).abs().sum() / ga.abs().sum() < 1e-4, i
+
+
+def test_spatial_sort_is_a_relabelling_of_the_same_training():
+    """TrainConfig.spatial_sort only permutes the rows of the canonical Gaussians (densify.py: sort_spatially): the
+    same triples give the same loss and, row for row through the permutation, the same gradients (up to the order of
+    floating-point sums in the tile lists: equal depths are ordered by row index)."""
+    from dimo_amd.densify import morton_order
+    from dimo_amd.rasterizer import CapacityPolicy
+    from dimo_amd.renderer import Renderer
+    from dimo_amd.synth import init_synthetic_model
+    from dimo_amd.trainer import TrainConfig, Trainer
+    out = []
+    for sort in (False, True):
+        cfg = TrainConfig(num_pts=6000, num_cpts=64, num_motions=3, num_frames=5, num_views=4, motions_per_step=2,
+                          views_per_step=2, frames_per_step=2, resolution=96, spatial_sort=sort,
+                          progressive_resolution=False)
+        rd = Renderer(sh_degree=0, num_latent_code=cfg.num_motions, add_normal=True, device="cuda",
+                      capacity=CapacityPolicy(initial=1 << 18))
+        init_synthetic_model(rd, cfg.num_pts, cfg.num_cpts, seed=11, num_latent=cfg.num_motions)
+        xyz0 = rd.gaussians._xyz.detach().clone()
+        tr = Trainer(cfg, rd)
+        tr.step = 300
+        tr.optimizer.step = lambda *a, **k: None
+        rd.gaussians.zero_grad = lambda: None
+        assert tr.train_step(tr.sample()) == 8
+        out.append((tr.last_loss.item(), rd.gaussians._xyz.detach().clone(), rd.gaussians._xyz.grad.clone(),
+                    rd.gaussians._c_xyz.grad.clone(), xyz0))
+    (l0, x0, g0, c0, raw), (l1, x1, g1, c1, _) = out
+    perm = morton_order(raw)
+    assert torch.equal(x1, x0[perm]) and not torch.equal(perm, torch.arange(len(perm), device=perm.device))
+    assert abs(l0 - l1) <= 1e-5 * abs(l0), (l0, l1)
+    assert (g1 - g0[perm]).abs().sum() / g0.abs().sum() < 1e-4
+    assert (c1 - c0).abs().sum() / c0.abs().sum() < 1e-4
