@@ -48,9 +48,7 @@ __host__ __device__ inline size_t align_up(size_t x, size_t a = ALIGN) { return 
 
 constexpr int PRE_BLOCK = 256;  // Gaussians per preprocess block (also the scan granule)
 
-constexpr int SORT_BLOCK = 256;
-constexpr int SORT_ITEMS = 4;   // 1024 keys per block of the bucket scatter
-constexpr int SORT_TILE = SORT_BLOCK * SORT_ITEMS;
+constexpr int SORT_BLOCK = 256;  // threads of a depth-sort workgroup
 // Depth sort of a frame's Gaussians (binning.hip): coarse bins over [min, max] of the depth bits, every bin sorted in
 // LDS by one workgroup.  Word offsets inside the `bk` area of the geometry workspace:
 constexpr int NC_MAX = 256;                                          // coarse bins (128 up to 400 k Gaussians, else 256)
@@ -63,7 +61,7 @@ struct GeomLayout {
   size_t splat, rect, tiles, offsets, flags, total, block_sums;
   size_t nkeys_a, nvals_a, nkeys_b, nvals_b, bk;  // depth sort of the Gaussians (binning.hip)
   size_t cnt1;                                       // level-1 filter counters [segments of 256][256 supertiles]
-  size_t bytes, sort_blocks, nseg1;
+  size_t bytes, nseg1;
   __host__ explicit GeomLayout(int N) {
     size_t n = (size_t)(N > 0 ? N : 1);
     size_t o = 0;
@@ -76,7 +74,6 @@ struct GeomLayout {
     size_t nb = (n + PRE_BLOCK - 1) / PRE_BLOCK;
     // per preprocess block: tiles touched [nb + 1], then min / max of the depth bits of its visible Gaussians
     block_sums = o, o = align_up(o + 3 * (nb + 1) * sizeof(uint32_t));
-    sort_blocks = (n + SORT_TILE - 1) / SORT_TILE;
     nkeys_a = o, o = align_up(o + n * sizeof(uint64_t));
     nvals_a = o, o = align_up(o + n * sizeof(uint32_t));
     nkeys_b = o, o = align_up(o + n * sizeof(uint64_t));

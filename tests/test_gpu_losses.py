@@ -304,8 +304,10 @@ def test_direct_pipeline_data_parallel_two_ranks_on_one_device(tmp_path):
 
 
 def test_executor_modes_agree(monkeypatch):
-    """Per-render stream chains (3), fully batched (0) and batched ranges on private streams (-2, the default) are
-    three schedules of the same kernels: one step from the same state must give the same loss and gradients."""
+    """Per-render stream chains (3), fully batched (0) and batched ranges on private streams (-2, the default: joint
+    rasterizer backward over all renders; "-2/per-motion": each motion's backward in order on its own stream;
+    "-2/joint-losses": SSIM and image losses as single launches too) are schedules of the same kernels: one step from
+    the same state must give the same loss and gradients."""
     from dimo_amd.rasterizer import CapacityPolicy
     from dimo_amd.renderer import Renderer
     from dimo_amd.synth import init_synthetic_model
@@ -313,8 +315,10 @@ def test_executor_modes_agree(monkeypatch):
     cfg = TrainConfig(num_pts=5000, num_cpts=64, num_motions=4, num_frames=6, num_views=4, motions_per_step=2,
                       views_per_step=2, frames_per_step=2, resolution=128)
     res = {}
-    for mode in ("3", "0", "-2"):
-        monkeypatch.setenv("DIMO_EXEC_STREAMS", mode)
+    for mode in ("3", "0", "-2", "-2/per-motion", "-2/joint-losses"):
+        monkeypatch.setenv("DIMO_EXEC_STREAMS", mode.split("/")[0])
+        monkeypatch.setenv("DIMO_JOINT_BWD", "0" if mode.endswith("per-motion") else "1")
+        monkeypatch.setenv("DIMO_JOINT_LOSSES", "1" if mode.endswith("joint-losses") else "0")
         rd = Renderer(sh_degree=0, num_latent_code=cfg.num_motions, add_normal=True, device="cuda",
                       capacity=CapacityPolicy(initial=1 << 19))
         init_synthetic_model(rd, cfg.num_pts, cfg.num_cpts, seed=0, num_latent=cfg.num_motions)
@@ -326,7 +330,7 @@ def test_executor_modes_agree(monkeypatch):
         g = rd.gaussians
         # the TimeNet weight gradients are summed with hardware atomics (order not fixed): compare those loosely
         res[mode] = (tr.last_loss.item(), g.flat_grads.clone(), g._xyz.grad.clone(), g._c_xyz.grad.clone())
-    for mode in ("0", "-2"):
+    for mode in ("0", "-2", "-2/per-motion", "-2/joint-losses"):
         assert abs(res[mode][0] - res["3"][0]) <= 1e-6 * abs(res["3"][0])
         # per-Gaussian gradients: the batched modes sum the two views of a (motion, frame) pair before the skinning
         # backward and reduce a tile's pixels in one wave instead of two, so only the summation order differs
