@@ -193,6 +193,13 @@ def test_depth_sort_bucket_paths(case):
     _check_forward(sc, cam, (0.2, 0.2, 0.2), 0)
 
 
+def test_depth_sort_with_256_bins_above_400k_gaussians():
+    """Above 400 000 Gaussians the depth sort switches from 128 to 256 coarse bins (binning.hip: depth_bins_log2)."""
+    cam = camera_np(10.0, W=128, H=96)
+    sc = random_scene(420_000, seed=42, scale=0.004, opacity=(0.05, 0.3))
+    _check_forward(sc, cam, (0.1, 0.1, 0.1), 0)
+
+
 def _rel_l1(a, b):
     return np.abs(a - b).sum() / (np.abs(b).sum() + 1e-12)
 
