@@ -129,34 +129,27 @@ __global__ void __launch_bounds__(DEF_BLOCK) lbs_fwd_batched_kernel(int N, int M
 // EXTRA adds the rasterizer gradients of the other renders of a deformation group to the leader's (the backward is
 // linear in them); NoExtra for a single render.
 struct NoExtra {
-  __device__ __forceinline__ void rot(size_t, float4 &) const {}
-  __device__ __forceinline__ void vec3(int, size_t, float &, float &, float &) const {}
-  __device__ __forceinline__ void opac(size_t, float &) const {}
+  __device__ __forceinline__ void add_all(size_t, float4 &, float (&)[3], float (&)[3], float &) const {}
 };
 struct GroupExtra {
   const RenderBatch &b;
   unsigned others;  // bitmask of the group's renders without the leader
-  __device__ __forceinline__ void rot(size_t i, float4 &v) const {
+  // the four gradient arrays of one other render are requested together, before the first add (one memory round trip
+  // per member instead of four spread over the body)
+  __device__ __forceinline__ void add_all(size_t i, float4 &rot, float (&xyz)[3], float (&sc)[3], float &op) const {
 #pragma unroll
     for (int j = 1; j < MAX_BATCH; ++j)
       if ((others >> j) & 1u) {
-        const float4 t = *reinterpret_cast<const float4 *>(b.r[j].g_rot + 4 * i);
-        v.x += t.x, v.y += t.y, v.z += t.z, v.w += t.w;
+        const dimo_render_desc &r = b.r[j];
+        const float4 t = *reinterpret_cast<const float4 *>(r.g_rot + 4 * i);
+        const float p0 = r.g_means3D[3 * i], p1 = r.g_means3D[3 * i + 1], p2 = r.g_means3D[3 * i + 2];
+        const float s0 = r.g_scales[3 * i], s1 = r.g_scales[3 * i + 1], s2 = r.g_scales[3 * i + 2];
+        const float o = r.g_opac[i];
+        rot.x += t.x, rot.y += t.y, rot.z += t.z, rot.w += t.w;
+        xyz[0] += p0, xyz[1] += p1, xyz[2] += p2;
+        sc[0] += s0, sc[1] += s1, sc[2] += s2;
+        op += o;
       }
-  }
-  // which = 0: g_means3D, 1: g_scales
-  __device__ __forceinline__ void vec3(int which, size_t i, float &a, float &c, float &d) const {
-#pragma unroll
-    for (int j = 1; j < MAX_BATCH; ++j)
-      if ((others >> j) & 1u) {
-        const float *p = (which == 0 ? b.r[j].g_means3D : b.r[j].g_scales) + 3 * i;
-        a += p[0], c += p[1], d += p[2];
-      }
-  }
-  __device__ __forceinline__ void opac(size_t i, float &v) const {
-#pragma unroll
-    for (int j = 1; j < MAX_BATCH; ++j)
-      if ((others >> j) & 1u) v += b.r[j].g_opac[i];
   }
 };
 
@@ -182,12 +175,35 @@ __device__ __forceinline__ void lbs_bwd_body(int N, int M, GaussIO g, CtrlTable 
     const float x0 = g.xyz[3 * i], x1 = g.xyz[3 * i + 1], x2 = g.xyz[3 * i + 2];
     const float4 q0 = *reinterpret_cast<const float4 *>(g.rot + 4 * (size_t)i);
     const float4 dd = *reinterpret_cast<const float4 *>(g.nn_dist + 4 * (size_t)i);
-    const float dist[DEF_K] = {dd.x, dd.y, dd.z, dd.w};
+    // every global input of this Gaussian is requested here, before the first use: spread over the body they were five
+    // dependent memory round trips per iteration of a kernel that runs ~3 waves per SIMD
+    float4 go = *reinterpret_cast<const float4 *>(g_rot + 4 * (size_t)i);
+    float gp[3] = {g_xyz[3 * i], g_xyz[3 * i + 1], g_xyz[3 * i + 2]};
+    float gsc[3] = {g_scales[3 * i], g_scales[3 * i + 1], g_scales[3 * i + 2]};
+    float gopac = g_opacity[i];
+    const float op_raw = g.opacity[i];
+    const float sc_raw[3] = {g.scaling[3 * i], g.scaling[3 * i + 1], g.scaling[3 * i + 2]};
+    extra.add_all((size_t)i, go, gp, gsc, gopac);
     float wt[DEF_K], ex[DEF_K], W = 0.f;
     int idx[DEF_K];
+    float dist[DEF_K] = {dd.x, dd.y, dd.z, dd.w};
+#pragma unroll
+    for (int k = 0; k < DEF_K; ++k) idx[k] = (int)g.nn_idx[4 * (size_t)i + k];
+    // The neighbour slots are re-ordered by control-point index (a 5-exchange network on (index, distance)): the sums
+    // over the four neighbours do not care, and Gaussians that are neighbours in memory (Morton order) then hold the
+    // same control point in the same slot, so the run-combining of the LDS atomics below merges far more lanes -- the
+    // kernel is bound by the LDS atomic unit (~4 cycles per active lane).
+#define DIMO_CX(A, B)                                                                 \
+  {                                                                                   \
+    const bool sw = idx[A] > idx[B];                                                  \
+    const int ia = sw ? idx[B] : idx[A], ib = sw ? idx[A] : idx[B];                   \
+    const float da = sw ? dist[B] : dist[A], db = sw ? dist[A] : dist[B];             \
+    idx[A] = ia, idx[B] = ib, dist[A] = da, dist[B] = db;                             \
+  }
+    DIMO_CX(0, 1) DIMO_CX(2, 3) DIMO_CX(0, 2) DIMO_CX(1, 3) DIMO_CX(1, 2)
+#undef DIMO_CX
 #pragma unroll
     for (int k = 0; k < DEF_K; ++k) {
-      idx[k] = (int)g.nn_idx[4 * (size_t)i + k];
       const float r = s_cp[idx[k] * CP_STRIDE + 3];
       ex[k] = __expf(-1.0f * dist[k] * dist[k] / (2.0f * (r * r)));
       wt[k] = ex[k] + LBS_EPS;
@@ -211,8 +227,6 @@ __device__ __forceinline__ void lbs_bwd_body(int N, int M, GaussIO g, CtrlTable 
     const float inv_n = 1.0f / nrm;
     const float uw = ow * inv_n, ux = ox * inv_n, uy = oy * inv_n, uz = oz * inv_n;
     // normalisation backward
-    float4 go = *reinterpret_cast<const float4 *>(g_rot + 4 * (size_t)i);
-    extra.rot((size_t)i, go);
     const float dotg = uw * go.x + ux * go.y + uy * go.z + uz * go.w;
     const float gw = (go.x - uw * dotg) * inv_n, gx = (go.y - ux * dotg) * inv_n;
     const float gy = (go.z - uy * dotg) * inv_n, gz = (go.w - uz * dotg) * inv_n;
@@ -235,8 +249,7 @@ __device__ __forceinline__ void lbs_bwd_body(int N, int M, GaussIO g, CtrlTable 
       *dst = v;
     }
 
-    float gp0 = g_xyz[3 * i], gp1 = g_xyz[3 * i + 1], gp2 = g_xyz[3 * i + 2];
-    extra.vec3(0, (size_t)i, gp0, gp1, gp2);
+    const float gp0 = gp[0], gp1 = gp[1], gp2 = gp[2];
     float dx0 = LOCAL_FRAME ? 0.f : gp0, dx1 = LOCAL_FRAME ? 0.f : gp1, dx2 = LOCAL_FRAME ? 0.f : gp2;
     float gwk[DEF_K], sum_wg = 0.f;
     // this Gaussian's contribution to columns 3..10 of the gradient row of neighbour k (columns 0..2, the gradient
@@ -302,16 +315,12 @@ __device__ __forceinline__ void lbs_bwd_body(int N, int M, GaussIO g, CtrlTable 
     for (int k = 0; k < DEF_K; ++k)
       wave_scatter_add<CP_STRIDE - 3>(s_acc + 3, CP_STRIDE, idx[k], cpg[k], valid, lane);
     if (valid) {
-      const float o = 1.0f / (1.0f + __expf(-g.opacity[i]));
-      float gopac = g_opacity[i];
-      extra.opac((size_t)i, gopac);
+      const float o = 1.0f / (1.0f + __expf(-op_raw));
       const float gop = gopac * o * (1.0f - o);
       const float dxs[3] = {dx0, dx1, dx2};
-      float gsc[3] = {g_scales[3 * i], g_scales[3 * i + 1], g_scales[3 * i + 2]};
-      extra.vec3(1, (size_t)i, gsc[0], gsc[1], gsc[2]);
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        const float gs = gsc[c] * __expf(g.scaling[3 * i + c]);
+        const float gs = gsc[c] * __expf(sc_raw[c]);
         d_xyz_out[3 * i + c] = ACC ? d_xyz_out[3 * i + c] + dxs[c] : dxs[c];
         d_scaling_out[3 * i + c] = ACC ? d_scaling_out[3 * i + c] + gs : gs;
       }
