@@ -254,6 +254,7 @@ __device__ __forceinline__ void lbs_bwd_body(int N, int M, GaussIO g, CtrlTable 
     float gwk[DEF_K], sum_wg = 0.f;
     // this Gaussian's contribution to columns 3..10 of the gradient row of neighbour k (columns 0..2, the gradient
     // of the control point's position, follow from columns 4..6 after the reduction: see the end of the kernel)
+    static_assert(CP_STRIDE - 3 == 8, "wave_scatter_add_match8 takes eight values per neighbour");
     float cpg[DEF_K][CP_STRIDE - 3];
 #pragma unroll
     for (int k = 0; k < DEF_K; ++k) {
@@ -313,7 +314,7 @@ __device__ __forceinline__ void lbs_bwd_body(int N, int M, GaussIO g, CtrlTable 
     }
 #pragma unroll
     for (int k = 0; k < DEF_K; ++k)
-      wave_scatter_add<CP_STRIDE - 3>(s_acc + 3, CP_STRIDE, idx[k], cpg[k], valid, lane);
+      wave_scatter_add_match8(s_acc + 3, CP_STRIDE, idx[k], cpg[k], valid, lane);
     if (valid) {
       const float o = 1.0f / (1.0f + __expf(-op_raw));
       const float gop = gopac * o * (1.0f - o);

@@ -102,4 +102,40 @@ __device__ __forceinline__ void wave_scatter_add(float *table, int stride, int i
   }
 }
 
+// table[idx * stride + c] += sum over the wave's lanes with that idx of v[c], c < 8 -- by MATCHING: the lanes of one
+// index are found with a ballot, two indices' values share one 16-value halving reduction, and eight lanes issue the
+// adds.  For a wave whose lanes hold FEW distinct indices (Morton-ordered Gaussians: 2-4 control points per neighbour
+// slot) this is ~230 VALU cycles per pair of indices, where one LDS float atomic per lane and value costs the CU's single
+// LDS atomic unit ~4 cycles per active lane (the skinning backward was bound by exactly that).
+constexpr int MATCH_ROUNDS = 3;  // pairs of indices matched before the remaining lanes fall back to plain atomics
+__device__ __forceinline__ void wave_scatter_add_match8(float *table, int stride, int idx, const float (&v)[8],
+                                                        bool valid, int lane) {
+  unsigned long long rem = __ballot(valid);
+  for (int round = 0; rem != 0ull; ++round) {
+    if (round == MATCH_ROUNDS) {  // many distinct indices (unordered Gaussians): the rest by run-combined atomics
+      wave_scatter_add<8>(table, stride, idx, v, (rem >> lane) & 1ull, lane);
+      return;
+    }
+    const int A = __builtin_amdgcn_readlane(idx, __ffsll((long long)rem) - 1);
+    const bool inA = valid && idx == A;
+    const unsigned long long mA = __ballot(inA);
+    rem &= ~mA;
+    int B = A;
+    bool inB = false;
+    unsigned long long mB = 0ull;
+    if (rem != 0ull) {  // (wave-uniform)
+      B = __builtin_amdgcn_readlane(idx, __ffsll((long long)rem) - 1);
+      inB = valid && idx == B;
+      mB = __ballot(inB);
+      rem &= ~mB;
+    }
+    float r[16];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) r[c] = inA ? v[c] : 0.0f, r[8 + c] = inB ? v[c] : 0.0f;
+    const float tot = wave_reduce16(r);
+    const int s = reduce16_slot(lane);
+    if ((lane & 3) == 0 && (s < 8 || mB != 0ull)) atomicAdd(table + (s < 8 ? A : B) * stride + (s & 7), tot);
+  }
+}
+
 }  // namespace dimo
