@@ -104,7 +104,8 @@ __device__ __forceinline__ void write_offsets_body(int N, const uint32_t *__rest
     const uint32_t key = __float_as_uint(splat[i].depth);
     nkeys[i] = v ? (uint64_t)key : 0xffffffffull;
     nvals[i] = (uint32_t)i;
-    if (v) atomicAdd(&s_hist[(key - bk[BK_KMIN]) >> bk[BK_SHIFT]], 1u);  // this block's share of its depth bin
+    // this block's share of its depth bin (the clamp is insurance: min / max come from the same keys)
+    if (v) atomicAdd(&s_hist[min((key - bk[BK_KMIN]) >> bk[BK_SHIFT], (uint32_t)nc - 1u)], 1u);
   }
   __syncthreads();
   if ((int)threadIdx.x < nc) bk[BK_HIST + (size_t)blockIdx.x * nc + threadIdx.x] = s_hist[threadIdx.x];
@@ -194,7 +195,7 @@ __device__ __forceinline__ void depth_bin_scatter_body(int N, const uint64_t *__
   if (idx >= N) return;
   const uint64_t k = keys_in[idx];
   if ((uint32_t)k == 0xffffffffu) return;  // touches no tile: not sorted at all
-  const uint32_t pos = atomicAdd(&s_cur[((uint32_t)k - bk[BK_KMIN]) >> bk[BK_SHIFT]], 1u);
+  const uint32_t pos = atomicAdd(&s_cur[min(((uint32_t)k - bk[BK_KMIN]) >> bk[BK_SHIFT], (uint32_t)nc - 1u)], 1u);
   keys_out[pos] = k;
   vals_out[pos] = (uint32_t)idx;
 }
@@ -298,7 +299,7 @@ __device__ __forceinline__ void depth_bin_sort_body(int N, uint64_t *__restrict_
 #pragma unroll
     for (int q = 0; q < PER; ++q)
       if ((uint32_t)q * SORT_BLOCK + threadIdx.x < n)
-        atomicAdd(&s_cur[((uint32_t)(mine[q] >> 32) - klo) >> sub_shift], 1u);
+        atomicAdd(&s_cur[min(((uint32_t)(mine[q] >> 32) - klo) >> sub_shift, (uint32_t)SUB_BINS - 1u)], 1u);
     __syncthreads();
     {  // exclusive scan of the 256 sub-bin sizes (thread f owns sub-bin f)
       const uint32_t cnt = s_cur[threadIdx.x];
@@ -325,11 +326,11 @@ __device__ __forceinline__ void depth_bin_sort_body(int N, uint64_t *__restrict_
 #pragma unroll
     for (int q = 0; q < PER; ++q)
       if ((uint32_t)q * SORT_BLOCK + threadIdx.x < n)
-        s_k[atomicAdd(&s_cur[((uint32_t)(mine[q] >> 32) - klo) >> sub_shift], 1u)] = mine[q];
+        s_k[atomicAdd(&s_cur[min(((uint32_t)(mine[q] >> 32) - klo) >> sub_shift, (uint32_t)SUB_BINS - 1u)], 1u)] = mine[q];
     __syncthreads();
     for (uint32_t e = threadIdx.x; e < n; e += SORT_BLOCK) {
       const unsigned long long c = s_k[e];
-      const uint32_t f = ((uint32_t)(c >> 32) - klo) >> sub_shift;
+      const uint32_t f = min(((uint32_t)(c >> 32) - klo) >> sub_shift, (uint32_t)SUB_BINS - 1u);
       const uint32_t lo = s_start[f], hi = s_start[f + 1];
       uint32_t r = 0;
       for (uint32_t t = lo; t < hi; t += 8) {  // eight LDS reads in flight (clamped, masked)
