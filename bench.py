@@ -111,7 +111,7 @@ def read_timing():
     return out
 
 
-def cpu_baseline(num_pts, resolution, renders=24):
+def cpu_baseline(num_pts, resolution, renders=20):
     """Same train step on the host cores: product host logic + CPU oracle kernels (kind 'port')."""
     from dimo_amd.trainer import TrainConfig
     from tests.cpu_backend import make_cpu_trainer
