@@ -528,13 +528,24 @@ __device__ __forceinline__ void level1_scan_body(int nseg, int NS, uint32_t *__r
     if (part == 0) s_scan[sidx] += add;
     __syncthreads();
   }
-  if (part != 0) return;
-  const uint32_t start = s_scan[sidx] - padded;
-  meta[META_LEN + sidx] = len;
-  meta[META_START + sidx] = start;
-  if (sidx == C - 1) meta[META_NWIN] = (uint32_t)min((size_t)(s_scan[sidx] / SEG), max_windows);
-  for (uint32_t w = start / SEG; w < (start + padded) / SEG; ++w)
-    if (w < max_windows) meta[META_WIN + w] = (uint32_t)sidx;
+  if (part == 0) {
+    const uint32_t start = s_scan[sidx] - padded;
+    meta[META_LEN + sidx] = len;
+    meta[META_START + sidx] = start;
+    if (sidx == C - 1) meta[META_NWIN] = (uint32_t)min((size_t)(s_scan[sidx] / SEG), max_windows);
+  }
+  // window -> supertile table, by ALL threads: window w belongs to the first supertile whose inclusive end (in
+  // windows) lies beyond it -- a binary search over the <= 256 ends in LDS.  (One thread per supertile walking its
+  // own windows was a serial chain of a list's length / 256 stores: 6 us of this kernel at R = 1e6, 35 us at 3e6.)
+  const uint32_t n_win = (uint32_t)min((size_t)(s_scan[C - 1] / SEG), max_windows);
+  for (uint32_t w = threadIdx.x; w < n_win; w += L1_PARTS * MAX_SUPER) {
+    int lo = 0, hi = C - 1;  // smallest s with s_scan[s] / SEG > w
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (s_scan[mid] / SEG > w) hi = mid; else lo = mid + 1;
+    }
+    meta[META_WIN + w] = (uint32_t)lo;
+  }
 }
 
 // A workgroup (4 waves) per 256-entry window, one wave per 64 entries (same reasoning as level 1: few windows per
