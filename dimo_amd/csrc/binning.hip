@@ -16,6 +16,25 @@
 
 namespace dimo {
 
+// Depth-bin map (see "depth sort"): keys at or below `lo` fall into bin 0, keys past the last bin into the last one
+__device__ __forceinline__ uint32_t depth_bin(uint32_t key, uint32_t lo, uint32_t shift, uint32_t nbins) {
+  return key <= lo ? 0u : min((key - lo) >> shift, nbins - 1u);
+}
+
+// Sub-bins of a bin: 256 over its 2^shift keys; bin 0 also holds every key below the binned range, so its sub-bins
+// start at the smallest key and are correspondingly wider.
+__device__ __forceinline__ void sub_bin_map(const uint32_t *bk, uint32_t bin, uint32_t &klo, uint32_t &sub_shift) {
+  const uint32_t shift = bk[BK_SHIFT];
+  klo = bk[BK_KMIN] + (bin << shift);
+  uint32_t width = 1u << shift;
+  if (bin == 0u) {
+    width += klo - bk[BK_KMIN0];
+    klo = bk[BK_KMIN0];
+  }
+  const int nbits = 32 - __clz((int)(width - 1u) | 1);
+  sub_shift = (uint32_t)(nbits > 8 ? nbits - 8 : 0);
+}
+
 // ------------------------------------------------------------------------------------ scan
 // Exclusive scan of the per-block sums (nb <= a few thousand) by one workgroup; writes the
 // grand total R to total[0] and clears the overflow flag total[1].
@@ -23,27 +42,45 @@ __device__ __forceinline__ void scan_block_sums_body(int nb, int N, uint32_t *__
                                                      uint32_t *__restrict__ total, uint32_t *__restrict__ bk) {
   __shared__ uint32_t wave_tot[16];
   __shared__ uint32_t carry_s;
-  __shared__ uint32_t wave_mn[16], wave_mx[16];
+  __shared__ uint32_t wave_mn[16], wave_mx[16], wave_a[16], wave_b[16];
   if (threadIdx.x == 0) carry_s = 0;
-  // the depth sort's bin map (see "depth sort" below): range of the keys over the preprocess blocks, bin width 2^shift
-  // with (max - min) >> shift < number of bins
+  // the depth sort's bin map (see "depth sort" below).  The binned range is NOT [min, max] of the keys: a few floaters
+  // far behind (or in front of) the scene would stretch it until the scene's bulk shares a handful of bins.  A block's
+  // MIN ignores a far outlier inside it and its MAX a near one, so A = the largest block minimum and B = the smallest
+  // block maximum bracket the bulk whatever the order of the Gaussians (Morton order: A ~ far end, B ~ near end;
+  // random order: the other way round); the range is [min(A, B), max(A, B)] widened by a quarter on both sides,
+  // inside [min, max].  Keys outside it fall into the first / last bin (whose sub-bins start at the smallest key).
   {
-    uint32_t mn = 0xffffffffu, mx = 0u;
-    for (int i = threadIdx.x; i < nb; i += 1024) mn = min(mn, sums[(nb + 1) + i]), mx = max(mx, sums[2 * (nb + 1) + i]);
+    uint32_t mn = 0xffffffffu, mx = 0u, a_ = 0u, b_ = 0xffffffffu;
+    for (int i = threadIdx.x; i < nb; i += 1024) {
+      const uint32_t bmin = sums[(nb + 1) + i], bmax = sums[2 * (nb + 1) + i];
+      if (bmin != 0xffffffffu) mn = min(mn, bmin), mx = max(mx, bmax), a_ = max(a_, bmin), b_ = min(b_, bmax);
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
       mn = min(mn, (uint32_t)__shfl_down((int)mn, o, 64));
       mx = max(mx, (uint32_t)__shfl_down((int)mx, o, 64));
+      a_ = max(a_, (uint32_t)__shfl_down((int)a_, o, 64));
+      b_ = min(b_, (uint32_t)__shfl_down((int)b_, o, 64));
     }
-    if ((threadIdx.x & 63) == 0) wave_mn[threadIdx.x >> 6] = mn, wave_mx[threadIdx.x >> 6] = mx;
+    if ((threadIdx.x & 63) == 0)
+      wave_mn[threadIdx.x >> 6] = mn, wave_mx[threadIdx.x >> 6] = mx, wave_a[threadIdx.x >> 6] = a_,
+      wave_b[threadIdx.x >> 6] = b_;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    uint32_t mn = wave_mn[0], mx = wave_mx[0];
-    for (int w = 1; w < 16; ++w) mn = min(mn, wave_mn[w]), mx = max(mx, wave_mx[w]);
-    const uint32_t span = mx >= mn ? mx - mn : 0u;
+    uint32_t mn = wave_mn[0], mx = wave_mx[0], a_ = wave_a[0], b_ = wave_b[0];
+    for (int w = 1; w < 16; ++w)
+      mn = min(mn, wave_mn[w]), mx = max(mx, wave_mx[w]), a_ = max(a_, wave_a[w]), b_ = min(b_, wave_b[w]);
+    uint32_t lo = mn, span = 0u;
+    if (mx >= mn) {  // (some Gaussian touches a tile)
+      const uint32_t rl = min(a_, b_), rh = max(a_, b_), ext = (rh - rl) >> 2;
+      lo = rl - mn > ext ? rl - ext : mn;
+      const uint32_t hi = mx - rh > ext ? rh + ext : mx;
+      span = hi - lo;
+    }
     const int nbits = span ? 32 - __clz((int)span) : 0, lg = depth_bins_log2(N);
-    bk[BK_KMIN] = mn, bk[BK_SHIFT] = (uint32_t)(nbits > lg ? nbits - lg : 0);
+    bk[BK_KMIN] = lo, bk[BK_SHIFT] = (uint32_t)(nbits > lg ? nbits - lg : 0), bk[BK_KMIN0] = min(mn, lo);
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -105,7 +142,7 @@ __device__ __forceinline__ void write_offsets_body(int N, const uint32_t *__rest
     nkeys[i] = v ? (uint64_t)key : 0xffffffffull;
     nvals[i] = (uint32_t)i;
     // this block's share of its depth bin (the clamp is insurance: min / max come from the same keys)
-    if (v) atomicAdd(&s_hist[min((key - bk[BK_KMIN]) >> bk[BK_SHIFT], (uint32_t)nc - 1u)], 1u);
+    if (v) atomicAdd(&s_hist[depth_bin(key, bk[BK_KMIN], bk[BK_SHIFT], (uint32_t)nc)], 1u);
   }
   __syncthreads();
   if ((int)threadIdx.x < nc) bk[BK_HIST + (size_t)blockIdx.x * nc + threadIdx.x] = s_hist[threadIdx.x];
@@ -116,19 +153,26 @@ __device__ __forceinline__ void write_offsets_body(int N, const uint32_t *__rest
 // gives.  A frame has ~1e5 of them: an LSD radix sort was 4 passes x 3 launches of pure launch / ramp latency (99 us
 // per batch of 8 renders), and device-scope atomics (a first bucket sort: 2 per key) are slow on this chip (one
 // counter bump per key cost 27 us per batch).  So, without a single global atomic:
-//   1. preprocess leaves the min / max key per block and scan_block_sums derives the bin map (64 or 256 coarse bins of
-//      width 2^shift over [min, max]: monotone in the key); write_offsets counts each block's keys per bin in LDS;
+//   1. preprocess leaves the min / max key per block and scan_block_sums derives the bin map (128 or 256 coarse bins
+//      of width 2^shift over a range that brackets the BULK of the keys -- not [min, max]: see there --, monotone in
+//      the key); write_offsets counts each block's keys per bin in LDS;
 //   2. depth_bin_scan (one workgroup): column sums over the blocks -> bin bases, every block's first slot per bin;
 //   3. depth_bin_scatter: a block drops its (key, id) pairs into their bins (LDS cursor per bin: unordered inside);
 //   4. depth_bin_sort: ONE WORKGROUP PER BIN (~1 600 entries at 1e5 Gaussians) sorts its bin in LDS: a counting pass
 //      over 256 sub-bins of the bin's key range, then every entry ranks itself inside its sub-bin (a handful of
-//      entries) by the 64-bit word (key << 32 | id) -- all distinct because the ids are.  A bin that does not fit
-//      (thousands of Gaussians at nearly one depth) is sorted by the same workgroup with nine stable byte passes
+//      entries) by the 64-bit word (key << 32 | id) -- all distinct because the ids are.  A bin above 6144 entries is
+//      cut along its sub-bins into slices for extra workgroups of the same launch; only a sub-bin above 2048 entries
+//      (thousands of Gaussians at nearly ONE depth) sends its bin to nine stable byte passes of a single workgroup
 //      through global memory: slow, correct, rare.
 // The result does not depend on the order the LDS atomics resolved in.
 constexpr int BIN_CAP = 6144;      // entries a workgroup sorts in LDS (48 KB)
 constexpr int SUB_BINS = 256;
 constexpr int SUB_MAX = 2048;      // largest sub-bin ranked quadratically
+// A bin above BIN_CAP (a few far outliers stretch [min, max] and the scene's bulk lands in a handful of bins) is cut
+// into SLICES of ~SLICE_TARGET entries along its sub-bins, one extra workgroup each: without them 8 floaters 30 units
+// behind a 1e5-Gaussian scene cost 0.6 ms per render in the single-workgroup fallback.
+constexpr int SLICE_TARGET = BIN_CAP - SUB_MAX;
+constexpr int SLICE_GRID = 64;     // extra workgroups of a launch that work the slice list off
 
 // one workgroup of 1024 threads: thread (part, c) first sums its slice of column c of the [blocks][bins] counts, then
 // (bases known) rewrites the slice as each block's first slot
@@ -165,10 +209,28 @@ __device__ __forceinline__ void depth_bin_scan_body(int N, uint32_t *__restrict_
     __syncthreads();
   }
   const uint32_t base = s_scan[c] - len;
+  __shared__ uint32_t s_nslice;
+  if (threadIdx.x == 0) s_nslice = 0u;
+  __syncthreads();
   if (part == 0) {
     bk[BK_BASE + c] = base;
     if (c == nc - 1) bk[BK_BASE + nc] = s_scan[c], total[3] = s_scan[c];
+    uint32_t J = 0;
+    if (len > (uint32_t)BIN_CAP) {  // an oversized bin: its slices go on the list (if they fit; else J stays 0)
+      const uint32_t want = (len + SLICE_TARGET - 1) / SLICE_TARGET;
+      const uint32_t pos = want <= 255u ? atomicAdd(&s_nslice, want) : (uint32_t)MAX_SLICES;
+      if (pos + want <= (uint32_t)MAX_SLICES) {
+        J = want;
+        for (uint32_t j = 0; j < want; ++j) bk[BK_SLICE + pos + j] = ((uint32_t)c << 16) | (want << 8) | j;
+      } else if (want <= 255u) {
+        // (list full: the entries this bin reserved stay unused; mark them so)
+        for (uint32_t j = pos; j < min(pos + want, (uint32_t)MAX_SLICES); ++j) bk[BK_SLICE + j] = 0xffffffffu;
+      }
+    }
+    bk[BK_BINJ + c] = J;
   }
+  __syncthreads();
+  if (threadIdx.x == 0) bk[BK_NSLICE] = min(s_nslice, (uint32_t)MAX_SLICES);
   uint32_t run = base + before;
   for (int b0 = b_lo; b0 < b_hi; b0 += 16) {
     uint32_t v[16];
@@ -195,7 +257,7 @@ __device__ __forceinline__ void depth_bin_scatter_body(int N, const uint64_t *__
   if (idx >= N) return;
   const uint64_t k = keys_in[idx];
   if ((uint32_t)k == 0xffffffffu) return;  // touches no tile: not sorted at all
-  const uint32_t pos = atomicAdd(&s_cur[min(((uint32_t)k - bk[BK_KMIN]) >> bk[BK_SHIFT], (uint32_t)nc - 1u)], 1u);
+  const uint32_t pos = atomicAdd(&s_cur[depth_bin((uint32_t)k, bk[BK_KMIN], bk[BK_SHIFT], (uint32_t)nc)], 1u);
   keys_out[pos] = k;
   vals_out[pos] = (uint32_t)idx;
 }
@@ -275,13 +337,120 @@ __device__ __forceinline__ void depth_bin_sort_body(int N, uint64_t *__restrict_
   __shared__ uint32_t s_cnt[SORT_BLOCK / 64][256];
   __shared__ uint32_t s_big;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t nc = 1u << depth_bins_log2(N);
+  if (blockIdx.x >= nc) {
+    // ---- slices of oversized bins: every slice counts the bin's sub-bins itself, takes the run of sub-bins whose
+    // first entry falls into its share of the bin, and sorts those (<= SLICE_TARGET + SUB_MAX = BIN_CAP entries)
+    const uint32_t n_slices = bk[BK_NSLICE];
+    for (uint32_t t = blockIdx.x - nc; t < n_slices; t += gridDim.x - nc) {
+      const uint32_t code = bk[BK_SLICE + t];
+      if (code == 0xffffffffu) continue;
+      const uint32_t b = code >> 16, J = (code >> 8) & 255u, j = code & 255u;
+      const uint32_t base = bk[BK_BASE + b], n = bk[BK_BASE + b + 1] - base;
+      uint32_t klo, sub_shift;
+      sub_bin_map(bk, b, klo, sub_shift);
+      __syncthreads();  // (the previous slice's LDS has been consumed)
+      s_cur[threadIdx.x] = 0u;
+      if (threadIdx.x == 0) s_big = 0u;
+      __syncthreads();
+      for (uint32_t e0 = 0; e0 < n; e0 += 8 * SORT_BLOCK) {
+        uint32_t kk[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) kk[u] = (uint32_t)keys_b[base + min(e0 + u * SORT_BLOCK + threadIdx.x, n - 1)];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (e0 + u * SORT_BLOCK + threadIdx.x < n)
+            atomicAdd(&s_cur[depth_bin(kk[u], klo, sub_shift, (uint32_t)SUB_BINS)], 1u);
+      }
+      __syncthreads();
+      {
+        const uint32_t cnt = s_cur[threadIdx.x];
+        if (cnt > (uint32_t)SUB_MAX) s_big = 1u;
+        uint32_t inc = cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const uint32_t tt = __shfl_up(inc, o, 64);
+          if (lane >= o) inc += tt;
+        }
+        if (lane == 63) s_run[wave] = inc;
+        __syncthreads();
+        uint32_t off = 0;
+        for (int w = 0; w < wave; ++w) off += s_run[w];
+        s_start[threadIdx.x] = off + inc - cnt;
+        if (threadIdx.x == SORT_BLOCK - 1) s_start[SUB_BINS] = off + inc;
+      }
+      __syncthreads();
+      if (s_big != 0u) {  // a sub-bin too large to rank: slice 0 sorts the whole bin the slow way
+        if (j == 0) {
+          for (int byte = 0; byte < 9; ++byte) {
+            const bool b2a = (byte & 1) == 0;
+            wg_radix_pass((b2a ? keys_b : keys_a) + base, (b2a ? vals_b : vals_a) + base,
+                          (b2a ? keys_a : keys_b) + base, (b2a ? vals_a : vals_b) + base, n, byte, s_run, s_cnt);
+            __threadfence_block();
+            __syncthreads();
+          }
+        }
+        continue;
+      }
+      // this slice's sub-bins: those whose first entry lies in [j T, (j + 1) T)
+      const uint32_t T = (n + J - 1) / J;
+      const uint32_t my0 = s_start[threadIdx.x];
+      const bool in = my0 >= j * T && my0 < (j + 1) * T && s_start[threadIdx.x + 1] > my0;
+      const uint32_t f_lo_key = in ? threadIdx.x : 0xffffu, f_hi_key = in ? threadIdx.x + 1 : 0u;
+      uint32_t mn = f_lo_key, mx = f_hi_key;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        mn = min(mn, (uint32_t)__shfl_xor((int)mn, o, 64));
+        mx = max(mx, (uint32_t)__shfl_xor((int)mx, o, 64));
+      }
+      if (lane == 0) s_run[wave] = mn, s_run[4 + wave] = mx;
+      __syncthreads();
+      const uint32_t f0 = min(min(s_run[0], s_run[1]), min(s_run[2], s_run[3]));
+      const uint32_t f1 = max(max(s_run[4], s_run[5]), max(s_run[6], s_run[7]));
+      __syncthreads();
+      if (f0 >= f1) continue;  // (an empty share)
+      const uint32_t first = s_start[f0];
+      s_cur[threadIdx.x] = s_start[threadIdx.x] - first;  // LDS cursors of the slice's sub-bins
+      __syncthreads();
+      for (uint32_t e0 = 0; e0 < n; e0 += 8 * SORT_BLOCK) {
+        unsigned long long kv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const uint32_t e = min(e0 + u * SORT_BLOCK + threadIdx.x, n - 1);
+          kv[u] = (keys_b[base + e] << 32) | (unsigned long long)vals_b[base + e];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const uint32_t f = depth_bin((uint32_t)(kv[u] >> 32), klo, sub_shift, (uint32_t)SUB_BINS);
+          if (e0 + u * SORT_BLOCK + threadIdx.x < n && f >= f0 && f < f1) s_k[atomicAdd(&s_cur[f], 1u)] = kv[u];
+        }
+      }
+      __syncthreads();
+      const uint32_t m = s_start[f1] - first;  // entries of the slice (<= BIN_CAP)
+      for (uint32_t e = threadIdx.x; e < m; e += SORT_BLOCK) {
+        const unsigned long long c = s_k[e];
+        const uint32_t f = depth_bin((uint32_t)(c >> 32), klo, sub_shift, (uint32_t)SUB_BINS);
+        const uint32_t lo = s_start[f] - first, hi = s_start[f + 1] - first;
+        uint32_t r = 0;
+        for (uint32_t tt = lo; tt < hi; tt += 8) {
+          unsigned long long v[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) v[u] = s_k[min(tt + u, hi - 1)];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) r += (tt + u < hi && v[u] < c) ? 1u : 0u;
+        }
+        keys_a[base + first + lo + r] = c >> 32;
+        vals_a[base + first + lo + r] = (uint32_t)c;
+      }
+    }
+    return;
+  }
   const uint32_t bin = blockIdx.x;
-  if ((int)bin >= (1 << depth_bins_log2(N))) return;
   const uint32_t base = bk[BK_BASE + bin], n = bk[BK_BASE + bin + 1] - base;
   if (n == 0) return;
-  const uint32_t shift = bk[BK_SHIFT];
-  const uint32_t klo = bk[BK_KMIN] + (bin << shift);  // smallest key of the bin
-  const uint32_t sub_shift = shift > 8 ? shift - 8 : 0;  // 256 sub-bins over the bin's 2^shift keys
+  if (n > (uint32_t)BIN_CAP && bk[BK_BINJ + bin] != 0u) return;  // cut into slices: the extra workgroups sort it
+  uint32_t klo, sub_shift;
+  sub_bin_map(bk, bin, klo, sub_shift);
   bool lds = n <= (uint32_t)BIN_CAP;
   // the thread's entries, every load issued before the first use (a load -> LDS-atomic loop was one memory round
   // trip per 256 entries: 42 us for the kernel)
@@ -299,7 +468,7 @@ __device__ __forceinline__ void depth_bin_sort_body(int N, uint64_t *__restrict_
 #pragma unroll
     for (int q = 0; q < PER; ++q)
       if ((uint32_t)q * SORT_BLOCK + threadIdx.x < n)
-        atomicAdd(&s_cur[min(((uint32_t)(mine[q] >> 32) - klo) >> sub_shift, (uint32_t)SUB_BINS - 1u)], 1u);
+        atomicAdd(&s_cur[depth_bin((uint32_t)(mine[q] >> 32), klo, sub_shift, (uint32_t)SUB_BINS)], 1u);
     __syncthreads();
     {  // exclusive scan of the 256 sub-bin sizes (thread f owns sub-bin f)
       const uint32_t cnt = s_cur[threadIdx.x];
@@ -326,11 +495,11 @@ __device__ __forceinline__ void depth_bin_sort_body(int N, uint64_t *__restrict_
 #pragma unroll
     for (int q = 0; q < PER; ++q)
       if ((uint32_t)q * SORT_BLOCK + threadIdx.x < n)
-        s_k[atomicAdd(&s_cur[min(((uint32_t)(mine[q] >> 32) - klo) >> sub_shift, (uint32_t)SUB_BINS - 1u)], 1u)] = mine[q];
+        s_k[atomicAdd(&s_cur[depth_bin((uint32_t)(mine[q] >> 32), klo, sub_shift, (uint32_t)SUB_BINS)], 1u)] = mine[q];
     __syncthreads();
     for (uint32_t e = threadIdx.x; e < n; e += SORT_BLOCK) {
       const unsigned long long c = s_k[e];
-      const uint32_t f = min(((uint32_t)(c >> 32) - klo) >> sub_shift, (uint32_t)SUB_BINS - 1u);
+      const uint32_t f = depth_bin((uint32_t)(c >> 32), klo, sub_shift, (uint32_t)SUB_BINS);
       const uint32_t lo = s_start[f], hi = s_start[f + 1];
       uint32_t r = 0;
       for (uint32_t t = lo; t < hi; t += 8) {  // eight LDS reads in flight (clamped, masked)
@@ -849,7 +1018,7 @@ int bin_instances(int N, int H, int W, int64_t R_cap, const void *geom_c, void *
     const unsigned nb = (unsigned)((N + PRE_BLOCK - 1) / PRE_BLOCK), nc = 1u << depth_bins_log2(N);
     hipLaunchKernelGGL(depth_bin_scan_kernel, dim3(1), dim3(1024), 0, stream, N, G, geom);
     hipLaunchKernelGGL(depth_bin_scatter_kernel, dim3(nb), dim3(PRE_BLOCK), 0, stream, N, G, geom);
-    hipLaunchKernelGGL(depth_bin_sort_kernel, dim3(nc), dim3(SORT_BLOCK), 0, stream, N, G, geom);
+    hipLaunchKernelGGL(depth_bin_sort_kernel, dim3(nc + SLICE_GRID), dim3(SORT_BLOCK), 0, stream, N, G, geom);
   }
   const int nseg = (int)G.nseg1;
   {
@@ -895,7 +1064,7 @@ int bin_instances_batched(const dimo_step_common &c, const RenderBatch &b, int n
     const unsigned nb = (unsigned)((c.N + PRE_BLOCK - 1) / PRE_BLOCK), nc = 1u << depth_bins_log2(c.N);
     hipLaunchKernelGGL(depth_bin_scan_batched_kernel, dim3(1, n), dim3(1024), 0, stream, c.N, G, b);
     hipLaunchKernelGGL(depth_bin_scatter_batched_kernel, dim3(nb, n), dim3(PRE_BLOCK), 0, stream, c.N, G, b);
-    hipLaunchKernelGGL(depth_bin_sort_batched_kernel, dim3(nc, n), dim3(SORT_BLOCK), 0, stream, c.N, G, b);
+    hipLaunchKernelGGL(depth_bin_sort_batched_kernel, dim3(nc + SLICE_GRID, n), dim3(SORT_BLOCK), 0, stream, c.N, G, b);
   }
   const int nseg = (int)G.nseg1;
   {

@@ -54,7 +54,12 @@ constexpr int SORT_BLOCK = 256;  // threads of a depth-sort workgroup
 constexpr int NC_MAX = 256;                                          // coarse bins (128 up to 400 k Gaussians, else 256)
 constexpr size_t BK_KMIN = 0, BK_SHIFT = 1;                          // header (4 words): smallest key, log2 bin width
 constexpr size_t BK_BASE = 4;                                        // NC + 1 exclusive prefix sums of the bin sizes
-constexpr size_t BK_HIST = BK_BASE + NC_MAX + 4;                     // [preprocess blocks][NC]: counts, then offsets
+constexpr int MAX_SLICES = 256;                                      // slices of oversized bins (one workgroup each)
+constexpr size_t BK_NSLICE = 2;                                      // header word: number of slices listed
+constexpr size_t BK_KMIN0 = 3;                                       // header word: smallest key (origin of bin 0's sub-bins)
+constexpr size_t BK_BINJ = BK_BASE + NC_MAX + 4;                     // per bin: slices it was cut into (0: none)
+constexpr size_t BK_SLICE = BK_BINJ + NC_MAX;                        // slice list: bin << 16 | slices << 8 | slice
+constexpr size_t BK_HIST = BK_SLICE + MAX_SLICES;                    // [preprocess blocks][NC]: counts, then offsets
 inline __host__ __device__ int depth_bins_log2(int N) { return N <= 400000 ? 7 : 8; }
 
 struct GeomLayout {

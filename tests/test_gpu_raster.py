@@ -193,6 +193,19 @@ def test_depth_sort_bucket_paths(case):
     _check_forward(sc, cam, (0.2, 0.2, 0.2), 0)
 
 
+@pytest.mark.parametrize("far", [30.0, 1.0e5, -1.0])
+def test_depth_sort_with_floaters(far):
+    """A few floaters far behind (or in front of) the scene must not decide the depth bins: the binned range brackets
+    the bulk (largest block minimum / smallest block maximum), keys outside it fall into the end bins, and a bin that
+    still overflows is cut into slices sorted by extra workgroups (binning.hip).  Keys and order stay the oracle's."""
+    cam = camera_np(0.0, W=128, H=96)
+    sc = random_scene(60_000, seed=7, scale=0.006, opacity=(0.05, 0.4))
+    view = np.asarray(cam["view"], np.float64)
+    axis = (view[:3, 2] / np.linalg.norm(view[:3, 2])).astype(np.float32)
+    sc["means3D"][:8] += np.float32(far) * axis
+    _check_forward(sc, cam, (0.1, 0.1, 0.1), 0)
+
+
 def test_depth_sort_with_256_bins_above_400k_gaussians():
     """Above 400 000 Gaussians the depth sort switches from 128 to 256 coarse bins (binning.hip: depth_bins_log2)."""
     cam = camera_np(10.0, W=128, H=96)
