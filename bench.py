@@ -65,10 +65,12 @@ def make_trainer(device, rank, world, num_pts, resolution, per_gpu=(2, 2, 2), ca
     return tr, pol
 
 
-def kernel_rooflines(timing_iso, N, V, R, P, C=NFEAT, renders_per_launch=1.0):
+def kernel_rooflines(timing_iso, N, V, R, P, C=NFEAT, renders_in_window=None, views_per_group=1):
     """name -> algorithmic bytes per render (DESIGN.md section 4 / SURVEY.md 8d formulas), time per launch, GB/s,
-    fraction of the HBM peak -- from the BATCHED launches of the timed schedule when `renders_per_launch` > 1 (a
-    launch then moves that many renders' bytes).  The blend kernels are FP32-VALU bound (see `roofline.note`)."""
+    fraction of the HBM peak.  `renders_in_window` = renders this rank took through the pipeline while the timers
+    ran: every kernel group gets ITS OWN renders per launch = that / its launch count (the forward stages launch per
+    motion batch, the joint backward over all the step's renders); None = one render per launch (isolated run).
+    The blend kernels are FP32-VALU bound (see `roofline.note`)."""
     alg = {
         "deform_fwd": 92 * N,
         "preprocess_fwd": 56 * N + 77 * V,
@@ -88,10 +90,11 @@ def kernel_rooflines(timing_iso, N, V, R, P, C=NFEAT, renders_per_launch=1.0):
         if not n or ms <= 0:
             continue
         t = ms / n * 1e-3
-        # the skinning kernels run once per (motion, frame) GROUP of a batch: two views share a group in this workload
-        b = b * (renders_per_launch / 2.0 if (k.startswith("deform") and renders_per_launch > 1) else renders_per_launch)
-        out[k] = {"algorithmic_bytes_per_launch": float(b), "ms": ms / n, "GBps": b / t / 1e9,
-                  "frac_of_hbm_peak": b / t / 1e9 / HBM_PEAK_GBS}
+        rpl = (renders_in_window / n) if renders_in_window else 1.0
+        # the skinning kernels run once per (motion, frame) GROUP of a batch: the views of a pair share a group
+        b = b * (rpl / views_per_group if (k.startswith("deform") and renders_in_window) else rpl)
+        out[k] = {"algorithmic_bytes_per_launch": float(b), "renders_per_launch": rpl, "ms": ms / n,
+                  "GBps": b / t / 1e9, "frac_of_hbm_peak": b / t / 1e9 / HBM_PEAK_GBS}
     return out
 
 
@@ -133,6 +136,20 @@ def cpu_baseline(num_pts, resolution, renders=20):
                       f"(forward OpenMP over {cores} threads, backward single-threaded); {dt:.1f} s"}
 
 
+def self_launch(n):
+    """Re-executes this script as n ranks under torch.distributed.run (127.0.0.1, a free port); returns its exit code."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+               OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "4"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -147,15 +164,21 @@ def main():
                     help="strong scaling: the reference's batch_size b -> a FIXED step of 2b x b x b renders (b = 2: 16, "
                          "b = 4: 128) sharded over the ranks, instead of 8 renders per GPU")
     ap.add_argument("--per-gpu", default="2,2,2", help="weak scaling: motions,views,frames per GPU and step")
+    ap.add_argument("--sustained-steps", type=int, default=1200,
+                    help="consecutive steps of the `sustained` figure (0: skip); they cross a stage-s2 prune")
     ap.add_argument("--sync-exact", action="store_true", help="size sort buffers by reading R back (one sync per render)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: launch the N ranks ourselves (one process per GPU, rendezvous on a free
+        # loopback port) through the same torch.distributed.run form the driver uses; rank 0's JSON line is this
+        # process's output, the exit code is the launcher's
+        sys.exit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit(f"--gpus {args.gpus} needs a torch.distributed.run launch with --nproc-per-node {args.gpus}")
+        sys.exit(f"--gpus {args.gpus} does not match the launcher's WORLD_SIZE {world}")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the product path has no CPU fallback)")
     local = local % torch.cuda.device_count()  # (several ranks may share a device under --backend gloo)
@@ -212,18 +235,21 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     skipped_timed = tr.skipped_steps - skipped_warmup  # (read with a lag of one step: the last step is not in yet)
+    R_step = getattr(pol, "last_r_mean", None) if pol is not None else None
+    tr_views = 1 if tr.cfg.vae_latent else tr.cfg.views_per_step
     ar_ms = [a.elapsed_time(b) for a, b in tr.allreduce_events] if getattr(tr, "allreduce_events", None) else []
     tr.time_allreduce = False
     if trace is not None:
         print("step-end host times (ms):", " ".join(f"{1e3 * x:.2f}" for x in trace), f"| total {1e3 * elapsed:.2f}",
               f"skipped={tr.skipped_steps}", file=sys.stderr)
     L.dimo_timing_enable(0)
-    tt = torch.tensor([elapsed, float(renders)], dtype=torch.float64, device=device)
+    tt = torch.tensor([elapsed, float(renders), 1.0], dtype=torch.float64, device=device)
+    ranks_seen = 1
     if world > 1:
         tmax = tt.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(tt, op=dist.ReduceOp.SUM)
-        elapsed, renders_total = float(tmax[0]), float(tt[1])
+        elapsed, renders_total, ranks_seen = float(tmax[0]), float(tt[1]), int(round(float(tt[2])))
     else:
         renders_total = float(renders)
     timing = read_timing()
@@ -248,6 +274,9 @@ def main():
     skipped_total = tr.skipped_steps
     peak_mem = torch.cuda.max_memory_allocated(device)
 
+    R = V = cam = None
+    timing_iso = {}
+    iso_ms = iso_n = 0
     if rank == 0:
         # measured R (tile instances) and V (visible Gaussians) of this workload, outside the timed region
         cam = tr.cams.get(0, tr.azimuths[0], tr.cfg.radius, args.resolution, args.resolution)
@@ -281,11 +310,51 @@ def main():
         tr.renderer.gaussians.zero_grad()
         if pol is not None:
             pol.check()
+
+    # sustained rate: the fresh-state figure above is steps ~26-45 of a process; a long run drifts (random targets blow
+    # a few Gaussians up, R grows) and crosses the schedule's stage-s2 opacity prune (step % 1000 == 0: the Gaussian
+    # count changes, every workspace is rebuilt).  >= 1000 consecutive steps, every rank, collectives included.
+    sustained = None
+    if args.sustained_steps > 0:
+        n0 = tr.renderer.gaussians._xyz.shape[0]
+        r0 = getattr(pol, "last_r_mean", None) if pol is not None else None
+        step0, skipped0 = tr.step, tr.skipped_steps
+        barrier()
+        ts = time.perf_counter()
+        ns = 0
+        for _ in range(args.sustained_steps):
+            ns += tr.train_step()
+        barrier()
+        dts = time.perf_counter() - ts
+        st = torch.tensor([dts, float(ns)], dtype=torch.float64, device=device)
+        if world > 1:
+            smax = st.clone()
+            dist.all_reduce(smax, op=dist.ReduceOp.MAX)
+            dist.all_reduce(st, op=dist.ReduceOp.SUM)
+            dts, ns = float(smax[0]), float(st[1])
+        if pol is not None:
+            pol.poll(lag=0)
+        sustained = {"frames_per_s": ns / dts, "ms_per_step": 1e3 * dts / args.sustained_steps,
+                     "steps": args.sustained_steps, "schedule_steps": [step0 + 1, tr.step],
+                     "s2_prunes_crossed": sum(1 for q in range(step0 + 1, tr.step + 1)
+                                              if q % tr.cfg.densification_interval_s2 == 0
+                                              and q < tr.cfg.density_end_iter_s2),
+                     "gaussians_start_end": [int(n0), int(tr.renderer.gaussians._xyz.shape[0])],
+                     "R_mean_per_render_start_end": [r0, getattr(pol, "last_r_mean", None) if pol is not None else None],
+                     "skipped_steps": tr.skipped_steps - skipped0,
+                     "what": "consecutive training steps right after the measurements above, same process and "
+                             "trainer, wall clock with a barrier + device sync on both sides, max over ranks"}
+    if rank == 0:
         P = args.resolution * args.resolution
         bwd_ms, bwd_n = timing["blend_bwd"]
         # the step executor launches the blend backward once per BATCH of renders (one motion's renders in the
         # default mode): a launch moves the algorithmic bytes of all of them
         rpl = renders / max(bwd_n, 1)
+        rps_local = renders / max(args.steps, 1)  # renders this rank takes through one step
+        win = 3 * rps_local                       # ... and through the three steps every kernel group was timed in
+        rpl_of = lambda k: (win / timing_all[k][1]) if timing_all.get(k, (0, 0))[1] else 1.0
+        if R_step:  # mean instance count per render of the last timed steps (the capacity policy's lagged read-back)
+            R = int(R_step)
         alg_render = (28 + 4 * NFEAT) * R + (8 * (NFEAT + 1) + 8) * P + (24 + 4 * NFEAT) * V
         alg_bytes = alg_render * rpl
         avg_s = (bwd_ms / max(bwd_n, 1)) * 1e-3
@@ -319,6 +388,10 @@ def main():
             "value": renders_total / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "strong" if args.global_batch else "weak", "vs_baseline": None, "dtype": "f32",
+            # every rank adds 1 through the same all-reduce the elapsed time goes through
+            "ranks_seen": ranks_seen,
+            "backend": (("rccl (torch.distributed 'nccl')" if args.backend == "nccl" else args.backend)
+                        if world > 1 else "none (one rank)"),
             "data": "synthetic (seeded Gaussians initialised as the reference does, random-init TimeNet, "
                     "random targets; no dataset/LPIPS weights offline; LPIPS/ARAP/GA/KL terms excluded)",
             "config": {"workload": f"{shape_name}: {args.num_pts} Gaussians, 512 control points, {args.resolution}^2, stage s2, "
@@ -338,7 +411,8 @@ def main():
             "setup_steps_before_warmup": PRESTEPS,
             "skipped_steps": {"timed_region": skipped_timed, "whole_run": skipped_total},
             "allreduce_exposed_ms_per_step": (sum(ar_ms) / len(ar_ms)) if ar_ms else (0.0 if world == 1 else None),
-            "roofline": {"bound": "hbm", "kernel": "blend_bwd_batched_kernel", "achieved": achieved,
+            "roofline": {"bound": "valu", "frac_is_of": "hbm peak (as the metric asks)",
+                         "kernel": "blend_bwd_batched_kernel", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "renders_per_launch": rpl,
                          "avg_ms": bwd_ms / max(bwd_n, 1), "launches": bwd_n,
@@ -361,14 +435,16 @@ def main():
             # pixel-Gaussian interactions I = sum over tiles of len * 256, against the FP32 vector peak
             "interactions": {"per_render": R * 256, "blend_bwd_per_s": R * 256 / (avg_s / rpl) if avg_s > 0 else None,
                              "blend_fwd_per_s": (R * 256 / (timing_all["blend_fwd"][0] / timing_all["blend_fwd"][1]
-                                                            * 1e-3 / rpl) if timing_all["blend_fwd"][1] else None),
+                                                            * 1e-3 / rpl_of("blend_fwd"))
+                                                 if timing_all["blend_fwd"][1] else None),
                              "fp32_vector_peak_flops": FP32_VALU_PEAK,
                              "note": "list entries x 256 pixels; culling and saturation skip most of them, so the "
                                      "rate is an upper-bound style figure, not executed FLOPs"},
             # achieved HBM GB/s per kernel against the 8 TB/s peak, from the ALGORITHMIC bytes of
             # DESIGN.md section 4 and (a) the BATCHED launches the step really runs, (b) single-render launches
             # measured alone on the device
-            "kernel_rooflines": kernel_rooflines(timing_all, args.num_pts, V, R, P, renders_per_launch=rpl),
+            "kernel_rooflines": kernel_rooflines(timing_all, args.num_pts, V, R, P, renders_in_window=win,
+                                                 views_per_group=tr_views),
             "kernel_rooflines_isolated": kernel_rooflines(timing_iso, args.num_pts, V, R, P),
             # BASELINE.json metric (ii): rasterizer forward / backward device time of ONE render alone on the device
             # (sum of its kernels' HIP-event times: project, scan, depth sort, placement, blend | blend, projection)
@@ -377,10 +453,11 @@ def main():
                                ("preprocess_fwd", "scan", "sort", "emit", "ranges", "place", "blend_fwd")),
                 "backward": sum(per_launch(timing_iso, k) for k in ("blend_bwd", "preprocess_bwd"))},
             "raster_ms_per_render_batched": {
-                "forward": sum(per_launch(timing_all, k) for k in
-                               ("preprocess_fwd", "scan", "sort", "emit", "ranges", "place", "blend_fwd")) / max(rpl, 1),
-                "backward": sum(per_launch(timing_all, k) for k in ("blend_bwd", "preprocess_bwd")) / max(rpl, 1),
+                "forward": sum(per_launch(timing_all, k) / max(rpl_of(k), 1) for k in
+                               ("preprocess_fwd", "scan", "sort", "emit", "ranges", "place", "blend_fwd")),
+                "backward": sum(per_launch(timing_all, k) / max(rpl_of(k), 1) for k in ("blend_bwd", "preprocess_bwd")),
                 "what": "per render of a batched launch in the timed schedule (two motions' batches share the chip)"},
+            "sustained": sustained,
             "kernels_ms_per_launch": {k: (v[0] / v[1] if v[1] else None) for k, v in timing_all.items()},
             "kernels_ms_per_launch_isolated": {k: (v[0] / v[1] if v[1] else None) for k, v in timing_iso.items()},
         }

@@ -28,7 +28,8 @@ SMALL = ["--steps", "4", "--warmup", "3", "--num-pts", "20000", "--resolution", 
 def test_bench_two_ranks_on_one_device(strong):
     port = 24500 + (os.getpid() % 2000) + int(strong)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "2", "--backend", "gloo", "--no-dropin"] + SMALL
+           "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "2", "--backend", "gloo", "--no-dropin",
+           "--sustained-steps", "30"] + SMALL
     if strong:
         cmd += ["--global-batch", "2"]
     r = _run(cmd)
@@ -38,7 +39,19 @@ def test_bench_two_ranks_on_one_device(strong):
     assert r["skipped_steps"] == {"timed_region": 0, "whole_run": 0}
     assert r["allreduce_exposed_ms_per_step"] is not None and r["allreduce_exposed_ms_per_step"] >= 0.0
     assert r["value"] > 0 and abs(r["value"] - 16 * 1e3 / r["ms_per_step"]) < 1e-6 * r["value"]
-    assert r["roofline"]["bound"] in ("hbm", "mfma") and r["roofline"]["achieved"] > 0
+    assert r["roofline"]["bound"] in ("hbm", "mfma", "valu") and r["roofline"]["achieved"] > 0
+
+
+@pytest.mark.timeout(1200)
+def test_bench_self_launches_ranks():
+    """`python bench.py --gpus 2` WITHOUT torchrun (the command shape the driver uses for N = 1): the script spawns
+    its own ranks, and rank 0's line says how many ranks took part."""
+    r = _run([sys.executable, "bench.py", "--gpus", "2", "--backend", "gloo", "--no-dropin", "--sustained-steps", "30"]
+             + SMALL)
+    assert r["n_gpus"] == 2 and r["ranks_seen"] == 2 and r["backend"] == "gloo"
+    assert r["config"]["renders_per_step"] == 16 and r["config"]["parallelism"] == "dp2"
+    assert r["sustained"]["steps"] == 30 and r["sustained"]["frames_per_s"] > 0
+    assert r["skipped_steps"]["whole_run"] == 0
 
 
 @pytest.mark.timeout(1200)
@@ -52,3 +65,11 @@ def test_bench_single_rank_record_fields():
     assert r["dropin_frames_per_s"] and r["dropin_frames_per_s"] < r["value"]
     assert r["skipped_steps"]["whole_run"] == 0
     assert r["kernel_rooflines"]["blend_bwd"]["ms"] > 0
+    assert r["ranks_seen"] == 1
+    # every kernel group is priced with ITS renders per launch: the forward stages run per motion batch (4 renders),
+    # the joint backward over the step's 8
+    assert r["kernel_rooflines"]["blend_fwd"]["renders_per_launch"] == 4
+    assert r["kernel_rooflines"]["blend_bwd"]["renders_per_launch"] == 8
+    s = r["sustained"]  # default: 1200 consecutive steps, across the stage-s2 prune of step 2000
+    assert s["steps"] >= 1000 and s["s2_prunes_crossed"] >= 1 and s["frames_per_s"] > 0
+    assert s["gaussians_start_end"][0] == 20000 and s["gaussians_start_end"][1] <= 20000

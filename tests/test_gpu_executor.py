@@ -29,7 +29,7 @@ def _rel_l1(a, b):
     return np.abs(a - b).sum() / (np.abs(b).sum() + 1e-12)
 
 
-def _run_batched(N, res, renders_per_motion, n_motions, seed=0, streams="-2", monkeypatch=None):
+def _run_batched(N, res, renders_per_motion, n_motions, seed=0, streams="-2", monkeypatch=None, joint=False):
     """Drives the executor the way Trainer._forward_backward_direct does (one range per motion, each range in
     order on its private stream) with random TimeNet outputs and random gradient images."""
     from dimo_amd import _lib  # noqa: F401
@@ -102,11 +102,15 @@ def _run_batched(N, res, renders_per_motion, n_motions, seed=0, streams="-2", mo
     for i in range(n // 2, n):
         ex.descs[i].g_dot = dot.data_ptr() + i * HW4
     torch.cuda.synchronize()
-    for first in firsts:
-        if ex.ranged:
-            ex.backward_launch_in_order(first, renders_per_motion)
-        else:
-            ex.backward_launch(first, renders_per_motion)
+    if joint:  # the default schedule's backward: launches over up to 8 renders spanning the motions' ranges
+        assert ex.ranged
+        ex.backward_launch_joint(0, n)
+    else:
+        for first in firsts:
+            if ex.ranged:
+                ex.backward_launch_in_order(first, renders_per_motion)
+            else:
+                ex.backward_launch(first, renders_per_motion)
     torch.cuda.synchronize()
     for i in range(n):
         s = ex.slots[i]
@@ -168,6 +172,21 @@ def test_batched_executor_kernels_against_the_oracle(N, res, per_motion, motions
     assert ex.batched and ex.ranged
     Rs = [_check_render(o, f_dc, bg, res, res) for o in outs]
     assert min(Rs) > 5 * N  # a dense workload: every Gaussian lands in several tiles
+
+
+@pytest.mark.timeout(1800)
+@pytest.mark.parametrize("N,res,per_motion,motions", [
+    (100_000, 512, 4, 2),   # C3 as bench.py times it: ONE blend_bwd_batched launch over the step's 8 renders
+    (30_000, 256, 6, 2),    # 12 renders: ranges of 6 do not merge into a launch of <= 8 -> two launches of 6
+    (30_000, 256, 10, 1),   # a range longer than a launch: cut 8 + 2 exactly like its forward
+])
+def test_joint_backward_launch_against_the_oracle(N, res, per_motion, motions, monkeypatch):
+    """dimo_executor_backward_launch_joint (main_train_dimo.py:415: the ONE backward over all the step's renders) --
+    the launch bench.py's roofline is quoted on -- per render against the C oracle."""
+    outs, f_dc, bg, ex = _run_batched(N, res, per_motion, motions, seed=N % 89, monkeypatch=monkeypatch, joint=True)
+    assert ex.batched and ex.ranged
+    for o in outs:
+        _check_render(o, f_dc, bg, res, res)
 
 
 def test_batched_executor_single_stream_mode_small(monkeypatch):
