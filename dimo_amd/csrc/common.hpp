@@ -48,25 +48,52 @@ __host__ __device__ inline size_t align_up(size_t x, size_t a = ALIGN) { return 
 
 constexpr int PRE_BLOCK = 256;  // Gaussians per preprocess block (also the scan granule)
 
-constexpr int SORT_BLOCK = 256;  // threads of a depth-sort workgroup
-// Depth sort of a frame's Gaussians (binning.hip): coarse bins over [min, max] of the depth bits, every bin sorted in
-// LDS by one workgroup.  Word offsets inside the `bk` area of the geometry workspace:
-constexpr int NC_MAX = 256;                                          // coarse bins (128 up to 400 k Gaussians, else 256)
-constexpr size_t BK_KMIN = 0, BK_SHIFT = 1;                          // header (4 words): smallest key, log2 bin width
-constexpr size_t BK_BASE = 4;                                        // NC + 1 exclusive prefix sums of the bin sizes
-constexpr int MAX_SLICES = 256;                                      // slices of oversized bins (one workgroup each)
-constexpr size_t BK_NSLICE = 2;                                      // header word: number of slices listed
-constexpr size_t BK_KMIN0 = 3;                                       // header word: smallest key (origin of bin 0's sub-bins)
-constexpr size_t BK_BINJ = BK_BASE + NC_MAX + 4;                     // per bin: slices it was cut into (0: none)
-constexpr size_t BK_SLICE = BK_BINJ + NC_MAX;                        // slice list: bin << 16 | slices << 8 | slice
-constexpr size_t BK_HIST = BK_SLICE + MAX_SLICES;                    // [preprocess blocks][NC]: counts, then offsets
-inline __host__ __device__ int depth_bins_log2(int N) { return N <= 400000 ? 7 : 8; }
+constexpr int SORT_BLOCK = 256;  // threads of a bucket-sort workgroup
+// Tile binning (binning.hip).  Level 1 drops every visible Gaussian into BUCKETS = (supertile it touches, coarse depth
+// bin): the image is cut into <= MAX_SUPER supertiles of SS x SS tiles (SS <= 8: at most 64 tiles, one lane each at
+// level 2), the depth bits into 2^nb_log2 bins over a range that brackets the bulk of the keys.
+constexpr int MAX_SUPER = 256;     // supertiles
+constexpr int MAX_BUCKETS = 2048;  // supertiles x depth bins
+constexpr int MAX_L1_WG = 4096;    // level-1 workgroups (beyond: several preprocess blocks per workgroup)
+struct BinGrid {
+  int tiles_x, tiles_y, ss_shift, stx, sty, NS;  // supertile edge = 1 << ss_shift tiles, stx * sty = NS supertiles
+};
+// supertile edge: the smallest power of two that leaves <= 64 supertiles, else <= MAX_SUPER; edge <= 8
+inline __host__ bool make_bin_grid(int H, int W, BinGrid &gi) {
+  gi.tiles_x = (W + TILE - 1) / TILE, gi.tiles_y = (H + TILE - 1) / TILE;
+  for (int limit : {64, MAX_SUPER})
+    for (int sh = 0; sh <= 3; ++sh) {
+      const int ss = 1 << sh;
+      const int stx = (gi.tiles_x + ss - 1) / ss, sty = (gi.tiles_y + ss - 1) / ss;
+      if (stx * sty <= limit) {
+        gi.ss_shift = sh, gi.stx = stx, gi.sty = sty, gi.NS = stx * sty;
+        return true;
+      }
+    }
+  return false;
+}
+// depth bins per supertile: buckets of ~300-600 entries on average (a Gaussian touches ~2.4 supertiles; the busiest
+// buckets of a frame hold ~6x the average: a few of them exceed the 2048 entries a workgroup sorts in LDS and are
+// cut into slices), a power of two <= 32, NS * bins <= MAX_BUCKETS
+inline __host__ __device__ int depth_bins_log2(int N, int NS) {
+  int lg = 0;
+  while (lg < 5 && ((size_t)NS << (lg + 1)) <= (size_t)MAX_BUCKETS && (12 * (size_t)N / 5) > ((size_t)NS << lg) * 600) ++lg;
+  return lg;
+}
+// words of the `bk` area in the geometry workspace
+constexpr int MAX_SLICES = 256;                                          // slices of oversized buckets (one workgroup each)
+constexpr size_t BK_KMIN = 0, BK_SHIFT = 1, BK_KMIN0 = 2, BK_NBLOG = 3;  // bin map: origin, log2 bin width, smallest key, log2 bins
+constexpr size_t BK_NSLICE = 4;                                          // number of slices listed
+constexpr size_t BK_TOT = 8;                                             // [MAX_BUCKETS] entries per bucket (atomically summed)
+constexpr size_t BK_START = BK_TOT + MAX_BUCKETS;                        // [MAX_BUCKETS] first entry of the bucket in the level-1 array
+constexpr size_t BK_BINJ = BK_START + MAX_BUCKETS;                       // [MAX_BUCKETS] slices the bucket was cut into (0: none)
+constexpr size_t BK_SLICE = BK_BINJ + MAX_BUCKETS;                       // slice list: bucket << 16 | slices << 8 | slice
+constexpr size_t BK_WORDS = BK_SLICE + MAX_SLICES;
 
 struct GeomLayout {
-  size_t splat, rect, tiles, offsets, flags, total, block_sums;
-  size_t nkeys_a, nvals_a, nkeys_b, nvals_b, bk;  // depth sort of the Gaussians (binning.hip)
-  size_t cnt1;                                       // level-1 filter counters [segments of 256][256 supertiles]
-  size_t bytes, nseg1;
+  size_t splat, rect, tiles, offsets, flags, total, block_sums, key32, bk, wgbase;
+  size_t bytes;
+  int nb, per, nwg1;  // preprocess blocks; blocks per level-1 workgroup; level-1 workgroups
   __host__ explicit GeomLayout(int N) {
     size_t n = (size_t)(N > 0 ? N : 1);
     size_t o = 0;
@@ -75,17 +102,17 @@ struct GeomLayout {
     tiles = o, o = align_up(o + n * sizeof(uint32_t));
     offsets = o, o = align_up(o + n * sizeof(uint32_t));
     flags = o, o = align_up(o + n);
-    total = o, o = align_up(o + 4 * sizeof(uint32_t));  // R, overflow flag, 0, number of depth-sorted Gaussians
-    size_t nb = (n + PRE_BLOCK - 1) / PRE_BLOCK;
-    // per preprocess block: tiles touched [nb + 1], then min / max of the depth bits of its visible Gaussians
-    block_sums = o, o = align_up(o + 3 * (nb + 1) * sizeof(uint32_t));
-    nkeys_a = o, o = align_up(o + n * sizeof(uint64_t));
-    nvals_a = o, o = align_up(o + n * sizeof(uint32_t));
-    nkeys_b = o, o = align_up(o + n * sizeof(uint64_t));
-    nvals_b = o, o = align_up(o + n * sizeof(uint32_t));
-    bk = o, o = align_up(o + (BK_HIST + nb * ((size_t)1 << depth_bins_log2(N))) * sizeof(uint32_t));
-    nseg1 = (n + 255) / 256;
-    cnt1 = o, o = align_up(o + nseg1 * 256 * sizeof(uint32_t));
+    total = o, o = align_up(o + 4 * sizeof(uint32_t));  // R, overflow flag, level-1 entries, 0
+    nb = (int)((n + PRE_BLOCK - 1) / PRE_BLOCK);
+    per = (nb + MAX_L1_WG - 1) / MAX_L1_WG, nwg1 = (nb + per - 1) / per;
+    // per preprocess block [nb + 1] each: tiles touched, min / max of the depth bits of its visible Gaussians,
+    // level-1 entries (supertiles touched)
+    block_sums = o, o = align_up(o + 4 * ((size_t)nb + 1) * sizeof(uint32_t));
+    key32 = o, o = align_up(o + n * sizeof(uint32_t));  // depth bits, 0xffffffff for a Gaussian without tiles
+    bk = o, o = align_up(o + BK_WORDS * sizeof(uint32_t));
+    // wgbase[workgroup][bucket]: where the level-1 workgroup's entries of that bucket start inside the bucket (only
+    // the words of the buckets a workgroup touches are written and read)
+    wgbase = o, o = align_up(o + (size_t)nwg1 * MAX_BUCKETS * sizeof(uint32_t));
     bytes = o;
   }
 };
@@ -93,25 +120,32 @@ struct GeomLayout {
 constexpr int BUCKET = 64;       // list entries per backward work item
 constexpr int CKPT_FLOATS = 9;   // T, 7 accumulated features, accumulated weight
 struct BinLayout {
-  size_t keys_b, vals_b, ranges, totals, meta, l1list, cnt2, ckpt, work, bytes;
+  size_t dkeys, vals_b, ranges, totals, meta, l1tmp, l1a, l1b, l1list, cnt2, ckpt, work, bytes;
   int tiles_x, tiles_y, T;
   size_t cap, ckpt_slots, l1cap, max_windows;
   __host__ BinLayout(int64_t R_cap, int H, int W) {
     cap = (size_t)(R_cap > 0 ? R_cap : 1);
     tiles_x = (W + TILE - 1) / TILE, tiles_y = (H + TILE - 1) / TILE, T = tiles_x * tiles_y;
     size_t o = 0;
-    keys_b = o, o = align_up(o + cap * sizeof(uint64_t));
+    // per instance, in the order of the per-tile lists: the 32 depth bits of its sort key (the key's tile is the
+    // list it sits in: `ranges`) and the Gaussian id
+    dkeys = o, o = align_up(o + cap * sizeof(uint32_t));
     vals_b = o, o = align_up(o + cap * sizeof(uint32_t));
     ranges = o, o = align_up(o + (size_t)T * 2 * sizeof(uint32_t));
-    totals = o, o = align_up(o + (size_t)T * sizeof(uint32_t));  // tile total, then tile start
-    // placement (binning.hip): per-supertile lists of (id, depth) -- at most one entry per instance, every list
-    // start rounded up to a 256-entry window --, per-window tile counters, and the level-1 metadata
+    totals = o, o = align_up(o + (size_t)T * sizeof(uint32_t));  // instances per tile (atomically summed)
+    // level 1 (binning.hip): per-supertile lists -- at most one entry per instance, every list start rounded up to
+    // a 256-entry window.  l1tmp: the 16-byte entries (depth bits, id, tile rectangle) bucket by bucket as the level-1
+    // scatter leaves them; l1a / l1b: 64-bit scratch of the byte-wise fallback sort; l1list: the sorted entries (id,
+    // depth bits, tile rectangle)
     l1cap = (cap + 255) / 256 * 256 + 256 * 256;
     max_windows = l1cap / 256;
-    l1list = o, o = align_up(o + l1cap * 2 * sizeof(uint32_t));
+    l1tmp = o, o = align_up(o + l1cap * 4 * sizeof(uint32_t));
+    l1a = o, o = align_up(o + l1cap * sizeof(uint64_t));
+    l1b = o, o = align_up(o + l1cap * sizeof(uint64_t));
+    l1list = o, o = align_up(o + l1cap * 4 * sizeof(uint32_t));
     // per-window tile counts [max_windows][64], then the same per (window, wave) [max_windows][4][64]
     cnt2 = o, o = align_up(o + max_windows * 64 * 5 * sizeof(uint32_t));
-    meta = o, o = align_up(o + (4 * 256 + max_windows) * sizeof(uint32_t));
+    meta = o, o = align_up(o + (4 * 256 + 4 * max_windows) * sizeof(uint32_t));
     // blend checkpoints: per (tile, bucket of BUCKET list entries) the 256 pixels' compositing state at the
     // bucket's first entry -- slot (lo_tile / BUCKET + tile + bucket), see blend.hip; work: [0] = item count,
     // then one word (tile << 12 | bucket) per bucket some pixel of the tile reaches
@@ -208,8 +242,6 @@ int blend_forward_batched(const dimo_step_common &c, const RenderBatch &b, int n
 int blend_backward_batched(const dimo_step_common &c, const RenderBatch &b, int n, hipStream_t stream);
 
 // ---- internal (C++ linkage) entry points shared between translation units ---------------------
-int scan_block_sums(int nb, int N, uint32_t *block_sums, uint32_t *total, uint32_t *bk, hipStream_t stream);
-int write_offsets(int N, const void *geom, hipStream_t stream);
 int bin_instances(int N, int H, int W, int64_t R_cap, const void *geom, void *bin, hipStream_t stream);
 int preprocess_backward_launch(int N, int sh_degree, int M, int H, int W, int64_t R_cap, const float *means3D,
                                const float *shs, const float *colors_precomp, const float *scales,

@@ -116,9 +116,15 @@ __device__ __forceinline__ void preprocess_fwd_body(
     const float *__restrict__ rotations, const float *__restrict__ cov3D_precomp, float scale_mod,
     const float *__restrict__ Vg, const float *__restrict__ Pg, const float *__restrict__ camg, float tanfovx,
     float tanfovy, int32_t *__restrict__ radii, Splat *__restrict__ splat, uint16_t *__restrict__ rect,
-    uint32_t *__restrict__ tiles_touched, uint8_t *__restrict__ flags, uint32_t *__restrict__ block_sums) {
+    uint32_t *__restrict__ tiles_touched, uint8_t *__restrict__ flags, uint32_t *__restrict__ block_sums,
+    uint32_t *__restrict__ key32, uint32_t *__restrict__ bk, int ss_shift) {
   __shared__ uint32_t wave_sums[PRE_BLOCK / 64], wave_min[PRE_BLOCK / 64], wave_max[PRE_BLOCK / 64];
+  __shared__ uint32_t wave_ent[PRE_BLOCK / 64];
   const int i = blockIdx.x * PRE_BLOCK + threadIdx.x;
+  // the binning's per-bucket entry counters start every frame at zero: cleared here, one launch ahead of
+  // the level-1 kernel that adds to them (binning.hip)
+  if (blockIdx.x == 0)
+    for (int t = threadIdx.x; t < MAX_BUCKETS; t += PRE_BLOCK) bk[BK_TOT + t] = 0u;
   // camera: uniform loads (scalar cache)
   float V[16], P[16], cam[3];
 #pragma unroll
@@ -126,6 +132,7 @@ __device__ __forceinline__ void preprocess_fwd_body(
   cam[0] = camg[0], cam[1] = camg[1], cam[2] = camg[2];
 
   uint32_t my_tiles = 0, my_key = 0xffffffffu;  // (key = depth bits of a Gaussian that touches a tile)
+  uint32_t my_ent = 0;                          // supertiles it touches = its level-1 entries (binning.hip)
   if (i < N) {
     const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
     const float fx = (float)W / (2.0f * tanfovx), fy = (float)H / (2.0f * tanfovy);
@@ -207,6 +214,8 @@ __device__ __forceinline__ void preprocess_fwd_body(
           my_radius = rr;
           my_tiles = (uint32_t)cnt;
           my_key = __float_as_uint(pv[2]);
+          my_ent = (uint32_t)((((rx1 - 1) >> ss_shift) - (rx0 >> ss_shift) + 1) *
+                              (((ry1 - 1) >> ss_shift) - (ry0 >> ss_shift) + 1));
           out.x = pix_x, out.y = pix_y, out.A = cA, out.B = cB, out.C = cC, out.opacity = opacities[i];
           out.r = rgb[0], out.g = rgb[1], out.b = rgb[2], out.depth = pv[2];
           out.nx = nv[0], out.ny = nv[1], out.nz = nv[2];
@@ -216,6 +225,7 @@ __device__ __forceinline__ void preprocess_fwd_body(
     }
     radii[i] = my_radius;
     tiles_touched[i] = my_tiles;
+    key32[i] = my_key;
     flags[i] = fl;
     // 64-B record and 8-B rect as wide stores
     float4 *dst = reinterpret_cast<float4 *>(splat + i);
@@ -225,10 +235,10 @@ __device__ __forceinline__ void preprocess_fwd_body(
         make_uint2((uint32_t)rc[0] | ((uint32_t)rc[1] << 16), (uint32_t)rc[2] | ((uint32_t)rc[3] << 16));
   }
   // block sum of tiles_touched (feeds the 2-level scan)
-  uint32_t v = my_tiles;
+  uint32_t v = my_tiles, ve = my_ent;
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-  if ((threadIdx.x & 63) == 0) wave_sums[threadIdx.x >> 6] = v;
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64), ve += __shfl_down(ve, o, 64);
+  if ((threadIdx.x & 63) == 0) wave_sums[threadIdx.x >> 6] = v, wave_ent[threadIdx.x >> 6] = ve;
   // ... and the block's range of depth-sort keys (the depth bits of the Gaussians that touch a tile): the sort cuts
   // [min, max] into buckets (binning.hip)
   uint32_t kmn = my_key, kmx = my_key == 0xffffffffu ? 0u : my_key;
@@ -243,6 +253,7 @@ __device__ __forceinline__ void preprocess_fwd_body(
     block_sums[blockIdx.x] = wave_sums[0] + wave_sums[1] + wave_sums[2] + wave_sums[3];
     block_sums[(gridDim.x + 1) + blockIdx.x] = min(min(wave_min[0], wave_min[1]), min(wave_min[2], wave_min[3]));
     block_sums[2 * (gridDim.x + 1) + blockIdx.x] = max(max(wave_max[0], wave_max[1]), max(wave_max[2], wave_max[3]));
+    block_sums[3 * (gridDim.x + 1) + blockIdx.x] = wave_ent[0] + wave_ent[1] + wave_ent[2] + wave_ent[3];
   }
 }
 
@@ -256,19 +267,35 @@ __global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_kernel(
     const float *__restrict__ rotations, const float *__restrict__ cov3D_precomp, float scale_mod,
     const float *__restrict__ Vg, const float *__restrict__ Pg, const float *__restrict__ camg, float tanfovx,
     float tanfovy, int32_t *__restrict__ radii, Splat *__restrict__ splat, uint16_t *__restrict__ rect,
-    uint32_t *__restrict__ tiles_touched, uint8_t *__restrict__ flags, uint32_t *__restrict__ block_sums) {
+    uint32_t *__restrict__ tiles_touched, uint8_t *__restrict__ flags, uint32_t *__restrict__ block_sums,
+    uint32_t *__restrict__ key32, uint32_t *__restrict__ bk, int ss_shift) {
   preprocess_fwd_body(N, deg, M, H, W, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
-                      scale_mod, Vg, Pg, camg, tanfovx, tanfovy, radii, splat, rect, tiles_touched, flags, block_sums);
+                      scale_mod, Vg, Pg, camg, tanfovx, tanfovy, radii, splat, rect, tiles_touched, flags, block_sums,
+                      key32, bk, ss_shift);
+}
+// total[0] = R = sum of the blocks' tile counts: only for callers that size their buffers from a read-back of R
+// (dimo_raster_preprocess_forward with R_host); the binning's level-1 kernel writes the same word
+__global__ void __launch_bounds__(256) total_instances_kernel(int nb, const uint32_t *__restrict__ sums,
+                                                              uint32_t *__restrict__ total) {
+  __shared__ uint32_t part[4];
+  uint32_t v = 0;
+  for (int i = threadIdx.x; i < nb; i += 256) v += sums[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) total[0] = part[0] + part[1] + part[2] + part[3], total[1] = 0, total[2] = 0, total[3] = 0;
 }
 // blockIdx.y = render of the batch: degree-0 colour from the shared f_dc, scale/rotation covariance
 __global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_batched_kernel(int N, int H, int W,
                                                                            const float *__restrict__ f_dc,
                                                                            float scale_mod, GeomLayout L,
-                                                                           RenderBatch b) {
+                                                                           int ss_shift, RenderBatch b) {
   const dimo_render_desc &r = b.r[blockIdx.y];
   preprocess_fwd_body(N, 0, 1, H, W, r.pts, f_dc, nullptr, r.opac, r.scales, r.rot, nullptr, scale_mod, r.view, r.proj,
                       r.campos, r.tanfovx, r.tanfovy, r.radii, at<Splat>(r.geom, L.splat), at<uint16_t>(r.geom, L.rect),
-                      at<uint32_t>(r.geom, L.tiles), at<uint8_t>(r.geom, L.flags), at<uint32_t>(r.geom, L.block_sums));
+                      at<uint32_t>(r.geom, L.tiles), at<uint8_t>(r.geom, L.flags), at<uint32_t>(r.geom, L.block_sums),
+                      at<uint32_t>(r.geom, L.key32), at<uint32_t>(r.geom, L.bk), ss_shift);
 }
 
 __device__ __forceinline__ void preprocess_bwd_body(
@@ -571,20 +598,19 @@ __global__ void __launch_bounds__(PRE_BLOCK) preprocess_bwd_batched_kernel(int N
 }
 
 // scan of tiles_touched for every render of a batch (binning.hip)
-int scan_offsets_batched(int N, const GeomLayout &L, const RenderBatch &b, int n, hipStream_t stream);
 
 int preprocess_forward_batched(const dimo_step_common &c, const RenderBatch &b, int n, hipStream_t stream) {
   if (n <= 0) return DIMO_OK;
   GeomLayout L(c.N);
   if (c.geom_bytes < L.bytes) return DIMO_E_WORKSPACE;
-  const int nb = (c.N + PRE_BLOCK - 1) / PRE_BLOCK;
-  if (nb > 0) {
-    ScopedTimer tm(T_PREPROCESS_FWD, stream);
-    hipLaunchKernelGGL(preprocess_fwd_batched_kernel, dim3(nb, n), dim3(PRE_BLOCK), 0, stream, c.N, c.H, c.W, c.f_dc,
-                       c.scale_modifier, L, b);
-  }
-  ScopedTimer tm(T_SCAN, stream);
-  return scan_offsets_batched(c.N, L, b, n, stream);
+  BinGrid gi;
+  if (!make_bin_grid(c.H, c.W, gi)) return DIMO_E_ARG;  // more than MAX_SUPER * 64 tiles
+  // (N = 0 still runs one block: it clears the binning's counters)
+  const int nb = c.N > 0 ? (c.N + PRE_BLOCK - 1) / PRE_BLOCK : 1;
+  ScopedTimer tm(T_PREPROCESS_FWD, stream);
+  hipLaunchKernelGGL(preprocess_fwd_batched_kernel, dim3(nb, n), dim3(PRE_BLOCK), 0, stream, c.N, c.H, c.W, c.f_dc,
+                     c.scale_modifier, L, gi.ss_shift, b);
+  return check_launch();
 }
 
 int preprocess_backward_batched(const dimo_step_common &c, const RenderBatch &b, int n, hipStream_t stream) {
@@ -620,23 +646,21 @@ extern "C" int dimo_raster_preprocess_forward(int N, int sh_degree, int M, int H
   GeomLayout L(N);
   if (geom_bytes < L.bytes) return DIMO_E_WORKSPACE;
   if (N > 0 && (!means3D || !opacities || !radii)) return DIMO_E_ARG;
-  const int nb = (N + PRE_BLOCK - 1) / PRE_BLOCK;
-  if (nb > 0) {
+  BinGrid gi;
+  if (!make_bin_grid(H, W, gi)) return DIMO_E_ARG;  // more than MAX_SUPER * 64 tiles
+  const int nb = N > 0 ? (N + PRE_BLOCK - 1) / PRE_BLOCK : 1;  // (N = 0: one block clears the binning's counters)
+  {
     ScopedTimer tm(T_PREPROCESS_FWD, stream);
     hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(nb), dim3(PRE_BLOCK), 0, stream, N, sh_degree, M, H, W, means3D,
                        shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, scale_modifier, viewmatrix,
                        projmatrix, campos, tanfovx, tanfovy, radii, at<Splat>(geom, L.splat),
                        at<uint16_t>(geom, L.rect), at<uint32_t>(geom, L.tiles), at<uint8_t>(geom, L.flags),
-                       at<uint32_t>(geom, L.block_sums));
+                       at<uint32_t>(geom, L.block_sums), at<uint32_t>(geom, L.key32), at<uint32_t>(geom, L.bk),
+                       gi.ss_shift);
   }
-  ScopedTimer *scan_tm = new ScopedTimer(T_SCAN, stream);
-  int rc = scan_block_sums(nb, N, at<uint32_t>(geom, L.block_sums), at<uint32_t>(geom, L.total), at<uint32_t>(geom, L.bk),
-                           stream);
-  if (rc) return rc;
-  rc = write_offsets(N, geom, stream);
-  delete scan_tm;
-  if (rc) return rc;
   if (R_host) {
+    hipLaunchKernelGGL(total_instances_kernel, dim3(1), dim3(256), 0, stream, nb, at<uint32_t>(geom, L.block_sums),
+                       at<uint32_t>(geom, L.total));
     uint32_t tot[4] = {0, 0, 0, 0};
     if (hipMemcpyAsync(tot, at<uint32_t>(geom, L.total), sizeof(tot), hipMemcpyDeviceToHost, stream) != hipSuccess)
       return DIMO_E_LAUNCH;

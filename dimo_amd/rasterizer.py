@@ -355,6 +355,15 @@ def inspect_state(ctx_tensors, N, H, W, r_cap):
 
     n = max(N, 1)
     total = view(geom, go[5], 16, torch.int32)
+    ranges = view(bin_ws, bo[2], T * 8, torch.int32).view(T, 2)
+    # The library stores the 32 depth bits of every instance's sort key; the key's tile is the list the instance
+    # sits in (`ranges`), so the published 64-bit (tile << 32 | depth bits) keys are rebuilt here for inspection.
+    R = int(min(int(total[0]) & 0xFFFFFFFF, r_cap))
+    dkeys = view(bin_ws, bo[0], r_cap * 4, torch.int32)
+    lens = (ranges[:, 1] - ranges[:, 0]).to(torch.int64).clamp_(min=0)
+    tile_of = torch.repeat_interleave(torch.arange(T, dtype=torch.int64, device=geom.device), lens)[:R]
+    keys = torch.zeros(max(R, 1), dtype=torch.int64, device=geom.device)
+    keys[:tile_of.numel()] = (tile_of << 32) | (dkeys[:tile_of.numel()].to(torch.int64) & 0xFFFFFFFF)
     return dict(
         splat=view(geom, go[0], n * 64, torch.float32).view(n, 16)[:N],
         rect=view(geom, go[1], n * 8, torch.int16).view(n, 4)[:N],
@@ -362,9 +371,10 @@ def inspect_state(ctx_tensors, N, H, W, r_cap):
         offsets=view(geom, go[3], n * 4, torch.int32)[:N],
         flags=view(geom, go[4], n, torch.uint8)[:N],
         total=total,
-        keys_sorted=view(bin_ws, bo[0], r_cap * 8, torch.int64),
+        keys_sorted=keys,
+        depth_keys_sorted=dkeys,
         vals_sorted=view(bin_ws, bo[1], r_cap * 4, torch.int32),
-        ranges=view(bin_ws, bo[2], T * 8, torch.int32).view(T, 2),
+        ranges=ranges,
         final_T=view(img_ws, io[0], H * W * 4, torch.float32).view(H, W),
         n_contrib=view(img_ws, io[1], H * W * 4, torch.int32).view(H, W),
     )

@@ -54,8 +54,8 @@ const char *dimo_last_error(void);
  * stream it is launched on.  dimo_timing_read synchronises the device and returns the summed
  * duration and launch count of one group: "preprocess_fwd" "scan" "emit" "sort" "ranges" "blend_fwd"
  * "blend_bwd" "preprocess_bwd" "knn" "dist2" "ssim_fwd" "ssim_bwd" "deform_fwd" "deform_bwd" "image_loss" "adam"
- * "timenet_fwd" "timenet_bwd" "place" ("sort" = depth sort of the Gaussians, "emit" = per-chunk tile counts,
- * "ranges" = column scan + tile ranges, "place" = placement of the instances).
+ * "timenet_fwd" "timenet_bwd" "place" (binning, dimo_amd/csrc/binning.hip: "scan" = offsets + level-1 entries,
+ * "sort" = per-bucket LDS sort, "ranges" = level-2 count, "place" = level-2 fill; "emit" is no longer used).
  * dimo_timing_enable(1) clears earlier records; returns the previous state.  dimo_timing_select restricts the
  * instrumentation to a comma-separated list of groups (NULL or "": all) -- two event records per launch are not
  * free, a throughput run that only needs one kernel's duration selects that kernel. */
@@ -66,7 +66,7 @@ int dimo_timing_read(const char *name, double *total_ms, int64_t *launches);
 /* ------------------------------------------------------------------ rasterizer workspaces
  * geom : per-Gaussian state written by preprocess (splat records, tile rects, tiles_touched,
  *        offsets, flags, block sums).  Needed by backward.
- * bin  : tile-instance state (sorted keys and values, tile ranges, placement counters, blend checkpoints).
+ * bin  : tile-instance state (per-tile lists of depth bits and ids, tile ranges, level-1 lists, blend checkpoints).
  *        Sized for a CAPACITY R_cap >= R (number of (Gaussian, tile) instances).  Needed by backward.
  * img  : per-pixel state (final transmittance, n_contrib).  Needed by backward.
  */
@@ -78,14 +78,24 @@ size_t dimo_raster_img_bytes(int H, int W);
  * geom: [0] splat float[N][16] = (x y A B C opacity r g b depth nx ny nz pad pad pad)
  *       [1] rect  uint16[N][4] = (xmin ymin xmax ymax) in tiles     [2] tiles_touched uint32[N]
  *       [3] offsets uint32[N] (inclusive scan)                      [4] flags uint8[N] (bit c = SH channel c clamped)
- *       [5] total  uint32[4]  = (R, overflow flag, 0, 0)
- * bin : [0] keys_sorted uint64[R_cap]   [1] vals_sorted uint32[R_cap]   [2] ranges uint32[T][2]
+ *       [5] total  uint32[4]  = (R, overflow flag, level-1 entries, 0)
+ * bin : [0] depth_keys_sorted uint32[R_cap]   [1] vals_sorted uint32[R_cap]   [2] ranges uint32[T][2]
+ *       The published 64-bit sort key of an instance is (tile << 32 | fp32 depth bits); an instance's tile is the
+ *       list it sits in (tile t owns slots [ranges[t][0], ranges[t][1])), so only the depth bits are stored.
  *       (the instances are placed straight into their sorted slots: there is no unsorted emission to look at)
  * img : [0] final_T float[H*W]          [1] n_contrib uint32[H*W]
  */
 int dimo_raster_geom_layout(int N, size_t out_offsets[6]);
 int dimo_raster_bin_layout(int64_t R_cap, int H, int W, size_t out_offsets[3]);
 int dimo_raster_img_layout(int H, int W, size_t out_offsets[2]);
+/* Diagnostic (tools/bin_stats.py): where the binning's level-1 state lives -- out = (byte offset of the bucket words
+ * in geom, of the unsorted and of the sorted level-1 entries in bin, buckets, log2 depth bins, supertiles,
+ * word offsets of the bucket totals / starts / slice count inside the bucket words). */
+int dimo_debug_bin_layout(int N, int64_t R_cap, int H, int W, size_t out[9]);
+/* Diagnostic: per-workgroup phase trace of the binning kernels (tools/bin_trace.py; needs a library built with
+ * DIMO_BIN_TRACE=1, else a non-NULL buffer is refused).  buffer = device memory for `capacity` records of 32 x u64,
+ * NULL = off; returns the number of records written since the last call. */
+int64_t dimo_debug_bin_trace(void *buffer, int64_t capacity);
 
 /*
  * Stage 1 (per Gaussian): cull, project, 3D->2D covariance, conic, radius, tile rect, SH->RGB,

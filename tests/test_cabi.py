@@ -39,7 +39,7 @@ def test_layout_queries(lib):
     for arr in (g, b, i):
         offs = list(arr)
         assert offs == sorted(offs) and all(o % 256 == 0 for o in offs)
-    assert g[1] - g[0] >= 1000 * 64 and b[1] - b[0] >= 50000 * 8 and i[1] - i[0] >= 128 * 96 * 4
+    assert g[1] - g[0] >= 1000 * 64 and b[1] - b[0] >= 50000 * 4 and i[1] - i[0] >= 128 * 96 * 4
     assert lib.dimo_raster_geom_bytes(1000) > g[5]
     assert lib.dimo_raster_bin_bytes(50000, 128, 96) > b[2]
     assert lib.dimo_raster_geom_bytes(0) > 0  # empty scenes still get a valid workspace
