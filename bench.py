@@ -74,11 +74,12 @@ def kernel_rooflines(timing_iso, N, V, R, P, C=NFEAT, renders_in_window=None, vi
     alg = {
         "deform_fwd": 92 * N,
         "preprocess_fwd": 56 * N + 77 * V,
-        "scan": 8 * N,
-        "sort": 2 * 24 * N,  # bin scatter + in-LDS bin sort (binning.hip): read and write (key, id) twice
-        "emit": 12 * N + 16 * N,           # level 1: (id, rect) in, ~2 N (id, depth) entries out
-        "ranges": 8 * 2 * N + 8 * (P // 256),  # level 2 count + scan + tile starts: the level-1 entries once more
-        "place": 8 * 2 * N + 12 * R,       # level 2 fill: entries in, one (key, value) per instance out
+        # binning (dimo_amd/csrc/binning.hip), E = level-1 entries ~ 2.4 N (one per supertile a Gaussian touches):
+        "scan": 20 * N,                    # level-1 count: tiles, depth key, rectangle in; offsets out
+        "emit": 16 * N + 16 * 2.4 * N,     # level-1 scatter: the same in; one 16-byte entry per supertile touched out
+        "sort": 2 * 16 * 2.4 * N,          # per-bucket LDS sort: entries in, sorted entries out
+        "ranges": 16 * 2.4 * N + 8 * (P // 256),  # level-2 count: entries in, per-window tile counts out
+        "place": 16 * 2.4 * N + 9 * R,     # level-2 fill: entries in; depth bits + id + cleared flag per instance out
         "blend_fwd": (28 + 4 * C) * R + 4 * (C + 1) * P + 8 * P,
         "blend_bwd": (28 + 4 * C) * R + (8 * (C + 1) + 8) * P + (24 + 4 * C) * V,
         "preprocess_bwd": (24 + 4 * C) * V + 56 * N + 56 * N + 12 * N,
@@ -477,9 +478,13 @@ def main():
                 n2 = sum(tr2.train_step() for _ in range(k2))
                 torch.cuda.synchronize()
                 res["dropin_frames_per_s"] = n2 / (time.perf_counter() - t2)
-                res["dropin_what"] = ("same C3 step through the drop-in surface only: Renderer.render + "
-                                      "GaussianRasterizerNormal (autograd, one launch chain and one R read-back per render), "
-                                      "PyTorch TimeNet and losses (fused SSIM op), FlatAdam; %d steps" % k2)
+                bt = getattr(tr2.renderer, "_batcher", None)
+                res["dropin_what"] = ("same C3 step through the drop-in surface only: Renderer.render per (motion, view, "
+                                      "frame) triple + ONE autograd backward (Trainer(direct=False), the reference's loop "
+                                      "shape); the renders of a step are batched behind render() (lazy outputs, "
+                                      "dimo_amd/batched_render.py: %d renders in %d launch chains), TimeNet and the image "
+                                      "losses are single autograd nodes on the fused kernels, FlatAdam; %d steps"
+                                      % (getattr(bt, "rendered", 0), getattr(bt, "flushes", 0), k2))
                 del tr2
             except Exception as e:
                 res["dropin_frames_per_s"] = None

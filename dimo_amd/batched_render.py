@@ -1,0 +1,430 @@
+"""Batched execution behind the reference-shaped call surface.
+
+The reference's step calls `Renderer.render(cam, time=, stage=, latent_index=)` once per (motion, view, frame) triple
+and runs ONE `loss.backward()` over all of them (main_train_dimo.py:276-318, 415).  Rendered one by one, a render's
+kernels cannot fill an MI355X (a 512^2 blend forward of one render takes 57 us alone, 27 us as one of eight) and every
+call pays its own launch chain.  This module keeps the call surface and batches underneath:
+
+  * `Renderer.render` hands its request to a `RenderBatcher` and returns the usual dict whose image / depth / normal /
+    alpha / radii entries are `LazyTensor`s -- stand-ins that run the pending batch the first time anything looks at
+    them (any torch function, method, operator or attribute).  A loop that renders all its triples and only then forms
+    the losses gets ONE launch per rasterizer stage for all of them (the native step executor, dimo_amd/executor.py);
+    a loop that consumes each render at once degrades to batches of one, with unchanged results.
+  * A batch is ONE autograd node (`_BatchRenderFn`): its backward receives the gradient images of all its renders at
+    once and runs the joint rasterizer + skinning backward the trainer's direct pipeline runs.
+  * TimeNet for `deform=None` calls is evaluated once per batch for the distinct (latent, time) pairs by the fused HIP
+    forward (`timenet_apply`, also used by `Trainer.batched_deform`).
+
+GPU only: the conditions under which `Renderer.render` may batch are in `Renderer._batchable`; everything else takes
+the immediate per-render path.  No CPU fallback anywhere (a request that cannot be batched is rendered by the HIP
+kernels directly, never by a host implementation).
+"""
+import ctypes as C
+import weakref
+
+import torch
+from torch.utils._pytree import tree_map
+
+from . import _lib
+
+
+# ------------------------------------------------------------------------------------------------ lazy tensors
+class LazyTensor:
+    """Stand-in for a tensor that a pending batch will produce.  Not a `torch.Tensor` subclass on purpose: nothing
+    about it needs the dispatcher until it is used, and the first use replaces it by the real tensor."""
+    __slots__ = ("_fn", "_val", "__weakref__")
+
+    def __init__(self, fn):
+        self._fn, self._val = fn, None
+
+    def materialize(self):
+        if self._fn is not None:
+            self._val, self._fn = self._fn(), None
+        return self._val
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        return func(*tree_map(_unwrap, args), **tree_map(_unwrap, kwargs or {}))
+
+    def __getattr__(self, name):  # (only reached for names the class does not define)
+        return getattr(self.materialize(), name)
+
+    def __repr__(self):
+        return "LazyTensor(pending)" if self._fn is not None else f"LazyTensor({self._val!r})"
+
+
+def _unwrap(x):
+    return x.materialize() if isinstance(x, LazyTensor) else x
+
+
+def _forward_dunder(name):
+    def method(self, *args, **kwargs):
+        return getattr(self.materialize(), name)(*tree_map(_unwrap, args), **tree_map(_unwrap, kwargs))
+    method.__name__ = name
+    return method
+
+
+for _n in ("add", "sub", "mul", "truediv", "floordiv", "pow", "matmul", "mod", "and", "or", "xor", "lshift", "rshift"):
+    setattr(LazyTensor, f"__{_n}__", _forward_dunder(f"__{_n}__"))
+    setattr(LazyTensor, f"__r{_n}__", _forward_dunder(f"__r{_n}__"))
+for _n in ("neg", "pos", "abs", "invert", "lt", "le", "gt", "ge", "eq", "ne", "getitem", "setitem", "len", "iter",
+           "bool", "float", "int", "index", "contains", "format", "array"):
+    setattr(LazyTensor, f"__{_n}__", _forward_dunder(f"__{_n}__"))
+LazyTensor.__hash__ = lambda self: id(self)
+
+
+def materialize(x):
+    """The real tensor behind `x` (identity for anything that is not a LazyTensor)."""
+    return _unwrap(x)
+
+
+# ------------------------------------------------------------------------------------------------ fused TimeNet
+class _TimeNetFn(torch.autograd.Function):
+    """TimeNet on the HIP library as one autograd node.  The gradients of the network's OWN parameters are added to
+    their `.grad` by the backward kernel (FusedTimeNet.backward); control points and latents get theirs returned."""
+
+    @staticmethod
+    def forward(ctx, net, pts, latent_table, times, rows):
+        from .fused_timenet import FusedTimeNet
+        fused = FusedTimeNet(net)  # (its workspace belongs to this call: several forwards may precede one backward)
+        d_xyz, d_rot = fused.forward(pts.detach().contiguous(), times, latent_table.detach().contiguous(), rows)
+        ctx.fused, ctx.shapes = fused, (pts.shape, latent_table.shape)
+        return d_xyz, d_rot
+
+    @staticmethod
+    def backward(ctx, g_xyz, g_rot):
+        pshape, lshape = ctx.shapes
+        dev = g_xyz.device
+        g_pts = torch.zeros(pshape, dtype=torch.float32, device=dev)
+        g_lat = torch.zeros(lshape, dtype=torch.float32, device=dev)
+        ctx.fused.backward(g_xyz.contiguous(), g_rot.contiguous(), g_pts, g_lat)
+        return None, g_pts, g_lat, None, None
+
+
+def timenet_fusable(net, pts):
+    return pts.is_cuda and len(getattr(net, "skips", [0, 0])) <= 1 and pts.dtype == torch.float32
+
+
+def timenet_apply(net, pts, latent_table, times, rows=None):
+    """d_xyz [P,M,3], d_rot [P,M,4] of `net` for P (latent row, time) pairs in ONE fused launch chain, differentiable
+    w.r.t. pts, the latent table and (by side effect on .grad) the network's parameters."""
+    for p in net.parameters():  # the backward kernel ADDS to .grad: every parameter needs one
+        if p.requires_grad and p.grad is None:
+            p.grad = torch.zeros_like(p)
+    return _TimeNetFn.apply(net, pts, latent_table, [float(t) for t in times], None if rows is None else list(rows))
+
+
+# ------------------------------------------------------------------------------------------------ the batch node
+class _Ticket:
+    """Holds a batch's render slots; gives them back when the autograd graph (or a no-grad caller) lets go."""
+
+    def __init__(self, batcher, first, count):
+        self.batcher, self.first, self.count = weakref.ref(batcher), first, count
+
+    def release(self):
+        b = self.batcher()
+        if b is not None and self.count:
+            b._release(self.first, self.count)
+        self.count = 0
+
+    def __del__(self):
+        self.release()
+
+
+def _aligned_views(dev, shapes):
+    """One zero-filled allocation carved into fp32 tensors of `shapes`, every start 16-byte aligned."""
+    offs, o = [], 0
+    for s in shapes:
+        n = 1
+        for d in s:
+            n *= d
+        offs.append((o, n))
+        o += (n + 3) // 4 * 4
+    buf = torch.zeros(max(o, 4), dtype=torch.float32, device=dev)
+    return [buf[a:a + n].view(s) for (a, n), s in zip(offs, shapes)]
+
+
+class _BatchRenderFn(torch.autograd.Function):
+    """All renders of a pending batch: skinning -> projection -> binning -> blend, one launch per stage for the batch
+    (native step executor, fully batched on the caller's stream).  Inputs: the canonical Gaussians' raw parameters,
+    control points, then per DISTINCT deformation its (d_xyz, d_rot), then one screen-space gradient sink per render.
+    Outputs per render: clamped image, depth, normal (or an empty tensor), alpha -- then radii of every render."""
+
+    @staticmethod
+    def forward(ctx, job, xyz, rotation, scaling, opacity, f_dc, c_xyz, c_radius, *rest):
+        b, ex, n = job.batcher, job.batcher.ex, len(job.reqs)
+        nd = len(job.deforms)
+        deform_t, sinks = rest[:2 * nd], rest[2 * nd:]
+        dev = xyz.device
+        H, W = ex.H, ex.W
+        f32 = dict(dtype=torch.float32, device=dev)
+        raw = torch.empty(n, 3, H, W, **f32)
+        depth, alpha = torch.empty(n, 1, H, W, **f32), torch.empty(n, 1, H, W, **f32)
+        normal = torch.empty(n, 3, H, W, **f32) if b.with_normal else None
+        radii = torch.empty(n, ex.N, dtype=torch.int32, device=dev)
+        c = ex.common
+        p = _lib.ptr
+        c.stage1, c.log_r, c.g_log_r = 0, None, None
+        c.N, c.M, c.H, c.W = ex.N, ex.M, H, W
+        c.with_normal, c.local_frame, c.R_cap = int(b.with_normal), int(job.local_frame), ex.r_cap
+        keep = [t.detach().contiguous() for t in (xyz, rotation, scaling, opacity, f_dc, c_xyz, c_radius)]
+        c.xyz, c.rotation, c.scaling, c.opacity, c.f_dc, c.c_xyz, c.c_log_radius = [p(t) for t in keep]
+        c.nn_dist, c.nn_idx, c.bg = p(job.nn_dist), p(job.nn_idx), p(job.bg)
+        c.scale_modifier = float(job.scale_modifier)
+        c.lbs_scratch, c.lbs_scratch_bytes = p(ex.lbs_scratch), ex.lbs_scratch.numel()
+        c.geom_bytes, c.bin_bytes, c.img_bytes, c.bwd_scratch_bytes = ex.geom_bytes, ex.bin_bytes, ex.img_bytes, ex.bwd_bytes
+        dkeep = [t.detach().contiguous() for t in deform_t]
+        HW4 = H * W * 4
+        for i, rq in enumerate(job.reqs):
+            d = ex.descs[job.first + i]
+            cam = rq.cam
+            d.view, d.proj, d.campos = p(cam.world_view_transform), p(cam.full_proj_transform), p(cam.camera_center)
+            d.tanfovx, d.tanfovy = rq.tanfovx, rq.tanfovy
+            d.d_xyz, d.d_rot = p(dkeep[2 * rq.deform]), p(dkeep[2 * rq.deform + 1])
+            d.g_d_xyz, d.g_d_rot = None, None  # (set by the backward; equal within a deformation group either way)
+            d.out_color, d.out_depth = raw.data_ptr() + i * 3 * HW4, depth.data_ptr() + i * HW4
+            d.out_normal = (normal.data_ptr() + i * 3 * HW4) if normal is not None else None
+            d.out_alpha = alpha.data_ptr() + i * HW4
+            d.radii = radii.data_ptr() + i * ex.N * 4
+            d.g_color = d.g_depth = d.g_normal = d.g_alpha = d.g_dot = None
+        # deformation groups are found by pointer equality of (d_xyz, d_rot, g_d_xyz, g_d_rot): give the renders of one
+        # deformation the same (still unset) gradient rows NOW so that the forward groups exactly like the backward
+        job.grad_rows = _aligned_views(dev, [s for t in dkeep for s in (tuple(t.shape),)])
+        for i, rq in enumerate(job.reqs):
+            d = ex.descs[job.first + i]
+            d.g_d_xyz, d.g_d_rot = p(job.grad_rows[2 * rq.deform]), p(job.grad_rows[2 * rq.deform + 1])
+        ex.forward_range(job.first, n)
+        if b.capacity is not None:
+            for w_ in ex.total_words_range(job.first, n):
+                b.capacity.track(w_)
+        image = raw.clamp(0.0, 1.0)
+        ctx.job, ctx.keep, ctx.n = job, (keep, dkeep, raw, radii), n
+        ctx.ticket = job.ticket
+        ctx.mark_non_differentiable(radii)
+        outs = []
+        for i in range(n):
+            outs += [image[i], depth[i], normal[i] if normal is not None else raw.new_empty(0), alpha[i]]
+        return (*outs, radii)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        job, n = ctx.job, ctx.n
+        b, ex = job.batcher, job.batcher.ex
+        keep, dkeep, raw, _radii = ctx.keep
+        dev = raw.device
+        H, W = ex.H, ex.W
+        N, M = ex.N, ex.M
+        f32 = dict(dtype=torch.float32, device=dev)
+
+        def stack(k, ch):  # gradient images of output k of every render; None where autograd had none
+            gs = [grads[4 * i + k] for i in range(n)]
+            if all(g is None for g in gs):
+                return None
+            z = None
+            out = []
+            for g in gs:
+                if g is None:
+                    z = torch.zeros(ch, H, W, **f32) if z is None else z
+                    g = z
+                out.append(g)
+            return torch.stack(out).contiguous()
+
+        g_img, g_depth, g_alpha = stack(0, 3), stack(1, 1), stack(3, 1)
+        g_normal = stack(2, 3) if b.with_normal else None
+        if g_img is None:
+            g_img = torch.zeros(n, 3, H, W, **f32)
+        else:  # through the clamp of the returned image
+            g_img = g_img * ((raw >= 0.0) & (raw <= 1.0))
+        if g_alpha is None:
+            g_alpha = torch.zeros(n, 1, H, W, **f32)
+        (g_xyz, g_rot, g_scaling, g_opacity, g_fdc, g_cxyz, g_crad) = _aligned_views(
+            dev, [(N, 3), (N, 4), (N, 3), (N, 1), (N, 1, 3), (M, 3), (M, 1)])
+        for t in job.grad_rows:
+            t.zero_()
+        c = ex.common
+        p = _lib.ptr
+        c.xyz, c.rotation, c.scaling, c.opacity, c.f_dc, c.c_xyz, c.c_log_radius = [p(t) for t in keep]
+        c.nn_dist, c.nn_idx, c.bg = p(job.nn_dist), p(job.nn_idx), p(job.bg)
+        c.with_normal, c.local_frame, c.scale_modifier = int(b.with_normal), int(job.local_frame), float(job.scale_modifier)
+        c.g_xyz, c.g_rotation, c.g_scaling, c.g_opacity, c.g_f_dc = p(g_xyz), p(g_rot), p(g_scaling), p(g_opacity), p(g_fdc)
+        c.g_c_xyz, c.g_c_log_radius = p(g_cxyz), p(g_crad)
+        HW4 = H * W * 4
+        for i in range(n):
+            d = ex.descs[job.first + i]
+            d.g_color, d.g_alpha = g_img.data_ptr() + i * 3 * HW4, g_alpha.data_ptr() + i * HW4
+            d.g_depth = (g_depth.data_ptr() + i * HW4) if g_depth is not None else None
+            d.g_normal = (g_normal.data_ptr() + i * 3 * HW4) if g_normal is not None else None
+            d.g_dot = None
+        ex.backward_launch(job.first, n)
+        ex.backward_accumulate(job.first, n)
+        sink_grads = []
+        for i in range(n):  # screen-space gradients (densification statistics read them)
+            need = ctx.needs_input_grad[8 + 2 * len(job.deforms) + i]
+            sink_grads.append(ex.slots[job.first + i]["g_means2D"].clone() if need else None)
+        ctx.ticket.release()
+        return (None, g_xyz, g_rot, g_scaling, g_opacity, g_fdc, g_cxyz, g_crad, *job.grad_rows, *sink_grads)
+
+
+class _Request:
+    __slots__ = ("cam", "tanfovx", "tanfovy", "deform", "sink", "index")
+
+
+class _Job:
+    """What a flushed batch's autograd node needs (NOT its outputs: those reference the node)."""
+    __slots__ = ("batcher", "reqs", "deforms", "first", "ticket", "local_frame", "scale_modifier", "nn_dist", "nn_idx",
+                 "bg", "grad_rows")
+
+
+class RenderBatcher:
+    """Collects `Renderer.render` requests and runs them as batches on a `StepExecutor` (all on the caller's stream).
+    A request takes its render slot when it is queued (the slots of a batch are consecutive); a slot is free again
+    when its batch's backward has run or its autograd graph is gone."""
+
+    def __init__(self, renderer, slots=16):
+        self.renderer = weakref.proxy(renderer)
+        self.n_slots = slots
+        self.ex = None
+        self.in_use = []
+        self.pending = None
+        self.flushes = 0   # (diagnostics: batches run, renders in them)
+        self.rendered = 0
+
+    # ---- slots
+    def _ensure_executor(self, N, M, H, W):
+        """True if the executor fits (N, M, H, W); re-created only while none of its slots is taken."""
+        from .executor import StepExecutor
+        cap = self.capacity.next_capacity()
+        ex = self.ex
+        busy = any(self.in_use) if ex is not None else False
+        if ex is not None and (ex.N, ex.M, ex.H, ex.W) == (N, M, H, W):
+            if ex.r_cap != cap and not busy:
+                ex.resize_capacity(cap)
+            return True
+        if busy:
+            return False  # renders whose backward is still to come live in the old slots: the caller renders directly
+        if ex is not None:
+            torch.cuda.synchronize()
+            self.ex = None
+            del ex
+        self.ex = StepExecutor(N, M, H, W, self.n_slots, cap, self.renderer.device, n_streams=0)
+        self.in_use = [False] * self.n_slots
+        return True
+
+    def _release(self, first, count):
+        for j in range(first, first + count):
+            if j < len(self.in_use):
+                self.in_use[j] = False
+
+    @property
+    def capacity(self):
+        return self.renderer.capacity_policy()
+
+    @property
+    def with_normal(self):
+        return bool(self.renderer.add_normal)
+
+    # ---- requests
+    def add(self, cam, tanfovx, tanfovy, key, deform, time, latent_index, sink):
+        """Queues one render.  key = (H, W, scale_modifier, local_frame): what a batch shares.  Returns (batch record,
+        index in it), or None if no render slot is free (the caller then renders directly)."""
+        g = self.renderer.gaussians
+        pend = self.pending
+        if pend is not None and pend["key"] != key:
+            self.flush()
+            pend = None
+        if pend is None and not self._ensure_executor(g._xyz.shape[0], g._c_xyz.shape[0], key[0], key[1]):
+            return None
+        if pend is not None:
+            nxt = pend["first"] + len(pend["reqs"])
+            if nxt >= len(self.in_use) or self.in_use[nxt]:
+                self.flush()
+                pend = None
+                if not self._ensure_executor(g._xyz.shape[0], g._c_xyz.shape[0], key[0], key[1]):
+                    return None
+        if pend is None:
+            free = [i for i, used in enumerate(self.in_use) if not used]
+            if not free:
+                return None
+            # the start of the longest free run: the batch may grow there
+            best, best_len, i = free[0], 0, 0
+            while i < len(self.in_use):
+                if self.in_use[i]:
+                    i += 1
+                    continue
+                j = i
+                while j < len(self.in_use) and not self.in_use[j]:
+                    j += 1
+                if j - i > best_len:
+                    best, best_len = i, j - i
+                i = j
+            pend = self.pending = dict(key=key, first=best, reqs=[], deforms=[], deform_ids={}, lazy_pairs=[],
+                                       outputs=None)
+            nxt = best
+        self.in_use[nxt] = True
+        rq = _Request()
+        rq.cam, rq.tanfovx, rq.tanfovy, rq.sink, rq.index = cam, float(tanfovx), float(tanfovy), sink, len(pend["reqs"])
+        if deform is not None:
+            dx, dq = deform
+            k = (dx.data_ptr(), dq.data_ptr(), tuple(dx.shape))
+            if k not in pend["deform_ids"]:
+                pend["deform_ids"][k] = len(pend["deforms"])
+                pend["deforms"].append((dx, dq))
+        else:  # TimeNet is evaluated at flush time, once for the batch's distinct (latent, time) pairs
+            k = ("lazy", latent_index, float(time))
+            if k not in pend["deform_ids"]:
+                pend["deform_ids"][k] = len(pend["deforms"])
+                pend["deforms"].append(None)
+                pend["lazy_pairs"].append((len(pend["deforms"]) - 1, latent_index, float(time)))
+        rq.deform = pend["deform_ids"][k]
+        pend["reqs"].append(rq)
+        return pend, rq.index
+
+    def output(self, pend, index, name):
+        if pend["outputs"] is None:
+            self.flush(pend)
+        return pend["outputs"][index][name]
+
+    def flush(self, pend=None):
+        """Runs the pending batch (no-op if there is none or `pend` is not the pending one)."""
+        if self.pending is None or (pend is not None and pend is not self.pending):
+            return
+        pend, self.pending = self.pending, None
+        r = self.renderer
+        g = r.gaussians
+        reqs = pend["reqs"]
+        n = len(reqs)
+        _H, _W, scale_modifier, local_frame = pend["key"]
+        deforms = list(pend["deforms"])
+        if pend["lazy_pairs"]:
+            pairs = pend["lazy_pairs"]
+            if g.vae_latent:
+                table, rows = torch.stack([g.latent_code(li) for (_, li, _) in pairs]), None
+            else:
+                table, rows = g._latent_codes, [li for (_, li, _) in pairs]
+            dx, dq = timenet_apply(g._timenet, g._c_xyz, table, [t for (_, _, t) in pairs], rows)
+            for j, (slot, _, _) in enumerate(pairs):
+                deforms[slot] = (dx[j], dq[j])
+        job = _Job()
+        job.batcher, job.reqs, job.deforms = self, reqs, deforms
+        job.local_frame, job.scale_modifier = bool(local_frame), float(scale_modifier)
+        job.nn_dist, job.nn_idx, job.bg = g.neighbor_dists, g.neighbor_indices, r.bg_color
+        job.first, job.ticket = pend["first"], _Ticket(self, pend["first"], n)
+        flat = [t for dq in deforms for t in dq]
+        sinks = [rq.sink for rq in reqs]
+        outs = _BatchRenderFn.apply(job, g._xyz, g._rotation, g._scaling, g._opacity, g._features_dc, g._c_xyz,
+                                    g._c_radius, *flat, *sinks)
+        radii = outs[-1]
+        outputs, lead = [], {}
+        for i, rq in enumerate(reqs):
+            image, depth, normal, alpha = outs[4 * i:4 * i + 4]
+            # (the skinned Gaussians of a deformation group live in the slot of its first render of the launch chunk)
+            leader = lead.setdefault((i // 8, rq.deform), i)
+            outputs.append(dict(image=image, depth=depth, normal=normal if self.with_normal else None, alpha=alpha,
+                                radii=radii[i], cpts_delta=deforms[rq.deform][0], pts_slot=pend["first"] + leader))
+        pend["outputs"] = outputs
+        pend["reqs"], pend["deforms"] = None, None
+        self.flushes += 1
+        self.rendered += n
+        if not any(t.requires_grad for t in outs[:-1]):
+            job.ticket.release()  # nothing will come back for these renders: their slots are free again
+        job.ticket = None  # (the autograd node holds the only other reference)

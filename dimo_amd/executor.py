@@ -107,6 +107,11 @@ class StepExecutor:
         from .rasterizer import _total_view
         return [_total_view(self.slots[i]["geom"], self.N) for i in range(n)]
 
+    def total_words_range(self, first, n):
+        """The same for slots [first, first + n)."""
+        from .rasterizer import _total_view
+        return [_total_view(self.slots[i]["geom"], self.N) for i in range(first, first + n)]
+
     def set_common(self, g, bg, with_normal, local_frame=True, scale_modifier=1.0, stage1=False):
         """stage1: direct deformation (stage s1) -- d_xyz of a render is [N, 3], scales = exp(g._r)."""
         c = self.common

@@ -9,7 +9,12 @@ Differences that do not change results:
   * rasterizer = dimo_amd HIP kernels (both flavours; `add_normal=False` returns normal=None instead of
     the reference's NameError, latent_gs_renderer.py:1286);
   * settings tuples / tan(fov) come from a per-camera cache instead of being rebuilt per call;
-  * an optional `CapacityPolicy` makes the call free of host synchronisation.
+  * on the GPU the instance buffers are sized by a `CapacityPolicy` (no host synchronisation per render;
+    `capacity=False` restores the exact, synchronising sizing of the CUDA original);
+  * on the GPU, in the configuration DIMO trains in (stage s2, degree-0 colour, <= 1800 control points), the renders
+    of a step are BATCHED behind this call surface: `render()` returns lazy stand-ins for image / depth / normal /
+    alpha / radii and the pending renders run as one launch chain the first time one of them is used
+    (dimo_amd/batched_render.py; `batch_renders=False` switches it off).
 """
 import math
 
@@ -33,7 +38,7 @@ def _ball_points(n, radius, rng):
 class Renderer:
     def __init__(self, sh_degree=3, white_background=True, radius=1, delta_t=1 / 32, num_latent_code=1,
                  latent_code_dim=32, add_normal=False, vae_latent=False, device=None, rasterizer_factory=None,
-                 capacity=None, dist2_fn=None):
+                 capacity=None, dist2_fn=None, batch_renders=True):
         self.sh_degree = sh_degree
         self.white_background = white_background
         self.radius = radius
@@ -45,7 +50,11 @@ class Renderer:
                                      device=self.device)
         self.delta_t = delta_t
         self.add_normal = add_normal
+        # capacity: a CapacityPolicy, None (GPU: a default policy is created at the first render) or False (exact
+        # sizing from a read-back of the instance count: one stream sync per render, like the CUDA original)
         self.capacity = capacity
+        self.batch_renders = batch_renders
+        self._batcher = None
         # tests inject a CPU rasterizer here; the product default is the HIP one (no fallback)
         self._rasterizer_factory = rasterizer_factory
         self._np_rng = np.random  # the reference draws from numpy's global RNG
@@ -83,12 +92,87 @@ class Renderer:
         return torch.randn_like(std) * std + mu
 
     # ------------------------------------------------------------------ rasterizer plumbing
+    def capacity_policy(self):
+        """The CapacityPolicy of this renderer (created on first use unless `capacity=False`); None = exact sizing."""
+        if self.capacity is None and self.device.type == "cuda" and self._rasterizer_factory is None:
+            from .rasterizer import CapacityPolicy
+            self.capacity = CapacityPolicy(initial=max(1 << 20, 40 * max(1, self.gaussians._xyz.shape[0])))
+        return self.capacity or None
+
     def _make_rasterizer(self, settings):
         if self._rasterizer_factory is not None:
             return self._rasterizer_factory(settings, self.add_normal)
         from . import rasterizer as rz
         cls = rz.GaussianRasterizerNormal if self.add_normal else rz.GaussianRasterizer
-        return cls(raster_settings=settings, capacity=self.capacity)
+        return cls(raster_settings=settings, capacity=self.capacity_policy())
+
+    def _guard_capacity(self):
+        """Nobody consumes the policy's instance counts (a trainer does, once per step): look at them every 64 renders
+        so that an overflow of the instance capacity cannot pass unnoticed (one stream sync per 64 renders)."""
+        cap = self.capacity
+        if cap and len(cap._pending) >= 64 and not cap.check():
+            raise RuntimeError("a render since the last check overflowed the instance capacity and dropped tile "
+                               f"instances; the capacity is now {cap.capacity}: repeat the step")
+
+    def flush(self):
+        """Runs the renders `render()` has queued (see dimo_amd/batched_render.py).  Never needed for correctness: the
+        first use of any queued output does it."""
+        if self._batcher is not None:
+            self._batcher.flush()
+
+    def _batchable(self, stage, override_color, bg_color, xyz_detach, deform):
+        g = self.gaussians
+        if not (self.batch_renders and self.device.type == "cuda" and self._rasterizer_factory is None):
+            return False
+        if stage < "s2" or len(g._r) != 0 or override_color is not None or bg_color is not None or xyz_detach:
+            return False
+        if g._features_rest.numel() != 0 or g.neighbor_indices is None or self.capacity is False:
+            return False
+        from .deform import fused_skinning_available
+        if not fused_skinning_available(g._xyz, g._c_xyz, g.neighbor_indices) or g._c_xyz.shape[0] > 1800:
+            return False
+        if deform is None:
+            from .batched_render import timenet_fusable
+            if g.vae_latent or not timenet_fusable(g._timenet, g._c_xyz):
+                return False
+        else:
+            dx, dq = deform
+            if not (dx.is_cuda and dx.dtype == torch.float32 and dq.dtype == torch.float32):
+                return False
+        return True
+
+    def _render_batched(self, cam, scaling_modifier, local_frame, deform, time, latent_index):
+        """Queues the render (dimo_amd/batched_render.py); None if no render slot is free."""
+        from .batched_render import LazyTensor, RenderBatcher
+        g = self.gaussians
+        if self._batcher is None:
+            self._batcher = RenderBatcher(self)
+        b = self._batcher
+        tanfovx = getattr(cam, "tanfovx", None) or math.tan(cam.FoVx * 0.5)
+        tanfovy = getattr(cam, "tanfovy", None) or math.tan(cam.FoVy * 0.5)
+        sink = torch.zeros_like(g._xyz, requires_grad=True)
+        key = (int(cam.image_height), int(cam.image_width), float(scaling_modifier), bool(local_frame))
+        if deform is not None:
+            deform = (deform[0].contiguous(), deform[1].contiguous())
+        handle = b.add(cam, tanfovx, tanfovy, key, deform, time, latent_index, sink)
+        if handle is None:
+            return None
+        pend, i = handle
+        lazy = lambda name: LazyTensor(lambda: b.output(pend, i, name))
+        radii = lazy("radii")
+        if deform is not None:
+            cpts_t = g._c_xyz + deform[0]
+        else:
+            cpts_t = LazyTensor(lambda: g._c_xyz + b.output(pend, i, "cpts_delta"))
+
+        def pts_t():  # the skinned Gaussians live in a render slot (overwritten by the batch's backward)
+            return b.ex.slots[b.output(pend, i, "pts_slot")]["pts"].clone()
+
+        return {
+            "image": lazy("image"), "depth": lazy("depth"), "normal": lazy("normal") if self.add_normal else None,
+            "alpha": lazy("alpha"), "viewspace_points": sink, "visibility_filter": LazyTensor(lambda: radii > 0),
+            "radii": radii, "pts_t": LazyTensor(pts_t), "cpts_t": cpts_t,
+        }
 
     def _settings(self, cam, scaling_modifier, bg_color):
         from .rasterizer import GaussianRasterizationSettings
@@ -110,6 +194,13 @@ class Renderer:
         g = self.gaussians
         if compute_cov3D_python or convert_SHs_python:
             raise NotImplementedError("python-side covariance / SH conversion is not on DIMO's training path")
+        self._guard_capacity()
+        if self._batchable(stage, override_color, bg_color, xyz_detach, deform):
+            out = self._render_batched(viewpoint_camera, scaling_modifier, local_frame, deform, time, latent_index)
+            if out is not None:
+                return out
+        elif self._batcher is not None:
+            self._batcher.flush()  # (keeps the order of renders that share state with an unbatched one)
         # gradient sink for the screen-space means (densification statistics read .grad)
         screenspace_points = torch.zeros_like(g.get_xyz, requires_grad=True)
         settings = self._settings(viewpoint_camera, scaling_modifier, bg_color)

@@ -200,7 +200,7 @@ class Trainer:
                    (cfg.stage == "s1" and tuple(g0._r.shape) == (1, 1))
         self.direct = (direct if direct is not None else True) and self.device.type == "cuda" \
             and stage_ok and cfg.sh_degree == 0 and renderer._rasterizer_factory is None
-        if self.direct and renderer.capacity is None:
+        if self.direct and not renderer.capacity:
             from .rasterizer import CapacityPolicy
             renderer.capacity = CapacityPolicy(initial=max(1 << 20, 40 * cfg.num_pts))
 
@@ -291,10 +291,19 @@ class Trainer:
         if not pairs:
             return {}
         M = g._c_xyz.shape[0]
-        times = torch.tensor([self.source_time[p[-1]] for p in pairs], dtype=torch.float32, device=self.device)
-        times = times[:, None, None].expand(-1, M, 1)
-        lat = torch.stack([g.latent_code(p[0]) for p in pairs])[:, None, :].expand(-1, M, -1)
-        dxyz, dquat = self._timenet_batched(g._c_xyz[None], times, lat)
+        from .batched_render import timenet_apply, timenet_fusable
+        if self.device.type == "cuda" and self.fused_timenet and timenet_fusable(g._timenet, g._c_xyz):
+            # one fused forward for the step's distinct pairs, one autograd node (dimo_amd/batched_render.py)
+            tl = [self.source_time[p[-1]] for p in pairs]
+            if g.vae_latent:
+                dxyz, dquat = timenet_apply(g._timenet, g._c_xyz, torch.stack([g.latent_code(p[0]) for p in pairs]), tl)
+            else:
+                dxyz, dquat = timenet_apply(g._timenet, g._c_xyz, g._latent_codes, tl, [p[0] for p in pairs])
+        else:
+            times = torch.tensor([self.source_time[p[-1]] for p in pairs], dtype=torch.float32, device=self.device)
+            times = times[:, None, None].expand(-1, M, 1)
+            lat = torch.stack([g.latent_code(p[0]) for p in pairs])[:, None, :].expand(-1, M, -1)
+            dxyz, dquat = self._timenet_batched(g._c_xyz[None], times, lat)
         self._deform_batch = (dxyz, dquat, {(m, v, f): pairs.index(key(m, v, f)) for (m, v, f) in triples})
         out = {p: (dxyz[i], dquat[i]) for i, p in enumerate(pairs)}
         return {(m, v, f): out[key(m, v, f)] for (m, v, f) in triples}
@@ -345,16 +354,26 @@ class Trainer:
         """Loss of one motion's local images; mean-type terms carry the share len(outs)/n_img."""
         c = self.cfg
         img = torch.stack([o["image"] for o in outs])
-        gt = torch.stack(gts)
         share = len(outs) / n_img
+        depth_on, normal_on = self._reg_on()
+        alpha = torch.stack([o["alpha"] for o in outs])
+        if img.is_cuda and self.ssim.__module__ == "dimo_amd.fused_ssim" and not c.use_lpips:
+            # every image term of the motion as ONE autograd node on the fused kernels (dimo_amd/fused_losses.py)
+            from .fused_losses import motion_loss as fused_motion_loss
+            from .image_loss import loss_weights
+            B, _, H, W = img.shape
+            depth = torch.stack([o["depth"] for o in outs]) if depth_on else None
+            normal = torch.stack([o["normal"] for o in outs]) if normal_on else None
+            return fused_motion_loss(img, depth, normal, alpha, list(gts), list(masks),
+                                     [c.lambda_mse * w / (3 * H * W) for w in weights],
+                                     loss_weights(c, B, n_img, H, W, depth_on, normal_on), c.lambda_ssim * share)
+        gt = torch.stack(gts)
         w = torch.tensor(weights, dtype=img.dtype, device=img.device)
         per_img_mse = ((img - gt) ** 2).mean(dim=(1, 2, 3))
         loss = c.lambda_mse * (w * per_img_mse).sum()
         loss = loss + c.lambda_ssim * share * (1 - self.ssim(img, gt))
-        alpha = torch.stack([o["alpha"] for o in outs])
         loss = loss + c.lambda_mask * share * ((alpha - torch.stack(masks)) ** 2).mean()
         img_hwc = img.permute(0, 2, 3, 1)
-        depth_on, normal_on = self._reg_on()
         if depth_on:
             depth = torch.stack([o["depth"] for o in outs]).permute(0, 2, 3, 1)
             loss = loss + c.lambda_smooth * share * compute_edge_aware_smoothness_loss(depth, img_hwc)
@@ -787,7 +806,7 @@ class Trainer:
     def train_step(self, triples=None):
         """Runs one optimisation step; returns the number of renders THIS rank performed."""
         g = self.renderer.gaussians
-        cap = self.renderer.capacity
+        cap = self.renderer.capacity_policy()
         c = self.cfg
         if self._flat_adam and cap is not None:
             bad = cap.poll()  # last step's instance counts (copied asynchronously)
