@@ -40,6 +40,8 @@ _SIGNATURES = {
     "dimo_knn": (C.c_int, [C.c_int, C.c_int, C.c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     "dimo_knn_seeded": (C.c_int, [C.c_int, C.c_int, C.c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     "dimo_dist2": (C.c_int, [C.c_int, c_ptr, c_ptr, c_ptr]),
+    "dimo_dist2_workspace_bytes": (C.c_size_t, [C.c_int]),
+    "dimo_dist2_grid": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "dimo_deform_max_ctrl_points": (C.c_int, []),
     "dimo_deform_backward_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "dimo_deform_forward": (C.c_int, [C.c_int] * 3 + [c_ptr] * 15),

@@ -86,7 +86,7 @@ using namespace dimo;
 static std::vector<hipStream_t> &stream_pool() {
   static std::vector<hipStream_t> pool[64];
   int dev = 0;
-  (void)hipGetDevice(&dev);
+  (void)hipGetDevice(&dev);  // (the caller has made the device that owns its buffers current: torch.cuda.set_device)
   return pool[dev >= 0 && dev < 64 ? dev : 0];
 }
 
@@ -127,10 +127,12 @@ extern "C" void *dimo_executor_create(int n_streams) {
 extern "C" void dimo_executor_destroy(void *h) {
   Executor *ex = reinterpret_cast<Executor *>(h);
   if (!ex) return;
-  for (auto s : ex->streams) (void)hipStreamSynchronize(s);  // (the streams stay in the process-wide pool)
-  for (auto e : ex->stream_done) (void)hipEventDestroy(e);
-  for (auto e : ex->render_done) (void)hipEventDestroy(e);
-  for (auto e : ex->fwd_done) (void)hipEventDestroy(e);
+  // The private streams stay in the process-wide pool and may be carrying another live executor's work: wait for THIS
+  // executor's own events (what it last recorded on them), not for the streams.  (An event that was never recorded
+  // reports complete.)
+  for (auto e : ex->stream_done) (void)hipEventSynchronize(e), (void)hipEventDestroy(e);
+  for (auto e : ex->render_done) (void)hipEventSynchronize(e), (void)hipEventDestroy(e);
+  for (auto e : ex->fwd_done) (void)hipEventSynchronize(e), (void)hipEventDestroy(e);
   if (ex->main_ready) (void)hipEventDestroy(ex->main_ready);
   delete ex;
 }

@@ -75,12 +75,18 @@ class StepExecutor:
                       "g_means2D", "g_shs", "g_opac", "g_scales", "g_rot"):
                 setattr(d, k, s[k].data_ptr())
 
+    def destroy(self):
+        """Releases the native executor (its events; the private streams belong to a per-device pool).  The caller
+        makes sure the device has finished with the slots' buffers (`Trainer._executor` synchronises first)."""
+        if getattr(self, "handle", None):
+            self.L.dimo_executor_destroy(self.handle)
+            self.handle = None
+
     def __del__(self):
         try:
             if getattr(self, "handle", None):
                 torch.cuda.synchronize()
-                self.L.dimo_executor_destroy(self.handle)
-                self.handle = None
+                self.destroy()
         except Exception:
             pass
 

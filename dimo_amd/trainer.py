@@ -98,6 +98,10 @@ class TrainConfig:
     densify_opacity_threshold_s2: float = 0.01
     init_type: str = "ag"
     FPS_iter: int = 1000  # stage s1: farthest-point down-sampling to num_cpts every FPS_iter steps
+    # exactly the reference's schedule: render at 128 / 256 / 512 WHATEVER the targets' size and resample the targets
+    # (main_train_dimo.py:261-313).  Default off: a run configured with smaller targets (the tests, the CPU oracle)
+    # keeps rendering at most at the targets' size -- identical for the reference's own ref_size = 512 configuration
+    progressive_upsample: bool = False
     # MI355X layout (no reference counterpart): keep the canonical Gaussians in Morton order (densify.py)
     spatial_sort: bool = True
     # regularisers (configs/train_config.yaml:57-65).  Off by default: BASELINE.json's metric is quoted without them
@@ -245,7 +249,8 @@ class Trainer:
         c = self.cfg
         if not c.progressive_resolution:
             return c.resolution
-        return min(c.resolution, 128 if self.step < 300 else (256 if self.step < 450 else 512))
+        r = 128 if self.step < 300 else (256 if self.step < 450 else 512)
+        return r if c.progressive_upsample else min(c.resolution, r)
 
     def target(self, m, v, f):
         """(image [3, r, r], mask [1, r, r]) of a triple at the step's render size (bilinear, align_corners=False:
@@ -538,6 +543,10 @@ class Trainer:
         if self._exec is None or self._exec.max_renders < n_renders or self._exec.N != g._xyz.shape[0] \
                 or self._exec.H != res:
             import os
+            if self._exec is not None:  # explicitly, before the new one takes the pool's streams (not at some later GC)
+                torch.cuda.synchronize()
+                self._exec.destroy()
+                self._exec = None
             self._exec = StepExecutor(g._xyz.shape[0], g._c_xyz.shape[0], res, res,
                                       max(n_renders, 8), cap, self.device,
                                       # 0 = batched: every stage is one launch over all renders of the step.
@@ -844,6 +853,8 @@ class Trainer:
             # no host sync at all: the overflow words of this step's renders become a device-side skip flag that
             # travels through the all-reduce; the host looks at them one step later (CapacityPolicy.poll)
             tot = cap.collect_async() if cap is not None else None
+            # (device scalar, no read-back: a step whose renders overflowed must not feed the densification statistics)
+            self._step_overflow = tot[:, 1].max() if tot is not None else None
             if self.world > 1:  # the flag rides in the tail of the gradient bucket through the all-reduce
                 if tot is not None:
                     g.grad_flag.copy_(tot[:, 1].max().to(torch.float32))
@@ -885,6 +896,9 @@ class Trainer:
         if last is not None and self.rank == getattr(self, "_stats_owner", 0):
             r, g2d = last  # radii [N] int32, gradient of the screen-space means [N, 3]
             vis = r > 0
+            ovf = getattr(self, "_step_overflow", None)
+            if ovf is not None:  # the update of an overflowed step is skipped on the device: so are its statistics
+                vis = vis & (ovf == 0)
             stats[vis, 0] = torch.norm(g2d[vis, :2], dim=-1)
             stats[vis, 1] = 1.0
             radii[vis] = r[vis].to(radii.dtype)

@@ -157,6 +157,10 @@ int dimo_knn_seeded(int M, int N, int k, const float *ref, const float *query, f
 
 /* dimo_dist2: mean squared distance of each point to its 3 nearest other points. points[N,3] out[N]. */
 int dimo_dist2(int N, const float *points, float *out, void *stream);
+/* The same result (bit for bit) on a uniform grid, O(N) for reasonably spread points (the brute-force call is O(N^2):
+ * 5 ms at 1e5 points, 0.5 s at 1e6).  workspace: dimo_dist2_workspace_bytes(N) bytes of device memory. */
+size_t dimo_dist2_workspace_bytes(int N);
+int dimo_dist2_grid(int N, const float *points, float *out, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------ fused SSIM (11x11, sigma 1.5, zero padding)
  * img1,img2 [B,C,H,W]; ssim_sum: one float accumulator (zeroed by the call) receiving the SUM of the

@@ -70,6 +70,42 @@ def test_dist2_bit_exact(N):
     assert np.array_equal(out.view(np.uint32), ro.dist2(pts).view(np.uint32))
 
 
+@pytest.mark.parametrize("case", ["ball", "clusters", "plane", "line", "duplicates", "outlier"])
+def test_dist2_grid_equals_brute_force_bit_for_bit(case):
+    """dimo_dist2_grid (uniform grid, O(N): renderer/latent_gs_renderer.py:426 at the 1e5-1e6 points of a real
+    initialisation) against the brute-force dimo_dist2 (itself bit-exact against the oracle above) on layouts that
+    stress the grid: empty cells, a degenerate bounding box, many points per cell, one far point stretching the box."""
+    import ctypes as C
+    from dimo_amd import _lib
+    rng = np.random.default_rng(11)
+    N = 60000
+    if case == "ball":
+        pts = rng.standard_normal((N, 3)) * 0.3
+    elif case == "clusters":
+        pts = rng.standard_normal((N, 3)) * 0.01 + rng.integers(0, 5, (N, 3)) * 1.0
+    elif case == "plane":
+        pts = rng.random((N, 3))
+        pts[:, 2] = 0.25
+    elif case == "line":
+        pts = np.zeros((N, 3))
+        pts[:, 0] = rng.random(N)
+    elif case == "duplicates":
+        pts = np.repeat(rng.random((N // 6, 3)), 6, axis=0)
+    else:
+        pts = rng.random((N, 3))
+        pts[17] = (1.0e4, -3.0e3, 50.0)
+    pts = torch.tensor(np.ascontiguousarray(pts, np.float32)).cuda()
+    n = pts.shape[0]
+    L = _lib.lib()
+    brute, grid = torch.empty(n, device="cuda"), torch.empty(n, device="cuda")
+    _lib.check(L.dimo_dist2(n, _lib.ptr(pts), _lib.ptr(brute), _lib.current_stream()), "dimo_dist2")
+    ws = torch.empty(L.dimo_dist2_workspace_bytes(n), dtype=torch.uint8, device="cuda")
+    _lib.check(L.dimo_dist2_grid(n, _lib.ptr(pts), _lib.ptr(grid), _lib.ptr(ws), ws.numel(), _lib.current_stream()),
+               "dimo_dist2_grid")
+    assert torch.equal(brute.view(torch.int32), grid.view(torch.int32))
+    assert L.dimo_dist2_grid(n, _lib.ptr(pts), _lib.ptr(grid), _lib.ptr(ws), 16, _lib.current_stream()) == -3  # workspace
+
+
 def test_ssim_matches_reference_fixture():
     from dimo_amd.fused_ssim import fused_ssim
     z = np.load(os.path.join(GOLD, "image_losses.npz"))
