@@ -67,6 +67,7 @@ struct Executor {
   std::vector<int> range_count;   // ... and its number of renders
   int next_stream = 0;
   hipEvent_t main_ready = nullptr;
+  bool bwd_on_main = false;  // the last rasterizer backward ran on the caller's stream (joint launch): no event to wait for
 };
 
 __global__ void __launch_bounds__(256) accumulate_kernel(size_t n, float *__restrict__ dst,
@@ -305,6 +306,7 @@ extern "C" int dimo_executor_backward_launch(void *h, const dimo_step_common *c,
   const int S = (int)ex->streams.size();
   if (ex->batched && S == 0) return batched_backward_raster(c, d, first, count, main);
   if (first + count > (int)ex->render_done.size()) return DIMO_E_ARG;
+  ex->bwd_on_main = false;
   if (ex->batched) {
     const int si = ex->range_stream[first] >= 0 ? ex->range_stream[first] : 0;
     hipStream_t s = ex->streams[si];
@@ -348,6 +350,7 @@ extern "C" int dimo_executor_backward_launch_in_order(void *h, const dimo_step_c
   const int si = ex->range_stream[first];
   if (si < 0) return DIMO_E_ARG;
   clear_errors();
+  ex->bwd_on_main = false;
   hipStream_t s = ex->streams[si];
   const int rc = batched_backward_raster(c, d, first, count, s);
   if (rc) return rc;
@@ -379,8 +382,8 @@ extern "C" int dimo_executor_backward_launch_joint(void *h, const dimo_step_comm
     const int rc = batched_backward_raster(c, d, ch.first, ch.second, main);
     if (rc) return rc;
   }
-  for (int i = first; i < first + count; ++i)
-    if (ex->range_stream[i] >= 0 && hipEventRecord(ex->render_done[i], main) != hipSuccess) return DIMO_E_LAUNCH;
+  ex->bwd_on_main = true;  // (dimo_executor_backward_accumulate on the same stream follows in order: a wait on an event
+                           // recorded on that very stream cost a 10 us bubble between the two calls' kernels)
   return DIMO_OK;
 }
 
@@ -396,7 +399,7 @@ extern "C" int dimo_executor_backward_accumulate(void *h, const dimo_step_common
   if (ex->batched) {
     if (!ex->streams.empty()) {
       if (first + count > (int)ex->render_done.size()) return DIMO_E_ARG;
-      if (hipStreamWaitEvent(main, ex->render_done[first], 0) != hipSuccess) return DIMO_E_LAUNCH;
+      if (!ex->bwd_on_main && hipStreamWaitEvent(main, ex->render_done[first], 0) != hipSuccess) return DIMO_E_LAUNCH;
     }
     std::vector<std::pair<int, int>> chunks;
     if (!plan_chunks(ex, first, count, chunks)) return DIMO_E_ARG;

@@ -309,8 +309,17 @@ __device__ __forceinline__ void preprocess_bwd_body(
     float *__restrict__ dL_dmeans3D, float *__restrict__ dL_dmeans2D, float *__restrict__ dL_dshs,
     float *__restrict__ dL_dcolors, float *__restrict__ dL_dopacity, float *__restrict__ dL_dscales,
     float *__restrict__ dL_drot, float *__restrict__ dL_dcov3D) {
-  const int i = blockIdx.x * PRE_BLOCK + threadIdx.x;
-  if (i >= N) return;
+  // A Gaussian with MANY instances (a splat blown up over hundreds of tiles: random targets produce them within a
+  // few hundred steps) would keep its thread in the gather loop long after the rest of the chip has finished --
+  // the kernel went from 80 to 230 us per 8 renders over a 1400-step run.  Such Gaussians are summed by a whole WAVE
+  // (lanes stride over the records, butterfly reduction) before the per-thread part; everything else is unchanged.
+  constexpr uint32_t BIG = 64;  // instances above which the wave takes over
+  __shared__ uint32_t s_big_n;
+  __shared__ uint32_t s_big_lo[PRE_BLOCK], s_big_hi[PRE_BLOCK];
+  __shared__ float s_big_sum[PRE_BLOCK][13];
+  const int i_raw = blockIdx.x * PRE_BLOCK + threadIdx.x;
+  const bool valid = i_raw < N;
+  const int i = valid ? i_raw : (N > 0 ? N - 1 : 0);
   float V[16], P[16], cam[3];
 #pragma unroll
   for (int k = 0; k < 16; ++k) V[k] = Vg[k], P[k] = Pg[k];
@@ -319,22 +328,62 @@ __device__ __forceinline__ void preprocess_bwd_body(
   float dmean[3] = {0, 0, 0}, dm2d[2] = {0, 0}, dop = 0.0f;
   float dsc[3] = {0, 0, 0}, dq[4] = {0, 0, 0, 0}, dSig[6] = {0, 0, 0, 0, 0, 0};
   float dfeat[NFEAT] = {0, 0, 0, 0, 0, 0, 0};
-  const bool visible = radii[i] > 0;
+  const bool visible = valid && N > 0 && radii[i] > 0;
   // the Gaussian's own inputs are requested before the gather loop (they are only needed after it)
-  uint32_t lo = offsets[i == 0 ? 0 : i - 1], hi = offsets[i];
-  const Splat sp = splat[i];
-  const float p[3] = {means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2]};
+  uint32_t lo = N > 0 ? offsets[i == 0 ? 0 : i - 1] : 0u, hi = N > 0 ? offsets[i] : 0u;
+  const Splat sp = N > 0 ? splat[i] : Splat{};
+  const float p[3] = {N > 0 ? means3D[3 * i] : 0.f, N > 0 ? means3D[3 * i + 1] : 0.f, N > 0 ? means3D[3 * i + 2] : 0.f};
   float q[4] = {1, 0, 0, 0}, s[3] = {0, 0, 0};
-  if (!cov3D_precomp) {  // (kernel-uniform)
+  if (!cov3D_precomp && N > 0) {  // (kernel-uniform)
     q[0] = rotations[4 * i], q[1] = rotations[4 * i + 1], q[2] = rotations[4 * i + 2], q[3] = rotations[4 * i + 3];
     s[0] = scales[3 * i], s[1] = scales[3 * i + 1], s[2] = scales[3 * i + 2];
   }
+  lo = i == 0 ? 0u : lo;
+  lo = min(lo, R_cap), hi = min(hi, R_cap);
+  if (threadIdx.x == 0) s_big_n = 0u;
+  __syncthreads();
+  const bool big = visible && hi > lo && hi - lo > BIG;
+  uint32_t big_slot = 0;
+  if (big) {
+    big_slot = atomicAdd(&s_big_n, 1u);
+    s_big_lo[big_slot] = lo, s_big_hi[big_slot] = hi;
+  }
+  __syncthreads();
+  {
+    const uint32_t n_big = s_big_n;  // (workgroup-uniform)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (uint32_t b = (uint32_t)wave; b < n_big; b += PRE_BLOCK / 64) {
+      const uint32_t blo = s_big_lo[b], bhi = s_big_hi[b];
+      float a[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+      for (uint32_t e = blo + (uint32_t)lane; e < bhi; e += 64) {
+        if (inst_flag[e]) {
+          const float4 *rp = reinterpret_cast<const float4 *>(inst_grad + e);
+          const float4 ra = rp[0], rb = rp[1], rc = rp[2], rd = rp[3];
+          a[0] += ra.x, a[1] += ra.y, a[2] += ra.z, a[3] += ra.w, a[4] += rb.x, a[5] += rb.y, a[6] += rb.z;
+          a[7] += rb.w, a[8] += rc.x, a[9] += rc.y, a[10] += rc.z, a[11] += rc.w, a[12] += rd.x;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 13; ++k) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) a[k] += __shfl_xor(a[k], o, 64);
+        if (lane == 0) s_big_sum[b][k] = a[k];
+      }
+    }
+  }
+  __syncthreads();
+  if (!valid) return;
 
   if (visible) {
     // ---- gather the instance records
     float m0 = 0, mx = 0, my = 0, mxx = 0, mxy = 0, myy = 0;
-    lo = i == 0 ? 0u : lo;
-    lo = min(lo, R_cap), hi = min(hi, R_cap);
+    if (big) {
+      const float *a = s_big_sum[big_slot];
+      m0 = a[0], mx = a[1], my = a[2], mxx = a[3], mxy = a[4], myy = a[5];
+#pragma unroll
+      for (int k = 0; k < NFEAT; ++k) dfeat[k] = a[6 + k];
+      lo = hi;  // (nothing left for the loop below)
+    }
     // Eight instances per round, every load of the round issued before the first use: the flags first, then the four
     // float4s of each record -- from the record when its flag is set (an instance no pixel reached has no record),
     // from ONE dummy line otherwise (a cache hit; an unconditional clamped load instead of a branch around it).
