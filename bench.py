@@ -137,6 +137,70 @@ def cpu_baseline(num_pts, resolution, renders=20):
                       f"(forward OpenMP over {cores} threads, backward single-threaded); {dt:.1f} s"}
 
 
+def live_pmc(timeout=180):
+    """HBM traffic and VALU occupancy of the dominant kernel from rocprofv3 PMC counters, collected DURING this run in
+    child processes: three passes over tools/pmc_probe.py (the same C3 workload), one counter set each, never combined
+    with a trace -- FETCH_SIZE, WRITE_SIZE (corrected with the in-run calibration on a 1 GiB copy, as
+    MI355X_MICROARCH.md's HBM section prescribes: FETCH_SIZE reads half of a wide streaming read on gfx950) and one SQ
+    set.  Returns (dict or None, note)."""
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if any("ROCPROF" in k or k.startswith("ROCP_") for k in os.environ):
+        return None, "not collected: this run is itself under rocprofv3"
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "not collected: rocprofv3 not found"
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from pmc_summarise import per_kernel
+    tmp = tempfile.mkdtemp(prefix="dimo_pmc_", dir="/tmp")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["TMPDIR"] = "/tmp"
+    sets = {"fetch": "FETCH_SIZE", "write": "WRITE_SIZE",
+            "sq": "SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"}
+    files = {}
+    try:
+        for name, ctrs in sets.items():
+            d = os.path.join(tmp, name)
+            cmd = [exe, "--pmc", *ctrs.split(), "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable,
+                   os.path.join(ROOT, "tools", "pmc_probe.py"), "--steps", "3"] + (["--no-calibration"] if name == "sq" else [])
+            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout)
+            hits = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if not hits:
+                return None, f"not collected: the {name} pass left no counter file"
+            files[name] = hits[0]
+        pat = "blend_bwd_batched_kernel"
+        find = lambda dct: next((v for k, v in dct.items() if pat in k), [])
+        mean = lambda xs: sum(xs) / len(xs) if xs else None
+        fetch, write = per_kernel(files["fetch"], "FETCH_SIZE"), per_kernel(files["write"], "WRITE_SIZE")
+        big = lambda dct: [v for k, vs in dct.items() if "__amd_rocclr_copyBuffer" in k for v in vs if v > 100000.0]
+        cal_f, cal_w = mean(big(fetch)), mean(big(write))
+        kf = (float(1 << 20) / cal_f) if cal_f else 2.0
+        kw = (float(1 << 20) / cal_w) if cal_w else 1.0
+        fk, wk = mean(find(fetch)), mean(find(write))
+        if fk is None or wk is None:
+            return None, "not collected: the kernel is not in the counter files"
+        out = {"hbm_bytes_per_launch": (fk * kf + wk * kw) * 1024.0, "renders_per_launch": 8.0,
+               "fetch_factor": kf, "write_factor": kw, "launches": len(find(fetch))}
+        sq = {c: mean(find(per_kernel(files["sq"], c))) for c in sets["sq"].split()}
+        g = (sq.get("GRBM_GUI_ACTIVE") or 0.0) / 8.0  # (summed over the 8 XCDs)
+        if g and sq.get("SQ_WAVE_CYCLES"):
+            out["valu"] = {"valu_busy_at_4_cycles_per_inst": 4.0 * sq["SQ_ACTIVE_INST_VALU"] / (1024.0 * g),
+                           "valu_busy_at_2_cycles_per_inst": 2.0 * sq["SQ_INSTS_VALU"] / (1024.0 * g),
+                           "waves_per_simd": 4.0 * sq["SQ_WAVE_CYCLES"] / (1024.0 * g),
+                           "valu_insts_per_wave": sq["SQ_INSTS_VALU"] / max(sq["SQ_WAVES"], 1.0),
+                           "wave_wait_any": sq["SQ_WAIT_ANY"] / sq["SQ_WAVE_CYCLES"],
+                           "source": "rocprofv3 --pmc SQ pass of tools/pmc_probe.py, collected during this run"}
+        return out, ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes over tools/pmc_probe.py = this workload, "
+                     "child processes of THIS run, after the timed region), FETCH_SIZE x %.3f / WRITE_SIZE x %.3f from "
+                     "the in-run 1 GiB copy calibration; %d launches of 8 renders" % (kf, kw, out["launches"]))
+    except Exception as e:  # the counters must never take the throughput number down with them
+        return None, f"not collected: {e!r}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def self_launch(n):
     """Re-executes this script as n ranks under torch.distributed.run (127.0.0.1, a free port); returns its exit code."""
     import socket
@@ -167,6 +231,8 @@ def main():
     ap.add_argument("--per-gpu", default="2,2,2", help="weak scaling: motions,views,frames per GPU and step")
     ap.add_argument("--sustained-steps", type=int, default=1200,
                     help="consecutive steps of the `sustained` figure (0: skip); they cross a stage-s2 prune")
+    ap.add_argument("--no-live-pmc", action="store_true",
+                    help="take roofline.traffic / roofline.valu from profiles/ instead of collecting them during the run")
     ap.add_argument("--sync-exact", action="store_true", help="size sort buffers by reading R back (one sync per render)")
     args = ap.parse_args()
 
@@ -372,8 +438,15 @@ def main():
                         "separate run of tools/pmc_probe.py)"}
             except Exception:
                 valu = None
+        traffic_source = None
+        c3_default = (args.num_pts, args.resolution, args.per_gpu, args.global_batch) == (100000, 512, "2,2,2", 0)
+        if world == 1 and c3_default and not args.no_live_pmc:
+            live, traffic_source = live_pmc()
+            if live is not None:
+                traffic = live["hbm_bytes_per_launch"] * rpl / live["renders_per_launch"]
+                valu = live.get("valu", valu)
         pmc = os.path.join(ROOT, "profiles", "pmc_blend_bwd.json")
-        if os.path.exists(pmc):
+        if traffic is None and os.path.exists(pmc):
             try:
                 pj = json.load(open(pmc))
                 traffic = pj.get("hbm_bytes_per_launch")
@@ -417,9 +490,12 @@ def main():
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "renders_per_launch": rpl,
                          "avg_ms": bwd_ms / max(bwd_n, 1), "launches": bwd_n,
-                         "traffic_source": "profiles/pmc_blend_bwd.json: FETCH_SIZE / WRITE_SIZE of separate rocprofv3 "
-                                           "--pmc passes over tools/pmc_probe.py, calibrated on a 1 GiB copy; scaled to "
-                                           "this run's renders per launch" if traffic is not None else None,
+                         "traffic_source": (traffic_source if (traffic_source and not traffic_source.startswith("not"))
+                                            else ((traffic_source + "; " if traffic_source else "") +
+                                                  "profiles/pmc_blend_bwd.json: FETCH_SIZE / WRITE_SIZE of separate "
+                                                  "rocprofv3 --pmc passes over tools/pmc_probe.py in an earlier run, "
+                                                  "calibrated on a 1 GiB copy; scaled to this run's renders per launch"
+                                                  if traffic is not None else traffic_source)),
                          "valu": valu,
                          "isolated": {"avg_ms": iso_ms / max(iso_n, 1), "launches": iso_n, "renders_per_launch": 1,
                                       "achieved": alg_render / (iso_ms / max(iso_n, 1) * 1e-3) / 1e9 if iso_ms else None,

@@ -20,7 +20,7 @@ def _run(cmd):
     return json.loads(lines[0])
 
 
-SMALL = ["--steps", "4", "--warmup", "3", "--num-pts", "20000", "--resolution", "128", "--no-cpu-baseline"]
+SMALL = ["--steps", "4", "--warmup", "3", "--num-pts", "20000", "--resolution", "128", "--no-cpu-baseline", "--no-live-pmc"]
 
 
 @pytest.mark.timeout(1200)
