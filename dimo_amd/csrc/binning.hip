@@ -152,9 +152,9 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // Gaussians are Morton neighbours, so most of its entries share a handful of buckets -- one LDS atomic per entry was
 // a 64-way same-address conflict per instruction.  Lane `lane` has `cnt` entries:
 // supertiles (sx0 + e % nx, sy0 + e / nx), depth bin db.  f(bucket, lanes of the group, leader lane, this lane is in it).
-template <class F>
+template <class F, class G>
 __device__ __forceinline__ void for_each_group(bool has, const uint2 rc, uint32_t db, const BinGrid &gi, int lg, int lane,
-                                               F f) {
+                                               F f, G direct) {
   const int x0 = rc.x & 0xffff, y0 = rc.x >> 16, x1 = rc.y & 0xffff, y1 = rc.y >> 16;
   const int sx0 = x0 >> gi.ss_shift, sy0 = y0 >> gi.ss_shift;
   const int nx = has ? ((x1 - 1) >> gi.ss_shift) - sx0 + 1 : 0, ny = has ? ((y1 - 1) >> gi.ss_shift) - sy0 + 1 : 0;
@@ -164,7 +164,9 @@ __device__ __forceinline__ void for_each_group(bool has, const uint2 rc, uint32_
     u64 todo = __ballot(on);
     if (todo == 0) break;
     const uint32_t bucket = ((uint32_t)((sy0 + cy) * gi.stx + sx0 + cx) << lg) + db;
-    while (todo) {
+    // up to four groups by their leaders; a wave whose lanes name many buckets (Gaussians in no spatial order: a model
+    // that was never Morton-sorted) has no conflicts to avoid -- its remaining lanes go one by one
+    for (int round = 0; round < 4 && todo; ++round) {
       const int leader = __ffsll((long long)todo) - 1;
       const uint32_t bl = (uint32_t)__builtin_amdgcn_readlane((int)bucket, leader);
       const bool mine = on && bucket == bl;
@@ -172,6 +174,7 @@ __device__ __forceinline__ void for_each_group(bool has, const uint2 rc, uint32_
       f(bl, m, leader, mine);
       todo &= ~m;
     }
+    if (todo) direct(bucket, (todo >> lane) & 1ull);
     if (++cx >= nx) cx = 0, ++cy;
   }
 }
@@ -299,6 +302,9 @@ __device__ __forceinline__ void level1_count_body(const BinArgs &a, void *geom, 
     for_each_group(v0 != 0u && !big, r0, depth_bin(k0, lo, shift, nbins), a.gi, a.lg, lane,
                    [&](uint32_t bl, u64 m, int leader, bool) {
                      if (lane == leader) atomicAdd(&s_hist[bl], (uint32_t)__popcll(m));
+                   },
+                   [&](uint32_t bucket, bool mine) {
+                     if (mine) atomicAdd(&s_hist[bucket], 1u);
                    });
     lds_barrier();
     for_each_big(s_bigi, s_bign, rect, key32, lo, shift, nbins, a.gi, a.lg,
@@ -458,6 +464,12 @@ __device__ __forceinline__ void level1_scatter_body(const BinArgs &a, void *geom
                      first = (uint32_t)__builtin_amdgcn_readlane((int)first, leader);
                      const size_t pos = (size_t)first + (uint32_t)__popcll(m & lt);
                      if (mine && pos < a.l1cap) l1tmp[pos] = en;
+                   },
+                   [&](uint32_t bucket, bool mine) {
+                     if (mine) {
+                       const size_t pos = atomicAdd(&s_cur[bucket], 1u);
+                       if (pos < a.l1cap) l1tmp[pos] = en;
+                     }
                    });
     lds_barrier();
     for_each_big(s_bigi, s_bign, rect, key32, lo, shift, (uint32_t)nbins, a.gi, a.lg,
@@ -986,6 +998,10 @@ static bool make_args(int N, int H, int W, int64_t R_cap, int n_renders, const G
   // level-1 workgroups walk `per` preprocess blocks each: their fixed work (reducing the per-block words, the bucket
   // tables) is per workgroup, and the kernels are instruction bound -- about 1024 workgroups per launch
   int per = (int)(((size_t)G.nb * (size_t)(n_renders > 0 ? n_renders : 1) + 1023) / 1024);
+  // ... and at most ~128 workgroups per render: every workgroup adds to each bucket it touches with one returning
+  // atomic, and the workgroups of a model that was never Morton-sorted touch nearly all of them (391 workgroups x 400
+  // buckets on 512 words: 50 us of serialised atomics for one render)
+  if (per < (G.nb + 127) / 128) per = (G.nb + 127) / 128;
   if (per < G.per) per = G.per;
   if (per > 8) per = 8 > G.per ? 8 : G.per;
   a.N = N, a.nb = G.nb, a.per = per, a.nwg1 = (G.nb + per - 1) / per, a.lg = depth_bins_log2(N, a.gi.NS), a.T = B.T;

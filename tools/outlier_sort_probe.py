@@ -1,4 +1,4 @@
-"""Depth-sort cost when a few far outliers stretch the key range (the coarse bins of the main cluster overflow):
+"""Level-1 binning cost (count + scatter + bucket sort) when a few far outliers stretch the key range:
     python tools/outlier_sort_probe.py"""
 import os, sys
 sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '/root/repo'))
@@ -20,6 +20,10 @@ for far in (0.0, 30.0, 1000.0, 1e5, -1.0):
     L.dimo_timing_select(None); L.dimo_timing_enable(1)
     for _ in range(5): _run_hip(sc, cam, (0, 0, 0), 0)
     torch.cuda.synchronize(); L.dimo_timing_enable(0)
-    ms, n = C.c_double(0), C.c_int64(0)
-    L.dimo_timing_read(b"sort", C.byref(ms), C.byref(n))
-    print("outliers at +%g: depth sort %.1f us per render" % (far, 1e3 * ms.value / max(n.value, 1)))
+    tot = {}
+    for name in (b"scan", b"emit", b"sort"):
+        ms, n = C.c_double(0), C.c_int64(0)
+        L.dimo_timing_read(name, C.byref(ms), C.byref(n))
+        tot[name.decode()] = 1e3 * ms.value / max(n.value, 1)
+    print("outliers at +%g: level-1 count %.1f + scatter %.1f + bucket sort %.1f = %.1f us per render"
+          % (far, tot["scan"], tot["emit"], tot["sort"], sum(tot.values())))
