@@ -362,7 +362,7 @@ def main():
             tr.renderer.capacity = p2
             with torch.no_grad():
                 tr.renderer.render(cam, time=tr.source_time[3], stage="s2", latent_index=0)
-            tot = torch.stack(p2._pending).cpu()
+            tot = torch.cat(p2._pending).cpu()
             R = int(tot[:, 0].max())
         # the same kernel alone on the device (the timed region overlaps 3-4 renders, which stretches each
         # individual launch): 5 isolated fwd+bwd renders on one stream, outside the timed region

@@ -195,8 +195,7 @@ class _BatchRenderFn(torch.autograd.Function):
             d.g_d_xyz, d.g_d_rot = p(job.grad_rows[2 * rq.deform]), p(job.grad_rows[2 * rq.deform + 1])
         ex.forward_range(job.first, n)
         if b.capacity is not None:
-            for w_ in ex.total_words_range(job.first, n):
-                b.capacity.track(w_)
+            b.capacity.track(ex.total_words_range(job.first, n))
         image = raw.clamp(0.0, 1.0)
         ctx.job, ctx.keep, ctx.n = job, (keep, dkeep, raw, radii), n
         ctx.ticket = job.ticket

@@ -801,7 +801,8 @@ struct L2Shared {  // (declared once in level2_dispatch: the four supertile-edge
 };
 template <bool FILL, int SSH>
 __device__ __forceinline__ void level2_body(const BinArgs &a, void *geom, void *bin, uint8_t *__restrict__ grad_flags,
-                                            L2Shared &sh, uint32_t *s_ts /* fill: first slot of every tile (T <= TS_LDS) */) {
+                                            uint32_t *__restrict__ totals_out, L2Shared &sh,
+                                            uint32_t *s_ts /* fill: first slot of every tile (T <= TS_LDS) */) {
   constexpr int ss = 1 << SSH, ntile = ss * ss;
   uint32_t (&s_c)[SEG / 64][64] = sh.c;
   uint32_t (&s_tsw)[64] = sh.tsw;
@@ -854,15 +855,19 @@ __device__ __forceinline__ void level2_body(const BinArgs &a, void *geom, void *
       uint32_t *bk = at<uint32_t>(geom, a.g_bk);
       for (int t = tid; t < MAX_BUCKETS; t += SEG) bk[BK_TOT + t] = 0u;
       uint32_t run = my_first;
+      int ovf = 0;
       for (int q = 0; q < K; ++q) {
         const int t = tid * K + q;
         if (t >= a.T) break;
         const uint32_t v = tile_tot[t];
         // an empty tile reports (0, 0) like the published identifyTileRanges leaves it
         ranges[2 * t] = v ? min(run, a.R_cap) : 0u, ranges[2 * t + 1] = v ? min(run + v, a.R_cap) : 0u;
-        if (run + v > a.R_cap) total[1] = 1;  // capacity overflow: flagged, never written out of bounds
+        if (run + v > a.R_cap) total[1] = 1, ovf = 1;  // capacity overflow: flagged, never written out of bounds
         run += v;
       }
+      ovf = __syncthreads_or(ovf);
+      // the render's (R, overflow) for the step-level array (dimo_render_desc.totals_out)
+      if (totals_out && tid == 0) totals_out[0] = total[0], totals_out[1] = (uint32_t)(ovf != 0);
     }
   }
   tr.mark();
@@ -949,14 +954,15 @@ __device__ __forceinline__ void level2_body(const BinArgs &a, void *geom, void *
 }
 
 template <bool FILL>
-__device__ __forceinline__ void level2_dispatch(const BinArgs &a, void *geom, void *bin, uint8_t *grad_flags) {
+__device__ __forceinline__ void level2_dispatch(const BinArgs &a, void *geom, void *bin, uint8_t *grad_flags,
+                                                uint32_t *totals_out) {
   __shared__ L2Shared sh;
   __shared__ uint32_t s_ts[FILL ? TS_LDS : 1];
   switch (a.gi.ss_shift) {  // (uniform)
-    case 0: level2_body<FILL, 0>(a, geom, bin, grad_flags, sh, s_ts); break;
-    case 1: level2_body<FILL, 1>(a, geom, bin, grad_flags, sh, s_ts); break;
-    case 2: level2_body<FILL, 2>(a, geom, bin, grad_flags, sh, s_ts); break;
-    default: level2_body<FILL, 3>(a, geom, bin, grad_flags, sh, s_ts); break;
+    case 0: level2_body<FILL, 0>(a, geom, bin, grad_flags, totals_out, sh, s_ts); break;
+    case 1: level2_body<FILL, 1>(a, geom, bin, grad_flags, totals_out, sh, s_ts); break;
+    case 2: level2_body<FILL, 2>(a, geom, bin, grad_flags, totals_out, sh, s_ts); break;
+    default: level2_body<FILL, 3>(a, geom, bin, grad_flags, totals_out, sh, s_ts); break;
   }
 }
 
@@ -974,7 +980,7 @@ __global__ void __launch_bounds__(SORT_BLOCK) bucket_sort_kernel(BinArgs a, void
 }
 template <bool FILL>
 __global__ void __launch_bounds__(SEG) level2_kernel(BinArgs a, void *geom, void *bin) {
-  level2_dispatch<FILL>(a, geom, bin, nullptr);  // (the C-ABI backward clears its own scratch)
+  level2_dispatch<FILL>(a, geom, bin, nullptr, nullptr);  // (the C-ABI backward clears its own scratch)
 }
 __global__ void __launch_bounds__(SORT_BLOCK) level1_count_batched_kernel(BinArgs a, RenderBatch b) {
   level1_count_body(a, b.r[blockIdx.y].geom, b.r[blockIdx.y].bin);
@@ -988,7 +994,7 @@ __global__ void __launch_bounds__(SORT_BLOCK) bucket_sort_batched_kernel(BinArgs
 template <bool FILL>
 __global__ void __launch_bounds__(SEG) level2_batched_kernel(BinArgs a, size_t flag_off, RenderBatch b) {
   const dimo_render_desc &r = b.r[blockIdx.y];
-  level2_dispatch<FILL>(a, r.geom, r.bin, FILL ? at<uint8_t>(r.bwd_scratch, flag_off) : nullptr);
+  level2_dispatch<FILL>(a, r.geom, r.bin, FILL ? at<uint8_t>(r.bwd_scratch, flag_off) : nullptr, FILL ? r.totals_out : nullptr);
 }
 
 // ------------------------------------------------------------------------------------ host side

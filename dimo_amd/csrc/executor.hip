@@ -45,6 +45,7 @@ typedef struct {
   void *geom, *bin, *img, *bwd_scratch;
   float *g_means3D, *g_means2D, *g_shs, *g_opac, *g_scales, *g_rot;
   const float *g_dot;              // optional per-pixel sum of gradient x rendered value (include/dimo_hip.h)
+  uint32_t *totals_out;            // optional (R, overflow) copy (include/dimo_hip.h)
 } dimo_render_desc;
 }
 #endif

@@ -35,7 +35,7 @@ class RenderDesc(C.Structure):
                 ("pts", _fp), ("rot", _fp), ("scales", _fp), ("opac", _fp), ("radii", _vp),
                 ("geom", _vp), ("bin", _vp), ("img", _vp), ("bwd_scratch", _vp),
                 ("g_means3D", _fp), ("g_means2D", _fp), ("g_shs", _fp), ("g_opac", _fp), ("g_scales", _fp),
-                ("g_rot", _fp), ("g_dot", _fp)]
+                ("g_rot", _fp), ("g_dot", _fp), ("totals_out", _vp)]
 
 
 class StepExecutor:
@@ -69,11 +69,15 @@ class StepExecutor:
         self.r_cap = 0
         self.resize_capacity(r_cap)
         self.common = StepCommon()
+        # (R, overflow) of every slot's last render, written by the binning's last kernel (dimo_render_desc.totals_out)
+        self.totals = torch.zeros(max_renders, 2, dtype=torch.int32, device=device)
         self.descs = (RenderDesc * max_renders)()
         for d, s in zip(self.descs, self.slots):
             for k in ("pts", "rot", "scales", "opac", "radii", "geom", "img", "bin", "bwd_scratch", "g_means3D",
                       "g_means2D", "g_shs", "g_opac", "g_scales", "g_rot"):
                 setattr(d, k, s[k].data_ptr())
+        for i, d in enumerate(self.descs):
+            d.totals_out = self.totals.data_ptr() + 8 * i
 
     def destroy(self):
         """Releases the native executor (its events; the private streams belong to a per-device pool).  The caller
@@ -109,14 +113,12 @@ class StepExecutor:
                 d.bin, d.bwd_scratch = s["bin"].data_ptr(), s["bwd_scratch"].data_ptr()
 
     def total_words(self, n):
-        """Device views of the (R, overflow) words of the first n slots (for CapacityPolicy / the skip flag)."""
-        from .rasterizer import _total_view
-        return [_total_view(self.slots[i]["geom"], self.N) for i in range(n)]
+        """(R, overflow) words of the first n slots: ONE [n, 2] view (for CapacityPolicy / the skip flag)."""
+        return self.totals[:n]
 
     def total_words_range(self, first, n):
-        """The same for slots [first, first + n)."""
-        from .rasterizer import _total_view
-        return [_total_view(self.slots[i]["geom"], self.N) for i in range(first, first + n)]
+        """(R, overflow) words of slots [first, first + n) as ONE [n, 2] view (no gather of the per-slot workspaces)."""
+        return self.totals[first:first + n]
 
     def set_common(self, g, bg, with_normal, local_frame=True, scale_modifier=1.0, stage1=False):
         """stage1: direct deformation (stage s1) -- d_xyz of a render is [N, 3], scales = exp(g._r)."""

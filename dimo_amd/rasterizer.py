@@ -60,7 +60,9 @@ class CapacityPolicy:
         return self.capacity
 
     def track(self, total_view):
-        self._pending.append(total_view)
+        """total_view: the (R, overflow) words of ONE render ([2] or longer: the first two words count) or of several
+        ([n, 2], e.g. StepExecutor.total_words)."""
+        self._pending.append(total_view[:2][None] if total_view.dim() == 1 else total_view)
 
     def _update(self, tot):
         r_max = int(tot[:, 0].max())
@@ -79,7 +81,7 @@ class CapacityPolicy:
         on overflow the capacity is raised and the caller must redo the step."""
         if not self._pending:
             return True
-        tot = torch.stack(self._pending).cpu()
+        tot = (self._pending[0] if len(self._pending) == 1 else torch.cat(self._pending)).cpu()
         self._pending = []
         return self._update(tot)
 
@@ -89,7 +91,7 @@ class CapacityPolicy:
         `poll()` evaluates later."""
         if not self._pending:
             return None
-        tot = torch.stack(self._pending)
+        tot = self._pending[0] if len(self._pending) == 1 else torch.cat(self._pending)
         self._pending = []
         host = torch.empty(tot.shape, dtype=tot.dtype, pin_memory=True)
         host.copy_(tot, non_blocking=True)

@@ -110,7 +110,7 @@ class Renderer:
         """Nobody consumes the policy's instance counts (a trainer does, once per step): look at them every 64 renders
         so that an overflow of the instance capacity cannot pass unnoticed (one stream sync per 64 renders)."""
         cap = self.capacity
-        if cap and len(cap._pending) >= 64 and not cap.check():
+        if cap and sum(t.shape[0] for t in cap._pending) >= 64 and not cap.check():
             raise RuntimeError("a render since the last check overflowed the instance capacity and dropped tile "
                                f"instances; the capacity is now {cap.capacity}: repeat the step")
 

@@ -654,8 +654,7 @@ class Trainer:
                 ex.forward_range(first[m], len(trs))
         else:
             ex.forward(n)
-        for w_ in ex.total_words(n):
-            self.renderer.capacity.track(w_)
+        self.renderer.capacity.track(ex.total_words(n))
 
         loss_accum = zeroed[o_q + dquat_c.numel():o_q + dquat_c.numel() + _LOSS_WORDS]
         # scalars produced on THIS stream (KL, ARAP, GA, LPIPS): summed apart from `loss_accum`, which the private
@@ -853,8 +852,9 @@ class Trainer:
             # no host sync at all: the overflow words of this step's renders become a device-side skip flag that
             # travels through the all-reduce; the host looks at them one step later (CapacityPolicy.poll)
             tot = cap.collect_async() if cap is not None else None
-            # (device scalar, no read-back: a step whose renders overflowed must not feed the densification statistics)
-            self._step_overflow = tot[:, 1].max() if tot is not None else None
+            # (device scalar, no read-back: a step whose renders overflowed must not feed the densification statistics --
+            # stage s1 only, where they are gathered)
+            self._step_overflow = tot[:, 1].max() if (tot is not None and self.stage == "s1") else None
             if self.world > 1:  # the flag rides in the tail of the gradient bucket through the all-reduce
                 if tot is not None:
                     g.grad_flag.copy_(tot[:, 1].max().to(torch.float32))

@@ -339,6 +339,10 @@ typedef struct {
   /* optional [H,W]: sum over the output channels of (gradient image x rendered image) per pixel, as dimo_image_loss
    * emits it; NULL: the blend backward forms it from the forward's final accumulators */
   const float *g_dot;
+  /* optional: two words that receive this render's (instance count R, overflow flag) when its tile lists are complete
+   * -- the renders of a step can point into ONE array that the capacity policy and the optimizer's skip flag read
+   * without gathering the per-render workspaces' words */
+  uint32_t *totals_out;
 } dimo_render_desc;
 
 /* n_streams > 0: per-render chains on that many private streams (render i on stream i % n).
