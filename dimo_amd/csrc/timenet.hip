@@ -466,20 +466,24 @@ struct WaveWeights {
   const float4 *w0, *w1;  // this lane's float4 of block 0 of the wave's two column tiles
   int nE, nkb;            // embedding blocks (A from the embedding tile), blocks in all
 };
+// NT = column tiles (16 columns each) per wave: 2 with 8 waves per workgroup, 1 with 16
+template <int NT = 2>
 __device__ __forceinline__ WaveWeights wave_weights(const float *packed, int E, bool use_embed, bool use_hidden,
                                                     int wave, int lane) {
   WaveWeights w;
   w.nE = use_embed ? embed_blocks(E) : 0;
   w.nkb = w.nE + (use_hidden ? FW / 16 : 0);
-  w.w0 = reinterpret_cast<const float4 *>(packed) + (size_t)(2 * wave) * w.nkb * 64 + lane;
-  w.w1 = w.w0 + (size_t)w.nkb * 64;
+  w.w0 = reinterpret_cast<const float4 *>(packed) + (size_t)(NT * wave) * w.nkb * 64 + lane;
+  w.w1 = NT == 2 ? w.w0 + (size_t)w.nkb * 64 : w.w0;
   return w;
 }
+template <int NT = 2>
 __device__ __forceinline__ void prefetch_blocks(const WaveWeights &w, float4 (&q0)[FPF], float4 (&q1)[FPF]) {
 #pragma unroll
   for (int u = 0; u < FPF; ++u) {
     const int blk = min(u, w.nkb - 1);
-    q0[u] = w.w0[blk * 64], q1[u] = w.w1[blk * 64];
+    q0[u] = w.w0[blk * 64];
+    if (NT == 2) q1[u] = w.w1[blk * 64];
   }
 }
 
@@ -523,6 +527,7 @@ __device__ __forceinline__ void fused_chunk(const float *xa /* this lane's A poi
 
 // acc = [embed | hidden] (LDS tiles, zero padded to whole chunks) * W^T for the wave's 32 columns: an embedding chunk
 // (layer 0 and the layer after the skip) and / or a hidden chunk; the ring runs on into the next layer's weights (wn)
+template <int NT = 2>
 __device__ __forceinline__ void fused_matmul(const float *s_c, const float *s_in, const WaveWeights &w,
                                              const WaveWeights &wn, float4 (&q0)[FPF], float4 (&q1)[FPF], f32x4 &c0,
                                              f32x4 &c1, int lane) {
@@ -531,43 +536,48 @@ __device__ __forceinline__ void fused_matmul(const float *s_c, const float *s_in
   const bool hidden = w.nkb > w.nE;
   if (w.nE) {
     const float4 *n0 = hidden ? w.w0 + EB * 64 : wn.w0, *n1 = hidden ? w.w1 + EB * 64 : wn.w1;
-    fused_chunk<EB>(s_c + mn * FC_LD + 4 * kq, w.w0, w.w1, n0, n1, q0, q1, c0, c1);
+    fused_chunk<EB, NT, NT>(s_c + mn * FC_LD + 4 * kq, w.w0, w.w1, n0, n1, q0, q1, c0, c1);
   }
   if (hidden)
-    fused_chunk<HB>(s_in + mn * FH_LD + 4 * kq, w.w0 + w.nE * 64, w.w1 + w.nE * 64, wn.w0, wn.w1, q0, q1, c0, c1);
+    fused_chunk<HB, NT, NT>(s_in + mn * FH_LD + 4 * kq, w.w0 + w.nE * 64, w.w1 + w.nE * 64, wn.w0, wn.w1, q0, q1, c0, c1);
 }
 
 // relu(acc + bias) -> LDS tile + workspace
+template <int NT = 2>
 __device__ __forceinline__ void fused_epilogue(const f32x4 &c0, const f32x4 &c1, float b0, float b1, float *s_out,
                                                float *__restrict__ gout, int ld_out, int row0, int R, int lane,
                                                int wave) {
-  const int kq = lane >> 4, mn = lane & 15, n0 = wave * 32;
+  const int kq = lane >> 4, mn = lane & 15, n0 = wave * 16 * NT;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int m = 4 * kq + r;
     const float v0 = fmaxf(c0[r] + b0, 0.f), v1 = fmaxf(c1[r] + b1, 0.f);
     s_out[m * FH_LD + n0 + mn] = v0;
-    s_out[m * FH_LD + n0 + 16 + mn] = v1;
+    if (NT == 2) s_out[m * FH_LD + n0 + 16 + mn] = v1;
     if (row0 + m < R) {
       gout[(size_t)(row0 + m) * ld_out + n0 + mn] = v0;
-      gout[(size_t)(row0 + m) * ld_out + n0 + 16 + mn] = v1;
+      if (NT == 2) gout[(size_t)(row0 + m) * ld_out + n0 + 16 + mn] = v1;
     }
   }
 }
 
-__global__ __launch_bounds__(512) void timenet_fwd_fused_kernel(FusedArgs g) {
+// NW waves per workgroup: 8 (each wave 32 columns) or 16 (16 columns: twice the weight blocks in flight per CU -- the
+// kernel lives on the latency of its weight stream, 128 workgroups on 256 CUs)
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void timenet_fwd_fused_kernel(FusedArgs g) {
+  constexpr int NT = 16 / NW, NTHR = 64 * NW;
   __shared__ __attribute__((aligned(16))) float s_c[FR * FC_LD];
   __shared__ __attribute__((aligned(16))) float s_h[2][FR * FH_LD];
   __shared__ float s_wo[7 * FW];  // the 3 + 4 rows of the head output layers (read 16 x per workgroup at the very end)
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int row0 = blockIdx.x * FR;
-  for (int e = t; e < 7 * FW; e += 512) s_wo[e] = e < 3 * FW ? g.W[g.D + 1][e] : g.W[g.D + 3][e - 3 * FW];
+  for (int e = t; e < 7 * FW; e += NTHR) s_wo[e] = e < 3 * FW ? g.W[g.D + 1][e] : g.W[g.D + 3][e - 3 * FW];
   float4 q0[FPF], q1[FPF];
-  WaveWeights w = wave_weights(g.Wp[0], g.E, true, false, wave, lane);
-  prefetch_blocks(w, q0, q1);  // in flight under the embedding
+  WaveWeights w = wave_weights<NT>(g.Wp[0], g.E, true, false, wave, lane);
+  prefetch_blocks<NT>(w, q0, q1);  // in flight under the embedding
   // embedding of the 16 rows (same arithmetic as embed_kernel) -> LDS (zero padded) and the workspace
   const int npts = 6 * g.pts_freqs, ntime = 2 * g.time_freqs;
-  for (int e = t; e < FR * FE_MAX; e += 512) {
+  for (int e = t; e < FR * FE_MAX; e += NTHR) {
     const int m = e / FE_MAX, col = e % FE_MAX;
     const int row = min(row0 + m, g.R - 1);
     const int p = row / g.Mc, cp = row % g.Mc;
@@ -594,16 +604,17 @@ __global__ __launch_bounds__(512) void timenet_fwd_fused_kernel(FusedArgs g) {
     const int li = head ? g.D + 2 * (step - g.D) : step;
     f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
     // (requested before the matmul: after it they would be a full memory round trip on the critical path)
-    const float bias0 = g.b[li][wave * 32 + (lane & 15)], bias1 = g.b[li][wave * 32 + 16 + (lane & 15)];
+    const float bias0 = g.b[li][wave * 16 * NT + (lane & 15)];
+    const float bias1 = NT == 2 ? g.b[li][wave * 32 + 16 + (lane & 15)] : 0.f;
     WaveWeights wn = w;  // (after the last layer the ring refills with clamped repeats of its own blocks)
     if (step + 1 < g.D + 2) {
       const int ns = step + 1, nli = ns >= g.D ? g.D + 2 * (ns - g.D) : ns;
-      wn = wave_weights(g.Wp[nli], g.E, ns < g.D && ns - 1 == g.skip, true, wave, lane);
+      wn = wave_weights<NT>(g.Wp[nli], g.E, ns < g.D && ns - 1 == g.skip, true, wave, lane);
     }
-    fused_matmul(s_c, s_h[cur], w, wn, q0, q1, c0, c1, lane);
+    fused_matmul<NT>(s_c, s_h[cur], w, wn, q0, q1, c0, c1, lane);
     w = wn;
     if (!head) {
-      fused_epilogue(c0, c1, bias0, bias1, s_h[cur ^ 1], g.act[li], g.act_ld[li], row0, g.R, lane, wave);
+      fused_epilogue<NT>(c0, c1, bias0, bias1, s_h[cur ^ 1], g.act[li], g.act_ld[li], row0, g.R, lane, wave);
       cur ^= 1;
       lds_barrier();
       continue;
@@ -611,12 +622,12 @@ __global__ __launch_bounds__(512) void timenet_fwd_fused_kernel(FusedArgs g) {
     // head hidden layer -> s_h[cur ^ 1]; its 3 / 4 output columns are wave dot products (two rows per wave, the
     // arithmetic of head_out_kernel)
     const int hd = step - g.D;
-    fused_epilogue(c0, c1, bias0, bias1, s_h[cur ^ 1], hd ? g.hr : g.hp, FW, row0, g.R, lane, wave);
+    fused_epilogue<NT>(c0, c1, bias0, bias1, s_h[cur ^ 1], hd ? g.hr : g.hp, FW, row0, g.R, lane, wave);
     lds_barrier();
     const float *Wo = s_wo + (hd ? 3 * FW : 0), *bo = g.b[li + 1];
     const int nout = hd ? 4 : 3;
-    for (int rr = 0; rr < 2; ++rr) {
-      const int m = 2 * wave + rr;
+    for (int rr = 0; rr < FR / NW; ++rr) {
+      const int m = (FR / NW) * wave + rr;
       const float *x = s_h[cur ^ 1] + m * FH_LD;
       float a[4] = {0.f, 0.f, 0.f, 0.f};
       for (int c = lane; c < FW; c += 64) {
@@ -943,7 +954,11 @@ extern "C" int dimo_timenet_forward(const dimo_timenet_desc *d, int P, int M, co
       g.Wp[l] = ws + pl.packed[l];
     }
     pack_weights_kernel<<<dim3(16, pa.njobs), 256, 0, s>>>(pa);
-    timenet_fwd_fused_kernel<<<(R + FR - 1) / FR, 512, 0, s>>>(g);
+    static const bool wide = !getenv("DIMO_TIMENET_8WAVES");
+    if (wide)
+      timenet_fwd_fused_kernel<16><<<(R + FR - 1) / FR, 1024, 0, s>>>(g);
+    else
+      timenet_fwd_fused_kernel<8><<<(R + FR - 1) / FR, 512, 0, s>>>(g);
     return check_launch();
   }
   {

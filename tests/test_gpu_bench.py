@@ -73,3 +73,35 @@ def test_bench_single_rank_record_fields():
     s = r["sustained"]  # default: 1200 consecutive steps, across the stage-s2 prune of step 2000
     assert s["steps"] >= 1000 and s["s2_prunes_crossed"] >= 1 and s["frames_per_s"] > 0
     assert s["gaussians_start_end"][0] == 20000 and s["gaussians_start_end"][1] <= 20000
+
+
+@pytest.mark.timeout(600)
+def test_rccl_calls_of_the_data_parallel_step_on_a_one_rank_communicator():
+    """No multi-GPU box has ever been available: the RCCL calls of the sharded step (async all-reduce of the
+    per-Gaussian head of the gradient bucket under the TimeNet backward, the tail + overflow flag after it, the s1
+    statistics) are at least EXECUTED here -- one process, backend nccl (= RCCL), a communicator of one rank, the
+    trainer told it is rank 0 of 2 (so it renders half of the step's triples and reduces with itself)."""
+    code = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.getcwd())
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29700 + os.getpid() % 200), HSA_ENABLE_IPC_MODE_LEGACY="0")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+import bench
+tr, pol = bench.make_trainer(torch.device("cuda", 0), 0, 1, 20000, 128)
+tr.world = 2          # shard as rank 0 of 2; every collective runs on the one-rank RCCL communicator
+tr.time_allreduce = True
+p0 = tr.renderer.gaussians.flat_params.clone()
+n = sum(tr.train_step() for _ in range(3))
+torch.cuda.synchronize()
+assert n == 3 * 4, n   # half of the 8 triples per step
+assert len(tr.allreduce_events) == 3 and all(a.elapsed_time(b) >= 0.0 for a, b in tr.allreduce_events)
+assert torch.isfinite(tr.last_loss) and torch.isfinite(tr.renderer.gaussians.flat_params).all()
+assert not torch.equal(p0, tr.renderer.gaussians.flat_params) and tr.skipped_steps == 0
+t = torch.ones(4, device="cuda"); dist.all_reduce(t); assert float(t.sum()) == 4.0
+dist.destroy_process_group()
+print("RCCL_ONE_RANK_OK", dist.is_nccl_available())
+'''
+    p = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=dict(os.environ), capture_output=True, text=True,
+                       timeout=500)
+    assert p.returncode == 0 and "RCCL_ONE_RANK_OK True" in p.stdout, p.stdout[-2000:] + p.stderr[-3000:]
