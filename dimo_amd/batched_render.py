@@ -23,7 +23,6 @@ import ctypes as C
 import weakref
 
 import torch
-from torch.utils._pytree import tree_map
 
 from . import _lib
 
@@ -44,7 +43,7 @@ class LazyTensor:
 
     @classmethod
     def __torch_function__(cls, func, types, args=(), kwargs=None):
-        return func(*tree_map(_unwrap, args), **tree_map(_unwrap, kwargs or {}))
+        return func(*_unwrap_all(args), **(_unwrap_all(kwargs) if kwargs else {}))
 
     def __getattr__(self, name):  # (only reached for names the class does not define)
         return getattr(self.materialize(), name)
@@ -57,9 +56,22 @@ def _unwrap(x):
     return x.materialize() if isinstance(x, LazyTensor) else x
 
 
+def _unwrap_all(x):
+    """`x` with every LazyTensor inside lists / tuples / dicts replaced by its tensor (a pytree map costs 40 us per
+    call: the reference-shaped step makes sixteen such calls and is host bound)."""
+    t = type(x)
+    if t is LazyTensor:
+        return x.materialize()
+    if t is list or t is tuple:
+        return t(_unwrap_all(y) for y in x)
+    if t is dict:
+        return {k: _unwrap_all(v) for k, v in x.items()}
+    return x
+
+
 def _forward_dunder(name):
     def method(self, *args, **kwargs):
-        return getattr(self.materialize(), name)(*tree_map(_unwrap, args), **tree_map(_unwrap, kwargs))
+        return getattr(self.materialize(), name)(*_unwrap_all(args), **_unwrap_all(kwargs))
     method.__name__ = name
     return method
 
@@ -248,18 +260,20 @@ class _BatchRenderFn(torch.autograd.Function):
         c.g_xyz, c.g_rotation, c.g_scaling, c.g_opacity, c.g_f_dc = p(g_xyz), p(g_rot), p(g_scaling), p(g_opacity), p(g_fdc)
         c.g_c_xyz, c.g_c_log_radius = p(g_cxyz), p(g_crad)
         HW4 = H * W * 4
+        # the screen-space gradients go to a tensor of this backward (not to the slots' buffers, which the next batch
+        # overwrites): the sinks' .grad may keep views of it
+        gm2d = torch.empty(n, N, 3, **f32)
         for i in range(n):
             d = ex.descs[job.first + i]
+            d.g_means2D = gm2d.data_ptr() + i * N * 12
             d.g_color, d.g_alpha = g_img.data_ptr() + i * 3 * HW4, g_alpha.data_ptr() + i * HW4
             d.g_depth = (g_depth.data_ptr() + i * HW4) if g_depth is not None else None
             d.g_normal = (g_normal.data_ptr() + i * 3 * HW4) if g_normal is not None else None
             d.g_dot = None
         ex.backward_launch(job.first, n)
         ex.backward_accumulate(job.first, n)
-        sink_grads = []
-        for i in range(n):  # screen-space gradients (densification statistics read them)
-            need = ctx.needs_input_grad[8 + 2 * len(job.deforms) + i]
-            sink_grads.append(ex.slots[job.first + i]["g_means2D"].clone() if need else None)
+        # screen-space gradients (densification statistics read them)
+        sink_grads = [gm2d[i] if ctx.needs_input_grad[8 + 2 * len(job.deforms) + i] else None for i in range(n)]
         ctx.ticket.release()
         return (None, g_xyz, g_rot, g_scaling, g_opacity, g_fdc, g_cxyz, g_crad, *job.grad_rows, *sink_grads)
 
