@@ -213,6 +213,23 @@ def test_depth_sort_with_256_bins_above_400k_gaussians():
     _check_forward(sc, cam, (0.1, 0.1, 0.1), 0)
 
 
+@pytest.mark.parametrize("H,W", [(1040, 2048), (1296, 1296)])
+def test_images_with_more_than_4096_tiles(H, W):
+    """Above 4096 tiles the level-2 fill no longer keeps every tile's first slot in LDS and walks the current
+    supertile's starts per window instead (binning.hip: TS_LDS); 8 x 8-tile supertiles (ss_shift 3)."""
+    cam = camera_np(15.0, elevation=-5, W=W, H=H)
+    sc = random_scene(6000, seed=77, scale=0.02)
+    _check_forward(sc, cam, (0.0, 0.0, 0.0), 0)
+
+
+def test_image_beyond_the_supertile_grid_is_refused():
+    """More than 256 supertiles of 8 x 8 tiles (16384 tiles, e.g. above 2048^2 pixels): DIMO_E_ARG, no launch."""
+    cam = camera_np(0.0, W=2064, H=2064)
+    sc = random_scene(100, seed=1)
+    with pytest.raises(RuntimeError):
+        _run_hip(sc, cam, (0, 0, 0), 0)
+
+
 def _rel_l1(a, b):
     return np.abs(a - b).sum() / (np.abs(b).sum() + 1e-12)
 
