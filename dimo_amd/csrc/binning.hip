@@ -144,9 +144,6 @@ struct BinTrace {
 #endif
 };
 
-// Workgroup barrier for data exchanged through LDS only: waits for this wave's LDS operations, NOT for its global
-// loads (__syncthreads() carries a fence that drains vmcnt, i.e. it would wait for every prefetch in flight).
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // The level-1 entries of a wave's 64 Gaussians, walked in GROUPS of lanes that name the same bucket: a wave's
 // Gaussians are Morton neighbours, so most of its entries share a handful of buckets -- one LDS atomic per entry was

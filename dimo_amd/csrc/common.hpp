@@ -179,6 +179,10 @@ __host__ __device__ inline const T *at(const void *base, size_t off) {
   return reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + off);
 }
 
+// Workgroup barrier for data exchanged through LDS only: waits for this wave's LDS operations, NOT for its global
+// loads (__syncthreads() carries a fence that drains vmcnt, i.e. it would wait for every prefetch in flight).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 void set_last_error(hipError_t e, const char *where);  // api.hip; text retrievable with dimo_last_error()
 #define check_launch() ::dimo::check_launch_at(__FILE__ ":" DIMO_STR(__LINE__))
 #define DIMO_STR2(x) #x

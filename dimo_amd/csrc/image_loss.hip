@@ -7,8 +7,8 @@
 //   + an optional dL/d(clamped image) term coming from the fused SSIM backward.
 // In the reference (and in a PyTorch restatement) this is ~60 elementwise / reduction kernels forward and as
 // many backward per motion, each streaming [B,C,H,W] tensors; the losses are closed-form, so one pass reads
-// the eight rendered planes + targets (with the 4-neighbour stencil served from cache) and writes the four
-// gradient images the rasterizer backward consumes.  HBM-bound: 12 planes in, 8 planes out per image.
+// the eight rendered planes + targets once and writes the four gradient images the rasterizer backward consumes
+// (+ the per-pixel gradient x value plane).  HBM-bound: 15 planes in, 9 planes out per image.
 #include "common.hpp"
 
 namespace dimo {
@@ -26,55 +26,86 @@ struct LossParams {
 };
 
 struct Px {
+  float c[3], d, n[3];  // clamped colour, depth, normal
+};
+struct Grad {
   float c[3], d, n[3];
 };
 
 __device__ __forceinline__ float clamp01(float v) { return fminf(fmaxf(v, 0.0f), 1.0f); }
 __device__ __forceinline__ float sgn(float v) { return (v > 0.0f) ? 1.0f : ((v < 0.0f) ? -1.0f : 0.0f); }
-
-template <bool DEPTH, bool NORMAL>
-__device__ __forceinline__ Px load_px(const float *img, const float *depth, const float *normal, size_t HW,
-                                      size_t pix) {
-  Px p;
-  p.c[0] = clamp01(img[pix]), p.c[1] = clamp01(img[HW + pix]), p.c[2] = clamp01(img[2 * HW + pix]);
-  p.d = DEPTH ? depth[pix] : 0.0f;
-  if (NORMAL) p.n[0] = normal[pix], p.n[1] = normal[HW + pix], p.n[2] = normal[2 * HW + pix];
-  else p.n[0] = p.n[1] = p.n[2] = 0.0f;
-  return p;
+// lane l <- lane l - 1 / lane l + 1 of the wave (DPP wave shifts: no LDS, one VALU move each)
+__device__ __forceinline__ float from_lane_below(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float from_lane_above(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
 }
 
-// One neighbouring pair (A = left/top, B = right/bottom).  `side` = +1 if the calling pixel is A, -1 if B.
-// Adds the calling pixel's share of the gradients; returns the pair's loss (counted by the A side only).
+// One neighbouring pair (A = left / top, B = right / bottom): returns the pair's loss and the gradient w.r.t. A's
+// values in t; the gradient w.r.t. B's values is -t (every term is a function of A - B).
+//   edge-aware depth smoothness   w_sm |dA - dB| exp(-gI)                         src/loss.py:64-83
+//   bilateral normal smoothness   w_bl sqrt(1 + (|nA - nB| exp(-3 gI))^2)         src/loss.py:86-106
+// with gI = mean_c |cA - cB|.  v_rsq_f32 (1 ulp) replaces sqrt + division.
 template <bool DEPTH, bool NORMAL>
-__device__ __forceinline__ float pair_term(const Px &A, const Px &B, float side, float w_sm, float w_bl, float *gc,
-                                           float &gd, float *gn) {
+__device__ __forceinline__ float pair_term(const Px &A, const Px &B, float w_sm, float w_bl, Grad &t) {
   const float dc0 = A.c[0] - B.c[0], dc1 = A.c[1] - B.c[1], dc2 = A.c[2] - B.c[2];
   const float gI = (fabsf(dc0) + fabsf(dc1) + fabsf(dc2)) * (1.0f / 3.0f);
   float loss = 0.0f, dL_dgI = 0.0f;
+  const float e1 = __expf(-gI);
+  t.d = 0.0f, t.n[0] = t.n[1] = t.n[2] = 0.0f;
   if (DEPTH) {
-    const float e1 = __expf(-gI);
     const float dd = A.d - B.d;
-    loss += w_sm * fabsf(dd) * e1;
-    gd += side * w_sm * sgn(dd) * e1;
-    dL_dgI += -w_sm * fabsf(dd) * e1;
+    const float l = w_sm * fabsf(dd) * e1;
+    loss += l;
+    t.d = w_sm * sgn(dd) * e1;
+    dL_dgI -= l;
   }
   if (NORMAL) {
-    const float e3 = __expf(-3.0f * gI);
+    const float e3 = e1 * e1 * e1;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      const float dn = A.n[k] - B.n[k];
-      const float a = fabsf(dn) * e3;
-      const float root = sqrtf(1.0f + a * a);
-      const float q = a / root;
-      loss += w_bl * root;
-      gn[k] += side * w_bl * q * e3 * sgn(dn);
-      dL_dgI += -3.0f * w_bl * q * a;
+      const float an = (A.n[k] - B.n[k]) * e3;  // signed |dn| e3
+      const float s = 1.0f + an * an;
+      const float r = __builtin_amdgcn_rsqf(s);
+      loss += w_bl * (s * r);                    // sqrt(s)
+      const float q = an * r;                    // signed a / root
+      t.n[k] = w_bl * q * e3;
+      dL_dgI -= 3.0f * w_bl * q * an;
     }
   }
-  const float s = side * dL_dgI * (1.0f / 3.0f);
-  gc[0] += s * sgn(dc0), gc[1] += s * sgn(dc1), gc[2] += s * sgn(dc2);
+  const float g = dL_dgI * (1.0f / 3.0f);
+  t.c[0] = g * sgn(dc0), t.c[1] = g * sgn(dc1), t.c[2] = g * sgn(dc2);
   return loss;
 }
+__device__ __forceinline__ void add(Grad &g, const Grad &t, float s) {
+#pragma unroll
+  for (int k = 0; k < 3; ++k) g.c[k] += s * t.c[k], g.n[k] += s * t.n[k];
+  g.d += s * t.d;
+}
+
+// scalar base + 32-bit byte offset per lane: the addressing mode of global_load / global_store with an SGPR base
+// (a 64-bit address per lane and plane cost two VALU instructions per access)
+__device__ __forceinline__ float ld(const float *base, unsigned off) {
+  return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + off);
+}
+__device__ __forceinline__ void st(float *base, unsigned off, float v) {
+  *reinterpret_cast<float *>(reinterpret_cast<char *>(base) + off) = v;
+}
+
+// A WAVE owns LOSS_COLS columns x LOSS_ROWS rows of one image and walks down its rows: lane l holds pixel
+// (x0 - 1 + l, y) -- lanes 0 and 63 are halo columns, the first and last row visited are halo rows.  Every
+// neighbouring pair is evaluated ONCE per wave (the first version evaluated the four pairs of every pixel: each pair
+// twice, 790 VALU instructions per pixel and VALU-bound at 3 TB/s): the horizontal pair (x - 1, x) by lane x, its
+// other half handed to lane x - 1 with a DPP wave shift; the vertical pair (y - 1, y) when row y arrives, its other
+// half completing row y - 1, which is then written.  A pixel's planes are loaded once (the row below is the next
+// iteration's own row), not once per neighbour.
+constexpr int LOSS_COLS = 62, LOSS_ROWS = 8;
+
+template <bool DEPTH, bool NORMAL>
+struct RowLoad {  // one pixel's inputs as loaded (the next row's are in flight while this row is processed)
+  float raw[3], d, n[3], gt[3], a, m, sg[3];
+};
 
 template <bool DEPTH, bool NORMAL>
 __global__ void __launch_bounds__(256) image_loss_kernel(
@@ -84,66 +115,134 @@ __global__ void __launch_bounds__(256) image_loss_kernel(
     float *__restrict__ loss_out, float *__restrict__ g_image, float *__restrict__ g_depth,
     float *__restrict__ g_normal, float *__restrict__ g_alpha, float *__restrict__ g_dot) {
   __shared__ float s_red[4];
-  const size_t HW = (size_t)H * W;
+  const int HW = H * W;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // scalar: the image pointers stay in SGPRs
+  const int strips = (W + LOSS_COLS - 1) / LOSS_COLS, blocks = (H + LOSS_ROWS - 1) / LOSS_ROWS;
+  const int units = strips * blocks * n_images;
   float loss = 0.0f;
-  // a workgroup walks 32x8 pixel tiles (image, ty, tx) with stride gridDim.x: ONE atomic per workgroup, spread over
-  // 16 words in 16 cache lines (same-address atomics drain at ~7 ns each: 4096 of them were most of this kernel's
-  // 67 us, 1024 still 4 of 40; with the spread the grid size no longer matters -- 35 us for 8 images = 5 TB/s)
-  const int tiles_x = (W + 31) / 32, tiles_y = (H + 7) / 8;
-  for (int tile = blockIdx.x; tile < tiles_x * tiles_y * n_images; tile += gridDim.x) {
-  const int b = tile / (tiles_x * tiles_y);
-  const int x = (tile % tiles_x) * 32 + (threadIdx.x & 31), y = ((tile / tiles_x) % tiles_y) * 8 + (threadIdx.x >> 5);
-  const float *img = image + (size_t)b * 3 * HW, *dep = DEPTH ? depth + (size_t)b * HW : nullptr;
-  const float *nrm = NORMAL ? normal + (size_t)b * 3 * HW : nullptr;
-  if (x < W && y < H) {
-    const size_t pix = (size_t)y * W + x;
-    const Px P = load_px<DEPTH, NORMAL>(img, dep, nrm, HW, pix);
-    float gc[3] = {0, 0, 0}, gd = 0.0f, gn[3] = {0, 0, 0};
-    // per-pixel terms
+  for (int unit = blockIdx.x * 4 + wave; unit < units; unit += gridDim.x * 4) {
+    const int b = unit / (strips * blocks), rem = unit - b * (strips * blocks);
+    const int blk = rem / strips, strip = rem - blk * strips;
+    const int x = strip * LOSS_COLS - 1 + lane, y0 = blk * LOSS_ROWS;
+    const int y_end = min(y0 + LOSS_ROWS, H);                       // useful rows: y0 .. y_end - 1
+    const bool own_x = lane >= 1 && lane <= LOSS_COLS && x < W;     // this lane's pixels are written by this wave
+    const int xc = min(max(x, 0), W - 1);
+    const bool pair_x = x >= 1 && x < W;                            // the pair (x - 1, x) exists
+    const float w_sx = pair_x ? prm.w_smooth_x : 0.0f, w_bx = pair_x ? prm.w_bilat_x : 0.0f;
+    const float *img = image + (size_t)b * 3 * HW, *dep = DEPTH ? depth + (size_t)b * HW : nullptr;
+    const float *nrm = NORMAL ? normal + (size_t)b * 3 * HW : nullptr;
+    const float *gtb = prm.gt_image[b] ? prm.gt_image[b] : gt + (size_t)b * 3 * HW;
+    const float *mkb = prm.mask_image[b] ? prm.mask_image[b] : mask + (size_t)b * mask_stride;
+    const float *alp = alpha + (size_t)b * HW;
+    const float *sgb = ssim_grad ? ssim_grad + (size_t)b * 3 * HW : nullptr;
     const float wm = prm.w_mse[b];
+
+    auto load_row = [&](int r, RowLoad<DEPTH, NORMAL> &L) {
+      const unsigned off = 4u * (unsigned)(min(max(r, 0), H - 1) * W + xc);
+      L.raw[0] = ld(img, off), L.raw[1] = ld(img + HW, off), L.raw[2] = ld(img + 2 * HW, off);
+      if (DEPTH) L.d = ld(dep, off);
+      if (NORMAL) L.n[0] = ld(nrm, off), L.n[1] = ld(nrm + HW, off), L.n[2] = ld(nrm + 2 * HW, off);
+      if (r >= y0 && r < y_end) {  // wave-uniform: the per-pixel terms only exist for the rows this wave writes
+        L.gt[0] = ld(gtb, off), L.gt[1] = ld(gtb + HW, off), L.gt[2] = ld(gtb + 2 * HW, off);
+        L.a = ld(alp, off), L.m = ld(mkb, off);
+        if (sgb) L.sg[0] = ld(sgb, off), L.sg[1] = ld(sgb + HW, off), L.sg[2] = ld(sgb + 2 * HW, off);
+      }
+    };
+
+    Px Pp;            // previous row: pixel, accumulated gradient, what its write-out still needs
+    Grad gp;
+    float raw_p[3], ga_p = 0.0f, a_p = 0.0f;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const float *gtb = prm.gt_image[b] ? prm.gt_image[b] : gt + (size_t)b * 3 * HW;
-      const float e = P.c[k] - gtb[k * HW + pix];
-      loss += wm * e * e;
-      gc[k] += 2.0f * wm * e;
-    }
-    const float a = alpha[(size_t)b * HW + pix];
-    const float em = a - (prm.mask_image[b] ? prm.mask_image[b][pix] : mask[(size_t)b * mask_stride + pix]);
-    loss += prm.w_mask * em * em;
-    g_alpha[(size_t)b * HW + pix] = 2.0f * prm.w_mask * em;
-    float dot = 2.0f * prm.w_mask * em * a;  // sum over the channels of gradient x rendered value (see g_dot)
-    // stencil terms.  The four neighbours are loaded UNCONDITIONALLY (clamped to the pixel itself at the image
-    // border, where the pair's weights are zero): a branch around each neighbour's loads made the compiler wait for
-    // them one after the other -- four dependent memory round trips per pixel.
-    if (DEPTH || NORMAL) {
-      const bool vr = x + 1 < W, vd = y + 1 < H, vl = x > 0, vu = y > 0;
-      const Px QR = load_px<DEPTH, NORMAL>(img, dep, nrm, HW, vr ? pix + 1 : pix);
-      const Px QD = load_px<DEPTH, NORMAL>(img, dep, nrm, HW, vd ? pix + W : pix);
-      const Px QL = load_px<DEPTH, NORMAL>(img, dep, nrm, HW, vl ? pix - 1 : pix);
-      const Px QU = load_px<DEPTH, NORMAL>(img, dep, nrm, HW, vu ? pix - W : pix);
-      loss += pair_term<DEPTH, NORMAL>(P, QR, 1.0f, vr ? prm.w_smooth_x : 0.0f, vr ? prm.w_bilat_x : 0.0f, gc, gd, gn);
-      loss += pair_term<DEPTH, NORMAL>(P, QD, 1.0f, vd ? prm.w_smooth_y : 0.0f, vd ? prm.w_bilat_y : 0.0f, gc, gd, gn);
-      (void)pair_term<DEPTH, NORMAL>(QL, P, -1.0f, vl ? prm.w_smooth_x : 0.0f, vl ? prm.w_bilat_x : 0.0f, gc, gd, gn);
-      (void)pair_term<DEPTH, NORMAL>(QU, P, -1.0f, vu ? prm.w_smooth_y : 0.0f, vu ? prm.w_bilat_y : 0.0f, gc, gd, gn);
-    }
+    for (int k = 0; k < 3; ++k) Pp.c[k] = Pp.n[k] = gp.c[k] = gp.n[k] = raw_p[k] = 0.0f;
+    Pp.d = gp.d = 0.0f;
+
+    auto process = [&](int r, const RowLoad<DEPTH, NORMAL> &cur) {
+      const bool own_row = r >= y0 && r < y_end;
+      Px P;
+      P.c[0] = clamp01(cur.raw[0]), P.c[1] = clamp01(cur.raw[1]), P.c[2] = clamp01(cur.raw[2]);
+      P.d = DEPTH ? cur.d : 0.0f;
+      P.n[0] = NORMAL ? cur.n[0] : 0.0f, P.n[1] = NORMAL ? cur.n[1] : 0.0f, P.n[2] = NORMAL ? cur.n[2] : 0.0f;
+      Grad g;
+      g.c[0] = g.c[1] = g.c[2] = g.d = g.n[0] = g.n[1] = g.n[2] = 0.0f;
+      float ga = 0.0f;
+      if (own_row) {
+        float l = 0.0f;
+        // per-pixel terms: weighted MSE on the clamped image, mask MSE on alpha, the SSIM gradient
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      float g = gc[k];
-      if (ssim_grad) g += ssim_grad[(size_t)b * 3 * HW + k * HW + pix];
-      const float raw = img[k * HW + pix];
-      g = (raw >= 0.0f && raw <= 1.0f) ? g : 0.0f;  // clamp backward
-      g_image[(size_t)b * 3 * HW + k * HW + pix] = g;
-      dot += g * raw;
-    }
-    if (g_depth) g_depth[(size_t)b * HW + pix] = gd, dot += gd * P.d;
-    if (NORMAL) {
+        for (int k = 0; k < 3; ++k) {
+          const float e = P.c[k] - cur.gt[k];
+          l += wm * e * e;
+          g.c[k] = 2.0f * wm * e + (sgb ? cur.sg[k] : 0.0f);
+        }
+        const float em = cur.a - cur.m;
+        l += prm.w_mask * em * em;
+        ga = 2.0f * prm.w_mask * em;
+        if (DEPTH || NORMAL) {
+          // horizontal pair (x - 1, x): this lane is B, lane - 1 is A
+          Px A;
 #pragma unroll
-      for (int k = 0; k < 3; ++k) g_normal[(size_t)b * 3 * HW + k * HW + pix] = gn[k], dot += gn[k] * P.n[k];
+          for (int k = 0; k < 3; ++k) A.c[k] = from_lane_below(P.c[k]), A.n[k] = NORMAL ? from_lane_below(P.n[k]) : 0.0f;
+          A.d = DEPTH ? from_lane_below(P.d) : 0.0f;
+          Grad t;
+          l += pair_term<DEPTH, NORMAL>(A, P, w_sx, w_bx, t);  // (counted where B is an own pixel: each pair once)
+          add(g, t, -1.0f);
+          Grad ta;  // lane + 1's pair has this lane as A
+#pragma unroll
+          for (int k = 0; k < 3; ++k) ta.c[k] = from_lane_above(t.c[k]), ta.n[k] = NORMAL ? from_lane_above(t.n[k]) : 0.0f;
+          ta.d = DEPTH ? from_lane_above(t.d) : 0.0f;
+          add(g, ta, 1.0f);
+        }
+        if (own_x) loss += l;
+      }
+      if ((DEPTH || NORMAL) && r >= y0) {
+        // vertical pair (r - 1, r): completes row r - 1
+        const bool pair_y = r >= 1 && r < H && x >= 0 && x < W;
+        Grad t;
+        const float l = pair_term<DEPTH, NORMAL>(Pp, P, pair_y ? prm.w_smooth_y : 0.0f, pair_y ? prm.w_bilat_y : 0.0f, t);
+        if (own_row && own_x) loss += l;  // counted with its lower row
+        add(gp, t, 1.0f);
+        add(g, t, -1.0f);
+      }
+      if (r > y0 && own_x) {  // row r - 1 is an own row and complete
+        const unsigned off = 4u * (unsigned)((r - 1) * W + x);
+        float dot = ga_p * a_p;  // sum over the channels of gradient x rendered value (see g_dot)
+        st(g_alpha + (size_t)b * HW, off, ga_p);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const float gk = (raw_p[k] >= 0.0f && raw_p[k] <= 1.0f) ? gp.c[k] : 0.0f;  // clamp backward
+          st(g_image + (size_t)b * 3 * HW + k * HW, off, gk);
+          dot += gk * raw_p[k];
+        }
+        if (g_depth) st(g_depth + (size_t)b * HW, off, gp.d), dot += gp.d * Pp.d;
+        if (NORMAL) {
+#pragma unroll
+          for (int k = 0; k < 3; ++k) st(g_normal + (size_t)b * 3 * HW + k * HW, off, gp.n[k]), dot += gp.n[k] * Pp.n[k];
+        }
+        if (g_dot) st(g_dot + (size_t)b * HW, off, dot);
+      }
+      Pp = P, gp = g, ga_p = ga, a_p = cur.a;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) raw_p[k] = cur.raw[k];
+    };
+
+    // rows y0 - 1 .. y_end through a ring of three buffers: two rows are in flight while one is processed (a wave
+    // holds ~4 KB per row; with one row ahead the chip had < 9 MB in flight and the kernel ran in bursts at 3.3 TB/s).
+    // The ring is unrolled by hand: moving a buffer whose loads are in flight would wait for them.
+    RowLoad<DEPTH, NORMAL> L0{}, L1{}, L2{};
+    load_row(y0 - 1, L0);
+    load_row(y0, L1);
+    for (int r = y0 - 1; r <= y_end; r += 3) {
+      if (r + 2 <= y_end) load_row(r + 2, L2);
+      process(r, L0);
+      if (r + 1 > y_end) break;
+      if (r + 3 <= y_end) load_row(r + 3, L0);
+      process(r + 1, L1);
+      if (r + 2 > y_end) break;
+      if (r + 4 <= y_end) load_row(r + 4, L1);
+      process(r + 2, L2);
     }
-    if (g_dot) g_dot[(size_t)b * HW + pix] = dot;
-  }
-  }  // tiles
+  }  // units
   float v = loss;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
@@ -181,8 +280,10 @@ extern "C" int dimo_image_loss(int B, int H, int W, const float *image, const fl
   }
   prm.w_mask = w_mask, prm.w_smooth_x = w_smooth_x, prm.w_smooth_y = w_smooth_y;
   prm.w_bilat_x = w_bilat_x, prm.w_bilat_y = w_bilat_y;
-  const long tiles = (long)((W + 31) / 32) * ((H + 7) / 8) * B;
-  const dim3 grid((unsigned)(tiles < 1024 ? tiles : 1024)), block(256);
+  if ((long)H * W > (1L << 28)) return DIMO_E_ARG;  // byte offsets inside an image are 32-bit
+  const long units = (long)((W + LOSS_COLS - 1) / LOSS_COLS) * ((H + LOSS_ROWS - 1) / LOSS_ROWS) * B;  // one per wave
+  const long wgs = (units + 3) / 4;
+  const dim3 grid((unsigned)(wgs < 2048 ? wgs : 2048)), block(256);
   const size_t mstride = mask_per_image ? (size_t)H * W : 0;
   ScopedTimer tm(T_LOSS, stream);
 #define DIMO_LAUNCH_LOSS(D, N)                                                                                  \

@@ -79,6 +79,26 @@ __device__ __forceinline__ void taps(const Window &win, const float (&in)[NIN], 
   }
 }
 
+// SSIM of one pixel from the filtered maps mu1 = E[x], mu2 = E[y], e_sq = E[x^2 + y^2], e12 = E[xy], and its total
+// derivatives w.r.t. mu1, E[x^2] and E[xy] (sigma terms expanded; src/loss.py:144-175).  The reciprocals are
+// v_rcp_f32 (1 ulp) instead of IEEE divisions (10 instructions each, twice per pixel of the halo).
+struct SsimPoint {
+  float m, d_mu1, d_e11, d_e12;
+};
+__device__ __forceinline__ SsimPoint ssim_point(float mu1, float mu2, float e_sq, float e12) {
+  const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
+  const float s12 = e12 - mu12;
+  const float A1 = 2.0f * mu12 + SSIM_C1, A2 = 2.0f * s12 + SSIM_C2;
+  const float B1 = mu1_sq + mu2_sq + SSIM_C1, B2 = (e_sq - mu1_sq - mu2_sq) + SSIM_C2;
+  const float inv = __builtin_amdgcn_rcpf(B1 * B2);
+  SsimPoint r;
+  r.m = A1 * A2 * inv;
+  r.d_mu1 = (2.0f * mu2 * (A2 - A1) - r.m * 2.0f * mu1 * (B2 - B1)) * inv;
+  r.d_e11 = -r.m * __builtin_amdgcn_rcpf(B2);
+  r.d_e12 = 2.0f * A1 * inv;
+  return r;
+}
+
 __global__ void __launch_bounds__(256) ssim_fwd_kernel(int H, int W, int n_planes, int clamp1, Window win,
                                                        const float *__restrict__ img1,
                                                        const float *__restrict__ img2,
@@ -115,13 +135,13 @@ __global__ void __launch_bounds__(256) ssim_fwd_kernel(int H, int W, int n_plane
     float x[18], y[18];
 #pragma unroll
     for (int i = 0; i < 18; ++i) x[i] = s_x[ly][c0 + i], y[i] = s_y[ly][c0 + i];
-    float st[5][4];
+    float st[4][4];
 #pragma unroll
-    for (int q = 0; q < 5; ++q) {  // maps: x, y, x^2, y^2, x y
+    for (int q = 0; q < 4; ++q) {  // maps: x, y, x^2 + y^2, x y (the two variances only ever appear as their sum)
       if (hrow) {
         float v[18], o[8];
 #pragma unroll
-        for (int i = 0; i < 18; ++i) v[i] = q == 0 ? x[i] : q == 1 ? y[i] : q == 2 ? x[i] * x[i] : q == 3 ? y[i] * y[i] : x[i] * y[i];
+        for (int i = 0; i < 18; ++i) v[i] = q == 0 ? x[i] : q == 1 ? y[i] : q == 2 ? x[i] * x[i] + y[i] * y[i] : x[i] * y[i];
         taps<8, 18>(win, v, o);
 #pragma unroll
         for (int i = 0; i < 8; ++i) s_h[ly][c0 + i] = o[i];
@@ -138,20 +158,13 @@ __global__ void __launch_bounds__(256) ssim_fwd_kernel(int H, int W, int n_plane
     for (int i = 0; i < 4; ++i) {
       const int gy = y0 + r0 + i;
       if (gx < W && gy < H) {
-        const float mu1 = st[0][i], mu2 = st[1][i], e11 = st[2][i], e22 = st[3][i], e12 = st[4][i];
-        const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
-        const float s1 = e11 - mu1_sq, s2 = e22 - mu2_sq, s12 = e12 - mu12;
-        const float A1 = 2.0f * mu12 + SSIM_C1, A2 = 2.0f * s12 + SSIM_C2;
-        const float B1 = mu1_sq + mu2_sq + SSIM_C1, B2 = s1 + s2 + SSIM_C2;
-        const float inv = 1.0f / (B1 * B2);
-        const float m = A1 * A2 * inv;
-        m_acc += m;
+        const SsimPoint sp = ssim_point(st[0][i], st[1][i], st[2][i], st[3][i]);
+        m_acc += sp.m;
         if (partials) {
-          // total derivatives w.r.t. mu1, E[x^2], E[xy] (sigma terms expanded)
           const size_t o = (size_t)plane * H * W + (size_t)gy * W + gx;
-          partials[o] = (2.0f * mu2 * (A2 - A1) - m * 2.0f * mu1 * (B2 - B1)) * inv;
-          partials[plane_stride_total + o] = -m / B2;
-          partials[2 * plane_stride_total + o] = 2.0f * A1 * inv;
+          partials[o] = sp.d_mu1;
+          partials[plane_stride_total + o] = sp.d_e11;
+          partials[2 * plane_stride_total + o] = sp.d_e12;
         }
       }
     }
@@ -230,7 +243,23 @@ __global__ void __launch_bounds__(256) ssim_bwd_kernel(int H, int W, int n_plane
 // halo of its 32x32 tile from a 52x52 input halo (2.6x the pixels, all VALU), keeps the derivative planes in LDS,
 // and applies the window a second time.  Positions outside the image carry zero derivatives (the zero padding of
 // the backward convolution).
+//
+// The kernel is bound by the LDS pipe, not by its FMAs (profiles/r03_ssim_bisection.txt: with every tap removed
+// it still took 58 of 66 us; with the global loads removed as well, 50).  So the first window pass runs VERTICALLY
+// straight from registers: a thread loads 21 rows of one input column from global memory (lanes along the row:
+// coalesced), filters the four maps and writes 11 rows of each -- the inputs never visit the LDS.  The horizontal pass
+// then reads rows with ds_read_b128 (row stride 52 floats = 13 x 16 B: the 16 lanes of a read group hold 16 different
+// rows and fall on 16 different 16-byte slots) and keeps the statistics of its 8 pixels in registers.  LDS cycles per
+// tile (tools/lds_rate.hip): ~2400 against ~5100 for the version that staged the inputs and filtered horizontally
+// first; barriers per tile 9 against 16.  66 -> 51 us for 4 x 3 x 512^2, 103 -> 92 us for 8 x 3 x 512^2.
 constexpr int IS = HS + 2 * SR;  // 52: input halo edge
+constexpr int MS = IS;           // row stride of a vertically filtered map (42 rows x 52 columns)
+constexpr int MAP_WORDS = HS * MS;
+constexpr int PS = 52;           // row stride of a derivative plane on the 42 x 42 halo (same slot argument)
+constexpr int V_ROWS = 11;       // rows of the 42 a thread of the vertical pass produces (from 21 input rows)
+// 168 VGPRs: THREE workgroups per CU, persistent (grid = 3 x 256 CUs).  At 128 VGPRs (four per CU) the vertical pass
+// spilled 61 registers: 83 us against 51; one tile per workgroup instead of the persistent loop: 59.
+constexpr int SSIM_WGS_PER_CU = 3, SSIM_GRID = SSIM_WGS_PER_CU * 256;
 // Optional per-image base pointers of img2 (the targets of a batch live in a resident pool, one tensor per image:
 // stacking them cost two copy kernels per motion at the head of every step).  n == 0: img2 is one contiguous tensor.
 constexpr int SSIM_MAX_IMAGES = 32;
@@ -238,125 +267,199 @@ struct ImagePtrs {
   int n, channels;
   const float *p[SSIM_MAX_IMAGES];
 };
-__global__ void __launch_bounds__(256, 4) ssim_fused_kernel(int H, int W, int n_planes, int clamp1, Window win,
+// Optional phase trace of the fused kernel (tools/ssim_bisect.hip, -DDIMO_SSIM_TRACE): wave 0 of a workgroup stamps
+// the 100 MHz clock at the phase boundaries of its first tile.
+#ifdef DIMO_SSIM_TRACE
+__device__ unsigned long long *g_ssim_trace = nullptr;  // [workgroups][16]
+#define SSIM_MARK(k)                                                                                      \
+  do {                                                                                                    \
+    if (g_ssim_trace && tid == 0 && tile == (int)blockIdx.x) g_ssim_trace[blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#else
+#define SSIM_MARK(k)
+#endif
+__global__ void __launch_bounds__(256, SSIM_WGS_PER_CU) ssim_fused_kernel(int H, int W, int n_planes, int clamp1, Window win,
                                                          const float *__restrict__ img1,
                                                          const float *__restrict__ img2, ImagePtrs img2_images,
                                                          const float *__restrict__ dL_dmean, float inv_numel,
                                                          float *__restrict__ ssim_sum, float *__restrict__ dL_dimg1) {
-  // 31 KB of LDS per workgroup (53 KB in round 1: three workgroups then owned ALL of a CU's LDS, and in the
-  // two-stream schedule no blend workgroup of the other motion could join them on that CU -- the kernel showed 200+ us
-  // there against 77 us alone).  The derivative planes live over the input planes, which are dead once the five maps
-  // are filtered; x and y of the tile's own pixels are re-read from global at the end.  128 VGPRs: FOUR workgroups
-  // per CU (the phases of a tile are short and separated by barriers, so the kernel lives on the other workgroups'
-  // waves: 80 -> 71 us for 8 x 3 x 512^2 against three per CU with x / y held in registers).
-  __shared__ float s_xy[2][IS][IS + 1];
-  __shared__ float s_h[IS][HS + 1];      // horizontally filtered map (52 x 42); reused as 42 x 32 in the second pass
+  // 40 KB of LDS per workgroup (three workgroups leave 39 KB of a CU's LDS to the other motion's blend workgroups in
+  // the two-stream schedule).  The derivative planes live over the filtered maps, which are dead once the statistics
+  // are in registers; x and y of the tile's own pixels are re-read from global before the second pass.
+  __shared__ __attribute__((aligned(16))) float s_m[4 * MAP_WORDS + 8];  // four maps (+ the last row's over-read)
+  __shared__ float s_h[HS][TS + 1];  // second pass: horizontally filtered derivative plane (42 x 32)
   __shared__ float s_red[4];
-  static_assert(3 * HS * (HS + 1) <= 2 * IS * (IS + 1), "derivative planes must fit over the input planes");
-  float (*s_x)[IS + 1] = s_xy[0], (*s_y)[IS + 1] = s_xy[1];
+  static_assert(3 * HS * PS <= 4 * MAP_WORDS, "derivative planes must fit over the filtered maps");
+  float *const s_p = s_m;  // [3][HS][PS]
   const WindowV winv = window_to_vgprs(win);
-  float (*s_p)[HS][HS + 1] = reinterpret_cast<float (*)[HS][HS + 1]>(&s_xy[0][0][0]);  // derivative planes on the halo
   const int tid = threadIdx.x;
   const int tiles_x = (W + TS - 1) / TS, tiles_y = (H + TS - 1) / TS;
   const int total_tiles = tiles_x * tiles_y * n_planes;
   const float scale = dL_dmean[0] * inv_numel;
-  // first pass, horizontal: 52 rows x 3 groups of 14 columns; vertical: 42 columns x 6 groups of 7 rows
-  const bool h1 = tid < IS * 3;
-  const int h1_row = h1 ? tid / 3 : 0, h1_c0 = (tid % 3) * 14;
-  const bool v1 = tid < HS * 6;
-  const int v1_c = v1 ? tid % HS : 0, v1_r0 = v1 ? (tid / HS) * 7 : 0;
-  // second pass (as ssim_bwd_kernel): horizontal 42 rows x 4 groups of 8; vertical column c, rows r0 .. r0 + 3
+  // first pass, vertical: 52 columns x 4 row groups (rows 0-10, 11-21, 22-32, 31-41 of the 42: the last overlaps)
+  const bool v1 = tid < IS * 4;
+  const int v1_c = tid % IS, v1_r0 = min((tid / IS) * V_ROWS, HS - V_ROWS);
+  // first pass, horizontal: 42 rows x 6 groups of 8 columns (the last group: columns 40, 41 and six unused ones)
+  const bool h1 = tid < HS * 6;
+  const int h1_row = tid % HS, h1_c0 = (tid / HS) * 8;
+  // second pass, horizontal: 42 rows x 4 groups of 8; vertical: column c, rows r0 .. r0 + 3
   const bool h2 = tid < HS * (TS / 8);
-  const int h2_row = h2 ? tid / (TS / 8) : 0, h2_c0 = (tid % (TS / 8)) * 8;
+  const int h2_row = tid % HS, h2_c0 = (tid / HS) * 8;
   const int c = tid & (TS - 1), r0 = (tid >> 5) * 4;
   float m_acc = 0.0f;
-  for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
-    const int plane = tile / (tiles_x * tiles_y);
-    const int x0 = (tile % tiles_x) * TS, y0 = ((tile / tiles_x) % tiles_y) * TS;
-    const float *p1 = img1 + (size_t)plane * H * W;
-    const float *p2 = img2_images.n ? img2_images.p[plane / img2_images.channels] +
-                                          (size_t)(plane % img2_images.channels) * H * W
-                                    : img2 + (size_t)plane * H * W;
-    __syncthreads();  // the previous tile's LDS has been consumed
-    for (int t = tid; t < IS * IS; t += 256) {
-      const int hy = t / IS, hx = t - hy * IS;
-      const int gy = y0 + hy - 2 * SR, gx = x0 + hx - 2 * SR;
-      const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
-      const size_t o = in ? (size_t)gy * W + gx : 0;
-      const float a = p1[o], b = p2[o];
-      s_x[hy][hx] = in ? maybe_clamp(a, clamp1) : 0.0f;
-      s_y[hy][hx] = in ? b : 0.0f;
-    }
-    __syncthreads();
-    float st[5][7];
+  struct Tile {
+    int plane, x0, y0;
+    const float *p1, *p2;
+  };
+  auto tile_at = [&](int tile) {
+    Tile t;
+    t.plane = tile / (tiles_x * tiles_y);
+    t.x0 = (tile % tiles_x) * TS, t.y0 = ((tile / tiles_x) % tiles_y) * TS;
+    t.p1 = img1 + (size_t)t.plane * H * W;
+    t.p2 = img2_images.n ? img2_images.p[t.plane / img2_images.channels] +
+                               (size_t)(t.plane % img2_images.channels) * H * W
+                         : img2 + (size_t)t.plane * H * W;
+    return t;
+  };
+  float xs[2 * V_ROWS - 1], ys[2 * V_ROWS - 1];  // 21 input rows of this thread's column
+  // Requests the inputs of a tile: address = scalar row base + one 32-bit lane offset for all 21 rows.  Tiles whose
+  // 52 x 52 halo lies inside the image (three in four at 512^2) load unconditionally; the others mask the lanes
+  // outside off, and nothing inside the masked region may USE a loaded value (a use makes the loads wait for one
+  // another: 5 us for the 42 -- the clamp of img1 is applied when the vertical pass reads the registers).
+  auto request = [&](const Tile &t) {
+    if (!v1) return;
+    const int gx = t.x0 + v1_c - 2 * SR, gy0 = t.y0 + v1_r0 - 2 * SR;
+    const unsigned off = 4u * (unsigned)(v1_r0 * W + gx);
+    const bool interior = t.x0 >= 2 * SR && t.x0 + TS + 2 * SR <= W && t.y0 >= 2 * SR && t.y0 + TS + 2 * SR <= H;
+    if (interior) {
 #pragma unroll
-    for (int q = 0; q < 5; ++q) {  // maps: x, y, x^2, y^2, x y
-      if (h1) {
-        float v[24], o[14];
+      for (int i = 0; i < 2 * V_ROWS - 1; ++i) {
+        const ptrdiff_t row = (ptrdiff_t)(t.y0 + i - 2 * SR) * W;
+        xs[i] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(t.p1 + row) + off);
+        ys[i] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(t.p2 + row) + off);
+      }
+    } else {
+      const bool in_x = gx >= 0 && gx < W;
 #pragma unroll
-        for (int i = 0; i < 24; ++i) {  // (re-read from LDS per map: holding x and y cost 48 VGPRs = one wave per SIMD)
-          const float a = (q == 1 || q == 3) ? s_y[h1_row][h1_c0 + i] : s_x[h1_row][h1_c0 + i];
-          v[i] = q < 2 ? a : q < 4 ? a * a : a * s_y[h1_row][h1_c0 + i];
+      for (int i = 0; i < 2 * V_ROWS - 1; ++i) {
+        const ptrdiff_t row = (ptrdiff_t)(t.y0 + i - 2 * SR) * W;
+        float a = 0.0f, b = 0.0f;
+        if (in_x && gy0 + i >= 0 && gy0 + i < H) {
+          a = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(t.p1 + row) + off);
+          b = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(t.p2 + row) + off);
         }
-        taps<14, 24>(winv, v, o);
-#pragma unroll
-        for (int i = 0; i < 14; ++i) s_h[h1_row][h1_c0 + i] = o[i];
+        xs[i] = a, ys[i] = b;
       }
-      __syncthreads();
-      float col[17];
-#pragma unroll
-      for (int i = 0; i < 17; ++i) col[i] = s_h[v1_r0 + i][v1_c];
-      taps<7, 17>(winv, col, st[q]);
-      __syncthreads();
     }
+  };
+  // The workgroups are persistent (three per CU).  Requesting the NEXT tile's inputs early (after the vertical pass,
+  // or before the second window pass) was slower: 42 more live registers, and the requests' issue slots are the cost,
+  // not their latency (55-65 us against 51).  Barriers order LDS traffic only (lds_barrier).
+  for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
+    const Tile cur = tile_at(tile);
+    const int plane = cur.plane, x0 = cur.x0, y0 = cur.y0;
+    const float *p1 = cur.p1, *p2 = cur.p2;
+    SSIM_MARK(0);
+    request(cur);
+    SSIM_MARK(1);
+    lds_barrier();  // the previous tile's LDS has been consumed
+    SSIM_MARK(2);
     if (v1) {
-      const int gx = x0 + v1_c - SR;
 #pragma unroll
-      for (int i = 0; i < 7; ++i) {
-        const int hy = v1_r0 + i, gy = y0 + hy - SR;
-        const bool in = gx >= 0 && gx < W && gy >= 0 && gy < H;
-        const float mu1 = st[0][i], mu2 = st[1][i], e11 = st[2][i], e22 = st[3][i], e12 = st[4][i];
-        const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
-        const float s1 = e11 - mu1_sq, s2 = e22 - mu2_sq, s12 = e12 - mu12;
-        const float A1 = 2.0f * mu12 + SSIM_C1, A2 = 2.0f * s12 + SSIM_C2;
-        const float B1 = mu1_sq + mu2_sq + SSIM_C1, B2 = s1 + s2 + SSIM_C2;
-        const float inv = 1.0f / (B1 * B2);
-        const float m = A1 * A2 * inv;
-        const bool own = hy >= SR && hy < SR + TS && v1_c >= SR && v1_c < SR + TS;  // this tile's 32 x 32 outputs
-        if (in && own) m_acc += m;
-        s_p[0][hy][v1_c] = in ? (2.0f * mu2 * (A2 - A1) - m * 2.0f * mu1 * (B2 - B1)) * inv : 0.0f;
-        s_p[1][hy][v1_c] = in ? -m / B2 : 0.0f;
-        s_p[2][hy][v1_c] = in ? 2.0f * A1 * inv : 0.0f;
+      for (int i = 0; i < 2 * V_ROWS - 1; ++i) xs[i] = maybe_clamp(xs[i], clamp1);  // (0 outside the image stays 0)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {  // maps: x, y, x^2 + y^2, x y (the two variances only ever appear as their sum)
+        float v[2 * V_ROWS - 1], o[V_ROWS];
+#pragma unroll
+        for (int i = 0; i < 2 * V_ROWS - 1; ++i)
+          v[i] = q == 0 ? xs[i] : q == 1 ? ys[i] : q == 2 ? xs[i] * xs[i] + ys[i] * ys[i] : xs[i] * ys[i];
+        taps<V_ROWS, 2 * V_ROWS - 1>(winv, v, o);
+#pragma unroll
+        for (int j = 0; j < V_ROWS; ++j) s_m[q * MAP_WORDS + (v1_r0 + j) * MS + v1_c] = o[j];
       }
+    }
+    SSIM_MARK(3);
+    lds_barrier();
+    SSIM_MARK(4);
+    float d[3][8];  // derivative planes of this thread's 8 halo pixels
+    if (h1) {
+      float st[4][8];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float in[20];
+        const float4 *row = reinterpret_cast<const float4 *>(&s_m[q * MAP_WORDS + h1_row * MS + h1_c0]);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+          const float4 t = row[i];
+          in[4 * i] = t.x, in[4 * i + 1] = t.y, in[4 * i + 2] = t.z, in[4 * i + 3] = t.w;
+        }
+        taps<8, 20>(winv, in, st[q]);
+      }
+      const int gy = y0 + h1_row - SR;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int hx = h1_c0 + i, gx = x0 + hx - SR;
+        const bool in = hx < HS && gx >= 0 && gx < W && gy >= 0 && gy < H;
+        const SsimPoint sp = ssim_point(st[0][i], st[1][i], st[2][i], st[3][i]);
+        const bool own = h1_row >= SR && h1_row < SR + TS && hx >= SR && hx < SR + TS;  // this tile's 32 x 32 outputs
+        if (in && own) m_acc += sp.m;
+        d[0][i] = in ? sp.d_mu1 : 0.0f, d[1][i] = in ? sp.d_e11 : 0.0f, d[2][i] = in ? sp.d_e12 : 0.0f;
+      }
+    }
+    SSIM_MARK(5);
+    lds_barrier();  // every map has been read: the derivative planes may overwrite them
+    SSIM_MARK(6);
+    if (h1) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        float4 *row = reinterpret_cast<float4 *>(&s_p[(k * HS + h1_row) * PS + h1_c0]);
+        row[0] = make_float4(d[k][0], d[k][1], d[k][2], d[k][3]);
+        row[1] = make_float4(d[k][4], d[k][5], d[k][6], d[k][7]);
+      }
+    }
+    // x and y of this thread's four output pixels (used after the second pass), then the next tile's inputs: the
+    // statistics' registers are free now (requesting right after the vertical pass spilled: 48 -> 65 us)
+    const int gx = x0 + c;
+    float xo[4], yo[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int gy = y0 + r0 + i;
+      const int o = (gx < W && gy < H) ? gy * W + gx : 0;
+      xo[i] = p1[o], yo[i] = p2[o];
     }
     float g[3][4];
+    SSIM_MARK(7);
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
-      __syncthreads();  // s_p complete (q = 0) / s_h free again
+    for (int q = 0; q < 3; ++q) {  // (sharing the barriers between the planes, with a buffer each, changed nothing)
+      lds_barrier();  // s_p complete (q = 0) / s_h free again
       if (h2) {
-        float v[18], o[8];
+        float in[20], o[8];
+        const float4 *row = reinterpret_cast<const float4 *>(&s_p[(q * HS + h2_row) * PS + h2_c0]);
 #pragma unroll
-        for (int i = 0; i < 18; ++i) v[i] = s_p[q][h2_row][h2_c0 + i];
-        taps<8, 18>(winv, v, o);
+        for (int i = 0; i < 5; ++i) {
+          const float4 t = row[i];
+          in[4 * i] = t.x, in[4 * i + 1] = t.y, in[4 * i + 2] = t.z, in[4 * i + 3] = t.w;
+        }
+        taps<8, 20>(winv, in, o);
 #pragma unroll
         for (int i = 0; i < 8; ++i) s_h[h2_row][h2_c0 + i] = o[i];
       }
-      __syncthreads();
+      lds_barrier();
       float col[14];
 #pragma unroll
       for (int i = 0; i < 14; ++i) col[i] = s_h[r0 + i][c];
       taps<4, 14>(winv, col, g[q]);
     }
-    const int gx = x0 + c;
+    SSIM_MARK(8);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int gy = y0 + r0 + i;
       if (gx < W && gy < H) {
         const size_t o = (size_t)gy * W + gx;
-        const float xv = maybe_clamp(p1[o], clamp1), yv = p2[o];
-        dL_dimg1[(size_t)plane * H * W + o] = (g[0][i] + 2.0f * xv * g[1][i] + yv * g[2][i]) * scale;
+        dL_dimg1[(size_t)plane * H * W + o] = (g[0][i] + 2.0f * maybe_clamp(xo[i], clamp1) * g[1][i] + yo[i] * g[2][i]) * scale;
       }
     }
+    SSIM_MARK(9);
   }  // tiles
   float v = m_acc;
 #pragma unroll
@@ -441,7 +544,7 @@ static int ssim_forward_backward_impl(int B, int C, int H, int W, int clamp_img1
     if (!ptrs.p[b]) return DIMO_E_ARG;
   static const Window win = make_window();
   const long tiles = (long)((W + TS - 1) / TS) * ((H + TS - 1) / TS) * planes;
-  const dim3 grid((unsigned)(tiles < 4096 ? tiles : 4096)), block(256);
+  const dim3 grid((unsigned)(tiles < SSIM_GRID ? tiles : SSIM_GRID)), block(256);
   ScopedTimer tm(T_SSIM_FWD, stream);
   hipLaunchKernelGGL(ssim_fused_kernel, grid, block, 0, stream, H, W, (int)planes, clamp_img1, win, img1, img2, ptrs,
                      dL_dmean, 1.0f / (float)((double)planes * H * W), ssim_sum, dL_dimg1);
