@@ -84,6 +84,11 @@ def kernel_rooflines(timing_iso, N, V, R, P, C=NFEAT, renders_in_window=None, vi
         "blend_bwd": (28 + 4 * C) * R + (8 * (C + 1) + 8) * P + (24 + 4 * C) * V,
         "preprocess_bwd": (24 + 4 * C) * V + 56 * N + 56 * N + 12 * N,
         "deform_bwd": 200 * N,
+        # per image of P pixels: SSIM value + gradient reads image and target (3 channels each), writes the gradient;
+        # the fused image losses read 15 planes (image 3, depth, normal 3, alpha, target 3, mask, SSIM gradient 3) and
+        # write 9 (the four gradient images + the gradient x value plane)
+        "ssim_fwd": 4 * 9 * P,
+        "image_loss": 4 * 24 * P,
     }
     out = {}
     for k, b in alg.items():
