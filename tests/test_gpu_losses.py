@@ -15,7 +15,11 @@ def _lam(cfg):
 
 
 @pytest.mark.parametrize("B,H,W,share,dn", [(4, 64, 48, 1.0, (True, True)), (1, 33, 70, 0.5, (True, False)),
-                                            (3, 128, 128, 0.75, (False, True)), (2, 40, 40, 1.0, (False, False))])
+                                            (3, 128, 128, 0.75, (False, True)), (2, 40, 40, 1.0, (False, False)),
+                                            # a wave owns 62 columns x 8 rows: one-column last strip, one-row last block
+                                            (2, 17, 125, 1.0, (True, True)), (1, 9, 63, 1.0, (True, True)),
+                                            (1, 2, 300, 1.0, (True, True)), (1, 70, 2, 1.0, (True, True)),
+                                            (2, 512, 512, 1.0, (True, True))])
 def test_image_loss_kernel_vs_reference_assembly(B, H, W, share, dn):
     from dimo_amd import _lib
     from dimo_amd.image_loss import fused_image_loss, loss_weights
@@ -49,8 +53,17 @@ def test_image_loss_kernel_vs_reference_assembly(B, H, W, share, dn):
     _lib.check(L.dimo_ssim_backward(B, 3, H, W, 1, _lib.ptr(img_d), _lib.ptr(gt_d), _lib.ptr(partials), _lib.ptr(coef), _lib.ptr(sg), st), "b")
     acc = torch.zeros(512, device="cuda")  # DIMO_LOSS_WORDS
     w_mse = [cfg.lambda_mse * w / (3 * H * W) for w in wts]
+    gdot = torch.full((B, 1, H, W), float("nan"), device="cuda")
     gi, gd, gn, ga = fused_image_loss(img_d, dep_d if dn[0] else None, nrm_d if dn[1] else None, alp_d, gt_d, mask_d,
-                                      w_mse, loss_weights(cfg, B, n_img, H, W), sg, acc)
+                                      w_mse, loss_weights(cfg, B, n_img, H, W), sg, acc, g_dot=gdot)
+    # the per-pixel plane the rasterizer backward consumes: sum over the channels of gradient x rendered value
+    want = (gi * img_d).sum(1, keepdim=True) + ga * alp_d
+    if gd is not None:
+        want = want + gd * dep_d
+    if gn is not None:
+        want = want + (gn * nrm_d).sum(1, keepdim=True)
+    assert torch.isfinite(gdot).all()
+    assert (gdot - want).abs().max().item() <= 1e-6 * max(want.abs().max().item(), 1e-12) + 1e-12
     loss = acc.sum().item() + cfg.lambda_ssim * (B / n_img) * (1 - ssum[0].item() / (B * 3 * H * W))
     assert abs(loss - ref.item()) <= 2e-5 * abs(ref.item()), (loss, ref.item())
     for got, leaf, name in ((gi, leaves[0], "image"), (gd, leaves[1], "depth"), (gn, leaves[2], "normal"),

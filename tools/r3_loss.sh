@@ -1,5 +1,5 @@
 #!/bin/bash
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p gpurun_out
-python tools/loss_probe.py 4 8 > gpurun_out/r3_loss.log 2>&1
+timeout 900 python -m pytest tests/test_gpu_losses.py -x -q 2>&1 | tail -15 > gpurun_out/r3_loss.log
 cat gpurun_out/r3_loss.log
