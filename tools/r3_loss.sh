@@ -1,6 +1,5 @@
 #!/bin/bash
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p gpurun_out
-timeout 1500 python -m pytest tests/test_gpu_losses.py tests/test_gpu_executor.py -x -q 2>&1 | tail -3 > gpurun_out/r3_loss.log
-for i in 1 2 3; do for m in 1 0; do echo -n "DIMO_DEFER_ACC=$m " >> gpurun_out/r3_loss.log; DIMO_DEFER_ACC=$m timeout 600 python bench.py --no-cpu-baseline --no-live-pmc --no-dropin --sustained-steps 0 --steps 100 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])" >> gpurun_out/r3_loss.log; done; done
-cat gpurun_out/r3_loss.log
+{ python tools/timenet_probe.py 30; timeout 600 python -m pytest tests/test_gpu_timenet.py -x -q 2>&1 | tail -3; } > gpurun_out/r3_tnq.log 2>&1
+cat gpurun_out/r3_tnq.log
