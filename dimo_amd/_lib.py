@@ -60,6 +60,7 @@ _SIGNATURES = {
     "dimo_executor_destroy": (None, [C.c_void_p]),
     "dimo_executor_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "dimo_executor_forward_range": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "dimo_executor_forward_range_on_caller": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "dimo_executor_join": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "dimo_executor_backward_launch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "dimo_executor_range_stream": (C.c_void_p, [C.c_void_p, C.c_int]),

@@ -276,6 +276,24 @@ extern "C" int dimo_executor_forward_range(void *h, const dimo_step_common *c, i
   return DIMO_OK;
 }
 
+// Batched ranges only: the forward chain of the range [first, first + count) ON THE CALLER'S STREAM, in order behind
+// what it holds (no cross-stream dependency: one costs 10-12 us on this platform, tools/xstream_latency.hip), while
+// other ranges of the step run on private streams.  dimo_executor_range_stream returns null for such a range and
+// dimo_executor_join / dimo_executor_backward_launch_joint have nothing to wait for.
+extern "C" int dimo_executor_forward_range_on_caller(void *h, const dimo_step_common *c, int first, int count,
+                                                     const dimo_render_desc *d, void *main_stream) {
+  Executor *ex = reinterpret_cast<Executor *>(h);
+  if (!ex || !c || first < 0 || count < 0 || (count > 0 && !d)) return DIMO_E_ARG;
+  if (count == 0) return DIMO_OK;
+  if (!ex->batched || ex->streams.empty()) return DIMO_E_ARG;
+  clear_errors();
+  const int rc = ensure_events(ex, first + count);
+  if (rc) return rc;
+  if (first == 0) std::fill(ex->range_stream.begin(), ex->range_stream.end(), -1);  // a new step's ranges
+  ex->range_stream[first] = (int)ex->streams.size(), ex->range_count[first] = count;  // marker: the caller's stream
+  return batched_forward(c, d, first, count, (hipStream_t)main_stream);
+}
+
 extern "C" int dimo_executor_forward(void *h, const dimo_step_common *c, int n, const dimo_render_desc *d,
                                      void *main_stream) {
   return dimo_executor_forward_range(h, c, 0, n, d, main_stream);
@@ -290,6 +308,7 @@ extern "C" int dimo_executor_join(void *h, int first, int count, void *main_stre
   if (first + count > (int)ex->fwd_done.size()) return DIMO_E_ARG;
   for (int i = first; i < first + count; ++i) {
     if (ex->batched && ex->range_stream[i] < 0) continue;  // only range starts carry an event
+    if (ex->batched && ex->range_stream[i] >= (int)ex->streams.size()) continue;  // a range on the caller's stream
     if (hipStreamWaitEvent(main, ex->fwd_done[i], 0) != hipSuccess) return DIMO_E_LAUNCH;
   }
   return DIMO_OK;
@@ -310,6 +329,7 @@ extern "C" int dimo_executor_backward_launch(void *h, const dimo_step_common *c,
   ex->bwd_on_main = false;
   if (ex->batched) {
     const int si = ex->range_stream[first] >= 0 ? ex->range_stream[first] : 0;
+    if (si >= S) return DIMO_E_ARG;  // a range on the caller's stream: use the joint launch
     hipStream_t s = ex->streams[si];
     int rc = fork_one(ex, main, s);
     if (!rc) rc = batched_backward_raster(c, d, first, count, s);
@@ -340,7 +360,7 @@ extern "C" void *dimo_executor_range_stream(void *h, int first) {
   Executor *ex = reinterpret_cast<Executor *>(h);
   if (!ex || !ex->batched || ex->streams.empty() || first < 0 || first >= (int)ex->range_stream.size()) return nullptr;
   const int si = ex->range_stream[first];
-  return si >= 0 ? (void *)ex->streams[si] : nullptr;
+  return si >= 0 && si < (int)ex->streams.size() ? (void *)ex->streams[si] : nullptr;
 }
 extern "C" int dimo_executor_backward_launch_in_order(void *h, const dimo_step_common *c, int first, int count,
                                                       const dimo_render_desc *d) {
@@ -349,7 +369,7 @@ extern "C" int dimo_executor_backward_launch_in_order(void *h, const dimo_step_c
   if (count == 0) return DIMO_OK;
   if (!ex->batched || ex->streams.empty() || first + count > (int)ex->render_done.size()) return DIMO_E_ARG;
   const int si = ex->range_stream[first];
-  if (si < 0) return DIMO_E_ARG;
+  if (si < 0 || si >= (int)ex->streams.size()) return DIMO_E_ARG;
   clear_errors();
   ex->bwd_on_main = false;
   hipStream_t s = ex->streams[si];
@@ -372,7 +392,7 @@ extern "C" int dimo_executor_backward_launch_joint(void *h, const dimo_step_comm
   clear_errors();
   for (int i = first; i < first + count; ++i) {
     const int si = ex->range_stream[i];
-    if (si < 0) continue;
+    if (si < 0 || si >= (int)ex->streams.size()) continue;  // (a range on the caller's stream is already in order)
     if (hipEventRecord(ex->fwd_done[i], ex->streams[si]) != hipSuccess ||
         hipStreamWaitEvent(main, ex->fwd_done[i], 0) != hipSuccess)
       return DIMO_E_LAUNCH;

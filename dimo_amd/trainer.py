@@ -193,6 +193,7 @@ class Trainer:
         self.skipped_steps = 0
         self.time_allreduce = False  # bench.py: event pairs around the step's collective (exposed time)
         self.allreduce_events = []
+        self._main_chain = int(os.environ.get("DIMO_MAIN_CHAIN", "1"))
         self._flat_adam = type(self.optimizer).__name__ == "FlatAdam"
         self._inorder_losses = os.environ.get("DIMO_INORDER_LOSSES", "1") == "1"
         self._joint_bwd = os.environ.get("DIMO_JOINT_BWD", "1") == "1"
@@ -649,9 +650,18 @@ class Trainer:
         # overlap the other motion's blend forward in the default.
         joint_bwd = bool(ex.ranged and self._joint_bwd and self._inorder_losses and not c.use_lpips and n > 0)
         joint = joint_bwd and self._joint_losses and n <= 32
+        # Joint backward: the LAST motion's chain (forward and losses) runs on this stream itself: it starts at once, where
+        # a private stream starts behind a cross-stream dependency (10-12 us on this platform, tools/xstream_latency.hip)
+        # and the joint backward waits for another one when it gets there: 6790 against 6710 frames/s.  (The other
+        # motions' losses on this stream as well, their forward long finished by then: 6650.)
+        main_chain = self._main_chain if (joint_bwd and not joint) else 0
+        main_motion = list(by_motion)[-1] if (main_chain and by_motion) else None
         if ex.ranged:  # one batch per motion, on alternating private streams
             for m, trs in by_motion.items():
-                ex.forward_range(first[m], len(trs))
+                if m != main_motion:
+                    ex.forward_range(first[m], len(trs))
+            if main_motion is not None:
+                ex.forward_range(first[main_motion], len(by_motion[main_motion]), on_caller=True)
         else:
             ex.forward(n)
         self.renderer.capacity.track(ex.total_words(n))
@@ -709,7 +719,7 @@ class Trainer:
             # batched ranges: this motion's losses and rasterizer backward continue ON ITS OWN STREAM, in order behind
             # its renders (no cross-stream event until the skinning backward); otherwise join this stream
             own = ex.range_stream(first[m]) if (ex.ranged and self._inorder_losses and not c.use_lpips) else None
-            if own is None:
+            if own is None and m != main_motion:
                 ex.join(first[m], B)  # only this motion's renders: the other motions keep rendering underneath
             stream_m = own if own is not None else stream
             gt, mask = gathered[m]
@@ -747,7 +757,7 @@ class Trainer:
                 d.g_depth = (gd.data_ptr() + b * HW4) if gd is not None else None
                 d.g_normal = (gn.data_ptr() + b * 3 * HW4) if gn is not None else None
                 d.g_dot = (g_dot.data_ptr() + b * HW4) if g_dot is not None else None
-            if own is not None and joint_bwd:
+            if joint_bwd:
                 pass  # one launch chain over all the step's renders, below
             elif own is not None:
                 ex.backward_launch_in_order(first[m], B)

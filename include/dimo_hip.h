@@ -368,6 +368,11 @@ int dimo_executor_backward_launch(void *executor, const dimo_step_common *common
 /* batched ranges (n_streams < 0): the private stream of the range that starts at render `first` (NULL if none), so
  * that the caller can enqueue the range's loss kernels behind its forward without a cross-stream join, and the
  * rasterizer backward continuing on that stream (no fork from a caller stream) */
+/* Batched ranges only: this range's forward chain on the CALLER's stream (in order, no cross-stream dependency) while
+ * the step's other ranges use private streams; dimo_executor_range_stream is null for it, dimo_executor_join and
+ * dimo_executor_backward_launch_joint do not wait for it.  (One of the motions of main_train_dimo.py:276-318.) */
+int dimo_executor_forward_range_on_caller(void *executor, const dimo_step_common *common, int first, int count,
+                                          const dimo_render_desc *renders, void *main_stream);
 void *dimo_executor_range_stream(void *executor, int first);
 /* Batched ranges only: the rasterizer backward of every range inside [first, first + count) in launches of up to 8
  * renders on the CALLER's stream, ordered behind what the ranges' private streams hold at the time of the call. */

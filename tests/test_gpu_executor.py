@@ -81,7 +81,8 @@ def _run_batched(N, res, renders_per_motion, n_motions, seed=0, streams="-2", mo
     torch.cuda.synchronize()
     firsts = list(range(0, n, renders_per_motion))
     for first in firsts:
-        ex.forward_range(first, renders_per_motion) if ex.ranged else None
+        # (joint mode, as the trainer schedules it: the last motion's chain on the caller's stream)
+        ex.forward_range(first, renders_per_motion, on_caller=joint and first == firsts[-1]) if ex.ranged else None
     if not ex.ranged:
         ex.forward(n)
     torch.cuda.synchronize()
