@@ -85,21 +85,33 @@ class CapacityPolicy:
         self._pending = []
         return self._update(tot)
 
-    def collect_async(self):
+    def collect_async(self, defer_copy=False):
         """Sync-free variant: returns the stacked device words [k, 2] (R, overflow) of the renders since the last
         call (for device-side consumers, e.g. the optimizer's skip flag) and starts a pinned-memory copy that
-        `poll()` evaluates later."""
+        `poll()` evaluates later.  defer_copy: the copy is started by start_copy() instead -- the trainer enqueues it
+        BEHIND the optimizer's launch (a 4 us copy and its gap sat in front of Adam on the step's critical path)."""
         if not self._pending:
             return None
         tot = self._pending[0] if len(self._pending) == 1 else torch.cat(self._pending)
         self._pending = []
+        if defer_copy:
+            self._deferred = tot
+            return tot
+        self._start_copy(tot)
+        return tot
+
+    def start_copy(self):
+        tot, self._deferred = getattr(self, "_deferred", None), None
+        if tot is not None:
+            self._start_copy(tot)
+
+    def _start_copy(self, tot):
         host = torch.empty(tot.shape, dtype=tot.dtype, pin_memory=True)
         host.copy_(tot, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
         self._inflight = getattr(self, "_inflight", [])
         self._inflight.append((host, ev))
-        return tot
 
     def poll(self, lag=1):
         """Evaluates the asynchronous copies except the `lag` newest ones.  Returns the number of steps that had

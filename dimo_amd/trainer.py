@@ -861,7 +861,7 @@ class Trainer:
         if self._flat_adam:
             # no host sync at all: the overflow words of this step's renders become a device-side skip flag that
             # travels through the all-reduce; the host looks at them one step later (CapacityPolicy.poll)
-            tot = cap.collect_async() if cap is not None else None
+            tot = cap.collect_async(defer_copy=True) if cap is not None else None
             # (device scalar, no read-back: a step whose renders overflowed must not feed the densification statistics --
             # stage s1 only, where they are gathered)
             self._step_overflow = tot[:, 1].max() if (tot is not None and self.stage == "s1") else None
@@ -881,6 +881,8 @@ class Trainer:
                 self.optimizer.step(skip_flags=g.grad_flag.view(torch.int32), zero_grad=True)
             else:  # one rank: Adam reads the renders' (R, overflow) words directly
                 self.optimizer.step(skip_flags=tot, zero_grad=True)
+            if cap is not None:
+                cap.start_copy()  # the words' copy for the host (poll, next step), behind the optimizer
             self._mark("allreduce+adam")
         else:
             if cap is not None and not cap.check():  # host sync; parameters are still untouched
