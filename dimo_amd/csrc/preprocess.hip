@@ -298,6 +298,8 @@ __global__ void __launch_bounds__(PRE_BLOCK) preprocess_fwd_batched_kernel(int N
                       at<uint32_t>(r.geom, L.key32), at<uint32_t>(r.geom, L.bk), ss_shift);
 }
 
+constexpr uint32_t PRESUM_MIN = 64;   // instances above which a Gaussian's records are summed cooperatively
+constexpr int PRESUM_MAX_N = 8192;    // Gaussians up to which that is a launch of its own (one workgroup per Gaussian)
 __device__ __forceinline__ void preprocess_bwd_body(
     int N, int deg, int M, int H, int W, uint32_t R_cap, const float *__restrict__ means3D,
     const float *__restrict__ shs, const float *__restrict__ colors_precomp, const float *__restrict__ scales,
@@ -308,12 +310,14 @@ __device__ __forceinline__ void preprocess_bwd_body(
     const uint8_t *__restrict__ inst_flag,
     float *__restrict__ dL_dmeans3D, float *__restrict__ dL_dmeans2D, float *__restrict__ dL_dshs,
     float *__restrict__ dL_dcolors, float *__restrict__ dL_dopacity, float *__restrict__ dL_dscales,
-    float *__restrict__ dL_drot, float *__restrict__ dL_dcov3D) {
+    float *__restrict__ dL_drot, float *__restrict__ dL_dcov3D, const float *__restrict__ presum = nullptr) {
   // A Gaussian with MANY instances (a splat blown up over hundreds of tiles: random targets produce them within a
   // few hundred steps) would keep its thread in the gather loop long after the rest of the chip has finished --
   // the kernel went from 80 to 230 us per 8 renders over a 1400-step run.  Such Gaussians are summed by a whole WAVE
   // (lanes stride over the records, butterfly reduction) before the per-thread part; everything else is unchanged.
-  constexpr uint32_t BIG = 64;  // instances above which the wave takes over
+  // `presum` (stage-s1 shapes: a few hundred Gaussians, every one of them over hundreds of tiles): the sums of the big
+  // Gaussians were formed by instance_sums_batched_kernel, one workgroup per Gaussian, [16 N] floats.
+  constexpr uint32_t BIG = PRESUM_MIN;  // instances above which the wave takes over
   __shared__ uint32_t s_big_n;
   __shared__ uint32_t s_big_lo[PRE_BLOCK], s_big_hi[PRE_BLOCK];
   __shared__ float s_big_sum[PRE_BLOCK][13];
@@ -344,12 +348,12 @@ __device__ __forceinline__ void preprocess_bwd_body(
   __syncthreads();
   const bool big = visible && hi > lo && hi - lo > BIG;
   uint32_t big_slot = 0;
-  if (big) {
+  if (big && !presum) {
     big_slot = atomicAdd(&s_big_n, 1u);
     s_big_lo[big_slot] = lo, s_big_hi[big_slot] = hi;
   }
   __syncthreads();
-  {
+  if (!presum) {
     const uint32_t n_big = s_big_n;  // (workgroup-uniform)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (uint32_t b = (uint32_t)wave; b < n_big; b += PRE_BLOCK / 64) {
@@ -378,7 +382,7 @@ __device__ __forceinline__ void preprocess_bwd_body(
     // ---- gather the instance records
     float m0 = 0, mx = 0, my = 0, mxx = 0, mxy = 0, myy = 0;
     if (big) {
-      const float *a = s_big_sum[big_slot];
+      const float *a = presum ? presum + 16 * (size_t)i : s_big_sum[big_slot];
       m0 = a[0], mx = a[1], my = a[2], mxx = a[3], mxy = a[4], myy = a[5];
 #pragma unroll
       for (int k = 0; k < NFEAT; ++k) dfeat[k] = a[6 + k];
@@ -637,13 +641,66 @@ __global__ void __launch_bounds__(PRE_BLOCK) preprocess_bwd_kernel(
 __global__ void __launch_bounds__(PRE_BLOCK) preprocess_bwd_batched_kernel(int N, int H, int W, uint32_t R_cap,
                                                                            const float *__restrict__ f_dc,
                                                                            float scale_mod, GeomLayout L,
-                                                                           size_t flag_offset, RenderBatch b) {
+                                                                           size_t flag_offset, size_t presum_offset,
+                                                                           RenderBatch b) {
   const dimo_render_desc &r = b.r[blockIdx.y];
   preprocess_bwd_body(N, 0, 1, H, W, R_cap, r.pts, f_dc, nullptr, r.scales, r.rot, nullptr, scale_mod, r.view, r.proj,
                       r.campos, r.tanfovx, r.tanfovy, r.radii, at<Splat>(r.geom, L.splat),
                       at<uint32_t>(r.geom, L.offsets), at<uint8_t>(r.geom, L.flags),
                       reinterpret_cast<const SplatGrad *>(r.bwd_scratch), at<uint8_t>(r.bwd_scratch, flag_offset),
-                      r.g_means3D, r.g_means2D, r.g_shs, nullptr, r.g_opac, r.g_scales, r.g_rot, nullptr);
+                      r.g_means3D, r.g_means2D, r.g_shs, nullptr, r.g_opac, r.g_scales, r.g_rot, nullptr,
+                      presum_offset != ~(size_t)0 ? at<float>(r.bin, presum_offset) : nullptr);
+}
+
+// Stage-s1 shapes (main_train_dimo.py: 512 Gaussians of radius exp(_r), each over hundreds of tiles): the projection
+// backward is 2 workgroups per render there and its 8 waves walked ~10^6 instance records per render between them
+// (229 us per 8 renders).  One WORKGROUP per Gaussian sums the records first -- four records of a thread in flight,
+// waves and lanes reduced in a fixed order -- into [16 N] floats that live in the binning's fallback-sort scratch
+// (free during the backward).
+__global__ void __launch_bounds__(256) instance_sums_batched_kernel(int N, uint32_t R_cap, GeomLayout L, size_t flag_offset,
+                                                                    size_t presum_offset, RenderBatch b) {
+  __shared__ float s_part[4][13];
+  const dimo_render_desc &r = b.r[blockIdx.y];
+  const int g = blockIdx.x;
+  const uint32_t *__restrict__ offsets = at<uint32_t>(r.geom, L.offsets);
+  const uint32_t lo = min(g == 0 ? 0u : offsets[g - 1], R_cap), hi = min(offsets[g], R_cap);
+  if (hi <= lo || hi - lo <= PRESUM_MIN) return;  // (workgroup-uniform)
+  const SplatGrad *__restrict__ inst_grad = reinterpret_cast<const SplatGrad *>(r.bwd_scratch);
+  const uint8_t *__restrict__ inst_flag = at<uint8_t>(r.bwd_scratch, flag_offset);
+  const float4 *const dummy = reinterpret_cast<const float4 *>(inst_grad);
+  float a[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  constexpr int GR = 4;
+  for (uint32_t e0 = lo + threadIdx.x; e0 < hi; e0 += GR * 256) {
+    uint32_t fl[GR];
+#pragma unroll
+    for (int k = 0; k < GR; ++k) fl[k] = inst_flag[min(e0 + k * 256, hi - 1)];
+    float4 ra[GR], rb[GR], rc[GR], rd[GR];
+#pragma unroll
+    for (int k = 0; k < GR; ++k) {
+      const bool on = e0 + k * 256 < hi && fl[k] != 0;
+      fl[k] = on;
+      const float4 *rp = on ? reinterpret_cast<const float4 *>(inst_grad + e0 + k * 256) : dummy;
+      ra[k] = rp[0], rb[k] = rp[1], rc[k] = rp[2], rd[k] = rp[3];
+    }
+#pragma unroll
+    for (int k = 0; k < GR; ++k)
+      if (fl[k]) {
+        a[0] += ra[k].x, a[1] += ra[k].y, a[2] += ra[k].z, a[3] += ra[k].w, a[4] += rb[k].x, a[5] += rb[k].y;
+        a[6] += rb[k].z, a[7] += rb[k].w, a[8] += rc[k].x, a[9] += rc[k].y, a[10] += rc[k].z, a[11] += rc[k].w;
+        a[12] += rd[k].x;
+      }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 13; ++k) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a[k] += __shfl_xor(a[k], o, 64);
+    if (lane == 0) s_part[wave][k] = a[k];
+  }
+  __syncthreads();
+  if (threadIdx.x < 13)
+    at<float>(r.bin, presum_offset)[16 * (size_t)g + threadIdx.x] =
+        ((s_part[0][threadIdx.x] + s_part[1][threadIdx.x]) + s_part[2][threadIdx.x]) + s_part[3][threadIdx.x];
 }
 
 // scan of tiles_touched for every render of a batch (binning.hip)
@@ -667,10 +724,16 @@ int preprocess_backward_batched(const dimo_step_common &c, const RenderBatch &b,
   if (nb == 0 || n <= 0) return DIMO_OK;
   GeomLayout L(c.N);
   const uint32_t cap = (uint32_t)(c.R_cap > 0xffffffffLL ? 0xffffffffu : (uint32_t)c.R_cap);
+  const size_t flag_offset = align_up((size_t)(c.R_cap > 0 ? c.R_cap : 1) * sizeof(SplatGrad));
+  // few Gaussians (stage s1): their instance records are summed one workgroup per Gaussian first
+  BinLayout B(c.R_cap, c.H, c.W);
+  const bool presum = c.N <= PRESUM_MAX_N && B.l1b - B.l1a >= 64 * (size_t)c.N && c.bin_bytes >= B.bytes;
   ScopedTimer tm(T_PREPROCESS_BWD, stream);
+  if (presum)
+    hipLaunchKernelGGL(instance_sums_batched_kernel, dim3(c.N, n), dim3(256), 0, stream, c.N, cap, L, flag_offset,
+                       B.l1a, b);
   hipLaunchKernelGGL(preprocess_bwd_batched_kernel, dim3(nb, n), dim3(PRE_BLOCK), 0, stream, c.N, c.H, c.W, cap,
-                     c.f_dc, c.scale_modifier, L,
-                     align_up((size_t)(c.R_cap > 0 ? c.R_cap : 1) * sizeof(SplatGrad)), b);
+                     c.f_dc, c.scale_modifier, L, flag_offset, presum ? B.l1a : ~(size_t)0, b);
   return check_launch();
 }
 

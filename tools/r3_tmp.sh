@@ -1,0 +1,5 @@
+#!/bin/bash
+cd ${GRAFT_REPO_ROOT:-/root/repo}
+mkdir -p gpurun_out
+{ python tools/s1_probe.py 100; timeout 1200 python -m pytest tests/test_gpu_losses.py tests/test_gpu_executor.py tests/test_gpu_deform.py -x -q 2>&1 | tail -3; bash tools/kstats_all.sh $GRAFT_REPO_ROOT/tools/s1_probe.py 30 2>&1 | head -8; } > gpurun_out/r3_s1.log 2>&1
+cat gpurun_out/r3_s1.log
