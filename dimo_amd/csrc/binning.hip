@@ -184,19 +184,31 @@ __device__ __forceinline__ int rect_entries(const uint2 rc, const BinGrid &gi) {
   const int x0 = rc.x & 0xffff, y0 = rc.x >> 16, x1 = rc.y & 0xffff, y1 = rc.y >> 16;
   return (((x1 - 1) >> gi.ss_shift) - (x0 >> gi.ss_shift) + 1) * (((y1 - 1) >> gi.ss_shift) - (y0 >> gi.ss_shift) + 1);
 }
+// (The list keeps the Gaussian's key and rectangle beside its index, and every WAVE walks a Gaussian of its own, a
+// lane per supertile: with the words re-read from global memory inside a workgroup-wide loop, a stage-s1 model --
+// 512 Gaussians, each over most of the image -- spent 75 + 93 us per launch in 256 dependent round trips per workgroup.)
+struct BigList {
+  uint32_t n;
+  uint32_t i[PRE_BLOCK], key[PRE_BLOCK];
+  uint2 rc[PRE_BLOCK];
+  __device__ __forceinline__ void push(uint32_t gi_, uint32_t k, uint2 r) {
+    const uint32_t slot = atomicAdd(&n, 1u);
+    i[slot] = gi_, key[slot] = k, rc[slot] = r;
+  }
+};
 template <class F>
-__device__ __forceinline__ void for_each_big(const uint32_t *s_bigi, uint32_t n_big, const uint16_t *__restrict__ rect,
-                                             const uint32_t *__restrict__ key32, uint32_t lo, uint32_t shift,
-                                             uint32_t nbins, const BinGrid &gi, int lg, F f) {
-  for (uint32_t b = 0; b < n_big; ++b) {
-    const uint32_t i = s_bigi[b];
-    const uint2 rc = *reinterpret_cast<const uint2 *>(rect + 4 * (size_t)i);
-    const uint32_t key = key32[i];
+__device__ __forceinline__ void for_each_big(const BigList &L, uint32_t lo, uint32_t shift, uint32_t nbins,
+                                             const BinGrid &gi, int lg, F f) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t n_big = L.n;
+  for (uint32_t b = (uint32_t)wave; b < n_big; b += SORT_BLOCK / 64) {
+    const uint32_t i = L.i[b], key = L.key[b];
+    const uint2 rc = L.rc[b];
     const uint32_t db = depth_bin(key, lo, shift, nbins);
     const int x0 = rc.x & 0xffff, y0 = rc.x >> 16, x1 = rc.y & 0xffff;
     const int sx0 = x0 >> gi.ss_shift, sy0 = y0 >> gi.ss_shift, nx = ((x1 - 1) >> gi.ss_shift) - sx0 + 1;
     const int cnt = rect_entries(rc, gi);
-    for (int e = threadIdx.x; e < cnt; e += SORT_BLOCK)
+    for (int e = lane; e < cnt; e += 64)
       f((((uint32_t)((sy0 + e / nx) * gi.stx + sx0 + e % nx)) << lg) + db, i, key, rc);
   }
 }
@@ -206,7 +218,7 @@ __device__ __forceinline__ void level1_count_body(const BinArgs &a, void *geom, 
   __shared__ uint32_t s_hist[MAX_BUCKETS];
   __shared__ uint32_t s_w[4][8];
   __shared__ uint32_t s_wt[4];
-  __shared__ uint32_t s_bign, s_bigi[PRE_BLOCK];
+  __shared__ BigList s_big;
   const uint32_t *__restrict__ tiles = at<uint32_t>(geom, a.g_tiles);
   const uint32_t *__restrict__ key32 = at<uint32_t>(geom, a.g_key32);
   const uint16_t *__restrict__ rect = at<uint16_t>(geom, a.g_rect);
@@ -288,14 +300,14 @@ __device__ __forceinline__ void level1_count_body(const BinArgs &a, void *geom, 
     const uint32_t inc = wave_scan_incl(v0, lane);
     lds_barrier();  // (s_wt / the list of the previous block have been read; first round: s_hist cleared)
     if (lane == 63) s_wt[wave] = inc;
-    if (tid == 0) s_bign = 0u;
+    if (tid == 0) s_big.n = 0u;
     lds_barrier();
     uint32_t off = carry;
     for (int w = 0; w < wave; ++w) off += s_wt[w];
     carry += s_wt[0] + s_wt[1] + s_wt[2] + s_wt[3];
     if (i < a.N) offsets[i] = off + inc;
     const bool big = v0 != 0u && rect_entries(r0, a.gi) > BIG_ENTRIES;
-    if (big) s_bigi[atomicAdd(&s_bign, 1u)] = (uint32_t)i;
+    if (big) s_big.push((uint32_t)i, k0, r0);
     for_each_group(v0 != 0u && !big, r0, depth_bin(k0, lo, shift, nbins), a.gi, a.lg, lane,
                    [&](uint32_t bl, u64 m, int leader, bool) {
                      if (lane == leader) atomicAdd(&s_hist[bl], (uint32_t)__popcll(m));
@@ -304,7 +316,7 @@ __device__ __forceinline__ void level1_count_body(const BinArgs &a, void *geom, 
                      if (mine) atomicAdd(&s_hist[bucket], 1u);
                    });
     lds_barrier();
-    for_each_big(s_bigi, s_bign, rect, key32, lo, shift, nbins, a.gi, a.lg,
+    for_each_big(s_big, lo, shift, nbins, a.gi, a.lg,
                  [&](uint32_t bucket, uint32_t, uint32_t, uint2) { atomicAdd(&s_hist[bucket], 1u); });
   }
   __syncthreads();
@@ -343,7 +355,7 @@ __device__ __forceinline__ void level1_scatter_body(const BinArgs &a, void *geom
   __shared__ uint32_t s_len[MAX_SUPER];
   __shared__ uint32_t s_wt[4];
   __shared__ uint32_t s_nslice;
-  __shared__ uint32_t s_bign, s_bigi[PRE_BLOCK];
+  __shared__ BigList s_big;
   const uint32_t *__restrict__ tiles = at<uint32_t>(geom, a.g_tiles);
   const uint32_t *__restrict__ key32 = at<uint32_t>(geom, a.g_key32);
   const uint16_t *__restrict__ rect = at<uint16_t>(geom, a.g_rect);
@@ -450,10 +462,10 @@ __device__ __forceinline__ void level1_scatter_body(const BinArgs &a, void *geom
     const uint4 en = make_uint4(k0, (uint32_t)i, r0.x, r0.y);
     const u64 lt = (1ull << lane) - 1ull;
     lds_barrier();  // (the list of the previous block has been read)
-    if (tid == 0) s_bign = 0u;
+    if (tid == 0) s_big.n = 0u;
     lds_barrier();
     const bool big = v0 != 0u && rect_entries(r0, a.gi) > BIG_ENTRIES;
-    if (big) s_bigi[atomicAdd(&s_bign, 1u)] = (uint32_t)i;
+    if (big) s_big.push((uint32_t)i, k0, r0);
     for_each_group(v0 != 0u && !big, r0, depth_bin(k0, lo, shift, (uint32_t)nbins), a.gi, a.lg, lane,
                    [&](uint32_t bl, u64 m, int leader, bool mine) {
                      uint32_t first = 0;  // the group's slots: one returning LDS atomic by its leader
@@ -469,7 +481,7 @@ __device__ __forceinline__ void level1_scatter_body(const BinArgs &a, void *geom
                      }
                    });
     lds_barrier();
-    for_each_big(s_bigi, s_bign, rect, key32, lo, shift, (uint32_t)nbins, a.gi, a.lg,
+    for_each_big(s_big, lo, shift, (uint32_t)nbins, a.gi, a.lg,
                  [&](uint32_t bucket, uint32_t gi_, uint32_t key, uint2 rc) {
                    const size_t pos = atomicAdd(&s_cur[bucket], 1u);
                    if (pos < a.l1cap) l1tmp[pos] = make_uint4(key, gi_, rc.x, rc.y);
