@@ -98,7 +98,7 @@ __device__ __forceinline__ void blend_fwd_body(
     const Splat *__restrict__ splat, const float *__restrict__ bg, float *__restrict__ out_color,
     float *__restrict__ out_depth, float *__restrict__ out_normal, float *__restrict__ out_alpha,
     float *__restrict__ final_T, uint32_t *__restrict__ n_contrib, float *__restrict__ final_acc,
-    float *__restrict__ ckpt, uint32_t *__restrict__ work, uint32_t chain) {
+    float *__restrict__ ckpt, uint32_t *__restrict__ work, uint32_t chain, int tile) {
   __shared__ uint32_t s_last[BLEND_BLOCK / 64];
   __shared__ float4 s_geo[BATCH];   // x y A B
   __shared__ float4 s_col[BATCH];   // C opacity r g
@@ -106,7 +106,6 @@ __device__ __forceinline__ void blend_fwd_body(
   __shared__ float s_nz[BATCH];
   __shared__ uint32_t s_mask[BATCH];
 
-  const int tile = blockIdx.x;
   const int tile_x = tile % tiles_x, tile_y = tile / tiles_x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int px, py;
@@ -560,7 +559,7 @@ __global__ void __launch_bounds__(BLEND_BLOCK) blend_fwd_kernel(
     float *__restrict__ final_T, uint32_t *__restrict__ n_contrib, float *__restrict__ final_acc,
     float *__restrict__ ckpt, uint32_t *__restrict__ work, uint32_t chain) {
   blend_fwd_body<NORMAL>(H, W, tiles_x, ranges, vals_sorted, splat, bg, out_color, out_depth, out_normal, out_alpha,
-                         final_T, n_contrib, final_acc, ckpt, work, chain);
+                         final_T, n_contrib, final_acc, ckpt, work, chain, (int)blockIdx.x);
 }
 struct SingleView {
   BwdView v;
@@ -576,7 +575,7 @@ __global__ void __launch_bounds__(64, BWD_WAVES_PER_SIMD) blend_bwd_kernel(int H
 // the renders' items over a one-dimensional grid.
 struct BlendOffsets {
   size_t splat, rect, offsets, total;           // geom
-  size_t ranges, vals, ckpt, work;              // bin
+  size_t ranges, vals, ckpt, work, order;       // bin
   size_t final_T, n_contrib, final_acc;         // img
   size_t flag;                                  // backward scratch: records at 0, flags here
 };
@@ -584,11 +583,17 @@ template <bool NORMAL>
 __global__ void __launch_bounds__(BLEND_BLOCK) blend_fwd_batched_kernel(int H, int W, int tiles_x,
                                                                         const float *__restrict__ bg, BlendOffsets o,
                                                                         uint32_t chain, RenderBatch b) {
-  const dimo_render_desc &r = b.r[blockIdx.y];
+  // Workgroups start in the order of their linear index: the renders of the batch interleaved, and inside a render the
+  // tiles by descending list length (the order the level-2 fill left in the bin workspace) -- the long lists of every
+  // render first, the empty tiles of the border as the launch's tail.
+  const uint32_t lin = blockIdx.y * gridDim.x + blockIdx.x;
+  const dimo_render_desc &r = b.r[lin % gridDim.y];
+  const int tile = (int)at<uint32_t>(r.bin, o.order)[lin / gridDim.y];
   blend_fwd_body<NORMAL>(H, W, tiles_x, at<uint32_t>(r.bin, o.ranges), at<uint32_t>(r.bin, o.vals),
                          at<Splat>(r.geom, o.splat), bg, r.out_color, r.out_depth, NORMAL ? r.out_normal : nullptr,
                          r.out_alpha, at<float>(r.img, o.final_T), at<uint32_t>(r.img, o.n_contrib),
-                         at<float>(r.img, o.final_acc), at<float>(r.bin, o.ckpt), at<uint32_t>(r.bin, o.work), chain);
+                         at<float>(r.img, o.final_acc), at<float>(r.bin, o.ckpt), at<uint32_t>(r.bin, o.work), chain,
+                         tile);
 }
 template <bool NORMAL>
 struct BatchView {
@@ -631,7 +636,7 @@ static uint32_t bwd_chain(int n) {
 static BlendOffsets blend_offsets(const GeomLayout &G, const BinLayout &B, const ImgLayout &I) {
   BlendOffsets o;
   o.splat = G.splat, o.rect = G.rect, o.offsets = G.offsets, o.total = G.total;
-  o.ranges = B.ranges, o.vals = B.vals_b, o.ckpt = B.ckpt, o.work = B.work;
+  o.ranges = B.ranges, o.vals = B.vals_b, o.ckpt = B.ckpt, o.work = B.work, o.order = B.order;
   o.final_T = I.final_T, o.n_contrib = I.n_contrib, o.final_acc = I.final_acc;
   o.flag = align_up(B.cap * sizeof(SplatGrad));
   return o;

@@ -120,7 +120,7 @@ struct GeomLayout {
 constexpr int BUCKET = 64;       // list entries per backward work item
 constexpr int CKPT_FLOATS = 9;   // T, 7 accumulated features, accumulated weight
 struct BinLayout {
-  size_t dkeys, vals_b, ranges, totals, meta, l1tmp, l1a, l1b, l1list, cnt2, ckpt, work, bytes;
+  size_t dkeys, vals_b, ranges, totals, meta, l1tmp, l1a, l1b, l1list, cnt2, ckpt, work, order, bytes;
   int tiles_x, tiles_y, T;
   size_t cap, ckpt_slots, l1cap, max_windows;
   __host__ BinLayout(int64_t R_cap, int H, int W) {
@@ -154,6 +154,8 @@ struct BinLayout {
     // [0..2] = item counts of the three queues (head / second / deeper chains), then 16-byte items: heads at
     // [1, 1 + T), seconds at [1 + T, 1 + 2 T), the rest behind (blend.hip)
     work = o, o = align_up(o + (4 * (ckpt_slots + 2 * (size_t)T) + 8) * sizeof(uint32_t));
+    // the tiles by descending list length (the blend forward's dispatch order; written by the level-2 fill)
+    order = o, o = align_up(o + (size_t)T * sizeof(uint32_t));
     bytes = o;
   }
 };
