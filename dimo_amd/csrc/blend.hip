@@ -516,12 +516,15 @@ __device__ __forceinline__ void blend_bwd_item(int H, int W, int tiles_x, uint32
   }
 }
 
-// Items are taken class by class from the BACK -- the deep chains, then the second ones, then the heads (see the
-// forward's queues) -- in the hardware's in-order workgroup dispatch over blockIdx: no atomics.  Measured on the C3
-// batch: deep-first 196-203 us per launch, heads-first 200-223 us (the sparse deep items are latency bound and mix
-// well with the VALU-bound heads when they start together; started last they leave the chip half idle).  Virtual
-// item v = blockIdx.x, + gridDim.x, ...: render v % n, that render's (v / n)-th item from the back, so the renders of
-// a batch interleave.
+// Items are taken class by class -- the deep chains, then the second ones, then the heads (see the forward's queues)
+// -- in the hardware's in-order workgroup dispatch over blockIdx: no atomics.  Measured on the C3 batch: deep-first
+// 196-203 us per launch, heads-first 200-223 us (the sparse deep items are latency bound and mix well with the
+// VALU-bound heads when they start together; started last they leave the chip half idle).  Inside a class the items are
+// taken from the FRONT of the queue: the forward starts its tiles longest list first, so the queues fill roughly by
+// descending list length and the launch ends on its cheapest items (from the back -- the order of round 2, when
+// the queues filled in tile order -- the blend backward took 278 us per 8 renders, from the front 270).  Virtual
+// item v = blockIdx.x, + gridDim.x, ...: render v % n, that render's (v / n)-th item, so the renders of a batch
+// interleave.
 template <bool NORMAL, class VIEW>
 __device__ __forceinline__ void blend_bwd_loop(int H, int W, int tiles_x, uint32_t R_cap, const float *__restrict__ bg,
                                                int n, VIEW view) {
@@ -542,8 +545,7 @@ __device__ __forceinline__ void blend_bwd_loop(int H, int W, int tiles_x, uint32
     const BwdView r = view((int)(v % (uint32_t)n));
     const uint32_t local = v / (uint32_t)n, c0 = r.work[0], c1 = r.work[1], c2 = r.work[2];
     if (local >= c0 + c1 + c2) continue;
-    const uint32_t l2 = c0 + c1 + c2 - 1 - local;
-    const uint32_t slot = l2 < c0 ? l2 : (l2 < c0 + c1 ? T + (l2 - c0) : 2u * T + (l2 - c0 - c1));
+    const uint32_t slot = local < c2 ? 2u * T + local : (local < c2 + c1 ? T + (local - c2) : local - c2 - c1);
     const uint4 it = reinterpret_cast<const uint4 *>(r.work)[1 + slot];
     blend_bwd_item<NORMAL>(H, W, tiles_x, R_cap, bg, r, it, s_geo, s_col, s_aux, s_nz, s_mask, s_acc,
                            (int)(v % (uint32_t)n));
