@@ -37,6 +37,7 @@
 #include <type_traits>
 
 #include "common.hpp"
+#include <cstdlib>
 
 namespace dimo {
 
@@ -1036,10 +1037,13 @@ static bool make_args(int N, int H, int W, int64_t R_cap, int n_renders, const G
   // level-1 workgroups walk `per` preprocess blocks each: their fixed work (reducing the per-block words, the bucket
   // tables) is per workgroup, and the kernels are instruction bound -- about 1024 workgroups per launch
   int per = (int)(((size_t)G.nb * (size_t)(n_renders > 0 ? n_renders : 1) + 1023) / 1024);
-  // ... and at most ~128 workgroups per render: every workgroup adds to each bucket it touches with one returning
+  // ... and at most ~256 workgroups per render: every workgroup adds to each bucket it touches with one returning
   // atomic, and the workgroups of a model that was never Morton-sorted touch nearly all of them (391 workgroups x 400
-  // buckets on 512 words: 50 us of serialised atomics for one render)
-  if (per < (G.nb + 127) / 128) per = (G.nb + 127) / 128;
+  // buckets on 512 words: 50 us of serialised atomics for one render).  (~128 until the workgroups' lifetimes were
+  // looked at: all of a launch's workgroups are resident at once, the launch lasts as long as its slowest one, and
+  // with four blocks each the slowest took twice the mean -- two blocks: 7130 against 7040 frames/s, and no worse
+  // for an unsorted model, 73.5 against 78.6 us per render for count + scatter + sort.)
+  if (per < (G.nb + 255) / 256) per = (G.nb + 255) / 256;
   if (per < G.per) per = G.per;
   if (per > 8) per = 8 > G.per ? 8 : G.per;
   a.N = N, a.nb = G.nb, a.per = per, a.nwg1 = (G.nb + per - 1) / per, a.lg = depth_bins_log2(N, a.gi.NS), a.T = B.T;
