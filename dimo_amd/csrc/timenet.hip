@@ -506,6 +506,18 @@ __device__ __forceinline__ void fused_chunk(const float *xa /* this lane's A poi
     const int u = blk % FPF;
     const float4 a = a_next;
     if (blk + 1 < LEN) a_next = *reinterpret_cast<const float4 *>(xa + 16 * (blk + 1));
+    // A wave that is ahead yields: the SIMD's arbiter otherwise serves its oldest wave first, wave 0 of a workgroup
+    // is through a layer's 16 blocks after 2.9 us and wave 15 after 5.2 (profiles/r03_timenet_notes.txt), and the
+    // layer ends with one wave per SIMD chaining dependent MFMAs behind a thin weight stream.  The priority falls in
+    // four steps over the chunk and is re-stated at every block (stated only where it changes: half the gain):
+    // forward 75.3 -> 69.5 us, backward group 121.9 -> 115.3 us on one box (tools/timenet_probe.py).
+    {
+      const int q4 = (4 * blk) / LEN;  // (constant after unrolling)
+      if (q4 == 0) __builtin_amdgcn_s_setprio(3);
+      else if (q4 == 1) __builtin_amdgcn_s_setprio(2);
+      else if (q4 == 2) __builtin_amdgcn_s_setprio(1);
+      else __builtin_amdgcn_s_setprio(0);
+    }
     const float4 p0 = q0[u], p1 = q1[u];
     if (blk + FPF < LEN) {
       q0[u] = w0[(blk + FPF) * 64];
