@@ -388,12 +388,15 @@ __device__ __forceinline__ void preprocess_bwd_body(
       for (int k = 0; k < NFEAT; ++k) dfeat[k] = a[6 + k];
       lo = hi;  // (nothing left for the loop below)
     }
-    // Eight instances per round, every load of the round issued before the first use: the flags first, then the four
+    // Several instances per round, every load of the round issued before the first use: the flags first, then the four
     // float4s of each record -- from the record when its flag is set (an instance no pixel reached has no record),
     // from ONE dummy line otherwise (a cache hit; an unconditional clamped load instead of a branch around it).
     // The one-entry-at-a-time loop was two dependent memory round trips per instance with ~1.5 waves per SIMD to
     // hide them: 24 us per wave of pure latency.
-    constexpr int GR = 8;
+    // (FOUR per round: eight held 104 registers of records in flight, 149 VGPRs = three waves per SIMD, and a stamp per
+    // workgroup showed 1.65 workgroups per CU alive on average; four: 122 VGPRs, four waves per SIMD, the same number
+    // of loads in flight per SIMD -- 100 -> 94 us per 8 renders in the timed step.)
+    constexpr int GR = 4;
     const float4 *const dummy = reinterpret_cast<const float4 *>(inst_grad);
     for (uint32_t e0 = lo; e0 < hi; e0 += GR) {
       uint32_t fl[GR];
