@@ -142,6 +142,80 @@ def cpu_baseline(num_pts, resolution, renders=20):
                       f"(forward OpenMP over {cores} threads, backward single-threaded); {dt:.1f} s"}
 
 
+def dropin_figures(device, num_pts, resolution, per_gpu, steps=12):
+    """frames/s of the C3 step through the drop-in surface ONLY.  Headline (`dropin_frames_per_s`): the reference's own
+    loop body, verbatim order of operations including its TensorBoard `.item()` reads (dimo_amd/reference_step.py
+    restating main_train_dimo.py:246-417; Renderer.render + MiniCam per triple, torch.cat per motion, F.mse_loss per
+    image, the ssim / smoothness drop-ins, ONE backward, optimizer.step).  Beside it: the same loop without the logging
+    reads, with the geometry-anchor term and its per-render `.item()` (:295-303), and the repo's own reference-shaped
+    trainer (`Trainer(direct=False)`: collects the outputs, one fused loss node per motion)."""
+    from dimo_amd.reference_step import ReferenceLoop
+    from dimo_amd.rasterizer import CapacityPolicy
+    from dimo_amd.renderer import Renderer
+    from dimo_amd.synth import SyntheticTargets, init_synthetic_model
+    from dimo_amd.trainer import TrainConfig
+    out, detail = {}, {}
+
+    def run_loop(log, ga):
+        cfg = TrainConfig(num_pts=num_pts, resolution=resolution, motions_per_step=per_gpu[0], views_per_step=per_gpu[1],
+                          frames_per_step=per_gpu[2], add_ga=ga)
+        cfg.progressive_resolution = resolution <= 512
+        rd = Renderer(sh_degree=0, white_background=True, radius=cfg.radius, num_latent_code=cfg.num_motions,
+                      latent_code_dim=cfg.latent_code_dim, add_normal=True, device=device,
+                      capacity=CapacityPolicy(initial=max(1 << 20, 40 * num_pts)))
+        init_synthetic_model(rd, cfg.num_pts, cfg.num_cpts, seed=0, regime="trained", num_latent=cfg.num_motions)
+        rd.gaussians.sort_spatially()
+        rd.gaussians.training_setup(cfg)
+        cpts = None
+        if ga:
+            c = rd.gaussians._c_xyz.detach()
+            cpts = [[c] * cfg.num_frames for _ in range(cfg.num_motions)]
+        loop = ReferenceLoop(cfg, rd, SyntheticTargets(resolution, device, seed=0), log_scalars=log, cpts_s1=cpts)
+        loop.step = 1000
+        for _ in range(4):
+            loop.train_step()
+        torch.cuda.synchronize()
+        b = rd._batcher
+        f0, r0 = (b.flushes, b.rendered) if b is not None else (0, 0)
+        t0 = time.perf_counter()
+        n = sum(loop.train_step() for _ in range(steps))
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        fl = ((b.flushes - f0), (b.rendered - r0)) if b is not None else (None, None)
+        del loop, rd
+        torch.cuda.empty_cache()
+        return n / dt, fl
+
+    v, fl = run_loop(True, False)
+    out["dropin_frames_per_s"] = v
+    detail["literal_loop_with_logging_reads"] = v
+    detail["launch_chains_per_step"] = (fl[0] / steps) if fl[0] is not None else None
+    detail["renders_per_launch_chain"] = (fl[1] / fl[0]) if fl[0] else None
+    detail["literal_loop_without_logging_reads"], _ = run_loop(False, False)
+    v_ga, fl_ga = run_loop(True, True)
+    detail["literal_loop_with_ga_term_and_its_item"] = v_ga
+    detail["launch_chains_per_step_with_ga"] = (fl_ga[0] / steps) if fl_ga[0] is not None else None
+    tr2, _ = make_trainer(device, 0, 1, num_pts, resolution, per_gpu=per_gpu, capacity=True, direct=False)
+    for _ in range(3):
+        tr2.train_step()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    n2 = sum(tr2.train_step() for _ in range(steps))
+    torch.cuda.synchronize()
+    detail["collected_outputs_trainer_direct_false"] = n2 / (time.perf_counter() - t2)
+    del tr2
+    out["dropin_detail"] = detail
+    out["dropin_what"] = ("C3 step through the drop-in surface only; headline = the reference's loop body in its own "
+                          "order of operations INCLUDING its per-motion tb_writer .item() reads "
+                          "(dimo_amd/reference_step.py restates main_train_dimo.py:246-417): Renderer.render + MiniCam "
+                          "per (motion, view, frame) triple, out[...].unsqueeze(0), torch.cat per motion, F.mse_loss per "
+                          "image, ssim / smoothness drop-ins, ONE loss.backward(), FlatAdam.step; the step's renders run "
+                          "as %.2f launch chain(s) per step behind render() (lazy outputs with deferred view / cat ops, "
+                          "dimo_amd/batched_render.py); %d steps per figure"
+                          % (detail["launch_chains_per_step"] or 0.0, steps))
+    return out
+
+
 def live_pmc(timeout=180):
     """HBM traffic and VALU occupancy of the dominant kernel from rocprofv3 PMC counters, collected DURING this run in
     child processes: three passes over tools/pmc_probe.py (the same C3 workload), one counter set each, never combined
@@ -544,29 +618,12 @@ def main():
             "kernels_ms_per_launch_isolated": {k: (v[0] / v[1] if v[1] else None) for k, v in timing_iso.items()},
         }
         if world == 1 and not args.no_dropin:
-            # what a maintainer gets who only swaps the imports: the reference-shaped step --
-            # Renderer.render per triple through the GaussianRasterizer autograd module, torch losses, one backward
+            # what a maintainer gets who only swaps the imports and keeps the reference's
+            # trainer: dimo_amd/reference_step.py restates GUI.train_step's loop body in its order of operations
             try:
                 del tr
                 torch.cuda.empty_cache()
-                tr2, _ = make_trainer(device, 0, 1, args.num_pts, args.resolution, per_gpu=per_gpu, capacity=False,
-                                      direct=False)
-                for _ in range(3):
-                    tr2.train_step()
-                torch.cuda.synchronize()
-                k2 = 10
-                t2 = time.perf_counter()
-                n2 = sum(tr2.train_step() for _ in range(k2))
-                torch.cuda.synchronize()
-                res["dropin_frames_per_s"] = n2 / (time.perf_counter() - t2)
-                bt = getattr(tr2.renderer, "_batcher", None)
-                res["dropin_what"] = ("same C3 step through the drop-in surface only: Renderer.render per (motion, view, "
-                                      "frame) triple + ONE autograd backward (Trainer(direct=False), the reference's loop "
-                                      "shape); the renders of a step are batched behind render() (lazy outputs, "
-                                      "dimo_amd/batched_render.py: %d renders in %d launch chains), TimeNet and the image "
-                                      "losses are single autograd nodes on the fused kernels, FlatAdam; %d steps"
-                                      % (getattr(bt, "rendered", 0), getattr(bt, "flushes", 0), k2))
-                del tr2
+                res.update(dropin_figures(device, args.num_pts, args.resolution, per_gpu))
             except Exception as e:
                 res["dropin_frames_per_s"] = None
                 res["dropin_what"] = f"failed: {e!r}"

@@ -28,28 +28,208 @@ from . import _lib
 
 
 # ------------------------------------------------------------------------------------------------ lazy tensors
+_METAS = {}
+
+
+def _meta(shape, dtype=torch.float32):
+    """Cached meta tensor (shape + dtype, no storage): what a stand-in answers metadata questions from."""
+    key = (tuple(shape), dtype)
+    m = _METAS.get(key)
+    if m is None:
+        m = _METAS[key] = torch.empty(key[0], dtype=dtype, device="meta")
+    return m
+
+
+# methods that a PENDING stand-in answers with another stand-in (shape from the meta tensor, the work replayed at
+# first use): the reference's loop body applies exactly such ops to every render before it looks at a value --
+# out["image"].unsqueeze(0) (main_train_dimo.py:305,310,315,317), torch.cat per motion (:320-325),
+# .permute(0, 2, 3, 1) (:364,370), [i] (:333) -- and must not cut the step's batch into batches of one
+_DEFERRED_METHODS = ("unsqueeze", "squeeze", "view", "reshape", "permute", "transpose", "flatten", "contiguous",
+                     "detach", "clamp", "clamp_min", "clamp_max", "expand", "movedim", "unflatten", "narrow", "select",
+                     "float")
+
+
+def _basic_index(idx):
+    """True for an index made of ints, slices, None and Ellipsis only (a view, no tensor operand)."""
+    if isinstance(idx, tuple):
+        return all(_basic_index(i) for i in idx)
+    return idx is None or idx is Ellipsis or isinstance(idx, (int, slice))
+
+
 class LazyTensor:
     """Stand-in for a tensor that a pending batch will produce.  Not a `torch.Tensor` subclass on purpose: nothing
-    about it needs the dispatcher until it is used, and the first use replaces it by the real tensor."""
-    __slots__ = ("_fn", "_val", "__weakref__")
+    about it needs the dispatcher until it is used, and the first use replaces it by the real tensor.
 
-    def __init__(self, fn):
-        self._fn, self._val = fn, None
+    Metadata (`shape`, `dtype`, `device`, `dim()`, `size()`, `len()`) is answered from the queued request without
+    running anything; view-type methods, basic indexing and `torch.cat` / `torch.stack` over stand-ins return new
+    stand-ins (`defer=False` switches that off: the stand-in then materialises on any access).  Everything else --
+    any other torch function, method, operator or attribute -- runs the pending batch and works on the real tensor.
+    A stand-in handed to a custom `autograd.Function.apply` or a C extension is NOT unwrapped by torch: pass
+    `materialize(x)` there (the drop-ins of this package do)."""
+    __slots__ = ("_fn", "_val", "_meta", "_dev", "_src", "_defer", "unit_range", "__weakref__")
+
+    def __init__(self, fn, meta=None, device=None, src=None, defer=True, unit_range=False):
+        self._fn, self._val, self._meta, self._dev, self._src = fn, None, meta, device, src
+        self._defer = bool(defer and meta is not None)
+        # values known to lie in [0, 1] (the clamped render and its views / concatenations): lets the fused smoothness
+        # drop-ins, which read rgb as clamp(rgb, 0, 1), stand in for src/loss.py:64-106 without changing a value
+        self.unit_range = unit_range
 
     def materialize(self):
         if self._fn is not None:
             self._val, self._fn = self._fn(), None
         return self._val
 
+    @property
+    def pending(self):
+        return self._fn is not None
+
+    # ---- metadata: no flush
+    def _m(self):
+        return self._meta if (self._fn is not None and self._meta is not None) else self.materialize()
+
+    shape = property(lambda self: self._m().shape)
+    dtype = property(lambda self: self._m().dtype)
+    ndim = property(lambda self: self._m().dim())
+    device = property(lambda self: self._dev if (self._fn is not None and self._dev is not None)
+                      else self.materialize().device)
+    is_cuda = property(lambda self: self.device.type == "cuda")
+
+    def dim(self):
+        return self._m().dim()
+
+    def size(self, *a):
+        return self._m().size(*a)
+
+    def numel(self):
+        return self._m().numel()
+
+    def __len__(self):
+        return self._m().shape[0]
+
+    # ---- deferred views
+    def _derive(self, name, args, kwargs, src=None):
+        if self._fn is None:
+            val = getattr(self._val, name)(*_unwrap_all(args), **_unwrap_all(kwargs))
+            if self.unit_range and _keeps_unit_range(name, args) and isinstance(val, torch.Tensor):
+                out = LazyTensor(None, unit_range=True)  # (already resolved: only carries the [0, 1] tag on)
+                out._val = val
+                return out
+            return val
+        if self._defer and not any(type(a) is LazyTensor for a in args) and not kwargs:
+            try:
+                meta = getattr(self._meta, name)(*args)
+            except Exception:
+                meta = None  # (let the real tensor raise the real error)
+            if meta is not None:
+                parent = self
+                return LazyTensor(lambda: getattr(parent.materialize(), name)(*args), meta, self._dev, src,
+                                  unit_range=self.unit_range and _keeps_unit_range(name, args))
+        return getattr(self.materialize(), name)(*_unwrap_all(args), **_unwrap_all(kwargs))
+
+    def unsqueeze(self, *args, **kwargs):
+        s = self._src
+        src = (s[0], s[1], s[2], "unsq0") if (s is not None and s[3] == "plain" and args == (0,)) else None
+        return self._derive("unsqueeze", args, kwargs, src)
+
+    def contiguous(self, *args, **kwargs):
+        return self._derive("contiguous", args, kwargs, self._src)
+
+    def __getitem__(self, idx):
+        if self._fn is not None and self._defer and _basic_index(idx):
+            s = self._src
+            lead = idx == (None, Ellipsis) or idx is None or idx == (None,)
+            src = (s[0], s[1], s[2], "unsq0") if (s is not None and s[3] == "plain" and lead) else None
+            return self._derive("__getitem__", (idx,), {}, src)
+        return self.materialize()[_unwrap_all(idx)]
+
     @classmethod
     def __torch_function__(cls, func, types, args=(), kwargs=None):
+        if func in _CAT_FUNCS:
+            out = _lazy_cat(func, args, kwargs or {})
+            if out is not None:
+                return out
         return func(*_unwrap_all(args), **(_unwrap_all(kwargs) if kwargs else {}))
 
     def __getattr__(self, name):  # (only reached for names the class does not define)
         return getattr(self.materialize(), name)
 
     def __repr__(self):
-        return "LazyTensor(pending)" if self._fn is not None else f"LazyTensor({self._val!r})"
+        if self._fn is not None:
+            return "LazyTensor(pending%s)" % ("" if self._meta is None else f", shape={tuple(self._meta.shape)}")
+        return f"LazyTensor({self._val!r})"
+
+
+def _keeps_unit_range(name, args):
+    """Does method `name(*args)` map values in [0, 1] to values in [0, 1]?  (Views do; a clamp does when its lower
+    bound is <= 1 and its upper bound >= 0.)"""
+    if not name.startswith("clamp"):
+        return True
+    try:
+        lo, hi = {"clamp": lambda a: (a[0] if len(a) > 0 else None, a[1] if len(a) > 1 else None),
+                  "clamp_min": lambda a: (a[0], None), "clamp_max": lambda a: (None, a[0])}[name](args)
+        return (lo is None or float(lo) <= 1.0) and (hi is None or float(hi) >= 0.0)
+    except Exception:
+        return False
+
+
+def _deferred_method(name):
+    def method(self, *args, **kwargs):
+        return self._derive(name, args, kwargs)
+    method.__name__ = name
+    return method
+
+
+for _n in _DEFERRED_METHODS:
+    if _n not in LazyTensor.__dict__:
+        setattr(LazyTensor, _n, _deferred_method(_n))
+
+_CAT_FUNCS = {torch.cat: "cat", torch.stack: "stack"}
+for _n in ("concat", "concatenate"):
+    if hasattr(torch, _n):
+        _CAT_FUNCS[getattr(torch, _n)] = "cat"
+
+
+def _lazy_cat(func, args, kwargs):
+    """torch.cat / torch.stack over stand-ins only, at least one of them pending: a stand-in for the result.  When the
+    parts turn out to be the consecutive renders of ONE batch -- `out[name].unsqueeze(0)` for cat, `out[name]` for
+    stack, dim 0: the reference's per-motion collection -- the result is a zero-copy slice of the batch's contiguous
+    [n, C, H, W] output (and its gradient reaches the batch's autograd node as one tensor)."""
+    if "out" in kwargs:
+        return None
+    parts = args[0] if args else kwargs.get("tensors")
+    dim = args[1] if len(args) > 1 else kwargs.get("dim", 0)
+    if not isinstance(parts, (list, tuple)) or not parts or not isinstance(dim, int):
+        return None
+    if not all(type(p) is LazyTensor and p._defer for p in parts) or not any(p._fn is not None for p in parts):
+        return None
+    try:
+        meta = func([p._meta for p in parts], dim)
+    except Exception:
+        return None
+    parts, kind = tuple(parts), _CAT_FUNCS[func]
+
+    def run():
+        view = _batch_view(parts, kind, dim)
+        return view if view is not None else func([p.materialize() for p in parts], dim)
+
+    return LazyTensor(run, meta, parts[0]._dev, unit_range=all(p.unit_range for p in parts))
+
+
+def _batch_view(parts, kind, dim):
+    want = "unsq0" if kind == "cat" else "plain"
+    s0 = parts[0]._src
+    if dim != 0 or s0 is None:
+        return None
+    pend, i0, name, _ = s0
+    for k, p in enumerate(parts):
+        s = p._src
+        if s is None or s[0] is not pend or s[1] != i0 + k or s[2] != name or s[3] != want:
+            return None
+    full = pend["batcher"].full_output(pend, name)
+    if full is None:
+        return None
+    return full if (i0 == 0 and len(parts) == full.shape[0]) else full[i0:i0 + len(parts)]
 
 
 def _unwrap(x):
@@ -79,7 +259,7 @@ def _forward_dunder(name):
 for _n in ("add", "sub", "mul", "truediv", "floordiv", "pow", "matmul", "mod", "and", "or", "xor", "lshift", "rshift"):
     setattr(LazyTensor, f"__{_n}__", _forward_dunder(f"__{_n}__"))
     setattr(LazyTensor, f"__r{_n}__", _forward_dunder(f"__r{_n}__"))
-for _n in ("neg", "pos", "abs", "invert", "lt", "le", "gt", "ge", "eq", "ne", "getitem", "setitem", "len", "iter",
+for _n in ("neg", "pos", "abs", "invert", "lt", "le", "gt", "ge", "eq", "ne", "setitem", "iter",
            "bool", "float", "int", "index", "contains", "format", "array"):
     setattr(LazyTensor, f"__{_n}__", _forward_dunder(f"__{_n}__"))
 LazyTensor.__hash__ = lambda self: id(self)
@@ -160,7 +340,8 @@ class _BatchRenderFn(torch.autograd.Function):
     """All renders of a pending batch: skinning -> projection -> binning -> blend, one launch per stage for the batch
     (native step executor, fully batched on the caller's stream).  Inputs: the canonical Gaussians' raw parameters,
     control points, then per DISTINCT deformation its (d_xyz, d_rot), then one screen-space gradient sink per render.
-    Outputs per render: clamped image, depth, normal (or an empty tensor), alpha -- then radii of every render."""
+    Outputs, each for the whole batch: clamped image [n,3,H,W], depth [n,1,H,W], normal [n,3,H,W] (or an empty
+    tensor), alpha [n,1,H,W], radii [n,N]."""
 
     @staticmethod
     def forward(ctx, job, xyz, rotation, scaling, opacity, f_dc, c_xyz, c_radius, *rest):
@@ -207,15 +388,16 @@ class _BatchRenderFn(torch.autograd.Function):
             d.g_d_xyz, d.g_d_rot = p(job.grad_rows[2 * rq.deform]), p(job.grad_rows[2 * rq.deform + 1])
         ex.forward_range(job.first, n)
         if b.capacity is not None:
-            b.capacity.track(ex.total_words_range(job.first, n))
+            # a SNAPSHOT: the binning's fill kernel rewrites these words whenever the slots are re-used, and a renderer
+            # nobody polls looks at them only every 64 renders (8n bytes, same stream)
+            b.capacity.track(ex.total_words_range(job.first, n).clone())
         image = raw.clamp(0.0, 1.0)
         ctx.job, ctx.keep, ctx.n = job, (keep, dkeep, raw, radii), n
         ctx.ticket = job.ticket
         ctx.mark_non_differentiable(radii)
-        outs = []
-        for i in range(n):
-            outs += [image[i], depth[i], normal[i] if normal is not None else raw.new_empty(0), alpha[i]]
-        return (*outs, radii)
+        # the batch's outputs stay whole: a render's image is a select of [n, 3, H, W] made outside this node, and the
+        # reference's per-motion torch.cat (main_train_dimo.py:320-325) is a slice of it (`_batch_view`)
+        return image, depth, normal if normal is not None else raw.new_empty(0), alpha, radii
 
     @staticmethod
     def backward(ctx, *grads):
@@ -227,21 +409,9 @@ class _BatchRenderFn(torch.autograd.Function):
         N, M = ex.N, ex.M
         f32 = dict(dtype=torch.float32, device=dev)
 
-        def stack(k, ch):  # gradient images of output k of every render; None where autograd had none
-            gs = [grads[4 * i + k] for i in range(n)]
-            if all(g is None for g in gs):
-                return None
-            z = None
-            out = []
-            for g in gs:
-                if g is None:
-                    z = torch.zeros(ch, H, W, **f32) if z is None else z
-                    g = z
-                out.append(g)
-            return torch.stack(out).contiguous()
-
-        g_img, g_depth, g_alpha = stack(0, 3), stack(1, 1), stack(3, 1)
-        g_normal = stack(2, 3) if b.with_normal else None
+        g_img, g_depth, g_normal, g_alpha = [None if g is None else g.contiguous() for g in grads[:4]]
+        if not b.with_normal:
+            g_normal = None
         if g_img is None:
             g_img = torch.zeros(n, 3, H, W, **f32)
         else:  # through the clamp of the returned image
@@ -338,9 +508,12 @@ class RenderBatcher:
 
     # ---- requests
     def add(self, cam, tanfovx, tanfovy, key, deform, time, latent_index, sink):
-        """Queues one render.  key = (H, W, scale_modifier, local_frame): what a batch shares.  Returns (batch record,
-        index in it), or None if no render slot is free (the caller then renders directly)."""
+        """Queues one render.  key = what a batch shares: (H, W, scale_modifier, local_frame), the autograd mode of the
+        caller and the identity of the model (row counts, parameter storage) -- a change of any of them runs the
+        pending batch first.  Returns (batch record, index in it), or None if no render slot is free (the caller then
+        renders directly)."""
         g = self.renderer.gaussians
+        key = (*key, torch.is_grad_enabled(), g._xyz.shape[0], g._c_xyz.shape[0], g._xyz.data_ptr())
         pend = self.pending
         if pend is not None and pend["key"] != key:
             self.flush()
@@ -371,7 +544,7 @@ class RenderBatcher:
                     best, best_len = i, j - i
                 i = j
             pend = self.pending = dict(key=key, first=best, reqs=[], deforms=[], deform_ids={}, lazy_pairs=[],
-                                       outputs=None)
+                                       full=None, selects={}, error=None, batcher=self, leaders=None)
             nxt = best
         self.in_use[nxt] = True
         rq = _Request()
@@ -382,7 +555,7 @@ class RenderBatcher:
             if k not in pend["deform_ids"]:
                 pend["deform_ids"][k] = len(pend["deforms"])
                 pend["deforms"].append((dx, dq))
-        else:  # TimeNet is evaluated at flush time, once for the batch's distinct (latent, time) pairs
+        else:  # TimeNet is evaluated when first needed, once for the distinct (latent, time) pairs queued by then
             k = ("lazy", latent_index, float(time))
             if k not in pend["deform_ids"]:
                 pend["deform_ids"][k] = len(pend["deforms"])
@@ -392,31 +565,80 @@ class RenderBatcher:
         pend["reqs"].append(rq)
         return pend, rq.index
 
-    def output(self, pend, index, name):
-        if pend["outputs"] is None:
+    def _ran(self, pend):
+        """Runs `pend` if it is still the pending batch; raises if it failed."""
+        if pend["full"] is None and pend["error"] is None:
             self.flush(pend)
-        return pend["outputs"][index][name]
+        if pend["error"] is not None:
+            raise RuntimeError("the batch this output belongs to failed: %r" % (pend["error"],)) from pend["error"]
 
-    def flush(self, pend=None):
-        """Runs the pending batch (no-op if there is none or `pend` is not the pending one)."""
-        if self.pending is None or (pend is not None and pend is not self.pending):
+    def full_output(self, pend, name):
+        """Output `name` of the whole batch: [n, C, H, W] (radii: [n, N])."""
+        self._ran(pend)
+        return pend["full"][name]
+
+    def output(self, pend, index, name):
+        """Output `name` of render `index` of the batch (a select of the batch's tensor, made once)."""
+        self._ran(pend)
+        key = (index, name)
+        t = pend["selects"].get(key)
+        if t is None:
+            full = pend["full"][name]
+            t = pend["selects"][key] = None if full is None else full[index]
+        return t
+
+    def pts_slot(self, pend, index):
+        self._ran(pend)
+        return pend["leaders"][index]
+
+    def deform_of(self, pend, slot):
+        """(d_xyz [M,3], d_rot [M,4]) of the batch's deformation `slot`.  Lazily evaluated pairs run through ONE fused
+        TimeNet forward for all the pairs queued so far and not yet evaluated -- WITHOUT running the batch's renders:
+        the reference reads out["cpts_t"] right after every render() (geometry-anchor term, main_train_dimo.py:295-303)."""
+        d = pend["deforms"][slot]
+        if d is None:
+            self._eval_lazy_pairs(pend)
+            d = pend["deforms"][slot]
+        return d
+
+    def _eval_lazy_pairs(self, pend):
+        pairs = [q for q in pend["lazy_pairs"] if pend["deforms"][q[0]] is None]
+        if not pairs:
             return
-        pend, self.pending = self.pending, None
-        r = self.renderer
-        g = r.gaussians
-        reqs = pend["reqs"]
-        n = len(reqs)
-        _H, _W, scale_modifier, local_frame = pend["key"]
-        deforms = list(pend["deforms"])
-        if pend["lazy_pairs"]:
-            pairs = pend["lazy_pairs"]
+        g = self.renderer.gaussians
+        with torch.set_grad_enabled(pend["key"][4]):
             if g.vae_latent:
                 table, rows = torch.stack([g.latent_code(li) for (_, li, _) in pairs]), None
             else:
                 table, rows = g._latent_codes, [li for (_, li, _) in pairs]
             dx, dq = timenet_apply(g._timenet, g._c_xyz, table, [t for (_, _, t) in pairs], rows)
             for j, (slot, _, _) in enumerate(pairs):
-                deforms[slot] = (dx[j], dq[j])
+                pend["deforms"][slot] = (dx[j], dq[j])
+
+    def flush(self, pend=None):
+        """Runs the pending batch (no-op if there is none or `pend` is not the pending one)."""
+        if self.pending is None or (pend is not None and pend is not self.pending):
+            return
+        pend, self.pending = self.pending, None
+        n = len(pend["reqs"])
+        try:
+            with torch.set_grad_enabled(pend["key"][4]):  # (the mode the renders were queued in)
+                self._run(pend)
+        except BaseException as e:  # the stand-ins of this batch re-raise it; its slots are free again
+            pend["error"] = e
+            self._release(pend["first"], n)
+            raise
+        finally:
+            pend["reqs"] = None
+
+    def _run(self, pend):
+        r = self.renderer
+        g = r.gaussians
+        reqs = pend["reqs"]
+        n = len(reqs)
+        _H, _W, scale_modifier, local_frame = pend["key"][:4]
+        self._eval_lazy_pairs(pend)
+        deforms = pend["deforms"]
         job = _Job()
         job.batcher, job.reqs, job.deforms = self, reqs, deforms
         job.local_frame, job.scale_modifier = bool(local_frame), float(scale_modifier)
@@ -424,20 +646,17 @@ class RenderBatcher:
         job.first, job.ticket = pend["first"], _Ticket(self, pend["first"], n)
         flat = [t for dq in deforms for t in dq]
         sinks = [rq.sink for rq in reqs]
-        outs = _BatchRenderFn.apply(job, g._xyz, g._rotation, g._scaling, g._opacity, g._features_dc, g._c_xyz,
-                                    g._c_radius, *flat, *sinks)
-        radii = outs[-1]
-        outputs, lead = [], {}
+        image, depth, normal, alpha, radii = _BatchRenderFn.apply(
+            job, g._xyz, g._rotation, g._scaling, g._opacity, g._features_dc, g._c_xyz, g._c_radius, *flat, *sinks)
+        # (the skinned Gaussians of a deformation group live in the slot of its first render of the launch chunk)
+        lead, leaders = {}, []
         for i, rq in enumerate(reqs):
-            image, depth, normal, alpha = outs[4 * i:4 * i + 4]
-            # (the skinned Gaussians of a deformation group live in the slot of its first render of the launch chunk)
-            leader = lead.setdefault((i // 8, rq.deform), i)
-            outputs.append(dict(image=image, depth=depth, normal=normal if self.with_normal else None, alpha=alpha,
-                                radii=radii[i], cpts_delta=deforms[rq.deform][0], pts_slot=pend["first"] + leader))
-        pend["outputs"] = outputs
-        pend["reqs"], pend["deforms"] = None, None
+            leaders.append(pend["first"] + lead.setdefault((i // 8, rq.deform), i))
+        pend["leaders"] = leaders
+        pend["full"] = dict(image=image, depth=depth, normal=normal if self.with_normal else None, alpha=alpha,
+                            radii=radii)
         self.flushes += 1
         self.rendered += n
-        if not any(t.requires_grad for t in outs[:-1]):
+        if not (image.requires_grad or depth.requires_grad or alpha.requires_grad):
             job.ticket.release()  # nothing will come back for these renders: their slots are free again
         job.ticket = None  # (the autograd node holds the only other reference)

@@ -82,25 +82,40 @@ def getProjectionMatrix(znear, zfar, fovX, fovY):
     return P
 
 
+_DEVICE_MATRICES = {}
+
+
 class MiniCam:
+    """renderer/latent_gs_renderer.py:943-970.  The reference builds one per render (main_train_dimo.py:286-287): a
+    numpy inverse and four synchronous host-to-device copies, each of which waits for everything queued on the stream.
+    The device matrices are therefore cached by VALUE (pose bytes, size, fov, planes, device): the same 9 views come
+    back thousands of times, and a loop that constructs a MiniCam per render never touches the device after the first
+    time it sees a view."""
+
     def __init__(self, c2w, width, height, fovy, fovx, znear, zfar, device=None):
         if device is None:
             device = "cuda" if torch.cuda.is_available() else "cpu"
         self.image_width, self.image_height = width, height
         self.FoVy, self.FoVx = fovy, fovx
         self.znear, self.zfar = znear, zfar
-        w2c = np.linalg.inv(c2w)
-        w2c[1:3, :3] *= -1  # flip y and z rows of the rotation
-        w2c[:3, 3] *= -1  # negate the translation
-        wv = torch.tensor(w2c).transpose(0, 1)
-        proj = getProjectionMatrix(znear=znear, zfar=zfar, fovX=fovx, fovY=fovy).transpose(0, 1)
-        # all three are tiny: build on the host, upload once
-        self.world_view_transform = wv.contiguous().to(device)
-        self.projection_matrix = proj.contiguous().to(device)
-        self.full_proj_transform = (wv @ proj.to(wv.dtype)).contiguous().to(device)
-        self.camera_center = (-torch.tensor(c2w[:3, 3])).to(device)
         self.tanfovx = math.tan(fovx * 0.5)
         self.tanfovy = math.tan(fovy * 0.5)
+        c2w = np.asarray(c2w)
+        key = (c2w.tobytes(), str(c2w.dtype), float(fovy), float(fovx), float(znear), float(zfar), str(device))
+        hit = _DEVICE_MATRICES.get(key)
+        if hit is None:
+            w2c = np.linalg.inv(c2w)
+            w2c[1:3, :3] *= -1  # flip y and z rows of the rotation
+            w2c[:3, 3] *= -1  # negate the translation
+            wv = torch.tensor(w2c).transpose(0, 1)
+            proj = getProjectionMatrix(znear=znear, zfar=zfar, fovX=fovx, fovY=fovy).transpose(0, 1)
+            # all four are tiny: build on the host, upload once
+            hit = (wv.contiguous().to(device), proj.contiguous().to(device),
+                   (wv @ proj.to(wv.dtype)).contiguous().to(device), (-torch.tensor(c2w[:3, 3])).to(device))
+            if len(_DEVICE_MATRICES) > 4096:
+                _DEVICE_MATRICES.clear()
+            _DEVICE_MATRICES[key] = hit
+        self.world_view_transform, self.projection_matrix, self.full_proj_transform, self.camera_center = hit
 
 
 class CameraCache:

@@ -188,6 +188,7 @@ class DensifyMixin:
         statistics move together; returns the permutation (new row -> old row)."""
         perm = morton_order(self._xyz.detach())
         if self.optimizer is None:
+            self.flush_pending_renders()
             for name in ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation") + \
                     (("_r",) if self.r_is_per_point() else ()):
                 p = getattr(self, name)

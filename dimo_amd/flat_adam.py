@@ -22,6 +22,7 @@ class FlatAdam:
         self.flat_params, self.flat_grads = flat_params, flat_grads
         self.exp_avg = torch.zeros_like(flat_params)
         self.exp_avg_sq = torch.zeros_like(flat_params)
+        self.pre_step = None  # callable run before every step (GaussianModel: renders queued behind render() run first)
         self.launches = 0  # every step() call, applied or skipped on the device
         self.skipped_host = 0  # skipped launches the host knows of (Trainer: read back with a lag of one step)
         # the device's own count of skipped launches (two words written alternately, see adam.hip): the bias
@@ -60,6 +61,8 @@ class FlatAdam:
     def step(self, skip_flags=None, zero_grad=False):
         """skip_flags: optional int32 tensor [k, 2] (rasterizer `total` words: R, overflow) -- any non-zero
         overflow word turns this step into a no-op on the device."""
+        if self.pre_step is not None:
+            self.pre_step()
         self.launches += 1
         lrs = (C.c_float * self._n_seg)(*[float(g["lr"]) for g in self.param_groups])
         b1, b2 = self.defaults["betas"]

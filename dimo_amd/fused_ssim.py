@@ -41,6 +41,8 @@ class _FusedSSIM(torch.autograd.Function):
 def fused_ssim(img1, img2, padding="same", train=True):
     if padding != "same":
         raise NotImplementedError("only zero 'same' padding (the reference's src/loss.py:144 semantics)")
+    from .losses import materialize  # (stand-ins of queued renders: an autograd Function needs the tensors)
+    img1, img2 = materialize(img1), materialize(img2)
     if img1.dim() == 3:
         img1, img2 = img1[None], img2[None]
     return _FusedSSIM.apply(img1, img2)

@@ -91,6 +91,15 @@ class GaussianModel(DensifyMixin, PlyMixin):
         self.neighbor_dists = self.neighbor_indices = None
         self.flat_params = self.flat_grads = None
         self._dist2_fn = dist2_fn  # defaults to the HIP distCUDA2 drop-in (no CPU fallback)
+        self._flush_pending_renders = None  # set by a Renderer that queues renders (dimo_amd/batched_render.py)
+
+    def flush_pending_renders(self):
+        """Runs the renders a batching `Renderer` has queued and nobody has looked at yet.  Called before anything
+        changes the parameters (optimizer step, densify / prune / sort): a queued render shows the model of the
+        moment `render()` was called, exactly as an immediate render would."""
+        fn = self._flush_pending_renders
+        if fn is not None:
+            fn()
 
     # ------------------------------------------------------------------ activations / accessors
     scaling_activation = staticmethod(torch.exp)
@@ -272,6 +281,7 @@ class GaussianModel(DensifyMixin, PlyMixin):
         from the plan's source rows (zero for fresh rows / the `zero_moments` groups), everything else carried over;
         ONE rebuild of the flat parameter / gradient / moment buckets."""
         assert self.optimizer is not None, "training_setup first"
+        self.flush_pending_renders()
         old = self.per_gaussian()
         new_moments, carried = {}, {}
         for k, p in old.items():
@@ -328,8 +338,10 @@ class GaussianModel(DensifyMixin, PlyMixin):
         if fused == "flat":  # one HIP launch over the flat bucket (dimo_amd/csrc/adam.hip)
             from .flat_adam import FlatAdam
             self.optimizer = FlatAdam(groups, self.flat_params, self.flat_grads, eps=1e-15)
+            self.optimizer.pre_step = self.flush_pending_renders
         else:
             self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15, **({"fused": True} if fused else {}))
+            self.optimizer.register_step_pre_hook(lambda *a, **k: self.flush_pending_renders())
 
     def training_setup(self, training_args, fused=None):
         self.percent_dense = training_args.percent_dense

@@ -144,6 +144,7 @@ class Renderer:
     def _render_batched(self, cam, scaling_modifier, local_frame, deform, time, latent_index):
         """Queues the render (dimo_amd/batched_render.py); None if no render slot is free."""
         from .batched_render import LazyTensor, RenderBatcher
+        from .batched_render import _meta as _meta_of
         g = self.gaussians
         if self._batcher is None:
             self._batcher = RenderBatcher(self)
@@ -158,21 +159,35 @@ class Renderer:
         if handle is None:
             return None
         pend, i = handle
-        lazy = lambda name: LazyTensor(lambda: b.output(pend, i, name))
-        radii = lazy("radii")
-        if deform is not None:
-            cpts_t = g._c_xyz + deform[0]
-        else:
-            cpts_t = LazyTensor(lambda: g._c_xyz + b.output(pend, i, "cpts_delta"))
+        g._flush_pending_renders = self._flush_ref  # the model's mutators and its optimizer run what is queued first
+        dev, N, M = self.device, g._xyz.shape[0], g._c_xyz.shape[0]
+        H, W = key[0], key[1]
+        f32, meta = torch.float32, _meta_of
+
+        def lazy(name, shape, dtype=f32):
+            return LazyTensor(lambda: b.output(pend, i, name), meta(shape, dtype), dev, (pend, i, name, "plain"),
+                              unit_range=name == "image")  # (the returned image is clamped: latent_gs_renderer.py:1279)
+
+        radii = lazy("radii", (N,), torch.int32)
+        slot = pend["reqs"][i].deform
+        # (no deferred indexing on cpts_t / pts_t: the reference hands cpts_t[None] to a third-party autograd
+        # extension -- chamferdist, main_train_dimo.py:297-299 -- which needs a real tensor)
+        cpts_t = LazyTensor(lambda: g._c_xyz + b.deform_of(pend, slot)[0], meta((M, 3), f32), dev, defer=False)
 
         def pts_t():  # the skinned Gaussians live in a render slot (overwritten by the batch's backward)
-            return b.ex.slots[b.output(pend, i, "pts_slot")]["pts"].clone()
+            return b.ex.slots[b.pts_slot(pend, i)]["pts"].clone()
 
         return {
-            "image": lazy("image"), "depth": lazy("depth"), "normal": lazy("normal") if self.add_normal else None,
-            "alpha": lazy("alpha"), "viewspace_points": sink, "visibility_filter": LazyTensor(lambda: radii > 0),
-            "radii": radii, "pts_t": LazyTensor(pts_t), "cpts_t": cpts_t,
+            "image": lazy("image", (3, H, W)), "depth": lazy("depth", (1, H, W)),
+            "normal": lazy("normal", (3, H, W)) if self.add_normal else None,
+            "alpha": lazy("alpha", (1, H, W)), "viewspace_points": sink,
+            "visibility_filter": LazyTensor(lambda: radii.materialize() > 0, meta((N,), torch.bool), dev, defer=False),
+            "radii": radii, "pts_t": LazyTensor(pts_t, meta((N, 3), f32), dev, defer=False), "cpts_t": cpts_t,
         }
+
+    def _flush_ref(self):
+        if self._batcher is not None:
+            self._batcher.flush()
 
     def _settings(self, cam, scaling_modifier, bg_color):
         from .rasterizer import GaussianRasterizationSettings

@@ -359,17 +359,18 @@ class Trainer:
     def motion_loss(self, outs, gts, masks, weights, n_img):
         """Loss of one motion's local images; mean-type terms carry the share len(outs)/n_img."""
         c = self.cfg
-        img = torch.stack([o["image"] for o in outs])
+        from .batched_render import materialize  # (stand-ins of queued renders -> the batch's tensors, zero-copy)
+        img = materialize(torch.stack([o["image"] for o in outs]))  # (the clamped render: values in [0, 1])
         share = len(outs) / n_img
         depth_on, normal_on = self._reg_on()
-        alpha = torch.stack([o["alpha"] for o in outs])
+        alpha = materialize(torch.stack([o["alpha"] for o in outs]))
         if img.is_cuda and self.ssim.__module__ == "dimo_amd.fused_ssim" and not c.use_lpips:
             # every image term of the motion as ONE autograd node on the fused kernels (dimo_amd/fused_losses.py)
             from .fused_losses import motion_loss as fused_motion_loss
             from .image_loss import loss_weights
             B, _, H, W = img.shape
-            depth = torch.stack([o["depth"] for o in outs]) if depth_on else None
-            normal = torch.stack([o["normal"] for o in outs]) if normal_on else None
+            depth = materialize(torch.stack([o["depth"] for o in outs])) if depth_on else None
+            normal = materialize(torch.stack([o["normal"] for o in outs])) if normal_on else None
             return fused_motion_loss(img, depth, normal, alpha, list(gts), list(masks),
                                      [c.lambda_mse * w / (3 * H * W) for w in weights],
                                      loss_weights(c, B, n_img, H, W, depth_on, normal_on), c.lambda_ssim * share)
@@ -381,11 +382,11 @@ class Trainer:
         loss = loss + c.lambda_mask * share * ((alpha - torch.stack(masks)) ** 2).mean()
         img_hwc = img.permute(0, 2, 3, 1)
         if depth_on:
-            depth = torch.stack([o["depth"] for o in outs]).permute(0, 2, 3, 1)
-            loss = loss + c.lambda_smooth * share * compute_edge_aware_smoothness_loss(depth, img_hwc)
+            depth = materialize(torch.stack([o["depth"] for o in outs])).permute(0, 2, 3, 1)
+            loss = loss + c.lambda_smooth * share * compute_edge_aware_smoothness_loss(depth, img_hwc, img.is_cuda)
         if normal_on:
-            normal = torch.stack([o["normal"] for o in outs]).permute(0, 2, 3, 1)
-            loss = loss + c.lambda_bilateral * share * compute_bilateral_normal_smoothness_loss(normal, img_hwc)
+            normal = materialize(torch.stack([o["normal"] for o in outs])).permute(0, 2, 3, 1)
+            loss = loss + c.lambda_bilateral * share * compute_bilateral_normal_smoothness_loss(normal, img_hwc, img.is_cuda)
         if c.use_lpips:
             loss = loss + c.lambda_lpips * share * self.lpips_metric()(img, gt).mean()
         return loss

@@ -74,3 +74,136 @@ def test_capacity_policy_takes_single_renders_and_batches():
     before = pol.capacity
     assert not pol.check() and pol.capacity >= before
     assert pol.check()  # nothing pending
+
+
+# ---------------------------------------------------------------------------- deferred metadata / views / cat (round 4)
+def _lazy_meta(value, **kw):
+    from dimo_amd.batched_render import _meta
+    calls = []
+
+    def fn():
+        calls.append(1)
+        return value
+
+    return LazyTensor(fn, _meta(value.shape, value.dtype), value.device, **kw), calls
+
+
+def test_metadata_is_answered_without_running_anything():
+    lz, calls = _lazy_meta(torch.zeros(3, 8, 6))
+    assert tuple(lz.shape) == (3, 8, 6) and lz.dtype == torch.float32 and lz.device.type == "cpu" and not lz.is_cuda
+    assert lz.dim() == 3 and lz.ndim == 3 and lz.size(1) == 8 and tuple(lz.size()) == (3, 8, 6) and len(lz) == 3
+    assert lz.numel() == 144 and "pending" in repr(lz) and not calls
+
+
+def test_the_reference_loops_view_ops_stay_pending_and_give_the_same_values():
+    """main_train_dimo.py:305-325, 333, 364: unsqueeze(0) per render, torch.cat per motion, [k] per image, permute for
+    the smoothness terms -- none of them may run the batch; the first VALUE use does, once."""
+    base = [torch.randn(3, 5, 4, requires_grad=True) for _ in range(4)]
+    lz, calls = zip(*[_lazy_meta(b * 2.0) for b in base])
+    cat = torch.cat([x.unsqueeze(0) for x in lz], dim=0)
+    k1 = cat[1]
+    hwc = cat.permute(0, 2, 3, 1)
+    st = torch.stack(list(lz))
+    none_idx = lz[2][None, ...]
+    assert not any(calls), "a view op ran the producer"
+    assert tuple(cat.shape) == (4, 3, 5, 4) and tuple(k1.shape) == (3, 5, 4) and tuple(hwc.shape) == (4, 5, 4, 3)
+    assert tuple(st.shape) == (4, 3, 5, 4) and tuple(none_idx.shape) == (1, 3, 5, 4)
+    want = torch.cat([(b * 2.0).unsqueeze(0) for b in base])
+    loss = torch.nn.functional.mse_loss(k1, torch.zeros(3, 5, 4)) + hwc.sum() + (st * 0.5).sum() + none_idx.sum()
+    assert all(len(c) == 1 for c in calls)
+    assert torch.equal(materialize(cat), want) and torch.equal(materialize(hwc), want.permute(0, 2, 3, 1))
+    loss.backward()
+    ref = [b.detach().clone().requires_grad_(True) for b in base]
+    w = torch.cat([(b * 2.0).unsqueeze(0) for b in ref])
+    (torch.nn.functional.mse_loss(w[1], torch.zeros(3, 5, 4)) + w.permute(0, 2, 3, 1).sum() +
+     (torch.stack([b * 2.0 for b in ref]) * 0.5).sum() + (ref[2] * 2.0)[None, ...].sum()).backward()
+    for b, r in zip(base, ref):
+        assert torch.allclose(b.grad, r.grad)
+
+
+def test_cat_with_a_real_tensor_or_a_non_deferring_stand_in_materialises():
+    lz, calls = _lazy_meta(torch.ones(2, 3))
+    out = torch.cat([lz, torch.zeros(2, 3)])
+    assert isinstance(out, torch.Tensor) and calls == [1]
+    nd, c2 = _lazy_meta(torch.ones(4, 3), defer=False)
+    got = nd[None]          # (cpts_t: handed to third-party autograd extensions, must be a tensor)
+    assert isinstance(got, torch.Tensor) and c2 == [1] and tuple(got.shape) == (1, 4, 3)
+    assert tuple(nd.shape) == (4, 3)
+
+
+def test_tensor_index_and_bad_view_fall_back_to_the_real_tensor():
+    lz, calls = _lazy_meta(torch.arange(12.0).reshape(3, 4))
+    got = lz[torch.tensor([0, 2])]
+    assert isinstance(got, torch.Tensor) and calls == [1] and tuple(got.shape) == (2, 4)
+    lz2, c2 = _lazy_meta(torch.arange(12.0).reshape(3, 4))
+    try:
+        lz2.view(5, 5)
+        raise AssertionError("an impossible view must raise")
+    except RuntimeError:
+        pass
+    assert c2 == [1]  # the real tensor raised the real error
+
+
+def test_consecutive_renders_of_one_batch_concatenate_to_a_zero_copy_slice():
+    """`_batch_view`: out[name].unsqueeze(0) of renders i0 .. i0+n-1 of ONE batch, cat on dim 0 (or the plain outputs,
+    stack) is the slice [i0 : i0+n] of the batch's [n, C, H, W] output -- same storage, no copy; any other
+    combination is an ordinary cat of the materialised parts."""
+    from dimo_amd.batched_render import _meta
+    full = torch.arange(6 * 2 * 3 * 3, dtype=torch.float32).reshape(6, 2, 3, 3)
+    flushed = []
+
+    class FakeBatcher:
+        def full_output(self, pend, name):
+            flushed.append(name)
+            return full
+
+        def output(self, pend, i, name):
+            return full[i]
+
+    pend = dict(batcher=FakeBatcher())
+    outs = [LazyTensor(lambda i=i: pend["batcher"].output(pend, i, "image"), _meta((2, 3, 3)), torch.device("cpu"),
+                       (pend, i, "image", "plain")) for i in range(6)]
+    a = torch.cat([o.unsqueeze(0) for o in outs[2:5]], dim=0)
+    b = torch.stack(outs[0:6])
+    c = torch.cat([outs[1][None], outs[2][None, ...]])
+    d = torch.cat([outs[3].unsqueeze(0), outs[1].unsqueeze(0)])      # not consecutive: ordinary cat
+    e = torch.cat([o.unsqueeze(0) for o in outs[2:4]], dim=1)          # not dim 0: ordinary cat
+    assert not flushed
+    ta, tb, tc, td, te = (materialize(x) for x in (a, b, c, d, e))
+    assert ta.data_ptr() == full[2:5].data_ptr() and torch.equal(ta, full[2:5])
+    assert tb.data_ptr() == full.data_ptr() and tb.shape == full.shape
+    assert tc.data_ptr() == full[1:3].data_ptr()
+    assert torch.equal(td, torch.stack([full[3], full[1]])) and td.data_ptr() != full[3].data_ptr()
+    assert tuple(te.shape) == (1, 4, 3, 3)
+
+
+def test_unit_range_tag_follows_views_and_cats_of_the_clamped_image():
+    """The fused smoothness drop-ins read rgb as clamp(rgb, 0, 1); they may stand in for src/loss.py:64-106 only for
+    values known to lie in [0, 1]: the tag `Renderer.render` puts on out["image"] must survive the reference's
+    unsqueeze / cat / permute, before AND after the batch has run, and nothing else may carry it."""
+    img, _ = _lazy_meta(torch.rand(3, 4, 4), unit_range=True)
+    dep, _ = _lazy_meta(torch.rand(1, 4, 4))
+    cat = torch.cat([img.unsqueeze(0), img.unsqueeze(0)])
+    assert cat.unit_range and cat.permute(0, 2, 3, 1).unit_range and cat[0].clamp(0, 1).unit_range
+    assert not cat.clamp(2.0, 3.0).unit_range and not dep.unsqueeze(0).unit_range
+    assert not torch.cat([img.unsqueeze(0), torch.cat([dep, dep, dep]).unsqueeze(0)]).unit_range
+    materialize(cat)
+    after = cat.permute(0, 2, 3, 1)      # the loss section permutes AFTER the per-image MSE has run the batch
+    assert getattr(after, "unit_range", False) and tuple(after.shape) == (2, 4, 4, 3)
+    from dimo_amd.losses import _fused_ok
+    x = torch.rand(2, 4, 4, 1)
+    assert not _fused_ok(x, torch.rand(2, 4, 4, 3), 1, None)           # an arbitrary tensor: PyTorch formulation
+    assert not _fused_ok(x, torch.rand(2, 4, 4, 3), 1, True)           # (CPU: never fused)
+
+
+def test_a_failing_producer_raises_at_the_use():
+    def boom():
+        raise RuntimeError("render failed")
+    from dimo_amd.batched_render import _meta
+    lz = LazyTensor(boom, _meta((2, 2)), torch.device("cpu"))
+    v = lz.unsqueeze(0)
+    try:
+        v.sum()
+        raise AssertionError("expected the producer's error")
+    except RuntimeError as e:
+        assert "render failed" in str(e)

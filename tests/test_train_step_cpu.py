@@ -221,3 +221,82 @@ def test_progressive_render_resolution_rule():
     assert torch.equal(img, want)
     cfg2 = small_cfg(motions_per_step=1, resolution=96, num_pts=50)
     assert make_cpu_trainer(cfg2).render_resolution() == 96  # never above the configured size
+
+
+# ---------------------------------------------------------------------------- world sizes 3 / 4 / 8 (round 4)
+def _dp_cfg(kind):
+    if kind == "uneven":     # 4 renders: world 3 -> shards of 1, 1, 2; world 8 -> four ranks with an EMPTY shard
+        return small_cfg(motions_per_step=2, views_per_step=2, frames_per_step=1, resolution=48, num_pts=300)
+    if kind == "strong_b2":  # the reference's batch_size 2 step: 4 motions x 2 views x 2 frames = 16 renders
+        return small_cfg(num_motions=4, motions_per_step=4, views_per_step=2, frames_per_step=2, resolution=32,
+                         num_pts=200, num_cpts=16)
+    raise ValueError(kind)
+
+
+def _dp_worker_n(rank, world, port, out, kind, steps):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    tr = make_cpu_trainer(_dp_cfg(kind), rank=rank, world=world)
+    tr.step = 250  # every image term on
+    counts = [tr.train_step() for _ in range(steps)]
+    torch.save(dict(params=tr.renderer.gaussians.flat_params.clone(), counts=counts), f"{out}/rank{rank}.pt")
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("world,kind,steps", [(3, "uneven", 2), (8, "uneven", 2), (4, "strong_b2", 1), (8, "strong_b2", 1)])
+def test_data_parallel_world_sizes_uneven_and_empty_shards(tmp_path, world, kind, steps):
+    """SURVEY section 4 asks for 2-8 ranks: uneven shards (world 3), ranks with NO render at all (4 renders on 8
+    ranks: they still take part in every collective and apply the same update) and the strong-scaling shape of
+    DESIGN section 6 (batch_size 2 = 16 renders: 4 / 2 per rank at world 4 / 8).  Replicas bit-identical, render
+    counts = the contiguous shard sizes, parameters equal to the single-process step."""
+    port = 21500 + (os.getpid() * 7 + world * 131 + len(kind)) % 6000
+    mp.spawn(_dp_worker_n, args=(world, port, str(tmp_path), kind, steps), nprocs=world, join=True)
+    outs = [torch.load(f"{tmp_path}/rank{r}.pt") for r in range(world)]
+    n = len(enumerate_triples(range(_dp_cfg(kind).motions_per_step), range(_dp_cfg(kind).views_per_step),
+                              range(_dp_cfg(kind).frames_per_step)))
+    want = [len(shard(list(range(n)), r, world)) for r in range(world)]
+    assert [o["counts"][0] for o in outs] == want and sum(want) == n
+    if kind == "uneven" and world == 8:
+        assert want.count(0) == 4
+    for o in outs[1:]:
+        assert torch.equal(outs[0]["params"], o["params"]), "replicas diverged"
+    single = make_cpu_trainer(_dp_cfg(kind))
+    single.step = 250
+    for _ in range(steps):
+        single.train_step()
+    p = single.renderer.gaussians.flat_params
+    rel = (p - outs[0]["params"]).abs().sum() / p.abs().sum()
+    assert rel < 1e-4, rel
+
+
+def _s1_worker_n(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    tr = make_cpu_trainer(_s1_cfg(), rank=rank, world=world, regime="init")
+    g = tr.renderer.gaussians
+    torch.manual_seed(100 + rank)
+    sizes, counts = [], []
+    for _ in range(4):
+        counts.append(tr.train_step())
+        sizes.append(g._xyz.shape[0])
+    torch.save(dict(params=g.flat_params.clone(), sizes=sizes, counts=counts, accum=g.xyz_gradient_accum.clone(),
+                    denom=g.denom.clone(), radii=g.max_radii2D.clone()), f"{out}/rank{rank}.pt")
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_stage_s1_densification_at_world_4_with_idle_ranks(tmp_path):
+    """Two renders per step on FOUR ranks: two ranks render nothing, the rank that owns the step's LAST triple feeds the
+    densification statistics (main_train_dimo.py:429-431), every rank densifies identically."""
+    port = 27500 + (os.getpid() % 2000)
+    mp.spawn(_s1_worker_n, args=(4, port, str(tmp_path)), nprocs=4, join=True)
+    outs = [torch.load(f"{tmp_path}/rank{r}.pt") for r in range(4)]
+    assert [o["counts"][0] for o in outs] == [0, 1, 0, 1]
+    assert outs[0]["sizes"][0] == 48 and outs[0]["sizes"][-1] != 48, outs[0]["sizes"]
+    for o in outs[1:]:
+        assert o["sizes"] == outs[0]["sizes"] and torch.equal(o["params"], outs[0]["params"]), "replicas diverged"
+        for k in ("accum", "denom", "radii"):
+            assert torch.equal(o[k], outs[0][k]), k
