@@ -64,7 +64,8 @@ _SIGNATURES = {
     "dimo_executor_join": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "dimo_executor_backward_launch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "dimo_executor_range_stream": (C.c_void_p, [C.c_void_p, C.c_int]),
-    "dimo_executor_backward_launch_in_order": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "dimo_executor_backward_launch_in_order": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                                         C.c_void_p]),
     "dimo_executor_backward_launch_joint": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "dimo_executor_backward_accumulate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
                                                     C.c_void_p]),

@@ -68,7 +68,9 @@ struct Executor {
   std::vector<int> range_count;   // ... and its number of renders
   int next_stream = 0;
   hipEvent_t main_ready = nullptr;
-  bool bwd_on_main = false;  // the last rasterizer backward ran on the caller's stream (joint launch): no event to wait for
+  // per range start: its rasterizer backward ran on the CALLER's stream (joint launch, or a range whose whole chain is
+  // on the caller's stream): dimo_executor_backward_accumulate has no event to wait for
+  std::vector<char> range_bwd_main;
 };
 
 __global__ void __launch_bounds__(256) accumulate_kernel(size_t n, float *__restrict__ dst,
@@ -154,6 +156,7 @@ static int ensure_events(Executor *ex, int n) {
     ex->fwd_done.push_back(f);
   }
   if ((int)ex->range_stream.size() < n) ex->range_stream.resize(n, -1), ex->range_count.resize(n, 0);
+  if ((int)ex->range_bwd_main.size() < n) ex->range_bwd_main.resize(n, 0);
   return DIMO_OK;
 }
 
@@ -326,7 +329,7 @@ extern "C" int dimo_executor_backward_launch(void *h, const dimo_step_common *c,
   const int S = (int)ex->streams.size();
   if (ex->batched && S == 0) return batched_backward_raster(c, d, first, count, main);
   if (first + count > (int)ex->render_done.size()) return DIMO_E_ARG;
-  ex->bwd_on_main = false;
+  for (int i = first; i < first + count && i < (int)ex->range_bwd_main.size(); ++i) ex->range_bwd_main[i] = 0;
   if (ex->batched) {
     const int si = ex->range_stream[first] >= 0 ? ex->range_stream[first] : 0;
     if (si >= S) return DIMO_E_ARG;  // a range on the caller's stream: use the joint launch
@@ -363,15 +366,19 @@ extern "C" void *dimo_executor_range_stream(void *h, int first) {
   return si >= 0 && si < (int)ex->streams.size() ? (void *)ex->streams[si] : nullptr;
 }
 extern "C" int dimo_executor_backward_launch_in_order(void *h, const dimo_step_common *c, int first, int count,
-                                                      const dimo_render_desc *d) {
+                                                      const dimo_render_desc *d, void *main_stream) {
   Executor *ex = reinterpret_cast<Executor *>(h);
   if (!ex || !c || first < 0 || count < 0 || (count > 0 && !d)) return DIMO_E_ARG;
   if (count == 0) return DIMO_OK;
   if (!ex->batched || ex->streams.empty() || first + count > (int)ex->render_done.size()) return DIMO_E_ARG;
   const int si = ex->range_stream[first];
-  if (si < 0 || si >= (int)ex->streams.size()) return DIMO_E_ARG;
+  if (si < 0 || si > (int)ex->streams.size()) return DIMO_E_ARG;
   clear_errors();
-  ex->bwd_on_main = false;
+  if (si == (int)ex->streams.size()) {  // the range's chain is on the caller's stream: so is its backward
+    ex->range_bwd_main[first] = 1;
+    return batched_backward_raster(c, d, first, count, (hipStream_t)main_stream);
+  }
+  ex->range_bwd_main[first] = 0;
   hipStream_t s = ex->streams[si];
   const int rc = batched_backward_raster(c, d, first, count, s);
   if (rc) return rc;
@@ -403,8 +410,9 @@ extern "C" int dimo_executor_backward_launch_joint(void *h, const dimo_step_comm
     const int rc = batched_backward_raster(c, d, ch.first, ch.second, main);
     if (rc) return rc;
   }
-  ex->bwd_on_main = true;  // (dimo_executor_backward_accumulate on the same stream follows in order: a wait on an event
-                           // recorded on that very stream cost a 10 us bubble between the two calls' kernels)
+  // (dimo_executor_backward_accumulate on the same stream follows in order: a wait on an event recorded on that very
+  // stream cost a 10 us bubble between the two calls' kernels)
+  for (int i = first; i < first + count; ++i) ex->range_bwd_main[i] = 1;
   return DIMO_OK;
 }
 
@@ -420,7 +428,14 @@ extern "C" int dimo_executor_backward_accumulate(void *h, const dimo_step_common
   if (ex->batched) {
     if (!ex->streams.empty()) {
       if (first + count > (int)ex->render_done.size()) return DIMO_E_ARG;
-      if (!ex->bwd_on_main && hipStreamWaitEvent(main, ex->render_done[first], 0) != hipSuccess) return DIMO_E_LAUNCH;
+      // every range inside [first, first + count) whose rasterizer backward ran on a private stream (plain batched
+      // launches record their event at `first`)
+      for (int i = first; i < first + count; ++i) {
+        const bool start = i == first || (i < (int)ex->range_stream.size() && ex->range_stream[i] >= 0);
+        if (!start || ex->range_bwd_main[i]) continue;
+        if (i != first && ex->range_stream[i] >= (int)ex->streams.size()) continue;
+        if (hipStreamWaitEvent(main, ex->render_done[i], 0) != hipSuccess) return DIMO_E_LAUNCH;
+      }
     }
     std::vector<std::pair<int, int>> chunks;
     if (!plan_chunks(ex, first, count, chunks)) return DIMO_E_ARG;

@@ -172,9 +172,23 @@ class DensifyMixin:
         plan.keep(~mask)
         self._finish_prune(plan)
 
-    def _finish_prune(self, plan):
+    @torch.no_grad()
+    def prune_s1_end(self, min_opacity, extent=None, max_screen_size=None):
+        """latent_gs_renderer.py:914-919 / 748-766 (end of stage s1, main_train_dimo.py:200): removes the Gaussians
+        below `min_opacity` AND the same rows of the control points -- at that point both have `num_cpts` rows (the
+        last FPS ran after the density window closed) and stage s2 is about to copy the Gaussians' positions into
+        the control points (`prepare_train_s2`).  Like the reference, only the opacity criterion is applied."""
+        if self._c_xyz.shape[0] != self._xyz.shape[0]:
+            raise ValueError("prune_s1_end: the control points must have one row per Gaussian "
+                             f"({self._c_xyz.shape[0]} vs {self._xyz.shape[0]})")
+        plan = _Plan(self)
+        mask = (plan.opacity_act() < min_opacity).squeeze(-1)
+        plan.keep(~mask)
+        self._finish_prune(plan, ctrl_keep=~mask)
+
+    def _finish_prune(self, plan, ctrl_keep=None):
         src = plan.src
-        self.rebuild(plan)
+        self.rebuild(plan, ctrl_keep=ctrl_keep)
         self.xyz_gradient_accum = self.xyz_gradient_accum[src]
         self.denom = self.denom[src]
         self.max_radii2D = self.max_radii2D[src]

@@ -166,7 +166,7 @@ class StepExecutor:
 
     def backward_launch_in_order(self, first, count):
         _lib.check(self.L.dimo_executor_backward_launch_in_order(self.handle, C.addressof(self.common), first, count,
-                                                                 C.addressof(self.descs)),
+                                                                 C.addressof(self.descs), _lib.current_stream()),
                    "dimo_executor_backward_launch_in_order")
 
     def backward_launch_joint(self, first, count):

@@ -276,10 +276,11 @@ class GaussianModel(DensifyMixin, PlyMixin):
             return None
         return st["exp_avg"], st["exp_avg_sq"], st["step"]
 
-    def rebuild(self, plan, zero_moments=()):
+    def rebuild(self, plan, zero_moments=(), ctrl_keep=None):
         """Applies a densify.py plan: new per-Gaussian parameters (values from the plan), Adam moments gathered
         from the plan's source rows (zero for fresh rows / the `zero_moments` groups), everything else carried over;
-        ONE rebuild of the flat parameter / gradient / moment buckets."""
+        ONE rebuild of the flat parameter / gradient / moment buckets.  `ctrl_keep` (bool mask over the control
+        points, `prune_s1_end` only): the control points, their radii and their moments keep those rows."""
         assert self.optimizer is not None, "training_setup first"
         self.flush_pending_renders()
         old = self.per_gaussian()
@@ -300,6 +301,14 @@ class GaussianModel(DensifyMixin, PlyMixin):
                     mo = self._moments(p)
                     if mo is not None:
                         carried[id(p)] = (mo[0].clone(), mo[1].clone(), mo[2])
+        if ctrl_keep is not None:
+            for name in ("_c_xyz", "_c_radius"):
+                old_p = getattr(self, name)
+                new_p = nn.Parameter(old_p.detach()[ctrl_keep].clone().contiguous().requires_grad_(True))
+                mo = carried.pop(id(old_p), None)
+                if mo is not None:
+                    carried[id(new_p)] = (mo[0][ctrl_keep].clone(), mo[1][ctrl_keep].clone(), mo[2])
+                setattr(self, name, new_p)
         lrs = {grp["name"]: grp["lr"] for grp in self.optimizer.param_groups}
         old_opt = self.optimizer
         P = lambda t: nn.Parameter(t.detach().clone().contiguous().requires_grad_(True))

@@ -100,6 +100,71 @@ class SyntheticTargets:
         return t
 
 
+class TeacherTargets:
+    """Self-consistent targets: the renders of a hidden, seeded TEACHER model at every (motion, view, frame) of the
+    schedule -- image = the teacher's clamped render over the white background, mask = its alpha (what the reference's
+    data loader gets from the alpha matte of a frame, utils/load_utils.py) -- generated once, resident in HBM.
+    Unlike `SyntheticTargets` (seeded noise, SURVEY.md 8d's headline workload) these can be LEARNED: a loss that falls
+    and a PSNR that rises on them is evidence that the step trains, which single-step parity cannot give."""
+
+    def __init__(self, teacher, num_motions, num_views, num_frames, resolution, radius=2, fovy=33.9, elevation=0):
+        from .camera import CameraCache
+        self.res, self.device = resolution, teacher.device
+        self.shape = (num_motions, num_views, num_frames)
+        cams = CameraCache(fovy_deg=fovy, device=teacher.device)
+        az, times = default_azimuths(num_views), frame_times(num_frames)
+        g = teacher.gaussians
+        if g.neighbor_indices is None:
+            from .knn_cuda import knn_points
+            g.neighbor_dists, g.neighbor_indices = knn_points(g._c_xyz.detach(), g._xyz.detach(), 4)
+        n = num_motions * num_views * num_frames
+        self.images = torch.empty(n, 3, resolution, resolution, device=teacher.device)
+        self.masks = torch.empty(n, 1, resolution, resolution, device=teacher.device)
+        k = 0
+        with torch.no_grad():
+            for m in range(num_motions):
+                for v in range(num_views):
+                    cam = cams.get(elevation, az[v], radius, resolution, resolution)
+                    outs = [teacher.render(cam, time=times[f], stage="s2", latent_index=m) for f in range(num_frames)]
+                    for o in outs:
+                        self.images[k].copy_(o["image"] + 0)
+                        self.masks[k].copy_(o["alpha"] + 0)
+                        k += 1
+        teacher.flush()
+
+    def get(self, motion, view, frame):
+        M, V, F = self.shape
+        k = (motion * V + view) * F + frame
+        return self.images[k], self.masks[k]
+
+
+def make_teacher(device, num_cpts=48, pts_per_cpt=40, num_motions=3, seed=1234, motion_gain=1.0):
+    """A hidden model of the family the schedule can reach: `num_cpts` control points in the unit ball, `pts_per_cpt`
+    opaque coloured Gaussians around each (colour by position: the object has structure to match), a TimeNet whose
+    heads (N(0, 1e-2) weights, scaled by `motion_gain`) move the control points."""
+    from .renderer import Renderer
+    rd = Renderer(sh_degree=0, white_background=True, num_latent_code=num_motions, add_normal=True, device=device)
+    n = num_cpts * pts_per_cpt
+    init_synthetic_model(rd, n, num_cpts, seed=seed, regime="trained", num_latent=num_motions)
+    g = rd.gaussians
+    tg = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        c = g._c_xyz.detach().cpu()
+        # an object, not a cloud: control points on a blobby shell, the Gaussians close around them
+        c = c / c.norm(dim=1, keepdim=True).clamp_min(1e-6) * (0.25 + 0.1 * torch.rand(num_cpts, 1, generator=tg))
+        g._c_xyz.copy_(c.to(g.device))
+        local = 0.05 * torch.randn(num_cpts, pts_per_cpt, 3, generator=tg)
+        xyz = (c[:, None, :] + local).reshape(-1, 3)
+        g._xyz.copy_(xyz.to(g.device))
+        g._scaling.fill_(math.log(0.025))
+        g._opacity.fill_(3.0)
+        col = (xyz / 0.4 * 0.5 + 0.5).clamp(0.05, 0.95)
+        g._features_dc.copy_(RGB2SH(col)[:, None, :].to(g.device))
+        g._c_radius.fill_(math.log(0.08))
+        g._timenet.pts_layers[-1].weight.mul_(motion_gain)
+    return rd
+
+
 def default_azimuths(num_views=9):
     return [360.0 / num_views * i for i in range(num_views)]  # main_train_dimo.py:80
 

@@ -97,6 +97,8 @@ class TrainConfig:
     densify_opacity_threshold_s1: float = 0.01
     densify_opacity_threshold_s2: float = 0.01
     init_type: str = "ag"
+    init_ratio: float = 1.0       # configs/train_config.yaml:118
+    num_pts_per_cpt: int = 200    # Gaussians spawned around every control point at the start of stage s2 (init_type "ag")
     FPS_iter: int = 1000  # stage s1: farthest-point down-sampling to num_cpts every FPS_iter steps
     # exactly the reference's schedule: render at 128 / 256 / 512 WHATEVER the targets' size and resample the targets
     # (main_train_dimo.py:261-313).  Default off: a run configured with smaller targets (the tests, the CPU oracle)
@@ -196,13 +198,23 @@ class Trainer:
         self._main_chain = int(os.environ.get("DIMO_MAIN_CHAIN", "1"))
         self._flat_adam = type(self.optimizer).__name__ == "FlatAdam"
         self._inorder_losses = os.environ.get("DIMO_INORDER_LOSSES", "1") == "1"
-        self._joint_bwd = os.environ.get("DIMO_JOINT_BWD", "1") == "1"
+        # per-motion backward (default since round 4): every motion's chain -- forward, losses, rasterizer backward --
+        # runs in order on ONE stream (the last motion's on this stream itself), so a motion's backward overlaps the
+        # other motion's losses: 1.6-4 % more frames/s than the joint launch.  "1": ONE blend / projection
+        # backward launch over all the step's renders on this stream (the kernel then runs alone on the device: bench.py
+        # switches to it for the pass its roofline clock is taken in)
+        self._joint_bwd = os.environ.get("DIMO_JOINT_BWD", "0") == "1"
         self._joint_losses = os.environ.get("DIMO_JOINT_LOSSES", "0") == "1"
-        # direct HIP pipeline: GPU, degree-0 colour (DIMO's configuration), product rasterizer; stage s2 (skinning by
-        # <= 1800 control points, `_r` retired) or stage s1 (the TimeNet moves the Gaussians, shared (1, 1) radius `_r`)
+        self._direct_wanted = direct
+        self._decide_direct()
+
+    def _decide_direct(self):
+        """Direct HIP pipeline: GPU, degree-0 colour (DIMO's configuration), product rasterizer; stage s2 (skinning by
+        <= 1800 control points, `_r` retired) or stage s1 (the TimeNet moves the Gaussians, shared (1, 1) radius `_r`)."""
+        cfg, renderer, direct = self.cfg, self.renderer, self._direct_wanted
         g0 = renderer.gaussians
-        stage_ok = (cfg.stage >= "s2" and len(g0._r) == 0 and g0._c_xyz.shape[0] <= 1800) or \
-                   (cfg.stage == "s1" and tuple(g0._r.shape) == (1, 1))
+        stage_ok = (self.stage >= "s2" and len(g0._r) == 0 and g0._c_xyz.shape[0] <= 1800) or \
+                   (self.stage == "s1" and tuple(g0._r.shape) == (1, 1))
         self.direct = (direct if direct is not None else True) and self.device.type == "cuda" \
             and stage_ok and cfg.sh_degree == 0 and renderer._rasterizer_factory is None
         if self.direct and not renderer.capacity:
@@ -221,6 +233,75 @@ class Trainer:
         if isinstance(loss, _LazyLoss):
             loss = self._last_loss = loss.value()
         return loss.detach() if loss is not None else None
+
+    # ------------------------------------------------------------------ the two-stage schedule
+    def finish_stage_s1(self):
+        """End of stage s1 (main_train_dimo.py:199-200): Gaussians and control points below opacity 0.01 go."""
+        self.renderer.gaussians.prune_s1_end(min_opacity=0.01, extent=4, max_screen_size=1)
+
+    def prepare_train_s2(self, iters_s2=None):
+        """`GUI.prepare_train_s2` (main_train_dimo.py:471-500): the stage-s1 Gaussians BECOME the control points (their
+        positions, the shared radius exp(_r) as every control radius), the canonical Gaussians are re-initialised --
+        `init_type` "ag": `num_pts_per_cpt` around every control point, "normal": `num_pts` in the unit ball --, the
+        optimizer starts afresh (TimeNet and latents keep their values), `_r` retires, and the position learning-rate
+        schedule becomes 2e-4 -> 2e-6 over `iters_s2` steps (:497-500, applied by the `lr_setup` of :209)."""
+        c, rd, g = self.cfg, self.renderer, self.renderer.gaussians
+        g.flush_pending_renders()
+        if g._c_xyz.shape[0] != g._xyz.shape[0]:
+            raise ValueError("prepare_train_s2: stage s1 must end with one Gaussian per control point "
+                             f"({g._xyz.shape[0]} Gaussians, {g._c_xyz.shape[0]} control points): run FPS / "
+                             "prune_s1_end first")
+        self.stage, self.step, c.stage = "s2", 0, "s2"
+        with torch.no_grad():
+            g._c_xyz.copy_(g._xyz)
+            g._c_radius.copy_(g._r.detach().reshape(1, -1)[:, :1].expand_as(g._c_radius))
+        g.optimizer = None  # (stage s1's: the model below is a new one)
+        rd._np_rng = np.random.default_rng(c.seed + 7919)  # (rank-identical re-initialisation; the reference draws from numpy's global generator)
+        if c.init_type == "normal":
+            rd.initialize(num_pts=c.num_pts, only_init_gaussians=True)
+        elif c.init_type == "ag":
+            rd.initialize_ag(g._c_xyz, g.get_c_radius(stage="s2"), num_cpts=g._c_xyz.shape[0],
+                             num_pts_per_cpt=c.num_pts_per_cpt, init_ratio=c.init_ratio)
+        else:
+            raise ValueError("Unsupported init type!!!")
+        # (the reference retires `_r` right AFTER training_setup and pops its Adam group; retiring it first leaves the
+        # same optimizer: the flat bucket has no slot for a parameter nobody trains)
+        g._r = torch.empty(0, device=self.device)
+        g.neighbor_dists = g.neighbor_indices = None
+        if c.spatial_sort:
+            g.sort_spatially()
+        g.training_setup(c)
+        g.active_sh_degree = g.max_sh_degree
+        if iters_s2 is not None:
+            c.position_lr_max_steps = int(iters_s2)
+        c.position_lr_init, c.position_lr_final = 0.0002, 0.000002
+        g.lr_setup(c)
+        self.cpts_s1 = None
+        self._resampled.clear()
+        self._fused_tn = None
+        self._last_stats = None
+        if self._exec is not None:
+            torch.cuda.synchronize()
+            self._exec.destroy()
+            self._exec = None
+        self._flat_adam = type(self.optimizer).__name__ == "FlatAdam"
+        self._decide_direct()
+
+    def train_dynamic(self, iters_s1, iters_s2, on_step=None):
+        """`GUI.train_dynamic` (main_train_dimo.py:170-218) without its file I/O: stage s1, the end-of-stage prune, the
+        hand-over, stage s2.  `on_step(trainer)` is called after every step (logging / evaluation hooks)."""
+        if self.stage == "s1":
+            for _ in range(iters_s1):
+                self.train_step()
+                if on_step is not None:
+                    on_step(self)
+            if iters_s1 > 0:
+                self.finish_stage_s1()
+            self.prepare_train_s2(iters_s2)
+        for _ in range(iters_s2):
+            self.train_step()
+            if on_step is not None:
+                on_step(self)
 
     # ------------------------------------------------------------------ pieces of train_step
     def find_knn(self, k=4):
@@ -655,7 +736,8 @@ class Trainer:
         # a private stream starts behind a cross-stream dependency (10-12 us on this platform, tools/xstream_latency.hip)
         # and the joint backward waits for another one when it gets there: 6790 against 6710 frames/s.  (The other
         # motions' losses on this stream as well, their forward long finished by then: 6650.)
-        main_chain = self._main_chain if (joint_bwd and not joint) else 0
+        in_order = bool(ex.ranged and self._inorder_losses and not c.use_lpips)
+        main_chain = self._main_chain if (in_order and not joint) else 0
         main_motion = list(by_motion)[-1] if (main_chain and by_motion) else None
         if ex.ranged:  # one batch per motion, on alternating private streams
             for m, trs in by_motion.items():
@@ -719,7 +801,7 @@ class Trainer:
             img, depth, normal, alpha = bufs[m]
             # batched ranges: this motion's losses and rasterizer backward continue ON ITS OWN STREAM, in order behind
             # its renders (no cross-stream event until the skinning backward); otherwise join this stream
-            own = ex.range_stream(first[m]) if (ex.ranged and self._inorder_losses and not c.use_lpips) else None
+            own = ex.range_stream(first[m]) if in_order else None
             if own is None and m != main_motion:
                 ex.join(first[m], B)  # only this motion's renders: the other motions keep rendering underneath
             stream_m = own if own is not None else stream
@@ -760,8 +842,8 @@ class Trainer:
                 d.g_dot = (g_dot.data_ptr() + b * HW4) if g_dot is not None else None
             if joint_bwd:
                 pass  # one launch chain over all the step's renders, below
-            elif own is not None:
-                ex.backward_launch_in_order(first[m], B)
+            elif own is not None or (m == main_motion and in_order):
+                ex.backward_launch_in_order(first[m], B)  # (on the stream the motion's chain runs on)
             elif ex.ranged or not ex.batched:
                 ex.backward_launch(first[m], B)  # overlaps with the next motion's losses on this stream
             if g.vae_latent:  # KL term of this motion (main_train_dimo.py:355-360): tiny, autograd

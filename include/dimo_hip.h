@@ -378,8 +378,12 @@ void *dimo_executor_range_stream(void *executor, int first);
  * renders on the CALLER's stream, ordered behind what the ranges' private streams hold at the time of the call. */
 int dimo_executor_backward_launch_joint(void *executor, const dimo_step_common *common, int first, int count,
                                         const dimo_render_desc *descs, void *main_stream);
+/* Batched ranges only: the rasterizer backward of the range that starts at `first`, IN ORDER on the stream that ran
+ * its forward chain (and its loss kernels) -- its private stream, or main_stream for a range rendered with
+ * dimo_executor_forward_range_on_caller.  Per-motion backward: one motion's backward overlaps the other motion's
+ * loss kernels (each motion of main_train_dimo.py:276-318 is one range). */
 int dimo_executor_backward_launch_in_order(void *executor, const dimo_step_common *common, int first, int count,
-                                           const dimo_render_desc *renders);
+                                           const dimo_render_desc *renders, void *main_stream);
 /* ... and, on main_stream, per render: wait for it, g_f_dc += g_shs, skinning backward (accumulate) */
 int dimo_executor_backward_accumulate(void *executor, const dimo_step_common *common, int first, int count,
                                       const dimo_render_desc *renders, void *main_stream);

@@ -300,3 +300,57 @@ def test_stage_s1_densification_at_world_4_with_idle_ranks(tmp_path):
         assert o["sizes"] == outs[0]["sizes"] and torch.equal(o["params"], outs[0]["params"]), "replicas diverged"
         for k in ("accum", "denom", "radii"):
             assert torch.equal(o[k], outs[0][k]), k
+
+
+def test_two_stage_schedule_hand_over():
+    """`Trainer.train_dynamic` = GUI.train_dynamic's shape (main_train_dimo.py:170-218): stage s1 with FPS and the
+    density window, `prune_s1_end`, `prepare_train_s2` (:471-500: Gaussians -> control points, shared radius -> control
+    radii, `num_pts_per_cpt` fresh Gaussians per control point, a new optimizer without the `r` group, position lr
+    2e-4 -> 2e-6 over iters_s2), stage s2."""
+    mk = lambda: small_cfg(stage="s1", num_pts=60, num_cpts=24, num_pts_per_cpt=5, motions_per_step=1, views_per_step=1,
+                           frames_per_step=1, resolution=32, FPS_iter=3, density_start_iter=1, density_end_iter=2,
+                           densification_interval=2, densify_grad_threshold=1e-9, position_lr_max_steps=500)
+    tr = make_cpu_trainer(mk(), regime="trained")
+    g = tr.renderer.gaussians
+    seen = []
+    tr.train_dynamic(4, 2, on_step=lambda t: seen.append((t.stage, t.step, t.renderer.gaussians._xyz.shape[0])))
+    assert [s[0] for s in seen] == ["s1"] * 4 + ["s2"] * 2 and [s[1] for s in seen] == [1, 2, 3, 4, 1, 2]
+    assert seen[0][2] == 24 and seen[3][2] == 24          # FPS at steps 0 and 3 (densified in between)
+    m = g._c_xyz.shape[0]
+    assert m <= 24 and g._xyz.shape[0] == m * 5 and seen[-1][2] == m * 5
+    assert tr.stage == "s2" and len(g._r) == 0
+    names = [grp["name"] for grp in tr.optimizer.param_groups]
+    assert "r" not in names and names[0] == "xyz"
+    assert g._xyz.data_ptr() == g.flat_params.data_ptr()
+    lr = {grp["name"]: grp["lr"] for grp in tr.optimizer.param_groups}
+    assert lr["xyz"] == 0.0002                                # main_train_dimo.py:250-253
+    assert abs(g.xyz_scheduler_args(2) - 0.000002) < 1e-12   # ... and the schedule ends at 2e-6 after iters_s2 = 2
+    assert torch.isfinite(g.flat_params).all() and torch.isfinite(tr.last_loss)
+    # right after the hand-over (no s2 step yet): the control points are where the stage-s1 Gaussians were, every
+    # control radius is the shared exp(_r), and the fresh Gaussians sit within that radius of their control point
+    tr2 = make_cpu_trainer(mk(), regime="trained")  # (the hand-over switches its config to stage s2: a fresh one)
+    g2 = tr2.renderer.gaussians
+    for _ in range(4):
+        tr2.train_step()
+    s1_xyz, s1_r = g2._xyz.detach().clone(), float(g2._r.detach().reshape(-1)[0])
+    tr2.train_dynamic(0, 0)  # (already past stage s1's steps: prune_s1_end is skipped, the hand-over runs)
+    assert torch.equal(g2._c_xyz.detach(), s1_xyz) and torch.all(g2._c_radius.detach() == s1_r)
+    d = (g2._xyz.detach()[:, None, :] - g2._c_xyz.detach()[None]).norm(dim=-1).min(dim=1).values
+    assert float(d.max()) <= float(np.exp(s1_r)) * (1 + 1e-5)
+
+
+def test_prune_s1_end_prunes_gaussians_and_control_points_together():
+    cfg = small_cfg(stage="s1", num_pts=40, num_cpts=40, resolution=32, FPS_iter=10 ** 9)
+    tr = make_cpu_trainer(cfg, regime="trained")
+    g = tr.renderer.gaussians
+    tr.train_step()
+    with torch.no_grad():
+        g._opacity[::4] = -10.0  # sigmoid < 0.01
+    keep = (torch.sigmoid(g._opacity.detach()) >= 0.01).squeeze(-1)
+    xyz, cxyz = g._xyz.detach()[keep].clone(), g._c_xyz.detach()[keep].clone()
+    m_c = g.optimizer.state[g._c_xyz]["exp_avg"][keep].clone() if g._c_xyz in g.optimizer.state else None
+    g.prune_s1_end(min_opacity=0.01, extent=4, max_screen_size=1)
+    assert g._xyz.shape[0] == 30 and g._c_xyz.shape[0] == 30 and g._c_radius.shape[0] == 30
+    assert torch.equal(g._xyz.detach(), xyz) and torch.equal(g._c_xyz.detach(), cxyz)
+    if m_c is not None:
+        assert torch.equal(g.optimizer.state[g._c_xyz]["exp_avg"], m_c)
