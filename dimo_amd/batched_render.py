@@ -203,11 +203,28 @@ def _lazy_cat(func, args, kwargs):
         return None
     if not all(type(p) is LazyTensor and p._defer for p in parts) or not any(p._fn is not None for p in parts):
         return None
-    try:
-        meta = func([p._meta for p in parts], dim)
-    except Exception:
+    # the result's shape by hand: torch.cat / torch.stack on META tensors run a Python decomposition (~140 us per call,
+    # 1.2 ms per step of the reference's loop -- more than all the renders' own host work)
+    kind = _CAT_FUNCS[func]
+    s0, dt = tuple(parts[0]._meta.shape), parts[0]._meta.dtype
+    nd = len(s0) + (1 if kind == "stack" else 0)
+    if not -nd <= dim < nd or nd == 0:
         return None
-    parts, kind = tuple(parts), _CAT_FUNCS[func]
+    d = dim % nd
+    if kind == "stack":
+        if any(tuple(p._meta.shape) != s0 or p._meta.dtype != dt for p in parts):
+            return None
+        shape = s0[:d] + (len(parts),) + s0[d:]
+    else:
+        tot = 0
+        for p in parts:
+            sp = tuple(p._meta.shape)
+            if len(sp) != nd or sp[:d] != s0[:d] or sp[d + 1:] != s0[d + 1:] or p._meta.dtype != dt:
+                return None
+            tot += sp[d]
+        shape = s0[:d] + (tot,) + s0[d + 1:]
+    meta = _meta(shape, dt)
+    parts = tuple(parts)
 
     def run():
         view = _batch_view(parts, kind, dim)
@@ -271,6 +288,9 @@ def materialize(x):
 
 
 # ------------------------------------------------------------------------------------------------ fused TimeNet
+_TN_POOL = weakref.WeakKeyDictionary()  # net -> FusedTimeNet wrappers not in flight (one wraps twenty ctypes pointers)
+
+
 class _TimeNetFn(torch.autograd.Function):
     """TimeNet on the HIP library as one autograd node.  The gradients of the network's OWN parameters are added to
     their `.grad` by the backward kernel (FusedTimeNet.backward); control points and latents get theirs returned."""
@@ -278,9 +298,12 @@ class _TimeNetFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, net, pts, latent_table, times, rows):
         from .fused_timenet import FusedTimeNet
-        fused = FusedTimeNet(net)  # (its workspace belongs to this call: several forwards may precede one backward)
+        free = _TN_POOL.setdefault(net, [])
+        # (a wrapper's workspace belongs to ONE forward until its backward has run: several forwards may precede one
+        # backward, each then takes its own wrapper)
+        fused = free.pop() if free else FusedTimeNet(net)
         d_xyz, d_rot = fused.forward(pts.detach().contiguous(), times, latent_table.detach().contiguous(), rows)
-        ctx.fused, ctx.shapes = fused, (pts.shape, latent_table.shape)
+        ctx.fused, ctx.shapes, ctx.net = fused, (pts.shape, latent_table.shape), net
         return d_xyz, d_rot
 
     @staticmethod
@@ -290,6 +313,10 @@ class _TimeNetFn(torch.autograd.Function):
         g_pts = torch.zeros(pshape, dtype=torch.float32, device=dev)
         g_lat = torch.zeros(lshape, dtype=torch.float32, device=dev)
         ctx.fused.backward(g_xyz.contiguous(), g_rot.contiguous(), g_pts, g_lat)
+        free = _TN_POOL.setdefault(ctx.net, [])
+        if len(free) < 8:
+            free.append(ctx.fused)
+        ctx.fused = None
         return None, g_pts, g_lat, None, None
 
 
@@ -300,9 +327,10 @@ def timenet_fusable(net, pts):
 def timenet_apply(net, pts, latent_table, times, rows=None):
     """d_xyz [P,M,3], d_rot [P,M,4] of `net` for P (latent row, time) pairs in ONE fused launch chain, differentiable
     w.r.t. pts, the latent table and (by side effect on .grad) the network's parameters."""
-    for p in net.parameters():  # the backward kernel ADDS to .grad: every parameter needs one
-        if p.requires_grad and p.grad is None:
-            p.grad = torch.zeros_like(p)
+    if net.deformnet[0].weight.grad is None or net.rot_layers[-1].bias.grad is None:
+        for p in net.parameters():  # the backward kernel ADDS to .grad: every parameter needs one
+            if p.requires_grad and p.grad is None:
+                p.grad = torch.zeros_like(p)
     return _TimeNetFn.apply(net, pts, latent_table, [float(t) for t in times], None if rows is None else list(rows))
 
 
@@ -392,7 +420,7 @@ class _BatchRenderFn(torch.autograd.Function):
             # nobody polls looks at them only every 64 renders (8n bytes, same stream)
             b.capacity.track(ex.total_words_range(job.first, n).clone())
         image = raw.clamp(0.0, 1.0)
-        ctx.job, ctx.keep, ctx.n = job, (keep, dkeep, raw, radii), n
+        ctx.job, ctx.keep, ctx.n = job, (keep, dkeep, raw, radii, image), n
         ctx.ticket = job.ticket
         ctx.mark_non_differentiable(radii)
         # the batch's outputs stay whole: a render's image is a select of [n, 3, H, W] made outside this node, and the
@@ -403,7 +431,7 @@ class _BatchRenderFn(torch.autograd.Function):
     def backward(ctx, *grads):
         job, n = ctx.job, ctx.n
         b, ex = job.batcher, job.batcher.ex
-        keep, dkeep, raw, _radii = ctx.keep
+        keep, dkeep, raw, _radii, image = ctx.keep
         dev = raw.device
         H, W = ex.H, ex.W
         N, M = ex.N, ex.M
@@ -414,15 +442,13 @@ class _BatchRenderFn(torch.autograd.Function):
             g_normal = None
         if g_img is None:
             g_img = torch.zeros(n, 3, H, W, **f32)
-        else:  # through the clamp of the returned image
-            g_img = g_img * ((raw >= 0.0) & (raw <= 1.0))
+        else:  # through the clamp of the returned image (it passes where the clamp changed nothing, bounds included)
+            g_img = g_img * (image == raw)
         if g_alpha is None:
             g_alpha = torch.zeros(n, 1, H, W, **f32)
         (g_xyz, g_rot, g_scaling, g_opacity, g_fdc, g_cxyz, g_crad) = _aligned_views(
             dev, [(N, 3), (N, 4), (N, 3), (N, 1), (N, 1, 3), (M, 3), (M, 1)])
-        for t in job.grad_rows:
-            t.zero_()
-        c = ex.common
+        c = ex.common  # (job.grad_rows were zero-filled when they were made and nothing has written them since)
         p = _lib.ptr
         c.xyz, c.rotation, c.scaling, c.opacity, c.f_dc, c.c_xyz, c.c_log_radius = [p(t) for t in keep]
         c.nn_dist, c.nn_idx, c.bg = p(job.nn_dist), p(job.nn_idx), p(job.bg)
@@ -469,6 +495,7 @@ class RenderBatcher:
         self.ex = None
         self.in_use = []
         self.pending = None
+        self._sink_zeros = None
         self.flushes = 0   # (diagnostics: batches run, renders in them)
         self.rendered = 0
 
@@ -507,7 +534,7 @@ class RenderBatcher:
         return bool(self.renderer.add_normal)
 
     # ---- requests
-    def add(self, cam, tanfovx, tanfovy, key, deform, time, latent_index, sink):
+    def add(self, cam, tanfovx, tanfovy, key, deform, time, latent_index):
         """Queues one render.  key = what a batch shares: (H, W, scale_modifier, local_frame), the autograd mode of the
         caller and the identity of the model (row counts, parameter storage) -- a change of any of them runs the
         pending batch first.  Returns (batch record, index in it), or None if no render slot is free (the caller then
@@ -548,6 +575,14 @@ class RenderBatcher:
             nxt = best
         self.in_use[nxt] = True
         rq = _Request()
+        # gradient sink for the screen-space means (latent_gs_renderer.py:1114-1126: zeros with requires_grad; the
+        # densification statistics read its .grad): a leaf that SHARES a persistent block of zeros -- nobody writes
+        # a sink's values -- instead of a fresh 1.2 MB memset per render
+        z = self._sink_zeros
+        if z is None or z.shape[1] != g._xyz.shape[0] or z.shape[0] != len(self.in_use):
+            z = self._sink_zeros = torch.zeros(len(self.in_use), g._xyz.shape[0], 3, dtype=torch.float32,
+                                               device=g._xyz.device)
+        sink = z[nxt].detach().requires_grad_(True)
         rq.cam, rq.tanfovx, rq.tanfovy, rq.sink, rq.index = cam, float(tanfovx), float(tanfovy), sink, len(pend["reqs"])
         if deform is not None:
             dx, dq = deform

@@ -38,8 +38,26 @@ def look_at(campos, target, opengl=True):
     return np.stack([right, up, fwd], axis=1)
 
 
+_POSES = {}
+
+
 def orbit_camera(elevation, azimuth, radius=1, is_degree=True, target=None, opengl=True):
-    """Elevation/azimuth -> camera-to-world pose [4,4] float32."""
+    """Elevation/azimuth -> camera-to-world pose [4,4] float32.  The reference calls this for every render
+    (main_train_dimo.py:286) with one of its 9 azimuths: the poses are memoised (a copy is returned)."""
+    key = (float(elevation), float(azimuth), float(radius), bool(is_degree), bool(opengl)) if target is None else None
+    if key is not None:
+        hit = _POSES.get(key)
+        if hit is not None:
+            return hit.copy()
+    pose = _orbit_camera(elevation, azimuth, radius, is_degree, target, opengl)
+    if key is not None:
+        if len(_POSES) > 4096:
+            _POSES.clear()
+        _POSES[key] = pose.copy()
+    return pose
+
+
+def _orbit_camera(elevation, azimuth, radius, is_degree, target, opengl):
     if is_degree:
         elevation = np.deg2rad(elevation)
         azimuth = np.deg2rad(azimuth)

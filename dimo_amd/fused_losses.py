@@ -64,10 +64,50 @@ def motion_loss(img, depth, normal, alpha, gts, masks, w_mse, weights, lam_ssim)
 
 
 _ZERO = dict(w_mask=0.0, w_smooth_x=0.0, w_smooth_y=0.0, w_bilat_x=0.0, w_bilat_y=0.0)
+_CONST = {}
 
 
 def _nchw(x):  # [B,H,W,C] (the reference's layout for the smoothness terms) -> [B,C,H,W]
     return x.permute(0, 3, 1, 2)
+
+
+def _consts(B, H, W, dev):
+    """Read-only zeros standing in for the terms a smoothness-only call does not have (alpha, mask) and a scratch
+    plane for the alpha gradient nobody reads: made once per shape instead of two memsets per call."""
+    key = (B, H, W, str(dev))
+    c = _CONST.get(key)
+    if c is None:
+        if len(_CONST) > 32:
+            _CONST.clear()
+        c = _CONST[key] = (torch.zeros(B, 1, H, W, dtype=torch.float32, device=dev),
+                           torch.zeros(1, H, W, dtype=torch.float32, device=dev),
+                           torch.empty(B, 1, H, W, dtype=torch.float32, device=dev))
+    return c
+
+
+class _SmoothFn(torch.autograd.Function):
+    """One smoothness term (depth: src/loss.py:64-83, normal: :86-106) on the fused image-loss kernel with every other
+    weight zero: value and both gradient images from one launch."""
+
+    @staticmethod
+    def forward(ctx, img, x, is_depth, weights):
+        if not img.is_cuda:
+            raise RuntimeError("dimo_amd.fused_losses needs GPU tensors (no CPU fallback in the product path)")
+        B, _, H, W = img.shape
+        imgc, xc = img.detach().contiguous(), x.detach().contiguous()
+        zero_alpha, zero_mask, scratch = _consts(B, H, W, img.device)
+        acc = torch.zeros(LOSS_WORDS, dtype=torch.float32, device=img.device)
+        g_img, g_x = torch.empty_like(imgc), torch.empty_like(xc)
+        fused_image_loss(imgc, xc if is_depth else None, None if is_depth else xc, zero_alpha, imgc, zero_mask,
+                         [0.0] * B, weights, None, acc,
+                         out=(g_img, g_x if is_depth else None, None if is_depth else g_x, scratch))
+        ctx.save_for_backward(g_img, g_x)
+        return acc.sum()
+
+    @staticmethod
+    def backward(ctx, g):
+        g_img, g_x = ctx.saved_tensors
+        return g_img * g, g_x * g, None, None
 
 
 def edge_aware_smoothness(depth_bhwc, rgb_bhwc):
@@ -76,10 +116,7 @@ def edge_aware_smoothness(depth_bhwc, rgb_bhwc):
     B, H, W, _ = depth_bhwc.shape
     w = dict(_ZERO, w_smooth_x=1.0 / (B * H * (W - 1)) if W > 1 else 0.0,
              w_smooth_y=1.0 / (B * (H - 1) * W) if H > 1 else 0.0)
-    img, depth = _nchw(rgb_bhwc), _nchw(depth_bhwc)
-    zeros1 = torch.zeros(B, 1, H, W, dtype=torch.float32, device=img.device)
-    return _MotionLossFn.apply(img, depth, None, zeros1, [img.detach()[i] for i in range(B)],
-                               [zeros1[i] for i in range(B)], [0.0] * B, w, 0.0)
+    return _SmoothFn.apply(_nchw(rgb_bhwc), _nchw(depth_bhwc), True, w)
 
 
 def bilateral_normal_smoothness(normal_bhwc, rgb_bhwc):
@@ -87,7 +124,4 @@ def bilateral_normal_smoothness(normal_bhwc, rgb_bhwc):
     B, H, W, _ = normal_bhwc.shape
     w = dict(_ZERO, w_bilat_x=1.0 / (3 * B * H * (W - 1)) if W > 1 else 0.0,
              w_bilat_y=1.0 / (3 * B * (H - 1) * W) if H > 1 else 0.0)
-    img, normal = _nchw(rgb_bhwc), _nchw(normal_bhwc)
-    zeros1 = torch.zeros(B, 1, H, W, dtype=torch.float32, device=img.device)
-    return _MotionLossFn.apply(img, None, normal, zeros1, [img.detach()[i] for i in range(B)],
-                               [zeros1[i] for i in range(B)], [0.0] * B, w, 0.0)
+    return _SmoothFn.apply(_nchw(rgb_bhwc), _nchw(normal_bhwc), False, w)

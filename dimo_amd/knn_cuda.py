@@ -29,6 +29,9 @@ def knn_points(ref, query, k, seed=None):
     return dist, idx
 
 
+_LAST_IDX = {}  # (N, M, k, device) -> the neighbours the module found last time: seeds of the next search
+
+
 class KNN(torch.nn.Module):
     def __init__(self, k, transpose_mode=False):
         super().__init__()
@@ -38,6 +41,16 @@ class KNN(torch.nn.Module):
     def forward(self, ref, query):
         assert ref.size(0) == query.size(0), "ref.shape={} != query.shape={}".format(ref.shape, query.shape)
         with torch.no_grad():
+            if self._t and ref.size(0) == 1:  # the trainer's call (main_train_dimo.py:505): no stacking copies
+                # the reference builds a new KNN module every step, so the seeds (they only prune the search: the
+                # result is the same bits for ANY seed values) are remembered per problem shape, not per module
+                key = (query.size(1), ref.size(1), self.k, str(query.device))
+                d, i = knn_points(ref[0], query[0], self.k, seed=_LAST_IDX.get(key))
+                if self.k == 4:
+                    if len(_LAST_IDX) > 16:
+                        _LAST_IDX.clear()
+                    _LAST_IDX[key] = i
+                return d[None], i[None]
             if not self._t:  # [B, dim, n] layout
                 ref, query = ref.transpose(1, 2), query.transpose(1, 2)
             D, I = [], []

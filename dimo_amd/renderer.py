@@ -151,14 +151,14 @@ class Renderer:
         b = self._batcher
         tanfovx = getattr(cam, "tanfovx", None) or math.tan(cam.FoVx * 0.5)
         tanfovy = getattr(cam, "tanfovy", None) or math.tan(cam.FoVy * 0.5)
-        sink = torch.zeros_like(g._xyz, requires_grad=True)
         key = (int(cam.image_height), int(cam.image_width), float(scaling_modifier), bool(local_frame))
         if deform is not None:
             deform = (deform[0].contiguous(), deform[1].contiguous())
-        handle = b.add(cam, tanfovx, tanfovy, key, deform, time, latent_index, sink)
+        handle = b.add(cam, tanfovx, tanfovy, key, deform, time, latent_index)
         if handle is None:
             return None
         pend, i = handle
+        sink = pend["reqs"][i].sink
         g._flush_pending_renders = self._flush_ref  # the model's mutators and its optimizer run what is queued first
         dev, N, M = self.device, g._xyz.shape[0], g._c_xyz.shape[0]
         H, W = key[0], key[1]

@@ -195,7 +195,10 @@ class Trainer:
         self.skipped_steps = 0
         self.time_allreduce = False  # bench.py: event pairs around the step's collective (exposed time)
         self.allreduce_events = []
-        self._main_chain = int(os.environ.get("DIMO_MAIN_CHAIN", "1"))
+        # the step's last motion on THIS stream instead of a private one: pays with the joint backward (which has to wait
+        # for every chain anyway: +1.2 %), costs with the per-motion backward (7330-7350 against 7395-7413 frames/s: the
+        # main stream's chain delays the skinning backward behind it).  Default: follows the backward mode
+        self._main_chain = int(os.environ["DIMO_MAIN_CHAIN"]) if "DIMO_MAIN_CHAIN" in os.environ else None
         self._flat_adam = type(self.optimizer).__name__ == "FlatAdam"
         self._inorder_losses = os.environ.get("DIMO_INORDER_LOSSES", "1") == "1"
         # per-motion backward (default since round 4): every motion's chain -- forward, losses, rasterizer backward --
@@ -737,7 +740,7 @@ class Trainer:
         # and the joint backward waits for another one when it gets there: 6790 against 6710 frames/s.  (The other
         # motions' losses on this stream as well, their forward long finished by then: 6650.)
         in_order = bool(ex.ranged and self._inorder_losses and not c.use_lpips)
-        main_chain = self._main_chain if (in_order and not joint) else 0
+        main_chain = (self._main_chain if self._main_chain is not None else int(joint_bwd)) if (in_order and not joint) else 0
         main_motion = list(by_motion)[-1] if (main_chain and by_motion) else None
         if ex.ranged:  # one batch per motion, on alternating private streams
             for m, trs in by_motion.items():
@@ -867,7 +870,9 @@ class Trainer:
             for m, trs in by_motion.items():
                 ex.backward_accumulate(first[m], len(trs))
         self._mark("raster_bwd+skinning_bwd")
-        self.all_reduce_point_grads_async()
+        if not s1:  # (stage s1: the TimeNet backward below still adds its INPUT gradient to `_xyz.grad`, the head of
+            # the bucket -- found by the two-replica schedule test: the ranks' Gaussian counts drifted apart)
+            self.all_reduce_point_grads_async()
         # the s1 densification statistics come from the step's last render (main_train_dimo.py:429-431)
         self._last_stats = None
         if s1 and n > 0:

@@ -66,10 +66,14 @@ def test_bench_single_rank_record_fields():
     assert r["skipped_steps"]["whole_run"] == 0
     assert r["kernel_rooflines"]["blend_bwd"]["ms"] > 0
     assert r["ranks_seen"] == 1
-    # every kernel group is priced with ITS renders per launch: the forward stages run per motion batch (4 renders),
-    # the joint backward over the step's 8
+    # every kernel group is priced with ITS renders per launch: in the timed schedule every stage runs per motion batch
+    # (4 renders); the roofline clock is taken in an extra pass with ONE backward launch over the step's 8
     assert r["kernel_rooflines"]["blend_fwd"]["renders_per_launch"] == 4
-    assert r["kernel_rooflines"]["blend_bwd"]["renders_per_launch"] == 8
+    assert r["kernel_rooflines"]["blend_bwd"]["renders_per_launch"] == 4
+    assert r["roofline"]["renders_per_launch"] == 8 and r["roofline"]["timed_region"]["renders_per_launch"] == 4
+    assert r["roofline"]["avg_ms"] > 0 and r["roofline"]["timed_region"]["avg_ms"] > 0
+    assert "literal_loop_with_logging_reads" in r["dropin_detail"]
+    assert r["dropin_detail"]["launch_chains_per_step"] == 1.0
     s = r["sustained"]  # default: 1200 consecutive steps, across the stage-s2 prune of step 2000
     assert s["steps"] >= 1000 and s["s2_prunes_crossed"] >= 1 and s["frames_per_s"] > 0
     assert s["gaussians_start_end"][0] == 20000 and s["gaussians_start_end"][1] <= 20000

@@ -129,7 +129,11 @@ def test_a_queued_render_shows_the_model_and_the_grad_mode_of_the_call():
     assert float((o["image"] - want["image"]).abs().max()) <= 1e-5
     with torch.no_grad():
         assert (o["image"] * 1.0).requires_grad is False
-    assert o["image"].unsqueeze(0).sum().requires_grad, "queued with autograd on: the graph must exist"
+    loss = o["image"].unsqueeze(0).sum()
+    assert loss.requires_grad, "queued with autograd on: the graph must exist"
+    del loss, o  # (the graph goes: its render slot is free and the executor can be rebuilt for the new row count;
+    #              while a slot is held, renders of a different model take the immediate path)
+    assert not any(rd._batcher.in_use)
     # the pruned model renders with its own row count, in a new batch
     loop.find_knn(g)
     with torch.no_grad():
