@@ -420,7 +420,10 @@ class _BatchRenderFn(torch.autograd.Function):
             # nobody polls looks at them only every 64 renders (8n bytes, same stream)
             b.capacity.track(ex.total_words_range(job.first, n).clone())
         image = raw.clamp(0.0, 1.0)
-        ctx.job, ctx.keep, ctx.n = job, (keep, dkeep, raw, radii, image), n
+        # where the clamp changed nothing (bounds included) the gradient passes.  (The mask, not `image`, is kept: an
+        # OUTPUT held by its own node's ctx is a reference cycle, and the render slots would wait for the garbage
+        # collector instead of coming back when the graph is dropped.)
+        ctx.job, ctx.keep, ctx.n = job, (keep, dkeep, raw, radii, image == raw), n
         ctx.ticket = job.ticket
         ctx.mark_non_differentiable(radii)
         # the batch's outputs stay whole: a render's image is a select of [n, 3, H, W] made outside this node, and the
@@ -431,7 +434,7 @@ class _BatchRenderFn(torch.autograd.Function):
     def backward(ctx, *grads):
         job, n = ctx.job, ctx.n
         b, ex = job.batcher, job.batcher.ex
-        keep, dkeep, raw, _radii, image = ctx.keep
+        keep, dkeep, raw, _radii, passes = ctx.keep
         dev = raw.device
         H, W = ex.H, ex.W
         N, M = ex.N, ex.M
@@ -442,8 +445,8 @@ class _BatchRenderFn(torch.autograd.Function):
             g_normal = None
         if g_img is None:
             g_img = torch.zeros(n, 3, H, W, **f32)
-        else:  # through the clamp of the returned image (it passes where the clamp changed nothing, bounds included)
-            g_img = g_img * (image == raw)
+        else:  # through the clamp of the returned image
+            g_img = g_img * passes
         if g_alpha is None:
             g_alpha = torch.zeros(n, 1, H, W, **f32)
         (g_xyz, g_rot, g_scaling, g_opacity, g_fdc, g_cxyz, g_crad) = _aligned_views(

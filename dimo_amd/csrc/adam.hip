@@ -26,7 +26,22 @@ __global__ void __launch_bounds__(256) flat_adam_kernel(long long n, float *__re
                                                         float *__restrict__ m, float *__restrict__ v, AdamSegs segs,
                                                         float beta1, float beta2, float eps, long long launch,
                                                         const int *__restrict__ skip_flags, int n_flags,
-                                                        int flag_stride, int zero_grad, int *__restrict__ skipped) {
+                                                        int flag_stride, int zero_grad, int *__restrict__ skipped,
+                                                        const uint32_t *__restrict__ report_src, int report_words,
+                                                        uint32_t *report_dst, uint32_t report_seq,
+                                                        float *__restrict__ zero_extra, long long zero_n) {
+  // Optional report for the host: `report_words` device words (the step's (R, overflow) instance counts) copied into
+  // host-visible pinned memory behind a sequence number -- the host looks at them a step later without an event or a
+  // copy engine (a 4 us device-to-host copy and the ~13 us gap behind it sat on every step's critical path).
+  if (report_dst && blockIdx.x == 0) {
+    for (int k = threadIdx.x; k < report_words; k += 256) report_dst[1 + k] = report_src[k];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(report_dst, report_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  // Optional scratch region zeroed for the NEXT step (its accumulators: a fill launch at the head of every step)
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < zero_n; i += (long long)gridDim.x * 256)
+    zero_extra[i] = 0.f;
   bool skip = false;
   for (int k = 0; k < n_flags; ++k) skip |= skip_flags[(size_t)k * flag_stride] != 0;
   // effective step = launches so far - launches skipped before this one; this launch reads word (launch & 1) and
@@ -89,13 +104,16 @@ extern "C" int dimo_flat_adam_step(int64_t n, float *params, float *grads, float
                                    int n_segments, const int64_t *segment_end_host, const float *segment_lr_host,
                                    float beta1, float beta2, float eps, int64_t step, const int *skip_flags,
                                    int n_flags, int flag_stride, int zero_grad, int *skipped_launches,
-                                   void *stream_) {
+                                   const uint32_t *report_src, int report_words, uint32_t *report_dst_host,
+                                   uint32_t report_seq, float *zero_extra, int64_t zero_n, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   clear_errors();
   if (n < 0 || n_segments < 1 || n_segments > ADAM_MAX_SEG || step < 1 || n_flags < 0) return DIMO_E_ARG;
   if (n == 0) return DIMO_OK;
   if (!params || !grads || !exp_avg || !exp_avg_sq || !segment_end_host || !segment_lr_host) return DIMO_E_ARG;
   if (n_flags > 0 && !skip_flags) return DIMO_E_ARG;
+  if (report_words < 0 || zero_n < 0 || (report_dst_host && report_words > 0 && !report_src) || (zero_n > 0 && !zero_extra))
+    return DIMO_E_ARG;
   if ((reinterpret_cast<uintptr_t>(params) | reinterpret_cast<uintptr_t>(grads) |
        reinterpret_cast<uintptr_t>(exp_avg) | reinterpret_cast<uintptr_t>(exp_avg_sq)) & 15)
     return DIMO_E_ARG;  // float4 path needs 16-byte aligned buckets
@@ -112,6 +130,7 @@ extern "C" int dimo_flat_adam_step(int64_t n, float *params, float *grads, float
   ScopedTimer tm(T_ADAM, stream);
   hipLaunchKernelGGL(flat_adam_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (long long)n, params, grads,
                      exp_avg, exp_avg_sq, segs, beta1, beta2, eps, (long long)step, skip_flags, n_flags, flag_stride,
-                     zero_grad, skipped_launches);
+                     zero_grad, skipped_launches, report_src, report_words, report_dst_host, report_seq, zero_extra,
+                     (long long)zero_n);
   return check_launch();
 }

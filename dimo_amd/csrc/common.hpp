@@ -240,7 +240,8 @@ struct RenderBatch {
 void group_deformations(RenderBatch &b, int n);
 int lbs_forward_batched(const dimo_step_common &c, const RenderBatch &b, int n, hipStream_t stream);
 size_t lbs_backward_batched_scratch_bytes(int N, int M, int n);
-int lbs_backward_batched(const dimo_step_common &c, const RenderBatch &b, int n, hipStream_t stream);
+int lbs_backward_batched(const dimo_step_common &c, const RenderBatch &b, int n, hipStream_t stream, int first_abs = 0,
+                         int phase = 0);
 int preprocess_forward_batched(const dimo_step_common &c, const RenderBatch &b, int n, hipStream_t stream);
 int preprocess_backward_batched(const dimo_step_common &c, const RenderBatch &b, int n, hipStream_t stream);
 int bin_instances_batched(const dimo_step_common &c, const RenderBatch &b, int n, hipStream_t stream);

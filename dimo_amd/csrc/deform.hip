@@ -384,10 +384,16 @@ __global__ void __launch_bounds__(DEF_BLOCK) lbs_bwd_batched_kernel(int N, int M
 // output j of EVERY group, so the adds into the shared control-point gradients are ordered.
 constexpr int RED_GROUPS = 4;   // groups reduced side by side (threadIdx.z)
 constexpr int RED_LOADS = 32;   // tables per chunk-thread and pass: 16 x 32 = 512 tables in one round of loads
+//
+// `stage_end` (optional): the sums that go to the SHARED control-point gradients (d c_xyz, d c_log_radius) are not
+// added there but STORED in the group leader's staging table -- M x 4 floats at stage_end - (slot + 1) * stride, slot =
+// first_abs + leader -- and folded in by accumulate_batched_kernel: the skinning backward of two motions can then run
+// on two streams at once (nothing shared is written), and the fold adds the groups in a fixed order.
 __global__ void __launch_bounds__(256 * RED_GROUPS) lbs_reduce_batched_kernel(int M, int nblocks, int n_groups,
                                                                               const float *__restrict__ partials,
                                                                               float *d_c_xyz, float *d_c_lr,
-                                                                              RenderBatch b) {
+                                                                              RenderBatch b, float *stage_end,
+                                                                              size_t stage_stride, int first_abs) {
   __shared__ float s_part[MAX_BATCH][16][17];
   const int jj = threadIdx.x & 15, chunk = threadIdx.x >> 4, zz = threadIdx.z;
   const int j = blockIdx.x * 16 + jj;
@@ -412,6 +418,10 @@ __global__ void __launch_bounds__(256 * RED_GROUPS) lbs_reduce_batched_kernel(in
 #pragma unroll
     for (int k = 0; k < 16; ++k) s += s_part[r][k][jj];
     float *dst;
+    if (c < 4 && stage_end) {
+      (stage_end - (size_t)(first_abs + (int)b.leader[r] + 1) * stage_stride)[4 * m + c] = s;
+      continue;
+    }
     if (c < 3) dst = d_c_xyz + 3 * m + c;
     else if (c == 3) dst = d_c_lr + m;
     else if (c < 7) dst = b.r[b.leader[r]].g_d_xyz + 3 * m + (c - 4);
@@ -422,13 +432,28 @@ __global__ void __launch_bounds__(256 * RED_GROUPS) lbs_reduce_batched_kernel(in
 
 // dst[i] += sum_r src_r[i] for the five per-Gaussian gradient arrays of a batch (fixed order): the skinning
 // backward left the first four in the group leaders' buffers, the colour gradient is per render
+// (+ with `stage_end`: the staged control-point sums of the batch's groups, see lbs_reduce_batched_kernel -- 4 M more
+// outputs behind the 14 N per-Gaussian ones)
 __global__ void __launch_bounds__(256) accumulate_batched_kernel(int N, int n_renders, RenderBatch b, float *g_xyz,
                                                                  float *g_rotation, float *g_scaling,
-                                                                 float *g_opacity, float *g_f_dc) {
+                                                                 float *g_opacity, float *g_f_dc, int M,
+                                                                 float *g_c_xyz, float *g_c_lr,
+                                                                 const float *stage_end, size_t stage_stride,
+                                                                 int first_abs) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   // segments: [0,3N) xyz | [3N,7N) rotation | [7N,10N) scaling | [10N,11N) opacity | [11N,14N) f_dc
   const size_t n = (size_t)N;
-  if (i >= 14 * n) return;
+  if (i >= 14 * n) {
+    const size_t j = i - 14 * n;
+    if (!stage_end || j >= 4 * (size_t)M) return;
+    const int m = (int)(j >> 2), cc = (int)(j & 3);
+    float *dst = cc < 3 ? g_c_xyz + 3 * m + cc : g_c_lr + m;
+    float s = *dst;
+    for (int q = 0; q < b.n_groups; ++q)
+      s += (stage_end - (size_t)(first_abs + (int)b.leader[q] + 1) * stage_stride)[j];
+    *dst = s;
+    return;
+  }
   float *dst;
   size_t k;
   int which;
@@ -634,24 +659,52 @@ int lbs_forward_batched(const dimo_step_common &c, const RenderBatch &b, int n, 
   return check_launch();
 }
 
-size_t lbs_backward_batched_scratch_bytes(int N, int M, int n) {  // (an upper bound for any grouping of the n renders)
+// Per render: room for the partial control-point tables of one group (an upper bound for any grouping of n renders)
+// + the group leader's staging table of the shared control-point sums (phased backward, below).  The partial tables of
+// a launch over renders [first, first + n) start at first x `lbs_partials_slice`; the staging tables sit at the END of
+// the scratch buffer, slot r at end - (r + 1) x `lbs_stage_stride`.
+static size_t lbs_partials_slice(int N, int M) {
   const size_t per = (size_t)((N > 0 ? N : 1) + DEF_BLOCK - 1) / DEF_BLOCK;
-  return (size_t)n * align_up(per * (size_t)(M > 0 ? M : 1) * CP_STRIDE * sizeof(float));
+  return align_up(per * (size_t)(M > 0 ? M : 1) * CP_STRIDE * sizeof(float));
+}
+static size_t lbs_stage_stride(int M) { return align_up((size_t)(M > 0 ? M : 1) * 4 * sizeof(float)); }
+size_t lbs_backward_batched_scratch_bytes(int N, int M, int n) {
+  return (size_t)n * (lbs_partials_slice(N, M) + lbs_stage_stride(M));
 }
 
-int lbs_backward_batched(const dimo_step_common &c, const RenderBatch &b, int n, hipStream_t stream) {
+// phase 0: the whole skinning backward of the batch on `stream` (skin, control-point reduction INTO the shared
+// gradients, per-Gaussian accumulation).  Phased form for batches that are skinned on different streams at once:
+// phase 1 = skin + reduction into the leaders' staging tables (touches nothing shared), phase 2 = the accumulation,
+// which also folds the staged control-point sums in, over ALL the step's renders on one stream.  `first_abs` = slot of
+// the batch's first render in the caller's slot numbering (places this launch's scratch).
+int lbs_backward_batched(const dimo_step_common &c, const RenderBatch &b, int n, hipStream_t stream, int first_abs,
+                         int phase) {
   if (c.N <= 0 || n <= 0) return DIMO_OK;
   if (c.stage1) {
+    if (phase == 2) return DIMO_OK;  // (stage s1 has no control points: phase 1 does everything)
     if (!c.log_r || !c.g_log_r) return DIMO_E_ARG;
     ScopedTimer tm(T_DEFORM_BWD, stream);
     hipLaunchKernelGGL(s1_bwd_batched_kernel, dim3((c.N + 255) / 256, b.n_groups), dim3(256), 0, stream, c.N,
                        c.rotation, c.opacity, c.log_r, c.g_log_r, b);
     const size_t total = 14 * (size_t)c.N;
     hipLaunchKernelGGL(accumulate_batched_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, c.N, n,
-                       b, c.g_xyz, c.g_rotation, c.g_scaling, c.g_opacity, c.g_f_dc);
+                       b, c.g_xyz, c.g_rotation, c.g_scaling, c.g_opacity, c.g_f_dc, 0, (float *)nullptr,
+                       (float *)nullptr, (const float *)nullptr, (size_t)0, 0);
     return check_launch();
   }
-  if (c.lbs_scratch_bytes < lbs_backward_batched_scratch_bytes(c.N, c.M, n)) return DIMO_E_WORKSPACE;
+  if (first_abs < 0 || phase < 0 || phase > 2) return DIMO_E_ARG;
+  if (c.lbs_scratch_bytes < lbs_backward_batched_scratch_bytes(c.N, c.M, first_abs + n)) return DIMO_E_WORKSPACE;
+  const size_t stage_stride = lbs_stage_stride(c.M) / sizeof(float);
+  float *const stage_end = phase ? reinterpret_cast<float *>(static_cast<char *>(c.lbs_scratch) + c.lbs_scratch_bytes)
+                                 : nullptr;
+  if (phase == 2) {
+    const size_t total = 14 * (size_t)c.N + 4 * (size_t)c.M;
+    ScopedTimer tm(T_DEFORM_BWD, stream);
+    hipLaunchKernelGGL(accumulate_batched_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, c.N, n, b,
+                       c.g_xyz, c.g_rotation, c.g_scaling, c.g_opacity, c.g_f_dc, c.M, c.g_c_xyz, c.g_c_log_radius,
+                       (const float *)stage_end, stage_stride, first_abs);
+    return check_launch();
+  }
   GaussIO g{c.xyz, c.rotation, c.scaling, c.opacity, c.nn_dist, c.nn_idx};
   const size_t lds = 2 * (size_t)c.M * CP_STRIDE * sizeof(float);
   allow_big_lds();
@@ -660,7 +713,8 @@ int lbs_backward_batched(const dimo_step_common &c, const RenderBatch &b, int n,
   // it wants every CU slot: with 128 workgroups per group (round 1) a launch of two groups ran one wave per SIMD.
   static const int bwd_total = getenv("DIMO_LBS_WGS") ? atoi(getenv("DIMO_LBS_WGS")) : 768;
   const int grid = batched_grid(c.N, b.n_groups, bwd_total);
-  float *partials = reinterpret_cast<float *>(c.lbs_scratch);
+  float *partials = reinterpret_cast<float *>(static_cast<char *>(c.lbs_scratch) +
+                                              (phase ? (size_t)first_abs * lbs_partials_slice(c.N, c.M) : 0));
   ScopedTimer tm(T_DEFORM_BWD, stream);
   if (c.local_frame)
     hipLaunchKernelGGL(lbs_bwd_batched_kernel<true>, dim3(grid, b.n_groups), dim3(DEF_BLOCK), lds, stream, c.N, c.M, g, c.c_xyz,
@@ -670,10 +724,12 @@ int lbs_backward_batched(const dimo_step_common &c, const RenderBatch &b, int n,
                        c.c_xyz, c.c_log_radius, b, partials);
   hipLaunchKernelGGL(lbs_reduce_batched_kernel, dim3((c.M * CP_STRIDE + 15) / 16),
                      dim3(256, 1, b.n_groups < RED_GROUPS ? b.n_groups : RED_GROUPS), 0, stream, c.M, grid, b.n_groups,
-                     partials, c.g_c_xyz, c.g_c_log_radius, b);
+                     partials, c.g_c_xyz, c.g_c_log_radius, b, stage_end, stage_stride, first_abs);
+  if (phase == 1) return check_launch();
   const size_t total = 14 * (size_t)c.N;
   hipLaunchKernelGGL(accumulate_batched_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, c.N, n, b,
-                     c.g_xyz, c.g_rotation, c.g_scaling, c.g_opacity, c.g_f_dc);
+                     c.g_xyz, c.g_rotation, c.g_scaling, c.g_opacity, c.g_f_dc, 0, (float *)nullptr, (float *)nullptr,
+                     (const float *)nullptr, (size_t)0, 0);
   return check_launch();
 }
 

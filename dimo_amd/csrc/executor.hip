@@ -7,6 +7,8 @@
 // with the GPU idle.  All buffers are caller-owned and persistent (288 GB of HBM: eight render slots cost
 // < 2 GB), so a step is a fixed sequence of launches that needs no host logic in between.
 #include <algorithm>
+#include <cstdlib>
+#include <string>
 #include <utility>
 #include <vector>
 
@@ -71,7 +73,46 @@ struct Executor {
   // per range start: its rasterizer backward ran on the CALLER's stream (joint launch, or a range whose whole chain is
   // on the caller's stream): dimo_executor_backward_accumulate has no event to wait for
   std::vector<char> range_bwd_main;
+  // per range start: its skinning backward (phase 1: skin + control-point reduction into staging tables) already ran,
+  // in order behind its rasterizer backward: dimo_executor_backward_accumulate only folds (phase 2)
+  std::vector<char> range_skinned;
+  // Cross-stream dependencies through stream memory operations instead of events (DIMO_XSTREAM=value): the producer
+  // stream writes a sequence number into a device word (hipStreamWriteValue32), the consumer stream waits for it
+  // (hipStreamWaitValue32, >=).  Measured on this platform (tools/xstream_latency.hip): 4-5.5 us from the end of the
+  // producer's last kernel to the start of the consumer's first against 10.4-15.6 us through an event.
+  bool use_values = false;
+  uint32_t *sig = nullptr;            // [0]: the caller's stream ("fork"); [1 + si]: private stream si ("done")
+  uint32_t fork_seq = 0;
+  std::vector<uint32_t> done_seq;     // per private stream: last value written
+  std::vector<uint32_t> fwd_val, render_val;  // per range start: the value its fwd_done / render_done stands for
 };
+
+// "record" on private stream si what `ev` stands for, and remember it for range start `i`
+static int mark_done(Executor *ex, int si, hipEvent_t ev, std::vector<uint32_t> &vals, int i) {
+  if (ex->use_values) {
+    const uint32_t v = ++ex->done_seq[si];
+    vals[i] = v;
+    return hipStreamWriteValue32(ex->streams[si], ex->sig + 1 + si, v, 0) == hipSuccess ? DIMO_OK : DIMO_E_LAUNCH;
+  }
+  return hipEventRecord(ev, ex->streams[si]) == hipSuccess ? DIMO_OK : DIMO_E_LAUNCH;
+}
+// the caller's stream waits for it
+static int wait_done(Executor *ex, hipStream_t main, int si, hipEvent_t ev, const std::vector<uint32_t> &vals, int i) {
+  if (ex->use_values)
+    return hipStreamWaitValue32(main, ex->sig + 1 + si, vals[i], hipStreamWaitValueGte, 0xffffffffu) == hipSuccess
+               ? DIMO_OK : DIMO_E_LAUNCH;
+  return hipStreamWaitEvent(main, ev, 0) == hipSuccess ? DIMO_OK : DIMO_E_LAUNCH;
+}
+// sequence numbers stay below 2^31 (the comparison's signedness is not documented): start over long before
+static void renew_values(Executor *ex) {
+  bool high = ex->fork_seq > 0x70000000u;
+  for (uint32_t v : ex->done_seq) high |= v > 0x70000000u;
+  if (!high) return;
+  (void)hipDeviceSynchronize();
+  (void)hipMemset(ex->sig, 0, 64 * sizeof(uint32_t));
+  ex->fork_seq = 0;
+  std::fill(ex->done_seq.begin(), ex->done_seq.end(), 0u);
+}
 
 __global__ void __launch_bounds__(256) accumulate_kernel(size_t n, float *__restrict__ dst,
                                                          const float *__restrict__ src) {
@@ -125,6 +166,15 @@ extern "C" void *dimo_executor_create(int n_streams) {
     delete ex;
     return nullptr;
   }
+  ex->done_seq.assign(S, 0u);
+  const char *mode = getenv("DIMO_XSTREAM");
+  if (S > 0 && S < 60 && ex->batched && mode && std::string(mode) == "value") {
+    if (hipMalloc((void **)&ex->sig, 64 * sizeof(uint32_t)) == hipSuccess &&
+        hipMemset(ex->sig, 0, 64 * sizeof(uint32_t)) == hipSuccess)
+      ex->use_values = true;
+    else
+      ex->sig = nullptr;
+  }
   return ex;
 }
 
@@ -138,6 +188,10 @@ extern "C" void dimo_executor_destroy(void *h) {
   for (auto e : ex->render_done) (void)hipEventSynchronize(e), (void)hipEventDestroy(e);
   for (auto e : ex->fwd_done) (void)hipEventSynchronize(e), (void)hipEventDestroy(e);
   if (ex->main_ready) (void)hipEventDestroy(ex->main_ready);
+  if (ex->sig) {  // (value mode has no per-executor events to wait for: the streams may still reference the words)
+    for (auto st : ex->streams) (void)hipStreamSynchronize(st);
+    (void)hipFree(ex->sig);
+  }
   delete ex;
 }
 
@@ -157,6 +211,8 @@ static int ensure_events(Executor *ex, int n) {
   }
   if ((int)ex->range_stream.size() < n) ex->range_stream.resize(n, -1), ex->range_count.resize(n, 0);
   if ((int)ex->range_bwd_main.size() < n) ex->range_bwd_main.resize(n, 0);
+  if ((int)ex->range_skinned.size() < n) ex->range_skinned.resize(n, 0);
+  if ((int)ex->fwd_val.size() < n) ex->fwd_val.resize(n, 0u), ex->render_val.resize(n, 0u);
   return DIMO_OK;
 }
 
@@ -168,6 +224,12 @@ static int fork_from_main(Executor *ex, hipStream_t main) {
 }
 
 static int fork_one(Executor *ex, hipStream_t main, hipStream_t s) {
+  if (ex->use_values) {
+    renew_values(ex);
+    const uint32_t v = ++ex->fork_seq;
+    if (hipStreamWriteValue32(main, ex->sig, v, 0) != hipSuccess) return DIMO_E_LAUNCH;
+    return hipStreamWaitValue32(s, ex->sig, v, hipStreamWaitValueGte, 0xffffffffu) == hipSuccess ? DIMO_OK : DIMO_E_LAUNCH;
+  }
   if (hipEventRecord(ex->main_ready, main) != hipSuccess) return DIMO_E_LAUNCH;
   return hipStreamWaitEvent(s, ex->main_ready, 0) == hipSuccess ? DIMO_OK : DIMO_E_LAUNCH;
 }
@@ -250,11 +312,11 @@ extern "C" int dimo_executor_forward_range(void *h, const dimo_step_common *c, i
     const int si = ex->next_stream++ % S;
     hipStream_t s = ex->streams[si];
     if (first == 0) std::fill(ex->range_stream.begin(), ex->range_stream.end(), -1);  // a new step's ranges
-    ex->range_stream[first] = si, ex->range_count[first] = count;
+    ex->range_stream[first] = si, ex->range_count[first] = count, ex->range_skinned[first] = 0;
     rc = fork_one(ex, main, s);
     if (!rc) rc = batched_forward(c, d, first, count, s);
     if (rc) return rc;
-    return hipEventRecord(ex->fwd_done[first], s) == hipSuccess ? DIMO_OK : DIMO_E_LAUNCH;
+    return mark_done(ex, si, ex->fwd_done[first], ex->fwd_val, first);
   }
   if (c->stage1) return DIMO_E_ARG;  // stage s1 runs in the batched modes only
   rc = fork_from_main(ex, main);
@@ -294,6 +356,7 @@ extern "C" int dimo_executor_forward_range_on_caller(void *h, const dimo_step_co
   if (rc) return rc;
   if (first == 0) std::fill(ex->range_stream.begin(), ex->range_stream.end(), -1);  // a new step's ranges
   ex->range_stream[first] = (int)ex->streams.size(), ex->range_count[first] = count;  // marker: the caller's stream
+  ex->range_skinned[first] = 0;
   return batched_forward(c, d, first, count, (hipStream_t)main_stream);
 }
 
@@ -312,6 +375,10 @@ extern "C" int dimo_executor_join(void *h, int first, int count, void *main_stre
   for (int i = first; i < first + count; ++i) {
     if (ex->batched && ex->range_stream[i] < 0) continue;  // only range starts carry an event
     if (ex->batched && ex->range_stream[i] >= (int)ex->streams.size()) continue;  // a range on the caller's stream
+    if (ex->batched) {
+      if (wait_done(ex, main, ex->range_stream[i], ex->fwd_done[i], ex->fwd_val, i)) return DIMO_E_LAUNCH;
+      continue;
+    }
     if (hipStreamWaitEvent(main, ex->fwd_done[i], 0) != hipSuccess) return DIMO_E_LAUNCH;
   }
   return DIMO_OK;
@@ -337,7 +404,7 @@ extern "C" int dimo_executor_backward_launch(void *h, const dimo_step_common *c,
     int rc = fork_one(ex, main, s);
     if (!rc) rc = batched_backward_raster(c, d, first, count, s);
     if (rc) return rc;
-    return hipEventRecord(ex->render_done[first], s) == hipSuccess ? DIMO_OK : DIMO_E_LAUNCH;
+    return mark_done(ex, si, ex->render_done[first], ex->render_val, first);
   }
   int rc = fork_from_main(ex, main);
   if (rc) return rc;
@@ -382,7 +449,36 @@ extern "C" int dimo_executor_backward_launch_in_order(void *h, const dimo_step_c
   hipStream_t s = ex->streams[si];
   const int rc = batched_backward_raster(c, d, first, count, s);
   if (rc) return rc;
-  return hipEventRecord(ex->render_done[first], s) == hipSuccess ? DIMO_OK : DIMO_E_LAUNCH;
+  return mark_done(ex, si, ex->render_done[first], ex->render_val, first);
+}
+
+// Batched ranges only, after dimo_executor_backward_launch_in_order of the same range: the range's SKINNING backward
+// (per-Gaussian gradients in place in the group leaders' buffers, control-point sums into the leaders' staging tables:
+// nothing shared is written) in order on the same stream.  dimo_executor_backward_accumulate over the step's renders
+// then only folds -- one launch on the caller's stream instead of one skinning backward per motion there (57 + 46 us
+// serial on the step's critical path at the benchmark size).
+extern "C" int dimo_executor_backward_skinning_in_order(void *h, const dimo_step_common *c, int first, int count,
+                                                        const dimo_render_desc *d, void *main_stream) {
+  Executor *ex = reinterpret_cast<Executor *>(h);
+  if (!ex || !c || first < 0 || count < 0 || (count > 0 && !d)) return DIMO_E_ARG;
+  if (count == 0) return DIMO_OK;
+  if (!ex->batched || ex->streams.empty() || first + count > (int)ex->render_done.size()) return DIMO_E_ARG;
+  const int si = ex->range_stream[first];
+  if (si < 0 || si > (int)ex->streams.size() || ex->range_count[first] != count) return DIMO_E_ARG;
+  clear_errors();
+  const bool on_main = si == (int)ex->streams.size();
+  hipStream_t s = on_main ? (hipStream_t)main_stream : ex->streams[si];
+  std::vector<std::pair<int, int>> chunks;
+  if (!plan_chunks(ex, first, count, chunks)) return DIMO_E_ARG;
+  for (const auto &ch : chunks) {
+    RenderBatch b;
+    fill_batch(b, d + ch.first, ch.second);
+    const int rc = lbs_backward_batched(*c, b, ch.second, s, ch.first, 1);
+    if (rc) return rc;
+  }
+  ex->range_skinned[first] = 1;
+  if (on_main) return DIMO_OK;
+  return mark_done(ex, si, ex->render_done[first], ex->render_val, first);
 }
 
 // Batched ranges only.  The rasterizer backward of ALL the ranges inside [first, first + count) as launches over up to
@@ -400,8 +496,7 @@ extern "C" int dimo_executor_backward_launch_joint(void *h, const dimo_step_comm
   for (int i = first; i < first + count; ++i) {
     const int si = ex->range_stream[i];
     if (si < 0 || si >= (int)ex->streams.size()) continue;  // (a range on the caller's stream is already in order)
-    if (hipEventRecord(ex->fwd_done[i], ex->streams[si]) != hipSuccess ||
-        hipStreamWaitEvent(main, ex->fwd_done[i], 0) != hipSuccess)
+    if (mark_done(ex, si, ex->fwd_done[i], ex->fwd_val, i) || wait_done(ex, main, si, ex->fwd_done[i], ex->fwd_val, i))
       return DIMO_E_LAUNCH;
   }
   std::vector<std::pair<int, int>> chunks;
@@ -434,15 +529,32 @@ extern "C" int dimo_executor_backward_accumulate(void *h, const dimo_step_common
         const bool start = i == first || (i < (int)ex->range_stream.size() && ex->range_stream[i] >= 0);
         if (!start || ex->range_bwd_main[i]) continue;
         if (i != first && ex->range_stream[i] >= (int)ex->streams.size()) continue;
-        if (hipStreamWaitEvent(main, ex->render_done[i], 0) != hipSuccess) return DIMO_E_LAUNCH;
+        int si = i < (int)ex->range_stream.size() ? ex->range_stream[i] : -1;
+        if (si < 0) si = 0;  // (dimo_executor_backward_launch on a render that starts no range used stream 0)
+        if (si < (int)ex->streams.size()) {
+          if (wait_done(ex, main, si, ex->render_done[i], ex->render_val, i)) return DIMO_E_LAUNCH;
+        } else if (hipStreamWaitEvent(main, ex->render_done[i], 0) != hipSuccess) {
+          return DIMO_E_LAUNCH;
+        }
       }
     }
     std::vector<std::pair<int, int>> chunks;
     if (!plan_chunks(ex, first, count, chunks)) return DIMO_E_ARG;
     for (const auto &ch : chunks) {
+      // every range of the chunk skinned already (phase 1, on its own stream): only the fold is left; none: the whole
+      // skinning backward here.  (A chunk is one range or several WHOLE ranges.)
+      // (a chunk inside a long range belongs to the range that starts before it)
+      int skinned = 0, starts = 0;
+      const int nrs = (int)ex->range_stream.size();
+      int rs = ch.first < nrs ? ch.first : nrs - 1;
+      while (rs >= 0 && !(ex->range_stream[rs] >= 0 && rs + ex->range_count[rs] > ch.first)) --rs;
+      if (rs >= 0 && rs < ch.first) ++starts, skinned += ex->range_skinned[rs] ? 1 : 0;
+      for (int i = ch.first; i < ch.first + ch.second && i < nrs; ++i)
+        if (ex->range_stream[i] >= 0) ++starts, skinned += ex->range_skinned[i] ? 1 : 0;
+      if (skinned != 0 && skinned != starts) return DIMO_E_ARG;
       RenderBatch b;
       fill_batch(b, d + ch.first, ch.second);
-      const int rc = lbs_backward_batched(*c, b, ch.second, main);
+      const int rc = lbs_backward_batched(*c, b, ch.second, main, ch.first, skinned ? 2 : 0);
       if (rc) return rc;
     }
     return DIMO_OK;

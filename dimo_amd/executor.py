@@ -169,6 +169,13 @@ class StepExecutor:
                                                                  C.addressof(self.descs), _lib.current_stream()),
                    "dimo_executor_backward_launch_in_order")
 
+    def backward_skinning_in_order(self, first, count):
+        """The range's skinning backward behind its rasterizer backward, on the same stream (nothing shared is
+        written); `backward_accumulate` over the step's renders then only folds."""
+        _lib.check(self.L.dimo_executor_backward_skinning_in_order(self.handle, C.addressof(self.common), first, count,
+                                                                   C.addressof(self.descs), _lib.current_stream()),
+                   "dimo_executor_backward_skinning_in_order")
+
     def backward_launch_joint(self, first, count):
         _lib.check(self.L.dimo_executor_backward_launch_joint(self.handle, C.addressof(self.common), first, count,
                                                               C.addressof(self.descs), _lib.current_stream()),

@@ -58,9 +58,12 @@ class FlatAdam:
         self.skipped_host = 0
         self._skipped.zero_()
 
-    def step(self, skip_flags=None, zero_grad=False):
+    def step(self, skip_flags=None, zero_grad=False, report=None, zero_extra=None):
         """skip_flags: optional int32 tensor [k, 2] (rasterizer `total` words: R, overflow) -- any non-zero
-        overflow word turns this step into a no-op on the device."""
+        overflow word turns this step into a no-op on the device.  report: optional (src int32 device tensor, dst
+        PINNED int32 host tensor with >= 1 + src.numel() words, seq) -- the launch copies src to dst[1:] and then stores
+        seq to dst[0] (CapacityPolicy polls it a step later: no copy engine, no event).  zero_extra: optional fp32
+        device tensor cleared by the same launch."""
         if self.pre_step is not None:
             self.pre_step()
         self.launches += 1
@@ -74,10 +77,24 @@ class FlatAdam:
                 fptr, nfl, fstride = skip_flags.data_ptr(), skip_flags.numel(), 1
         else:
             fptr, nfl, fstride = None, 0, 1
+        if report is not None:
+            src, dst, seq = report
+            # (dst must be PINNED host memory -- not checked here: is_pinned() is a driver query per call)
+            assert src.dtype == torch.int32 and src.is_contiguous() and src.is_cuda
+            assert dst.dtype == torch.int32 and not dst.is_cuda and dst.numel() >= 1 + src.numel()
+            rsrc, rwords, rdst, rseq = src.data_ptr(), src.numel(), dst.data_ptr(), int(seq) & 0xffffffff
+        else:
+            rsrc, rwords, rdst, rseq = None, 0, None, 0
+        if zero_extra is not None:
+            assert zero_extra.dtype == torch.float32 and zero_extra.is_contiguous() and zero_extra.is_cuda
+            zptr, zn = zero_extra.data_ptr(), zero_extra.numel()
+        else:
+            zptr, zn = None, 0
         _lib.check(_lib.lib().dimo_flat_adam_step(
             self.flat_params.numel(), _lib.ptr(self.flat_params), _lib.ptr(self.flat_grads), _lib.ptr(self.exp_avg),
             _lib.ptr(self.exp_avg_sq), self._n_seg, self._ends, lrs, b1, b2, self.defaults["eps"], self.launches,
-            fptr, nfl, fstride, int(bool(zero_grad)), _lib.ptr(self._skipped), _lib.current_stream()),
+            fptr, nfl, fstride, int(bool(zero_grad)), _lib.ptr(self._skipped), rsrc, rwords, rdst, rseq, zptr, zn,
+            _lib.current_stream()),
             "dimo_flat_adam_step")
 
     def zero_grad(self, set_to_none=False):

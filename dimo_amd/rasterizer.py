@@ -25,6 +25,7 @@ a running bound so the whole render is enqueued without a host round trip; an ov
 is flagged on the device and surfaced by `CapacityPolicy.check()`.
 """
 import ctypes as C
+import time
 from typing import NamedTuple, Optional
 
 import torch
@@ -100,6 +101,32 @@ class CapacityPolicy:
         self._start_copy(tot)
         return tot
 
+    RING, RING_WORDS = 8, 1 + 2 * 256
+
+    def collect_report(self):
+        """Like `collect_async`, but the words reach the host THROUGH a kernel: returns (device words [k, 2], pinned
+        host slot, sequence number) for `FlatAdam.step(report=...)`, whose launch copies the words into the slot and
+        stores the sequence number behind them; `poll()` reads the slot a step later.  No copy engine, no event: the
+        4 us device-to-host copy and the ~13 us gap behind it sat between one step's optimizer and the next step's first
+        kernel.  None if nothing is pending (or the words do not fit a slot: use `collect_async`)."""
+        if not self._pending:
+            return None
+        n = sum(t.shape[0] for t in self._pending)
+        if 1 + 2 * n > self.RING_WORDS:
+            return None
+        tot = self._pending[0] if len(self._pending) == 1 else torch.cat(self._pending)
+        self._pending = []
+        if getattr(self, "_ring", None) is None:
+            self._ring = torch.zeros(self.RING, self.RING_WORDS, dtype=torch.int32, pin_memory=True)
+            self._slots = [self._ring[i] for i in range(self.RING)]
+            self._slot_np = [s.numpy() for s in self._slots]  # (the host's view: plain memory reads in poll)
+            self._seq = 0
+        self._seq += 1
+        slot = self._slots[self._seq % self.RING]
+        self._inflight = getattr(self, "_inflight", [])
+        self._inflight.append((slot, None, self._seq, int(tot.shape[0])))
+        return tot.contiguous(), slot, self._seq
+
     def start_copy(self):
         tot, self._deferred = getattr(self, "_deferred", None), None
         if tot is not None:
@@ -123,8 +150,29 @@ class CapacityPolicy:
         inflight = getattr(self, "_inflight", [])
         ready, self._inflight = (inflight[:-lag], inflight[-lag:]) if lag > 0 else (inflight, [])
         bad = 0
-        for host, ev in ready:
-            ev.synchronize()
+        for entry in ready:
+            host, ev = entry[0], entry[1]
+            if ev is None:  # a slot the optimizer's launch fills (collect_report): complete when its number is there
+                seq, n = entry[2], entry[3]
+                want = seq & 0xffffffff
+                view = self._slot_np[seq % self.RING]
+                # (normally there: the launch ran a step ago.  When the host is further ahead, wait for THAT launch
+                # only -- like an event wait; a device-wide sync would drain the queue the host has built up)
+                lost, deadline = False, None
+                while (int(view[0]) & 0xffffffff) != want:
+                    now = time.perf_counter()
+                    if deadline is None:
+                        deadline = now + 0.25
+                    elif now > deadline:  # the launch that carries the report never ran (an optimizer step somebody
+                        torch.cuda.synchronize()  # replaced or skipped): the device-side skip flag still guards the
+                        lost = (int(view[0]) & 0xffffffff) != want  # update
+                        break
+                if lost:
+                    self.lost_reports = getattr(self, "lost_reports", 0) + 1
+                    continue
+                host = torch.from_numpy(view[1:1 + 2 * n].reshape(n, 2).copy())
+            else:
+                ev.synchronize()
             if not self._update(host):
                 bad += 1
         return bad

@@ -208,6 +208,11 @@ class Trainer:
         # switches to it for the pass its roofline clock is taken in)
         self._joint_bwd = os.environ.get("DIMO_JOINT_BWD", "0") == "1"
         self._joint_losses = os.environ.get("DIMO_JOINT_LOSSES", "0") == "1"
+        # per-motion backward: the motion's SKINNING backward too in order on its stream (control-point sums staged,
+        # one fold on this stream at the end) instead of one skinning backward per motion on this stream
+        self._skin_in_order = os.environ.get("DIMO_SKIN_IN_ORDER", "1") == "1"
+        self._report_via_adam = os.environ.get("DIMO_REPORT", "1") == "1"  # "0": device-to-host copy + event per step
+        self._zero_via_adam = os.environ.get("DIMO_ZERO_NEXT", "1") == "1"  # "0": a fill launch per step
         self._direct_wanted = direct
         self._decide_direct()
 
@@ -675,7 +680,20 @@ class Trainer:
         # accumulated by the skinning backward; one zero-fill for both and for the loss accumulator
         o_q = (dxyz_c.numel() + 3) // 4 * 4  # 16-byte aligned start of the quaternion rows
         n_motions = len({t[0] for t in mine})
-        zeroed = torch.zeros(o_q + dquat_c.numel() + _LOSS_WORDS + n_motions, **f32)
+        # the step's accumulators (TimeNet output gradients, loss words, SSIM sums).  Two buffers alternate: the
+        # optimizer's launch of THIS step clears the one the next step will use (FlatAdam zero_extra) -- a fill launch
+        # between the TimeNet forward and the renders otherwise.  (`last_loss` of a step reads its buffer: valid until
+        # the NEXT step's optimizer has run.)
+        need = o_q + dquat_c.numel() + _LOSS_WORDS + n_motions
+        if self._flat_adam and self._zero_via_adam:
+            pair = getattr(self, "_acc_bufs", None)
+            if pair is None or pair[0].numel() != need:
+                pair = self._acc_bufs = [torch.zeros(need, **f32), torch.zeros(need, **f32)]
+                self._acc_at = 0
+            self._acc_at ^= 1
+            zeroed, self._zero_next = pair[self._acc_at], pair[self._acc_at ^ 1]
+        else:
+            zeroed = torch.zeros(need, **f32)
         g_dxyz = zeroed[:dxyz_c.numel()].view_as(dxyz_c)
         g_dquat = zeroed[o_q:o_q + dquat_c.numel()].view_as(dquat_c)
         by_motion = {}
@@ -786,6 +804,7 @@ class Trainer:
                 d.g_depth = (gd.data_ptr() + b * HW4) if gd is not None else None
                 d.g_normal = (gn.data_ptr() + b * 3 * HW4) if gn is not None else None
                 d.g_dot = (g_dot.data_ptr() + b * HW4) if g_dot is not None else None
+        skinned = 0
         for m, trs in by_motion.items():
             B = len(trs)
             share = B / n_img
@@ -847,6 +866,9 @@ class Trainer:
                 pass  # one launch chain over all the step's renders, below
             elif own is not None or (m == main_motion and in_order):
                 ex.backward_launch_in_order(first[m], B)  # (on the stream the motion's chain runs on)
+                if self._skin_in_order:  # ... and its skinning backward behind it (writes nothing shared)
+                    ex.backward_skinning_in_order(first[m], B)
+                    skinned += 1
             elif ex.ranged or not ex.batched:
                 ex.backward_launch(first[m], B)  # overlaps with the next motion's losses on this stream
             if g.vae_latent:  # KL term of this motion (main_train_dimo.py:355-360): tiny, autograd
@@ -866,6 +888,8 @@ class Trainer:
         elif ex.batched and not ex.ranged:
             ex.backward_launch(0, n)
             ex.backward_accumulate(0, n)
+        elif skinned and skinned == len(by_motion):
+            ex.backward_accumulate(0, n)  # every motion is skinned already: ONE fold over the step's renders
         else:
             for m, trs in by_motion.items():
                 ex.backward_accumulate(first[m], len(trs))
@@ -949,10 +973,13 @@ class Trainer:
         if self._flat_adam:
             # no host sync at all: the overflow words of this step's renders become a device-side skip flag that
             # travels through the all-reduce; the host looks at them one step later (CapacityPolicy.poll)
-            tot = cap.collect_async(defer_copy=True) if cap is not None else None
+            # (device words, pinned host slot, number): the optimizer's launch hands the counts to the host
+            rep = cap.collect_report() if (cap is not None and self._report_via_adam) else None
+            tot = rep[0] if rep is not None else (cap.collect_async(defer_copy=True) if cap is not None else None)
             # (device scalar, no read-back: a step whose renders overflowed must not feed the densification statistics --
             # stage s1 only, where they are gathered)
             self._step_overflow = tot[:, 1].max() if (tot is not None and self.stage == "s1") else None
+            zero_next, self._zero_next = getattr(self, "_zero_next", None), None
             if self.world > 1:  # the flag rides in the tail of the gradient bucket through the all-reduce
                 if tot is not None:
                     g.grad_flag.copy_(tot[:, 1].max().to(torch.float32))
@@ -966,10 +993,11 @@ class Trainer:
                 if timed:
                     e1.record()
                     self.allreduce_events.append((e0, e1))
-                self.optimizer.step(skip_flags=g.grad_flag.view(torch.int32), zero_grad=True)
+                self.optimizer.step(skip_flags=g.grad_flag.view(torch.int32), zero_grad=True, report=rep,
+                                    zero_extra=zero_next)
             else:  # one rank: Adam reads the renders' (R, overflow) words directly
-                self.optimizer.step(skip_flags=tot, zero_grad=True)
-            if cap is not None:
+                self.optimizer.step(skip_flags=tot, zero_grad=True, report=rep, zero_extra=zero_next)
+            if cap is not None and rep is None:
                 cap.start_copy()  # the words' copy for the host (poll, next step), behind the optimizer
             self._mark("allreduce+adam")
         else:

@@ -245,11 +245,18 @@ int dimo_deform_backward(int N, int M, int local_frame, int accumulate, const fl
  * no-op (used with the rasterizer's capacity-overflow word).  zero_grad != 0 clears grads in the same pass.
  * skipped_launches: optional 2 device ints, zero-initialised by the caller and owned by this function afterwards:
  * the number of no-op launches so far, kept on the device so that the bias corrections use the number of updates
- * actually applied (step - skipped) without a host read-back; `step` must then count EVERY launch (1, 2, 3, ...). */
+ * actually applied (step - skipped) without a host read-back; `step` must then count EVERY launch (1, 2, 3, ...).
+ * report_src / report_words / report_dst_host / report_seq: optional -- the launch copies report_words device words
+ * (the step's per-render (R, overflow) instance counts) to report_dst_host[1 ..] and then stores report_seq to
+ * report_dst_host[0] (system-scope release); report_dst_host is HOST-VISIBLE pinned memory (hipHostMalloc) of
+ * >= 1 + report_words words that the host polls a step later instead of a device-to-host copy + event.
+ * zero_extra / zero_n: optional device floats cleared by the same launch (the next step's accumulators). */
 int dimo_flat_adam_step(int64_t n, float *params, float *grads, float *exp_avg, float *exp_avg_sq, int n_segments,
                         const int64_t *segment_end_host, const float *segment_lr_host, float beta1, float beta2,
                         float eps, int64_t step, const int *skip_flags, int n_flags, int flag_stride, int zero_grad,
-                        int *skipped_launches, void *stream);
+                        int *skipped_launches, const uint32_t *report_src, int report_words,
+                        uint32_t *report_dst_host, uint32_t report_seq, float *zero_extra, int64_t zero_n,
+                        void *stream);
 
 /* Diagnostic (no reference counterpart): the 64-lane x 16-value wave reduction the rasterizer backward uses
  * (csrc/wave_ops.hpp), run on caller data.  in: 64 x 16 floats (lane-major), out: 16 floats = the column sums. */
@@ -384,6 +391,14 @@ int dimo_executor_backward_launch_joint(void *executor, const dimo_step_common *
  * loss kernels (each motion of main_train_dimo.py:276-318 is one range). */
 int dimo_executor_backward_launch_in_order(void *executor, const dimo_step_common *common, int first, int count,
                                            const dimo_render_desc *renders, void *main_stream);
+/* Batched ranges only, after dimo_executor_backward_launch_in_order of the same range: the range's skinning backward
+ * on the same stream, writing nothing shared (per-Gaussian gradients in place in the deformation groups' leader
+ * buffers, the control-point sums into per-leader staging tables inside lbs_scratch).
+ * dimo_executor_backward_accumulate over the step's renders then only folds those into the gradient views (one
+ * launch, fixed order), instead of running every motion's skinning backward on main_stream one after the other.
+ * (The LBS block of latent_gs_renderer.py:1191-1219, backward, per motion of main_train_dimo.py:276-318.) */
+int dimo_executor_backward_skinning_in_order(void *executor, const dimo_step_common *common, int first, int count,
+                                             const dimo_render_desc *renders, void *main_stream);
 /* ... and, on main_stream, per render: wait for it, g_f_dc += g_shs, skinning backward (accumulate) */
 int dimo_executor_backward_accumulate(void *executor, const dimo_step_common *common, int first, int count,
                                       const dimo_render_desc *renders, void *main_stream);

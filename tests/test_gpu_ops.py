@@ -225,3 +225,46 @@ def test_wave_reduce16_of_the_blend_backward():
         want = x.double().sum(0)
         got = out.cpu().double()
         assert torch.allclose(got, want, rtol=1e-5, atol=1e-5 * float(x.abs().sum(0).max())), (trial, got, want)
+
+
+def test_flat_adam_reports_to_pinned_host_memory_and_clears_the_next_steps_accumulators():
+    """dimo_flat_adam_step's optional extras (round 4): `report` -- device words copied to a PINNED host slot behind a
+    sequence number by the optimizer's own launch (CapacityPolicy.collect_report / poll: the instance counts reach the
+    host without a copy engine or an event) -- and `zero_extra`.  The update itself must not change."""
+    from dimo_amd.flat_adam import FlatAdam
+    from dimo_amd.rasterizer import CapacityPolicy
+    gen = torch.Generator().manual_seed(0)
+    n = 4099
+    res = []
+    for extras in (False, True):
+        p = torch.randn(n + (4 - n % 4) % 4, generator=gen.manual_seed(1)).cuda()
+        gr = torch.randn(p.shape, generator=gen.manual_seed(2)).cuda()
+        prm = torch.nn.Parameter(p[:n])
+        opt = FlatAdam([dict(params=[prm], lr=0.01, name="x")], p, gr)
+        kw = {}
+        if extras:
+            words = torch.tensor([[123456, 0], [654321, 0], [7, 0]], dtype=torch.int32, device="cuda")
+            slot = torch.zeros(16, dtype=torch.int32, pin_memory=True)
+            junk = torch.full((1000,), 3.0, device="cuda")
+            kw = dict(report=(words, slot, 41), zero_extra=junk)
+        opt.step(zero_grad=True, **kw)
+        torch.cuda.synchronize()
+        res.append(p.clone())
+        assert float(gr.abs().max()) == 0.0
+        if extras:
+            assert int(slot[0]) == 41 and slot[1:7].tolist() == [123456, 0, 654321, 0, 7, 0]
+            assert float(junk.abs().max()) == 0.0
+    assert torch.equal(res[0], res[1])
+    # the policy's side: collect_report -> (words, slot, seq); poll() evaluates the slot once its number is there
+    pol = CapacityPolicy(initial=1000, margin=1.5)
+    words = torch.tensor([[900, 0], [400, 0]], dtype=torch.int32, device="cuda")
+    pol.track(words)
+    tot, slot, seq = pol.collect_report()
+    p = torch.zeros(8, device="cuda")
+    opt = FlatAdam([dict(params=[torch.nn.Parameter(p)], lr=0.01, name="x")], p, torch.zeros(8, device="cuda"))
+    opt.step(report=(tot, slot, seq))
+    assert pol.poll(lag=0) == 0 and pol.last_r_max == 900 and pol.capacity >= 1350
+    pol.track(torch.tensor([[10, 1]], dtype=torch.int32, device="cuda"))
+    rep = pol.collect_report()
+    opt.step(report=rep)
+    assert pol.poll(lag=1) == 0 and pol.poll(lag=0) == 1  # (the newest report is left alone with lag = 1)

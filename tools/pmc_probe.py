@@ -16,7 +16,8 @@ if "--no-calibration" not in sys.argv:
         dst = src.clone()  # vectorized copy kernel: 1 GiB in, 1 GiB out
     torch.cuda.synchronize()
 tr, pol = bench.make_trainer(dev, 0, 1, 100000, 512)
-tr._joint_bwd = True  # the counters are read per launch of the roofline kernel: ONE launch over the step's 8 renders
+if "--default-schedule" not in sys.argv:
+    tr._joint_bwd = True  # the counters are read per launch of the roofline kernel: ONE launch over the step's 8 renders
 steps = int(sys.argv[sys.argv.index("--steps") + 1]) if "--steps" in sys.argv else 4
 for _ in range(steps):
     tr.train_step()
