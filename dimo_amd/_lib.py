@@ -66,6 +66,11 @@ _SIGNATURES = {
     "dimo_executor_range_stream": (C.c_void_p, [C.c_void_p, C.c_int]),
     "dimo_executor_backward_launch_in_order": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
                                                          C.c_void_p]),
+    "dimo_executor_side_stream": (C.c_void_p, [C.c_void_p, C.c_int, C.c_void_p]),
+    "dimo_executor_side_done": (C.c_int, [C.c_void_p, C.c_int]),
+    "dimo_executor_wait_side": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "dimo_executor_private_stream": (C.c_void_p, [C.c_void_p, C.c_int]),
+    "dimo_executor_join_ranges": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "dimo_executor_backward_skinning_in_order": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
                                                            C.c_void_p]),
     "dimo_executor_backward_launch_joint": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
@@ -73,7 +78,8 @@ _SIGNATURES = {
                                                     C.c_void_p]),
     "dimo_flat_adam_step": (C.c_int, [C.c_int64] + [c_ptr] * 4 + [C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_float)]
                             + [C.c_float] * 3 + [C.c_int64, c_ptr, C.c_int, C.c_int, C.c_int, c_ptr]
-                            + [c_ptr, C.c_int, c_ptr, C.c_uint32, c_ptr, C.c_int64, c_ptr]),
+                            + [c_ptr, C.c_int, c_ptr, C.c_uint32, c_ptr, C.c_int64, C.c_int64, C.c_int64, C.c_int,
+                               c_ptr]),
     "dimo_selftest_wave_reduce16": (C.c_int, [c_ptr, c_ptr, c_ptr]),
     "dimo_debug_blend_trace": (C.c_int64, [c_ptr, C.c_int64]),
     "dimo_image_loss": (C.c_int, [C.c_int] * 3 + [c_ptr] * 6 + [C.c_int, C.POINTER(C.c_float)] + [C.c_float] * 5

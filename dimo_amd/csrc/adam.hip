@@ -29,19 +29,21 @@ __global__ void __launch_bounds__(256) flat_adam_kernel(long long n, float *__re
                                                         int flag_stride, int zero_grad, int *__restrict__ skipped,
                                                         const uint32_t *__restrict__ report_src, int report_words,
                                                         uint32_t *report_dst, uint32_t report_seq,
-                                                        float *__restrict__ zero_extra, long long zero_n) {
+                                                        float *__restrict__ zero_extra, long long zero_n,
+                                                        long long begin, int final_part) {
   // Optional report for the host: `report_words` device words (the step's (R, overflow) instance counts) copied into
   // host-visible pinned memory behind a sequence number -- the host looks at them a step later without an event or a
   // copy engine (a 4 us device-to-host copy and the ~13 us gap behind it sat on every step's critical path).
-  if (report_dst && blockIdx.x == 0) {
+  if (report_dst && final_part && blockIdx.x == 0) {
     for (int k = threadIdx.x; k < report_words; k += 256) report_dst[1 + k] = report_src[k];
     __threadfence_system();
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_store(report_dst, report_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   // Optional scratch region zeroed for the NEXT step (its accumulators: a fill launch at the head of every step)
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < zero_n; i += (long long)gridDim.x * 256)
-    zero_extra[i] = 0.f;
+  if (final_part)
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < zero_n; i += (long long)gridDim.x * 256)
+      zero_extra[i] = 0.f;
   bool skip = false;
   for (int k = 0; k < n_flags; ++k) skip |= skip_flags[(size_t)k * flag_stride] != 0;
   // effective step = launches so far - launches skipped before this one; this launch reads word (launch & 1) and
@@ -52,12 +54,13 @@ __global__ void __launch_bounds__(256) flat_adam_kernel(long long n, float *__re
     const double t = (double)(launch - before);
     s_bc[0] = (float)(1.0 / (1.0 - pow((double)beta1, t)));
     s_bc[1] = (float)(1.0 / sqrt(1.0 - pow((double)beta2, t)));
-    if (skipped && blockIdx.x == 0) skipped[(launch + 1) & 1] = before + (skip ? 1 : 0);
+    // (a step taken as two launches -- [0, split) early, [split, n) later -- counts once: the final part writes)
+    if (skipped && final_part && blockIdx.x == 0) skipped[(launch + 1) & 1] = before + (skip ? 1 : 0);
   }
   __syncthreads();
   const float inv_bc1 = s_bc[0], inv_sqrt_bc2 = s_bc[1];
   const long long stride = (long long)gridDim.x * 256 * 4;
-  for (long long i0 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4; i0 < n; i0 += stride) {
+  for (long long i0 = begin + ((long long)blockIdx.x * 256 + threadIdx.x) * 4; i0 < n; i0 += stride) {
     if (i0 + 3 < n) {
       float4 gp = *reinterpret_cast<float4 *>(g + i0);
       if (!skip) {
@@ -105,7 +108,8 @@ extern "C" int dimo_flat_adam_step(int64_t n, float *params, float *grads, float
                                    float beta1, float beta2, float eps, int64_t step, const int *skip_flags,
                                    int n_flags, int flag_stride, int zero_grad, int *skipped_launches,
                                    const uint32_t *report_src, int report_words, uint32_t *report_dst_host,
-                                   uint32_t report_seq, float *zero_extra, int64_t zero_n, void *stream_) {
+                                   uint32_t report_seq, float *zero_extra, int64_t zero_n, int64_t range_begin,
+                                   int64_t range_end, int final_part, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   clear_errors();
   if (n < 0 || n_segments < 1 || n_segments > ADAM_MAX_SEG || step < 1 || n_flags < 0) return DIMO_E_ARG;
@@ -124,13 +128,18 @@ extern "C" int dimo_flat_adam_step(int64_t n, float *params, float *grads, float
     segs.lr[k] = k < n_segments ? segment_lr_host[k] : 0.0f;
   }
   if (segs.end[n_segments - 1] != n) return DIMO_E_ARG;
-  long long blocks = (n / 4 + 255) / 256;
+  // one step as two launches: [range_begin, range_end) of the bucket (multiples of 4; 0, 0 = everything)
+  if (range_begin == 0 && range_end == 0) range_end = n;
+  if (range_begin < 0 || range_end > n || range_begin > range_end || (range_begin & 3) ||
+      (range_end != n && (range_end & 3)))
+    return DIMO_E_ARG;
+  long long blocks = ((range_end - range_begin) / 4 + 255) / 256;
   if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;
   ScopedTimer tm(T_ADAM, stream);
-  hipLaunchKernelGGL(flat_adam_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (long long)n, params, grads,
+  hipLaunchKernelGGL(flat_adam_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (long long)range_end, params, grads,
                      exp_avg, exp_avg_sq, segs, beta1, beta2, eps, (long long)step, skip_flags, n_flags, flag_stride,
                      zero_grad, skipped_launches, report_src, report_words, report_dst_host, report_seq, zero_extra,
-                     (long long)zero_n);
+                     (long long)zero_n, (long long)range_begin, final_part);
   return check_launch();
 }

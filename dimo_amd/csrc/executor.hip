@@ -85,6 +85,10 @@ struct Executor {
   uint32_t fork_seq = 0;
   std::vector<uint32_t> done_seq;     // per private stream: last value written
   std::vector<uint32_t> fwd_val, render_val;  // per range start: the value its fwd_done / render_done stands for
+  // side work (dimo_executor_side_stream / _side_done): per private stream, what its last side work stands for
+  std::vector<hipEvent_t> side_ev;
+  std::vector<uint32_t> side_val;
+  std::vector<char> side_pending;
 };
 
 // "record" on private stream si what `ev` stands for, and remember it for range start `i`
@@ -161,14 +165,23 @@ extern "C" void *dimo_executor_create(int n_streams) {
     }
     ex->streams.push_back(pool[i]);
     ex->stream_done.push_back(e);
+    hipEvent_t e2;
+    if (hipEventCreateWithFlags(&e2, hipEventDisableTiming) != hipSuccess) {
+      delete ex;
+      return nullptr;
+    }
+    ex->side_ev.push_back(e2);
   }
+  ex->side_val.assign(S, 0u);
+  ex->side_pending.assign(S, 0);
   if (hipEventCreateWithFlags(&ex->main_ready, hipEventDisableTiming) != hipSuccess) {
     delete ex;
     return nullptr;
   }
   ex->done_seq.assign(S, 0u);
   const char *mode = getenv("DIMO_XSTREAM");
-  if (S > 0 && S < 60 && ex->batched && mode && std::string(mode) == "value") {
+  // default: stream write / wait values (7.62 -> 7.79 k frames/s on the benchmark step); DIMO_XSTREAM=event: events
+  if (S > 0 && S < 60 && ex->batched && !(mode && std::string(mode) == "event")) {
     if (hipMalloc((void **)&ex->sig, 64 * sizeof(uint32_t)) == hipSuccess &&
         hipMemset(ex->sig, 0, 64 * sizeof(uint32_t)) == hipSuccess)
       ex->use_values = true;
@@ -185,6 +198,7 @@ extern "C" void dimo_executor_destroy(void *h) {
   // executor's own events (what it last recorded on them), not for the streams.  (An event that was never recorded
   // reports complete.)
   for (auto e : ex->stream_done) (void)hipEventSynchronize(e), (void)hipEventDestroy(e);
+  for (auto e : ex->side_ev) (void)hipEventSynchronize(e), (void)hipEventDestroy(e);
   for (auto e : ex->render_done) (void)hipEventSynchronize(e), (void)hipEventDestroy(e);
   for (auto e : ex->fwd_done) (void)hipEventSynchronize(e), (void)hipEventDestroy(e);
   if (ex->main_ready) (void)hipEventDestroy(ex->main_ready);
@@ -232,6 +246,65 @@ static int fork_one(Executor *ex, hipStream_t main, hipStream_t s) {
   }
   if (hipEventRecord(ex->main_ready, main) != hipSuccess) return DIMO_E_LAUNCH;
   return hipStreamWaitEvent(s, ex->main_ready, 0) == hipSuccess ? DIMO_OK : DIMO_E_LAUNCH;
+}
+
+// Stream `s` (private stream `self`, or the caller's stream: self = -1) waits for the side work pending on the OTHER
+// private streams (in order behind it on its own).
+static int wait_side_work(Executor *ex, hipStream_t s, int self) {
+  for (int j = 0; j < (int)ex->streams.size(); ++j) {
+    if (j == self || !ex->side_pending[j]) continue;
+    if (ex->use_values) {
+      if (hipStreamWaitValue32(s, ex->sig + 1 + j, ex->side_val[j], hipStreamWaitValueGte, 0xffffffffu) != hipSuccess)
+        return DIMO_E_LAUNCH;
+    } else if (hipStreamWaitEvent(s, ex->side_ev[j], 0) != hipSuccess) {
+      return DIMO_E_LAUNCH;
+    }
+  }
+  return DIMO_OK;
+}
+
+// Side work: something the caller enqueues ITSELF on one of the executor's private streams, concurrently with what it
+// goes on enqueueing on its own stream -- the step's KNN next to the TimeNet forward (main_train_dimo.py:257-258 and
+// latent_gs_renderer.py:1171-1174 are independent of each other; both feed the skinning).
+// dimo_executor_side_stream: private stream `which`, made to wait for everything on main_stream so far; the caller
+// launches on it, then calls dimo_executor_side_done.  Every forward chain started afterwards (on any stream) waits for
+// it; a chain on stream `which` simply follows in order.
+extern "C" void *dimo_executor_side_stream(void *h, int which, void *main_stream) {
+  Executor *ex = reinterpret_cast<Executor *>(h);
+  if (!ex || !ex->batched || which < 0 || which >= (int)ex->streams.size()) return nullptr;
+  if (fork_one(ex, (hipStream_t)main_stream, ex->streams[which]) != DIMO_OK) return nullptr;
+  return (void *)ex->streams[which];
+}
+extern "C" int dimo_executor_side_done(void *h, int which) {
+  Executor *ex = reinterpret_cast<Executor *>(h);
+  if (!ex || !ex->batched || which < 0 || which >= (int)ex->streams.size()) return DIMO_E_ARG;
+  if (ex->use_values) {
+    const uint32_t v = ++ex->done_seq[which];
+    ex->side_val[which] = v;
+    if (hipStreamWriteValue32(ex->streams[which], ex->sig + 1 + which, v, 0) != hipSuccess) return DIMO_E_LAUNCH;
+  } else if (hipEventRecord(ex->side_ev[which], ex->streams[which]) != hipSuccess) {
+    return DIMO_E_LAUNCH;
+  }
+  ex->side_pending[which] = 1;
+  return DIMO_OK;
+}
+
+// The caller's stream waits for the side work of private stream `which`.
+extern "C" int dimo_executor_wait_side(void *h, int which, void *main_stream) {
+  Executor *ex = reinterpret_cast<Executor *>(h);
+  if (!ex || !ex->batched || which < 0 || which >= (int)ex->streams.size()) return DIMO_E_ARG;
+  if (!ex->side_pending[which]) return DIMO_OK;
+  hipStream_t main = (hipStream_t)main_stream;
+  if (ex->use_values)
+    return hipStreamWaitValue32(main, ex->sig + 1 + which, ex->side_val[which], hipStreamWaitValueGte, 0xffffffffu) ==
+                   hipSuccess ? DIMO_OK : DIMO_E_LAUNCH;
+  return hipStreamWaitEvent(main, ex->side_ev[which], 0) == hipSuccess ? DIMO_OK : DIMO_E_LAUNCH;
+}
+// Private stream `which` as it is (no dependency added): for work that continues what the stream already holds.
+extern "C" void *dimo_executor_private_stream(void *h, int which) {
+  Executor *ex = reinterpret_cast<Executor *>(h);
+  if (!ex || !ex->batched || which < 0 || which >= (int)ex->streams.size()) return nullptr;
+  return (void *)ex->streams[which];
 }
 
 // Launch chunks (start, count <= MAX_BATCH) over the ranges inside [first, first + count).  A range longer than a
@@ -314,6 +387,7 @@ extern "C" int dimo_executor_forward_range(void *h, const dimo_step_common *c, i
     if (first == 0) std::fill(ex->range_stream.begin(), ex->range_stream.end(), -1);  // a new step's ranges
     ex->range_stream[first] = si, ex->range_count[first] = count, ex->range_skinned[first] = 0;
     rc = fork_one(ex, main, s);
+    if (!rc) rc = wait_side_work(ex, s, si);
     if (!rc) rc = batched_forward(c, d, first, count, s);
     if (rc) return rc;
     return mark_done(ex, si, ex->fwd_done[first], ex->fwd_val, first);
@@ -357,6 +431,7 @@ extern "C" int dimo_executor_forward_range_on_caller(void *h, const dimo_step_co
   if (first == 0) std::fill(ex->range_stream.begin(), ex->range_stream.end(), -1);  // a new step's ranges
   ex->range_stream[first] = (int)ex->streams.size(), ex->range_count[first] = count;  // marker: the caller's stream
   ex->range_skinned[first] = 0;
+  if (wait_side_work(ex, (hipStream_t)main_stream, -1)) return DIMO_E_LAUNCH;
   return batched_forward(c, d, first, count, (hipStream_t)main_stream);
 }
 
@@ -511,6 +586,25 @@ extern "C" int dimo_executor_backward_launch_joint(void *h, const dimo_step_comm
   return DIMO_OK;
 }
 
+// Batched ranges only: `stream` waits for what every range inside [first, first + count) last recorded on its private
+// stream (its rasterizer backward, or its skinning backward after dimo_executor_backward_skinning_in_order) -- the
+// waits of dimo_executor_backward_accumulate without its kernels: when the fold runs on ANOTHER stream (next to the
+// TimeNet backward), the caller's stream still has to see the motions' TimeNet-row gradients.
+extern "C" int dimo_executor_join_ranges(void *h, int first, int count, void *stream_) {
+  Executor *ex = reinterpret_cast<Executor *>(h);
+  hipStream_t st = (hipStream_t)stream_;
+  if (!ex || first < 0 || count < 0 || !ex->batched) return DIMO_E_ARG;
+  if (ex->streams.empty()) return DIMO_OK;
+  if (first + count > (int)ex->render_done.size()) return DIMO_E_ARG;
+  for (int i = first; i < first + count; ++i) {
+    const int si = i < (int)ex->range_stream.size() ? ex->range_stream[i] : -1;
+    if (si < 0 || si >= (int)ex->streams.size() || ex->range_bwd_main[i]) continue;
+    if (ex->streams[si] == st) continue;  // (its own stream: in order)
+    if (wait_done(ex, st, si, ex->render_done[i], ex->render_val, i)) return DIMO_E_LAUNCH;
+  }
+  return DIMO_OK;
+}
+
 // On the caller's stream: wait for the rasterizer backward of renders [first, first + count), then the skinning
 // backward accumulating into the shared gradient views (g_f_dc += g_shs included).
 extern "C" int dimo_executor_backward_accumulate(void *h, const dimo_step_common *c, int first, int count,
@@ -557,6 +651,7 @@ extern "C" int dimo_executor_backward_accumulate(void *h, const dimo_step_common
       const int rc = lbs_backward_batched(*c, b, ch.second, main, ch.first, skinned ? 2 : 0);
       if (rc) return rc;
     }
+    std::fill(ex->side_pending.begin(), ex->side_pending.end(), 0);  // (every chain that waited for it has been joined)
     return DIMO_OK;
   }
   if (first + count > (int)ex->render_done.size()) return DIMO_E_ARG;

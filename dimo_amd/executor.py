@@ -169,6 +169,28 @@ class StepExecutor:
                                                                  C.addressof(self.descs), _lib.current_stream()),
                    "dimo_executor_backward_launch_in_order")
 
+    def side_stream(self, which=0):
+        """Raw handle of private stream `which`, waiting for the current stream's tail: the caller launches side work
+        on it (then `side_done`) while it goes on enqueueing on the current stream."""
+        s = self.L.dimo_executor_side_stream(self.handle, which, _lib.current_stream())
+        if not s:
+            raise RuntimeError("dimo_executor_side_stream failed")
+        return s
+
+    def side_done(self, which=0):
+        _lib.check(self.L.dimo_executor_side_done(self.handle, which), "dimo_executor_side_done")
+
+    def wait_side(self, which=0):
+        _lib.check(self.L.dimo_executor_wait_side(self.handle, which, _lib.current_stream()), "dimo_executor_wait_side")
+
+    def private_stream(self, which=0):
+        return self.L.dimo_executor_private_stream(self.handle, which) or None
+
+    def join_ranges(self, first, count, stream=None):
+        _lib.check(self.L.dimo_executor_join_ranges(self.handle, first, count,
+                                                    stream if stream is not None else _lib.current_stream()),
+                   "dimo_executor_join_ranges")
+
     def backward_skinning_in_order(self, first, count):
         """The range's skinning backward behind its rasterizer backward, on the same stream (nothing shared is
         written); `backward_accumulate` over the step's renders then only folds."""
@@ -181,7 +203,9 @@ class StepExecutor:
                                                               C.addressof(self.descs), _lib.current_stream()),
                    "dimo_executor_backward_launch_joint")
 
-    def backward_accumulate(self, first, count):
+    def backward_accumulate(self, first, count, stream=None):
+        """`stream`: raw handle of the stream to run on (default: the current one)."""
         _lib.check(self.L.dimo_executor_backward_accumulate(self.handle, C.addressof(self.common), first, count,
-                                                            C.addressof(self.descs), _lib.current_stream()),
+                                                            C.addressof(self.descs),
+                                                            stream if stream is not None else _lib.current_stream()),
                    "dimo_executor_backward_accumulate")

@@ -58,15 +58,26 @@ class FlatAdam:
         self.skipped_host = 0
         self._skipped.zero_()
 
-    def step(self, skip_flags=None, zero_grad=False, report=None, zero_extra=None):
+    def step(self, skip_flags=None, zero_grad=False, report=None, zero_extra=None, part=None, stream=None):
         """skip_flags: optional int32 tensor [k, 2] (rasterizer `total` words: R, overflow) -- any non-zero
         overflow word turns this step into a no-op on the device.  report: optional (src int32 device tensor, dst
         PINNED int32 host tensor with >= 1 + src.numel() words, seq) -- the launch copies src to dst[1:] and then stores
         seq to dst[0] (CapacityPolicy polls it a step later: no copy engine, no event).  zero_extra: optional fp32
-        device tensor cleared by the same launch."""
-        if self.pre_step is not None:
-            self.pre_step()
-        self.launches += 1
+        device tensor cleared by the same launch.  part: None = the whole bucket; ("head", split) = only [0, split)
+        -- the FIRST of the two launches of a step; ("tail", split) = [split, n), the second and final one (it counts
+        the step, reports, clears): the per-Gaussian head of the bucket can be updated as soon as ITS gradients are
+        final, under the TimeNet backward.  Both launches must see the same skip_flags.  stream: raw stream handle
+        (default: torch's current stream)."""
+        if part is None or part[0] == "head":
+            if self.pre_step is not None:
+                self.pre_step()
+            self.launches += 1
+        begin, end, final = 0, 0, 1
+        if part is not None:
+            kind, split = part
+            split = int(split)
+            assert split % 4 == 0 and 0 < split < self.flat_params.numel()
+            begin, end, final = (0, split, 0) if kind == "head" else (split, self.flat_params.numel(), 1)
         lrs = (C.c_float * self._n_seg)(*[float(g["lr"]) for g in self.param_groups])
         b1, b2 = self.defaults["betas"]
         if skip_flags is not None and skip_flags.numel() > 0:
@@ -94,7 +105,7 @@ class FlatAdam:
             self.flat_params.numel(), _lib.ptr(self.flat_params), _lib.ptr(self.flat_grads), _lib.ptr(self.exp_avg),
             _lib.ptr(self.exp_avg_sq), self._n_seg, self._ends, lrs, b1, b2, self.defaults["eps"], self.launches,
             fptr, nfl, fstride, int(bool(zero_grad)), _lib.ptr(self._skipped), rsrc, rwords, rdst, rseq, zptr, zn,
-            _lib.current_stream()),
+            begin, end, final, stream if stream is not None else _lib.current_stream()),
             "dimo_flat_adam_step")
 
     def zero_grad(self, set_to_none=False):

@@ -11,10 +11,11 @@ import torch
 from . import _lib
 
 
-def knn_points(ref, query, k, seed=None):
+def knn_points(ref, query, k, seed=None, stream=None):
     """ref [M,3], query [N,3] (cuda, fp32) -> (dist [N,k], idx [N,k] int64).  `seed` (optional, [N,4] int64, k = 4):
     candidate neighbours per query (the previous step's result) that only prune the search -- same output for any
-    seed values (include/dimo_hip.h: dimo_knn_seeded)."""
+    seed values (include/dimo_hip.h: dimo_knn_seeded).  `stream`: raw stream handle to launch on (default: torch's
+    current stream)."""
     if not (ref.is_cuda and query.is_cuda):
         raise RuntimeError("dimo_amd.knn_cuda needs GPU tensors (no CPU fallback in the product path)")
     ref, query = ref.detach().float().contiguous(), query.detach().float().contiguous()
@@ -25,7 +26,8 @@ def knn_points(ref, query, k, seed=None):
                                  and tuple(seed.shape) == (N, 4)):
         seed = None
     _lib.check(_lib.lib().dimo_knn_seeded(M, N, k, _lib.ptr(ref), _lib.ptr(query), _lib.ptr(dist), _lib.ptr(idx),
-                                          _lib.ptr(seed), _lib.current_stream()), "dimo_knn_seeded")
+                                          _lib.ptr(seed), stream if stream is not None else _lib.current_stream()),
+               "dimo_knn_seeded")
     return dist, idx
 
 

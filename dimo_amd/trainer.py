@@ -211,6 +211,8 @@ class Trainer:
         # per-motion backward: the motion's SKINNING backward too in order on its stream (control-point sums staged,
         # one fold on this stream at the end) instead of one skinning backward per motion on this stream
         self._skin_in_order = os.environ.get("DIMO_SKIN_IN_ORDER", "1") == "1"
+        self._split_adam = os.environ.get("DIMO_SPLIT_ADAM", "1") == "1"  # Adam's per-Gaussian head under the TimeNet backward
+        self._side_knn = os.environ.get("DIMO_SIDE_KNN", "1") == "1"  # KNN on a private stream next to the TimeNet forward
         self._report_via_adam = os.environ.get("DIMO_REPORT", "1") == "1"  # "0": device-to-host copy + event per step
         self._zero_via_adam = os.environ.get("DIMO_ZERO_NEXT", "1") == "1"  # "0": a fill launch per step
         self._direct_wanted = direct
@@ -312,12 +314,20 @@ class Trainer:
                 on_step(self)
 
     # ------------------------------------------------------------------ pieces of train_step
-    def find_knn(self, k=4):
+    def find_knn(self, k=4, stream=None):
+        """`stream`: raw handle of the stream to search on (the direct pipeline runs the search on one of the
+        executor's private streams, next to the TimeNet forward)."""
         g = self.renderer.gaussians
+        kw = {} if stream is None else {"stream": stream}
+        if stream is not None:
+            # the search READS last step's neighbours (its seeds) on a stream the caching allocator knows nothing about:
+            # they stay alive until the next search (by then this step's streams have been joined), instead of going
+            # back to the pool -- and under a kernel of this stream -- the moment they are replaced below
+            self._knn_keep = (g.neighbor_dists, g.neighbor_indices)
         if self._knn_seeded and g.neighbor_indices is not None:  # last step's neighbours prune this step's search
-            d, i = self.knn(g._c_xyz.detach(), g._xyz.detach(), k, seed=g.neighbor_indices)
+            d, i = self.knn(g._c_xyz.detach(), g._xyz.detach(), k, seed=g.neighbor_indices, **kw)
         else:
-            d, i = self.knn(g._c_xyz.detach(), g._xyz.detach(), k)
+            d, i = self.knn(g._c_xyz.detach(), g._xyz.detach(), k, **kw)
         g.neighbor_dists, g.neighbor_indices = d, i
 
     def fps(self, num_pts):
@@ -626,6 +636,18 @@ class Trainer:
             self._last_stats = (out["radii"], out["viewspace_points"].grad)
         return loss
 
+    def _collect_counts(self):
+        """(report, device words) of the renders since the last optimizer step: the (R, overflow) instance counts that
+        become the update's skip flag; `report` = (words, pinned host slot, number) when the optimizer's launch hands
+        them to the host (CapacityPolicy.collect_report), else None (a device-to-host copy behind the optimizer)."""
+        cap = self.renderer.capacity_policy()
+        rep = cap.collect_report() if (cap is not None and self._report_via_adam) else None
+        tot = rep[0] if rep is not None else (cap.collect_async(defer_copy=True) if cap is not None else None)
+        return rep, tot
+
+    def _knn_on_side(self):
+        return self.direct and self._side_knn and self._knn_seeded
+
     def _executor(self, n_renders):
         from .executor import StepExecutor
         g, c = self.renderer.gaussians, self.cfg
@@ -665,6 +687,15 @@ class Trainer:
         n = len(mine)
         ex = self._executor(n)
         s1 = self.stage == "s1"
+        if not s1 and self._knn_on_side():
+            # the step's KNN (main_train_dimo.py:257-258) on a private stream of the executor, NEXT TO the weight packing
+            # and the TimeNet forward on this stream (independent of each other: both feed the skinning; 25 us of the
+            # step's serial head).  The motion whose chain runs on that stream follows in order, the others wait for it.
+            if ex.ranged:
+                self.find_knn(k=4, stream=ex.side_stream(0))
+                ex.side_done(0)
+            else:
+                self.find_knn(k=4)
         ex.set_common(g, self.renderer.bg_color, self.renderer.add_normal, stage1=s1)
         self._mark("start")
         fused_tn = (self.fused_timenet or s1) and len(g._timenet.skips) <= 1
@@ -889,7 +920,20 @@ class Trainer:
             ex.backward_launch(0, n)
             ex.backward_accumulate(0, n)
         elif skinned and skinned == len(by_motion):
-            ex.backward_accumulate(0, n)  # every motion is skinned already: ONE fold over the step's renders
+            # every motion is skinned already: ONE fold over the step's renders
+            side = ex.private_stream(0) if (self._split_adam and not s1 and self.world == 1 and self._flat_adam) else None
+            if side is not None:
+                # ... on private stream 0, followed there by the optimizer's update of the per-Gaussian head of the
+                # bucket (its gradients are final with the fold), NEXT TO the TimeNet backward on this stream, which only
+                # needs the motions' TimeNet-row gradients; the tail of the bucket is updated after it (train_step)
+                ex.join_ranges(0, n)
+                ex.backward_accumulate(0, n, stream=side)
+                counts = self._collect_counts()
+                self.optimizer.step(skip_flags=counts[1], zero_grad=True, part=("head", g.flat_split), stream=side)
+                ex.side_done(0)
+                self._adam_head = counts
+            else:
+                ex.backward_accumulate(0, n)
         else:
             for m, trs in by_motion.items():
                 ex.backward_accumulate(first[m], len(trs))
@@ -955,7 +999,7 @@ class Trainer:
             for grp in self.optimizer.param_groups:
                 if grp["name"] == "xyz":
                     grp["lr"] = 0.0002
-        if self.stage >= "s2":
+        if self.stage >= "s2" and not self._knn_on_side():
             self.find_knn(k=4)
         if triples is None:
             triples = self.sample()
@@ -973,9 +1017,8 @@ class Trainer:
         if self._flat_adam:
             # no host sync at all: the overflow words of this step's renders become a device-side skip flag that
             # travels through the all-reduce; the host looks at them one step later (CapacityPolicy.poll)
-            # (device words, pinned host slot, number): the optimizer's launch hands the counts to the host
-            rep = cap.collect_report() if (cap is not None and self._report_via_adam) else None
-            tot = rep[0] if rep is not None else (cap.collect_async(defer_copy=True) if cap is not None else None)
+            head, self._adam_head = getattr(self, "_adam_head", None), None
+            rep, tot = head if head is not None else self._collect_counts()
             # (device scalar, no read-back: a step whose renders overflowed must not feed the densification statistics --
             # stage s1 only, where they are gathered)
             self._step_overflow = tot[:, 1].max() if (tot is not None and self.stage == "s1") else None
@@ -995,6 +1038,10 @@ class Trainer:
                     self.allreduce_events.append((e0, e1))
                 self.optimizer.step(skip_flags=g.grad_flag.view(torch.int32), zero_grad=True, report=rep,
                                     zero_extra=zero_next)
+            elif head is not None:  # the head of the bucket has been updated under the TimeNet backward: the tail now
+                self._exec.wait_side(0)
+                self.optimizer.step(skip_flags=tot, zero_grad=True, report=rep, zero_extra=zero_next,
+                                    part=("tail", g.flat_split))
             else:  # one rank: Adam reads the renders' (R, overflow) words directly
                 self.optimizer.step(skip_flags=tot, zero_grad=True, report=rep, zero_extra=zero_next)
             if cap is not None and rep is None:

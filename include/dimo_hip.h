@@ -250,13 +250,17 @@ int dimo_deform_backward(int N, int M, int local_frame, int accumulate, const fl
  * (the step's per-render (R, overflow) instance counts) to report_dst_host[1 ..] and then stores report_seq to
  * report_dst_host[0] (system-scope release); report_dst_host is HOST-VISIBLE pinned memory (hipHostMalloc) of
  * >= 1 + report_words words that the host polls a step later instead of a device-to-host copy + event.
- * zero_extra / zero_n: optional device floats cleared by the same launch (the next step's accumulators). */
+ * zero_extra / zero_n: optional device floats cleared by the same launch (the next step's accumulators).
+ * range_begin / range_end / final_part: ONE optimizer step taken as two launches over [0, split) and [split, n)
+ * (offsets in floats, multiples of 4; 0, 0 = the whole bucket): both are given the same `step`; the launch with
+ * final_part != 0 is the one that counts the step in skipped_launches, writes the report and clears zero_extra
+ * (it must be the LAST of the two to run). */
 int dimo_flat_adam_step(int64_t n, float *params, float *grads, float *exp_avg, float *exp_avg_sq, int n_segments,
                         const int64_t *segment_end_host, const float *segment_lr_host, float beta1, float beta2,
                         float eps, int64_t step, const int *skip_flags, int n_flags, int flag_stride, int zero_grad,
                         int *skipped_launches, const uint32_t *report_src, int report_words,
                         uint32_t *report_dst_host, uint32_t report_seq, float *zero_extra, int64_t zero_n,
-                        void *stream);
+                        int64_t range_begin, int64_t range_end, int final_part, void *stream);
 
 /* Diagnostic (no reference counterpart): the 64-lane x 16-value wave reduction the rasterizer backward uses
  * (csrc/wave_ops.hpp), run on caller data.  in: 64 x 16 floats (lane-major), out: 16 floats = the column sums. */
@@ -391,6 +395,19 @@ int dimo_executor_backward_launch_joint(void *executor, const dimo_step_common *
  * loss kernels (each motion of main_train_dimo.py:276-318 is one range). */
 int dimo_executor_backward_launch_in_order(void *executor, const dimo_step_common *common, int first, int count,
                                            const dimo_render_desc *renders, void *main_stream);
+/* Batched ranges only.  Side work: the caller enqueues something ITSELF on private stream `which` (returned as a
+ * hipStream_t, made to wait for main_stream's tail), concurrently with what it goes on enqueueing on main_stream, and
+ * then calls dimo_executor_side_done(which); every forward chain started afterwards waits for it (a chain on stream
+ * `which` follows in order).  Used for the step's KNN (main_train_dimo.py:257-258) next to the TimeNet forward. */
+void *dimo_executor_side_stream(void *executor, int which, void *main_stream);
+int dimo_executor_side_done(void *executor, int which);
+/* main_stream waits for the side work last marked on private stream `which`; the private stream itself (no dependency
+ * added), for work that CONTINUES what it holds -- the fold of the skinning backward and the optimizer's update of the
+ * per-Gaussian parameters behind one motion's chain, next to the TimeNet backward on the caller's stream -- and the
+ * waits of dimo_executor_backward_accumulate without its kernels, for a stream that only needs the ranges' results. */
+int dimo_executor_wait_side(void *executor, int which, void *main_stream);
+void *dimo_executor_private_stream(void *executor, int which);
+int dimo_executor_join_ranges(void *executor, int first, int count, void *stream);
 /* Batched ranges only, after dimo_executor_backward_launch_in_order of the same range: the range's skinning backward
  * on the same stream, writing nothing shared (per-Gaussian gradients in place in the deformation groups' leader
  * buffers, the control-point sums into per-leader staging tables inside lbs_scratch).
