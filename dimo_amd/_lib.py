@@ -135,6 +135,16 @@ def ptr_array(tensors):
     return (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
 
 
+_raw_stream = None
+
+
 def current_stream():
+    """Raw handle of torch's current stream on the current device.  (`torch.cuda.current_stream().cuda_stream` builds
+    a Stream object per call: ~15 us, a dozen times per step; the raw query is ~0.3 us.)"""
+    global _raw_stream
     import torch
+    if _raw_stream is None:
+        _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", False)
+    if _raw_stream:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream

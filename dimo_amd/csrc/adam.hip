@@ -134,7 +134,9 @@ extern "C" int dimo_flat_adam_step(int64_t n, float *params, float *grads, float
       (range_end != n && (range_end & 3)))
     return DIMO_E_ARG;
   long long blocks = ((range_end - range_begin) / 4 + 255) / 256;
-  if (blocks > 2048) blocks = 2048;
+  // (the early part of a two-launch step runs on a private stream next to the TimeNet backward: it leaves room)
+  const long long cap = final_part || (range_begin == 0 && range_end == n) ? 2048 : 768;
+  if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
   ScopedTimer tm(T_ADAM, stream);
   hipLaunchKernelGGL(flat_adam_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (long long)range_end, params, grads,

@@ -440,39 +440,48 @@ __global__ void __launch_bounds__(256) accumulate_batched_kernel(int N, int n_re
                                                                  float *g_c_xyz, float *g_c_lr,
                                                                  const float *stage_end, size_t stage_stride,
                                                                  int first_abs) {
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   // segments: [0,3N) xyz | [3N,7N) rotation | [7N,10N) scaling | [10N,11N) opacity | [11N,14N) f_dc
   const size_t n = (size_t)N;
-  if (i >= 14 * n) {
-    const size_t j = i - 14 * n;
-    if (!stage_end || j >= 4 * (size_t)M) return;
-    const int m = (int)(j >> 2), cc = (int)(j & 3);
-    float *dst = cc < 3 ? g_c_xyz + 3 * m + cc : g_c_lr + m;
-    float s = *dst;
-    for (int q = 0; q < b.n_groups; ++q)
-      s += (stage_end - (size_t)(first_abs + (int)b.leader[q] + 1) * stage_stride)[j];
-    *dst = s;
-    return;
-  }
-  float *dst;
-  size_t k;
-  int which;
-  if (i < 3 * n) dst = g_xyz, k = i, which = 0;
-  else if (i < 7 * n) dst = g_rotation, k = i - 3 * n, which = 1;
-  else if (i < 10 * n) dst = g_scaling, k = i - 7 * n, which = 2;
-  else if (i < 11 * n) dst = g_opacity, k = i - 10 * n, which = 3;
-  else dst = g_f_dc, k = i - 11 * n, which = 4;
-  float s = dst[k];
+  const size_t total = 14 * n + (stage_end ? 4 * (size_t)M : 0);
   unsigned leaders = 0;
   for (int q = 0; q < b.n_groups; ++q) leaders |= 1u << b.leader[q];
-  for (int r = 0; r < n_renders; ++r) {
-    if (which != 4 && !((leaders >> r) & 1u)) continue;
-    const dimo_render_desc &d = b.r[r];
-    const float *src = which == 0 ? d.g_means3D : which == 1 ? d.g_rot : which == 2 ? d.g_scales
-                       : which == 3 ? d.g_opac : d.g_shs;
-    s += src[k];
+  // (grid-stride over a capped grid: in the training step this runs on a private stream next to the TimeNet backward,
+  // whose one-per-CU workgroups of 16 waves must find room)
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    if (i >= 14 * n) {
+      const size_t j = i - 14 * n;
+      const int m = (int)(j >> 2), cc = (int)(j & 3);
+      float *dst = cc < 3 ? g_c_xyz + 3 * m + cc : g_c_lr + m;
+      float s = *dst;
+      for (int q = 0; q < b.n_groups; ++q)
+        s += (stage_end - (size_t)(first_abs + (int)b.leader[q] + 1) * stage_stride)[j];
+      *dst = s;
+      continue;
+    }
+    float *dst;
+    size_t k;
+    int which;
+    if (i < 3 * n) dst = g_xyz, k = i, which = 0;
+    else if (i < 7 * n) dst = g_rotation, k = i - 3 * n, which = 1;
+    else if (i < 10 * n) dst = g_scaling, k = i - 7 * n, which = 2;
+    else if (i < 11 * n) dst = g_opacity, k = i - 10 * n, which = 3;
+    else dst = g_f_dc, k = i - 11 * n, which = 4;
+    float s = dst[k];
+    for (int r = 0; r < n_renders; ++r) {
+      if (which != 4 && !((leaders >> r) & 1u)) continue;
+      const dimo_render_desc &d = b.r[r];
+      const float *src = which == 0 ? d.g_means3D : which == 1 ? d.g_rot : which == 2 ? d.g_scales
+                         : which == 3 ? d.g_opac : d.g_shs;
+      s += src[k];
+    }
+    dst[k] = s;
   }
-  dst[k] = s;
+}
+
+// at most four workgroups of four waves per CU (see accumulate_batched_kernel)
+static unsigned acc_grid(size_t total) {
+  const size_t want = (total + 255) / 256;
+  return (unsigned)(want < 1 ? 1 : (want > 1024 ? 1024 : want));
 }
 
 // sums the per-workgroup partial tables in a fixed order and scatters into the four gradient tensors
@@ -687,7 +696,7 @@ int lbs_backward_batched(const dimo_step_common &c, const RenderBatch &b, int n,
     hipLaunchKernelGGL(s1_bwd_batched_kernel, dim3((c.N + 255) / 256, b.n_groups), dim3(256), 0, stream, c.N,
                        c.rotation, c.opacity, c.log_r, c.g_log_r, b);
     const size_t total = 14 * (size_t)c.N;
-    hipLaunchKernelGGL(accumulate_batched_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, c.N, n,
+    hipLaunchKernelGGL(accumulate_batched_kernel, dim3(acc_grid(total)), dim3(256), 0, stream, c.N, n,
                        b, c.g_xyz, c.g_rotation, c.g_scaling, c.g_opacity, c.g_f_dc, 0, (float *)nullptr,
                        (float *)nullptr, (const float *)nullptr, (size_t)0, 0);
     return check_launch();
@@ -700,7 +709,7 @@ int lbs_backward_batched(const dimo_step_common &c, const RenderBatch &b, int n,
   if (phase == 2) {
     const size_t total = 14 * (size_t)c.N + 4 * (size_t)c.M;
     ScopedTimer tm(T_DEFORM_BWD, stream);
-    hipLaunchKernelGGL(accumulate_batched_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, c.N, n, b,
+    hipLaunchKernelGGL(accumulate_batched_kernel, dim3(acc_grid(total)), dim3(256), 0, stream, c.N, n, b,
                        c.g_xyz, c.g_rotation, c.g_scaling, c.g_opacity, c.g_f_dc, c.M, c.g_c_xyz, c.g_c_log_radius,
                        (const float *)stage_end, stage_stride, first_abs);
     return check_launch();
@@ -727,7 +736,7 @@ int lbs_backward_batched(const dimo_step_common &c, const RenderBatch &b, int n,
                      partials, c.g_c_xyz, c.g_c_log_radius, b, stage_end, stage_stride, first_abs);
   if (phase == 1) return check_launch();
   const size_t total = 14 * (size_t)c.N;
-  hipLaunchKernelGGL(accumulate_batched_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, c.N, n, b,
+  hipLaunchKernelGGL(accumulate_batched_kernel, dim3(acc_grid(total)), dim3(256), 0, stream, c.N, n, b,
                      c.g_xyz, c.g_rotation, c.g_scaling, c.g_opacity, c.g_f_dc, 0, (float *)nullptr, (float *)nullptr,
                      (const float *)nullptr, (size_t)0, 0);
   return check_launch();

@@ -37,14 +37,13 @@ __device__ __forceinline__ void knn4_insert(double &b0, double &b1, double &b2, 
   b2 = fmin(b2, r1);
   b3 = fmin(b3, r2);
 }
-__global__ void __launch_bounds__(KNN_BLOCK *KNN4_WAVES) knn4_kernel(int M, int N, int k, const float *__restrict__ ref,
-                                                                      const float *__restrict__ query,
-                                                                      float *__restrict__ dist, int64_t *__restrict__ idx,
-                                                                      const int64_t *__restrict__ seed) {
-  __shared__ float4 s_ref[KNN_CHUNK];
-  __shared__ double s_best[KNN4_WAVES][4][KNN_BLOCK];
+// One block of KNN_BLOCK queries by the workgroup's KNN4_WAVES waves (each scans a share of the candidates).
+__device__ __forceinline__ void knn4_block(int blk, int M, int N, int k, const float *__restrict__ ref,
+                                           const float *__restrict__ query, float *__restrict__ dist,
+                                           int64_t *__restrict__ idx, const int64_t *__restrict__ seed,
+                                           float4 *s_ref, double (*s_best)[4][KNN_BLOCK]) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int i = blockIdx.x * KNN_BLOCK + lane;
+  const int i = blk * KNN_BLOCK + lane;
   float qx = 0, qy = 0, qz = 0;
   if (i < N) qx = query[3 * i], qy = query[3 * i + 1], qz = query[3 * i + 2];
   const double empty = __longlong_as_double((long long)(((unsigned long long)__float_as_uint(INFINITY) << 32) | 0xffffffffull));
@@ -71,6 +70,41 @@ __global__ void __launch_bounds__(KNN_BLOCK *KNN4_WAVES) knn4_kernel(int M, int 
       worst = bound;
     }
   }
+  // Block bound (seeded searches).  The 64 queries of a block are Morton neighbours (densify.py: sort_spatially): with
+  // c the centre of their bounding box, r = max |q - c| and D = the largest seed bound, a candidate p with
+  // |p - c| > D + r is farther than D from EVERY query of the block (triangle inequality), so it fails every lane's
+  // `d2 <= worst` test below and can be skipped without evaluating it 64 times.  Each wave filters its share of the
+  // candidates with one distance per lane and walks the survivors (a few per cent of the 512 control points); the
+  // survivors are evaluated exactly as before, so distances and indices stay bit-exact.  Any non-finite query or
+  // missing bound in the block switches the filter off for the block.
+  float cx = 0.f, cy = 0.f, cz = 0.f, T2 = INFINITY;
+  bool prune = false;
+  {
+    const bool live = i < N;
+    const bool ok = !live || (worst < INFINITY && fabsf(qx) < INFINITY && fabsf(qy) < INFINITY && fabsf(qz) < INFINITY);
+    if (seed && __builtin_amdgcn_ballot_w64(!ok) == 0ull) {
+      float lo[3] = {live ? qx : INFINITY, live ? qy : INFINITY, live ? qz : INFINITY};
+      float hi[3] = {live ? qx : -INFINITY, live ? qy : -INFINITY, live ? qz : -INFINITY};
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          lo[a] = fminf(lo[a], __shfl_xor(lo[a], o, 64));
+          hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], o, 64));
+        }
+      cx = 0.5f * (lo[0] + hi[0]), cy = 0.5f * (lo[1] + hi[1]), cz = 0.5f * (lo[2] + hi[2]);
+      const float ex = qx - cx, ey = qy - cy, ez = qz - cz;
+      float r2 = live ? ex * ex + ey * ey + ez * ez : 0.f, dm = live ? worst : 0.f;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        r2 = fmaxf(r2, __shfl_xor(r2, o, 64));
+        dm = fmaxf(dm, __shfl_xor(dm, o, 64));
+      }
+      const float T = (sqrtf(dm) + sqrtf(r2)) * 1.0001f + 1e-6f;  // (generous against the rounding of the filter itself)
+      T2 = T * T;
+      prune = T2 < INFINITY;  // (an empty block has lo = +inf: NaN centre, T2 stays unusable -> false)
+    }
+  }
   for (int base = 0; base < M; base += KNN_CHUNK) {
     const int cnt = min(KNN_CHUNK, M - base);
     __syncthreads();
@@ -81,6 +115,29 @@ __global__ void __launch_bounds__(KNN_BLOCK *KNN4_WAVES) knn4_kernel(int M, int 
     __syncthreads();
     const int per = (cnt + KNN4_WAVES - 1) / KNN4_WAVES;
     const int m0 = wave * per, m1 = min(cnt, m0 + per);
+    if (prune) {
+      for (int off = m0; off < m1; off += 64) {
+        bool near = false;
+        if (off + lane < m1) {
+          const float4 c = s_ref[off + lane];
+          const float fx = c.x - cx, fy = c.y - cy, fz = c.z - cz;
+          near = fx * fx + fy * fy + fz * fz <= T2;
+        }
+        unsigned long long mask = __builtin_amdgcn_ballot_w64(near);
+        while (mask) {  // wave-uniform: the survivors of this share, in index order
+          const int m = off + (int)__builtin_ctzll(mask);
+          mask &= mask - 1ull;
+          const float4 c = s_ref[m];
+          const float dx = qx - c.x, dy = qy - c.y, dz = qz - c.z;
+          const float d2 = dx * dx + dy * dy + dz * dz;
+          if (__builtin_amdgcn_ballot_w64(d2 <= worst) != 0ull) {
+            knn4_insert(b0, b1, b2, b3, __hiloint2double((int)__float_as_uint(d2), base + m));
+            worst = fminf(worst, __uint_as_float((unsigned)__double2hiint(b3)));
+          }
+        }
+      }
+      continue;
+    }
     // A candidate can enter a lane's list only if it is not farther than the lane's current bound (the seed bound,
     // then the fourth best: an equal distance with a higher index loses the key comparison inside the insert): the
     // 12-instruction f64 insert runs only when some lane of the wave needs it.  With the Gaussians in Morton order
@@ -127,6 +184,21 @@ __global__ void __launch_bounds__(KNN_BLOCK *KNN4_WAVES) knn4_kernel(int M, int 
         dist[(size_t)i * k + j] = sqrtf(__uint_as_float((unsigned)__double2hiint(b[j])));
         idx[(size_t)i * k + j] = (int64_t)(lo == -1 && __double2hiint(b[j]) == (int)__float_as_uint(INFINITY) ? -1 : lo);
       }
+  }
+}
+// Persistent workgroups over the query blocks: the grid is capped (dimo_knn_seeded) so that the search leaves room on
+// every CU -- in the training step it runs on a private stream NEXT TO the TimeNet forward, whose workgroups (16 waves,
+// 60 KB of LDS, one per CU) cannot start on a CU whose wave slots a flood of short search workgroups has taken.
+__global__ void __launch_bounds__(KNN_BLOCK *KNN4_WAVES) knn4_kernel(int M, int N, int k, const float *__restrict__ ref,
+                                                                      const float *__restrict__ query,
+                                                                      float *__restrict__ dist, int64_t *__restrict__ idx,
+                                                                      const int64_t *__restrict__ seed) {
+  __shared__ float4 s_ref[KNN_CHUNK];
+  __shared__ double s_best[KNN4_WAVES][4][KNN_BLOCK];
+  const int nblk = (N + KNN_BLOCK - 1) / KNN_BLOCK;
+  for (int blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    knn4_block(blk, M, N, k, ref, query, dist, idx, seed, s_ref, s_best);
+    __syncthreads();  // (s_best / s_ref are re-used by the next block)
   }
 }
 
@@ -432,9 +504,13 @@ extern "C" int dimo_knn_seeded(int M, int N, int k, const float *ref, const floa
   if (!query || !dist || !idx || (M > 0 && !ref)) return DIMO_E_ARG;
   const dim3 grid((N + KNN_BLOCK - 1) / KNN_BLOCK), block(KNN_BLOCK);
   ScopedTimer tm(T_KNN, stream);
-  if (k <= 4)
-    hipLaunchKernelGGL(knn4_kernel, grid, dim3(KNN_BLOCK * KNN4_WAVES), 0, stream, M, N, k, ref, query, dist, idx,
+  if (k <= 4) {
+    // at most three workgroups (12 waves) per CU: see knn4_kernel
+    static const int cap = getenv("DIMO_KNN_WGS") ? atoi(getenv("DIMO_KNN_WGS")) : 768;
+    const dim3 grid4((unsigned)((int)grid.x < cap || cap <= 0 ? (int)grid.x : cap));
+    hipLaunchKernelGGL(knn4_kernel, grid4, dim3(KNN_BLOCK * KNN4_WAVES), 0, stream, M, N, k, ref, query, dist, idx,
                        seed_idx);
+  }
   else if (k <= 8)
     hipLaunchKernelGGL(knn_kernel<8>, grid, block, 0, stream, M, N, k, ref, query, dist, idx);
   else

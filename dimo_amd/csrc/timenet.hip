@@ -660,6 +660,245 @@ __global__ __launch_bounds__(64 * NW) void timenet_fwd_fused_kernel(FusedArgs g)
   }
 }
 
+// ---- the forward on EVERY CU: 8 rows per workgroup, v_mfma_f32_4x4x1_16b_f32 --------------------------------------
+// The 16-row kernel above puts the benchmark's 2048 rows on 128 of the 256 CUs: a layer costs a workgroup 3.4 us of
+// MFMA issue (16 waves x 64 MFMAs of 32 cycles on 4 SIMDs) behind a 3.1 us weight stream, 5.8 us with its barrier.
+// 16x16x4 cannot take fewer than 16 rows; the multi-block form 4x4x1 can: 16 blocks of (4 rows x 1 k) x (1 k x 4
+// columns), i.e. with the SAME four rows in every block ONE instruction is a 4-row x 64-column x 1-k product --
+// lane l supplies A = X[l % 4][k] and B = W[column l][k] and receives, in register r, Y[row r][column l].  Measured
+// (tools/mfma4_rate.hip): 10.1-10.5 cycles per instruction with >= 8 independent accumulators per SIMD, 80 % of the
+// 16x16x4 rate per MAC, 43 cycles dependent latency.  Eight rows per workgroup = 256 workgroups for 2048 rows, half
+// the MFMA work per CU; the weight stream per CU is what it was (every workgroup reads every weight).
+//
+// Work split: 16 waves = 4 column groups of 64 x 4 K-slices.  A wave holds rows 0-3 and 4-7 of its 64 columns, two
+// accumulators each (even / odd k: 16 independent chains per SIMD); the K-slices are summed through LDS in the
+// epilogue, which also adds the bias, applies the ReLU and writes the next layer's input tile.
+// Packed weights for this kernel ("quads"): quad (cg, kq) = 64 lanes x float4 { W[64 cg + lane][seg + 4 kq .. + 3] },
+// at float4 index (cg * nkq + kq) * 64 + lane -- one contiguous KiB per wave load, as before.
+constexpr int R8 = 8;             // rows per workgroup
+constexpr int QF = 8;             // quads in flight per wave (ring depth; 16 waves: 128 KB in flight per CU -- with 4,
+                                  // the stream ran dry under every layer's epilogue: 54 us against ...)
+constexpr int SUB = 2 * QF;       // quads per sub-chunk: every ring slot is refilled TWICE per loop body, so the body
+                                  // ends with the ring in the registers it started in (one refill: 16 register moves
+                                  // at the back edge, each waiting for its load)
+constexpr int KSE = 2;            // K-slices of the embedding segment: its 32 quads are two sub-chunks, taken by the
+                                  // K-slices 0 and 1 of every column group (the four K-slices of a column group share
+                                  // a SIMD, so the SIMDs stay balanced)
+constexpr int EQ = FE_MAX / 4;    // k-quads of the (zero padded) embedding segment: 32
+constexpr int HQ = FW / 4;        // ... of a hidden segment: 64
+constexpr int KS = 4;             // K-slices (waves per column group)
+static_assert(EQ / KSE == SUB && HQ / KS == SUB, "a wave's embedding / hidden chunk is one sub-chunk");
+
+__global__ __launch_bounds__(256) void pack_weights_quads_kernel(PackArgs a) {
+  const PackJob &j = a.job[blockIdx.y];
+  const int nE = j.E_seg ? EQ : 0, nkq = nE + (j.H_seg ? HQ : 0);
+  const int total = (FW / 64) * nkq * 64;  // float4s
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const int lane = i & 63, q = i >> 6;
+    const int kq = q % nkq, cg = q / nkq;
+    const bool emb = kq < nE;
+    const int kseg = 4 * (emb ? kq : kq - nE);
+    const int seg0 = emb ? 0 : j.E_seg, seglen = emb ? j.E_seg : j.H_seg;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (kseg + 3 < seglen) v = *reinterpret_cast<const float4 *>(j.W + (size_t)(cg * 64 + lane) * j.ldw + seg0 + kseg);
+    reinterpret_cast<float4 *>(j.out)[i] = v;
+  }
+}
+
+struct Wave4 {
+  const float4 *e, *h;  // this lane's float4 of the first quad of the wave's embedding / hidden chunk
+  bool has_e, has_h;    // (wave-uniform: the chunks are taken or skipped by scalar branches)
+};
+__device__ __forceinline__ Wave4 wave4(const float *packed, bool use_embed, bool use_hidden, int cg, int ks, int lane) {
+  const int nE = use_embed ? EQ : 0, nkq = nE + (use_hidden ? HQ : 0);
+  const float4 *base = reinterpret_cast<const float4 *>(packed) + (size_t)cg * nkq * 64 + lane;
+  Wave4 w;
+  w.has_e = use_embed && ks < KSE, w.has_h = use_hidden;
+  w.e = base + (size_t)((ks & (KSE - 1)) * (EQ / KSE)) * 64;
+  w.h = base + (size_t)(nE + ks * (HQ / KS)) * 64;
+  return w;
+}
+__device__ __forceinline__ const float4 *first_chunk(const Wave4 &w) { return w.has_e ? w.e : w.h; }
+
+// LEN quads of one wave: acc += X[8 rows x 4 LEN k] * W^T for the wave's 64 columns.  xa = this lane's A pointer
+// (row lane % 4 of the tile, first k of the chunk), rows 4-7 are ld4 = 4 * leading dimension floats further.  The ring
+// holds the chunk's first QF quads on entry and the first QF quads of the NEXT chunk of the wave's stream (nx) on exit.
+// MODE (bisection builds, DIMO_TIMENET_BISECT): 0 = the kernel; 1 = weight stream without the MFMAs (every quad is
+// folded into the accumulators with four adds); 2 = MFMAs without the weight stream (the ring is never refilled)
+template <int LEN, int MODE = 0>
+__device__ __forceinline__ void chunk4(const float *xa, int ld4, const float4 *__restrict__ w,
+                                       const float4 *__restrict__ nx, float4 (&q)[QF], f32x4 &c0e, f32x4 &c0o,
+                                       f32x4 &c1e, f32x4 &c1o) {
+  static_assert(LEN % QF == 0, "chunks are whole rings");
+  float4 lo_n = *reinterpret_cast<const float4 *>(xa), hi_n = *reinterpret_cast<const float4 *>(xa + ld4);
+#pragma unroll
+  for (int b = 0; b < LEN; ++b) {
+    const int u = b % QF;
+    const float4 lo = lo_n, hi = hi_n;
+    if (b + 1 < LEN) {
+      lo_n = *reinterpret_cast<const float4 *>(xa + 4 * (b + 1));
+      hi_n = *reinterpret_cast<const float4 *>(xa + ld4 + 4 * (b + 1));
+    }
+    {  // a wave that is ahead yields (see fused_chunk)
+      const int q4 = (4 * b) / LEN;
+      if (q4 == 0) __builtin_amdgcn_s_setprio(3);
+      else if (q4 == 1) __builtin_amdgcn_s_setprio(2);
+      else if (q4 == 2) __builtin_amdgcn_s_setprio(1);
+      else __builtin_amdgcn_s_setprio(0);
+    }
+    const float4 p = q[u];
+    if (MODE != 2) q[u] = b + QF < LEN ? w[(b + QF) * 64] : nx[(b + QF - LEN) * 64];
+    if (MODE == 1) {
+      c0e[0] += p.x + lo.x, c0o[0] += p.y + hi.y, c1e[0] += p.z, c1o[0] += p.w;
+      continue;
+    }
+    c0e = __builtin_amdgcn_mfma_f32_4x4x1f32(lo.x, p.x, c0e, 0, 0, 0);
+    c1e = __builtin_amdgcn_mfma_f32_4x4x1f32(hi.x, p.x, c1e, 0, 0, 0);
+    c0o = __builtin_amdgcn_mfma_f32_4x4x1f32(lo.y, p.y, c0o, 0, 0, 0);
+    c1o = __builtin_amdgcn_mfma_f32_4x4x1f32(hi.y, p.y, c1o, 0, 0, 0);
+    c0e = __builtin_amdgcn_mfma_f32_4x4x1f32(lo.z, p.z, c0e, 0, 0, 0);
+    c1e = __builtin_amdgcn_mfma_f32_4x4x1f32(hi.z, p.z, c1e, 0, 0, 0);
+    c0o = __builtin_amdgcn_mfma_f32_4x4x1f32(lo.w, p.w, c0o, 0, 0, 0);
+    c1o = __builtin_amdgcn_mfma_f32_4x4x1f32(hi.w, p.w, c1o, 0, 0, 0);
+  }
+}
+
+constexpr int G_LD = FW + 4, GC_LD = FE_MAX + 4;  // leading dimensions of the 8-row LDS tiles
+
+// the wave's K-slice of a layer as SUB-CHUNKS of two rings (SUB = 2 QF quads): [embedding (K-slices 0, 1)] [hidden];
+// `nx` = the first sub-chunk of the wave's next layer.  One loop body for all of them: with a branch per chunk the compiler
+// joins the two paths with register moves of the ring -- and a move of a register whose load is in flight waits for
+// it (s_waitcnt vmcnt(0) at the end of every embedding chunk).
+template <int MODE = 0>
+__device__ __forceinline__ void matmul4(const float *s_c, const float *s_in, const Wave4 &w, const float4 *nx,
+                                        float4 (&q)[QF], f32x4 &c0e, f32x4 &c0o, f32x4 &c1e, f32x4 &c1o, int ks,
+                                        int lane) {
+  const int r = lane & 3;
+  const int first = w.has_e ? 0 : 1, last = w.has_h ? 2 : 1;  // sub-chunk ids: 0 = embedding, 1 = hidden
+  for (int sc = first; sc < last; ++sc) {
+    const float *xa = sc == 0 ? s_c + r * GC_LD + ks * (FE_MAX / KSE) : s_in + r * G_LD + ks * (FW / KS);
+    const int ld4 = sc == 0 ? 4 * GC_LD : 4 * G_LD;
+    const float4 *wq = sc == 0 ? w.e : w.h;
+    const float4 *nq = sc + 1 < last ? w.h : nx;
+    chunk4<SUB, MODE>(xa, ld4, wq, nq, q, c0e, c0o, c1e, c1o);
+  }
+}
+
+// partial sums of the wave -> LDS [ks][row][column]
+__device__ __forceinline__ void store_partials(float *s_part, const f32x4 &c0e, const f32x4 &c0o, const f32x4 &c1e,
+                                               const f32x4 &c1o, int cg, int ks, int lane) {
+  float *sp = s_part + (size_t)ks * R8 * FW + cg * 64 + lane;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) sp[r * FW] = c0e[r] + c0o[r], sp[(4 + r) * FW] = c1e[r] + c1o[r];
+}
+
+template <int MODE = 0>
+__global__ __launch_bounds__(1024) void timenet_fwd_fused8_kernel(FusedArgs g) {
+  __shared__ __attribute__((aligned(16))) float s_c[R8 * GC_LD];
+  __shared__ __attribute__((aligned(16))) float s_h[2][R8 * G_LD];
+  __shared__ __attribute__((aligned(16))) float s_part[KS * R8 * FW];
+  __shared__ float s_wo[7 * FW];
+  // every bias of the net: a global load that is waited for in a layer's epilogue drains the weight ring with it
+  // (s_waitcnt vmcnt counts in order), an LDS read does not
+  __shared__ float s_bias[(MAX_LAYERS - 2) * FW + 8];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int cg = wave & 3, ks = wave >> 2;  // (the four K-slices of a column group share a SIMD)
+  const int row0 = blockIdx.x * R8;
+  for (int e = t; e < 7 * FW; e += 1024) s_wo[e] = e < 3 * FW ? g.W[g.D + 1][e] : g.W[g.D + 3][e - 3 * FW];
+  for (int e = t; e < (g.D + 2) * FW; e += 1024) {
+    const int st = e / FW, li = st >= g.D ? g.D + 2 * (st - g.D) : st;
+    s_bias[e] = g.b[li][e & (FW - 1)];
+  }
+  if (t < 7) s_bias[(MAX_LAYERS - 2) * FW + t] = t < 3 ? g.b[g.D + 1][t] : g.b[g.D + 3][t - 3];
+  float4 q[QF];
+  Wave4 w = wave4(g.Wp[0], true, false, cg, ks, lane);
+  {
+    // the ring starts with the first quads of the wave's FIRST chunk: layer 0 has only the embedding segment, which
+    // the K-slices >= KSE do not take -- their first chunk is layer 1's
+    const float4 *f = w.has_e ? w.e : first_chunk(wave4(g.Wp[1], 0 == g.skip, true, cg, ks, lane));
+#pragma unroll
+    for (int u = 0; u < QF; ++u) q[u] = f[u * 64];  // in flight under the embedding
+  }
+  const int npts = 6 * g.pts_freqs, ntime = 2 * g.time_freqs;
+  {  // embedding of the 8 rows (the arithmetic of embed_kernel): one element per thread
+    const int m = t / FE_MAX, col = t % FE_MAX;
+    const int row = min(row0 + m, g.R - 1);
+    const int p = row / g.Mc, cp = row % g.Mc;
+    float v = 0.f;
+    if (col < npts) {
+      const int f = col / 6, wd = col % 6;
+      const float x = g.c_xyz[cp * 3 + (wd % 3)] * exp2f((float)f);
+      v = wd < 3 ? sinf(x) : cosf(x);
+    } else if (col < npts + ntime) {
+      const int c = col - npts, f = c >> 1;
+      const float x = g.pt.time[p] * exp2f((float)f);
+      v = (c & 1) ? cosf(x) : sinf(x);
+    } else if (col < g.E) {
+      v = g.latent_table[(size_t)g.pt.latent_row[p] * g.latent_dim + (col - npts - ntime)];
+    }
+    s_c[m * GC_LD + col] = v;
+    if (col < g.E && row0 + m < g.R) g.cat[(size_t)(row0 + m) * g.CAT + col] = v;
+  }
+  __syncthreads();
+  int cur = 0;
+  for (int step = 0; step < g.D + 2; ++step) {
+    const bool head = step >= g.D;
+    const int li = head ? g.D + 2 * (step - g.D) : step;
+    f32x4 c0e = {0.f, 0.f, 0.f, 0.f}, c0o = c0e, c1e = c0e, c1o = c0e;
+    Wave4 wn = w;  // (after the last layer the ring refills with repeats of its own quads)
+    if (step + 1 < g.D + 2) {
+      const int ns = step + 1, nli = ns >= g.D ? g.D + 2 * (ns - g.D) : ns;
+      wn = wave4(g.Wp[nli], ns < g.D && ns - 1 == g.skip, true, cg, ks, lane);
+    }
+    matmul4<MODE>(s_c, s_h[cur], w, first_chunk(wn), q, c0e, c0o, c1e, c1o, ks, lane);
+    w = wn;
+    store_partials(s_part, c0e, c0o, c1e, c1o, cg, ks, lane);
+    lds_barrier();
+    float *s_out = s_h[cur ^ 1];
+    float *gout = head ? (step == g.D ? g.hp : g.hr) : g.act[li];
+    const int ld_out = head ? FW : g.act_ld[li];
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2) {
+      // (this thread's two outputs: row t / 256 and four rows further, column t % 256)
+      const int e = t + 1024 * h2, row = e / FW, col = e & (FW - 1);
+      float v = s_bias[step * FW + col];
+#pragma unroll
+      for (int k = 0; k < KS; ++k) v += s_part[k * R8 * FW + e];
+      v = fmaxf(v, 0.f);
+      s_out[row * G_LD + col] = v;
+      if (row0 + row < g.R) gout[(size_t)(row0 + row) * ld_out + col] = v;
+    }
+    lds_barrier();
+    if (!head) {
+      cur ^= 1;
+      continue;
+    }
+    // head output columns (3 / 4): a wave per row, the arithmetic of head_out_kernel
+    const int hd = step - g.D;
+    const float *Wo = s_wo + (hd ? 3 * FW : 0), *bo = s_bias + (MAX_LAYERS - 2) * FW + (hd ? 3 : 0);
+    const int nout = hd ? 4 : 3;
+    if (wave < R8) {
+      const int m = wave;
+      const float *x = s_out + m * G_LD;
+      float a[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int c = lane; c < FW; c += 64) {
+        const float xv = x[c];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (i < nout) a[i] = fmaf(xv, Wo[i * FW + c], a[i]);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (i < nout) a[i] = wave_sum(a[i]);
+      if (lane == 0 && row0 + m < g.R) {
+        float *dst = hd ? g.d_rot + (size_t)(row0 + m) * 4 : g.d_xyz + (size_t)(row0 + m) * 3;
+        for (int i = 0; i < nout; ++i) dst[i] = a[i] + bo[i];
+      }
+    }
+    lds_barrier();  // s_h[cur ^ 1] is overwritten by the second head
+  }
+}
+
 // ---- the dgrad chain in ONE launch (same shape class) ------------------------------------------------------------
 // Mirrors the forward: a workgroup owns 16 rows; dZ of the layer above stays in LDS (and goes to the workspace for the
 // weight gradients), the TRANSPOSED weights stream through the same register ring.  Sequence of matmuls per workgroup
@@ -817,6 +1056,153 @@ __global__ __launch_bounds__(512) void timenet_bwd_fused_kernel(FusedBwdArgs g) 
   }
 }
 
+// ---- the dgrad chain with 8 rows per workgroup (4x4x1 MFMA, see timenet_fwd_fused8_kernel) ------------------------
+// Same matmul sequence as timenet_bwd_fused_kernel; what differs:
+//   * the ReLU masks of EVERY layer of the workgroup's 8 rows are fetched once, at the start, and kept as bits in LDS
+//     (2.5 KB): a mask fetched per layer is a global load that the epilogue has to wait for, and on gfx9 that wait
+//     (s_waitcnt vmcnt counts in order) drains the weight ring with it;
+//   * the two embedding-gradient products (dZ[skip+1] W_{skip+1}[:, :E] and dZ[0] W_0) are ONE product over the
+//     concatenated contraction at the very end -- 2 column groups x 8 K-slices = all 16 waves with a whole sub-chunk
+//     each -- for which dZ[skip+1] stays in a fourth LDS tile.
+// Transposed quads: quad (cg, kq) = 64 lanes x float4 { W[4 kq + i][col0 + 64 cg + lane] }, i = 0..3 (zero past
+// `ncols`), at float4 index (cg * 64 + kq) * 64 + lane.
+__global__ __launch_bounds__(256) void pack_weights_t_quads_kernel(PackTArgs a) {
+  const PackTJob &j = a.job[blockIdx.y];
+  const int total = j.ntiles * HQ * 64;  // float4s; ntiles = column groups of 64 here
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const int lane = i & 63, qd = i >> 6;
+    const int kq = qd % HQ, cg = qd / HQ;
+    const int col = 64 * cg + lane, row = 4 * kq;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (col < j.ncols) {
+      const float *p = j.W + (size_t)row * j.ldw + j.col0 + col;
+      v = make_float4(p[0], p[j.ldw], p[2 * (size_t)j.ldw], p[3 * (size_t)j.ldw]);
+    }
+    reinterpret_cast<float4 *>(j.out)[i] = v;
+  }
+}
+
+__global__ __launch_bounds__(1024) void timenet_bwd_fused8_kernel(FusedBwdArgs g) {
+  __shared__ __attribute__((aligned(16))) float s_d[4][R8 * G_LD];
+  __shared__ __attribute__((aligned(16))) float s_part[KS * R8 * FW];
+  __shared__ unsigned long long s_mask[MAX_LAYERS * R8 * (FW / 64)];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int cg = wave & 3, ks = wave >> 2;
+  const int row0 = blockIdx.x * R8;
+  // this lane's float4 of the first quad of the wave's sub-chunk in a packed transposed matrix (4 column groups)
+  auto hq = [&](const float *packed) {
+    return reinterpret_cast<const float4 *>(packed) + ((size_t)cg * HQ + ks * SUB) * 64 + lane;
+  };
+  // ... and for the final embedding-gradient product: 2 column groups x 8 K-slices (4 per contracted matrix)
+  const int cg2 = wave & 1, ks8 = wave >> 1;
+  auto eq = [&](const float *packed) {
+    return reinterpret_cast<const float4 *>(packed) + ((size_t)cg2 * HQ + (ks8 & 3) * SUB) * 64 + lane;
+  };
+  float4 q[QF];
+  {
+    const float4 *f = hq(g.Tp[g.D]);
+#pragma unroll
+    for (int u = 0; u < QF; ++u) q[u] = f[u * 64];
+  }
+  // ReLU masks of the 8 rows, every layer: a wave covers 64 consecutive columns of one row per round
+  for (int m = 0; m < g.D; ++m) {
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2) {
+      const int e = t + 1024 * h2, row = e / FW, col = e & (FW - 1);
+      const float v = g.mask[m][(size_t)min(row0 + row, g.R - 1) * g.ld[m] + col];
+      const unsigned long long bal = __ballot(v > 0.f);
+      if (lane == 0) s_mask[(m * R8 + row) * (FW / 64) + (col >> 6)] = bal;
+    }
+  }
+  // dZp = (g_d_xyz Wp1) * (hp > 0), dZr = (g_d_rot Wr1) * (hr > 0)   (head_out_bwd_kernel's arithmetic)
+#pragma unroll
+  for (int h2 = 0; h2 < 2; ++h2) {
+    const int e = t + 1024 * h2, m = e / FW, c = e & (FW - 1);
+    const int row = min(row0 + m, g.R - 1);
+    float vp = 0.f, vr = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) vp = fmaf(g.g_d_xyz[row * 3 + i], g.Wp1[i * FW + c], vp);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) vr = fmaf(g.g_d_rot[row * 4 + i], g.Wr1[i * FW + c], vr);
+    vp = g.hp[(size_t)row * FW + c] > 0.f ? vp : 0.f;
+    vr = g.hr[(size_t)row * FW + c] > 0.f ? vr : 0.f;
+    s_d[0][m * G_LD + c] = vp;
+    s_d[1][m * G_LD + c] = vr;
+    if (row0 + m < g.R) g.dzp[(size_t)(row0 + m) * FW + c] = vp, g.dzr[(size_t)(row0 + m) * FW + c] = vr;
+  }
+  __syncthreads();
+
+  // the wave's K-slice of up to two products into the same accumulators (sub-chunks of one loop body: matmul4)
+  auto mm = [&](int nsub, const float *t0, const float4 *w0, const float *t1, const float4 *w1, const float4 *nx,
+                f32x4 &c0e, f32x4 &c0o, f32x4 &c1e, f32x4 &c1o) {
+    for (int sc = 0; sc < nsub; ++sc) {
+      const float *xa = (sc == 0 ? t0 : t1) + (lane & 3) * G_LD + ks * (FW / KS);
+      const float4 *wq = sc == 0 ? w0 : w1;
+      const float4 *nq = sc + 1 < nsub ? w1 : nx;
+      chunk4<SUB>(xa, 4 * G_LD, wq, nq, q, c0e, c0o, c1e, c1o);
+    }
+  };
+  // K-slices summed through LDS, ReLU mask of layer `ml` applied, -> LDS tile + workspace; `keep`: this step's INPUT
+  // tile is copied to tile 3 (dZ of the layer that read the embedding, for the product at the end)
+  auto epilogue = [&](const f32x4 &c0e, const f32x4 &c0o, const f32x4 &c1e, const f32x4 &c1o, int ml, float *s_out,
+                      const float *keep) {
+    store_partials(s_part, c0e, c0o, c1e, c1o, cg, ks, lane);
+    lds_barrier();
+    float *gout = g.dz[ml];
+    const int ld_out = g.ld[ml];
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2) {
+      const int e = t + 1024 * h2, row = e / FW, col = e & (FW - 1);
+      float v = 0.f;
+#pragma unroll
+      for (int k = 0; k < KS; ++k) v += s_part[k * R8 * FW + e];
+      const unsigned long long bits = s_mask[(ml * R8 + row) * (FW / 64) + (col >> 6)];
+      v = ((bits >> (col & 63)) & 1ull) ? v : 0.f;
+      s_out[row * G_LD + col] = v;
+      if (row0 + row < g.R) gout[(size_t)(row0 + row) * ld_out + col] = v;
+      if (keep) s_d[3][row * G_LD + col] = keep[row * G_LD + col];
+    }
+    lds_barrier();
+  };
+
+  int cur;
+  {  // head: dZ[D-1] = (dZp Wp0 + dZr Wr0) * (h[D-1] > 0)
+    f32x4 c0e = {0.f, 0.f, 0.f, 0.f}, c0o = c0e, c1e = c0e, c1o = c0e;
+    mm(2, s_d[0], hq(g.Tp[g.D]), s_d[1], hq(g.Tp[g.D + 2]), hq(g.Tp[g.D - 1]), c0e, c0o, c1e, c1o);
+    epilogue(c0e, c0o, c1e, c1o, g.D - 1, s_d[2], nullptr);
+    cur = 2;
+  }
+  // what the ring runs on into after layer 1: the wave's chunk of the final product (any valid quads for a wave that
+  // takes no part in it)
+  const bool from_skip = ks8 < 4;  // K-slices 0-3 contract dZ[skip+1], 4-7 dZ[0]
+  const bool takes_part = !(from_skip && g.skip < 0);
+  const float4 *final_w = eq(from_skip && g.skip >= 0 ? g.TpE[g.skip + 1] : g.TpE[0]);
+  for (int l = g.D - 1; l >= 1; --l) {  // dZ[l-1] = (dZ[l] W_l[:, hidden columns]) * (h[l-1] > 0)
+    f32x4 c0e = {0.f, 0.f, 0.f, 0.f}, c0o = c0e, c1e = c0e, c1o = c0e;
+    const float4 *nx = l > 1 ? hq(g.Tp[l - 1]) : final_w;
+    mm(1, s_d[cur], hq(g.Tp[l]), s_d[cur], hq(g.Tp[l]), nx, c0e, c0o, c1e, c1o);
+    const int out = (cur + 1) % 3;
+    epilogue(c0e, c0o, c1e, c1o, l - 1, s_d[out], l - 1 == g.skip ? s_d[cur] : nullptr);
+    cur = out;
+  }
+  {  // gE = [dZ[skip+1] | dZ[0]] [W_{skip+1}[:, :E] ; W_0]: 2 column groups x 8 K-slices; leaves the chip once
+    f32x4 c0e = {0.f, 0.f, 0.f, 0.f}, c0o = c0e, c1e = c0e, c1o = c0e;
+    if (takes_part) {
+      const float *tile = from_skip ? s_d[3] : s_d[cur];
+      chunk4<SUB>(tile + (lane & 3) * G_LD + (ks8 & 3) * (FW / KS), 4 * G_LD, final_w, final_w, q, c0e, c0o, c1e, c1o);
+    }
+    float *sp = s_part + (size_t)ks8 * R8 * FE_MAX + cg2 * 64 + lane;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sp[r * FE_MAX] = c0e[r] + c0o[r], sp[(4 + r) * FE_MAX] = c1e[r] + c1o[r];
+    lds_barrier();
+    const int row = t / FE_MAX, col = t & (FE_MAX - 1);
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v += s_part[k * R8 * FE_MAX + t];
+    if (col < g.E && row0 + row < g.R) g.g_cat[(size_t)(row0 + row) * g.CAT + col] = v;
+  }
+}
+
 // ---- host side -------------------------------------------------------------------------------------------------
 struct Plan {
   int D, Wd, skip, E, CAT, rows;
@@ -915,6 +1301,14 @@ bool fused_forward_ok(const dimo_timenet_desc *d, const Plan &pl) {
   return true;
 }
 
+// rows per workgroup of the fused kernels: DIMO_TIMENET_ROWS (both directions) or the per-direction variable, 8 or 16
+int timenet_rows(const char *var, int dflt) {
+  const char *e = getenv(var);
+  if (!e) e = getenv("DIMO_TIMENET_ROWS");
+  const int v = e ? atoi(e) : dflt;
+  return v == 8 || v == 16 ? v : dflt;
+}
+
 bool fill_pairs(int P, const float *times, const int *rows, PairTable &pt) {
   if (P > MAX_PAIRS) return false;
   for (int p = 0; p < P; ++p) pt.time[p] = times[p], pt.latent_row[p] = rows ? rows[p] : p;
@@ -964,6 +1358,18 @@ extern "C" int dimo_timenet_forward(const dimo_timenet_desc *d, int P, int M, co
       j.W = d->weight[l], j.out = ws + pl.packed[l], j.E_seg = use_embed ? pl.E : 0, j.H_seg = use_hidden ? FW : 0;
       j.ldw = j.E_seg + j.H_seg, j.nkb = pl.nkb[l];
       g.Wp[l] = ws + pl.packed[l];
+    }
+    // 16 rows per workgroup (128 of the 256 CUs for the benchmark's 2048 rows) by default: alone on the device the
+    // 8-row kernel is faster (55 against 69 us), but in the training step the forward runs NEXT TO the step's KNN, which
+    // takes the other half of the chip: 77 us against 84 (both kernels in flight).  DIMO_TIMENET_ROWS_FWD=8 selects it.
+    static const bool rows8 = timenet_rows("DIMO_TIMENET_ROWS_FWD", 16) == 8;
+    if (rows8) {
+      pack_weights_quads_kernel<<<dim3(16, pa.njobs), 256, 0, s>>>(pa);
+      static const int bisect = getenv("DIMO_TIMENET_BISECT") ? atoi(getenv("DIMO_TIMENET_BISECT")) : 0;
+      if (bisect == 1) timenet_fwd_fused8_kernel<1><<<(R + R8 - 1) / R8, 1024, 0, s>>>(g);
+      else if (bisect == 2) timenet_fwd_fused8_kernel<2><<<(R + R8 - 1) / R8, 1024, 0, s>>>(g);
+      else timenet_fwd_fused8_kernel<0><<<(R + R8 - 1) / R8, 1024, 0, s>>>(g);
+      return check_launch();
     }
     pack_weights_kernel<<<dim3(16, pa.njobs), 256, 0, s>>>(pa);
     static const bool wide = !getenv("DIMO_TIMENET_8WAVES");
@@ -1039,8 +1445,17 @@ extern "C" int dimo_timenet_backward(const dimo_timenet_desc *d, int P, int M, c
       }
     }
     for (int l = 0; l < D; ++l) g.mask[l] = ws + pl.act[l], g.dz[l] = ws + pl.dz[l], g.ld[l] = act_ld(pl, l);
-    pack_weights_t_kernel<<<dim3(16, pa.njobs), 256, 0, s>>>(pa);
-    timenet_bwd_fused_kernel<<<(R + FR - 1) / FR, 512, 0, s>>>(g);
+    // the dgrad chain: 8 rows per workgroup on every CU (4x4x1 MFMA; 103 against 115 us for the backward group, and
+    // the same in the training step, where only the optimizer's early part runs next to it); DIMO_TIMENET_ROWS_BWD=16
+    static const bool rows8 = timenet_rows("DIMO_TIMENET_ROWS_BWD", 8) == 8;
+    if (rows8) {  // column groups of 64 instead of tiles of 16
+      for (int k = 0; k < pa.njobs; ++k) pa.job[k].ntiles /= 4;
+      pack_weights_t_quads_kernel<<<dim3(16, pa.njobs), 256, 0, s>>>(pa);
+      timenet_bwd_fused8_kernel<<<(R + R8 - 1) / R8, 1024, 0, s>>>(g);
+    } else {
+      pack_weights_t_kernel<<<dim3(16, pa.njobs), 256, 0, s>>>(pa);
+      timenet_bwd_fused_kernel<<<(R + FR - 1) / FR, 512, 0, s>>>(g);
+    }
   }
   if (!fused) {
     const int n = R * Wd;
