@@ -216,7 +216,62 @@ def dropin_figures(device, num_pts, resolution, per_gpu, steps=12):
     return out
 
 
-def live_pmc(timeout=180):
+def teacher_sustained(device, num_pts, resolution, per_gpu, steps):
+    """The sustained figure on LEARNABLE targets: a hidden seeded teacher model of the same size (512 control points x
+    num_pts / 512 Gaussians, its own TimeNet weights and latents) renders the targets of 8 motions x 9 views x 21
+    frames once (resident in HBM); the benchmark's student trains on them for `steps` consecutive steps.  The noise
+    targets of the headline workload cannot be learned -- a long run on them drifts (Gaussians blow up,
+    instance counts creep) -- these can: frames/s and the PSNR on held renders before / after are reported."""
+    from dimo_amd.rasterizer import CapacityPolicy
+    from dimo_amd.renderer import Renderer
+    from dimo_amd.synth import TeacherTargets, init_synthetic_model, make_teacher
+    from dimo_amd.trainer import TrainConfig, Trainer
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import teacher_student as ts
+    motions = 8
+    cfg = TrainConfig(num_pts=num_pts, resolution=resolution, num_motions=motions, motions_per_step=per_gpu[0],
+                      views_per_step=per_gpu[1], frames_per_step=per_gpu[2])
+    cfg.progressive_resolution = resolution <= 512
+    teacher = make_teacher(device, num_cpts=cfg.num_cpts, pts_per_cpt=max(1, num_pts // cfg.num_cpts),
+                           num_motions=motions, scale="dist2")
+    t0 = time.perf_counter()
+    targets = TeacherTargets(teacher, motions, cfg.num_views, cfg.num_frames, resolution, radius=cfg.radius,
+                             fovy=cfg.fovy, elevation=cfg.elevation)
+    torch.cuda.synchronize()
+    t_targets = time.perf_counter() - t0
+    del teacher
+    rd = Renderer(sh_degree=0, white_background=True, radius=cfg.radius, num_latent_code=motions,
+                  latent_code_dim=cfg.latent_code_dim, add_normal=True, device=device,
+                  capacity=CapacityPolicy(initial=max(1 << 20, 40 * num_pts)))
+    init_synthetic_model(rd, cfg.num_pts, cfg.num_cpts, seed=0, regime="trained", num_latent=motions)
+    tr = Trainer(cfg, rd, targets=targets)
+    tr.step = 1000
+    held = [(m, v, f) for m in (0, 3, 6) for v in (0, 4) for f in (2, 11)]
+    p0 = ts.psnr(tr, held)
+    for _ in range(30):
+        tr.train_step()
+    torch.cuda.synchronize()
+    sk0 = tr.skipped_steps
+    t1 = time.perf_counter()
+    n = sum(tr.train_step() for _ in range(steps))
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t1
+    cap = rd.capacity_policy()
+    if cap is not None:
+        tr.skipped_steps += cap.poll(lag=0)
+    p1 = ts.psnr(tr, held)
+    out = {"frames_per_s": n / dt, "ms_per_step": 1e3 * dt / steps, "steps": steps, "psnr_start_end": [p0, p1],
+           "skipped_steps": tr.skipped_steps - sk0, "gaussians_start_end": [num_pts, int(rd.gaussians._xyz.shape[0])],
+           "targets": f"{motions} motions x {cfg.num_views} views x {cfg.num_frames} frames rendered by a hidden teacher "
+                      f"model ({num_pts} Gaussians) in {t_targets:.1f} s, resident in HBM",
+           "what": "the same training step as the headline on self-consistent (learnable) targets, consecutive steps "
+                   "from schedule step 1030 across the stage-s2 prune of step 2000; PSNR of 12 held renders"}
+    del tr, rd, targets
+    torch.cuda.empty_cache()
+    return out
+
+
+def live_pmc(timeout=120):
     """HBM traffic and VALU occupancy of the dominant kernel from rocprofv3 PMC counters, collected DURING this run in
     child processes: three passes over tools/pmc_probe.py (the same C3 workload), one counter set each, never combined
     with a trace -- FETCH_SIZE, WRITE_SIZE (corrected with the in-run calibration on a 1 GiB copy, as
@@ -236,6 +291,7 @@ def live_pmc(timeout=180):
     tmp = tempfile.mkdtemp(prefix="dimo_pmc_", dir="/tmp")
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     env["TMPDIR"] = "/tmp"
+    env["DIMO_XSTREAM"] = "event"  # (counter collection serialises dispatches: no stream-memory waits, see pmc_probe.py)
     sets = {"fetch": "FETCH_SIZE", "write": "WRITE_SIZE",
             "sq": "SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"}
     files = {}
@@ -244,7 +300,16 @@ def live_pmc(timeout=180):
             d = os.path.join(tmp, name)
             cmd = [exe, "--pmc", *ctrs.split(), "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable,
                    os.path.join(ROOT, "tools", "pmc_probe.py"), "--steps", "3"] + (["--no-calibration"] if name == "sq" else [])
-            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout)
+            # (its own process group: a pass that does not come back is killed WITH the workload it started)
+            proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                                    start_new_session=True)
+            try:
+                proc.wait(timeout=timeout)
+            except subprocess.TimeoutExpired:
+                import signal
+                os.killpg(proc.pid, signal.SIGKILL)
+                proc.wait()
+                return None, f"not collected: the {name} pass did not finish within {timeout} s"
             hits = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             if not hits:
                 return None, f"not collected: the {name} pass left no counter file"
@@ -310,6 +375,7 @@ def main():
     ap.add_argument("--per-gpu", default="2,2,2", help="weak scaling: motions,views,frames per GPU and step")
     ap.add_argument("--sustained-steps", type=int, default=1200,
                     help="consecutive steps of the `sustained` figure (0: skip); they cross a stage-s2 prune")
+    ap.add_argument("--no-teacher", action="store_true", help="skip the teacher-target sustained figure")
     ap.add_argument("--no-live-pmc", action="store_true",
                     help="take roofline.traffic / roofline.valu from profiles/ instead of collecting them during the run")
     ap.add_argument("--sync-exact", action="store_true", help="size sort buffers by reading R back (one sync per render)")
@@ -512,6 +578,12 @@ def main():
                      "skipped_steps": tr.skipped_steps - skipped0,
                      "what": "consecutive training steps right after the measurements above, same process and "
                              "trainer, wall clock with a barrier + device sync on both sides, max over ranks"}
+    sustained_teacher = None
+    if args.sustained_steps > 0 and world == 1 and not args.no_teacher:
+        try:
+            sustained_teacher = teacher_sustained(device, args.num_pts, args.resolution, per_gpu, args.sustained_steps)
+        except Exception as e:  # (never takes the headline down with it)
+            sustained_teacher = {"frames_per_s": None, "what": f"failed: {e!r}"}
     if rank == 0:
         P = args.resolution * args.resolution
         sched_ms, sched_n = timing["blend_bwd"]            # in the timed schedule (overlapped launches per motion)
@@ -588,7 +660,8 @@ def main():
             "skipped_steps": {"timed_region": skipped_timed, "whole_run": skipped_total},
             "allreduce_exposed_ms_per_step": (sum(ar_ms) / len(ar_ms)) if ar_ms else (0.0 if world == 1 else None),
             "roofline": {"bound": "valu", "frac_is_of": "hbm peak (as the metric asks)",
-                         "kernel": "blend_bwd_batched_kernel", "achieved": achieved,
+                         "kernel": "blend_bwd_batched_kernel<true, true> (the joint launch over the step's renders)",
+                         "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "renders_per_launch": rpl,
                          "avg_ms": bwd_ms / max(bwd_n, 1), "launches": bwd_n,
@@ -649,6 +722,7 @@ def main():
                 "backward": sum(per_launch(timing_all, k) / max(rpl_of(k), 1) for k in ("blend_bwd", "preprocess_bwd")),
                 "what": "per render of a batched launch in the timed schedule (two motions' batches share the chip)"},
             "sustained": sustained,
+            "sustained_teacher": sustained_teacher,
             "kernels_ms_per_launch": {k: (v[0] / v[1] if v[1] else None) for k, v in timing_all.items()},
             "kernels_ms_per_launch_isolated": {k: (v[0] / v[1] if v[1] else None) for k, v in timing_iso.items()},
         }

@@ -525,9 +525,11 @@ __device__ __forceinline__ void blend_bwd_item(int H, int W, int tiles_x, uint32
 // the queues filled in tile order -- the blend backward took 278 us per 8 renders, from the front 270).  Virtual
 // item v = blockIdx.x, + gridDim.x, ...: render v % n, that render's (v / n)-th item, so the renders of a batch
 // interleave.
+// `order` (DIMO_BWD_ORDER, experiments): 0 = deep, second, heads (the default described above); 1 = heads, second, deep;
+// 2 = second, deep, heads; 3 = heads, deep, second; 4 = heads and the other two classes interleaved in proportion.
 template <bool NORMAL, class VIEW>
 __device__ __forceinline__ void blend_bwd_loop(int H, int W, int tiles_x, uint32_t R_cap, const float *__restrict__ bg,
-                                               int n, VIEW view) {
+                                               int n, VIEW view, uint32_t order = 0) {
   __shared__ float4 s_geo[BUCKET];
   __shared__ float4 s_col[BUCKET];
   __shared__ float4 s_aux[BUCKET];
@@ -545,7 +547,28 @@ __device__ __forceinline__ void blend_bwd_loop(int H, int W, int tiles_x, uint32
     const BwdView r = view((int)(v % (uint32_t)n));
     const uint32_t local = v / (uint32_t)n, c0 = r.work[0], c1 = r.work[1], c2 = r.work[2];
     if (local >= c0 + c1 + c2) continue;
-    const uint32_t slot = local < c2 ? 2u * T + local : (local < c2 + c1 ? T + (local - c2) : local - c2 - c1);
+    uint32_t slot;
+    if (order == 0) {
+      slot = local < c2 ? 2u * T + local : (local < c2 + c1 ? T + (local - c2) : local - c2 - c1);
+    } else if (order == 1) {
+      slot = local < c0 ? local : (local < c0 + c1 ? T + (local - c0) : 2u * T + (local - c0 - c1));
+    } else if (order == 2) {
+      slot = local < c1 ? T + local : (local < c1 + c2 ? 2u * T + (local - c1) : local - c1 - c2);
+    } else if (order == 3) {
+      slot = local < c0 ? local : (local < c0 + c2 ? 2u * T + (local - c0) : T + (local - c0 - c2));
+    } else {
+      // Bresenham merge of the heads with (deep, second): position `local` takes a head when the running share of
+      // heads steps up there
+      const uint32_t tot = c0 + c1 + c2;
+      const uint32_t ha = (uint32_t)(((unsigned long long)local * c0) / tot);
+      const uint32_t hb = (uint32_t)(((unsigned long long)(local + 1) * c0) / tot);
+      if (hb > ha) {
+        slot = ha;
+      } else {
+        const uint32_t o = local - ha;  // index among the others: deep first, then second
+        slot = o < c2 ? 2u * T + o : T + (o - c2);
+      }
+    }
     const uint4 it = reinterpret_cast<const uint4 *>(r.work)[1 + slot];
     blend_bwd_item<NORMAL>(H, W, tiles_x, R_cap, bg, r, it, s_geo, s_col, s_aux, s_nz, s_mask, s_acc,
                            (int)(v % (uint32_t)n));
@@ -571,6 +594,14 @@ template <bool NORMAL>
 __global__ void __launch_bounds__(64, BWD_WAVES_PER_SIMD) blend_bwd_kernel(int H, int W, int tiles_x, uint32_t R_cap,
                                                                             const float *__restrict__ bg, SingleView sv) {
   blend_bwd_loop<NORMAL>(H, W, tiles_x, R_cap, bg, 1, sv);
+}
+static uint32_t bwd_order() {
+  static const int v = getenv("DIMO_BWD_ORDER") ? atoi(getenv("DIMO_BWD_ORDER")) : 0;
+  return (uint32_t)(v >= 0 && v <= 4 ? v : 0);
+}
+static unsigned bwd_grid() {
+  static const int v = getenv("DIMO_BWD_GRID") ? atoi(getenv("DIMO_BWD_GRID")) : BWD_GRID;
+  return (unsigned)(v >= 256 && v <= (1 << 20) ? v : BWD_GRID);
 }
 
 // Batched entry points (native step executor): blockIdx.y = render of the batch (forward); the backward interleaves
@@ -611,13 +642,17 @@ struct BatchView {
                    at<uint8_t>(r.bwd_scratch, o.flag), r.g_dot};
   }
 };
-template <bool NORMAL>
+// JOINT only names the launch (no code depends on it): the joint launch over ALL the step's renders on the caller's
+// stream -- the launch bench.py takes its roofline clock on, alone on the device -- appears in a kernel trace as
+// blend_bwd_batched_kernel<.., true>, apart from the per-motion launches of the default schedule (<.., false>), which
+// overlap the other motion's kernels and read longer than they are.
+template <bool NORMAL, bool JOINT>
 __global__ void __launch_bounds__(64, BWD_WAVES_PER_SIMD) blend_bwd_batched_kernel(int H, int W, int tiles_x,
                                                                                     uint32_t R_cap,
                                                                                     const float *__restrict__ bg,
                                                                                     BlendOffsets o, int n,
-                                                                                    RenderBatch b) {
-  blend_bwd_loop<NORMAL>(H, W, tiles_x, R_cap, bg, n, BatchView<NORMAL>{b, o});
+                                                                                    RenderBatch b, uint32_t order) {
+  blend_bwd_loop<NORMAL>(H, W, tiles_x, R_cap, bg, n, BatchView<NORMAL>{b, o}, order);
 }
 // Buckets per backward item.  Measured on the C3 batch (4 renders, ~10^4 buckets for 4096 wave slots): 189 / 231 /
 // 245 / 273 us per launch at 1 / 2 / 3 / 4 buckets per item -- what a longer chain saves in state loads it loses
@@ -662,7 +697,7 @@ int blend_forward_batched(const dimo_step_common &c, const RenderBatch &b, int n
   return check_launch();
 }
 
-int blend_backward_batched(const dimo_step_common &c, const RenderBatch &b, int n, hipStream_t stream) {
+int blend_backward_batched(const dimo_step_common &c, const RenderBatch &b, int n, hipStream_t stream, bool joint) {
   if (n <= 0 || c.N <= 0) return DIMO_OK;
   GeomLayout G(c.N);
   BinLayout B(c.R_cap, c.H, c.W);
@@ -673,12 +708,17 @@ int blend_backward_batched(const dimo_step_common &c, const RenderBatch &b, int 
   // (the "record written" flags were cleared by the placement's fill pass of this batch's forward: binning.hip)
   ScopedTimer tm(T_BLEND_BWD, stream);
   // (the chain length is the one the forward of this batch used: bwd_chain(n) is a function of n only)
-  if (c.with_normal)
-    hipLaunchKernelGGL(blend_bwd_batched_kernel<true>, dim3(BWD_GRID), dim3(64), 0, stream, c.H, c.W, B.tiles_x, cap,
-                       c.bg, o, n, b);
-  else
-    hipLaunchKernelGGL(blend_bwd_batched_kernel<false>, dim3(BWD_GRID), dim3(64), 0, stream, c.H, c.W, B.tiles_x, cap,
-                       c.bg, o, n, b);
+#define DIMO_LAUNCH_BWD(N_, J_)                                                                                       \
+  hipLaunchKernelGGL((blend_bwd_batched_kernel<N_, J_>), dim3(bwd_grid()), dim3(64), 0, stream, c.H, c.W, B.tiles_x, \
+                     cap, c.bg, o, n, b, bwd_order())
+  if (c.with_normal) {
+    if (joint) DIMO_LAUNCH_BWD(true, true);
+    else DIMO_LAUNCH_BWD(true, false);
+  } else {
+    if (joint) DIMO_LAUNCH_BWD(false, true);
+    else DIMO_LAUNCH_BWD(false, false);
+  }
+#undef DIMO_LAUNCH_BWD
   return check_launch();
 }
 

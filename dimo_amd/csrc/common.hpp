@@ -246,7 +246,8 @@ int preprocess_forward_batched(const dimo_step_common &c, const RenderBatch &b, 
 int preprocess_backward_batched(const dimo_step_common &c, const RenderBatch &b, int n, hipStream_t stream);
 int bin_instances_batched(const dimo_step_common &c, const RenderBatch &b, int n, hipStream_t stream);
 int blend_forward_batched(const dimo_step_common &c, const RenderBatch &b, int n, hipStream_t stream);
-int blend_backward_batched(const dimo_step_common &c, const RenderBatch &b, int n, hipStream_t stream);
+int blend_backward_batched(const dimo_step_common &c, const RenderBatch &b, int n, hipStream_t stream,
+                           bool joint = false);
 
 // ---- internal (C++ linkage) entry points shared between translation units ---------------------
 int bin_instances(int N, int H, int W, int64_t R_cap, const void *geom, void *bin, hipStream_t stream);

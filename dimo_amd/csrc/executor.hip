@@ -356,12 +356,12 @@ static int batched_forward(const dimo_step_common *c, const dimo_render_desc *d,
 }
 
 static int batched_backward_raster(const dimo_step_common *c, const dimo_render_desc *d, int first, int count,
-                                   hipStream_t s) {
+                                   hipStream_t s, bool joint = false) {
   for (int i0 = first; i0 < first + count; i0 += MAX_BATCH) {
     const int m = first + count - i0 < MAX_BATCH ? first + count - i0 : MAX_BATCH;
     RenderBatch b;
     fill_batch(b, d + i0, m);
-    int rc = blend_backward_batched(*c, b, m, s);
+    int rc = blend_backward_batched(*c, b, m, s, joint);
     if (!rc) rc = preprocess_backward_batched(*c, b, m, s);
     if (rc) return rc;
   }
@@ -577,7 +577,7 @@ extern "C" int dimo_executor_backward_launch_joint(void *h, const dimo_step_comm
   std::vector<std::pair<int, int>> chunks;
   if (!plan_chunks(ex, first, count, chunks)) return DIMO_E_ARG;
   for (const auto &ch : chunks) {
-    const int rc = batched_backward_raster(c, d, ch.first, ch.second, main);
+    const int rc = batched_backward_raster(c, d, ch.first, ch.second, main, true);
     if (rc) return rc;
   }
   // (dimo_executor_backward_accumulate on the same stream follows in order: a wait on an event recorded on that very

@@ -23,6 +23,7 @@ class FlatAdam:
         self.exp_avg = torch.zeros_like(flat_params)
         self.exp_avg_sq = torch.zeros_like(flat_params)
         self.pre_step = None  # callable run before every step (GaussianModel: renders queued behind render() run first)
+        self.finals = 0    # launches that finished a step (whole bucket, or the "tail" part): they clear zero_extra
         self.launches = 0  # every step() call, applied or skipped on the device
         self.skipped_host = 0  # skipped launches the host knows of (Trainer: read back with a lag of one step)
         # the device's own count of skipped launches (two words written alternately, see adam.hip): the bias
@@ -73,6 +74,8 @@ class FlatAdam:
                 self.pre_step()
             self.launches += 1
         begin, end, final = 0, 0, 1
+        if part is None or part[0] == "tail":
+            self.finals += 1
         if part is not None:
             kind, split = part
             split = int(split)

@@ -138,10 +138,11 @@ class TeacherTargets:
         return self.images[k], self.masks[k]
 
 
-def make_teacher(device, num_cpts=48, pts_per_cpt=40, num_motions=3, seed=1234, motion_gain=1.0):
+def make_teacher(device, num_cpts=48, pts_per_cpt=40, num_motions=3, seed=1234, motion_gain=1.0, scale=0.025):
     """A hidden model of the family the schedule can reach: `num_cpts` control points in the unit ball, `pts_per_cpt`
     opaque coloured Gaussians around each (colour by position: the object has structure to match), a TimeNet whose
-    heads (N(0, 1e-2) weights, scaled by `motion_gain`) move the control points."""
+    heads (N(0, 1e-2) weights, scaled by `motion_gain`) move the control points; `scale`: the Gaussians' size
+    ("dist2": from the nearest-neighbour distances, the reference's initialisation rule)."""
     from .renderer import Renderer
     rd = Renderer(sh_degree=0, white_background=True, num_latent_code=num_motions, add_normal=True, device=device)
     n = num_cpts * pts_per_cpt
@@ -156,7 +157,10 @@ def make_teacher(device, num_cpts=48, pts_per_cpt=40, num_motions=3, seed=1234, 
         local = 0.05 * torch.randn(num_cpts, pts_per_cpt, 3, generator=tg)
         xyz = (c[:, None, :] + local).reshape(-1, 3)
         g._xyz.copy_(xyz.to(g.device))
-        g._scaling.fill_(math.log(0.025))
+        if scale == "dist2":  # the reference's initialisation rule (latent_gs_renderer.py:426-427): nearest-neighbour sized
+            g._scaling.copy_(torch.log(torch.sqrt(torch.clamp_min(g._dist2(g._xyz.detach()), 1e-7)))[:, None].repeat(1, 3))
+        else:
+            g._scaling.fill_(math.log(scale))
         g._opacity.fill_(3.0)
         col = (xyz / 0.4 * 0.5 + 0.5).clamp(0.05, 0.95)
         g._features_dc.copy_(RGB2SH(col)[:, None, :].to(g.device))

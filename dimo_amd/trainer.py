@@ -1023,6 +1023,7 @@ class Trainer:
             # stage s1 only, where they are gathered)
             self._step_overflow = tot[:, 1].max() if (tot is not None and self.stage == "s1") else None
             zero_next, self._zero_next = getattr(self, "_zero_next", None), None
+            finals_before = getattr(self.optimizer, "finals", None)
             if self.world > 1:  # the flag rides in the tail of the gradient bucket through the all-reduce
                 if tot is not None:
                     g.grad_flag.copy_(tot[:, 1].max().to(torch.float32))
@@ -1044,6 +1045,8 @@ class Trainer:
                                     part=("tail", g.flat_split))
             else:  # one rank: Adam reads the renders' (R, overflow) words directly
                 self.optimizer.step(skip_flags=tot, zero_grad=True, report=rep, zero_extra=zero_next)
+            if zero_next is not None and getattr(self.optimizer, "finals", None) == finals_before:
+                zero_next.zero_()  # (the optimizer's launch did not run -- a caller replaced `step`: clear them here)
             if cap is not None and rep is None:
                 cap.start_copy()  # the words' copy for the host (poll, next step), behind the optimizer
             self._mark("allreduce+adam")

@@ -1,5 +1,5 @@
 cd /tmp && export TMPDIR=/tmp
-rm -rf /tmp/kp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kp -o k -- python "$@" > /dev/null 2>&1
+rm -rf /tmp/kp && timeout 280 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kp -o k -- python "$@" > /dev/null 2>&1
 python - <<'PY'
 import csv, glob
 f = glob.glob("/tmp/kp/**/*kernel_stats.csv", recursive=True)[0]

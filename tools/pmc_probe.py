@@ -3,6 +3,11 @@
 import os
 import sys
 
+# rocprofv3 --pmc SERIALISES kernel dispatches: a stream that waits for a value another stream has yet to write
+# (hipStreamWaitValue32, the executor's default cross-stream dependency) then never sees its producer scheduled --
+# the counter passes run with event dependencies
+os.environ["DIMO_XSTREAM"] = "event"
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 

@@ -16,7 +16,7 @@ for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU S
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_VMEM SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_BRANCH SQ_LEVEL_WAVES SQ_BUSY_CU_CYCLES SQ_INST_LEVEL_VMEM GRBM_GUI_ACTIVE"; do
   i=$((i + 1))
   rm -rf /tmp/sq_$i
-  rocprofv3 --pmc $grp --output-format csv -d /tmp/sq_$i -o p -- python $GRAFT_REPO_ROOT/tools/pmc_probe.py --no-calibration > /tmp/sq_$i.log 2>&1
+  timeout 200 rocprofv3 --pmc $grp --output-format csv -d /tmp/sq_$i -o p -- python $GRAFT_REPO_ROOT/tools/pmc_probe.py --no-calibration > /tmp/sq_$i.log 2>&1
   f=$(find /tmp/sq_$i -name "*counter_collection.csv" | head -1)
   csvs="$csvs $f"
 done

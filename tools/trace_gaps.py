@@ -4,6 +4,15 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 iv = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows)
 # steady state = the last 5 steps, delimited by the Adam kernel that ends every step
 adam = [x for x in iv if "flat_adam" in x[2]]
+# (a step may take its optimizer update as two launches -- the per-Gaussian head early, the tail at the end: launches
+# less than 0.4 ms apart belong to one step, whose end is the later one)
+_ends = []
+for a in adam:
+    if _ends and a[0] - _ends[-1][1] < 400_000:
+        _ends[-1] = a
+    else:
+        _ends.append(a)
+adam = _ends
 nsteps = min(5, len(adam) - 1)
 t0, t1 = adam[-1 - nsteps][1], adam[-1][1]
 iv = [x for x in iv if x[0] >= t0 and x[1] <= t1]

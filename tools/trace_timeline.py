@@ -3,6 +3,15 @@ import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 iv = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0][-40:], r["Queue_Id"]) for r in rows)
 adam = [x for x in iv if "flat_adam" in x[2]]
+# (a step may take its optimizer update as two launches -- the per-Gaussian head early, the tail at the end: launches
+# less than 0.4 ms apart belong to one step, whose end is the later one)
+_ends = []
+for a in adam:
+    if _ends and a[0] - _ends[-1][1] < 400_000:
+        _ends[-1] = a
+    else:
+        _ends.append(a)
+adam = _ends
 t0, t1 = adam[-2][1], adam[-1][1]
 step = [x for x in iv if x[0] >= t0 and x[1] <= t1]
 print("step ms", (t1 - t0) / 1e6, "kernels", len(step))
