@@ -2,10 +2,12 @@
 # passes are separate rocprofv3 runs (never combined).
 set -u
 tag=r04
+part=${1:-all}   # all | core (bench under rocprof, PMC traffic, the plain default run) | rest
 R=$GRAFT_REPO_ROOT
 out=$R/gpurun_out/profiles_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
+if [ "$part" != "rest" ]; then
 # 1. kernel stats of the bench command (default schedule + the serial roofline pass: the joint launch is
 #    blend_bwd_batched_kernel<true, true>, the per-motion launches <true, false>)
 rm -rf /tmp/p1
@@ -24,6 +26,12 @@ rm -rf /tmp/p2 /tmp/p3
 timeout 240 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/p2 -o f -- python $R/tools/pmc_probe.py > /dev/null 2>&1
 timeout 240 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/p3 -o w -- python $R/tools/pmc_probe.py > /dev/null 2>&1
 python $R/tools/pmc_summarise.py $(find /tmp/p2 -name "*counter_collection.csv" | head -1) $(find /tmp/p3 -name "*counter_collection.csv" | head -1) $out/${tag}_pmc_fetch_write.json 8
+# 8. the plain default run (everything on: drop-in figures, sustained + teacher, CPU baseline, live PMC)
+cd $R
+timeout 900 python bench.py > $out/${tag}_bench_plain.json 2> $out/${tag}_bench_plain.err
+fi
+if [ "$part" = "core" ]; then ls -la $out; exit 0; fi
+cd /tmp
 # 3. SQ counters
 timeout 600 bash $R/tools/pmc_sq.sh $tag blend_bwd_batched blend_fwd_batched ssim_fused lbs_bwd_batched preprocess_bwd image_loss level1_count_batched level1_scatter_batched bucket_sort_batched "level2_batched_kernel<false>" "level2_batched_kernel<true>" timenet_fwd_fused timenet_bwd_fused8 knn4 wgrad > $out/${tag}_sq.log 2>&1
 cd /tmp
@@ -48,6 +56,4 @@ d = json.loads(sys.stdin.read().strip().splitlines()[-1])
 print('%-44s %6.0f frames/s  %.4f ms/step' % ('$mode', d['value'], d['ms_per_step']))
 " >> $out/${tag}_schedule_modes.txt
 done
-# 8. the plain default run (everything on: drop-in figures, sustained + teacher, CPU baseline, live PMC)
-timeout 900 python bench.py > $out/${tag}_bench_plain.json 2> $out/${tag}_bench_plain.err
 ls -la $out
