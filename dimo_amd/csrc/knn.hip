@@ -394,8 +394,11 @@ __global__ void __launch_bounds__(256) d2_search_kernel(int N, D2Grid G, float *
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
     c[a] = d2_cell_axis(m, a, qp[a]);
-    const float f = qp[a] - (m.o[a] + (float)c[a] * m.cs[a]);
-    face[a] = fmaxf(0.0f, fminf(f, m.cs[a] - f) - 1e-5f * m.cs[a] * (float)m.g[a]);
+    // (origin subtracted FIRST, as the cell assignment does: o + c * cs rounds at ulp(|o|), which for a cloud far from the
+    // origin relative to its extent would eat the margin below; the margin also covers ulp(|q|) of the subtraction itself)
+    const float f = (qp[a] - m.o[a]) - (float)c[a] * m.cs[a];
+    const float margin = 1e-5f * m.cs[a] * (float)m.g[a] + 4.0f * 1.1920929e-7f * fmaxf(fabsf(qp[a]), fabsf(m.o[a]));
+    face[a] = fmaxf(0.0f, fminf(f, m.cs[a] - f) - margin);
   }
   float b0 = INFINITY, b1 = INFINITY, b2 = INFINITY;
   for (int r = 1;; ++r) {

@@ -70,7 +70,8 @@ def test_dist2_bit_exact(N):
     assert np.array_equal(out.view(np.uint32), ro.dist2(pts).view(np.uint32))
 
 
-@pytest.mark.parametrize("case", ["ball", "clusters", "plane", "line", "duplicates", "outlier"])
+@pytest.mark.parametrize("case", ["ball", "clusters", "plane", "line", "duplicates", "outlier", "far_from_origin",
+                                  "very_far_from_origin"])
 def test_dist2_grid_equals_brute_force_bit_for_bit(case):
     """dimo_dist2_grid (uniform grid, O(N): renderer/latent_gs_renderer.py:426 at the 1e5-1e6 points of a real
     initialisation) against the brute-force dimo_dist2 (itself bit-exact against the oracle above) on layouts that
@@ -91,6 +92,11 @@ def test_dist2_grid_equals_brute_force_bit_for_bit(case):
         pts[:, 0] = rng.random(N)
     elif case == "duplicates":
         pts = np.repeat(rng.random((N // 6, 3)), 6, axis=0)
+    elif case in ("far_from_origin", "very_far_from_origin"):
+        # |origin| / extent of 1e3 and 1e4: the own-cell face distance must not be computed as q - (o + c * cs), whose
+        # rounding at ulp(|o|) exceeds the ring search's safety margin there (advisor, round 3)
+        off = 1.0e3 if case == "far_from_origin" else 1.0e4
+        pts = rng.random((N, 3)) + np.array([off, -0.7 * off, 0.3 * off])
     else:
         pts = rng.random((N, 3))
         pts[17] = (1.0e4, -3.0e3, 50.0)

@@ -94,7 +94,10 @@ def _check_forward(sc, cam, bg, deg, with_normal=True, scale_mod=1.0):
     assert np.array_equal(_bits(sp[vis, 9]), _bits(o["feat"][vis, 3])), "depths differ"
     assert np.array_equal(_bits(sp[vis, 6:9]), _bits(o["feat"][vis, 0:3])), "colours differ"
     assert np.array_equal(_bits(sp[vis, 10:13]), _bits(o["feat"][vis, 4:7])), "normals differ"
-    # (the library places every instance straight into its sorted slot: there is no unsorted emission to compare)
+    # (the library places every instance straight into its sorted slot: there is no unsorted emission to compare.
+    # It stores the 32 DEPTH bits of an instance's key, not the 64-bit (tile | depth) word: `inspect_state` rebuilds the
+    # published keys from (tile ranges, depth bits) -- rasterizer.py -- so the tile half of this comparison is implied
+    # by the `ranges` comparison two lines down; the depth bits and the order are compared for real)
     assert np.array_equal(n(st["keys_sorted"])[:R].view(np.uint64), o["keys_sorted"]), "sort keys differ"
     assert np.array_equal(n(st["vals_sorted"])[:R].view(np.uint32), o["vals_sorted"]), "sorted order differs"
     assert np.array_equal(n(st["ranges"]).view(np.uint32), o["ranges"])
