@@ -228,6 +228,9 @@ struct WgradProblem {
 struct WgradArgs {
   WgradProblem p[MAX_LAYERS];
   int nprob, rows, kchunk;
+  int tiles, xcd;     // wgrad64_kernel: tiles per K chunk (1-D grid), 1 = XCD-contiguous virtual ids (DIMO_WGRAD_XCD)
+  int bisect;         // DIMO_WGRAD_BISECT (measurements): 1 no MFMAs, 2 no global loads after the first stage, 4 no
+                      // atomics, 8 no embedding backward
 };
 
 __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs g) {
@@ -244,7 +247,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs g) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) acc.c0[i] = 0.f, acc.c1[i] = 0.f;
   float bsum = 0.f;
-  if (p.vec) {
+  if (p.vec == 3) {  // (bit 0: dZ, bit 1: X may be loaded 16 bytes at a time)
     if (tn == 0)
       gemm_segment<false, false, true, true>(p.dZ, p.ld_dz, p.X, p.ld_x, p.M, p.N, m0, n0, kbeg, kend, As, Bs, acc, bsum);
     else
@@ -300,12 +303,17 @@ __global__ void embed_kernel(int P, int Mc, int E, int ld, int pts_freqs, int ti
 //   g_c_xyz[m, d]              += sum_f 2^f (g_sin cos - g_cos sin)      (sin / cos re-read from the saved embedding)
 //   g_latent_table[row(p), j]  += g_cat[(p, m), lat0 + j]
 // Each thread folds its rows first; the adds across blocks / pairs are hardware fp32 atomics.
-__global__ __launch_bounds__(256) void embed_bwd_kernel(int rows, int Mc, int ld, int pts_freqs, int lat0,
-                                                        int latent_dim, const float *__restrict__ cat,
-                                                        const float *__restrict__ g_cat, PairTable pt,
-                                                        float *__restrict__ g_c_xyz,
-                                                        float *__restrict__ g_latent_table) {
-  const int row0 = blockIdx.x * 64, t = threadIdx.x;
+struct EmbedBwdArgs {
+  int rows, Mc, ld, pts_freqs, lat0, latent_dim, nblocks;
+  const float *cat, *g_cat;
+  float *g_c_xyz, *g_latent_table;
+  int latent_row[MAX_PAIRS];
+};
+__device__ __forceinline__ void embed_bwd_body(int block, int rows, int Mc, int ld, int pts_freqs, int lat0,
+                                               int latent_dim, const float *__restrict__ cat,
+                                               const float *__restrict__ g_cat, const int *latent_row,
+                                               float *__restrict__ g_c_xyz, float *__restrict__ g_latent_table) {
+  const int row0 = block * 64, t = threadIdx.x;
   if (g_c_xyz && t < 192) {
     const int row = row0 + t / 3, d = t % 3;
     if (row < rows) {
@@ -327,12 +335,168 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(int rows, int Mc, int ld
     for (int row = first; row < min(rows, first + 8); ++row) {
       const int p = row / Mc;
       if (p != cur) {
-        if (cur >= 0) unsafeAtomicAdd(g_latent_table + (size_t)pt.latent_row[cur] * latent_dim + j, s);
+        if (cur >= 0) unsafeAtomicAdd(g_latent_table + (size_t)latent_row[cur] * latent_dim + j, s);
         cur = p, s = 0.f;
       }
       s += g_cat[(size_t)row * ld + lat0 + j];
     }
-    if (cur >= 0) unsafeAtomicAdd(g_latent_table + (size_t)pt.latent_row[cur] * latent_dim + j, s);
+    if (cur >= 0) unsafeAtomicAdd(g_latent_table + (size_t)latent_row[cur] * latent_dim + j, s);
+  }
+}
+
+__global__ __launch_bounds__(256) void embed_bwd_kernel(EmbedBwdArgs e) {
+  embed_bwd_body(blockIdx.x, e.rows, e.Mc, e.ld, e.pts_freqs, e.lat0, e.latent_dim, e.cat, e.g_cat, e.latent_row,
+                 e.g_c_xyz, e.g_latent_table);
+}
+
+// ---- the same grouped split-K problem on 64 x 64 tiles of v_mfma_f32_32x32x2_f32 ------------------------------------
+// wgrad_kernel above is bound by the LDS, not by its MFMAs: a 16 x 32 wave tile reads three operands per two 16x16x4
+// MFMAs, and with the [k][m] staging at leading dimension 65 the two 16-lane rows of a ds_read_b32 lane group overlap
+// in 15 of 16 banks (bank = dword address mod 32 for that instruction): every operand read is a 2-way conflict
+// (profiles/r04_sq_summary.txt: 46 % of the LDS cycles), ~4350 LDS cycles against 4096 MFMA cycles per CU and round of
+// stages.  Here a wave owns a 32 x 32 tile: ONE read per operand and 64-cycle MFMA, 32 consecutive dwords per lane
+// group (conflict-free at any leading dimension), the stage stored with ds_write_b128 straight from the 16-byte global
+// loads (rows of 64 floats, no padding) -- ~3070 LDS cycles against 8192 MFMA cycles for twice the flops.  Both
+// operands are k-major in memory (dZ [rows x M], X [rows x N]), so the stage is a plain copy.  Two accumulators
+// (even / odd pairs of k) keep consecutive MFMAs of a wave independent.  The split over K is chosen so that the launch
+// is ONE round of workgroups (four per CU: 32 KB of LDS each), in chunks of whole half stages.
+constexpr int W_T = 64, W_K = 64;  // tile edge (M and N), K rows per stage
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// loads this thread's share of a stage: rows k0 + t / 16 + 16 e (e < 4), columns c0 + 4 (t % 16) .. + 3 of a k-major
+// operand (element (k, c) at src[k * ld + c]).  Unconditional loads from clamped addresses; bit 4 e + j of `ok` says
+// whether element j of quad e is in range, and the others are zeroed when the stage is stored (behind the barrier: a
+// select next to the load becomes a branch around it, and every such load then waits for its own round trip).
+__device__ __forceinline__ uint32_t wload(const float *__restrict__ src, int ld, int cols, int c0, int k0, int kend,
+                                          bool vec, float4 (&v)[4]) {
+  const int t = threadIdx.x, c = c0 + 4 * (t & 15), h = t >> 4;
+  uint32_t ok = 0;
+  if (vec) {  // (workgroup-uniform) cols % 4 == 0: a quad is inside or outside as a whole
+    const int cc = min(c, cols - 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int k = k0 + h + 16 * e;
+      ok |= (c < cols && k < kend ? 0xfu : 0u) << (4 * e);
+      v[e] = *reinterpret_cast<const float4 *>(src + (size_t)min(k, kend - 1) * ld + cc);
+    }
+  } else {  // element by element (the head outputs: 3 and 4 columns)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int k = k0 + h + 16 * e;
+      const float *row = src + (size_t)min(k, kend - 1) * ld;
+      float x[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        x[j] = row[min(c + j, cols - 1)];
+        ok |= (uint32_t)(c + j < cols && k < kend) << (4 * e + j);
+      }
+      v[e] = make_float4(x[0], x[1], x[2], x[3]);
+    }
+  }
+  return ok;
+}
+__device__ __forceinline__ void wstore(float (*S)[W_T], uint32_t ok, const float4 (&v)[4]) {
+  const int t = threadIdx.x, q = 4 * (t & 15), h = t >> 4;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const uint32_t o = ok >> (4 * e);
+    *reinterpret_cast<float4 *>(&S[h + 16 * e][q]) = make_float4((o & 1u) ? v[e].x : 0.f, (o & 2u) ? v[e].y : 0.f,
+                                                                 (o & 4u) ? v[e].z : 0.f, (o & 8u) ? v[e].w : 0.f);
+  }
+}
+
+// The embedding backward rides in the same launch (its 64-row blocks are the FIRST workgroups: 32 of them at the
+// benchmark size, ten dependent rounds of loads each -- 10 us as a launch of its own behind this one).
+__global__ __launch_bounds__(256, 4) void wgrad64_kernel(WgradArgs g, EmbedBwdArgs e) {
+  __shared__ __attribute__((aligned(16))) float As[W_K][W_T], Bs[W_K][W_T];
+  // Virtual workgroup id: the launch order by default.  DIMO_WGRAD_XCD=1 remaps so that every XCD (the dispatcher
+  // places workgroup b on XCD b % 8) gets a CONTIGUOUS range of ids, i.e. the tiles of one problem and K chunk, which
+  // read the same 90 KB operand blocks four to six times over, share an L2 (bijective for any grid size).  Measured
+  // SLOWER (101.6 against 93.2 us for the backward group): the launch is not bound by operand traffic (181 MB, mostly
+  // L2 / Infinity Cache hits either way) and the contiguous ranges leave the short last K chunk and the embedding
+  // blocks on single XCDs.
+  int v = (int)blockIdx.x;
+  if (g.xcd) {
+    const int T = (int)gridDim.x, b = (int)blockIdx.x, xcd = b & 7, q = T >> 3, r = T & 7;
+    v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+  }
+  if (v < e.nblocks) {
+    if (g.bisect & 8) return;
+    embed_bwd_body(v, e.rows, e.Mc, e.ld, e.pts_freqs, e.lat0, e.latent_dim, e.cat, e.g_cat, e.latent_row, e.g_c_xyz,
+                   e.g_latent_table);
+    return;
+  }
+  const int bx = (v - e.nblocks) % g.tiles, by = (v - e.nblocks) / g.tiles;
+  int pi = 0;
+  while (pi + 1 < g.nprob && bx >= g.p[pi + 1].tile_begin) ++pi;
+  const WgradProblem &p = g.p[pi];
+  const int tile = bx - p.tile_begin;
+  const int tm = tile / p.tiles_n, tn = tile % p.tiles_n;
+  const int m0 = tm * W_T, n0 = tn * W_T;
+  const int kbeg = by * g.kchunk, kend = min(g.rows, kbeg + g.kchunk);
+  if (kbeg >= kend) return;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+  const bool vec_a = (p.vec & 1) != 0, vec_b = (p.vec & 2) != 0;
+  f32x16 acc0, acc1;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc0[i] = 0.f, acc1[i] = 0.f;
+  float bsum = 0.f;
+  const bool bias = tn == 0 && p.gbias;
+  const int nk = (kend - kbeg + W_K - 1) / W_K;
+  float4 ra[4], rb[4];
+  uint32_t oka = wload(p.dZ, p.ld_dz, p.M, m0, kbeg, kend, vec_a, ra);
+  uint32_t okb = wload(p.X, p.ld_x, p.N, n0, kbeg, kend, vec_b, rb);
+  for (int it = 0; it < nk; ++it) {
+    __syncthreads();  // the previous stage has been consumed
+    wstore(As, oka, ra);
+    wstore(Bs, okb, rb);
+    __syncthreads();
+    if (it + 1 < nk && !(g.bisect & 2)) {  // in flight under this stage's MFMAs
+      oka = wload(p.dZ, p.ld_dz, p.M, m0, kbeg + (it + 1) * W_K, kend, vec_a, ra);
+      okb = wload(p.X, p.ld_x, p.N, n0, kbeg + (it + 1) * W_K, kend, vec_b, rb);
+    }
+    // operand mapping of 32x32x2: A[m = lane % 32][k = lane / 32], B[k = lane / 32][n = lane % 32]; the operands of
+    // the next two MFMAs are read while the current two run (two register sets, each half unrolled in full).  The
+    // second half of a stage is skipped when the chunk ends in the first (chunks are whole HALF stages).
+    const float *pa = &As[lane >> 5][wm + (lane & 31)], *pb = &Bs[lane >> 5][wn + (lane & 31)];
+    const int valid = kend - (kbeg + it * W_K);  // k rows of this stage (the others are zero)
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      if ((half == 1 && valid <= W_K / 2) || (g.bisect & 1)) break;
+      const int k0 = half * (W_K / 2);
+      float a[2][2], b[2][2];
+      a[0][0] = pa[k0 * W_T], b[0][0] = pb[k0 * W_T], a[0][1] = pa[(k0 + 2) * W_T], b[0][1] = pb[(k0 + 2) * W_T];
+#pragma unroll
+      for (int kk = k0; kk < k0 + W_K / 2; kk += 4) {
+        const int cur = (kk >> 2) & 1;
+        if (kk + 4 < k0 + W_K / 2) {
+          a[cur ^ 1][0] = pa[(kk + 4) * W_T], b[cur ^ 1][0] = pb[(kk + 4) * W_T];
+          a[cur ^ 1][1] = pa[(kk + 6) * W_T], b[cur ^ 1][1] = pb[(kk + 6) * W_T];
+        }
+        __builtin_amdgcn_sched_barrier(0);  // (the scheduler otherwise folds the two sets into one and waits per pair)
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][0], b[cur][0], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][1], b[cur][1], acc1, 0, 0, 0);
+      }
+    }
+    if (bias) {  // column t % 64, k rows 16 (t / 64) .. + 15 of the stage (rows past kend are zero)
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) bsum += As[(t >> 6) * 16 + kk][t & 63];
+    }
+  }
+  if (g.bisect & 4) {
+    if (acc0[0] + acc1[3] + bsum == 12345.f) p.gW[0] = 1.f;  // (keeps the work alive)
+    return;
+  }
+  if (bias && m0 + (t & 63) < p.M) unsafeAtomicAdd(p.gbias + m0 + (t & 63), bsum);
+  // accumulator layout of 32x32: lane l, register r: row 8 (r / 4) + 4 (l / 32) + r % 4, column l % 32
+  const int n = n0 + wn + (lane & 31);
+  const int mb = m0 + wm + 4 * (lane >> 5);
+  if (n >= p.N) return;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = mb + (r & 3) + 8 * (r >> 2);
+    if (m < p.M) unsafeAtomicAdd(p.gW + (size_t)m * p.ld_w + n, acc0[r] + acc1[r]);
   }
 }
 
@@ -1315,6 +1479,36 @@ bool fill_pairs(int P, const float *times, const int *rows, PairTable &pt) {
   return true;
 }
 
+// the dgrad chain's packed (transposed) weights of every layer; fills g.Tp / g.TpE when `g` is given
+bool bwd_rows8() {
+  static const bool rows8 = timenet_rows("DIMO_TIMENET_ROWS_BWD", 8) == 8;
+  return rows8;
+}
+void pack_t_jobs(const dimo_timenet_desc *d, const Plan &pl, float *ws, PackTArgs &pa, FusedBwdArgs *g) {
+  const int D = d->D, Wd = pl.Wd;
+  for (int l = 0; l < D + 4; ++l) {
+    const int K = l == 0 ? pl.E : (l < D && l - 1 == pl.skip ? pl.CAT : Wd);  // row length of weight[l]
+    if (pl.has_t[l]) {
+      PackTJob &j = pa.job[pa.njobs++];
+      j.W = d->weight[l], j.out = ws + pl.packed_t[l], j.ldw = K, j.col0 = K - Wd, j.ncols = Wd, j.ntiles = 16;
+      if (g) g->Tp[l] = j.out;
+    }
+    if (pl.has_te[l]) {
+      PackTJob &j = pa.job[pa.njobs++];
+      j.W = d->weight[l], j.out = ws + pl.packed_te[l], j.ldw = K, j.col0 = 0, j.ncols = pl.E, j.ntiles = 8;
+      if (g) g->TpE[l] = j.out;
+    }
+  }
+  if (bwd_rows8())  // column groups of 64 instead of tiles of 16
+    for (int k = 0; k < pa.njobs; ++k) pa.job[k].ntiles /= 4;
+}
+void launch_pack_t(const PackTArgs &pa, hipStream_t s) {
+  if (bwd_rows8())
+    pack_weights_t_quads_kernel<<<dim3(16, pa.njobs), 256, 0, s>>>(pa);
+  else
+    pack_weights_t_kernel<<<dim3(16, pa.njobs), 256, 0, s>>>(pa);
+}
+
 }  // namespace
 
 extern "C" size_t dimo_timenet_workspace_bytes(const dimo_timenet_desc *d, int P, int M) {
@@ -1431,31 +1625,17 @@ extern "C" int dimo_timenet_backward(const dimo_timenet_desc *d, int P, int M, c
     g.R = R, g.E = pl.E, g.CAT = pl.CAT, g.D = D, g.skip = pl.skip;
     g.g_d_xyz = g_d_xyz, g.g_d_rot = g_d_rot, g.Wp1 = d->weight[D + 1], g.Wr1 = d->weight[D + 3];
     g.hp = ws + pl.hp, g.hr = ws + pl.hr, g.dzp = ws + pl.dzp, g.dzr = ws + pl.dzr, g.g_cat = ws + pl.g_cat;
-    for (int l = 0; l < D + 4; ++l) {
-      const int K = l == 0 ? pl.E : (l < D && l - 1 == pl.skip ? pl.CAT : Wd);  // row length of weight[l]
-      if (pl.has_t[l]) {
-        PackTJob &j = pa.job[pa.njobs++];
-        j.W = d->weight[l], j.out = ws + pl.packed_t[l], j.ldw = K, j.col0 = K - Wd, j.ncols = Wd, j.ntiles = 16;
-        g.Tp[l] = j.out;
-      }
-      if (pl.has_te[l]) {
-        PackTJob &j = pa.job[pa.njobs++];
-        j.W = d->weight[l], j.out = ws + pl.packed_te[l], j.ldw = K, j.col0 = 0, j.ncols = pl.E, j.ntiles = 8;
-        g.TpE[l] = j.out;
-      }
-    }
+    pack_t_jobs(d, pl, ws, pa, &g);
     for (int l = 0; l < D; ++l) g.mask[l] = ws + pl.act[l], g.dz[l] = ws + pl.dz[l], g.ld[l] = act_ld(pl, l);
+    // (packing NEXT TO the forward on a private stream -- the pack depends on the weights alone -- was slower: the
+    // forward is bound by its weight stream from L2, 69 -> 79 us with the pack beside it, 8073 -> 7982 frames/s)
+    launch_pack_t(pa, s);
     // the dgrad chain: 8 rows per workgroup on every CU (4x4x1 MFMA; 103 against 115 us for the backward group, and
     // the same in the training step, where only the optimizer's early part runs next to it); DIMO_TIMENET_ROWS_BWD=16
-    static const bool rows8 = timenet_rows("DIMO_TIMENET_ROWS_BWD", 8) == 8;
-    if (rows8) {  // column groups of 64 instead of tiles of 16
-      for (int k = 0; k < pa.njobs; ++k) pa.job[k].ntiles /= 4;
-      pack_weights_t_quads_kernel<<<dim3(16, pa.njobs), 256, 0, s>>>(pa);
+    if (bwd_rows8())
       timenet_bwd_fused8_kernel<<<(R + R8 - 1) / R8, 1024, 0, s>>>(g);
-    } else {
-      pack_weights_t_kernel<<<dim3(16, pa.njobs), 256, 0, s>>>(pa);
+    else
       timenet_bwd_fused_kernel<<<(R + FR - 1) / FR, 512, 0, s>>>(g);
-    }
   }
   if (!fused) {
     const int n = R * Wd;
@@ -1489,15 +1669,28 @@ extern "C" int dimo_timenet_backward(const dimo_timenet_desc *d, int P, int M, c
     }
     launch_gemm<true, false>(g, 1, s);
   }
+  EmbedBwdArgs eb = {};
+  {
+    eb.rows = R, eb.Mc = M, eb.ld = pl.CAT, eb.pts_freqs = d->pts_freqs;
+    eb.lat0 = 6 * d->pts_freqs + 2 * d->time_freqs, eb.latent_dim = d->latent_dim;
+    eb.cat = ws + pl.cat, eb.g_cat = ws + pl.g_cat;
+    eb.g_c_xyz = d->pts_freqs > 0 ? g_c_xyz : nullptr, eb.g_latent_table = d->latent_dim > 0 ? g_latent_table : nullptr;
+    for (int q = 0; q < P; ++q) eb.latent_row[q] = pt.latent_row[q];
+    eb.nblocks = (eb.g_c_xyz || eb.g_latent_table) ? (R + 63) / 64 : 0;
+  }
   {  // every weight / bias gradient in one grouped split-K launch
+    // DIMO_WGRAD=32: the 32 x 64 tiles of 16x16x4 MFMAs (rounds 2-4) and the embedding backward as a launch of its own;
+    // default: 64 x 64 tiles of 32x32x2 (wgrad64_kernel), the embedding backward in the same launch
+    static const bool wide = !(getenv("DIMO_WGRAD") && atoi(getenv("DIMO_WGRAD")) == 32);
+    const int tM = wide ? W_T : BM, tN = wide ? W_T : BN;
     WgradArgs w = {};
     int tiles = 0, np = 0;
     auto add = [&](const float *dz, int ld_dz, const float *x, int ld_x, int Mo, int No, int li) {
       WgradProblem &p = w.p[np++];
       p.dZ = dz, p.ld_dz = ld_dz, p.X = x, p.ld_x = ld_x, p.gW = d->g_weight[li], p.gbias = d->g_bias[li];
-      p.ld_w = No, p.M = Mo, p.N = No, p.tiles_n = (No + BN - 1) / BN, p.tile_begin = tiles;
-      p.vec = vec_ok(dz, ld_dz, Mo) && vec_ok(x, ld_x, No);
-      tiles += ((Mo + BM - 1) / BM) * p.tiles_n;
+      p.ld_w = No, p.M = Mo, p.N = No, p.tiles_n = (No + tN - 1) / tN, p.tile_begin = tiles;
+      p.vec = (vec_ok(dz, ld_dz, Mo) ? 1 : 0) | (vec_ok(x, ld_x, No) ? 2 : 0);
+      tiles += ((Mo + tM - 1) / tM) * p.tiles_n;
     };
     for (int l = 0; l < D; ++l) {
       size_t off;
@@ -1512,19 +1705,27 @@ extern "C" int dimo_timenet_backward(const dimo_timenet_desc *d, int P, int M, c
     add(ws + pl.dzr, Wd, hlast, ldl, Wd, Wd, D + 2);
     add(g_d_rot, 4, ws + pl.hr, Wd, 4, Wd, D + 3);
     w.nprob = np, w.rows = R;
-    // ~8 K-slices: enough workgroups to fill 256 CUs several times over, few enough atomics per element
-    int ksplit = (R + 255) / 256;
-    ksplit = ksplit < 1 ? 1 : (ksplit > 64 ? 64 : ksplit);
-    w.kchunk = (((R + ksplit - 1) / ksplit) + BK - 1) / BK * BK;
-    ksplit = (R + w.kchunk - 1) / w.kchunk;
-    wgrad_kernel<<<dim3(tiles, ksplit), 256, 0, s>>>(w);
-  }
-  {
-    float *gc = d->pts_freqs > 0 ? g_c_xyz : nullptr;
-    float *gl = d->latent_dim > 0 ? g_latent_table : nullptr;
-    if (gc || gl)
-      embed_bwd_kernel<<<(R + 63) / 64, 256, 0, s>>>(R, M, pl.CAT, d->pts_freqs, 6 * d->pts_freqs + 2 * d->time_freqs,
-                                                     d->latent_dim, ws + pl.cat, ws + pl.g_cat, pt, gc, gl);
+    if (wide) {
+      // ONE round of workgroups: four per CU (DIMO_WGRAD_WGS overrides the target), K chunks of whole half stages
+      static const int target = getenv("DIMO_WGRAD_WGS") ? atoi(getenv("DIMO_WGRAD_WGS")) : 1024;
+      const int halves = (R + W_K / 2 - 1) / (W_K / 2);
+      int ksplit = (target + tiles / 2) / tiles;
+      ksplit = ksplit < 1 ? 1 : (ksplit > halves ? halves : ksplit);
+      w.kchunk = ((halves + ksplit - 1) / ksplit) * (W_K / 2);
+      ksplit = (R + w.kchunk - 1) / w.kchunk;
+      static const bool xcd = getenv("DIMO_WGRAD_XCD") && atoi(getenv("DIMO_WGRAD_XCD")) == 1;
+      static const int bisect = getenv("DIMO_WGRAD_BISECT") ? atoi(getenv("DIMO_WGRAD_BISECT")) : 0;
+      w.tiles = tiles, w.xcd = xcd, w.bisect = bisect;
+      wgrad64_kernel<<<dim3(eb.nblocks + tiles * ksplit), 256, 0, s>>>(w, eb);
+    } else {
+      // ~8 K-slices: enough workgroups to fill 256 CUs several times over, few enough atomics per element
+      int ksplit = (R + 255) / 256;
+      ksplit = ksplit < 1 ? 1 : (ksplit > 64 ? 64 : ksplit);
+      w.kchunk = (((R + ksplit - 1) / ksplit) + BK - 1) / BK * BK;
+      ksplit = (R + w.kchunk - 1) / w.kchunk;
+      wgrad_kernel<<<dim3(tiles, ksplit), 256, 0, s>>>(w);
+      if (eb.nblocks) embed_bwd_kernel<<<eb.nblocks, 256, 0, s>>>(eb);
+    }
   }
   return check_launch();
 }

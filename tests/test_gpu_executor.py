@@ -214,3 +214,23 @@ def test_chained_buckets_mode_against_the_oracle(chain):
                         "(baseline_config_sizes and 100000) or (batched_executor_kernels and 50000)"],
                        cwd=root, env=env, capture_output=True, text=True, timeout=1500)
     assert p.returncode == 0 and " passed" in p.stdout, p.stdout[-3000:] + p.stderr[-2000:]
+
+
+@pytest.mark.timeout(1800)
+def test_forward_with_matrix_pipe_accumulators_against_the_oracle():
+    """DIMO_FWD_MFMA=1: the blend forward keeps its eight running sums in v_mfma_f32_4x4x1 accumulators (transposed:
+    a lane holds one feature of four neighbouring pixels; checkpoints and output planes written as float4).  Measured
+    slower than the per-lane FMAs and therefore off by default, but kept and held to the same parity: forward images,
+    the backward that starts from its checkpoints (single render at 100k / 512^2), an odd image width (the scalar
+    store path) and the batched executor.  The variable is read once per process: child process."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DIMO_FWD_MFMA="1")
+    p = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "tests/test_gpu_raster.py",
+                        "tests/test_gpu_executor.py", "-k",
+                        "(baseline_config_sizes and 100000) or (batched_executor_kernels and 50000) or "
+                        "test_forward_parity or test_backward_parity or edge_cases"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=1500)
+    assert p.returncode == 0 and " passed" in p.stdout, p.stdout[-3000:] + p.stderr[-2000:]

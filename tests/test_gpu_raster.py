@@ -115,7 +115,8 @@ def _check_forward(sc, cam, bg, deg, with_normal=True, scale_mod=1.0):
 
 
 @pytest.mark.parametrize("N,H,W,deg,M", [(1000, 128, 128, 0, 1), (5000, 80, 96, 0, 1), (3000, 128, 160, 3, 16),
-                                         (2000, 64, 64, 1, 4), (20000, 256, 256, 0, 1)])
+                                         (2000, 64, 64, 1, 4), (20000, 256, 256, 0, 1),
+                                         (1500, 50, 70, 0, 1)])  # (the last: partial tiles, a width not a multiple of 4)
 def test_forward_parity(N, H, W, deg, M):
     cam = camera_np(25.0, elevation=8, W=W, H=H)
     sc = random_scene(N, seed=N, sh_coeffs=M, scale=0.02)
@@ -261,7 +262,8 @@ GRADS_SH = dict(means3D="dL_dmeans3D", means2D="dL_dmean2D", shs="dL_dshs", opac
                 scales="dL_dscales", rotations="dL_drot")
 
 
-@pytest.mark.parametrize("N,H,W,deg,M", [(1000, 128, 128, 0, 1), (4000, 80, 96, 3, 16), (20000, 256, 256, 0, 1)])
+@pytest.mark.parametrize("N,H,W,deg,M", [(1000, 128, 128, 0, 1), (4000, 80, 96, 3, 16), (20000, 256, 256, 0, 1),
+                                         (1500, 50, 70, 1, 4)])
 def test_backward_parity(N, H, W, deg, M):
     cam = camera_np(25.0, elevation=8, W=W, H=H)
     sc = random_scene(N, seed=N + 1, sh_coeffs=M, scale=0.02)
