@@ -1473,6 +1473,13 @@ int timenet_rows(const char *var, int dflt) {
   return v == 8 || v == 16 ? v : dflt;
 }
 
+// workgroups per packed matrix: one float4 per thread at 64 (the loops are grid-stride; 16 until the end of round 4,
+// four to six dependent rounds per thread on the step's critical path); DIMO_PACK_WGS overrides
+unsigned pack_wgs() {
+  static const int v = getenv("DIMO_PACK_WGS") ? atoi(getenv("DIMO_PACK_WGS")) : 64;
+  return (unsigned)(v >= 1 && v <= 1024 ? v : 64);
+}
+
 bool fill_pairs(int P, const float *times, const int *rows, PairTable &pt) {
   if (P > MAX_PAIRS) return false;
   for (int p = 0; p < P; ++p) pt.time[p] = times[p], pt.latent_row[p] = rows ? rows[p] : p;
@@ -1504,9 +1511,9 @@ void pack_t_jobs(const dimo_timenet_desc *d, const Plan &pl, float *ws, PackTArg
 }
 void launch_pack_t(const PackTArgs &pa, hipStream_t s) {
   if (bwd_rows8())
-    pack_weights_t_quads_kernel<<<dim3(16, pa.njobs), 256, 0, s>>>(pa);
+    pack_weights_t_quads_kernel<<<dim3(pack_wgs(), pa.njobs), 256, 0, s>>>(pa);
   else
-    pack_weights_t_kernel<<<dim3(16, pa.njobs), 256, 0, s>>>(pa);
+    pack_weights_t_kernel<<<dim3(pack_wgs(), pa.njobs), 256, 0, s>>>(pa);
 }
 
 }  // namespace
@@ -1558,14 +1565,14 @@ extern "C" int dimo_timenet_forward(const dimo_timenet_desc *d, int P, int M, co
     // takes the other half of the chip: 77 us against 84 (both kernels in flight).  DIMO_TIMENET_ROWS_FWD=8 selects it.
     static const bool rows8 = timenet_rows("DIMO_TIMENET_ROWS_FWD", 16) == 8;
     if (rows8) {
-      pack_weights_quads_kernel<<<dim3(16, pa.njobs), 256, 0, s>>>(pa);
+      pack_weights_quads_kernel<<<dim3(pack_wgs(), pa.njobs), 256, 0, s>>>(pa);
       static const int bisect = getenv("DIMO_TIMENET_BISECT") ? atoi(getenv("DIMO_TIMENET_BISECT")) : 0;
       if (bisect == 1) timenet_fwd_fused8_kernel<1><<<(R + R8 - 1) / R8, 1024, 0, s>>>(g);
       else if (bisect == 2) timenet_fwd_fused8_kernel<2><<<(R + R8 - 1) / R8, 1024, 0, s>>>(g);
       else timenet_fwd_fused8_kernel<0><<<(R + R8 - 1) / R8, 1024, 0, s>>>(g);
       return check_launch();
     }
-    pack_weights_kernel<<<dim3(16, pa.njobs), 256, 0, s>>>(pa);
+    pack_weights_kernel<<<dim3(pack_wgs(), pa.njobs), 256, 0, s>>>(pa);
     static const bool wide = !getenv("DIMO_TIMENET_8WAVES");
     if (wide)
       timenet_fwd_fused_kernel<16><<<(R + FR - 1) / FR, 1024, 0, s>>>(g);
@@ -1627,8 +1634,11 @@ extern "C" int dimo_timenet_backward(const dimo_timenet_desc *d, int P, int M, c
     g.hp = ws + pl.hp, g.hr = ws + pl.hr, g.dzp = ws + pl.dzp, g.dzr = ws + pl.dzr, g.g_cat = ws + pl.g_cat;
     pack_t_jobs(d, pl, ws, pa, &g);
     for (int l = 0; l < D; ++l) g.mask[l] = ws + pl.act[l], g.dz[l] = ws + pl.dz[l], g.ld[l] = act_ld(pl, l);
-    // (packing NEXT TO the forward on a private stream -- the pack depends on the weights alone -- was slower: the
-    // forward is bound by its weight stream from L2, 69 -> 79 us with the pack beside it, 8073 -> 7982 frames/s)
+    // The pack depends on the weights alone, but it belongs HERE: written right in front of the chain, the packed
+    // weights are in the L2 when the chain streams them.  Packed early on this stream, in the shadow of the renders
+    // (a `dimo_timenet_backward_prepare` call after the forks), the launch left the serial tail and the chain lost
+    // more than that -- backward group 106 -> 119 us in the step, 8098 -> 8054 frames/s; packed NEXT TO the forward on
+    // a private stream, the forward (bound by its own weight stream) went 69 -> 79 us, 8073 -> 7982 frames/s.
     launch_pack_t(pa, s);
     // the dgrad chain: 8 rows per workgroup on every CU (4x4x1 MFMA; 103 against 115 us for the backward group, and
     // the same in the training step, where only the optimizer's early part runs next to it); DIMO_TIMENET_ROWS_BWD=16
