@@ -350,16 +350,19 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(EmbedBwdArgs e) {
 }
 
 // ---- the same grouped split-K problem on 64 x 64 tiles of v_mfma_f32_32x32x2_f32 ------------------------------------
-// wgrad_kernel above is bound by the LDS, not by its MFMAs: a 16 x 32 wave tile reads three operands per two 16x16x4
-// MFMAs, and with the [k][m] staging at leading dimension 65 the two 16-lane rows of a ds_read_b32 lane group overlap
-// in 15 of 16 banks (bank = dword address mod 32 for that instruction): every operand read is a 2-way conflict
-// (profiles/r04_sq_summary.txt: 46 % of the LDS cycles), ~4350 LDS cycles against 4096 MFMA cycles per CU and round of
-// stages.  Here a wave owns a 32 x 32 tile: ONE read per operand and 64-cycle MFMA, 32 consecutive dwords per lane
-// group (conflict-free at any leading dimension), the stage stored with ds_write_b128 straight from the 16-byte global
-// loads (rows of 64 floats, no padding) -- ~3070 LDS cycles against 8192 MFMA cycles for twice the flops.  Both
-// operands are k-major in memory (dZ [rows x M], X [rows x N]), so the stage is a plain copy.  Two accumulators
-// (even / odd pairs of k) keep consecutive MFMAs of a wave independent.  The split over K is chosen so that the launch
-// is ONE round of workgroups (four per CU: 32 KB of LDS each), in chunks of whole half stages.
+// In wgrad_kernel above a 16 x 32 wave tile reads three operands per two 16x16x4 MFMAs, and with the [k][m] staging at
+// leading dimension 65 the two 16-lane rows of a ds_read_b32 lane group overlap in 15 of 16 banks (bank = dword
+// address mod 32 for that instruction): every operand read is a 2-way conflict (profiles/r04_sq_summary.txt: 46 % of
+// the LDS cycles).  Here a wave owns a 32 x 32 tile: ONE read per operand and 64-cycle MFMA, 32 consecutive dwords per
+// lane group (conflict-free at any leading dimension: 0 conflicts measured), the stage stored with ds_write_b128
+// straight from the 16-byte global loads (rows of 64 floats, no padding).  Both operands are k-major in memory
+// (dZ [rows x M], X [rows x N]), so the stage is a plain copy.  Two accumulators (even / odd pairs of k) keep
+// consecutive MFMAs of a wave independent.  The split over K is chosen so that the launch is ONE round of workgroups
+// (four per CU: 32 KB of LDS each), in chunks of whole half stages.
+// What it is bound by (DIMO_WGRAD_BISECT, profiles/r04_timenet_wgrad64.txt): NOT the matrix pipe -- the launch's
+// skeleton (first loads, LDS stores, barriers) is 14 us, the 4.1 M fp32 atomics alone add 10.8 (~1.4 elements per
+// clock and L2 channel), the operand loads alone 14.1, the MFMAs alone 9.9, and the four barely overlap: one round
+// of workgroups runs its phases in lock step.  44 us with the embedding backward inside, against 42 + 10.7.
 constexpr int W_T = 64, W_K = 64;  // tile edge (M and N), K rows per stage
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
