@@ -34,7 +34,11 @@ namespace dimo {
 constexpr int BLEND_BLOCK = 256;
 constexpr int BATCH = 256;
 constexpr int BWD_GRID = 16384;  // single-wave workgroups striding over the work items (most get one)
-constexpr int BWD_WAVES_PER_SIMD = 4;  // register budget of the backward: 128 VGPRs
+#ifndef DIMO_BWD_WAVES
+#define DIMO_BWD_WAVES 4
+#endif
+constexpr int BWD_WAVES_PER_SIMD = DIMO_BWD_WAVES;  // register budget of the backward: 128 VGPRs at 4 (build.py passes
+                                                    // -DDIMO_BWD_WAVES=<n> when the environment has DIMO_BWD_WAVES)
 
 __device__ __forceinline__ void pixel_of_thread(int tile_x, int tile_y, int &px, int &py) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;

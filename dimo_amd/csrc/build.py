@@ -32,6 +32,8 @@ SOURCES = {
 }
 if os.environ.get("DIMO_BWD_TRACE") == "1":  # per-item trace of the blend backward (tools/bwd_trace.py)
     SOURCES["blend.hip"] = SOURCES["blend.hip"] + ["-DDIMO_BWD_TRACE"]
+if os.environ.get("DIMO_BWD_WAVES"):  # waves per SIMD the blend backward is compiled for (experiments; default 4)
+    SOURCES["blend.hip"] = SOURCES["blend.hip"] + ["-DDIMO_BWD_WAVES=%d" % int(os.environ["DIMO_BWD_WAVES"])]
 if os.environ.get("DIMO_BIN_TRACE") == "1":  # per-workgroup phase trace of the binning kernels (tools/bin_trace.py)
     SOURCES["binning.hip"] = SOURCES["binning.hip"] + ["-DDIMO_BIN_TRACE"]
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
