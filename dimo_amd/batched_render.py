@@ -433,6 +433,12 @@ class _BatchRenderFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *grads):
         job, n = ctx.job, ctx.n
+        if job.backward_done:
+            # (retain_graph=True / two losses backpropagated separately: the render slots went back to the batcher with
+            # the first pass and `grad_rows` still hold its sums -- a second pass would be silently wrong)
+            raise RuntimeError("a render batch's backward runs once: its render slots were released by the first pass; "
+                               "sum the losses and call backward() once (main_train_dimo.py:415)")
+        job.backward_done = True
         b, ex = job.batcher, job.batcher.ex
         keep, dkeep, raw, _radii, passes = ctx.keep
         dev = raw.device
@@ -484,7 +490,7 @@ class _Request:
 class _Job:
     """What a flushed batch's autograd node needs (NOT its outputs: those reference the node)."""
     __slots__ = ("batcher", "reqs", "deforms", "first", "ticket", "local_frame", "scale_modifier", "nn_dist", "nn_idx",
-                 "bg", "grad_rows")
+                 "bg", "grad_rows", "backward_done")
 
 
 class RenderBatcher:
@@ -682,6 +688,7 @@ class RenderBatcher:
         job.local_frame, job.scale_modifier = bool(local_frame), float(scale_modifier)
         job.nn_dist, job.nn_idx, job.bg = g.neighbor_dists, g.neighbor_indices, r.bg_color
         job.first, job.ticket = pend["first"], _Ticket(self, pend["first"], n)
+        job.backward_done = False
         flat = [t for dq in deforms for t in dq]
         sinks = [rq.sink for rq in reqs]
         image, depth, normal, alpha, radii = _BatchRenderFn.apply(

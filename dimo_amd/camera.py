@@ -108,7 +108,11 @@ class MiniCam:
     numpy inverse and four synchronous host-to-device copies, each of which waits for everything queued on the stream.
     The device matrices are therefore cached by VALUE (pose bytes, size, fov, planes, device): the same 9 views come
     back thousands of times, and a loop that constructs a MiniCam per render never touches the device after the first
-    time it sees a view."""
+    time it sees a view.
+
+    The four device tensors are therefore SHARED by every MiniCam of the same pose / fov / planes and are READ-ONLY: an
+    in-place edit (jitter, `.mul_`) would change every later camera of that view -- `clone()` the matrix first.  (A clone
+    per construction would put four copy launches per render back on the reference loop's host path.)"""
 
     def __init__(self, c2w, width, height, fovy, fovx, znear, zfar, device=None):
         if device is None:

@@ -451,11 +451,14 @@ __global__ void __launch_bounds__(256) accumulate_batched_kernel(int N, int n_re
     if (i >= 14 * n) {
       const size_t j = i - 14 * n;
       const int m = (int)(j >> 2), cc = (int)(j & 3);
+      // The staged sums are formed in a fixed order and ADDED ATOMICALLY: in the training step this fold runs on a
+      // private stream next to the TimeNet backward, whose embedding backward adds its input gradient to the same
+      // `_c_xyz.grad` words with atomics (timenet.hip) -- a plain read-modify-write here could lose those.
       float *dst = cc < 3 ? g_c_xyz + 3 * m + cc : g_c_lr + m;
-      float s = *dst;
+      float s = 0.0f;
       for (int q = 0; q < b.n_groups; ++q)
         s += (stage_end - (size_t)(first_abs + (int)b.leader[q] + 1) * stage_stride)[j];
-      *dst = s;
+      unsafeAtomicAdd(dst, s);
       continue;
     }
     float *dst;

@@ -791,6 +791,27 @@ class Trainer:
         in_order = bool(ex.ranged and self._inorder_losses and not c.use_lpips)
         main_chain = (self._main_chain if self._main_chain is not None else int(joint_bwd)) if (in_order and not joint) else 0
         main_motion = list(by_motion)[-1] if (main_chain and by_motion) else None
+        # Scalars produced on THIS stream (GA, KL, ARAP; LPIPS further down): summed apart from `loss_accum`, which the
+        # private streams' kernels add to atomically.  They run BEFORE the forward forks: their gradient writes -- GA into
+        # the TimeNet-row gradients `g_dxyz` and `_c_xyz.grad`, ARAP through autograd into the control points, the
+        # TimeNet and the latents, KL into `_mu` / `_log_var` -- are plain read-modify-writes, and the private streams'
+        # skinning backward (`lbs_reduce`: `*dst += s` into the same `g_d_xyz` rows) and the fold (control-point sums
+        # into `_c_xyz.grad`) must be ordered behind them; every private stream forks from this one below.
+        extra = None
+        if self._ga_active():
+            extra = self._ga_direct(mine, pair_of, dxyz_c, g_dxyz)
+        for m, trs in by_motion.items():
+            share = len(trs) / n_img
+            if g.vae_latent:  # KL term of this motion (main_train_dimo.py:355-360): tiny, autograd
+                mu, lv = g._mu[m], g._log_var[m]
+                kl = share * c.lambda_kl * (-0.5 * torch.sum(1 + lv - mu.pow(2) - lv.exp()))
+                kl.backward()
+                extra = kl.detach() if extra is None else extra + kl.detach()
+            reg = self.regularizer_loss(m)  # ARAP on the control points: its own small autograd graph
+            if reg is not None:
+                reg = share * reg
+                reg.backward()
+                extra = reg.detach() if extra is None else extra + reg.detach()
         if ex.ranged:  # one batch per motion, on alternating private streams
             for m, trs in by_motion.items():
                 if m != main_motion:
@@ -802,11 +823,6 @@ class Trainer:
         self.renderer.capacity.track(ex.total_words(n))
 
         loss_accum = zeroed[o_q + dquat_c.numel():o_q + dquat_c.numel() + _LOSS_WORDS]
-        # scalars produced on THIS stream (KL, ARAP, GA, LPIPS): summed apart from `loss_accum`, which the private
-        # streams' kernels add to atomically
-        extra = torch.zeros((), **f32)
-        if self._ga_active():
-            extra = extra + self._ga_direct(mine, pair_of, dxyz_c, g_dxyz)
         ssums = zeroed[o_q + dquat_c.numel() + _LOSS_WORDS:]
         ssim_terms, keep = [], []
         if joint:
@@ -839,17 +855,7 @@ class Trainer:
         for m, trs in by_motion.items():
             B = len(trs)
             share = B / n_img
-            if joint:  # only the motion's scalar terms are left (KL, ARAP)
-                if g.vae_latent:
-                    mu, lv = g._mu[m], g._log_var[m]
-                    kl = share * c.lambda_kl * (-0.5 * torch.sum(1 + lv - mu.pow(2) - lv.exp()))
-                    kl.backward()
-                    extra = extra + kl.detach()
-                reg = self.regularizer_loss(m)
-                if reg is not None:
-                    reg = share * reg
-                    reg.backward()
-                    extra = extra + reg.detach()
+            if joint:
                 continue
             img, depth, normal, alpha = bufs[m]
             # batched ranges: this motion's losses and rasterizer backward continue ON ITS OWN STREAM, in order behind
@@ -886,7 +892,7 @@ class Trainer:
                 lp = c.lambda_lpips * share * self.lpips_metric()(x, torch.stack(gt)).mean()
                 (g_lp,) = torch.autograd.grad(lp, x)
                 gi.add_(g_lp * ((img >= 0.0) & (img <= 1.0)))
-                extra = extra + lp.detach()
+                extra = lp.detach() if extra is None else extra + lp.detach()
             for b in range(B):
                 d = ex.descs[first[m] + b]
                 d.g_color, d.g_alpha = gi.data_ptr() + b * 3 * HW4, ga.data_ptr() + b * HW4
@@ -902,16 +908,6 @@ class Trainer:
                     skinned += 1
             elif ex.ranged or not ex.batched:
                 ex.backward_launch(first[m], B)  # overlaps with the next motion's losses on this stream
-            if g.vae_latent:  # KL term of this motion (main_train_dimo.py:355-360): tiny, autograd
-                mu, lv = g._mu[m], g._log_var[m]
-                kl = share * c.lambda_kl * (-0.5 * torch.sum(1 + lv - mu.pow(2) - lv.exp()))
-                kl.backward()
-                extra = extra + kl.detach()
-            reg = self.regularizer_loss(m)  # ARAP on the control points: its own small autograd graph
-            if reg is not None:
-                reg = share * reg
-                reg.backward()
-                extra = extra + reg.detach()
         self._mark("losses+launch")
         if joint_bwd:
             ex.backward_launch_joint(0, n)
@@ -921,7 +917,9 @@ class Trainer:
             ex.backward_accumulate(0, n)
         elif skinned and skinned == len(by_motion):
             # every motion is skinned already: ONE fold over the step's renders
-            side = ex.private_stream(0) if (self._split_adam and not s1 and self.world == 1 and self._flat_adam) else None
+            # (not with a motion's chain on THIS stream: the fold would run ahead of that motion's skinning backward)
+            side = ex.private_stream(0) if (self._split_adam and not s1 and self.world == 1 and self._flat_adam
+                                            and main_motion is None) else None
             if side is not None:
                 # ... on private stream 0, followed there by the optimizer's update of the per-Gaussian head of the
                 # bucket (its gradients are final with the fold), NEXT TO the TimeNet backward on this stream, which only
