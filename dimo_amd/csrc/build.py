@@ -24,6 +24,7 @@ SOURCES = {
     "knn.hip": ["-ffp-contract=off"],
     "ssim.hip": ["-fno-slp-vectorize"],  # packed FMAs need register pairs: with the window in VGPRs they spilled
     "deform.hip": [],
+    "tail.hip": ["-fno-slp-vectorize"],  # (packed FMAs: 216 VGPRs against 173, two waves per SIMD instead of three)
     "image_loss.hip": [],
     "adam.hip": [],
     "timenet.hip": [],
@@ -55,7 +56,8 @@ def _stale(out, deps):
 
 def build(force=False, verbose=False):
     hipcc = _hipcc()
-    headers = [os.path.join(HERE, "common.hpp"), os.path.join(HERE, "..", "..", "include", "dimo_hip.h"), __file__]
+    headers = [os.path.join(HERE, h) for h in ("common.hpp", "wave_ops.hpp", "proj_math.hpp", "deform_body.hpp")] + \
+              [os.path.join(HERE, "..", "..", "include", "dimo_hip.h"), __file__]
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
     jobs = []

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/dimo_hip.h"
 
@@ -242,6 +243,14 @@ int lbs_forward_batched(const dimo_step_common &c, const RenderBatch &b, int n, 
 size_t lbs_backward_batched_scratch_bytes(int N, int M, int n);
 int lbs_backward_batched(const dimo_step_common &c, const RenderBatch &b, int n, hipStream_t stream, int first_abs = 0,
                          int phase = 0);
+// Stage s2, batched modes: the projection backward of a deformation group's views and the group's skinning backward run
+// as ONE kernel (tail.hip), launched where the skinning backward was; preprocess_backward_batched is then skipped.
+// DIMO_FUSED_TAIL=0 keeps the two-kernel path (A/B measurements; stage s1 always takes it).
+inline bool fused_tail(const dimo_step_common &c) {
+  static const bool on = !(getenv("DIMO_FUSED_TAIL") && atoi(getenv("DIMO_FUSED_TAIL")) == 0);
+  return on && !c.stage1;
+}
+int tail_backward_batched(const dimo_step_common &c, const RenderBatch &b, int grid, float *partials, hipStream_t stream);
 int preprocess_forward_batched(const dimo_step_common &c, const RenderBatch &b, int n, hipStream_t stream);
 int preprocess_backward_batched(const dimo_step_common &c, const RenderBatch &b, int n, hipStream_t stream);
 int bin_instances_batched(const dimo_step_common &c, const RenderBatch &b, int n, hipStream_t stream);
