@@ -120,6 +120,26 @@ def read_timing():
     return out
 
 
+def cpu_baseline_c1(steps=20):
+    """BASELINE.json configs[0] / BASELINE.md section 2's C1: 1k Gaussians, 1 motion x 1 frame x 1 view at 128^2, deform +
+    render + losses + backward + Adam on PyTorch-CPU with the CPU oracle kernels (kind 'port'), `steps` train steps."""
+    from dimo_amd.trainer import TrainConfig
+    from tests.cpu_backend import make_cpu_trainer
+    cores = min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(cores)
+    cfg = TrainConfig(num_pts=1000, num_cpts=64, resolution=128, motions_per_step=1, views_per_step=1, frames_per_step=1)
+    cfg.progressive_resolution = False
+    tr = make_cpu_trainer(cfg)
+    tr.step = 1000
+    tr.train_step()
+    t0 = time.time()
+    n = sum(tr.train_step() for _ in range(steps))
+    dt = time.time() - t0
+    return {"value": n / dt, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"{steps} train steps of 1 render (C1: 1000 Gaussians, 64 control points, 128x128, 1 motion x 1 "
+                      f"view x 1 frame): torch-CPU deform/losses/Adam + C oracle rasterizer; {dt:.1f} s"}
+
+
 def cpu_baseline(num_pts, resolution, renders=20):
     """Same train step on the host cores: product host logic + CPU oracle kernels (kind 'port')."""
     from dimo_amd.trainer import TrainConfig
@@ -142,14 +162,60 @@ def cpu_baseline(num_pts, resolution, renders=20):
                       f"(forward OpenMP over {cores} threads, backward single-threaded); {dt:.1f} s"}
 
 
+def render_fps(device, num_pts, resolution, rounds=500):
+    """The reference's one benchmark-like harness, `GUI.test_fps` (main_test_dimo.py:872-894): one warm-up render, then
+    `rounds` calls of `Renderer.render(test_cam, time=0, stage="s2")` on the azimuth-0 orbit camera at 512^2, nothing
+    read back -- here under `torch.no_grad()` and with a device sync before the clock stops (the reference's loop has
+    none: it times the enqueue).  Two figures: the calls as the drop-in surface runs them (queued behind `render()`, a
+    launch chain per 8 calls: dimo_amd/batched_render.py) and one by one (`batch_renders = False`: every call runs its
+    own chain before it returns its tensors)."""
+    from dimo_amd.camera import MiniCam, OrbitCamera, orbit_camera
+    from dimo_amd.rasterizer import CapacityPolicy
+    from dimo_amd.renderer import Renderer
+    from dimo_amd.synth import init_synthetic_model
+    from dimo_amd.trainer import TrainConfig, Trainer
+    cfg = TrainConfig(num_pts=num_pts, resolution=resolution)
+    rd = Renderer(sh_degree=0, white_background=True, radius=cfg.radius, num_latent_code=cfg.num_motions,
+                  latent_code_dim=cfg.latent_code_dim, add_normal=True, device=device,
+                  capacity=CapacityPolicy(initial=max(1 << 20, 40 * num_pts)))
+    init_synthetic_model(rd, cfg.num_pts, cfg.num_cpts, seed=0, regime="trained", num_latent=cfg.num_motions)
+    tr = Trainer(cfg, rd)  # (Morton order + the KNN `find_knn` of the harness)
+    tr.find_knn(k=4)
+    oc = OrbitCamera(resolution, resolution, r=cfg.radius, fovy=cfg.fovy)
+    out = {}
+    for name, batched in (("through_the_batcher", True), ("one_by_one", False)):
+        rd.batch_renders = batched
+        with torch.no_grad():
+            cam = MiniCam(orbit_camera(cfg.elevation, 0, cfg.radius), resolution, resolution, oc.fovy, oc.fovx, oc.near,
+                          oc.far, device=device)
+            rd.render(cam, time=0, stage="s2")
+            rd.flush()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(rounds):
+                rd.render(cam, time=0, stage="s2")
+            t_enq = time.perf_counter() - t0
+            rd.flush()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        out[name] = {"fps": rounds / dt, "fps_enqueue_only_as_the_reference_times_it": rounds / t_enq}
+    rd.batch_renders = True
+    out["what"] = ("GUI.test_fps (main_test_dimo.py:872-894): 1 warm-up + %d Renderer.render(test_cam, time=0, "
+                   "stage='s2') calls, %d Gaussians, %d^2, torch.no_grad(), device sync before the clock stops"
+                   % (rounds, num_pts, resolution))
+    del tr, rd
+    torch.cuda.empty_cache()
+    return out
+
+
 def dropin_figures(device, num_pts, resolution, per_gpu, steps=12):
     """frames/s of the C3 step through the drop-in surface ONLY.  Headline (`dropin_frames_per_s`): the reference's own
-    loop body, verbatim order of operations including its TensorBoard `.item()` reads (dimo_amd/reference_step.py
+    loop body, verbatim order of operations including its TensorBoard `.item()` reads (tests/reference_step.py
     restating main_train_dimo.py:246-417; Renderer.render + MiniCam per triple, torch.cat per motion, F.mse_loss per
     image, the ssim / smoothness drop-ins, ONE backward, optimizer.step).  Beside it: the same loop without the logging
     reads, with the geometry-anchor term and its per-render `.item()` (:295-303), and the repo's own reference-shaped
     trainer (`Trainer(direct=False)`: collects the outputs, one fused loss node per motion)."""
-    from dimo_amd.reference_step import ReferenceLoop
+    from tests.reference_step import ReferenceLoop
     from dimo_amd.rasterizer import CapacityPolicy
     from dimo_amd.renderer import Renderer
     from dimo_amd.synth import SyntheticTargets, init_synthetic_model
@@ -207,7 +273,7 @@ def dropin_figures(device, num_pts, resolution, per_gpu, steps=12):
     out["dropin_detail"] = detail
     out["dropin_what"] = ("C3 step through the drop-in surface only; headline = the reference's loop body in its own "
                           "order of operations INCLUDING its per-motion tb_writer .item() reads "
-                          "(dimo_amd/reference_step.py restates main_train_dimo.py:246-417): Renderer.render + MiniCam "
+                          "(tests/reference_step.py restates main_train_dimo.py:246-417): Renderer.render + MiniCam "
                           "per (motion, view, frame) triple, out[...].unsqueeze(0), torch.cat per motion, F.mse_loss per "
                           "image, ssim / smoothness drop-ins, ONE loss.backward(), FlatAdam.step; the step's renders run "
                           "as %.2f launch chain(s) per step behind render() (lazy outputs with deferred view / cat ops, "
@@ -728,7 +794,7 @@ def main():
         }
         if world == 1 and not args.no_dropin:
             # what a maintainer gets who only swaps the imports and keeps the reference's
-            # trainer: dimo_amd/reference_step.py restates GUI.train_step's loop body in its order of operations
+            # trainer: tests/reference_step.py restates GUI.train_step's loop body in its order of operations
             try:
                 del tr
                 torch.cuda.empty_cache()
@@ -769,12 +835,23 @@ def main():
             except Exception as e:
                 res["s1_frames_per_s"] = None
                 res["s1_what"] = f"failed: {e!r}"
+        if world == 1 and not args.no_dropin:
+            # the reference's own benchmark-like harness (main_test_dimo.py:872-894): render-only calls per second
+            try:
+                res["render_fps"] = render_fps(device, args.num_pts, args.resolution)
+            except Exception as e:
+                res["render_fps"] = {"what": f"failed: {e!r}"}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 res["cpu_baseline"] = cpu_baseline(args.num_pts, args.resolution)
             except Exception as e:  # the baseline must never take the GPU number down with it
                 res["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": f"failed: {e!r}"}
+            try:  # the C1 plumbing configuration on the same host cores
+                res["cpu_baseline_c1"] = cpu_baseline_c1()
+            except Exception as e:
+                res["cpu_baseline_c1"] = {"value": None, "unit": "frames/s", "cores": os.cpu_count(), "kind": "port",
+                                          "sample": f"failed: {e!r}"}
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()

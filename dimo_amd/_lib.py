@@ -60,7 +60,6 @@ _SIGNATURES = {
     "dimo_executor_destroy": (None, [C.c_void_p]),
     "dimo_executor_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "dimo_executor_forward_range": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
-    "dimo_executor_forward_range_on_caller": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "dimo_executor_join": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "dimo_executor_backward_launch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "dimo_executor_range_stream": (C.c_void_p, [C.c_void_p, C.c_int]),
@@ -84,6 +83,8 @@ _SIGNATURES = {
     "dimo_debug_blend_trace": (C.c_int64, [c_ptr, C.c_int64]),
     "dimo_image_loss": (C.c_int, [C.c_int] * 3 + [c_ptr] * 6 + [C.c_int, C.POINTER(C.c_float)] + [C.c_float] * 5
                         + [c_ptr] * 7 + [C.POINTER(C.c_void_p)] * 2 + [c_ptr]),
+    "dimo_ssim_image_loss": (C.c_int, [C.c_int] * 3 + [c_ptr] * 6 + [C.c_int, C.POINTER(C.c_float)] + [C.c_float] * 5
+                             + [c_ptr] * 8 + [C.POINTER(C.c_void_p)] * 2 + [c_ptr]),
 }
 
 ERRORS = {-1: "DIMO_E_ARG (bad argument)", -2: "DIMO_E_LAUNCH (HIP launch/runtime error)",

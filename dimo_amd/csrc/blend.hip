@@ -263,185 +263,6 @@ __device__ __forceinline__ void blend_fwd_body(
   }
 }
 
-// ---------------------------------------------------------------------------------- forward, accumulators on the MFMA pipe
-// The same tile walk with the eight per-visit accumulations -- seven features and the weight sum, 8 of the visit's 37
-// vector instructions -- as two v_mfma_f32_4x4x1_16b_f32: sixteen independent blocks of (4 x 1) x (1 x 4), block b =
-// lanes 4b .. 4b + 3.  Lane 4b + i supplies A = the weight w of ITS pixel, lane 4b + j supplies B = feature j of the
-// record (one ds_read2_b32 of the staged feature vector [r g b depth | nx ny nz 1] at word lane % 4 and 4 + lane % 4),
-// and lane 4b + j receives in register i the running sum of feature j (resp. 4 + j) over the visits for pixel 4b + i:
-// the accumulators live TRANSPOSED (a lane holds one feature of four neighbouring pixels of a row), which costs
-// nothing: the checkpoint planes and the output planes are written as float4 along the row, and the background term
-// T * bg of the colour is one more MFMA (A = T, B = bg[j] or 0).  The products and their order per pixel are those of
-// the FMA chain (K = 1: one multiply-add per instruction and accumulator element).  The matrix pipe is otherwise idle
-// in this kernel; whether the trade pays is a measurement: see fwd_mfma() below (it does not).
-typedef float f32x4_t __attribute__((ext_vector_type(4)));
-template <bool NORMAL>
-__device__ __forceinline__ void blend_fwd_body_mfma(
-    int H, int W, int tiles_x, const uint32_t *__restrict__ ranges, const uint32_t *__restrict__ vals_sorted,
-    const Splat *__restrict__ splat, const float *__restrict__ bg, float *__restrict__ out_color,
-    float *__restrict__ out_depth, float *__restrict__ out_normal, float *__restrict__ out_alpha,
-    float *__restrict__ final_T, uint32_t *__restrict__ n_contrib, float *__restrict__ final_acc,
-    float *__restrict__ ckpt, uint32_t *__restrict__ work, uint32_t chain, int tile) {
-  __shared__ uint32_t s_last[BLEND_BLOCK / 64];
-  __shared__ float4 s_geo[BATCH];       // x y A B
-  __shared__ float2 s_co[BATCH];        // C opacity
-  __shared__ float4 s_feat[BATCH][2];   // r g b depth | nx ny nz 1
-  __shared__ uint32_t s_mask[BATCH];
-
-  const int tile_x = tile % tiles_x, tile_y = tile / tiles_x;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  int px, py;
-  pixel_of_thread(tile_x, tile_y, px, py);
-  const bool inside = px < W && py < H;
-  const float pxf = (float)px, pyf = (float)py;
-  const uint32_t lo = ranges[2 * tile], hi = ranges[2 * tile + 1];
-
-  float T = 1.0f;
-  f32x4_t accA = {0.f, 0.f, 0.f, 0.f}, accB = {0.f, 0.f, 0.f, 0.f};  // feature lane % 4 / 4 + lane % 4 of 4 pixels
-  uint32_t last = 0;
-  const bool done = !inside;
-  float *const ck_tile = ckpt + ((size_t)(lo / BUCKET) + tile) * (CKPT_FLOATS * TILE * TILE);
-  const int fj = lane & 3, p4 = wave * 64 + (lane & ~3);  // this lane's feature; thread index of its first pixel
-  const float *const feat_lane = reinterpret_cast<const float *>(&s_feat[0][0]) + fj;
-
-  float Tw = done ? 0.0f : 1.0f;  // working transmittance: T while the pixel is alive, 0 once it has stopped
-#define DIMO_VISIT(G, CO, F0, F1, POS)                                                            \
-  {                                                                                               \
-    const float dx = G.x - pxf, dy = G.y - pyf;                                                   \
-    const float power = -0.5f * (G.z * dx * dx + CO.x * dy * dy) - G.w * dx * dy;                 \
-    const float alpha = fminf(ALPHA_MAX, CO.y * __expf(power));                                   \
-    const float test_T = Tw * (1.0f - alpha);                                                     \
-    const bool hit = power <= 0.0f && alpha >= ALPHA_MIN;                                         \
-    const bool add = hit && !(test_T < T_STOP);                                                   \
-    const float w = add ? alpha * Tw : 0.0f;                                                      \
-    accA = __builtin_amdgcn_mfma_f32_4x4x1f32(w, F0, accA, 0, 0, 0);                              \
-    accB = __builtin_amdgcn_mfma_f32_4x4x1f32(w, F1, accB, 0, 0, 0);                              \
-    T = add ? test_T : T;                                                                         \
-    last = add ? (POS) + 1u : last;                                                               \
-    Tw = hit ? (add ? test_T : 0.0f) : Tw;                                                        \
-  }
-#define DIMO_LOAD(G, CO, F0, F1, J) \
-  G = s_geo[J], CO = s_co[J], F0 = feat_lane[8 * (J)], F1 = feat_lane[8 * (J) + 4];
-
-  for (uint32_t start = lo; start < hi; start += BATCH) {
-    if (__syncthreads_count(Tw == 0.0f) == BLEND_BLOCK) break;
-    const uint32_t idx = start + threadIdx.x;
-    if (idx < hi) {
-      const float4 *rp = reinterpret_cast<const float4 *>(splat + vals_sorted[idx]);
-      const float4 a = rp[0], b = rp[1], c = rp[2];
-      s_geo[threadIdx.x] = a;
-      s_co[threadIdx.x] = make_float2(b.x, b.y);
-      s_feat[threadIdx.x][0] = make_float4(b.z, b.w, c.x, c.y);
-      s_feat[threadIdx.x][1] = make_float4(c.z, c.w, NORMAL ? rp[3].x : 0.0f, 1.0f);
-      s_mask[threadIdx.x] = quadrant_mask(a.x, a.y, a.z, a.w, b.x, b.y, tile_x, tile_y);
-    }
-    __syncthreads();
-    const int count = (int)min((uint32_t)BATCH, hi - start);
-#pragma unroll 1
-    for (int ch = 0; ch < BATCH / 64; ++ch) {
-      const int jb = ch * 64;
-      if (jb >= count) break;
-      if (__builtin_amdgcn_ballot_w64(Tw != 0.0f) == 0ull) break;  // every pixel of the quadrant has stopped
-      const uint32_t bucket = (start - lo) / BUCKET + (uint32_t)ch;
-      if (bucket != 0u && bucket % chain == 0u) {  // checkpoint: plane 0 = T (lane = pixel), planes 1 .. 8 transposed
-        float *ck = ck_tile + (size_t)bucket * (CKPT_FLOATS * TILE * TILE);
-        ck[threadIdx.x] = T;
-        *reinterpret_cast<f32x4_t *>(ck + (1 + fj) * (TILE * TILE) + p4) = accA;
-        *reinterpret_cast<f32x4_t *>(ck + (5 + fj) * (TILE * TILE) + p4) = accB;
-      }
-      const int j_lane = jb + lane;
-      unsigned long long bits = __builtin_amdgcn_ballot_w64(j_lane < count && ((s_mask[j_lane] >> wave) & 1u));
-      if (bits == 0ull) continue;
-      const uint32_t pos0 = (start - lo) + (uint32_t)jb;
-      float4 g0, g1;
-      float2 c0, c1;
-      float f00, f01, f10, f11;
-      int j0 = __builtin_ctzll(bits), j1 = 0;
-      bits &= bits - 1ull;
-      DIMO_LOAD(g0, c0, f00, f01, jb + j0)
-      while (true) {
-        const bool more1 = bits != 0ull;
-        if (more1) {
-          j1 = __builtin_ctzll(bits);
-          bits &= bits - 1ull;
-          DIMO_LOAD(g1, c1, f10, f11, jb + j1)
-        }
-        DIMO_VISIT(g0, c0, f00, f01, pos0 + (uint32_t)j0)
-        if (!more1) break;
-        const bool more0 = bits != 0ull;
-        if (more0) {
-          j0 = __builtin_ctzll(bits);
-          bits &= bits - 1ull;
-          DIMO_LOAD(g0, c0, f00, f01, jb + j0)
-        }
-        DIMO_VISIT(g1, c1, f10, f11, pos0 + (uint32_t)j1)
-        if (!more0) break;
-        if (__builtin_amdgcn_ballot_w64(Tw != 0.0f) == 0ull) break;  // checked once per two visits
-      }
-    }
-  }
-#undef DIMO_VISIT
-#undef DIMO_LOAD
-  const size_t HW = (size_t)H * W;
-  if (inside) {
-    const size_t pix = (size_t)py * W + px;
-    final_T[pix] = T;
-    n_contrib[pix] = last;
-  }
-  {
-    // the lane's four pixels: one row of the quadrant, columns qx .. qx + 3 (a multiple of 4 inside the image row)
-    const int qx = tile_x * TILE + (wave & 1) * 8 + (lane & 4), qy = tile_y * TILE + (wave >> 1) * 8 + (lane >> 3);
-    const float bgj = fj < 3 ? bg[fj] : 0.0f;
-    // colour = sum + T * bg: A = this lane's T, B = bg[j] (0 for the depth lane)
-    const f32x4_t colA = __builtin_amdgcn_mfma_f32_4x4x1f32(T, bgj, accA, 0, 0, 0);
-    float *const accA_dst = final_acc + (size_t)fj * HW, *const accB_dst = final_acc + (size_t)(4 + fj) * HW;
-    float *const outA = fj < 3 ? out_color + (size_t)fj * HW : out_depth;
-    float *const outB = fj < 3 ? (NORMAL ? out_normal + (size_t)fj * HW : nullptr) : out_alpha;
-    if (qy < H && qx < W) {
-      const size_t pix0 = (size_t)qy * W + qx;
-      const bool quads = (W & 3) == 0 &&
-                         (((reinterpret_cast<uintptr_t>(accA_dst) | reinterpret_cast<uintptr_t>(accB_dst) |
-                            reinterpret_cast<uintptr_t>(outA) | reinterpret_cast<uintptr_t>(outB)) & 15) == 0);
-      if (quads) {  // whole quads inside, 16-byte aligned
-        *reinterpret_cast<f32x4_t *>(accA_dst + pix0) = accA;
-        *reinterpret_cast<f32x4_t *>(accB_dst + pix0) = accB;
-        *reinterpret_cast<f32x4_t *>(outA + pix0) = colA;
-        if (outB) *reinterpret_cast<f32x4_t *>(outB + pix0) = accB;
-      } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          if (qx + i >= W) break;
-          accA_dst[pix0 + i] = accA[i], accB_dst[pix0 + i] = accB[i];
-          outA[pix0 + i] = colA[i];
-          if (outB) outB[pix0 + i] = accB[i];
-        }
-      }
-    }
-  }
-  // queue one backward item per chain of `chain` buckets some pixel of this tile reaches (as blend_fwd_body)
-  uint32_t m = last;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
-  if (lane == 0) s_last[wave] = m;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const uint32_t deepest = max(max(s_last[0], s_last[1]), max(s_last[2], s_last[3]));
-    const uint32_t nb = (deepest + BUCKET - 1) / BUCKET;
-    if (nb) {
-      const uint32_t ni = (nb + chain - 1) / chain;
-      const uint32_t T_ = gridDim.x;
-      uint4 *const q = reinterpret_cast<uint4 *>(work) + 1;
-      q[atomicAdd(work, 1u)] = make_uint4(((uint32_t)tile << 12), lo, hi, min(chain, nb));
-      if (ni > 1) q[T_ + atomicAdd(work + 1, 1u)] = make_uint4(((uint32_t)tile << 12) | chain, lo, hi, min(chain, nb - chain));
-      if (ni > 2) {
-        const uint32_t base = atomicAdd(work + 2, ni - 2);
-        for (uint32_t i = 2; i < ni; ++i)
-          q[2 * T_ + base + (i - 2)] = make_uint4(((uint32_t)tile << 12) | (i * chain), lo, hi, min(chain, nb - i * chain));
-      }
-    }
-  }
-}
-
 // ---------------------------------------------------------------------------------- backward
 // (wave reduction: wave_ops.hpp)
 //
@@ -708,11 +529,12 @@ __device__ __forceinline__ void blend_bwd_item(int H, int W, int tiles_x, uint32
 // the queues filled in tile order -- the blend backward took 278 us per 8 renders, from the front 270).  Virtual
 // item v = blockIdx.x, + gridDim.x, ...: render v % n, that render's (v / n)-th item, so the renders of a batch
 // interleave.
-// `order` (DIMO_BWD_ORDER, experiments): 0 = deep, second, heads (the default described above); 1 = heads, second, deep;
-// 2 = second, deep, heads; 3 = heads, deep, second; 4 = heads and the other two classes interleaved in proportion.
+// (Round 4 measured every other order of the three classes -- heads / second / deep first, a proportional interleave of
+// the heads with the rest -- and grids of 4 096 / 8 192 / 12 288 workgroups: 259-316 us per 8-render launch against
+// 256.5 for this one on 16 384; the switches are gone.)
 template <bool NORMAL, class VIEW>
 __device__ __forceinline__ void blend_bwd_loop(int H, int W, int tiles_x, uint32_t R_cap, const float *__restrict__ bg,
-                                               int n, VIEW view, uint32_t order = 0) {
+                                               int n, VIEW view) {
   __shared__ float4 s_geo[BUCKET];
   __shared__ float4 s_col[BUCKET];
   __shared__ float4 s_aux[BUCKET];
@@ -730,28 +552,7 @@ __device__ __forceinline__ void blend_bwd_loop(int H, int W, int tiles_x, uint32
     const BwdView r = view((int)(v % (uint32_t)n));
     const uint32_t local = v / (uint32_t)n, c0 = r.work[0], c1 = r.work[1], c2 = r.work[2];
     if (local >= c0 + c1 + c2) continue;
-    uint32_t slot;
-    if (order == 0) {
-      slot = local < c2 ? 2u * T + local : (local < c2 + c1 ? T + (local - c2) : local - c2 - c1);
-    } else if (order == 1) {
-      slot = local < c0 ? local : (local < c0 + c1 ? T + (local - c0) : 2u * T + (local - c0 - c1));
-    } else if (order == 2) {
-      slot = local < c1 ? T + local : (local < c1 + c2 ? 2u * T + (local - c1) : local - c1 - c2);
-    } else if (order == 3) {
-      slot = local < c0 ? local : (local < c0 + c2 ? 2u * T + (local - c0) : T + (local - c0 - c2));
-    } else {
-      // Bresenham merge of the heads with (deep, second): position `local` takes a head when the running share of
-      // heads steps up there
-      const uint32_t tot = c0 + c1 + c2;
-      const uint32_t ha = (uint32_t)(((unsigned long long)local * c0) / tot);
-      const uint32_t hb = (uint32_t)(((unsigned long long)(local + 1) * c0) / tot);
-      if (hb > ha) {
-        slot = ha;
-      } else {
-        const uint32_t o = local - ha;  // index among the others: deep first, then second
-        slot = o < c2 ? 2u * T + o : T + (o - c2);
-      }
-    }
+    const uint32_t slot = local < c2 ? 2u * T + local : (local < c2 + c1 ? T + (local - c2) : local - c2 - c1);
     const uint4 it = reinterpret_cast<const uint4 *>(r.work)[1 + slot];
     blend_bwd_item<NORMAL>(H, W, tiles_x, R_cap, bg, r, it, s_geo, s_col, s_aux, s_nz, s_mask, s_acc,
                            (int)(v % (uint32_t)n));
@@ -759,30 +560,20 @@ __device__ __forceinline__ void blend_bwd_loop(int H, int W, int tiles_x, uint32
 }
 
 // ---------------------------------------------------------------------------------- kernel entry points
-// MACC: the accumulators on the matrix pipe (blend_fwd_body_mfma) or in the lanes' own registers (the default)
-template <bool NORMAL, bool MACC>
+template <bool NORMAL>
 __global__ void __launch_bounds__(BLEND_BLOCK) blend_fwd_kernel(
     int H, int W, int tiles_x, const uint32_t *__restrict__ ranges, const uint32_t *__restrict__ vals_sorted,
     const Splat *__restrict__ splat, const float *__restrict__ bg, float *__restrict__ out_color,
     float *__restrict__ out_depth, float *__restrict__ out_normal, float *__restrict__ out_alpha,
     float *__restrict__ final_T, uint32_t *__restrict__ n_contrib, float *__restrict__ final_acc,
     float *__restrict__ ckpt, uint32_t *__restrict__ work, uint32_t chain) {
-  if (MACC)
-    blend_fwd_body_mfma<NORMAL>(H, W, tiles_x, ranges, vals_sorted, splat, bg, out_color, out_depth, out_normal,
-                                out_alpha, final_T, n_contrib, final_acc, ckpt, work, chain, (int)blockIdx.x);
-  else
-    blend_fwd_body<NORMAL>(H, W, tiles_x, ranges, vals_sorted, splat, bg, out_color, out_depth, out_normal, out_alpha,
-                           final_T, n_contrib, final_acc, ckpt, work, chain, (int)blockIdx.x);
+  blend_fwd_body<NORMAL>(H, W, tiles_x, ranges, vals_sorted, splat, bg, out_color, out_depth, out_normal, out_alpha,
+                         final_T, n_contrib, final_acc, ckpt, work, chain, (int)blockIdx.x);
 }
-// DIMO_FWD_MFMA=1 selects the matrix-pipe accumulators.  Measured (C3 step, 4 renders per launch, two motions in
-// flight): 124 us against 115 with the per-lane FMAs -- the visit has 27 vector instructions + 2 MFMAs instead of 37,
-// but a 4x4x1 MFMA holds the wave's issue for its two passes (8 cycles), which is what its four v_fmac_f32 cost (2
-// cycles each with register operands), and the per-lane feature fetch adds an address op and an LDS read; parity is
-// the same (tests/test_gpu_raster.py in a subprocess).  So the default stays the FMA chain.
-static bool fwd_mfma() {
-  static const bool on = getenv("DIMO_FWD_MFMA") && atoi(getenv("DIMO_FWD_MFMA")) == 1;
-  return on;
-}
+// (Round 4 also built the visit's eight accumulations on the matrix pipe -- two v_mfma_f32_4x4x1_16b_f32 per visit,
+// accumulators transposed: 27 vector instructions + 2 MFMAs instead of 37, parity identical -- and measured it slower,
+// 124 us against 115 per 4-render launch in the step: a 4x4x1 MFMA holds the wave's issue for its two passes, which is
+// what its four v_fmac_f32 cost.  profiles/r04_blend_fwd_mfma.txt; removed in round 5.)
 struct SingleView {
   BwdView v;
   __device__ __forceinline__ const BwdView &operator()(int) const { return v; }
@@ -791,14 +582,6 @@ template <bool NORMAL>
 __global__ void __launch_bounds__(64, BWD_WAVES_PER_SIMD) blend_bwd_kernel(int H, int W, int tiles_x, uint32_t R_cap,
                                                                             const float *__restrict__ bg, SingleView sv) {
   blend_bwd_loop<NORMAL>(H, W, tiles_x, R_cap, bg, 1, sv);
-}
-static uint32_t bwd_order() {
-  static const int v = getenv("DIMO_BWD_ORDER") ? atoi(getenv("DIMO_BWD_ORDER")) : 0;
-  return (uint32_t)(v >= 0 && v <= 4 ? v : 0);
-}
-static unsigned bwd_grid() {
-  static const int v = getenv("DIMO_BWD_GRID") ? atoi(getenv("DIMO_BWD_GRID")) : BWD_GRID;
-  return (unsigned)(v >= 256 && v <= (1 << 20) ? v : BWD_GRID);
 }
 
 // Batched entry points (native step executor): blockIdx.y = render of the batch (forward); the backward interleaves
@@ -809,7 +592,7 @@ struct BlendOffsets {
   size_t final_T, n_contrib, final_acc;         // img
   size_t flag;                                  // backward scratch: records at 0, flags here
 };
-template <bool NORMAL, bool MACC>
+template <bool NORMAL>
 __global__ void __launch_bounds__(BLEND_BLOCK) blend_fwd_batched_kernel(int H, int W, int tiles_x,
                                                                         const float *__restrict__ bg, BlendOffsets o,
                                                                         uint32_t chain, RenderBatch b) {
@@ -819,18 +602,11 @@ __global__ void __launch_bounds__(BLEND_BLOCK) blend_fwd_batched_kernel(int H, i
   const uint32_t lin = blockIdx.y * gridDim.x + blockIdx.x;
   const dimo_render_desc &r = b.r[lin % gridDim.y];
   const int tile = (int)at<uint32_t>(r.bin, o.order)[lin / gridDim.y];
-  if (MACC)
-    blend_fwd_body_mfma<NORMAL>(H, W, tiles_x, at<uint32_t>(r.bin, o.ranges), at<uint32_t>(r.bin, o.vals),
-                                at<Splat>(r.geom, o.splat), bg, r.out_color, r.out_depth,
-                                NORMAL ? r.out_normal : nullptr, r.out_alpha, at<float>(r.img, o.final_T),
-                                at<uint32_t>(r.img, o.n_contrib), at<float>(r.img, o.final_acc),
-                                at<float>(r.bin, o.ckpt), at<uint32_t>(r.bin, o.work), chain, tile);
-  else
-    blend_fwd_body<NORMAL>(H, W, tiles_x, at<uint32_t>(r.bin, o.ranges), at<uint32_t>(r.bin, o.vals),
-                           at<Splat>(r.geom, o.splat), bg, r.out_color, r.out_depth, NORMAL ? r.out_normal : nullptr,
-                           r.out_alpha, at<float>(r.img, o.final_T), at<uint32_t>(r.img, o.n_contrib),
-                           at<float>(r.img, o.final_acc), at<float>(r.bin, o.ckpt), at<uint32_t>(r.bin, o.work),
-                           chain, tile);
+  blend_fwd_body<NORMAL>(H, W, tiles_x, at<uint32_t>(r.bin, o.ranges), at<uint32_t>(r.bin, o.vals),
+                         at<Splat>(r.geom, o.splat), bg, r.out_color, r.out_depth, NORMAL ? r.out_normal : nullptr,
+                         r.out_alpha, at<float>(r.img, o.final_T), at<uint32_t>(r.img, o.n_contrib),
+                         at<float>(r.img, o.final_acc), at<float>(r.bin, o.ckpt), at<uint32_t>(r.bin, o.work),
+                         chain, tile);
 }
 template <bool NORMAL>
 struct BatchView {
@@ -855,24 +631,16 @@ __global__ void __launch_bounds__(64, BWD_WAVES_PER_SIMD) blend_bwd_batched_kern
                                                                                     uint32_t R_cap,
                                                                                     const float *__restrict__ bg,
                                                                                     BlendOffsets o, int n,
-                                                                                    RenderBatch b, uint32_t order) {
-  blend_bwd_loop<NORMAL>(H, W, tiles_x, R_cap, bg, n, BatchView<NORMAL>{b, o}, order);
+                                                                                    RenderBatch b) {
+  blend_bwd_loop<NORMAL>(H, W, tiles_x, R_cap, bg, n, BatchView<NORMAL>{b, o});
 }
-// Buckets per backward item.  Measured on the C3 batch (4 renders, ~10^4 buckets for 4096 wave slots): 189 / 231 /
-// 245 / 273 us per launch at 1 / 2 / 3 / 4 buckets per item -- what a longer chain saves in state loads it loses
-// several times over in the tail of the launch (fewer, longer items), so the default is one bucket per item and the
-// head bucket (no checkpoint to read) is where the traffic saving comes from.  DIMO_BWD_CHAIN overrides, for
-// experiments; the forward and the backward of a render must use the same value, so it is fixed per process.
-static uint32_t bwd_chain(int n) {
-  static const int forced = [] {
-    const char *e = getenv("DIMO_BWD_CHAIN");
-    const int v = e ? atoi(e) : 0;
-    return (v >= 1 && v <= 64) ? v : 0;
-  }();
-  if (forced) return (uint32_t)forced;
-  (void)n;
-  return 1u;
-}
+// Buckets per backward item: ONE.  The kernels take the number as an argument (an item walking 2-4 consecutive buckets
+// with the pixel state in registers, checkpoints only at chain starts, was built and oracle-tested in round 2), but
+// measured on the C3 batch (4 renders, ~10^4 buckets for 4096 wave slots) 189 / 231 / 245 / 273 us per launch at 1 / 2
+// / 3 / 4 buckets per item -- what a longer chain saves in state loads it loses several times over in the tail of the
+// launch -- so the switch that selected it is gone (round 5) and the head bucket (no checkpoint to read) is where the
+// traffic saving comes from.
+constexpr uint32_t BWD_CHAIN = 1u;
 
 static BlendOffsets blend_offsets(const GeomLayout &G, const BinLayout &B, const ImgLayout &I) {
   BlendOffsets o;
@@ -890,18 +658,13 @@ int blend_forward_batched(const dimo_step_common &c, const RenderBatch &b, int n
   ImgLayout I(c.H, c.W);
   if (c.bin_bytes < B.bytes || c.img_bytes < I.bytes) return DIMO_E_WORKSPACE;
   const BlendOffsets o = blend_offsets(G, B, I);
-  const uint32_t chain = bwd_chain(n);
+  const uint32_t chain = BWD_CHAIN;
   ScopedTimer tm(T_BLEND_FWD, stream);
-#define DIMO_LAUNCH_FWD(N_, M_)                                                                                     \
-  hipLaunchKernelGGL((blend_fwd_batched_kernel<N_, M_>), dim3(B.T, n), dim3(BLEND_BLOCK), 0, stream, c.H, c.W,      \
-                     B.tiles_x, c.bg, o, chain, b)
-  if (c.with_normal) {
-    if (fwd_mfma()) DIMO_LAUNCH_FWD(true, true);
-    else DIMO_LAUNCH_FWD(true, false);
-  } else {
-    if (fwd_mfma()) DIMO_LAUNCH_FWD(false, true);
-    else DIMO_LAUNCH_FWD(false, false);
-  }
+#define DIMO_LAUNCH_FWD(N_)                                                                                    \
+  hipLaunchKernelGGL((blend_fwd_batched_kernel<N_>), dim3(B.T, n), dim3(BLEND_BLOCK), 0, stream, c.H, c.W, B.tiles_x, \
+                     c.bg, o, chain, b)
+  if (c.with_normal) DIMO_LAUNCH_FWD(true);
+  else DIMO_LAUNCH_FWD(false);
 #undef DIMO_LAUNCH_FWD
   return check_launch();
 }
@@ -916,10 +679,9 @@ int blend_backward_batched(const dimo_step_common &c, const RenderBatch &b, int 
   const uint32_t cap = (uint32_t)B.cap;
   // (the "record written" flags were cleared by the placement's fill pass of this batch's forward: binning.hip)
   ScopedTimer tm(T_BLEND_BWD, stream);
-  // (the chain length is the one the forward of this batch used: bwd_chain(n) is a function of n only)
-#define DIMO_LAUNCH_BWD(N_, J_)                                                                                       \
-  hipLaunchKernelGGL((blend_bwd_batched_kernel<N_, J_>), dim3(bwd_grid()), dim3(64), 0, stream, c.H, c.W, B.tiles_x, \
-                     cap, c.bg, o, n, b, bwd_order())
+#define DIMO_LAUNCH_BWD(N_, J_)                                                                                     \
+  hipLaunchKernelGGL((blend_bwd_batched_kernel<N_, J_>), dim3(BWD_GRID), dim3(64), 0, stream, c.H, c.W, B.tiles_x, \
+                     cap, c.bg, o, n, b)
   if (c.with_normal) {
     if (joint) DIMO_LAUNCH_BWD(true, true);
     else DIMO_LAUNCH_BWD(true, false);
@@ -952,18 +714,13 @@ extern "C" int dimo_raster_render_forward(int N, int H, int W, int64_t R_cap, co
   const uint32_t *vals = at<uint32_t>(bin, B.vals_b);
   const Splat *splat = at<Splat>(geom, G.splat);
   ScopedTimer tm(T_BLEND_FWD, stream);
-#define DIMO_LAUNCH_FWD(N_, M_)                                                                                     \
-  hipLaunchKernelGGL((blend_fwd_kernel<N_, M_>), dim3(B.T), dim3(BLEND_BLOCK), 0, stream, H, W, B.tiles_x, ranges,   \
-                     vals, splat, bg, out_color, out_depth, out_normal, out_alpha, at<float>(img, I.final_T),        \
+#define DIMO_LAUNCH_FWD(N_)                                                                                     \
+  hipLaunchKernelGGL((blend_fwd_kernel<N_>), dim3(B.T), dim3(BLEND_BLOCK), 0, stream, H, W, B.tiles_x, ranges, vals, \
+                     splat, bg, out_color, out_depth, out_normal, out_alpha, at<float>(img, I.final_T),              \
                      at<uint32_t>(img, I.n_contrib), at<float>(img, I.final_acc), at<float>(bin, B.ckpt),            \
-                     at<uint32_t>(bin, B.work), bwd_chain(1))
-  if (out_normal) {
-    if (fwd_mfma()) DIMO_LAUNCH_FWD(true, true);
-    else DIMO_LAUNCH_FWD(true, false);
-  } else {
-    if (fwd_mfma()) DIMO_LAUNCH_FWD(false, true);
-    else DIMO_LAUNCH_FWD(false, false);
-  }
+                     at<uint32_t>(bin, B.work), BWD_CHAIN)
+  if (out_normal) DIMO_LAUNCH_FWD(true);
+  else DIMO_LAUNCH_FWD(false);
 #undef DIMO_LAUNCH_FWD
   return check_launch();
 }

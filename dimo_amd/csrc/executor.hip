@@ -415,26 +415,6 @@ extern "C" int dimo_executor_forward_range(void *h, const dimo_step_common *c, i
   return DIMO_OK;
 }
 
-// Batched ranges only: the forward chain of the range [first, first + count) ON THE CALLER'S STREAM, in order behind
-// what it holds (no cross-stream dependency: one costs 10-12 us on this platform, tools/xstream_latency.hip), while
-// other ranges of the step run on private streams.  dimo_executor_range_stream returns null for such a range and
-// dimo_executor_join / dimo_executor_backward_launch_joint have nothing to wait for.
-extern "C" int dimo_executor_forward_range_on_caller(void *h, const dimo_step_common *c, int first, int count,
-                                                     const dimo_render_desc *d, void *main_stream) {
-  Executor *ex = reinterpret_cast<Executor *>(h);
-  if (!ex || !c || first < 0 || count < 0 || (count > 0 && !d)) return DIMO_E_ARG;
-  if (count == 0) return DIMO_OK;
-  if (!ex->batched || ex->streams.empty()) return DIMO_E_ARG;
-  clear_errors();
-  const int rc = ensure_events(ex, first + count);
-  if (rc) return rc;
-  if (first == 0) std::fill(ex->range_stream.begin(), ex->range_stream.end(), -1);  // a new step's ranges
-  ex->range_stream[first] = (int)ex->streams.size(), ex->range_count[first] = count;  // marker: the caller's stream
-  ex->range_skinned[first] = 0;
-  if (wait_side_work(ex, (hipStream_t)main_stream, -1)) return DIMO_E_LAUNCH;
-  return batched_forward(c, d, first, count, (hipStream_t)main_stream);
-}
-
 extern "C" int dimo_executor_forward(void *h, const dimo_step_common *c, int n, const dimo_render_desc *d,
                                      void *main_stream) {
   return dimo_executor_forward_range(h, c, 0, n, d, main_stream);

@@ -19,6 +19,7 @@ namespace dimo {
 
 // many-instance Gaussians a workgroup sums with whole waves per (iteration, view); beyond: by their own threads
 constexpr int TAIL_BIG_MAX = 64;
+constexpr int TAIL_MAX_DYNAMIC_LDS = 160 * 1024 - 4096;  // the rest is the kernel's static LDS (the wave-sum table)
 
 // scalar base + 32-bit byte offset per lane (global_load / global_store with an SGPR base): a 64-bit address per lane
 // and array cost a register PAIR each, held across the views' loops -- the first build spilled 40 registers of them
@@ -178,11 +179,14 @@ __global__ void __launch_bounds__(DEF_BLOCK, 3) tail_bwd_batched_kernel(int N, i
 
 static void allow_big_lds_tail() {
   static const bool once = [] {
-    const int lim = 160 * 1024;
+    // (dynamic + static LDS together must fit the 160 KB of a CU: asking for all of it on top of the kernel's own
+    // 3.8 KB is refused with "invalid argument", which the next launch check then reports)
+    const int lim = TAIL_MAX_DYNAMIC_LDS;
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(tail_bwd_batched_kernel<true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lim);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(tail_bwd_batched_kernel<false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+    clear_errors();
     return true;
   }();
   (void)once;
@@ -198,6 +202,7 @@ int tail_backward_batched(const dimo_step_common &c, const RenderBatch &b, int g
   const size_t flag_offset = align_up((size_t)(c.R_cap > 0 ? c.R_cap : 1) * sizeof(SplatGrad));
   GaussIO g{c.xyz, c.rotation, c.scaling, c.opacity, c.nn_dist, c.nn_idx};
   const size_t lds = 2 * (size_t)c.M * CP_STRIDE * sizeof(float);
+  if (lds > (size_t)TAIL_MAX_DYNAMIC_LDS) return DIMO_E_ARG;  // (fused_tail() keeps such a model on the two-kernel path)
   allow_big_lds_tail();
   if (c.local_frame)
     hipLaunchKernelGGL(tail_bwd_batched_kernel<true>, dim3(grid, b.n_groups), dim3(DEF_BLOCK), lds, stream, c.N, c.M, c.H,

@@ -144,11 +144,9 @@ class StepExecutor:
         _lib.check(self.L.dimo_executor_forward(self.handle, C.addressof(self.common), n, C.addressof(self.descs),
                                                 _lib.current_stream()), "dimo_executor_forward")
 
-    def forward_range(self, first, count, on_caller=False):
-        """Forward chain of renders [first, first + count) on a private stream, or (on_caller) on the current stream
-        itself, in order: no cross-stream dependency for that range."""
-        fn = self.L.dimo_executor_forward_range_on_caller if on_caller else self.L.dimo_executor_forward_range
-        _lib.check(fn(self.handle, C.addressof(self.common), first, count,
+    def forward_range(self, first, count):
+        """Forward chain of renders [first, first + count) on a private stream (round-robin)."""
+        _lib.check(self.L.dimo_executor_forward_range(self.handle, C.addressof(self.common), first, count,
                                                       C.addressof(self.descs), _lib.current_stream()),
                    "dimo_executor_forward_range")
 

@@ -219,6 +219,8 @@ class GaussianModel(DensifyMixin, PlyMixin):
             {"params": [self._r], "lr": a.r_lr, "name": "r"},
         ]
 
+    FLAG_WORDS = 4  # floats in front of the gradients inside `flat_grads_ext` (16 bytes: the gradients stay aligned)
+
     def flatten_parameters(self, groups):
         """Re-home every trainable tensor (and its .grad) into one flat fp32 buffer each."""
         params = [p for g in groups for p in g["params"] if p.numel() > 0]
@@ -228,10 +230,12 @@ class GaussianModel(DensifyMixin, PlyMixin):
         total = sum(pad4(p.numel()) for p in params)
         flat = torch.zeros(total, dtype=torch.float32, device=self.device)
         # 4 extra floats ride along with the gradient bucket (and its all-reduce): [0] = "some render of this
-        # step overflowed its instance capacity on some rank" -> every replica skips the update together
-        self.flat_grads_ext = torch.zeros(total + 4, dtype=torch.float32, device=self.device)
-        grads = self.flat_grads_ext[:total]
-        self.grad_flag = self.flat_grads_ext[total:total + 1]
+        # step overflowed its instance capacity on some rank" -> every replica skips the update together.  They LEAD the
+        # bucket: the optimizer's early launch over the per-Gaussian head (Trainer: under the TimeNet backward, behind
+        # the head's own all-reduce) must see the same all-reduced flag as its late launch over the tail
+        self.flat_grads_ext = torch.zeros(self.FLAG_WORDS + total, dtype=torch.float32, device=self.device)
+        grads = self.flat_grads_ext[self.FLAG_WORDS:]
+        self.grad_flag = self.flat_grads_ext[0:1]
         o = 0
         with torch.no_grad():
             for p in params:

@@ -63,3 +63,38 @@ def fused_image_loss(image, depth, normal, alpha, gt, mask, w_mse, weights, ssim
         stream if stream is not None else _lib.current_stream()),
         "dimo_image_loss")
     return g_image, g_depth, g_normal, g_alpha
+
+
+def fused_ssim_image_loss(image, depth, normal, alpha, gt, mask, w_mse, weights, ssim_coef, ssim_sum, loss_accum,
+                          out=None, stream=None, g_dot=None):
+    """`fused_image_loss` with the SSIM term inside (dimo_ssim_image_loss: ONE tile pass, no SSIM gradient image in
+    between).  `ssim_coef`: 1-element device tensor, dL/d(mean SSIM of the batch) = -lambda_ssim x share;
+    `ssim_sum`: 1-element device tensor (zeroed by the caller) that receives the sum of the SSIM map.  Everything
+    else as `fused_image_loss`."""
+    if not image.is_cuda:
+        raise RuntimeError("dimo_amd.image_loss needs GPU tensors (no CPU fallback in the product path)")
+    B, _, H, W = image.shape
+    if loss_accum.numel() < LOSS_WORDS:
+        raise ValueError(f"loss_accum needs {LOSS_WORDS} floats (dimo_hip.h: DIMO_LOSS_WORDS)")
+    new = lambda ref: torch.empty_like(ref)
+    if out is None:
+        g_image, g_alpha = new(image), new(alpha)
+        g_depth = new(depth) if depth is not None else None
+        g_normal = new(normal) if normal is not None else None
+    else:
+        g_image, g_depth, g_normal, g_alpha = out
+    gt_list = mask_list = None
+    if isinstance(gt, (list, tuple)):
+        gt_list, gt = _lib.ptr_array(gt), None
+    if isinstance(mask, (list, tuple)):
+        mask_list, mask = _lib.ptr_array(mask), None
+    per_image = 1 if (mask is not None and mask.dim() == 4 and mask.shape[0] == B and B > 1) else 0
+    w_arr = (C.c_float * B)(*w_mse)
+    _lib.check(_lib.lib().dimo_ssim_image_loss(
+        B, H, W, _lib.ptr(image), _lib.ptr(depth), _lib.ptr(normal), _lib.ptr(alpha), _lib.ptr(gt), _lib.ptr(mask),
+        per_image, w_arr, weights["w_mask"], weights["w_smooth_x"], weights["w_smooth_y"], weights["w_bilat_x"],
+        weights["w_bilat_y"], _lib.ptr(ssim_coef), _lib.ptr(ssim_sum), _lib.ptr(loss_accum), _lib.ptr(g_image),
+        _lib.ptr(g_depth), _lib.ptr(g_normal), _lib.ptr(g_alpha), _lib.ptr(g_dot), gt_list, mask_list,
+        stream if stream is not None else _lib.current_stream()),
+        "dimo_ssim_image_loss")
+    return g_image, g_depth, g_normal, g_alpha

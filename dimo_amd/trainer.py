@@ -182,12 +182,10 @@ class Trainer:
                     grp["lr"] = 0.0
         self._last_loss = None
         self._consts = {}
+        self._ext_streams = {}
         self._deform_batch = None
         self._exec = None
-        self._graphed = {}
         import os
-        # opt-in: HIP-graph capture of the MLP (measured gain 4 %; the capture crashed one pytest run -> off)
-        self.graph_timenet = os.environ.get("DIMO_GRAPH_TIMENET", "0") == "1"
         # TimeNet as two native calls (dimo_amd/csrc/timenet.hip) in the direct pipeline; "0": PyTorch autograd MLP
         self.fused_timenet = os.environ.get("DIMO_FUSED_TIMENET", "1") == "1"
         self._fused_tn = None
@@ -195,26 +193,21 @@ class Trainer:
         self.skipped_steps = 0
         self.time_allreduce = False  # bench.py: event pairs around the step's collective (exposed time)
         self.allreduce_events = []
-        # the step's last motion on THIS stream instead of a private one: pays with the joint backward (which has to wait
-        # for every chain anyway: +1.2 %), costs with the per-motion backward (7330-7350 against 7395-7413 frames/s: the
-        # main stream's chain delays the skinning backward behind it).  Default: follows the backward mode
-        self._main_chain = int(os.environ["DIMO_MAIN_CHAIN"]) if "DIMO_MAIN_CHAIN" in os.environ else None
         self._flat_adam = type(self.optimizer).__name__ == "FlatAdam"
-        self._inorder_losses = os.environ.get("DIMO_INORDER_LOSSES", "1") == "1"
         # per-motion backward (default since round 4): every motion's chain -- forward, losses, rasterizer backward --
         # runs in order on ONE stream (the last motion's on this stream itself), so a motion's backward overlaps the
         # other motion's losses: 1.6-4 % more frames/s than the joint launch.  "1": ONE blend / projection
         # backward launch over all the step's renders on this stream (the kernel then runs alone on the device: bench.py
         # switches to it for the pass its roofline clock is taken in)
         self._joint_bwd = os.environ.get("DIMO_JOINT_BWD", "0") == "1"
-        self._joint_losses = os.environ.get("DIMO_JOINT_LOSSES", "0") == "1"
         # per-motion backward: the motion's SKINNING backward too in order on its stream (control-point sums staged,
         # one fold on this stream at the end) instead of one skinning backward per motion on this stream
         self._skin_in_order = os.environ.get("DIMO_SKIN_IN_ORDER", "1") == "1"
         self._split_adam = os.environ.get("DIMO_SPLIT_ADAM", "1") == "1"  # Adam's per-Gaussian head under the TimeNet backward
+        # SSIM and the other image terms of a motion in ONE tile pass (csrc/ssim.hip: dimo_ssim_image_loss) instead of
+        # the SSIM kernel followed by the loss kernel
+        self._fused_loss = os.environ.get("DIMO_FUSED_LOSS", "0") == "1"
         self._side_knn = os.environ.get("DIMO_SIDE_KNN", "1") == "1"  # KNN on a private stream next to the TimeNet forward
-        self._report_via_adam = os.environ.get("DIMO_REPORT", "1") == "1"  # "0": device-to-host copy + event per step
-        self._zero_via_adam = os.environ.get("DIMO_ZERO_NEXT", "1") == "1"  # "0": a fill launch per step
         self._direct_wanted = direct
         self._decide_direct()
 
@@ -432,28 +425,8 @@ class Trainer:
         return dxyz, dquat, {(m, v, f): pairs.index(key(m, v, f)) for (m, v, f) in triples}, lat
 
     def _timenet_batched(self, pts, times, lat):
-        """TimeNet on the whole step's batch.  On the GPU the MLP's forward and backward are each captured once
-        per batch shape into a HIP graph (torch.cuda.make_graphed_callables): ~190 eager launches of 2-20 us
-        kernels (2-3 ms of a 4.7 ms step with nothing else running) become two graph replays."""
-        g = self.renderer.gaussians
-        if not (self.graph_timenet and self.device.type == "cuda"):
-            return g._timenet(pts, times, lat, t_apply=True)
-        key = (tuple(times.shape), tuple(lat.shape))
-        fn = self._graphed.get(key)
-        if fn is None:
-            class _Batched(torch.nn.Module):
-                def __init__(self, net):
-                    super().__init__()
-                    self.net = net
-
-                def forward(self, p, t, l):
-                    return self.net(p, t, l, t_apply=True)
-
-            sample = (pts.detach().clone().requires_grad_(True), times.detach().contiguous().clone(),
-                      lat.detach().contiguous().clone().requires_grad_(True))
-            fn = torch.cuda.make_graphed_callables(_Batched(g._timenet), sample)
-            self._graphed[key] = fn
-        return fn(pts, times.contiguous(), lat.contiguous())
+        """TimeNet on the whole step's batch (the autograd module; the direct pipeline uses dimo_timenet_*)."""
+        return self.renderer.gaussians._timenet(pts, times, lat, t_apply=True)
 
     def motion_loss(self, outs, gts, masks, weights, n_img):
         """Loss of one motion's local images; mean-type terms carry the share len(outs)/n_img."""
@@ -575,27 +548,40 @@ class Trainer:
         return None
 
     def all_reduce_grads(self):
-        """The step's collective: the flat gradient bucket (+ its 4-float tail carrying the overflow flag), SUM.
-        When `all_reduce_point_grads_async` already sent the per-Gaussian head of the bucket (5.6 of 8.2 MB at
-        N = 100 k) under the TimeNet backward, only the tail is left here."""
+        """The step's collective: the flat gradient bucket behind its 4 flag floats (the overflow flag), SUM.  When the
+        per-Gaussian head of the bucket (5.6 of 8.2 MB at N = 100 k) went out early -- `all_reduce_point_grads_async`,
+        or the side-stream fold of `_forward_backward_direct` -- only the tail is left here."""
         if self.world > 1:
-            ext = self.renderer.gaussians.flat_grads_ext
+            g = self.renderer.gaussians
+            ext = g.flat_grads_ext
             pending, self._pending_ar = getattr(self, "_pending_ar", None), None
             if pending is not None:
                 work, split = pending
-                dist.all_reduce(ext[split:], op=dist.ReduceOp.SUM, group=self.pg)
-                work.wait()
+                dist.all_reduce(ext[g.FLAG_WORDS + split:], op=dist.ReduceOp.SUM, group=self.pg)
+                if work is not None:
+                    work.wait()
             else:
                 dist.all_reduce(ext, op=dist.ReduceOp.SUM, group=self.pg)
 
-    def all_reduce_point_grads_async(self):
-        """Starts the all-reduce of the per-Gaussian gradients (the head of the bucket) as soon as the last skinning
-        backward has accumulated into them; it runs on the collective library's stream while this stream goes on
-        with the TimeNet backward.  `all_reduce_grads` completes the step's reduction."""
+    def _set_grad_flag(self, tot):
+        """The overflow words of this rank's renders -> the flag float that leads the bucket (SUM over the ranks: any
+        non-zero word skips the update everywhere)."""
+        g = self.renderer.gaussians
+        if tot is not None and tot.numel() > 0:
+            g.grad_flag.copy_(tot[:, 1].max().to(torch.float32))
+        else:
+            g.grad_flag.zero_()
+
+    def all_reduce_point_grads_async(self, tot=None):
+        """Starts the all-reduce of the flag + the per-Gaussian gradients (the head of the bucket) as soon as the last
+        skinning backward has accumulated into them; it runs on the collective library's stream while this stream goes
+        on with the TimeNet backward.  `all_reduce_grads` completes the step's reduction."""
         g = self.renderer.gaussians
         split = getattr(g, "flat_split", 0)
         if self.world > 1 and self._flat_adam and split > 0:
-            work = dist.all_reduce(g.flat_grads_ext[:split], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+            self._set_grad_flag(tot)
+            work = dist.all_reduce(g.flat_grads_ext[:g.FLAG_WORDS + split], op=dist.ReduceOp.SUM, group=self.pg,
+                                   async_op=True)
             self._pending_ar = (work, split)
 
     # ------------------------------------------------------------------ forward + backward, two ways
@@ -641,7 +627,7 @@ class Trainer:
         become the update's skip flag; `report` = (words, pinned host slot, number) when the optimizer's launch hands
         them to the host (CapacityPolicy.collect_report), else None (a device-to-host copy behind the optimizer)."""
         cap = self.renderer.capacity_policy()
-        rep = cap.collect_report() if (cap is not None and self._report_via_adam) else None
+        rep = cap.collect_report() if cap is not None else None
         tot = rep[0] if rep is not None else (cap.collect_async(defer_copy=True) if cap is not None else None)
         return rep, tot
 
@@ -679,7 +665,7 @@ class Trainer:
         flat gradient bucket.  Only the (batched) TimeNet MLP uses autograd.  Same math as
         `_forward_backward_autograd` (tests compare the two)."""
         from . import _lib
-        from .image_loss import fused_image_loss, loss_weights
+        from .image_loss import fused_image_loss, fused_ssim_image_loss, loss_weights
         c, g, L = self.cfg, self.renderer.gaussians, _lib.lib()
         dev, stream = self.device, _lib.current_stream()
         H = W = self.render_resolution()
@@ -716,7 +702,7 @@ class Trainer:
         # between the TimeNet forward and the renders otherwise.  (`last_loss` of a step reads its buffer: valid until
         # the NEXT step's optimizer has run.)
         need = o_q + dquat_c.numel() + _LOSS_WORDS + n_motions
-        if self._flat_adam and self._zero_via_adam:
+        if self._flat_adam:
             pair = getattr(self, "_acc_bufs", None)
             if pair is None or pair[0].numel() != need:
                 pair = self._acc_bufs = [torch.zeros(need, **f32), torch.zeros(need, **f32)]
@@ -776,21 +762,14 @@ class Trainer:
                     torch.empty_like(alpha_all), torch.empty_like(alpha_all))  # (last: the backward's per-pixel S)
         loss_bufs = {m: tuple(None if t is None else t[first[m]:first[m] + len(trs)] for t in loss_all)
                      for m, trs in by_motion.items()}
-        # Joint backward (default): every motion's forward chain and losses run in order on its own stream; THIS stream
-        # then waits for all of them and runs the rasterizer backward as launches over up to 8 of the step's renders
-        # (38 us per render in an 8-render launch against 45-57 in two overlapping launches of four, and the kernel
-        # the roofline is quoted on runs alone).  Joint LOSSES (opt-in, DIMO_JOINT_LOSSES=1: one SSIM and one loss
-        # launch over all images after all forwards) measured slower, 5860 against 6000 frames/s: a motion's losses
-        # overlap the other motion's blend forward in the default.
-        joint_bwd = bool(ex.ranged and self._joint_bwd and self._inorder_losses and not c.use_lpips and n > 0)
-        joint = joint_bwd and self._joint_losses and n <= 32
-        # Joint backward: the LAST motion's chain (forward and losses) runs on this stream itself: it starts at once, where
-        # a private stream starts behind a cross-stream dependency (10-12 us on this platform, tools/xstream_latency.hip)
-        # and the joint backward waits for another one when it gets there: 6790 against 6710 frames/s.  (The other
-        # motions' losses on this stream as well, their forward long finished by then: 6650.)
-        in_order = bool(ex.ranged and self._inorder_losses and not c.use_lpips)
-        main_chain = (self._main_chain if self._main_chain is not None else int(joint_bwd)) if (in_order and not joint) else 0
-        main_motion = list(by_motion)[-1] if (main_chain and by_motion) else None
+        # Every motion's chain -- forward, losses, rasterizer and skinning backward -- runs in order on its own private
+        # stream (the default: a motion's backward overlaps the other motion's losses).  `_joint_bwd` (bench.py's roofline
+        # pass): the forwards and losses as above, then THIS stream waits for all of them and runs the rasterizer backward
+        # as launches over up to 8 of the step's renders -- the kernel the roofline is quoted on then runs alone on the
+        # device.  (Measured and removed: one SSIM / loss launch over all the step's images, 5860 against 6000 frames/s;
+        # the step's last motion on this stream itself, +1.2 % with the joint backward only.)
+        in_order = bool(ex.ranged and not c.use_lpips)
+        joint_bwd = bool(in_order and self._joint_bwd and n > 0)
         # Scalars produced on THIS stream (GA, KL, ARAP; LPIPS further down): summed apart from `loss_accum`, which the
         # private streams' kernels add to atomically.  They run BEFORE the forward forks: their gradient writes -- GA into
         # the TimeNet-row gradients `g_dxyz` and `_c_xyz.grad`, ARAP through autograd into the control points, the
@@ -814,10 +793,7 @@ class Trainer:
                 extra = reg.detach() if extra is None else extra + reg.detach()
         if ex.ranged:  # one batch per motion, on alternating private streams
             for m, trs in by_motion.items():
-                if m != main_motion:
-                    ex.forward_range(first[m], len(trs))
-            if main_motion is not None:
-                ex.forward_range(first[main_motion], len(by_motion[main_motion]), on_caller=True)
+                ex.forward_range(first[m], len(trs))
         else:
             ex.forward(n)
         self.renderer.capacity.track(ex.total_words(n))
@@ -825,43 +801,14 @@ class Trainer:
         loss_accum = zeroed[o_q + dquat_c.numel():o_q + dquat_c.numel() + _LOSS_WORDS]
         ssums = zeroed[o_q + dquat_c.numel() + _LOSS_WORDS:]
         ssim_terms, keep = [], []
-        if joint:
-            for m, trs in by_motion.items():
-                ex.join(first[m], len(trs))
-            order = [t for trs in by_motion.values() for t in trs]  # = render index order
-            gt_all = [x for m in by_motion for x in gathered[m][0]]
-            mask_all = [x for m in by_motion for x in gathered[m][1]]
-            share_all = n / n_img
-            ssum = ssums[0:1]
-            ssim_grad, *grad_out, g_dot = loss_all
-            _lib.check(L.dimo_ssim_forward_backward_images(n, 3, H, W, 1 | 2, _lib.ptr(img_all), _lib.ptr_array(gt_all),
-                                                           _lib.ptr(self._const(-c.lambda_ssim * share_all)),
-                                                           _lib.ptr(ssum), _lib.ptr(ssim_grad), stream),
-                       "dimo_ssim_forward_backward_images")
-            ssim_terms.append((ssum, c.lambda_ssim * share_all, float(n * 3 * H * W)))
-            w_mse = [c.lambda_mse * (1.0 if (v == 0 or f == 0) else 0.5) / (3 * H * W) for (_m, v, f) in order]
-            gi, gd, gn, ga = fused_image_loss(img_all, depth_all if depth_on else None,
-                                              normal_all if normal_on else None, alpha_all, gt_all, mask_all, w_mse,
-                                              loss_weights(c, n, n_img, H, W, depth_on, normal_on), ssim_grad,
-                                              loss_accum, out=tuple(grad_out), stream=stream, g_dot=g_dot)
-            keep.append((gi, gd, gn, ga, ssim_grad, g_dot, gt_all, mask_all))
-            for b in range(n):
-                d = ex.descs[b]
-                d.g_color, d.g_alpha = gi.data_ptr() + b * 3 * HW4, ga.data_ptr() + b * HW4
-                d.g_depth = (gd.data_ptr() + b * HW4) if gd is not None else None
-                d.g_normal = (gn.data_ptr() + b * 3 * HW4) if gn is not None else None
-                d.g_dot = (g_dot.data_ptr() + b * HW4) if g_dot is not None else None
         skinned = 0
         for m, trs in by_motion.items():
             B = len(trs)
-            share = B / n_img
-            if joint:
-                continue
             img, depth, normal, alpha = bufs[m]
             # batched ranges: this motion's losses and rasterizer backward continue ON ITS OWN STREAM, in order behind
             # its renders (no cross-stream event until the skinning backward); otherwise join this stream
             own = ex.range_stream(first[m]) if in_order else None
-            if own is None and m != main_motion:
+            if own is None:
                 ex.join(first[m], B)  # only this motion's renders: the other motions keep rendering underneath
             stream_m = own if own is not None else stream
             gt, mask = gathered[m]
@@ -872,7 +819,9 @@ class Trainer:
             ssim_grad, *grad_out, g_dot = loss_bufs[m]
             if c.use_lpips:  # the LPIPS gradient is added to g_image afterwards: S would be stale
                 g_dot = None
-            if B <= 32:
+            if self._fused_loss and B <= 64 and not c.use_lpips:
+                pass  # (the SSIM term runs inside the loss launch below)
+            elif B <= 32:
                 _lib.check(L.dimo_ssim_forward_backward_images(B, 3, H, W, 1 | 2, _lib.ptr(img), _lib.ptr_array(gt),
                                                                _lib.ptr(coef), _lib.ptr(ssum), _lib.ptr(ssim_grad),
                                                                stream_m), "dimo_ssim_forward_backward_images")
@@ -882,10 +831,16 @@ class Trainer:
                            "dimo_ssim_forward_backward")
             ssim_terms.append((ssum, c.lambda_ssim * share, float(B * 3 * H * W)))
             w_mse = [c.lambda_mse * (1.0 if (v == 0 or f == 0) else 0.5) / (3 * H * W) for (_m, v, f) in trs]
-            gi, gd, gn, ga = fused_image_loss(img, depth if depth_on else None, normal if normal_on else None,
-                                              alpha, gt, mask, w_mse,
-                                              loss_weights(c, B, n_img, H, W, depth_on, normal_on), ssim_grad,
-                                              loss_accum, out=tuple(grad_out), stream=stream_m, g_dot=g_dot)
+            if self._fused_loss and B <= 64 and not c.use_lpips:  # SSIM + every other image term: one tile pass
+                gi, gd, gn, ga = fused_ssim_image_loss(img, depth if depth_on else None, normal if normal_on else None,
+                                                       alpha, gt, mask, w_mse,
+                                                       loss_weights(c, B, n_img, H, W, depth_on, normal_on), coef, ssum,
+                                                       loss_accum, out=tuple(grad_out), stream=stream_m, g_dot=g_dot)
+            else:
+                gi, gd, gn, ga = fused_image_loss(img, depth if depth_on else None, normal if normal_on else None,
+                                                  alpha, gt, mask, w_mse,
+                                                  loss_weights(c, B, n_img, H, W, depth_on, normal_on), ssim_grad,
+                                                  loss_accum, out=tuple(grad_out), stream=stream_m, g_dot=g_dot)
             keep.append((gi, gd, gn, ga, ssim_grad, g_dot))
             if c.use_lpips:  # torch (MIOpen) on this stream, on the clamped render; its gradient joins the image's
                 x = img.detach().clamp(0.0, 1.0).requires_grad_(True)
@@ -901,7 +856,7 @@ class Trainer:
                 d.g_dot = (g_dot.data_ptr() + b * HW4) if g_dot is not None else None
             if joint_bwd:
                 pass  # one launch chain over all the step's renders, below
-            elif own is not None or (m == main_motion and in_order):
+            elif own is not None:
                 ex.backward_launch_in_order(first[m], B)  # (on the stream the motion's chain runs on)
                 if self._skin_in_order:  # ... and its skinning backward behind it (writes nothing shared)
                     ex.backward_skinning_in_order(first[m], B)
@@ -917,17 +872,26 @@ class Trainer:
             ex.backward_accumulate(0, n)
         elif skinned and skinned == len(by_motion):
             # every motion is skinned already: ONE fold over the step's renders
-            # (not with a motion's chain on THIS stream: the fold would run ahead of that motion's skinning backward)
-            side = ex.private_stream(0) if (self._split_adam and not s1 and self.world == 1 and self._flat_adam
-                                            and main_motion is None) else None
+            side = ex.private_stream(0) if (self._split_adam and not s1 and self._flat_adam and g.flat_split > 0) else None
             if side is not None:
                 # ... on private stream 0, followed there by the optimizer's update of the per-Gaussian head of the
                 # bucket (its gradients are final with the fold), NEXT TO the TimeNet backward on this stream, which only
-                # needs the motions' TimeNet-row gradients; the tail of the bucket is updated after it (train_step)
+                # needs the motions' TimeNet-row gradients; the tail of the bucket is updated after it (train_step).
+                # With several ranks the head's all-reduce (flag words + per-Gaussian gradients) sits between the two on
+                # that stream: RCCL's stream waits for the fold, the optimizer's launch for RCCL.
                 ex.join_ranges(0, n)
                 ex.backward_accumulate(0, n, stream=side)
                 counts = self._collect_counts()
-                self.optimizer.step(skip_flags=counts[1], zero_grad=True, part=("head", g.flat_split), stream=side)
+                skip = counts[1]
+                if self.world > 1:
+                    with torch.cuda.stream(self._external_stream(side)):
+                        self._set_grad_flag(counts[1])
+                        work = dist.all_reduce(g.flat_grads_ext[:g.FLAG_WORDS + g.flat_split], op=dist.ReduceOp.SUM,
+                                               group=self.pg, async_op=True)
+                        work.wait()  # (the side stream waits; the host only where the backend has no streams: gloo)
+                    self._pending_ar = (None, g.flat_split)
+                    skip = g.grad_flag.view(torch.int32)
+                self.optimizer.step(skip_flags=skip, zero_grad=True, part=("head", g.flat_split), stream=side)
                 ex.side_done(0)
                 self._adam_head = counts
             else:
@@ -936,9 +900,11 @@ class Trainer:
             for m, trs in by_motion.items():
                 ex.backward_accumulate(first[m], len(trs))
         self._mark("raster_bwd+skinning_bwd")
-        if not s1:  # (stage s1: the TimeNet backward below still adds its INPUT gradient to `_xyz.grad`, the head of
+        if not s1 and getattr(self, "_pending_ar", None) is None and self.world > 1:
+            # (stage s1: the TimeNet backward below still adds its INPUT gradient to `_xyz.grad`, the head of
             # the bucket -- found by the two-replica schedule test: the ranks' Gaussian counts drifted apart)
-            self.all_reduce_point_grads_async()
+            self._early_counts = self._collect_counts() if self._flat_adam else None
+            self.all_reduce_point_grads_async(self._early_counts[1] if self._early_counts else None)
         # the s1 densification statistics come from the step's last render (main_train_dimo.py:429-431)
         self._last_stats = None
         if s1 and n > 0:
@@ -960,6 +926,13 @@ class Trainer:
         # the scalar loss is only read for logging: it is assembled from these parts when `last_loss` is looked at
         # (a dozen 4-us elementwise launches per step otherwise)
         return _LazyLoss(loss_accum, ssim_terms, extra)
+
+    def _external_stream(self, handle):
+        """torch's view of one of the executor's private streams (for the collective the step enqueues there)."""
+        st = self._ext_streams.get(handle)
+        if st is None:
+            st = self._ext_streams[handle] = torch.cuda.ExternalStream(handle)
+        return st
 
     def _mark(self, name):
         if self.marks is not None:
@@ -1016,17 +989,16 @@ class Trainer:
             # no host sync at all: the overflow words of this step's renders become a device-side skip flag that
             # travels through the all-reduce; the host looks at them one step later (CapacityPolicy.poll)
             head, self._adam_head = getattr(self, "_adam_head", None), None
-            rep, tot = head if head is not None else self._collect_counts()
+            early, self._early_counts = getattr(self, "_early_counts", None), None
+            rep, tot = head if head is not None else (early if early is not None else self._collect_counts())
             # (device scalar, no read-back: a step whose renders overflowed must not feed the densification statistics --
             # stage s1 only, where they are gathered)
             self._step_overflow = tot[:, 1].max() if (tot is not None and self.stage == "s1") else None
             zero_next, self._zero_next = getattr(self, "_zero_next", None), None
             finals_before = getattr(self.optimizer, "finals", None)
-            if self.world > 1:  # the flag rides in the tail of the gradient bucket through the all-reduce
-                if tot is not None:
-                    g.grad_flag.copy_(tot[:, 1].max().to(torch.float32))
-                else:
-                    g.grad_flag.zero_()
+            if self.world > 1:  # the flag rides at the head of the gradient bucket through the all-reduce
+                if getattr(self, "_pending_ar", None) is None:  # (nothing went out early: the whole bucket now)
+                    self._set_grad_flag(tot)
                 timed = getattr(self, "time_allreduce", False) and self.device.type == "cuda"
                 if timed:  # exposed time of the collective on this stream (bench.py reports the mean)
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -1035,8 +1007,13 @@ class Trainer:
                 if timed:
                     e1.record()
                     self.allreduce_events.append((e0, e1))
-                self.optimizer.step(skip_flags=g.grad_flag.view(torch.int32), zero_grad=True, report=rep,
-                                    zero_extra=zero_next)
+                flag = g.grad_flag.view(torch.int32)
+                if head is not None:  # the head of the bucket has been updated under the TimeNet backward: the tail now
+                    self._exec.wait_side(0)
+                    self.optimizer.step(skip_flags=flag, zero_grad=True, report=rep, zero_extra=zero_next,
+                                        part=("tail", g.flat_split))
+                else:
+                    self.optimizer.step(skip_flags=flag, zero_grad=True, report=rep, zero_extra=zero_next)
             elif head is not None:  # the head of the bucket has been updated under the TimeNet backward: the tail now
                 self._exec.wait_side(0)
                 self.optimizer.step(skip_flags=tot, zero_grad=True, report=rep, zero_extra=zero_next,

@@ -210,6 +210,19 @@ int dimo_image_loss(int B, int H, int W, const float *image, const float *depth,
                     float *g_normal, float *g_alpha, float *g_dot, const float *const *gt_images_host,
                     const float *const *mask_images_host, void *stream);
 
+/* SSIM + the image losses above in ONE tile pass (csrc/ssim.hip: ssim_loss_tile_kernel): what
+ * dimo_ssim_forward_backward_images(B, 3, H, W, clamp | prezeroed, image, gt images, ssim_coef, ssim_sum, ssim_grad)
+ * followed by dimo_image_loss(..., ssim_grad, ...) computes -- main_train_dimo.py:331-372 with src/loss.py:64-106,
+ * 132-175 -- without the SSIM gradient image in between.  ssim_coef: ONE device float, dL/d(mean SSIM) (the trainer
+ * passes -lambda_ssim x share); *ssim_sum (device, zeroed by the caller) receives the sum of the SSIM map over the
+ * B x 3 planes.  Everything else as dimo_image_loss. */
+int dimo_ssim_image_loss(int B, int H, int W, const float *image, const float *depth, const float *normal,
+                         const float *alpha, const float *gt, const float *mask, int mask_per_image,
+                         const float *w_mse_host, float w_mask, float w_smooth_x, float w_smooth_y, float w_bilat_x,
+                         float w_bilat_y, const float *ssim_coef, float *ssim_sum, float *loss_accum, float *g_image,
+                         float *g_depth, float *g_normal, float *g_alpha, float *g_dot,
+                         const float *const *gt_images_host, const float *const *mask_images_host, void *stream);
+
 /* ------------------------------------------------------------------ fused skinning (stage s2 of Renderer.render)
  * One kernel for renderer/latent_gs_renderer.py:1187-1219: LBS weights w_k = L1norm(exp(-d_k^2/(2 r_k^2)) + 1e-7),
  * out_xyz = sum_k w_k (R(dq_k/|dq_k|)(x - c_k) + c_k + dc_k)   (local_frame != 0; else x + sum_k w_k dc_k),
@@ -379,19 +392,13 @@ int dimo_executor_backward_launch(void *executor, const dimo_step_common *common
 /* batched ranges (n_streams < 0): the private stream of the range that starts at render `first` (NULL if none), so
  * that the caller can enqueue the range's loss kernels behind its forward without a cross-stream join, and the
  * rasterizer backward continuing on that stream (no fork from a caller stream) */
-/* Batched ranges only: this range's forward chain on the CALLER's stream (in order, no cross-stream dependency) while
- * the step's other ranges use private streams; dimo_executor_range_stream is null for it, dimo_executor_join and
- * dimo_executor_backward_launch_joint do not wait for it.  (One of the motions of main_train_dimo.py:276-318.) */
-int dimo_executor_forward_range_on_caller(void *executor, const dimo_step_common *common, int first, int count,
-                                          const dimo_render_desc *renders, void *main_stream);
 void *dimo_executor_range_stream(void *executor, int first);
 /* Batched ranges only: the rasterizer backward of every range inside [first, first + count) in launches of up to 8
  * renders on the CALLER's stream, ordered behind what the ranges' private streams hold at the time of the call. */
 int dimo_executor_backward_launch_joint(void *executor, const dimo_step_common *common, int first, int count,
                                         const dimo_render_desc *descs, void *main_stream);
 /* Batched ranges only: the rasterizer backward of the range that starts at `first`, IN ORDER on the stream that ran
- * its forward chain (and its loss kernels) -- its private stream, or main_stream for a range rendered with
- * dimo_executor_forward_range_on_caller.  Per-motion backward: one motion's backward overlaps the other motion's
+ * its forward chain (and its loss kernels), its private stream.  Per-motion backward: one motion's backward overlaps the other motion's
  * loss kernels (each motion of main_train_dimo.py:276-318 is one range). */
 int dimo_executor_backward_launch_in_order(void *executor, const dimo_step_common *common, int first, int count,
                                            const dimo_render_desc *renders, void *main_stream);

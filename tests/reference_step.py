@@ -19,11 +19,11 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-from .camera import MiniCam, OrbitCamera, orbit_camera
-from .knn_cuda import KNN
-from .losses import compute_bilateral_normal_smoothness_loss, compute_edge_aware_smoothness_loss, ssim
-from .regularizers import chamfer_forward
-from .synth import default_azimuths, frame_times
+from dimo_amd.camera import MiniCam, OrbitCamera, orbit_camera
+from dimo_amd.knn_cuda import KNN
+from dimo_amd.losses import compute_bilateral_normal_smoothness_loss, compute_edge_aware_smoothness_loss, ssim
+from dimo_amd.regularizers import chamfer_forward
+from dimo_amd.synth import default_azimuths, frame_times
 
 
 class ReferenceLoop:

@@ -1,4 +1,4 @@
-"""The reference's OWN loop body through the drop-in surface (dimo_amd/reference_step.py restates
+"""The reference's OWN loop body through the drop-in surface (tests/reference_step.py restates
 main_train_dimo.py:246-417 in its order of operations: render -> [GA term on out["cpts_t"] + .item()] ->
 out[...].unsqueeze(0) -> torch.cat per motion -> per-image mse on batch[...][k] -> ssim -> mask mse -> smoothness terms
 on .permute(0, 2, 3, 1) -> the logged .item() reads -> ONE backward -> optimizer.step).
@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _setup(batch, N=5000, M=32, res=64, ga=False, chamfer=True, log=True, capacity=None, seed=3):
-    from dimo_amd.reference_step import ReferenceLoop
+    from tests.reference_step import ReferenceLoop
     from dimo_amd.renderer import Renderer
     from dimo_amd.synth import SyntheticTargets, init_synthetic_model
     from dimo_amd.trainer import TrainConfig

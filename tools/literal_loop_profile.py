@@ -1,4 +1,4 @@
-"""Host-side profile of the reference's loop body through the drop-in surface (dimo_amd/reference_step.py):
+"""Host-side profile of the reference's loop body through the drop-in surface (tests/reference_step.py):
 python tools/literal_loop_profile.py [--log 0|1] [--res 512] [--num-pts 100000]"""
 import argparse
 import cProfile
@@ -18,7 +18,7 @@ ap.add_argument("--steps", type=int, default=20)
 a = ap.parse_args()
 
 from dimo_amd.rasterizer import CapacityPolicy
-from dimo_amd.reference_step import ReferenceLoop
+from tests.reference_step import ReferenceLoop
 from dimo_amd.renderer import Renderer
 from dimo_amd.synth import SyntheticTargets, init_synthetic_model
 from dimo_amd.trainer import TrainConfig

@@ -1,14 +1,30 @@
-"""SSIM (one launch: value + gradient) and the fused image losses alone, per launch of B x 3 x 512^2:
-    python tools/loss_probe.py [B ...]"""
+"""The image-loss kernels alone, per launch of B x 3 x 512^2 (one motion's batch):
+  two kernels : SSIM value + gradient (ssim_fused) then the fused image losses (image_loss)
+  one pass    : dimo_ssim_image_loss (ssim_loss_tile_kernel)
+    python tools/loss_probe.py [B ...]        (DIMO_SSIM_WGS=3|4 selects the SSIM kernels' workgroups per CU)"""
 import os, sys
 sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '/root/repo'))
-import ctypes as C
 import torch
 from dimo_amd import _lib
-from dimo_amd.image_loss import fused_image_loss, LOSS_WORDS
+from dimo_amd.image_loss import fused_image_loss, fused_ssim_image_loss, LOSS_WORDS
 L = _lib.lib()
 st = _lib.current_stream()
 H = W = 512
+
+
+def timed(fn, n=40):
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return 1e3 * a.elapsed_time(b) / n
+
+
 for B in [int(a) for a in sys.argv[1:]] or [4, 8]:
     g = torch.Generator().manual_seed(B)
     img = (torch.rand(B, 3, H, W, generator=g) * 1.2 - 0.1).cuda()
@@ -19,19 +35,18 @@ for B in [int(a) for a in sys.argv[1:]] or [4, 8]:
     acc, gdot = torch.zeros(LOSS_WORDS, device="cuda"), torch.empty_like(alp)
     wts = dict(w_mask=1e-6, w_smooth_x=1e-6, w_smooth_y=1e-6, w_bilat_x=1e-6, w_bilat_y=1e-6)
     out = (torch.empty_like(img), torch.empty_like(dep), torch.empty_like(nrm), torch.empty_like(alp))
+    w_mse = [1e-6] * B
 
-    def once():
-        _lib.check(L.dimo_ssim_forward_backward(B, 3, H, W, 1, _lib.ptr(img), _lib.ptr(gt), _lib.ptr(coef),
+    def ssim():
+        _lib.check(L.dimo_ssim_forward_backward(B, 3, H, W, 1 | 2, _lib.ptr(img), _lib.ptr(gt), _lib.ptr(coef),
                                                 _lib.ptr(ssum), _lib.ptr(gs), st), "ssim")
-        fused_image_loss(img, dep, nrm, alp, gt, mask, [1e-6] * B, wts, gs, acc, out=out, g_dot=gdot)
-    for _ in range(5): once()
-    torch.cuda.synchronize()
-    L.dimo_timing_select(None); L.dimo_timing_enable(1)
-    for _ in range(30): once()
-    torch.cuda.synchronize(); L.dimo_timing_enable(0)
-    res = {}
-    for name in (b"ssim_fwd", b"image_loss"):
-        ms, n = C.c_double(0), C.c_int64(0)
-        L.dimo_timing_read(name, C.byref(ms), C.byref(n))
-        res[name.decode()] = 1e3 * ms.value / max(n.value, 1)
-    print("B = %d: SSIM value + gradient %.1f us, image losses %.1f us per launch" % (B, res["ssim_fwd"], res["image_loss"]))
+
+    def losses():
+        fused_image_loss(img, dep, nrm, alp, gt, mask, w_mse, wts, gs, acc, out=out, g_dot=gdot)
+
+    def one_pass():
+        fused_ssim_image_loss(img, dep, nrm, alp, gt, mask, w_mse, wts, coef, ssum, acc, out=out, g_dot=gdot)
+
+    t_s, t_l, t_o = timed(ssim), timed(losses), timed(one_pass)
+    print("B = %d, DIMO_SSIM_WGS=%s: SSIM value + gradient %.1f us + image losses %.1f us = %.1f us | one pass %.1f us"
+          % (B, os.environ.get("DIMO_SSIM_WGS", "3"), t_s, t_l, t_s + t_l, t_o))
