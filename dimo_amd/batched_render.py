@@ -66,10 +66,11 @@ class LazyTensor:
     any other torch function, method, operator or attribute -- runs the pending batch and works on the real tensor.
     A stand-in handed to a custom `autograd.Function.apply` or a C extension is NOT unwrapped by torch: pass
     `materialize(x)` there (the drop-ins of this package do)."""
-    __slots__ = ("_fn", "_val", "_meta", "_dev", "_src", "_defer", "unit_range", "__weakref__")
+    __slots__ = ("_fn", "_val", "_meta", "_dev", "_src", "_defer", "unit_range", "_rows", "__weakref__")
 
     def __init__(self, fn, meta=None, device=None, src=None, defer=True, unit_range=False):
         self._fn, self._val, self._meta, self._dev, self._src = fn, None, meta, device, src
+        self._rows = None
         self._defer = bool(defer and meta is not None)
         # values known to lie in [0, 1] (the clamped render and its views / concatenations): lets the fused smoothness
         # drop-ins, which read rgb as clamp(rgb, 0, 1), stand in for src/loss.py:64-106 without changing a value
@@ -135,7 +136,22 @@ class LazyTensor:
     def contiguous(self, *args, **kwargs):
         return self._derive("contiguous", args, kwargs, self._src)
 
+    def _row(self, i):
+        """`self[i]` for an integer i through ONE `unbind` of the tensor, shared by all rows: the reference's loss loop
+        takes `batch[...][k]` image by image (main_train_dimo.py:331-337), and a `select` per image is a backward node
+        per image that zero-fills and copies a WHOLE batch-sized gradient, the engine then adding them up one by one;
+        `unbind` is one node whose backward stacks the rows' gradients once."""
+        if self._rows is None:
+            self._rows = self.materialize().unbind(0)
+        return self._rows[i]
+
     def __getitem__(self, idx):
+        if self._fn is not None and self._defer and type(idx) is int and self._meta.dim() > 1:
+            n = self._meta.shape[0]
+            if -n <= idx < n:
+                parent = self
+                return LazyTensor(lambda: parent._row(idx), _meta(tuple(self._meta.shape[1:]), self._meta.dtype),
+                                  self._dev, None, unit_range=self.unit_range)
         if self._fn is not None and self._defer and _basic_index(idx):
             s = self._src
             lead = idx == (None, Ellipsis) or idx is None or idx == (None,)

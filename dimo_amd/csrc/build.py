@@ -38,6 +38,12 @@ if os.environ.get("DIMO_BWD_WAVES"):  # waves per SIMD the blend backward is com
 if os.environ.get("DIMO_BIN_TRACE") == "1":  # per-workgroup phase trace of the binning kernels (tools/bin_trace.py)
     SOURCES["binning.hip"] = SOURCES["binning.hip"] + ["-DDIMO_BIN_TRACE"]
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+# A/B builds (tools/ab.sh "@name" modes): DIMO_BUILD_VARIANT=name [DIMO_BUILD_EXTRA="flags for every file"] builds
+# csrc/variants/name.so from the same sources into its own object directory; the default library is untouched
+VARIANT = os.environ.get("DIMO_BUILD_VARIANT")
+if VARIANT:
+    LIB = os.path.join(HERE, "variants", VARIANT + ".so")
+    COMMON = COMMON + os.environ.get("DIMO_BUILD_EXTRA", "").split()
 
 
 def _hipcc():
@@ -58,8 +64,9 @@ def build(force=False, verbose=False):
     hipcc = _hipcc()
     headers = [os.path.join(HERE, h) for h in ("common.hpp", "wave_ops.hpp", "proj_math.hpp", "deform_body.hpp")] + \
               [os.path.join(HERE, "..", "..", "include", "dimo_hip.h"), __file__]
-    objdir = os.path.join(HERE, "build")
+    objdir = os.path.join(HERE, "build" + ("_" + VARIANT if VARIANT else ""))
     os.makedirs(objdir, exist_ok=True)
+    os.makedirs(os.path.dirname(LIB), exist_ok=True)
     jobs = []
     for src, extra in SOURCES.items():
         path = os.path.join(HERE, src)

@@ -463,7 +463,7 @@ int lbs_forward_batched(const dimo_step_common &c, const RenderBatch &b, int n, 
   allow_big_lds();
   ScopedTimer tm(T_DEFORM_FWD, stream);
   // the control-point table is re-built per workgroup: fewer, fatter workgroups per render when batching
-  static const int fwd_total = getenv("DIMO_LBS_FWD_WGS") ? atoi(getenv("DIMO_LBS_FWD_WGS")) : 512;
+  const int fwd_total = 512;
   const int grid = batched_grid(c.N, b.n_groups, fwd_total);
   if (c.local_frame)
     hipLaunchKernelGGL(lbs_fwd_batched_kernel<true>, dim3(grid, b.n_groups), dim3(DEF_BLOCK), lds, stream, c.N, c.M, g, c.c_xyz,
@@ -526,7 +526,7 @@ int lbs_backward_batched(const dimo_step_common &c, const RenderBatch &b, int n,
   // 768 = three workgroups (45 KB of LDS, 144 VGPRs) on each of the 256 CUs.  The kernel is a latency chain per wave
   // (1 700 VALU instructions and 32 LDS-atomic instructions per 64 Gaussians) with N / 64 waves per group in all, so
   // it wants every CU slot: with 128 workgroups per group (round 1) a launch of two groups ran one wave per SIMD.
-  static const int bwd_total = getenv("DIMO_LBS_WGS") ? atoi(getenv("DIMO_LBS_WGS")) : 768;
+  const int bwd_total = 768;
   const int grid = batched_grid(c.N, b.n_groups, bwd_total);
   float *partials = reinterpret_cast<float *>(static_cast<char *>(c.lbs_scratch) +
                                               (phase ? (size_t)first_abs * lbs_partials_slice(c.N, c.M) : 0));

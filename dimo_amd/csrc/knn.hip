@@ -509,7 +509,7 @@ extern "C" int dimo_knn_seeded(int M, int N, int k, const float *ref, const floa
   ScopedTimer tm(T_KNN, stream);
   if (k <= 4) {
     // at most three workgroups (12 waves) per CU: see knn4_kernel
-    static const int cap = getenv("DIMO_KNN_WGS") ? atoi(getenv("DIMO_KNN_WGS")) : 768;
+    const int cap = 768;
     const dim3 grid4((unsigned)((int)grid.x < cap || cap <= 0 ? (int)grid.x : cap));
     hipLaunchKernelGGL(knn4_kernel, grid4, dim3(KNN_BLOCK * KNN4_WAVES), 0, stream, M, N, k, ref, query, dist, idx,
                        seed_idx);

@@ -259,14 +259,11 @@ constexpr int MS = IS;           // row stride of a vertically filtered map (42 
 constexpr int MAP_WORDS = HS * MS;
 constexpr int PS = 52;           // row stride of a derivative plane on the 42 x 42 halo (same slot argument)
 constexpr int V_ROWS = 11;       // rows of the 42 a thread of the vertical pass produces (from 21 input rows)
-// 168 VGPRs: THREE workgroups per CU, persistent (grid = 3 x 256 CUs).  At 128 VGPRs (four per CU) the vertical pass
-// spilled 61 registers: 83 us against 51; one tile per workgroup instead of the persistent loop: 59.
+// THREE workgroups per CU, persistent (grid = 3 x 256 CUs).  Round 3's kernel needed 168 VGPRs (at 128, four per CU,
+// its vertical pass spilled 61: 83 us against 51); with the tile body as a device function (round 5) it needs 98, and
+// four per CU -- all of a CU's LDS -- measured the same 44 us alone and 0.3 % less in the step
+// (profiles/r05_one_pass_losses.txt): three stay.  One tile per workgroup instead of the persistent loop: 59 us.
 constexpr int SSIM_WGS_PER_CU = 3;
-// DIMO_SSIM_WGS=4 (experiments): four workgroups per CU -- 128 VGPRs, 4 x 40 KB = all of a CU's LDS
-static int ssim_wgs() {
-  static const int v = getenv("DIMO_SSIM_WGS") ? atoi(getenv("DIMO_SSIM_WGS")) : SSIM_WGS_PER_CU;
-  return v == 4 ? 4 : 3;
-}
 // Optional per-image base pointers of img2 (the targets of a batch live in a resident pool, one tensor per image:
 // stacking them cost two copy kernels per motion at the head of every step).  n == 0: img2 is one contiguous tensor.
 constexpr int SSIM_MAX_IMAGES = 32;
@@ -733,15 +730,11 @@ static int ssim_forward_backward_impl(int B, int C, int H, int W, int clamp_img1
     if (!ptrs.p[b]) return DIMO_E_ARG;
   static const Window win = make_window();
   const long tiles = (long)((W + TS - 1) / TS) * ((H + TS - 1) / TS) * planes;
-  const int wgs = ssim_wgs();
+  const int wgs = SSIM_WGS_PER_CU;
   const dim3 grid((unsigned)(tiles < wgs * 256 ? tiles : wgs * 256)), block(256);
   ScopedTimer tm(T_SSIM_FWD, stream);
-  if (wgs == 4)
-    hipLaunchKernelGGL(ssim_fused_kernel<4>, grid, block, 0, stream, H, W, (int)planes, clamp_img1, win, img1, img2, ptrs,
-                       dL_dmean, 1.0f / (float)((double)planes * H * W), ssim_sum, dL_dimg1);
-  else
-    hipLaunchKernelGGL(ssim_fused_kernel<3>, grid, block, 0, stream, H, W, (int)planes, clamp_img1, win, img1, img2, ptrs,
-                       dL_dmean, 1.0f / (float)((double)planes * H * W), ssim_sum, dL_dimg1);
+  hipLaunchKernelGGL(ssim_fused_kernel<SSIM_WGS_PER_CU>, grid, block, 0, stream, H, W, (int)planes, clamp_img1, win,
+                     img1, img2, ptrs, dL_dmean, 1.0f / (float)((double)planes * H * W), ssim_sum, dL_dimg1);
   return check_launch();
 }
 
@@ -772,7 +765,7 @@ extern "C" int dimo_ssim_image_loss(int B, int H, int W, const float *image, con
   prm.w_bilat_x = w_bilat_x, prm.w_bilat_y = w_bilat_y;
   static const Window win = make_window();
   const long units = (long)((W + TS - 1) / TS) * ((H + TS - 1) / TS) * B;
-  const int wgs = ssim_wgs();
+  const int wgs = SSIM_WGS_PER_CU;
   const dim3 grid((unsigned)(units < wgs * 256 ? units : wgs * 256)), block(256);
   const size_t mstride = mask_per_image ? (size_t)H * W : 0;
   const float inv_numel = 1.0f / (float)((double)B * 3 * H * W);
@@ -781,9 +774,7 @@ extern "C" int dimo_ssim_image_loss(int B, int H, int W, const float *image, con
   hipLaunchKernelGGL((ssim_loss_tile_kernel<D, N, G>), grid, block, 0, stream, H, W, B, win, prm, image, depth, normal, \
                      alpha, gt, mask, mstride, ssim_coef, inv_numel, ssim_sum, loss_accum, g_image, g_depth, g_normal, \
                      g_alpha, g_dot)
-#define DIMO_LAUNCH_SL(D, N)        \
-  if (wgs == 4) DIMO_LAUNCH_SL2(D, N, 4); \
-  else DIMO_LAUNCH_SL2(D, N, 3)
+#define DIMO_LAUNCH_SL(D, N) DIMO_LAUNCH_SL2(D, N, SSIM_WGS_PER_CU)
   if (depth && normal) { DIMO_LAUNCH_SL(true, true); }
   else if (depth) { DIMO_LAUNCH_SL(true, false); }
   else if (normal) { DIMO_LAUNCH_SL(false, true); }

@@ -228,45 +228,8 @@ struct WgradProblem {
 struct WgradArgs {
   WgradProblem p[MAX_LAYERS];
   int nprob, rows, kchunk;
-  int tiles, xcd;     // wgrad64_kernel: tiles per K chunk (1-D grid), 1 = XCD-contiguous virtual ids (DIMO_WGRAD_XCD)
-  int bisect;         // DIMO_WGRAD_BISECT (measurements): 1 no MFMAs, 2 no global loads after the first stage, 4 no
-                      // atomics, 8 no embedding backward
+  int tiles;          // wgrad64_kernel: tiles per K chunk (1-D grid)
 };
-
-__global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs g) {
-  __shared__ float As[BK][LDT], Bs[BK][LDT];
-  int pi = 0;
-  while (pi + 1 < g.nprob && (int)blockIdx.x >= g.p[pi + 1].tile_begin) ++pi;
-  const WgradProblem &p = g.p[pi];
-  const int tile = blockIdx.x - p.tile_begin;
-  const int tm = tile / p.tiles_n, tn = tile % p.tiles_n;
-  const int m0 = tm * BM, n0 = tn * BN;
-  const int kbeg = blockIdx.y * g.kchunk, kend = min(g.rows, kbeg + g.kchunk);
-  if (kbeg >= kend) return;
-  Acc acc;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) acc.c0[i] = 0.f, acc.c1[i] = 0.f;
-  float bsum = 0.f;
-  if (p.vec == 3) {  // (bit 0: dZ, bit 1: X may be loaded 16 bytes at a time)
-    if (tn == 0)
-      gemm_segment<false, false, true, true>(p.dZ, p.ld_dz, p.X, p.ld_x, p.M, p.N, m0, n0, kbeg, kend, As, Bs, acc, bsum);
-    else
-      gemm_segment<false, false, false, true>(p.dZ, p.ld_dz, p.X, p.ld_x, p.M, p.N, m0, n0, kbeg, kend, As, Bs, acc, bsum);
-  } else {
-    gemm_segment<false, false, true, false>(p.dZ, p.ld_dz, p.X, p.ld_x, p.M, p.N, m0, n0, kbeg, kend, As, Bs, acc, bsum);
-  }
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (tn == 0 && p.gbias && m0 + (int)(threadIdx.x & 31) < p.M) unsafeAtomicAdd(p.gbias + m0 + (threadIdx.x & 31), bsum);
-  const int mb = m0 + (wave >> 1) * 16 + 4 * (lane >> 4);
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const int n = n0 + (wave & 1) * 32 + 16 * h + (lane & 15);
-    if (n >= p.N) continue;
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-      if (mb + r < p.M) unsafeAtomicAdd(p.gW + (size_t)(mb + r) * p.ld_w + n, h ? acc.c1[r] : acc.c0[r]);
-  }
-}
 
 // ---- embedding -------------------------------------------------------------------------------------------------
 struct PairTable {
@@ -344,11 +307,6 @@ __device__ __forceinline__ void embed_bwd_body(int block, int rows, int Mc, int 
   }
 }
 
-__global__ __launch_bounds__(256) void embed_bwd_kernel(EmbedBwdArgs e) {
-  embed_bwd_body(blockIdx.x, e.rows, e.Mc, e.ld, e.pts_freqs, e.lat0, e.latent_dim, e.cat, e.g_cat, e.latent_row,
-                 e.g_c_xyz, e.g_latent_table);
-}
-
 // ---- the same grouped split-K problem on 64 x 64 tiles of v_mfma_f32_32x32x2_f32 ------------------------------------
 // In wgrad_kernel above a 16 x 32 wave tile reads three operands per two 16x16x4 MFMAs, and with the [k][m] staging at
 // leading dimension 65 the two 16-lane rows of a ds_read_b32 lane group overlap in 15 of 16 banks (bank = dword
@@ -412,19 +370,8 @@ __device__ __forceinline__ void wstore(float (*S)[W_T], uint32_t ok, const float
 // benchmark size, ten dependent rounds of loads each -- 10 us as a launch of its own behind this one).
 __global__ __launch_bounds__(256, 4) void wgrad64_kernel(WgradArgs g, EmbedBwdArgs e) {
   __shared__ __attribute__((aligned(16))) float As[W_K][W_T], Bs[W_K][W_T];
-  // Virtual workgroup id: the launch order by default.  DIMO_WGRAD_XCD=1 remaps so that every XCD (the dispatcher
-  // places workgroup b on XCD b % 8) gets a CONTIGUOUS range of ids, i.e. the tiles of one problem and K chunk, which
-  // read the same 90 KB operand blocks four to six times over, share an L2 (bijective for any grid size).  Measured
-  // SLOWER (101.6 against 93.2 us for the backward group): the launch is not bound by operand traffic (181 MB, mostly
-  // L2 / Infinity Cache hits either way) and the contiguous ranges leave the short last K chunk and the embedding
-  // blocks on single XCDs.
-  int v = (int)blockIdx.x;
-  if (g.xcd) {
-    const int T = (int)gridDim.x, b = (int)blockIdx.x, xcd = b & 7, q = T >> 3, r = T & 7;
-    v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
-  }
+  const int v = (int)blockIdx.x;
   if (v < e.nblocks) {
-    if (g.bisect & 8) return;
     embed_bwd_body(v, e.rows, e.Mc, e.ld, e.pts_freqs, e.lat0, e.latent_dim, e.cat, e.g_cat, e.latent_row, e.g_c_xyz,
                    e.g_latent_table);
     return;
@@ -455,7 +402,7 @@ __global__ __launch_bounds__(256, 4) void wgrad64_kernel(WgradArgs g, EmbedBwdAr
     wstore(As, oka, ra);
     wstore(Bs, okb, rb);
     __syncthreads();
-    if (it + 1 < nk && !(g.bisect & 2)) {  // in flight under this stage's MFMAs
+    if (it + 1 < nk) {  // in flight under this stage's MFMAs
       oka = wload(p.dZ, p.ld_dz, p.M, m0, kbeg + (it + 1) * W_K, kend, vec_a, ra);
       okb = wload(p.X, p.ld_x, p.N, n0, kbeg + (it + 1) * W_K, kend, vec_b, rb);
     }
@@ -466,7 +413,7 @@ __global__ __launch_bounds__(256, 4) void wgrad64_kernel(WgradArgs g, EmbedBwdAr
     const int valid = kend - (kbeg + it * W_K);  // k rows of this stage (the others are zero)
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
-      if ((half == 1 && valid <= W_K / 2) || (g.bisect & 1)) break;
+      if (half == 1 && valid <= W_K / 2) break;
       const int k0 = half * (W_K / 2);
       float a[2][2], b[2][2];
       a[0][0] = pa[k0 * W_T], b[0][0] = pb[k0 * W_T], a[0][1] = pa[(k0 + 2) * W_T], b[0][1] = pb[(k0 + 2) * W_T];
@@ -486,10 +433,6 @@ __global__ __launch_bounds__(256, 4) void wgrad64_kernel(WgradArgs g, EmbedBwdAr
 #pragma unroll
       for (int kk = 0; kk < 16; ++kk) bsum += As[(t >> 6) * 16 + kk][t & 63];
     }
-  }
-  if (g.bisect & 4) {
-    if (acc0[0] + acc1[3] + bsum == 12345.f) p.gW[0] = 1.f;  // (keeps the work alive)
-    return;
   }
   if (bias && m0 + (t & 63) < p.M) unsafeAtomicAdd(p.gbias + m0 + (t & 63), bsum);
   // accumulator layout of 32x32: lane l, register r: row 8 (r / 4) + 4 (l / 32) + r % 4, column l % 32
@@ -1084,22 +1027,6 @@ struct PackTArgs {
   PackTJob job[MAX_LAYERS + 2];
   int njobs;
 };
-__global__ __launch_bounds__(256) void pack_weights_t_kernel(PackTArgs a) {
-  const PackTJob &j = a.job[blockIdx.y];
-  const int total = j.ntiles * (FW / 16) * 64;  // float4s
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
-    const int lane = i & 63, blk = i >> 6;
-    const int nb = blk % (FW / 16), jt = blk / (FW / 16);
-    const int kq = lane >> 4, mn = lane & 15;
-    const int col = 16 * jt + mn, row = 16 * nb + 4 * kq;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (col < j.ncols) {
-      const float *p = j.W + (size_t)row * j.ldw + j.col0 + col;
-      v = make_float4(p[0], p[j.ldw], p[2 * (size_t)j.ldw], p[3 * (size_t)j.ldw]);
-    }
-    reinterpret_cast<float4 *>(j.out)[i] = v;
-  }
-}
 
 struct FusedBwdArgs {
   int R, E, CAT, D, skip;
@@ -1130,98 +1057,6 @@ __device__ __forceinline__ void fused_bwd_epilogue(const f32x4 &c0, const f32x4 
   }
 }
 
-__global__ __launch_bounds__(512) void timenet_bwd_fused_kernel(FusedBwdArgs g) {
-  __shared__ __attribute__((aligned(16))) float s_d[3][FR * FH_LD];
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int kq = lane >> 4, mn = lane & 15;
-  const int row0 = blockIdx.x * FR;
-  constexpr int HB = FW / 16;
-  // this lane's float4 of block 0 of the wave's tiles in a packed matrix with 16 (hidden) / 8 (embedding) tiles
-  auto hidden_w0 = [&](const float *packed) {
-    return reinterpret_cast<const float4 *>(packed) + (size_t)(2 * wave) * HB * 64 + lane;
-  };
-  auto embed_w0 = [&](const float *packed) {
-    return reinterpret_cast<const float4 *>(packed) + (size_t)wave * HB * 64 + lane;
-  };
-  float4 q0[FPF], q1[FPF];
-  {  // first ring: the head's first chunk (dZp Wp0)
-    const float4 *w0 = hidden_w0(g.Tp[g.D]), *w1 = w0 + HB * 64;
-#pragma unroll
-    for (int u = 0; u < FPF; ++u) q0[u] = w0[u * 64], q1[u] = w1[u * 64];
-  }
-  // dZp = (g_d_xyz Wp1) * (hp > 0), dZr = (g_d_rot Wr1) * (hr > 0)   (head_out_bwd_kernel's arithmetic)
-  for (int e = t; e < FR * FW; e += 512) {
-    const int m = e / FW, c = e % FW;
-    const int row = min(row0 + m, g.R - 1);
-    float vp = 0.f, vr = 0.f;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) vp = fmaf(g.g_d_xyz[row * 3 + i], g.Wp1[i * FW + c], vp);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) vr = fmaf(g.g_d_rot[row * 4 + i], g.Wr1[i * FW + c], vr);
-    vp = g.hp[(size_t)row * FW + c] > 0.f ? vp : 0.f;
-    vr = g.hr[(size_t)row * FW + c] > 0.f ? vr : 0.f;
-    s_d[0][m * FH_LD + c] = vp;
-    s_d[1][m * FH_LD + c] = vr;
-    if (row0 + m < g.R) g.dzp[(size_t)(row0 + m) * FW + c] = vp, g.dzr[(size_t)(row0 + m) * FW + c] = vr;
-  }
-  lds_barrier();
-  const float *xa0 = s_d[0] + mn * FH_LD + 4 * kq;  // A pointers of the three tiles
-  auto xa = [&](int tile) { return xa0 + tile * (FR * FH_LD); };
-  auto load_mask = [&](int l, float (&mk)[8]) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const size_t row = (size_t)min(row0 + 4 * kq + r, g.R - 1) * g.ld[l];
-      mk[r] = g.mask[l][row + wave * 32 + mn], mk[4 + r] = g.mask[l][row + wave * 32 + 16 + mn];
-    }
-  };
-  f32x4 cE = {0.f, 0.f, 0.f, 0.f}, unused = {0.f, 0.f, 0.f, 0.f};
-  int cur;
-  {  // head: dZ[D-1] = (dZp Wp0 + dZr Wr0) * (h[D-1] > 0)
-    float mk[8];
-    load_mask(g.D - 1, mk);
-    f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
-    const float4 *wp = hidden_w0(g.Tp[g.D]), *wr = hidden_w0(g.Tp[g.D + 2]), *wn = hidden_w0(g.Tp[g.D - 1]);
-    fused_chunk<HB>(xa(0), wp, wp + HB * 64, wr, wr + HB * 64, q0, q1, c0, c1);
-    fused_chunk<HB>(xa(1), wr, wr + HB * 64, wn, wn + HB * 64, q0, q1, c0, c1);
-    fused_bwd_epilogue(c0, c1, mk, s_d[2], g.dz[g.D - 1], g.ld[g.D - 1], row0, g.R, lane, wave);
-    cur = 2;
-    lds_barrier();
-  }
-  for (int l = g.D - 1; l >= 1; --l) {  // dZ[l-1] = (dZ[l] W_l[:, hidden columns]) * (h[l-1] > 0)
-    float mk[8];
-    load_mask(l - 1, mk);
-    f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
-    const float4 *w = hidden_w0(g.Tp[l]);
-    const bool with_embed = l - 1 == g.skip;  // this layer also read the embedding: gE += dZ[l] W_l[:, :E]
-    // what the ring runs on into: this layer's embedding chunk, the next layer's hidden chunk, or (l == 1) layer
-    // 0's embedding chunk
-    const float4 *e = with_embed ? embed_w0(g.TpE[l]) : nullptr;
-    const float4 *nx = l > 1 ? hidden_w0(g.Tp[l - 1]) : embed_w0(g.TpE[0]);
-    if (with_embed) {
-      fused_chunk<HB, 2, 1>(xa(cur), w, w + HB * 64, e, e, q0, q1, c0, c1);
-      if (l > 1) fused_chunk<HB, 1, 2>(xa(cur), e, e, nx, nx + HB * 64, q0, q1, cE, unused);
-      else fused_chunk<HB, 1, 1>(xa(cur), e, e, nx, nx, q0, q1, cE, unused);
-    } else if (l > 1) {
-      fused_chunk<HB, 2, 2>(xa(cur), w, w + HB * 64, nx, nx + HB * 64, q0, q1, c0, c1);
-    } else {
-      fused_chunk<HB, 2, 1>(xa(cur), w, w + HB * 64, nx, nx, q0, q1, c0, c1);
-    }
-    const int out = (cur + 1) % 3;
-    fused_bwd_epilogue(c0, c1, mk, s_d[out], g.dz[l - 1], g.ld[l - 1], row0, g.R, lane, wave);
-    cur = out;
-    lds_barrier();
-  }
-  {  // gE += dZ[0] W_0 ; the embedding gradient leaves the chip once
-    const float4 *e = embed_w0(g.TpE[0]);
-    fused_chunk<HB, 1, 1>(xa(cur), e, e, e, e, q0, q1, cE, unused);
-    const int col = 16 * wave + mn;
-    if (col < g.E) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (row0 + 4 * kq + r < g.R) g.g_cat[(size_t)(row0 + 4 * kq + r) * g.CAT + col] = cE[r];
-    }
-  }
-}
 
 // ---- the dgrad chain with 8 rows per workgroup (4x4x1 MFMA, see timenet_fwd_fused8_kernel) ------------------------
 // Same matmul sequence as timenet_bwd_fused_kernel; what differs:
@@ -1461,27 +1296,22 @@ void launch_gemm(const GemmArgs &g, int z, hipStream_t s) {
 // the one-launch forward handles the reference's shape class: width 256, at most one skip, embedding <= 112 columns,
 // every operand 16-byte aligned with row lengths that are multiples of 4
 bool fused_forward_ok(const dimo_timenet_desc *d, const Plan &pl) {
-  if (getenv("DIMO_TIMENET_UNFUSED")) return false;
   if (pl.Wd != FW || pl.E > FE_MAX || (pl.E & 3) || pl.E < 4 || d->D + 4 > MAX_LAYERS) return false;
   for (int l = 0; l < d->D + 4; ++l)
     if ((reinterpret_cast<uintptr_t>(d->weight[l]) & 15) != 0) return false;
   return true;
 }
 
-// rows per workgroup of the fused kernels: DIMO_TIMENET_ROWS (both directions) or the per-direction variable, 8 or 16
+// rows per workgroup of the fused FORWARD: 16 (default) or 8 (DIMO_TIMENET_ROWS_FWD=8)
 int timenet_rows(const char *var, int dflt) {
   const char *e = getenv(var);
-  if (!e) e = getenv("DIMO_TIMENET_ROWS");
   const int v = e ? atoi(e) : dflt;
   return v == 8 || v == 16 ? v : dflt;
 }
 
-// workgroups per packed matrix: one float4 per thread at 64 (the loops are grid-stride; 16 until the end of round 4,
-// four to six dependent rounds per thread on the step's critical path); DIMO_PACK_WGS overrides
-unsigned pack_wgs() {
-  static const int v = getenv("DIMO_PACK_WGS") ? atoi(getenv("DIMO_PACK_WGS")) : 64;
-  return (unsigned)(v >= 1 && v <= 1024 ? v : 64);
-}
+// workgroups per packed matrix: one float4 per thread (the loops are grid-stride; 16 until the end of round 4, four to
+// six dependent rounds per thread on the step's critical path)
+unsigned pack_wgs() { return 64u; }
 
 bool fill_pairs(int P, const float *times, const int *rows, PairTable &pt) {
   if (P > MAX_PAIRS) return false;
@@ -1490,10 +1320,6 @@ bool fill_pairs(int P, const float *times, const int *rows, PairTable &pt) {
 }
 
 // the dgrad chain's packed (transposed) weights of every layer; fills g.Tp / g.TpE when `g` is given
-bool bwd_rows8() {
-  static const bool rows8 = timenet_rows("DIMO_TIMENET_ROWS_BWD", 8) == 8;
-  return rows8;
-}
 void pack_t_jobs(const dimo_timenet_desc *d, const Plan &pl, float *ws, PackTArgs &pa, FusedBwdArgs *g) {
   const int D = d->D, Wd = pl.Wd;
   for (int l = 0; l < D + 4; ++l) {
@@ -1509,14 +1335,10 @@ void pack_t_jobs(const dimo_timenet_desc *d, const Plan &pl, float *ws, PackTArg
       if (g) g->TpE[l] = j.out;
     }
   }
-  if (bwd_rows8())  // column groups of 64 instead of tiles of 16
-    for (int k = 0; k < pa.njobs; ++k) pa.job[k].ntiles /= 4;
+  for (int k = 0; k < pa.njobs; ++k) pa.job[k].ntiles /= 4;  // (column groups of 64, not tiles of 16)
 }
 void launch_pack_t(const PackTArgs &pa, hipStream_t s) {
-  if (bwd_rows8())
-    pack_weights_t_quads_kernel<<<dim3(pack_wgs(), pa.njobs), 256, 0, s>>>(pa);
-  else
-    pack_weights_t_kernel<<<dim3(pack_wgs(), pa.njobs), 256, 0, s>>>(pa);
+  pack_weights_t_quads_kernel<<<dim3(pack_wgs(), pa.njobs), 256, 0, s>>>(pa);
 }
 
 }  // namespace
@@ -1569,18 +1391,11 @@ extern "C" int dimo_timenet_forward(const dimo_timenet_desc *d, int P, int M, co
     static const bool rows8 = timenet_rows("DIMO_TIMENET_ROWS_FWD", 16) == 8;
     if (rows8) {
       pack_weights_quads_kernel<<<dim3(pack_wgs(), pa.njobs), 256, 0, s>>>(pa);
-      static const int bisect = getenv("DIMO_TIMENET_BISECT") ? atoi(getenv("DIMO_TIMENET_BISECT")) : 0;
-      if (bisect == 1) timenet_fwd_fused8_kernel<1><<<(R + R8 - 1) / R8, 1024, 0, s>>>(g);
-      else if (bisect == 2) timenet_fwd_fused8_kernel<2><<<(R + R8 - 1) / R8, 1024, 0, s>>>(g);
-      else timenet_fwd_fused8_kernel<0><<<(R + R8 - 1) / R8, 1024, 0, s>>>(g);
+      timenet_fwd_fused8_kernel<0><<<(R + R8 - 1) / R8, 1024, 0, s>>>(g);
       return check_launch();
     }
     pack_weights_kernel<<<dim3(pack_wgs(), pa.njobs), 256, 0, s>>>(pa);
-    static const bool wide = !getenv("DIMO_TIMENET_8WAVES");
-    if (wide)
-      timenet_fwd_fused_kernel<16><<<(R + FR - 1) / FR, 1024, 0, s>>>(g);
-    else
-      timenet_fwd_fused_kernel<8><<<(R + FR - 1) / FR, 512, 0, s>>>(g);
+    timenet_fwd_fused_kernel<16><<<(R + FR - 1) / FR, 1024, 0, s>>>(g);
     return check_launch();
   }
   {
@@ -1628,7 +1443,7 @@ extern "C" int dimo_timenet_backward(const dimo_timenet_desc *d, int P, int M, c
   ScopedTimer timer(T_TIMENET_BWD, s);
   float *ws = static_cast<float *>(workspace);
   const int R = pl.rows, D = d->D, Wd = pl.Wd;
-  const bool fused = fused_forward_ok(d, pl) && !getenv("DIMO_TIMENET_UNFUSED_BWD");
+  const bool fused = fused_forward_ok(d, pl);
   if (fused) {
     PackTArgs pa = {};
     FusedBwdArgs g = {};
@@ -1643,12 +1458,9 @@ extern "C" int dimo_timenet_backward(const dimo_timenet_desc *d, int P, int M, c
     // more than that -- backward group 106 -> 119 us in the step, 8098 -> 8054 frames/s; packed NEXT TO the forward on
     // a private stream, the forward (bound by its own weight stream) went 69 -> 79 us, 8073 -> 7982 frames/s.
     launch_pack_t(pa, s);
-    // the dgrad chain: 8 rows per workgroup on every CU (4x4x1 MFMA; 103 against 115 us for the backward group, and
-    // the same in the training step, where only the optimizer's early part runs next to it); DIMO_TIMENET_ROWS_BWD=16
-    if (bwd_rows8())
-      timenet_bwd_fused8_kernel<<<(R + R8 - 1) / R8, 1024, 0, s>>>(g);
-    else
-      timenet_bwd_fused_kernel<<<(R + FR - 1) / FR, 512, 0, s>>>(g);
+    // the dgrad chain: 8 rows per workgroup on every CU (4x4x1 MFMA; 103 against 115 us for the backward group with
+    // round 4's 16-row chain on 16x16x4, and the same in the training step; that chain is gone since round 5)
+    timenet_bwd_fused8_kernel<<<(R + R8 - 1) / R8, 1024, 0, s>>>(g);
   }
   if (!fused) {
     const int n = R * Wd;
@@ -1692,10 +1504,10 @@ extern "C" int dimo_timenet_backward(const dimo_timenet_desc *d, int P, int M, c
     eb.nblocks = (eb.g_c_xyz || eb.g_latent_table) ? (R + 63) / 64 : 0;
   }
   {  // every weight / bias gradient in one grouped split-K launch
-    // DIMO_WGRAD=32: the 32 x 64 tiles of 16x16x4 MFMAs (rounds 2-4) and the embedding backward as a launch of its own;
-    // default: 64 x 64 tiles of 32x32x2 (wgrad64_kernel), the embedding backward in the same launch
-    static const bool wide = !(getenv("DIMO_WGRAD") && atoi(getenv("DIMO_WGRAD")) == 32);
-    const int tM = wide ? W_T : BM, tN = wide ? W_T : BN;
+    // 64 x 64 tiles of 32x32x2 MFMAs (wgrad64_kernel), the embedding backward in the same launch.  (Rounds 2-4 ran
+    // 32 x 64 tiles of 16x16x4 MFMAs with 2-way LDS bank conflicts on every operand and the embedding backward as a
+    // launch of its own: profiles/r04_timenet_wgrad64.txt; removed in round 5.)
+    const int tM = W_T, tN = W_T;
     WgradArgs w = {};
     int tiles = 0, np = 0;
     auto add = [&](const float *dz, int ld_dz, const float *x, int ld_x, int Mo, int No, int li) {
@@ -1718,26 +1530,17 @@ extern "C" int dimo_timenet_backward(const dimo_timenet_desc *d, int P, int M, c
     add(ws + pl.dzr, Wd, hlast, ldl, Wd, Wd, D + 2);
     add(g_d_rot, 4, ws + pl.hr, Wd, 4, Wd, D + 3);
     w.nprob = np, w.rows = R;
-    if (wide) {
-      // ONE round of workgroups: four per CU (DIMO_WGRAD_WGS overrides the target), K chunks of whole half stages
-      static const int target = getenv("DIMO_WGRAD_WGS") ? atoi(getenv("DIMO_WGRAD_WGS")) : 1024;
+    {
+      // ONE round of workgroups, four per CU; K chunks of whole half stages.  (Measured and removed: XCD-contiguous
+      // workgroup ids, 101.6 against 93.2 us for the backward group; 512 / 2048 / 4096 workgroups, 105 / 97 / 111.)
+      const int target = 1024;
       const int halves = (R + W_K / 2 - 1) / (W_K / 2);
       int ksplit = (target + tiles / 2) / tiles;
       ksplit = ksplit < 1 ? 1 : (ksplit > halves ? halves : ksplit);
       w.kchunk = ((halves + ksplit - 1) / ksplit) * (W_K / 2);
       ksplit = (R + w.kchunk - 1) / w.kchunk;
-      static const bool xcd = getenv("DIMO_WGRAD_XCD") && atoi(getenv("DIMO_WGRAD_XCD")) == 1;
-      static const int bisect = getenv("DIMO_WGRAD_BISECT") ? atoi(getenv("DIMO_WGRAD_BISECT")) : 0;
-      w.tiles = tiles, w.xcd = xcd, w.bisect = bisect;
+      w.tiles = tiles;
       wgrad64_kernel<<<dim3(eb.nblocks + tiles * ksplit), 256, 0, s>>>(w, eb);
-    } else {
-      // ~8 K-slices: enough workgroups to fill 256 CUs several times over, few enough atomics per element
-      int ksplit = (R + 255) / 256;
-      ksplit = ksplit < 1 ? 1 : (ksplit > 64 ? 64 : ksplit);
-      w.kchunk = (((R + ksplit - 1) / ksplit) + BK - 1) / BK * BK;
-      ksplit = (R + w.kchunk - 1) / w.kchunk;
-      wgrad_kernel<<<dim3(tiles, ksplit), 256, 0, s>>>(w);
-      if (eb.nblocks) embed_bwd_kernel<<<eb.nblocks, 256, 0, s>>>(eb);
     }
   }
   return check_launch();

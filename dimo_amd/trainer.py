@@ -186,8 +186,8 @@ class Trainer:
         self._deform_batch = None
         self._exec = None
         import os
-        # TimeNet as two native calls (dimo_amd/csrc/timenet.hip) in the direct pipeline; "0": PyTorch autograd MLP
-        self.fused_timenet = os.environ.get("DIMO_FUSED_TIMENET", "1") == "1"
+        # TimeNet as two native calls (dimo_amd/csrc/timenet.hip) in the direct pipeline; False: PyTorch autograd MLP
+        self.fused_timenet = True
         self._fused_tn = None
         self.marks = None  # set to [] to collect (name, torch.cuda.Event) phase marks on the main stream
         self.skipped_steps = 0
@@ -195,19 +195,21 @@ class Trainer:
         self.allreduce_events = []
         self._flat_adam = type(self.optimizer).__name__ == "FlatAdam"
         # per-motion backward (default since round 4): every motion's chain -- forward, losses, rasterizer backward --
-        # runs in order on ONE stream (the last motion's on this stream itself), so a motion's backward overlaps the
-        # other motion's losses: 1.6-4 % more frames/s than the joint launch.  "1": ONE blend / projection
+        # runs in order on ONE private stream, so a motion's backward overlaps the other motion's losses: 1.6-4 % more
+        # frames/s than the joint launch.  DIMO_JOINT_BWD=1: ONE blend / projection
         # backward launch over all the step's renders on this stream (the kernel then runs alone on the device: bench.py
         # switches to it for the pass its roofline clock is taken in)
         self._joint_bwd = os.environ.get("DIMO_JOINT_BWD", "0") == "1"
+        # The three below are attributes, not switches: their "False" paths are what the stage-s1 / single-stream /
+        # several-rank schedules run anyway (the tests flip them to compare schedules).
         # per-motion backward: the motion's SKINNING backward too in order on its stream (control-point sums staged,
-        # one fold on this stream at the end) instead of one skinning backward per motion on this stream
-        self._skin_in_order = os.environ.get("DIMO_SKIN_IN_ORDER", "1") == "1"
-        self._split_adam = os.environ.get("DIMO_SPLIT_ADAM", "1") == "1"  # Adam's per-Gaussian head under the TimeNet backward
+        # one fold at the end) instead of one skinning backward per motion on this stream
+        self._skin_in_order = True
+        self._split_adam = True  # the fold + Adam's per-Gaussian head on a private stream under the TimeNet backward
         # SSIM and the other image terms of a motion in ONE tile pass (csrc/ssim.hip: dimo_ssim_image_loss) instead of
         # the SSIM kernel followed by the loss kernel
         self._fused_loss = os.environ.get("DIMO_FUSED_LOSS", "0") == "1"
-        self._side_knn = os.environ.get("DIMO_SIDE_KNN", "1") == "1"  # KNN on a private stream next to the TimeNet forward
+        self._side_knn = True  # KNN on a private stream next to the TimeNet forward
         self._direct_wanted = direct
         self._decide_direct()
 

@@ -76,29 +76,16 @@ def test_image_loss_kernel_vs_reference_assembly(B, H, W, share, dn):
         assert rel <= 1e-4, (name, rel.item())
 
 
-@pytest.mark.parametrize("wgs", ["3", "4"])
 @pytest.mark.parametrize("B,H,W,share,dn", [(4, 64, 48, 1.0, (True, True)), (1, 33, 70, 0.5, (True, False)),
                                             (3, 128, 128, 0.75, (False, True)), (2, 40, 40, 1.0, (False, False)),
                                             (2, 17, 125, 1.0, (True, True)), (1, 9, 63, 1.0, (True, True)),
                                             (1, 2, 300, 1.0, (True, True)), (1, 70, 2, 1.0, (True, True)),
                                             (2, 512, 512, 1.0, (True, True))])
-def test_one_pass_ssim_and_image_losses_vs_reference_assembly(B, H, W, share, dn, wgs):
+def test_one_pass_ssim_and_image_losses_vs_reference_assembly(B, H, W, share, dn):
     """dimo_ssim_image_loss (SSIM + every other image term of a motion's batch in ONE tile pass: csrc/ssim.hip) against
     the float64 restatement of the reference's loss assembly (main_train_dimo.py:331-372, src/loss.py:64-106,132-175)
     -- the same inputs and tolerances as the two-kernel test above, per-image targets / masks handed over as pointer
-    lists like the trainer does; both workgroup-per-CU builds of the kernel (child process: the variable is read once)."""
-    import os
-    import subprocess
-    import sys
-    if os.environ.get("DIMO_SSIM_WGS", "3") != wgs:
-        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-        if (B, H, W) != (4, 64, 48) or os.environ.get("DIMO_TEST_CHILD"):
-            pytest.skip("the other build runs once, for every shape, from the first shape's child process")
-        p = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "tests/test_gpu_losses.py", "-k",
-                            "one_pass_ssim"], cwd=root, env=dict(os.environ, DIMO_SSIM_WGS=wgs, DIMO_TEST_CHILD="1"), capture_output=True,
-                           text=True, timeout=900)
-        assert p.returncode == 0 and " passed" in p.stdout, p.stdout[-3000:] + p.stderr[-2000:]
-        return
+    lists like the trainer does."""
     from dimo_amd.image_loss import fused_ssim_image_loss, loss_weights
     from dimo_amd.trainer import TrainConfig
     cfg = TrainConfig(add_depth=dn[0], add_normal=dn[1])

@@ -207,3 +207,30 @@ def test_a_failing_producer_raises_at_the_use():
         raise AssertionError("expected the producer's error")
     except RuntimeError as e:
         assert "render failed" in str(e)
+
+
+def test_rows_of_a_pending_batch_share_one_unbind_node():
+    """`batch[k]` image by image (main_train_dimo.py:331-337: `F.mse_loss(batch_images[...][k], ...)`) on a deferred
+    stand-in: every row is still pending, all rows come from ONE `unbind` of the tensor (its backward stacks the rows'
+    gradients once, where a `select` per row zero-fills and copies a batch-sized gradient each), and the gradient equals
+    plain indexing's."""
+    from dimo_amd.batched_render import _meta
+    w = torch.randn(4, 3, 5, 5, requires_grad=True)
+    calls = []
+
+    def fn():
+        calls.append(1)
+        return w * 2.0
+
+    lz = LazyTensor(fn, _meta((4, 3, 5, 5)), torch.device("cpu"))
+    rows = [lz[k] for k in (0, 2, -1)]
+    assert not calls and all(r.pending for r in rows) and tuple(rows[0].shape) == (3, 5, 5)
+    loss = sum(((r - 0.5) ** 2).sum() * (i + 1) for i, r in enumerate(rows)) + lz.sum()
+    assert len(calls) == 1
+    assert {type(materialize(r).grad_fn).__name__ for r in rows} == {"UnbindBackward0"}
+    loss.backward()
+    ref = (w.detach() * 2.0).requires_grad_(True)
+    (sum(((ref[k] - 0.5) ** 2).sum() * (i + 1) for i, k in enumerate((0, 2, -1))) + ref.sum()).backward()
+    assert torch.allclose(w.grad, 2.0 * ref.grad)
+    # an index that is not a row of the leading dimension keeps the generic deferred path
+    assert tuple(lz[1:3].shape) == (2, 3, 5, 5) and tuple(lz[:, 0].shape) == (4, 5, 5)

@@ -6,7 +6,8 @@
 #     -r  repetitions of every mode's bench line (interleaved: boxes drift); default 2
 #     -s  bench steps per line; default 100
 #     -k  also a serial kernel table per mode (DIMO_EXEC_STREAMS=0 under rocprofv3: every kernel alone on the device)
-#   a mode "-" means "no switch" (the defaults)
+#   a mode "-" means "no switch" (the defaults); a mode token "@name" runs that line with the alternative build
+#   dimo_amd/csrc/variants/name.so (DIMO_BUILD_VARIANT=name python -m dimo_amd.csrc.build) in place of the library
 set -u
 cd $GRAFT_REPO_ROOT
 tag=$1; shift
@@ -17,6 +18,8 @@ done
 shift $((OPTIND - 1))
 o=gpurun_out/$tag; mkdir -p $o
 export TMPDIR=/tmp
+libdir=dimo_amd/csrc
+cp -f $libdir/libdimo_hip.so $libdir/libdimo_hip.default.so
 if [ -n "$tests" ]; then
   ( time timeout 900 python -m pytest $tests -q -m gpu ) > $o/pytest.log 2>&1; echo "rc=$?" >> $o/pytest.log
   tail -n 25 $o/pytest.log
@@ -25,6 +28,9 @@ fi
 for rep in $(seq 1 $reps); do
   for mode in "$@"; do
     m=$mode; [ "$m" = "-" ] && m="DIMO_AB_NONE=1"
+    cp -f $libdir/libdimo_hip.default.so $libdir/libdimo_hip.so
+    for tok in $m; do case $tok in @*) cp -f $libdir/variants/${tok#@}.so $libdir/libdimo_hip.so;; esac; done
+    m=$(echo "$m" | sed 's/@[A-Za-z0-9_]*//g'); [ -z "$(echo $m | tr -d ' ')" ] && m="DIMO_AB_NONE=1"
     env $m timeout 300 python bench.py --steps $steps --warmup 10 --no-cpu-baseline --sustained-steps 0 --no-live-pmc --no-dropin 2>$o/bench.err | python -c "
 import sys, json
 try:
@@ -37,12 +43,17 @@ except Exception as e:
     tail -n 3 $o/bench.err >> $o/modes.err
   done
 done
+cp -f $libdir/libdimo_hip.default.so $libdir/libdimo_hip.so
 cat $o/modes.txt
 if [ $kst = 1 ]; then
   for mode in "$@"; do
     m=$mode; [ "$m" = "-" ] && m="DIMO_AB_NONE=1"
-    f=$o/kstats_serial_$(echo "$mode" | tr ' =/' '___').txt
+    cp -f $libdir/libdimo_hip.default.so $libdir/libdimo_hip.so
+    for tok in $m; do case $tok in @*) cp -f $libdir/variants/${tok#@}.so $libdir/libdimo_hip.so;; esac; done
+    m=$(echo "$m" | sed 's/@[A-Za-z0-9_]*//g'); [ -z "$(echo $m | tr -d ' ')" ] && m="DIMO_AB_NONE=1"
+    f=$o/kstats_serial_$(echo "$mode" | tr ' =/@' '____').txt
     ( cd /tmp && env $m DIMO_EXEC_STREAMS=0 timeout 300 bash $GRAFT_REPO_ROOT/tools/kstats_all.sh $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-dropin --sustained-steps 0 --no-live-pmc ) > $f 2>&1
     echo "== $mode"; head -n 24 $f
   done
 fi
+cp -f $libdir/libdimo_hip.default.so $libdir/libdimo_hip.so

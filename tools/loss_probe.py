@@ -1,7 +1,7 @@
 """The image-loss kernels alone, per launch of B x 3 x 512^2 (one motion's batch):
   two kernels : SSIM value + gradient (ssim_fused) then the fused image losses (image_loss)
   one pass    : dimo_ssim_image_loss (ssim_loss_tile_kernel)
-    python tools/loss_probe.py [B ...]        (DIMO_SSIM_WGS=3|4 selects the SSIM kernels' workgroups per CU)"""
+    python tools/loss_probe.py [B ...]        """
 import os, sys
 sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '/root/repo'))
 import torch
@@ -48,5 +48,5 @@ for B in [int(a) for a in sys.argv[1:]] or [4, 8]:
         fused_ssim_image_loss(img, dep, nrm, alp, gt, mask, w_mse, wts, coef, ssum, acc, out=out, g_dot=gdot)
 
     t_s, t_l, t_o = timed(ssim), timed(losses), timed(one_pass)
-    print("B = %d, DIMO_SSIM_WGS=%s: SSIM value + gradient %.1f us + image losses %.1f us = %.1f us | one pass %.1f us"
-          % (B, os.environ.get("DIMO_SSIM_WGS", "3"), t_s, t_l, t_s + t_l, t_o))
+    print("B = %d: SSIM value + gradient %.1f us + image losses %.1f us = %.1f us | one pass %.1f us"
+          % (B, t_s, t_l, t_s + t_l, t_o))
