@@ -488,16 +488,28 @@ def main():
     PRESTEPS = 20
     for _ in range(PRESTEPS):
         tr.train_step()
+    # a full (generation-2) Python GC pass walks every object torch created at import time: ~45 ms, i.e. ten
+    # training steps, whenever it happens to fall into the timed region.  Long-running training loops park the
+    # start-up objects in the permanent generation for the same reason.  It runs HERE, in front of the warm-up steps,
+    # not between them and the timed region: the device sits idle for those 45 ms, its clocks drop, and the first ~15
+    # steps behind the gap ran 1.08-1.10 ms against 0.98 later (step-end times of `DIMO_BENCH_TRACE=1`, round 5:
+    # `--steps 20` read 7300-7470 frames/s where `--steps 100` read 7960-8030 on the same box) -- the warm-up steps
+    # exist to hand the timed region a device in steady state.
+    gc.collect()
+    gc.freeze()
     barrier()
+    # ... and the device is taken back to its steady state before the contract's W warm-up steps: with W = 5 (the
+    # driver's flags) five steps behind the collector's gap still left the first ten timed steps at 1.02-1.03 ms
+    # against 0.97 later
+    SETTLE = 20
+    for _ in range(SETTLE):
+        tr.train_step()
+    gc.collect()  # (what the settle steps left behind: a few hundred objects, well under a millisecond)
+    gc.freeze()
     for _ in range(args.warmup):
         tr.train_step()
     skipped_warmup = tr.skipped_steps
     tr.allreduce_events = []
-    # a full (generation-2) Python GC pass walks every object torch created at import time: ~45 ms, i.e. ten
-    # training steps, whenever it happens to fall into the timed region.  Long-running training loops park the
-    # start-up objects in the permanent generation for the same reason.
-    gc.collect()
-    gc.freeze()
     barrier()
     # the timed region carries event pairs around the dominant kernel only (two event records per launch are
     # not free); the other kernel groups are timed in three extra steps after it
@@ -722,7 +734,7 @@ def main():
                        "hbm_peak_allocated_GB": peak_mem / 1e9},
             # a step whose renders overflowed the instance capacity is skipped on the device (Adam no-op) but its
             # renders are still counted above: this must read 0 for `value` to be a training rate
-            "setup_steps_before_warmup": PRESTEPS,
+            "setup_steps_before_warmup": PRESTEPS + SETTLE,
             "skipped_steps": {"timed_region": skipped_timed, "whole_run": skipped_total},
             "allreduce_exposed_ms_per_step": (sum(ar_ms) / len(ar_ms)) if ar_ms else (0.0 if world == 1 else None),
             "roofline": {"bound": "valu", "frac_is_of": "hbm peak (as the metric asks)",

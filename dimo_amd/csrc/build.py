@@ -24,7 +24,6 @@ SOURCES = {
     "knn.hip": ["-ffp-contract=off"],
     "ssim.hip": ["-fno-slp-vectorize"],  # packed FMAs need register pairs: with the window in VGPRs they spilled
     "deform.hip": [],
-    "tail.hip": ["-fno-slp-vectorize"],  # (packed FMAs: 216 VGPRs against 173, two waves per SIMD instead of three)
     "image_loss.hip": [],
     "adam.hip": [],
     "timenet.hip": [],

@@ -243,17 +243,6 @@ int lbs_forward_batched(const dimo_step_common &c, const RenderBatch &b, int n, 
 size_t lbs_backward_batched_scratch_bytes(int N, int M, int n);
 int lbs_backward_batched(const dimo_step_common &c, const RenderBatch &b, int n, hipStream_t stream, int first_abs = 0,
                          int phase = 0);
-// Stage s2, batched modes: the projection backward of a deformation group's views and the group's skinning backward run
-// as ONE kernel (tail.hip), launched where the skinning backward was; preprocess_backward_batched is then skipped.
-// Opt-in (DIMO_FUSED_TAIL=1): measured 111.5 us per 8 renders alone against 70.5 + 37.7 and 2.8 % fewer frames/s in the
-// step (profiles/r05_fused_tail.txt): a thread that walks its group's views one after the other halves the loads in flight
-// of a latency-bound gather.  Stage s1 always takes the two-kernel path.
-inline bool fused_tail(const dimo_step_common &c) {
-  static const bool on = getenv("DIMO_FUSED_TAIL") && atoi(getenv("DIMO_FUSED_TAIL")) != 0;
-  // (the fused kernel keeps 4 KB of static LDS next to the two control-point tables: M <= 1810)
-  return on && !c.stage1 && 2 * (size_t)c.M * 11 * sizeof(float) <= 160 * 1024 - 4096;
-}
-int tail_backward_batched(const dimo_step_common &c, const RenderBatch &b, int grid, float *partials, hipStream_t stream);
 int preprocess_forward_batched(const dimo_step_common &c, const RenderBatch &b, int n, hipStream_t stream);
 int preprocess_backward_batched(const dimo_step_common &c, const RenderBatch &b, int n, hipStream_t stream);
 int bin_instances_batched(const dimo_step_common &c, const RenderBatch &b, int n, hipStream_t stream);

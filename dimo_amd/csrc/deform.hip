@@ -240,9 +240,7 @@ __global__ void __launch_bounds__(256) accumulate_batched_kernel(int N, int n_re
                                                                  float *g_opacity, float *g_f_dc, int M,
                                                                  float *g_c_xyz, float *g_c_lr,
                                                                  const float *stage_end, size_t stage_stride,
-                                                                 int first_abs, int shs_by_group) {
-  // (shs_by_group: the colour gradients were summed per deformation group too -- the fused tail, tail.hip -- and sit in
-  // the leaders' g_shs; otherwise every render holds its own)
+                                                                 int first_abs) {
   // segments: [0,3N) xyz | [3N,7N) rotation | [7N,10N) scaling | [10N,11N) opacity | [11N,14N) f_dc
   const size_t n = (size_t)N;
   const size_t total = 14 * n + (stage_end ? 4 * (size_t)M : 0);
@@ -274,7 +272,7 @@ __global__ void __launch_bounds__(256) accumulate_batched_kernel(int N, int n_re
     else dst = g_f_dc, k = i - 11 * n, which = 4;
     float s = dst[k];
     for (int r = 0; r < n_renders; ++r) {
-      if ((which != 4 || shs_by_group) && !((leaders >> r) & 1u)) continue;
+      if (which != 4 && !((leaders >> r) & 1u)) continue;
       const dimo_render_desc &d = b.r[r];
       const float *src = which == 0 ? d.g_means3D : which == 1 ? d.g_rot : which == 2 ? d.g_scales
                          : which == 3 ? d.g_opac : d.g_shs;
@@ -504,7 +502,7 @@ int lbs_backward_batched(const dimo_step_common &c, const RenderBatch &b, int n,
     const size_t total = 14 * (size_t)c.N;
     hipLaunchKernelGGL(accumulate_batched_kernel, dim3(acc_grid(total)), dim3(256), 0, stream, c.N, n,
                        b, c.g_xyz, c.g_rotation, c.g_scaling, c.g_opacity, c.g_f_dc, 0, (float *)nullptr,
-                       (float *)nullptr, (const float *)nullptr, (size_t)0, 0, 0);
+                       (float *)nullptr, (const float *)nullptr, (size_t)0, 0);
     return check_launch();
   }
   if (first_abs < 0 || phase < 0 || phase > 2) return DIMO_E_ARG;
@@ -517,7 +515,7 @@ int lbs_backward_batched(const dimo_step_common &c, const RenderBatch &b, int n,
     ScopedTimer tm(T_DEFORM_BWD, stream);
     hipLaunchKernelGGL(accumulate_batched_kernel, dim3(acc_grid(total)), dim3(256), 0, stream, c.N, n, b,
                        c.g_xyz, c.g_rotation, c.g_scaling, c.g_opacity, c.g_f_dc, c.M, c.g_c_xyz, c.g_c_log_radius,
-                       (const float *)stage_end, stage_stride, first_abs, fused_tail(c) ? 1 : 0);
+                       (const float *)stage_end, stage_stride, first_abs);
     return check_launch();
   }
   GaussIO g{c.xyz, c.rotation, c.scaling, c.opacity, c.nn_dist, c.nn_idx};
@@ -531,10 +529,7 @@ int lbs_backward_batched(const dimo_step_common &c, const RenderBatch &b, int n,
   float *partials = reinterpret_cast<float *>(static_cast<char *>(c.lbs_scratch) +
                                               (phase ? (size_t)first_abs * lbs_partials_slice(c.N, c.M) : 0));
   ScopedTimer tm(T_DEFORM_BWD, stream);
-  if (fused_tail(c)) {  // projection backward of the groups' views + skinning backward in one kernel (tail.hip)
-    const int rc = tail_backward_batched(c, b, grid, partials, stream);
-    if (rc) return rc;
-  } else if (c.local_frame)
+  if (c.local_frame)
     hipLaunchKernelGGL(lbs_bwd_batched_kernel<true>, dim3(grid, b.n_groups), dim3(DEF_BLOCK), lds, stream, c.N, c.M, g, c.c_xyz,
                        c.c_log_radius, b, partials);
   else
@@ -547,7 +542,7 @@ int lbs_backward_batched(const dimo_step_common &c, const RenderBatch &b, int n,
   const size_t total = 14 * (size_t)c.N;
   hipLaunchKernelGGL(accumulate_batched_kernel, dim3(acc_grid(total)), dim3(256), 0, stream, c.N, n, b,
                      c.g_xyz, c.g_rotation, c.g_scaling, c.g_opacity, c.g_f_dc, 0, (float *)nullptr, (float *)nullptr,
-                     (const float *)nullptr, (size_t)0, 0, fused_tail(c) ? 1 : 0);
+                     (const float *)nullptr, (size_t)0, 0);
   return check_launch();
 }
 

@@ -1,6 +1,6 @@
-// Device code of the skinning stage shared by deform.hip (the stand-alone skinning kernels) and tail.hip (the fused
-// backward tail: projection backward -> skinning backward in one kernel).  See deform.hip for the maths' provenance
-// (renderer/latent_gs_renderer.py:1187-1219).
+// Device code of the skinning stage (deform.hip); a header since round 5's fused backward tail (projection backward ->
+// skinning backward in one kernel: built, parity-green, measured slower and removed -- profiles/r05_fused_tail.txt) used
+// it from a second translation unit.  See deform.hip for the maths' provenance (renderer/latent_gs_renderer.py:1187-1219).
 #pragma once
 #include "common.hpp"
 #include "wave_ops.hpp"

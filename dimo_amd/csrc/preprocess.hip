@@ -489,7 +489,6 @@ int preprocess_forward_batched(const dimo_step_common &c, const RenderBatch &b, 
 int preprocess_backward_batched(const dimo_step_common &c, const RenderBatch &b, int n, hipStream_t stream) {
   const int nb = (c.N + PRE_BLOCK - 1) / PRE_BLOCK;
   if (nb == 0 || n <= 0) return DIMO_OK;
-  if (fused_tail(c)) return DIMO_OK;  // (done per deformation group by the skinning backward's launch: tail.hip)
   GeomLayout L(c.N);
   const uint32_t cap = (uint32_t)(c.R_cap > 0xffffffffLL ? 0xffffffffu : (uint32_t)c.R_cap);
   const size_t flag_offset = align_up((size_t)(c.R_cap > 0 ? c.R_cap : 1) * sizeof(SplatGrad));

@@ -1,4 +1,5 @@
-// Projection maths shared by the per-Gaussian kernels (preprocess.hip) and the fused backward tail (tail.hip).
+// Projection maths of the per-Gaussian kernels (preprocess.hip); a header since round 5's fused backward tail used it
+// from a second translation unit (removed: profiles/r05_fused_tail.txt).
 // NOTE on floating-point contraction: preprocess.hip is compiled with contraction OFF (tile rects, radii and depth
 // bits must match the CPU oracle bit for bit) and states so with a file-level pragma BEFORE including this header; the
 // functions below contain no pragma of their own and follow their includer.

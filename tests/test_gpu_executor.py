@@ -6,11 +6,6 @@ render against the C oracle (oracle/raster_ref.c):
   radii, tile rects, tiles_touched, offsets, (tile | depth) keys, sorted order, tile ranges      bit-exact
   colour / depth / normal / alpha images, final transmittance                                    <= 1e-4 L1
   per-Gaussian rasterizer gradients (before the skinning backward)                                <= 1e-4 rel-L1
-  -- since round 5 the projection backward of a deformation group's views and the group's skinning backward are ONE
-  kernel (csrc/tail.hip), so what the slots hold afterwards are the group's CANONICAL gradients: they are compared
-  with the C oracle's per-render rasterizer gradients, summed over the group's views and taken through the float64
-  autograd of the skinning oracle (oracle/deform_ref.py); the screen-space gradients stay per render.
-  DIMO_FUSED_TAIL=0 (two kernels) keeps the per-render comparison.
 
 Contract: renderer/latent_gs_renderer.py:1255-1266 (the diff_gauss call of Renderer.render).  The oracle is fed the
 skinned Gaussians the executor's own skinning kernel produced (that kernel has its own oracle test,
@@ -117,60 +112,13 @@ def _run_batched(N, res, renders_per_motion, n_motions, seed=0, streams="-2", mo
             else:
                 ex.backward_launch(first, renders_per_motion)
     torch.cuda.synchronize()
-    fused = _fused_tail()
-    if fused:  # the projection backward runs with the skinning backward: one kernel per deformation group
-        if joint or not ex.ranged:
-            ex.backward_accumulate(0, n)
-        else:
-            for first in firsts:
-                ex.backward_skinning_in_order(first, renders_per_motion)
-        torch.cuda.synchronize()
     for i in range(n):
         s = ex.slots[i]
         out[i]["g"] = {k: cpu(s["g_" + k]).copy() for k in ("means3D", "means2D", "shs", "opac", "scales", "rot")}
         out[i]["gw"] = [cpu(x[i]) for x in grads]
-        out[i]["fused"] = fused
-        out[i]["pair"] = i // 2
     bg = cpu(rd.bg_color)
     f_dc = cpu(g._features_dc)
-    canon = dict(xyz=g._xyz.detach().cpu(), rotation=g._rotation.detach().cpu(), scaling=g._scaling.detach().cpu(),
-                 opacity=g._opacity.detach().cpu(), c_xyz=g._c_xyz.detach().cpu(),
-                 c_log_radius=g._c_radius.detach().cpu(), d_xyz=dxyz.cpu(), d_rot=dquat.cpu(),
-                 nn_dist=g.neighbor_dists.detach().cpu(), nn_idx=g.neighbor_indices.detach().cpu())
-    for o in out:
-        o["canon"] = canon
     return out, f_dc, bg, ex
-
-
-def _fused_tail():
-    import os
-    return os.environ.get("DIMO_FUSED_TAIL", "0") != "0"
-
-
-def _check_groups(outs, gos):
-    """Fused tail: the leaders' buffers hold the deformation group's canonical gradients."""
-    from oracle.deform_ref import skinning_ref
-    if not outs or not outs[0]["fused"]:
-        return
-    c = outs[0]["canon"]
-    for lead in range(0, len(outs), 2):
-        members = [lead, lead + 1] if lead + 1 < len(outs) else [lead]
-        f64 = lambda t: t.double().clone()
-        leaves = [f64(c[k]).requires_grad_(True) for k in ("xyz", "rotation", "scaling", "opacity")]
-        pair = outs[lead]["pair"]
-        res = skinning_ref(*leaves, f64(c["c_xyz"]), f64(c["c_log_radius"]), f64(c["d_xyz"][pair]),
-                           f64(c["d_rot"][pair]), f64(c["nn_dist"]), c["nn_idx"])
-        up = [sum(torch.from_numpy(np.asarray(gos[m][k], dtype=np.float64)).reshape(r.shape) for m in members)
-              for k, r in zip(("dL_dmeans3D", "dL_drot", "dL_dscales", "dL_dopacity"), res)]
-        want = torch.autograd.grad(res, leaves, grad_outputs=up)
-        g = outs[lead]["g"]
-        for k, w in zip(("means3D", "rot", "scales", "opac"), want):
-            err = _rel_l1(g[k].reshape(-1), w.numpy().reshape(-1))
-            assert err <= L1_TOL, (k, err)
-            assert np.isfinite(g[k]).all()
-        want_shs = sum(gos[m]["dL_dshs"] for m in members)
-        err = _rel_l1(g["shs"].reshape(-1), want_shs.reshape(-1))
-        assert err <= L1_TOL, ("shs", err)
 
 
 def _check_render(o_hip, f_dc, bg, H, W):
@@ -205,14 +153,11 @@ def _check_render(o_hip, f_dc, bg, H, W):
     pairs = (("means3D", go["dL_dmeans3D"]), ("shs", go["dL_dshs"]), ("opac", go["dL_dopacity"]),
              ("scales", go["dL_dscales"]), ("rot", go["dL_drot"]))
     for k, want in pairs:
-        if o_hip["fused"]:  # (per deformation group, through the skinning backward: _check_groups)
-            break
         err = _rel_l1(g[k].reshape(-1), want.reshape(-1))
         assert err <= L1_TOL, (k, err)
         assert np.isfinite(g[k]).all()
     err = _rel_l1(g["means2D"][:, :2].reshape(-1), go["dL_dmean2D"].reshape(-1))
     assert err <= L1_TOL, ("means2D", err)
-    o_hip["go"] = go
     return R
 
 
@@ -227,7 +172,6 @@ def test_batched_executor_kernels_against_the_oracle(N, res, per_motion, motions
     assert ex.batched and ex.ranged
     Rs = [_check_render(o, f_dc, bg, res, res) for o in outs]
     assert min(Rs) > 5 * N  # a dense workload: every Gaussian lands in several tiles
-    _check_groups(outs, [o["go"] for o in outs])
 
 
 @pytest.mark.timeout(1800)
@@ -243,7 +187,6 @@ def test_joint_backward_launch_against_the_oracle(N, res, per_motion, motions, m
     assert ex.batched and ex.ranged
     for o in outs:
         _check_render(o, f_dc, bg, res, res)
-    _check_groups(outs, [o["go"] for o in outs])
 
 
 def test_batched_executor_single_stream_mode_small(monkeypatch):
@@ -252,4 +195,3 @@ def test_batched_executor_single_stream_mode_small(monkeypatch):
     assert ex.batched and not ex.ranged
     for o in outs:
         _check_render(o, f_dc, bg, 128, 128)
-    _check_groups(outs, [o["go"] for o in outs])
