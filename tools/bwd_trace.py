@@ -53,6 +53,13 @@ print(f"quadrant visits {n_quad.sum()}, of which some pixel used the entry in {n
       f"({n_useful.sum() / max(1, n_quad.sum()):.3f}); records {n_rec.sum()}")
 d = end - start
 print(f"{n} items, duration mean {d.mean():.0f} ticks, max {d.max()}")
+# quadrant visits per record, item by item: a record's 13-value wave reduction runs ONCE per
+# (record, tile) whatever the number of quadrants it was evaluated on
+ratio = n_quad[n_rec > 0] / n_rec[n_rec > 0]
+hist, edges = np.histogram(ratio, bins=[1.0, 1.25, 1.5, 2.0, 2.5, 3.0, 3.5, 4.01])
+print("items by mean quadrant visits per record:",
+      ", ".join(f"[{edges[i]:.2f}, {edges[i + 1]:.2f}): {hist[i] / max(1, len(ratio)):.3f}" for i in range(len(hist))),
+      f"| records weighted mean {n_quad.sum() / max(1, n_rec.sum()):.2f}")
 for b in range(0, 8):
     m = bucket == b
     if m.any():
