@@ -473,7 +473,7 @@ __device__ __forceinline__ void blend_bwd_item(int H, int W, int tiles_x, uint32
     }                                                                                                              \
     if (any) {                                                                                                     \
       ++n_rec;                                                                                                     \
-      const float tot = wave_reduce16(v); /* lane l: the wave total of value reduce16_slot(l) */                    \
+      const float tot = wave_reduce16<13>(v); /* lane l: the wave total of value reduce16_slot(l); 13 in use */      \
       if ((lane & 3) == 0) s_acc[(TT)][reduce16_slot(lane)] = tot; /* this wave is the only writer of the record */ \
     } else if (pos >= wlast) {                                                                                     \
       break; /* the list is ascending: nothing further reaches this tile */                                         \
@@ -743,13 +743,18 @@ extern "C" int64_t dimo_debug_blend_trace(void *buffer, int64_t capacity) {
 }
 
 // Diagnostic: the wave reduction of the backward on caller-supplied data (in: 64 lanes x 16 floats, lane-major;
-// out: 16 wave totals).  Lets a test pin the DPP / permlane sequence of wave_ops.hpp against a plain sum.
+// out: 3 x 16 wave totals -- all 16 values in use, then the 13-value and the 10-value forms the blend backward runs,
+// whose slots 13 .. 15 / 10 .. 15 are unspecified).  Lets a test pin the DPP / permlane sequences of wave_ops.hpp
+// against a plain sum.
 __global__ void __launch_bounds__(64) wave_reduce16_selftest_kernel(const float *__restrict__ in, float *__restrict__ out) {
-  float v[16];
+  float v[16], w[16], u[16];
 #pragma unroll
-  for (int k = 0; k < 16; ++k) v[k] = in[threadIdx.x * 16 + k];
-  const float tot = dimo::wave_reduce16(v);
-  if ((threadIdx.x & 3) == 0) out[dimo::reduce16_slot(threadIdx.x)] = tot;
+  for (int k = 0; k < 16; ++k) v[k] = w[k] = u[k] = in[threadIdx.x * 16 + k];
+  const float t16 = dimo::wave_reduce16<16>(v), t13 = dimo::wave_reduce16<13>(w), t10 = dimo::wave_reduce16<10>(u);
+  if ((threadIdx.x & 3) == 0) {
+    const int s = dimo::reduce16_slot(threadIdx.x);
+    out[s] = t16, out[16 + s] = t13, out[32 + s] = t10;
+  }
 }
 extern "C" int dimo_selftest_wave_reduce16(const float *in, float *out, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;

@@ -15,7 +15,9 @@ LIB = os.path.join(HERE, "libdimo_hip.so")
 ARCH = "gfx950"
 SOURCES = {
     "api.hip": [],
-    "preprocess.hip": ["-ffp-contract=off"],
+    # (no SLP packing: the projection backward needs 90 VGPRs instead of 110 -- five waves per SIMD -- and runs 67.9
+    # against 71.5 us per 8 renders alone: profiles/r05_kernel_stats_serial_8renders.txt vs gpurun call r5e)
+    "preprocess.hip": ["-ffp-contract=off", "-fno-slp-vectorize"],
     "binning.hip": [],
     # the SLP vectoriser turns the per-pixel maths into v_pk_*_f32 + v_mov shuffles: a packed op issues in the time of
     # its two scalar halves on gfx950 (profiles/r02_valu_issue_rates.txt), so the packing only adds the moves

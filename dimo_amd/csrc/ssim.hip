@@ -271,17 +271,6 @@ struct ImagePtrs {
   int n, channels;
   const float *p[SSIM_MAX_IMAGES];
 };
-// Optional phase trace of the fused kernel (tools/ssim_bisect.hip, -DDIMO_SSIM_TRACE): wave 0 of a workgroup stamps
-// the 100 MHz clock at the phase boundaries of its first tile.
-#ifdef DIMO_SSIM_TRACE
-__device__ unsigned long long *g_ssim_trace = nullptr;  // [workgroups][16]
-#define SSIM_MARK(k)                                                                                      \
-  do {                                                                                                    \
-    if (g_ssim_trace && tid == 0 && tile == (int)blockIdx.x) g_ssim_trace[blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); \
-  } while (0)
-#else
-#define SSIM_MARK(k)
-#endif
 // Per-thread index maps of the fused tile body (constant over the tiles a workgroup walks).
 struct SsimThread {
   bool v1, h1, h2;

@@ -33,33 +33,53 @@ constexpr int DPP_ROW_SHR8 = 0x118;
 __device__ __forceinline__ int reduce16_slot(int lane) {
   return 8 * ((lane >> 3) & 1) + 4 * ((lane >> 2) & 1) + 2 * ((lane >> 5) & 1) + ((lane >> 4) & 1);
 }
+// NV = number of values in use (v[0 .. NV - 1]; 16, 13 or 10): the first halving step pairs value s with value s + 8,
+// and where s + 8 >= NV there is nothing to fetch -- the lanes that would keep value s + 8 then hold garbage, which
+// stays among the lanes of the unused slots (a step only ever combines lanes of the same slot); the caller must not
+// read those slots.  Three (13) or six (10) DPP adds of 4 issue cycles fewer per reduction (134 -> 122 / 110 cycles).
+// The blend backward uses 13 for both rasterizer flavours: its records carry 13 sums, and the 4-output flavour's three
+// normal sums must read ZERO downstream (with 10 they were garbage: found by the 4-output parity test).
+template <int NV = 16>
 __device__ __forceinline__ float wave_reduce16(float (&v)[16]) {
-#define DIMO_RA(s, h) "v_add_f32_dpp %" #s ", %" #s ", %" #s " row_ror:8 row_mask:0xf bank_mask:0x3\n\t" \
-                      "v_add_f32_dpp %" #s ", %" #h ", %" #h " row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+  static_assert(NV == 16 || NV == 13 || NV == 10, "value counts the callers use");
+#define DIMO_RA1(s) "v_add_f32_dpp %" #s ", %" #s ", %" #s " row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+#define DIMO_RA(s, h) DIMO_RA1(s) "v_add_f32_dpp %" #s ", %" #h ", %" #h " row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
 #define DIMO_RB(t, u) "v_add_f32_dpp %" #t ", %" #t ", %" #t " row_shl:4 row_mask:0xf bank_mask:0x5\n\t" \
                       "v_add_f32_dpp %" #t ", %" #u ", %" #u " row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
-  asm volatile(
-      "s_nop 1\n\t"
-      DIMO_RA(0, 8) DIMO_RA(1, 9) DIMO_RA(2, 10) DIMO_RA(3, 11) DIMO_RA(4, 12) DIMO_RA(5, 13) DIMO_RA(6, 14) DIMO_RA(7, 15)
-      DIMO_RB(0, 4) DIMO_RB(1, 5) DIMO_RB(2, 6) DIMO_RB(3, 7)
-      "s_nop 1\n\t"
-      "v_permlane32_swap_b32 %0, %2\n\t"
-      "v_permlane32_swap_b32 %1, %3\n\t"
-      "s_nop 1\n\t"
-      "v_add_f32 %0, %0, %2\n\t"
-      "v_add_f32 %1, %1, %3\n\t"
-      "s_nop 1\n\t"
-      "v_permlane16_swap_b32 %0, %1\n\t"
-      "s_nop 1\n\t"
-      "v_add_f32 %0, %0, %1\n\t"
-      "s_nop 1\n\t"
-      "v_add_f32_dpp %1, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-      "s_nop 1\n\t"
+#define DIMO_RTAIL                                                                                      \
+      DIMO_RB(0, 4) DIMO_RB(1, 5) DIMO_RB(2, 6) DIMO_RB(3, 7)                                           \
+      "s_nop 1\n\t"                                                                                     \
+      "v_permlane32_swap_b32 %0, %2\n\t"                                                                \
+      "v_permlane32_swap_b32 %1, %3\n\t"                                                                \
+      "s_nop 1\n\t"                                                                                     \
+      "v_add_f32 %0, %0, %2\n\t"                                                                        \
+      "v_add_f32 %1, %1, %3\n\t"                                                                        \
+      "s_nop 1\n\t"                                                                                     \
+      "v_permlane16_swap_b32 %0, %1\n\t"                                                                \
+      "s_nop 1\n\t"                                                                                     \
+      "v_add_f32 %0, %0, %1\n\t"                                                                        \
+      "s_nop 1\n\t"                                                                                     \
+      "v_add_f32_dpp %1, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"                     \
+      "s_nop 1\n\t"                                                                                     \
       "v_add_f32_dpp %0, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-      : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7])
-      : "v"(v[8]), "v"(v[9]), "v"(v[10]), "v"(v[11]), "v"(v[12]), "v"(v[13]), "v"(v[14]), "v"(v[15]));
+#define DIMO_ROPS                                                                                                 \
+      : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7])           \
+      : "v"(v[8]), "v"(v[9]), "v"(v[10]), "v"(v[11]), "v"(v[12]), "v"(v[13]), "v"(v[14]), "v"(v[15])
+  if (NV == 16) {
+    asm volatile("s_nop 1\n\t" DIMO_RA(0, 8) DIMO_RA(1, 9) DIMO_RA(2, 10) DIMO_RA(3, 11) DIMO_RA(4, 12) DIMO_RA(5, 13)
+                 DIMO_RA(6, 14) DIMO_RA(7, 15) DIMO_RTAIL DIMO_ROPS);
+  } else if (NV == 13) {
+    asm volatile("s_nop 1\n\t" DIMO_RA(0, 8) DIMO_RA(1, 9) DIMO_RA(2, 10) DIMO_RA(3, 11) DIMO_RA(4, 12) DIMO_RA1(5)
+                 DIMO_RA1(6) DIMO_RA1(7) DIMO_RTAIL DIMO_ROPS);
+  } else {
+    asm volatile("s_nop 1\n\t" DIMO_RA(0, 8) DIMO_RA(1, 9) DIMO_RA1(2) DIMO_RA1(3) DIMO_RA1(4) DIMO_RA1(5) DIMO_RA1(6)
+                 DIMO_RA1(7) DIMO_RTAIL DIMO_ROPS);
+  }
+#undef DIMO_RA1
 #undef DIMO_RA
 #undef DIMO_RB
+#undef DIMO_RTAIL
+#undef DIMO_ROPS
   return v[0];
 }
 

@@ -276,7 +276,8 @@ int dimo_flat_adam_step(int64_t n, float *params, float *grads, float *exp_avg, 
                         int64_t range_begin, int64_t range_end, int final_part, void *stream);
 
 /* Diagnostic (no reference counterpart): the 64-lane x 16-value wave reduction the rasterizer backward uses
- * (csrc/wave_ops.hpp), run on caller data.  in: 64 x 16 floats (lane-major), out: 16 floats = the column sums. */
+ * (csrc/wave_ops.hpp), run on caller data.  in: 64 x 16 floats (lane-major), out: 3 x 16 floats = the column sums by
+ * the 16-value form, then by the 13-value and the 10-value forms (their columns 13..15 / 10..15 are unspecified). */
 int dimo_selftest_wave_reduce16(const float *in, float *out, void *stream);
 /* Diagnostic: per-work-item trace of the blend backward.  buffer: device memory for `capacity` records of 4 x uint64
  * (s_memrealtime = 100 MHz ticks at start, at end, XCC << 56 | render << 48 | item code, records << 48 | quadrant visits << 32 | HW_ID), or NULL to

@@ -226,11 +226,15 @@ def test_wave_reduce16_of_the_blend_backward():
         if trial == 0:
             x = torch.arange(64 * 16, dtype=torch.float32).reshape(64, 16)  # every (lane, value) distinguishable
         xd = x.cuda().contiguous()
-        out = torch.full((16,), float("nan"), device="cuda")
+        out = torch.full((48,), float("nan"), device="cuda")
         _lib.check(_lib.lib().dimo_selftest_wave_reduce16(_lib.ptr(xd), _lib.ptr(out), _lib.current_stream()), "selftest")
         want = x.double().sum(0)
         got = out.cpu().double()
-        assert torch.allclose(got, want, rtol=1e-5, atol=1e-5 * float(x.abs().sum(0).max())), (trial, got, want)
+        # all 16 values; the 13-value and 10-value forms of the blend backward (diff_gauss / diff_gaussian_rasterization
+        # flavours: their first halving step skips the fetch of values that are not there)
+        for lo, used in ((0, 16), (16, 13), (32, 10)):
+            assert torch.allclose(got[lo:lo + used], want[:used], rtol=1e-5,
+                                  atol=1e-5 * float(x.abs().sum(0).max())), (trial, used, got, want)
 
 
 def test_flat_adam_reports_to_pinned_host_memory_and_clears_the_next_steps_accumulators():
