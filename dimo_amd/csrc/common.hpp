@@ -31,8 +31,12 @@ struct __attribute__((aligned(64))) Splat {
   float r, g, b;      // colour
   float depth;        // view-space z
   float nx, ny, nz;   // view-space normal
-  float pad0, pad1, pad2;
+  // the conic once more, pre-multiplied for the blend kernels' base-2 exponent (CONIC_HALF A, CONIC_FULL B, CONIC_HALF C:
+  // a visit then computes power' = dx (A' dx + B' dy) + C' dy dy = log2(e) x the published exponent and feeds v_exp_f32
+  // directly); they ride in what was padding, in the float4 that carries nz
+  float As, Bs, Cs;
 };
+constexpr float CONIC_HALF = -0.5f * 1.44269504088896340736f, CONIC_FULL = -1.44269504088896340736f;
 static_assert(sizeof(Splat) == 64, "Splat must be 64 bytes");
 
 // Per-instance gradient record produced by the blend backward (one per (Gaussian, tile) instance,

@@ -119,6 +119,7 @@ __device__ __forceinline__ void preprocess_fwd_body(
           out.x = pix_x, out.y = pix_y, out.A = cA, out.B = cB, out.C = cC, out.opacity = opacities[i];
           out.r = rgb[0], out.g = rgb[1], out.b = rgb[2], out.depth = pv[2];
           out.nx = nv[0], out.ny = nv[1], out.nz = nv[2];
+          out.As = CONIC_HALF * cA, out.Bs = CONIC_FULL * cB, out.Cs = CONIC_HALF * cC;
           rc[0] = (uint16_t)rx0, rc[1] = (uint16_t)ry0, rc[2] = (uint16_t)rx1, rc[3] = (uint16_t)ry1;
         }
       }
