@@ -90,6 +90,10 @@ def kernel_rooflines(timing_iso, N, V, R, P, C=NFEAT, renders_in_window=None, vi
         "ssim_fwd": 4 * 9 * P,
         "image_loss": 4 * 24 * P,
     }
+    if not timing_iso.get("image_loss", (0.0, 0))[1]:
+        # the default: SSIM + every image term in ONE tile pass (dimo_ssim_image_loss, timed under "ssim_fwd"): 12
+        # planes read (image 3, depth, normal 3, alpha, target 3, mask), 9 written
+        alg["ssim_fwd"] = 4 * 21 * P
     out = {}
     for k, b in alg.items():
         ms, n = timing_iso.get(k, (0.0, 0))

@@ -206,9 +206,9 @@ class Trainer:
         # one fold at the end) instead of one skinning backward per motion on this stream
         self._skin_in_order = True
         self._split_adam = True  # the fold + Adam's per-Gaussian head on a private stream under the TimeNet backward
-        # SSIM and the other image terms of a motion in ONE tile pass (csrc/ssim.hip: dimo_ssim_image_loss) instead of
-        # the SSIM kernel followed by the loss kernel
-        self._fused_loss = os.environ.get("DIMO_FUSED_LOSS", "0") == "1"
+        # SSIM and the other image terms of a motion in ONE tile pass (csrc/ssim.hip: dimo_ssim_image_loss); "0": the
+        # SSIM kernel followed by the loss kernel (also what runs with LPIPS on, or above 64 images per motion)
+        self._fused_loss = os.environ.get("DIMO_FUSED_LOSS", "1") == "1"
         self._side_knn = True  # KNN on a private stream next to the TimeNet forward
         self._direct_wanted = direct
         self._decide_direct()

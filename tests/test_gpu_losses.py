@@ -379,7 +379,8 @@ def test_executor_modes_agree(monkeypatch):
     -- "-2": the DEFAULT schedule, every motion's chain incl. its rasterizer and skinning backward in order on its own
     stream; "-2/joint": the rasterizer backward as ONE launch over the step's renders on the caller's stream, the pass
     bench.py takes its roofline clock in -- are schedules of the same kernels: one step from the same state must give
-    the same loss and gradients."""
+    the same loss and gradients.  "-2/two-loss-kernels": the default schedule with DIMO_FUSED_LOSS=0, the SSIM kernel
+    followed by the loss kernel instead of the one tile pass (same terms, sums in another order)."""
     from dimo_amd.rasterizer import CapacityPolicy
     from dimo_amd.renderer import Renderer
     from dimo_amd.synth import init_synthetic_model
@@ -387,9 +388,10 @@ def test_executor_modes_agree(monkeypatch):
     cfg = TrainConfig(num_pts=5000, num_cpts=64, num_motions=4, num_frames=6, num_views=4, motions_per_step=2,
                       views_per_step=2, frames_per_step=2, resolution=128)
     res = {}
-    for mode in ("3", "0", "-2", "-2/joint"):
+    for mode in ("3", "0", "-2", "-2/joint", "-2/two-loss-kernels"):
         monkeypatch.setenv("DIMO_EXEC_STREAMS", mode.split("/")[0])
         monkeypatch.setenv("DIMO_JOINT_BWD", "1" if mode.endswith("joint") else "0")
+        monkeypatch.setenv("DIMO_FUSED_LOSS", "0" if mode.endswith("two-loss-kernels") else "1")
         rd = Renderer(sh_degree=0, num_latent_code=cfg.num_motions, add_normal=True, device="cuda",
                       capacity=CapacityPolicy(initial=1 << 19))
         init_synthetic_model(rd, cfg.num_pts, cfg.num_cpts, seed=0, num_latent=cfg.num_motions)
@@ -401,7 +403,7 @@ def test_executor_modes_agree(monkeypatch):
         g = rd.gaussians
         # the TimeNet weight gradients are summed with hardware atomics (order not fixed): compare those loosely
         res[mode] = (tr.last_loss.item(), g.flat_grads.clone(), g._xyz.grad.clone(), g._c_xyz.grad.clone())
-    for mode in ("0", "-2", "-2/joint"):
+    for mode in ("0", "-2", "-2/joint", "-2/two-loss-kernels"):
         assert abs(res[mode][0] - res["3"][0]) <= 1e-6 * abs(res["3"][0])
         # per-Gaussian gradients: the batched modes sum the two views of a (motion, frame) pair before the skinning
         # backward and reduce a tile's pixels in one wave instead of two, so only the summation order differs
