@@ -39,7 +39,7 @@ fi
 if [ "$part" = "core" ]; then ls -la $out; exit 0; fi
 cd /tmp
 # 4. SQ counters
-timeout 600 bash $R/tools/pmc_sq.sh $tag blend_bwd_batched blend_fwd_batched ssim_fused lbs_bwd_batched preprocess_bwd image_loss level1_count_batched level1_scatter_batched bucket_sort_batched "level2_batched_kernel<false>" "level2_batched_kernel<true>" timenet_fwd_fused timenet_bwd_fused8 knn4 wgrad > $out/${tag}_sq.log 2>&1
+timeout 600 bash $R/tools/pmc_sq.sh $tag blend_bwd_batched blend_fwd_batched ssim_loss_tile ssim_fused lbs_bwd_batched preprocess_bwd image_loss level1_count_batched level1_scatter_batched bucket_sort_batched "level2_batched_kernel<false>" "level2_batched_kernel<true>" timenet_fwd_fused timenet_bwd_fused8 knn4 wgrad > $out/${tag}_sq.log 2>&1
 cd /tmp
 # 5. every stage ONE launch over the 8 renders, each kernel alone on the device
 DIMO_EXEC_STREAMS=0 timeout 300 bash $R/tools/kstats_all.sh $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-dropin --sustained-steps 0 --no-live-pmc > $out/${tag}_kernel_stats_serial_8renders.txt 2>&1
@@ -56,7 +56,7 @@ timeout 300 python bench.py --num-pts 50000 --resolution 256 --per-gpu 1,4,1 --s
 timeout 300 python bench.py --num-pts 200000 --resolution 1024 --per-gpu 1,1,20 --steps 10 --warmup 3 --no-cpu-baseline --no-dropin --sustained-steps 0 --no-live-pmc > $out/${tag}_bench_c5_shape_1gpu.json 2>/dev/null
 timeout 300 python bench.py --global-batch 2 --steps 20 --warmup 5 --no-cpu-baseline --no-dropin --sustained-steps 0 --no-live-pmc > $out/${tag}_bench_strong_b2_1gpu.json 2>/dev/null
 # 9. the schedule's remaining alternatives, A/B on this box
-for mode in "DIMO_AB_NONE=1" "DIMO_JOINT_BWD=1" "DIMO_EXEC_STREAMS=0" "DIMO_XSTREAM=event" "DIMO_FUSED_LOSS=1" "DIMO_TIMENET_ROWS_FWD=8"; do
+for mode in "DIMO_AB_NONE=1" "DIMO_JOINT_BWD=1" "DIMO_EXEC_STREAMS=0" "DIMO_XSTREAM=event" "DIMO_FUSED_LOSS=0" "DIMO_TIMENET_ROWS_FWD=8"; do
   env $mode timeout 200 python bench.py --steps 100 --warmup 10 --no-cpu-baseline --sustained-steps 0 --no-live-pmc --no-dropin 2>/dev/null | python -c "
 import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1])
