@@ -317,7 +317,7 @@ __device__ __forceinline__ void embed_bwd_body(int block, int rows, int Mc, int 
 // (dZ [rows x M], X [rows x N]), so the stage is a plain copy.  Two accumulators (even / odd pairs of k) keep
 // consecutive MFMAs of a wave independent.  The split over K is chosen so that the launch is ONE round of workgroups
 // (four per CU: 32 KB of LDS each), in chunks of whole half stages.
-// What it is bound by (DIMO_WGRAD_BISECT, profiles/r04_timenet_wgrad64.txt): NOT the matrix pipe -- the launch's
+// What it is bound by (a bisection build of round 4, profiles/r04_timenet_wgrad64.txt): NOT the matrix pipe -- the launch's
 // skeleton (first loads, LDS stores, barriers) is 14 us, the 4.1 M fp32 atomics alone add 10.8 (~1.4 elements per
 // clock and L2 channel), the operand loads alone 14.1, the MFMAs alone 9.9, and the four barely overlap: one round
 // of workgroups runs its phases in lock step.  44 us with the embedding backward inside, against 42 + 10.7.

@@ -67,8 +67,8 @@ def test_side_stream_fold_against_single_stream_at_large_n():
     """the per-Gaussian fold + Adam head run on a private stream NEXT TO the TimeNet backward,
     whose embedding backward adds its input gradient to `_c_xyz.grad` atomically -- the fold's control-point sums must
     not be a plain read-modify-write of the same words.  Many Gaussians (a long fold), small images (short renders):
-    the two writers overlap; the control-point gradients must equal the serial schedule's (DIMO_SPLIT_ADAM=0) up to the
-    rounding of their atomics, step after step."""
+    the two writers overlap; the control-point gradients must equal the serial schedule's (`Trainer._split_adam = False`:
+    fold and ONE Adam launch on the caller's stream) up to the rounding of their atomics, step after step."""
     from dimo_amd.rasterizer import CapacityPolicy
     from dimo_amd.renderer import Renderer
     from dimo_amd.synth import init_synthetic_model
