@@ -1,0 +1,51 @@
+// Host build of dimo_amd/csrc/binning.hip on the SIMT emulation shim (tests/simt/build.py substitutes the two gfx950
+// inline-asm statements).  TEST INFRASTRUCTURE ONLY: exports the binning chain to tests/test_binning_emulated.py.
+#include "binning_src.inc"
+
+namespace dimo {
+void set_last_error(hipError_t, const char *) {}
+ScopedTimer::ScopedTimer(int id, hipStream_t s) : id_(id), stream_(s), a_(nullptr), b_(nullptr) {}
+ScopedTimer::~ScopedTimer() {}
+}  // namespace dimo
+
+extern "C" {
+// out: rect, tiles, offsets, total, block_sums, key32, bk, bytes, nb
+void simt_geom_layout(int N, size_t out[9]) {
+  dimo::GeomLayout G(N);
+  out[0] = G.rect, out[1] = G.tiles, out[2] = G.offsets, out[3] = G.total, out[4] = G.block_sums, out[5] = G.key32;
+  out[6] = G.bk, out[7] = G.bytes, out[8] = (size_t)G.nb;
+}
+// out: dkeys, vals, ranges, totals, order, bytes, T, cap, l1tmp, l1list, meta, cnt2, l1cap, max_windows
+void simt_bin_layout(int64_t R_cap, int H, int W, size_t out[14]) {
+  dimo::BinLayout B(R_cap, H, W);
+  out[0] = B.dkeys, out[1] = B.vals_b, out[2] = B.ranges, out[3] = B.totals, out[4] = B.order, out[5] = B.bytes;
+  out[6] = (size_t)B.T, out[7] = B.cap;
+  out[8] = B.l1tmp, out[9] = B.l1list, out[10] = B.meta, out[11] = B.cnt2, out[12] = B.l1cap, out[13] = B.max_windows;
+}
+int simt_supertile_shift(int H, int W) {
+  dimo::BinGrid gi;
+  return dimo::make_bin_grid(H, W, gi) ? gi.ss_shift : -1;
+}
+int simt_bin_instances(int N, int H, int W, int64_t R_cap, void *geom, void *bin) {
+  return dimo::bin_instances(N, H, W, R_cap, geom, bin, nullptr);
+}
+// the batched kernels (blockIdx.y = render): n renders with workspaces geom[i], bin[i], bwd_scratch[i]
+int simt_bin_instances_batched(int N, int H, int W, int64_t R_cap, int n, void **geom, void **bin, void **scratch,
+                               size_t geom_bytes, size_t bin_bytes, size_t scratch_bytes, uint32_t *totals_out) {
+  dimo_step_common c;
+  memset(&c, 0, sizeof(c));
+  c.N = N, c.H = H, c.W = W, c.R_cap = R_cap, c.geom_bytes = geom_bytes, c.bin_bytes = bin_bytes;
+  c.bwd_scratch_bytes = scratch_bytes;
+  dimo::RenderBatch b;
+  memset(&b, 0, sizeof(b));
+  for (int i = 0; i < n; ++i) {
+    b.r[i].geom = geom[i], b.r[i].bin = bin[i], b.r[i].bwd_scratch = scratch[i];
+    b.r[i].totals_out = totals_out ? totals_out + 2 * i : nullptr;
+  }
+  return dimo::bin_instances_batched(c, b, n, nullptr);
+}
+size_t simt_bwd_scratch_bytes(int64_t R_cap, int H, int W) {
+  dimo::BinLayout B(R_cap, H, W);
+  return dimo::align_up(B.cap * sizeof(dimo::SplatGrad)) + dimo::align_up(B.cap);
+}
+}

@@ -1,0 +1,251 @@
+// SIMT emulation runtime (see shim/hip/hip_runtime.h): fibers, wave rendezvous, workgroup barriers, launches.
+// TEST INFRASTRUCTURE ONLY.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+
+#include <atomic>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+extern "C" void simt_switch(void **save_sp, void *load_sp);
+asm(R"(
+.text
+.globl simt_switch
+.type simt_switch,@function
+simt_switch:
+  pushq %rbp
+  pushq %rbx
+  pushq %r12
+  pushq %r13
+  pushq %r14
+  pushq %r15
+  movq %rsp, (%rdi)
+  movq %rsi, %rsp
+  popq %r15
+  popq %r14
+  popq %r13
+  popq %r12
+  popq %rbx
+  popq %rbp
+  ret
+.size simt_switch,.-simt_switch
+)");
+
+namespace simt {
+
+constexpr int MAX_THREADS = 1024;
+constexpr size_t STACK_BYTES = 256 * 1024;
+
+struct WaveSync {
+  uint64_t val[2][64];
+  uint64_t part[2];  // lanes that deposited (a lane that has left the kernel takes no part)
+  int arrived, live;
+  unsigned phase;
+};
+struct Workgroup;
+struct Fiber {
+  void *sp;
+  char *stack;
+  Workgroup *wg;
+  Idx3 tid;
+  int linear, wave, lane;
+  bool done;
+};
+struct Workgroup {
+  Fiber f[MAX_THREADS];
+  WaveSync wave[MAX_THREADS / 64];
+  int n, live, bar_arrived, bar_or[2];
+  unsigned bar_phase;
+  unsigned long progress;
+  void *main_sp;
+  Idx3 bid, bdim, gdim;
+  const std::function<void()> *body;
+};
+
+thread_local Fiber *cur = nullptr;
+
+const Idx3 &thread_idx() { return cur->tid; }
+const Idx3 &block_idx() { return cur->wg->bid; }
+const Idx3 &block_dim() { return cur->wg->bdim; }
+const Idx3 &grid_dim() { return cur->wg->gdim; }
+int lane_id() { return cur->lane; }
+
+static void yield_from(Fiber *me) {
+  Workgroup *g = me->wg;
+  int i = me->linear;
+  for (int k = 0; k < g->n; ++k) {
+    i = i + 1 == g->n ? 0 : i + 1;
+    if (!g->f[i].done) {
+      if (&g->f[i] == me) return;
+      cur = &g->f[i];
+      simt_switch(&me->sp, g->f[i].sp);
+      return;
+    }
+  }
+  // nobody else is live
+  if (me->done) {
+    cur = nullptr;
+    simt_switch(&me->sp, g->main_sp);
+  }
+}
+
+static void wait_until(Fiber *me, const unsigned *phase, unsigned ph, const char *what) {
+  Workgroup *g = me->wg;
+  unsigned long seen = g->progress;
+  int idle = 0;
+  while (*(volatile const unsigned *)phase == ph) {
+    yield_from(me);
+    if (g->progress != seen) seen = g->progress, idle = 0;
+    else if (++idle > 4) {
+      fprintf(stderr, "simt: deadlock at a %s (block %u,%u thread %u): not every live lane reaches it\n", what,
+              g->bid.x, g->bid.y, me->tid.x);
+      abort();
+    }
+  }
+}
+
+// Two value buffers alternate: the lanes of operation k read buffer k & 1 after the rendezvous while the first of them
+// may already deposit for k + 1; buffer k & 1 is written again by operation k + 2 only, which cannot begin before every
+// lane has arrived at k + 1, i.e. has read its values of k.
+static const uint64_t *exchange(uint64_t v, uint64_t *participants) {
+  Fiber *me = cur;
+  WaveSync &w = me->wg->wave[me->wave];
+  const unsigned ph = w.phase;
+  w.val[ph & 1][me->lane] = v;
+  w.part[ph & 1] |= 1ull << me->lane;
+  me->wg->progress++;
+  if (++w.arrived == w.live) {
+    w.arrived = 0;
+    w.part[(ph + 1) & 1] = 0;
+    w.phase = ph + 1;
+  } else {
+    wait_until(me, &w.phase, ph, "wave operation");
+  }
+  if (participants) *participants = w.part[ph & 1];
+  return w.val[ph & 1];
+}
+const uint64_t *wave_exchange(uint64_t v) { return exchange(v, nullptr); }
+uint64_t wave_ballot(bool pred) {
+  uint64_t part = 0, m = 0;
+  const uint64_t *v = exchange(pred ? 1u : 0u, &part);
+  for (int l = 0; l < 64; ++l) m |= (v[l] & 1u) << l;
+  return m & part;
+}
+
+int wg_barrier_or(int v) {
+  Fiber *me = cur;
+  Workgroup *g = me->wg;
+  const unsigned ph = g->bar_phase;
+  if (v) g->bar_or[ph & 1] = 1;
+  g->progress++;
+  if (++g->bar_arrived == g->live) {
+    g->bar_arrived = 0;
+    g->bar_or[(ph + 1) & 1] = 0;
+    g->bar_phase = ph + 1;
+  } else {
+    wait_until(me, &g->bar_phase, ph, "workgroup barrier");
+  }
+  return g->bar_or[ph & 1];
+}
+void wg_barrier() { (void)wg_barrier_or(0); }
+
+static void fiber_main() {
+  Fiber *me = cur;
+  (*me->wg->body)();
+  me = cur;
+  Workgroup *g = me->wg;
+  me->done = true;
+  g->progress++;
+  // a lane that has left no longer takes part in rendezvous (what it deposited stays readable)
+  WaveSync &w = g->wave[me->wave];
+  --w.live;
+  if (w.live > 0 && w.arrived == w.live) w.arrived = 0, w.part[(w.phase + 1) & 1] = 0, w.phase++;
+  --g->live;
+  if (g->live > 0 && g->bar_arrived == g->live) {
+    g->bar_arrived = 0;
+    g->bar_or[(g->bar_phase + 1) & 1] = 0;
+    g->bar_phase++;
+  }
+  yield_from(me);
+  // not reached when another fiber or the main context took over
+  cur = nullptr;
+  simt_switch(&me->sp, g->main_sp);
+  abort();
+}
+
+static void run_workgroup(Workgroup *g, Idx3 bid, Idx3 bdim, Idx3 gdim, const std::function<void()> *body) {
+  const int n = (int)(bdim.x * bdim.y * bdim.z);
+  if (n > MAX_THREADS) abort();
+  g->n = n, g->live = n, g->bar_arrived = 0, g->bar_phase = 0, g->bar_or[0] = g->bar_or[1] = 0, g->progress = 0;
+  g->bid = bid, g->bdim = bdim, g->gdim = gdim, g->body = body;
+  const int nw = (n + 63) / 64;
+  for (int w = 0; w < nw; ++w) {
+    g->wave[w].arrived = 0, g->wave[w].phase = 0;
+    g->wave[w].live = w == nw - 1 ? n - 64 * w : 64;
+    memset(g->wave[w].val, 0, sizeof(g->wave[w].val));
+    g->wave[w].part[0] = g->wave[w].part[1] = 0;
+  }
+  for (int i = 0; i < n; ++i) {
+    Fiber &f = g->f[i];
+    if (!f.stack) f.stack = (char *)aligned_alloc(64, STACK_BYTES);
+    f.wg = g, f.linear = i, f.wave = i >> 6, f.lane = i & 63, f.done = false;
+    f.tid.x = i % bdim.x, f.tid.y = (i / bdim.x) % bdim.y, f.tid.z = i / (bdim.x * bdim.y);
+    uintptr_t top = ((uintptr_t)f.stack + STACK_BYTES) & ~(uintptr_t)63;
+    void **s = (void **)top;
+    s[-1] = nullptr;              // (a return address nobody returns to)
+    s[-2] = (void *)&fiber_main;  // popped by simt_switch's ret
+    for (int r = 3; r <= 8; ++r) s[-r] = nullptr;
+    f.sp = (void *)(s - 8);
+  }
+  cur = &g->f[0];
+  simt_switch(&g->main_sp, g->f[0].sp);
+  cur = nullptr;
+}
+
+static std::mutex g_free_mutex;
+static std::vector<Workgroup *> g_free;
+static Workgroup *acquire_workgroup() {
+  std::lock_guard<std::mutex> lock(g_free_mutex);
+  if (g_free.empty()) return new Workgroup();
+  Workgroup *g = g_free.back();
+  g_free.pop_back();
+  return g;
+}
+static void release_workgroup(Workgroup *g) {
+  std::lock_guard<std::mutex> lock(g_free_mutex);
+  g_free.push_back(g);
+}
+
+static int pool_size() {
+  const char *e = getenv("SIMT_THREADS");
+  int n = e ? atoi(e) : (int)std::thread::hardware_concurrency();
+  return n < 1 ? 1 : (n > 64 ? 64 : n);
+}
+
+void launch(dim3 grid, dim3 block, const std::function<void()> &body) {
+  const size_t total = (size_t)grid.x * grid.y * grid.z;
+  if (total == 0) return;
+  std::atomic<size_t> next{0};
+  const Idx3 bdim{block.x, block.y, block.z}, gdim{grid.x, grid.y, grid.z};
+  auto worker = [&]() {
+    Workgroup *g = acquire_workgroup();  // (fiber stacks are kept for the next launches)
+    for (;;) {
+      const size_t i = next.fetch_add(1);
+      if (i >= total) break;
+      const Idx3 bid{(unsigned)(i % grid.x), (unsigned)((i / grid.x) % grid.y), (unsigned)(i / ((size_t)grid.x * grid.y))};
+      run_workgroup(g, bid, bdim, gdim, &body);
+    }
+    release_workgroup(g);
+  };
+  const int nt = (int)std::min<size_t>((size_t)pool_size(), total);
+  if (nt <= 1) {
+    worker();
+    return;
+  }
+  std::vector<std::thread> th;
+  for (int t = 0; t < nt; ++t) th.emplace_back(worker);
+  for (auto &t : th) t.join();
+}
+
+}  // namespace simt

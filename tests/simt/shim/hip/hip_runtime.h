@@ -1,0 +1,140 @@
+// SIMT emulation shim: stands in for <hip/hip_runtime.h> when a .hip source of dimo_amd/csrc is compiled FOR THE HOST
+// by tests/simt/build.py.  TEST INFRASTRUCTURE ONLY: it lets the CPU test suite run the integer logic of the binning
+// kernels (the same source text hipcc compiles for gfx950) without a GPU.  Nothing in dimo_amd/ loads it.
+//
+// Execution model: a workgroup is 256 (blockDim.x) FIBERS inside one OS thread, switched cooperatively; wave-level
+// operations (__ballot, __shfl_*, readlane) and workgroup barriers are rendezvous points -- a fiber that reaches one
+// parks until every live lane of its wave (thread of its workgroup) has arrived.  Wave operations therefore must be
+// reached by all live lanes of a wave (as the kernels are written); a wave that never converges is reported as a
+// deadlock instead of hanging.  Workgroups of a launch run in any order on a pool of OS threads; global atomics are
+// real atomics.  Timing, memory-model races inside a wave and LDS bank behaviour are NOT modelled.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <functional>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __shared__ static thread_local
+#define __launch_bounds__(...)
+
+struct dim3 {
+  unsigned x, y, z;
+  dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct uint2 { uint32_t x, y; };
+struct uint4 { uint32_t x, y, z, w; };
+struct float2 { float x, y; };
+struct float4 { float x, y, z, w; };
+static inline uint2 make_uint2(uint32_t x, uint32_t y) { return uint2{x, y}; }
+static inline uint4 make_uint4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { return uint4{x, y, z, w}; }
+
+typedef void *hipStream_t;
+typedef void *hipEvent_t;
+enum hipError_t { hipSuccess = 0, hipErrorUnknown = 999 };
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+#define HIP_SYMBOL(x) (&(x))
+template <class T>
+static inline hipError_t hipMemcpyFromSymbol(void *dst, T *sym, size_t n) { memcpy(dst, sym, n); return hipSuccess; }
+template <class T>
+static inline hipError_t hipMemcpyToSymbol(T *sym, const void *src, size_t n) { memcpy(sym, src, n); return hipSuccess; }
+
+namespace simt {
+struct Idx3 { unsigned x, y, z; };
+struct Fiber;
+extern thread_local Fiber *cur;
+const Idx3 &thread_idx();
+const Idx3 &block_idx();
+const Idx3 &block_dim();
+const Idx3 &grid_dim();
+int lane_id();
+// deposits v, parks until every live lane of the wave has arrived, returns the 64 deposited values
+const uint64_t *wave_exchange(uint64_t v);
+uint64_t wave_ballot(bool pred);
+void wg_barrier();
+int wg_barrier_or(int v);
+void launch(dim3 grid, dim3 block, const std::function<void()> &body);
+}  // namespace simt
+
+#define threadIdx (simt::thread_idx())
+#define blockIdx (simt::block_idx())
+#define blockDim (simt::block_dim())
+#define gridDim (simt::grid_dim())
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
+  simt::launch((grid), (block), [&]() { kernel(__VA_ARGS__); })
+
+static inline void __syncthreads() { simt::wg_barrier(); }
+static inline int __syncthreads_or(int v) { return simt::wg_barrier_or(v); }
+static inline void __threadfence_block() {}
+static inline void __threadfence() {}
+static inline unsigned long long __ballot(int pred) { return simt::wave_ballot(pred != 0); }
+static inline int __shfl(int x, int src, int width = 64) {
+  (void)width;
+  return (int)(uint32_t)simt::wave_exchange((uint32_t)x)[src & 63];
+}
+static inline int __shfl_xor(int x, int mask, int width = 64) {
+  (void)width;
+  return (int)(uint32_t)simt::wave_exchange((uint32_t)x)[(simt::lane_id() ^ mask) & 63];
+}
+static inline int __shfl_up(int x, int delta, int width = 64) {
+  (void)width;
+  const int l = simt::lane_id();
+  const uint64_t *v = simt::wave_exchange((uint32_t)x);
+  return l >= delta ? (int)(uint32_t)v[l - delta] : x;
+}
+static inline int __shfl_down(int x, int delta, int width = 64) {
+  (void)width;
+  const int l = simt::lane_id();
+  const uint64_t *v = simt::wave_exchange((uint32_t)x);
+  return l + delta < 64 ? (int)(uint32_t)v[l + delta] : x;
+}
+static inline int simt_readlane(int x, int lane) { return (int)(uint32_t)simt::wave_exchange((uint32_t)x)[lane & 63]; }
+static inline uint32_t simt_mbcnt_lo(uint32_t mask, uint32_t base) {
+  const int l = simt::lane_id();
+  return base + (uint32_t)__builtin_popcount(l >= 32 ? mask : (mask & ((1u << l) - 1u)));
+}
+static inline uint32_t simt_mbcnt_hi(uint32_t mask, uint32_t base) {
+  const int l = simt::lane_id();
+  return base + (l > 32 ? (uint32_t)__builtin_popcount(mask & ((1u << (l - 32)) - 1u)) : 0u);
+}
+// v[lane J] = sval (sval is wave-uniform: the SGPR operand of v_writelane_b32)
+static inline uint32_t simt_writelane(uint32_t v, uint32_t sval, int J) { return simt::lane_id() == J ? sval : v; }
+#define __builtin_amdgcn_readlane simt_readlane
+#define __builtin_amdgcn_mbcnt_lo simt_mbcnt_lo
+#define __builtin_amdgcn_mbcnt_hi simt_mbcnt_hi
+#define __builtin_amdgcn_s_memrealtime() 0ull
+
+static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
+static inline int __popc(unsigned x) { return __builtin_popcount(x); }
+static inline int __ffsll(long long x) { return __builtin_ffsll(x); }
+static inline int __clz(int x) { return x ? __builtin_clz((unsigned)x) : 32; }
+
+template <class T>
+static inline T atomicAdd(T *p, T v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+template <class T>
+static inline T atomicMax(T *p, T v) {
+  T o = __atomic_load_n(p, __ATOMIC_RELAXED);
+  while (o < v && !__atomic_compare_exchange_n(p, &o, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+  return o;
+}
+template <class T>
+static inline T atomicOr(T *p, T v) { return __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
+
+static inline int min(int a, int b) { return a < b ? a : b; }
+static inline int max(int a, int b) { return a > b ? a : b; }
+static inline unsigned min(unsigned a, unsigned b) { return a < b ? a : b; }
+static inline unsigned max(unsigned a, unsigned b) { return a > b ? a : b; }
+static inline unsigned long min(unsigned long a, unsigned long b) { return a < b ? a : b; }
+static inline unsigned long max(unsigned long a, unsigned long b) { return a > b ? a : b; }
+static inline unsigned long long min(unsigned long long a, unsigned long long b) { return a < b ? a : b; }
+static inline unsigned long long max(unsigned long long a, unsigned long long b) { return a > b ? a : b; }
+static inline long min(long a, long b) { return a < b ? a : b; }
+static inline long max(long a, long b) { return a > b ? a : b; }
+static inline float min(float a, float b) { return a < b ? a : b; }
+static inline float max(float a, float b) { return a > b ? a : b; }
