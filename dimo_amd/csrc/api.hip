@@ -18,19 +18,14 @@ extern "C" int dimo_raster_geom_layout(int N, size_t out[6]) {
 extern "C" int dimo_raster_bin_layout(int64_t R_cap, int H, int W, size_t out[3]) {
   if (!out || R_cap < 0 || H <= 0 || W <= 0) return DIMO_E_ARG;
   BinLayout L(R_cap, H, W);
-  out[0] = L.dkeys, out[1] = L.vals_b, out[2] = L.ranges;
+  out[0] = L.vals_b, out[1] = L.ranges, out[2] = L.totals;
   return DIMO_OK;
 }
-extern "C" int dimo_debug_bin_layout(int N, int64_t R_cap, int H, int W, size_t out[9]) {
-  if (!out || N < 0 || R_cap < 0 || H <= 0 || W <= 0) return DIMO_E_ARG;
-  GeomLayout G(N);
-  BinLayout B(R_cap, H, W);
-  BinGrid gi;
-  if (!make_bin_grid(H, W, gi)) return DIMO_E_ARG;
-  const int lg = depth_bins_log2(N, gi.NS);
-  out[0] = G.bk, out[1] = B.l1tmp, out[2] = B.l1list, out[3] = (size_t)gi.NS << lg, out[4] = (size_t)lg, out[5] = (size_t)gi.NS;
-  out[6] = BK_TOT, out[7] = BK_START, out[8] = BK_NSLICE;
-  return DIMO_OK;
+extern "C" int dimo_raster_depth_keys(int N, int H, int W, int64_t R_cap, const void *geom, const void *bin, uint32_t *out,
+                                      void *stream) {
+  if (N < 0 || H <= 0 || W <= 0 || R_cap < 0 || !geom || !bin || !out) return DIMO_E_ARG;
+  clear_errors();
+  return instance_depth_keys(N, H, W, R_cap, geom, bin, out, (hipStream_t)stream);
 }
 extern "C" int dimo_raster_img_layout(int H, int W, size_t out[2]) {
   if (!out || H <= 0 || W <= 0) return DIMO_E_ARG;

@@ -1,36 +1,40 @@
-// Tile binning: produces, per tile, the list of Gaussians that touch it in (depth, id) order -- bit for bit the
-// arrays a stable radix sort of the (tile | fp32 depth bits) keys of all (Gaussian, tile) instances yields (the
-// published rasterizer's cub::DeviceRadixSort) -- without ever sorting the instances, in FIVE short launches:
-//   1. level1_count   : a Gaussian has one LEVEL-1 ENTRY per supertile (SS x SS tiles) it touches; an entry belongs
-//                       to the BUCKET (supertile, coarse depth bin).  A workgroup counts its 256 Gaussians' entries
-//                       per bucket in LDS; one returning atomic per (workgroup, non-empty bucket) on the bucket total
-//                       reserves the workgroup's share of the bucket.  Also: offsets (the inclusive scan of
-//                       tiles_touched), R, and the depth-bin map -- every workgroup reduces the per-block words
-//                       preprocess left (a few hundred) itself instead of waiting for a scan kernel.
-//   2. level1_scatter : bucket starts (every workgroup scans the <= 2048 bucket totals itself: supertile lists one
-//                       after the other, starts rounded up to a window of 256 entries, a supertile's buckets by depth
-//                       bin), then every entry (depth bits, id, tile rectangle) goes to start + share + an LDS cursor.
-//                       No ordering is kept inside a bucket.  Workgroup 0 also writes what the next kernels read:
-//                       bucket starts, the level-2 window table, the slice list of oversized buckets.
-//   3. bucket_sort    : ONE WORKGROUP PER BUCKET sorts its (contiguous) entries in LDS by the 64-bit word
-//                       (depth bits << 32 | id): a counting pass over 256 sub-bins of the bucket's key range, then every
-//                       entry ranks itself inside its sub-bin (all words are distinct because the ids are).  The
-//                       per-supertile lists come out in (depth, id) order.
-//   4. level2_count   : every 256-entry window of the level-1 array belongs to one supertile; a workgroup filters its
-//                       windows against the <= 64 tiles of their supertile (ballot / popcount give order-preserving
-//                       ranks), leaves per-tile counts per window and adds them to the tile totals.
-//   5. level2_fill    : the same walk; a window's first slot per tile = tile start (every workgroup scans the tile
-//                       totals itself) + the counts of the supertile's earlier windows (summed by the workgroup).
-//                       Writes (depth bits, id) per instance as long contiguous runs, the tile ranges, the overflow
-//                       flag, and clears the backward's record flags.
-// An ORDERED filter keeps the input order, so every tile list comes out in (depth, id) order.  A frame has ~10x fewer
+// Tile binning: produces, per tile, the list of Gaussians that touch it in (depth, id) order -- bit for bit the ids a
+// stable radix sort of the (tile | fp32 depth bits) keys of all (Gaussian, tile) instances yields (the published
+// rasterizer's cub::DeviceRadixSort) -- without ever sorting the instances, in THREE launches (five until round 5):
+//   1. level1      : a Gaussian has one LEVEL-1 ENTRY per supertile (SS x SS tiles) it touches; an entry belongs to
+//                    the BUCKET (supertile, coarse depth bin).  A workgroup walks its 256 x `per` Gaussians ONCE: it
+//                    counts its entries per bucket in LDS and every entry learns its rank inside the workgroup's share of
+//                    its bucket (kept as a 32-bit code in LDS); the workgroup's entries then go to ITS OWN contiguous
+//                    SEGMENT of the unsorted level-1 array (its place is known from the per-block entry counts the
+//                    projection kernel left: no bucket start is needed), grouped by bucket; one returning 64-bit atomic
+//                    per (workgroup, non-empty bucket) adds the entries to the bucket total and takes a slot in the
+//                    bucket's SEGMENT LIST, where the workgroup leaves (first entry, count).  Also: offsets (the
+//                    inclusive scan of tiles_touched), R, and the depth-bin map -- every workgroup reduces the per-block
+//                    words of the projection kernel (a few hundred) itself.
+//   2. bucket_sort : every workgroup scans the <= 2048 bucket totals itself (where the buckets start in the SORTED
+//                    level-1 array: supertile by supertile, a supertile's buckets by depth bin, every bucket rounded up
+//                    to whole GROUPS of 64 entries), then ONE WORKGROUP PER BUCKET gathers the bucket's segments and
+//                    sorts the entries in LDS by the 64-bit word (depth bits << 32 | id): a counting pass over 1024
+//                    sub-bins of the bucket's key range, then every entry ranks itself inside its sub-bin (all words are
+//                    distinct because the ids are).  While the sorted tile rectangles are still in LDS the workgroup runs
+//                    the first half of level 2 on them: per group of 64 sorted entries and per tile of the supertile,
+//                    how many entries of the bucket's EARLIER groups cover the tile (a row of 64 words per group), the
+//                    bucket's totals per tile (one row per bucket: the UNIT row), and the tile totals (atomics).
+//   3. level2_fill : one WAVE per group, no barriers: first slot of tile j for the group = tile start (every workgroup
+//                    scans the tile totals itself) + the unit rows of the supertile's earlier buckets + the group's own
+//                    row; an ORDERED filter (ballot / popcount ranks) then writes the Gaussian id per instance as long
+//                    contiguous runs.  Also: the tile ranges, the overflow flag, the blend forward's dispatch order, and
+//                    the backward's record flags cleared with wide stores.
+// An ordered filter keeps the input order, so every tile list comes out in (depth, id) order.  A frame has ~10x fewer
 // Gaussians than instances (1e5 vs 1e6 at the benchmark configuration).  Earlier versions: 6 radix passes over the
-// instances; 2 passes + a per-tile LDS sort; then (round 2) a depth sort of the Gaussians + two levels of ordered
-// filters in twelve launches, whose cost was their dependent single-workgroup scans and chains of dependent loads
-// (183 us per 8 renders for ~25 us of memory traffic; a kernel boundary itself costs ~1.5 us on this chip).  The
-// level-2 kernels are persistent over their windows and request the next window's entries before they work on the
-// current one.  The 64-bit (tile | depth) key of an instance is not stored: its tile is the list the instance sits
-// in (`ranges`), its depth bits are `dkeys`.
+// instances; 2 passes + a per-tile LDS sort; (round 2) a depth sort of the Gaussians + two levels of ordered filters in
+// twelve launches; (rounds 3-4) count / scatter / sort / level-2 count / level-2 fill in five, whose cost was their
+// instruction count (a kernel of a few thousand short waves runs at ~0.6 M wave-instructions per us chip-wide whatever
+// the mix: tools/latency_model.hip) -- the second walk over the Gaussians, the bucket-start scan of every scatter
+// workgroup, the second read of the sorted entries, two barriers and a prefix loop per 256-entry window in the fill,
+// and three stores per instance where one is needed are what this version removes.  The depth bits of an instance are
+// NOT stored per instance (they are its Gaussian's: geom key32 / the splat record's depth); its tile is the list the
+// instance sits in (`ranges`).
 //
 // Everything reads live counts from device memory and is sized by capacities, so the whole chain is enqueued without
 // a host round trip.
@@ -49,11 +53,10 @@ __device__ __forceinline__ uint32_t depth_bin(uint32_t key, uint32_t lo, uint32_
 }
 
 // Sub-bins of a bucket (monotone in the key): SUB_BINS = 1024 over the 2^shift keys of its depth bin (an entry ranks
-// itself against the other entries of its sub-bin: the cost is the sum of the squared sub-bin sizes, 16 of the
-// kernel's 54 us per 8 renders with 256 sub-bins).  Depth bin 0 also holds every key below the binned range (outliers
-// in front of the scene): those share sub-bin 0 and the bin's own keys get the upper half of the sub-bins -- with ONE
-// linear map from the smallest key a single floater would squeeze the bin's bulk into a few fat sub-bins.  Keys past
-// the last bin share the last sub-bin.
+// itself against the other entries of its sub-bin: the cost is the sum of the squared sub-bin sizes).  Depth bin 0
+// also holds every key below the binned range (outliers in front of the scene): those share sub-bin 0 and the bin's
+// own keys get the upper half of the sub-bins -- with ONE linear map from the smallest key a single floater would
+// squeeze the bin's bulk into a few fat sub-bins.  Keys past the last bin share the last sub-bin.
 constexpr int SUB_BINS = 1024;
 struct SubMap {
   uint32_t klo, off, sh;
@@ -72,22 +75,20 @@ __device__ __forceinline__ uint32_t sub_bin(uint32_t key, const SubMap &m) {
   return key < m.klo ? 0u : min(m.off + ((key - m.klo) >> m.sh), (uint32_t)SUB_BINS - 1u);
 }
 
-constexpr int SEG = 256;  // list entries per level-2 window: 4 waves x 64
-// level-1 metadata in the bin workspace (uint32): [0, 256) list length, [256, 512) list start (multiple of SEG),
-// [512] number of level-2 windows, [1024, ...) four words per window: supertile | valid entries << 16, first window
-// of that supertile, first tile x | y << 16, 0
-constexpr int META_LEN = 0, META_START = MAX_SUPER, META_NWIN = 2 * MAX_SUPER, META_WIN = 4 * MAX_SUPER;
+constexpr int GRP = 64;  // sorted level-1 entries per level-2 group: one wave
+// the small words of the bin workspace (`meta`, uint32): [0] number of groups the fill walks
+constexpr int META_NGRP = 0;
 
 struct BinArgs {
   int N, nb, per, nwg1, lg, T;  // Gaussians, preprocess blocks, blocks per level-1 workgroup, level-1 workgroups,
                                 // log2 depth bins, tiles
   uint32_t R_cap;
   BinGrid gi;
-  size_t l1cap, max_windows;
+  size_t l1cap;
   // byte offsets into the geometry (g_) and bin (b_) workspaces
-  size_t g_total, g_rect, g_tiles, g_offsets, g_sums, g_key32, g_bk, g_wgbase;
+  size_t g_total, g_rect, g_tiles, g_offsets, g_sums, g_key32, g_bk, g_segs;
   size_t b_order;
-  size_t b_meta, b_l1tmp, b_l1a, b_l1b, b_l1, b_cnt2, b_totals, b_ranges, b_work, b_dkeys, b_vals;
+  size_t b_meta, b_l1tmp, b_l1a, b_l1b, b_l1, b_grpbase, b_grpinfo, b_cntu, b_totals, b_ranges, b_work, b_vals;
 };
 
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
@@ -112,6 +113,19 @@ __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v, int lane) {
     if (lane >= o) v += t;
   }
   return v;
+}
+// exclusive prefix of v over the 256 threads of the workgroup, and the total; s4: four words of LDS (free to reuse
+// after the call's second barrier has been passed by everybody, i.e. behind the caller's next barrier)
+__device__ __forceinline__ uint32_t block_scan_excl(uint32_t v, uint32_t *s4, uint32_t &total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t inc = wave_scan_incl(v, lane);
+  lds_barrier();  // (s4 of an earlier call has been read)
+  if (lane == 63) s4[wave] = inc;
+  lds_barrier();
+  uint32_t base = 0;
+  for (int w = 0; w < wave; ++w) base += s4[w];
+  total = s4[0] + s4[1] + s4[2] + s4[3];
+  return base + inc - v;
 }
 
 // Optional per-workgroup phase trace (diagnostics; compiled in with -DDIMO_BIN_TRACE -- build.py does that when the
@@ -146,11 +160,11 @@ struct BinTrace {
 #endif
 };
 
-
 // The level-1 entries of a wave's 64 Gaussians, walked in GROUPS of lanes that name the same bucket: a wave's
 // Gaussians are Morton neighbours, so most of its entries share a handful of buckets -- one LDS atomic per entry was
-// a 64-way same-address conflict per instruction.  Lane `lane` has `cnt` entries:
-// supertiles (sx0 + e % nx, sy0 + e / nx), depth bin db.  f(bucket, lanes of the group, leader lane, this lane is in it).
+// a 64-way same-address conflict per instruction.  Lane `lane` has its entries in the supertiles
+// (sx0 + e % nx, sy0 + e / nx), depth bin db; iteration `it` of the walk is every lane's entry number `it`.
+// f(bucket, lanes of the group, leader lane, this lane is in it, it); direct(bucket, this lane is left over, it).
 template <class F, class G>
 __device__ __forceinline__ void for_each_group(bool has, const uint2 rc, uint32_t db, const BinGrid &gi, int lg, int lane,
                                                F f, G direct) {
@@ -158,7 +172,7 @@ __device__ __forceinline__ void for_each_group(bool has, const uint2 rc, uint32_
   const int sx0 = x0 >> gi.ss_shift, sy0 = y0 >> gi.ss_shift;
   const int nx = has ? ((x1 - 1) >> gi.ss_shift) - sx0 + 1 : 0, ny = has ? ((y1 - 1) >> gi.ss_shift) - sy0 + 1 : 0;
   int cx = 0, cy = 0;
-  for (;;) {
+  for (int it = 0;; ++it) {
     const bool on = cy < ny && nx > 0;
     u64 todo = __ballot(on);
     if (todo == 0) break;
@@ -170,10 +184,10 @@ __device__ __forceinline__ void for_each_group(bool has, const uint2 rc, uint32_
       const uint32_t bl = (uint32_t)__builtin_amdgcn_readlane((int)bucket, leader);
       const bool mine = on && bucket == bl;
       const u64 m = __ballot(mine);
-      f(bl, m, leader, mine);
+      f(bl, m, leader, mine, it);
       todo &= ~m;
     }
-    if (todo) direct(bucket, (todo >> lane) & 1ull);
+    if (todo) direct(bucket, (todo >> lane) & 1ull, it);
     if (++cx >= nx) cx = 0, ++cy;
   }
 }
@@ -215,54 +229,64 @@ __device__ __forceinline__ void for_each_big(const BigList &L, uint32_t lo, uint
   }
 }
 
-// ------------------------------------------------------------------------------------ 1. level-1 count
-__device__ __forceinline__ void level1_count_body(const BinArgs &a, void *geom, void *bin) {
-  __shared__ uint32_t s_hist[MAX_BUCKETS];
-  __shared__ uint32_t s_w[4][8];
+// ------------------------------------------------------------------------------------ 1. level 1
+// LDS: two counters per bucket (16 KB), the list of big Gaussians (4 KB) and, dynamically sized, one 32-bit code
+// (bucket << 16 | rank in the workgroup's share of the bucket) per (block, entry number, thread): per x 4 KB.
+__device__ __forceinline__ void level1_body(const BinArgs &a, void *geom, void *bin) {
+  __shared__ uint32_t s_hist[MAX_BUCKETS];  // entries of the lanes' walk per bucket; then the bucket's first slot in the segment
+  __shared__ uint32_t s_bigc[MAX_BUCKETS];  // entries of the big Gaussians per bucket; then their cursor
+  __shared__ uint32_t s_w[4][9];
   __shared__ uint32_t s_wt[4];
+  __shared__ uint32_t s_anybig;
   __shared__ BigList s_big;
+  HIP_DYNAMIC_SHARED(uint32_t, s_code)
   const uint32_t *__restrict__ tiles = at<uint32_t>(geom, a.g_tiles);
   const uint32_t *__restrict__ key32 = at<uint32_t>(geom, a.g_key32);
   const uint16_t *__restrict__ rect = at<uint16_t>(geom, a.g_rect);
   const uint32_t *__restrict__ sums = at<uint32_t>(geom, a.g_sums);
   uint32_t *__restrict__ offsets = at<uint32_t>(geom, a.g_offsets);
   uint32_t *__restrict__ bk = at<uint32_t>(geom, a.g_bk);
-  uint32_t *__restrict__ wgbase = at<uint32_t>(geom, a.g_wgbase) + (size_t)blockIdx.x * MAX_BUCKETS;
+  u64 *__restrict__ bk_tot = reinterpret_cast<u64 *>(bk + BK_TOT);
+  uint2 *__restrict__ segs = at<uint2>(geom, a.g_segs);
+  uint4 *__restrict__ l1tmp = at<uint4>(bin, a.b_l1tmp);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c0 = (int)blockIdx.x * a.per, c1 = min(a.nb, c0 + a.per);  // this workgroup's preprocess blocks
   const int stride = a.nb + 1;
   const int nbuckets = a.gi.NS << a.lg;
+  const u64 lt = (1ull << lane) - 1ull;
   BinTrace tr(1);
   // the first block's Gaussians, requested before anything else (one memory round trip with the reductions below)
   const int i0 = c0 * PRE_BLOCK + tid;
   uint32_t v0 = i0 < a.N ? tiles[i0] : 0u;
   uint32_t k0 = i0 < a.N ? key32[i0] : 0u;
   uint2 r0 = i0 < a.N ? *reinterpret_cast<const uint2 *>(rect + 4 * (size_t)i0) : make_uint2(0u, 0u);
-  for (int j = tid; j < nbuckets; j += SORT_BLOCK) s_hist[j] = 0u;
-  // ---- the per-block words of preprocess, reduced by every workgroup itself: instances before this workgroup's
-  // blocks and in total, and the depth-bin map.  The binned range is NOT [min, max] of the keys: a few floaters far behind
-  // (or in front of) the scene would stretch it until the scene's bulk shares a handful of bins.  A block's MIN ignores
-  // a far outlier inside it and its MAX a near one, so A = the largest block minimum and B = the smallest block maximum
-  // bracket the bulk whatever the order of the Gaussians (Morton order: A ~ far end, B ~ near end; random order: the
-  // other way round); the range is [min(A, B), max(A, B)] widened by a quarter on both sides, inside [min, max].
-  // Keys outside it fall into the first / last bin (whose sub-bins start at the smallest key).
-  uint32_t pre_t = 0, tot_t = 0, tot_e = 0, mn = 0xffffffffu, mx = 0u, A_ = 0u, B_ = 0xffffffffu;
+  for (int j = tid; j < nbuckets; j += SORT_BLOCK) s_hist[j] = 0u, s_bigc[j] = 0u;
+  if (tid == 0) s_anybig = 0u;
+  // ---- the per-block words of preprocess, reduced by every workgroup itself: instances and entries before this
+  // workgroup's blocks and in total, and the depth-bin map.  The binned range is NOT [min, max] of the keys: a few
+  // floaters far behind (or in front of) the scene would stretch it until the scene's bulk shares a handful of bins.  A
+  // block's MIN ignores a far outlier inside it and its MAX a near one, so A = the largest block minimum and B = the
+  // smallest block maximum bracket the bulk whatever the order of the Gaussians (Morton order: A ~ far end, B ~ near
+  // end; random order: the other way round); the range is [min(A, B), max(A, B)] widened by a quarter on both sides,
+  // inside [min, max].  Keys outside it fall into the first / last bin (whose sub-bins start at the smallest key).
+  uint32_t pre_t = 0, pre_e = 0, tot_t = 0, tot_e = 0, mn = 0xffffffffu, mx = 0u, A_ = 0u, B_ = 0xffffffffu;
   for (int i = tid; i < a.nb; i += SORT_BLOCK) {
     const uint32_t t = sums[i], bmin = sums[stride + i], bmax = sums[2 * stride + i], e = sums[3 * stride + i];
     tot_t += t, tot_e += e;
-    if (i < c0) pre_t += t;
+    if (i < c0) pre_t += t, pre_e += e;
     if (bmin != 0xffffffffu) mn = min(mn, bmin), mx = max(mx, bmax), A_ = max(A_, bmin), B_ = min(B_, bmax);
   }
-  pre_t = wave_sum(pre_t), tot_t = wave_sum(tot_t), tot_e = wave_sum(tot_e);
+  pre_t = wave_sum(pre_t), pre_e = wave_sum(pre_e), tot_t = wave_sum(tot_t), tot_e = wave_sum(tot_e);
   mn = wave_min(mn), mx = wave_max(mx), A_ = wave_max(A_), B_ = wave_min(B_);
   if (lane == 0) {
-    s_w[wave][0] = pre_t, s_w[wave][1] = tot_t, s_w[wave][2] = tot_e;
+    s_w[wave][0] = pre_t, s_w[wave][1] = tot_t, s_w[wave][2] = tot_e, s_w[wave][3] = pre_e;
     s_w[wave][4] = mn, s_w[wave][5] = mx, s_w[wave][6] = A_, s_w[wave][7] = B_;
   }
   __syncthreads();
   pre_t = s_w[0][0] + s_w[1][0] + s_w[2][0] + s_w[3][0];
   tot_t = s_w[0][1] + s_w[1][1] + s_w[2][1] + s_w[3][1];
   tot_e = s_w[0][2] + s_w[1][2] + s_w[2][2] + s_w[3][2];
+  pre_e = s_w[0][3] + s_w[1][3] + s_w[2][3] + s_w[3][3];
   mn = min(min(s_w[0][4], s_w[1][4]), min(s_w[2][4], s_w[3][4]));
   mx = max(max(s_w[0][5], s_w[1][5]), max(s_w[2][5], s_w[3][5]));
   A_ = max(max(s_w[0][6], s_w[1][6]), max(s_w[2][6], s_w[3][6]));
@@ -280,18 +304,20 @@ __device__ __forceinline__ void level1_count_body(const BinArgs &a, void *geom, 
     uint32_t *total = at<uint32_t>(geom, a.g_total);
     if (tid == 0) {
       bk[BK_KMIN] = lo, bk[BK_SHIFT] = shift, bk[BK_KMIN0] = min(mn, lo), bk[BK_NBLOG] = (uint32_t)a.lg;
-      total[0] = tot_t, total[1] = 0u, total[2] = tot_e, total[3] = 0u;
+      // (more level-1 entries than the unsorted array holds can only come with more instances than the capacity)
+      total[0] = tot_t, total[1] = (size_t)tot_e > a.l1cap ? 1u : 0u, total[2] = tot_e, total[3] = 0u;
     }
-    uint32_t *tile_tot = at<uint32_t>(bin, a.b_totals);  // summed atomically by level2_count
+    uint32_t *tile_tot = at<uint32_t>(bin, a.b_totals);  // summed atomically by bucket_sort
     for (int t = tid; t < a.T; t += SORT_BLOCK) tile_tot[t] = 0u;
   }
   tr.mark();
-  // ---- offsets, and this workgroup's entries per bucket
+  // ---- one walk: offsets; this workgroup's entries per bucket; every entry's rank among them
   uint32_t carry = pre_t;
   uint32_t vn = v0, kn = k0;
   uint2 rn = r0;
   for (int c = c0; c < c1; ++c) {
     const int i = c * PRE_BLOCK + tid;
+    uint32_t *code = s_code + (size_t)(c - c0) * BIG_ENTRIES * SORT_BLOCK + tid;
     v0 = vn, k0 = kn, r0 = rn;
     if (c + 1 < c1) {  // the next block's Gaussians, requested before this block is worked on
       const int i2 = i + PRE_BLOCK;
@@ -300,7 +326,7 @@ __device__ __forceinline__ void level1_count_body(const BinArgs &a, void *geom, 
       rn = i2 < a.N ? *reinterpret_cast<const uint2 *>(rect + 4 * (size_t)i2) : make_uint2(0u, 0u);
     }
     const uint32_t inc = wave_scan_incl(v0, lane);
-    lds_barrier();  // (s_wt / the list of the previous block have been read; first round: s_hist cleared)
+    lds_barrier();  // (s_wt / the list of the previous block have been read; first round: the counters are cleared)
     if (lane == 63) s_wt[wave] = inc;
     if (tid == 0) s_big.n = 0u;
     lds_barrier();
@@ -309,191 +335,99 @@ __device__ __forceinline__ void level1_count_body(const BinArgs &a, void *geom, 
     carry += s_wt[0] + s_wt[1] + s_wt[2] + s_wt[3];
     if (i < a.N) offsets[i] = off + inc;
     const bool big = v0 != 0u && rect_entries(r0, a.gi) > BIG_ENTRIES;
-    if (big) s_big.push((uint32_t)i, k0, r0);
+    if (big) s_big.push((uint32_t)i, k0, r0), s_anybig = 1u;
     for_each_group(v0 != 0u && !big, r0, depth_bin(k0, lo, shift, nbins), a.gi, a.lg, lane,
-                   [&](uint32_t bl, u64 m, int leader, bool) {
-                     if (lane == leader) atomicAdd(&s_hist[bl], (uint32_t)__popcll(m));
+                   [&](uint32_t bl, u64 m, int leader, bool mine, int it) {
+                     uint32_t first = 0;  // the group's ranks: one returning LDS atomic by its leader
+                     if (lane == leader) first = atomicAdd(&s_hist[bl], (uint32_t)__popcll(m));
+                     first = (uint32_t)__builtin_amdgcn_readlane((int)first, leader);
+                     if (mine) code[it * SORT_BLOCK] = (bl << 16) | (first + (uint32_t)__popcll(m & lt));
                    },
-                   [&](uint32_t bucket, bool mine) {
-                     if (mine) atomicAdd(&s_hist[bucket], 1u);
+                   [&](uint32_t bucket, bool mine, int it) {
+                     if (mine) code[it * SORT_BLOCK] = (bucket << 16) | atomicAdd(&s_hist[bucket], 1u);
                    });
     lds_barrier();
     for_each_big(s_big, lo, shift, nbins, a.gi, a.lg,
-                 [&](uint32_t bucket, uint32_t, uint32_t, uint2) { atomicAdd(&s_hist[bucket], 1u); });
+                 [&](uint32_t bucket, uint32_t, uint32_t, uint2) { atomicAdd(&s_bigc[bucket], 1u); });
   }
   __syncthreads();
   tr.mark();
-  // ---- every non-empty bucket of the workgroup: its share of the bucket (thread t owns counters [8 t, 8 t + 8))
+  // ---- every non-empty bucket of the workgroup (thread t owns buckets [8 t, 8 t + 8)): its place in the workgroup's
+  // segment, its entries added to the bucket total, and (first entry, count) left in the bucket's segment list
+  const bool any_big = s_anybig != 0u;
   {
     constexpr int OWN = MAX_BUCKETS / SORT_BLOCK;
-    uint32_t cnt[OWN], base[OWN];
+    uint32_t cn[OWN], cb[OWN], sum = 0, seg_total;
 #pragma unroll
-    for (int u = 0; u < OWN; ++u) cnt[u] = tid * OWN + u < nbuckets ? s_hist[tid * OWN + u] : 0u;
+    for (int u = 0; u < OWN; ++u) {
+      const bool in = tid * OWN + u < nbuckets;
+      cn[u] = in ? s_hist[tid * OWN + u] : 0u, cb[u] = in ? s_bigc[tid * OWN + u] : 0u, sum += cn[u] + cb[u];
+    }
+    uint32_t run = block_scan_excl(sum, s_wt, seg_total);
 #pragma unroll
-    for (int u = 0; u < OWN; ++u) base[u] = cnt[u] ? atomicAdd(&bk[BK_TOT + tid * OWN + u], cnt[u]) : 0u;
+    for (int u = 0; u < OWN; ++u) {
+      const uint32_t t = cn[u] + cb[u], b = (uint32_t)(tid * OWN + u);
+      if (t) {
+        const u64 old = atomicAdd(&bk_tot[b], (1ull << 32) | (u64)t);
+        const uint32_t slot = (uint32_t)(old >> 32);
+        if (slot < (uint32_t)a.nwg1) segs[(size_t)b * a.nwg1 + slot] = make_uint2(pre_e + run, t);
+        s_hist[b] = run, s_bigc[b] = run + cn[u];
+        run += t;
+      }
+    }
+  }
+  __syncthreads();
+  tr.mark();
+  // ---- the entries, to the workgroup's segment: pre_e + the bucket's first slot + the entry's rank
+  for (int c = c0; c < c1; ++c) {
+    const int i = c * PRE_BLOCK + tid;
+    const uint32_t *code = s_code + (size_t)(c - c0) * BIG_ENTRIES * SORT_BLOCK + tid;
+    const uint32_t v = i < a.N ? tiles[i] : 0u, k = i < a.N ? key32[i] : 0u;
+    const uint2 r = i < a.N ? *reinterpret_cast<const uint2 *>(rect + 4 * (size_t)i) : make_uint2(0u, 0u);
+    const int cnt = v != 0u ? rect_entries(r, a.gi) : 0;
+    if (cnt <= BIG_ENTRIES) {
+      const uint4 en = make_uint4(k, (uint32_t)i, r.x, r.y);
 #pragma unroll
-    for (int u = 0; u < OWN; ++u)
-      if (cnt[u]) wgbase[tid * OWN + u] = base[u];
+      for (int it = 0; it < BIG_ENTRIES; ++it)
+        if (it < cnt) {
+          const uint32_t cd = code[it * SORT_BLOCK];
+          const size_t pos = (size_t)pre_e + s_hist[cd >> 16] + (cd & 0xffffu);
+          if (pos < a.l1cap) l1tmp[pos] = en;
+        }
+    }
+    if (any_big) {  // (workgroup-uniform)
+      lds_barrier();  // (the list of the previous block has been read)
+      if (tid == 0) s_big.n = 0u;
+      lds_barrier();
+      if (cnt > BIG_ENTRIES) s_big.push((uint32_t)i, k, r);
+      lds_barrier();
+      for_each_big(s_big, lo, shift, nbins, a.gi, a.lg, [&](uint32_t bucket, uint32_t gi_, uint32_t key, uint2 rc) {
+        const size_t pos = (size_t)pre_e + atomicAdd(&s_bigc[bucket], 1u);
+        if (pos < a.l1cap) l1tmp[pos] = make_uint4(key, gi_, rc.x, rc.y);
+      });
+    }
   }
   tr.flush();
 }
 
-// ------------------------------------------------------------------------------------ 2. level-1 scatter
+// ------------------------------------------------------------------------------------ 2. bucket sort + level-2 counts
 constexpr int BIN_CAP = 2048;      // entries a workgroup sorts in LDS (16 KB)
 constexpr int SUB_MAX = 512;       // largest sub-bin ranked quadratically
 // A bucket above BIN_CAP (thousands of Gaussians of one supertile in one depth bin) is cut into SLICES of
-// ~SLICE_TARGET entries along its sub-bins, sorted by the extra workgroups of the bucket_sort launch; only a SUB-bin
-// above SUB_MAX (hundreds of Gaussians at nearly ONE depth) sends its bucket to eight stable byte passes of a single
-// workgroup through global memory: slow, correct, rare.  l1tmp is read-only in bucket_sort, so every slice of a
-// bucket sees the same counts and takes the same decision.
+// ~SLICE_TARGET entries along its sub-bins, sorted by the extra workgroups of the launch; only a SUB-bin above SUB_MAX
+// (hundreds of Gaussians at nearly ONE depth) sends its bucket to eight stable byte passes of a single workgroup
+// through global memory: slow, correct, rare.  The unsorted entries are read-only here, so every slice of a bucket sees
+// the same counts and takes the same decisions.  Every slice's sorted entries start at a whole group: a bucket of n
+// entries cut into J slices reserves n + 64 J slots (rounded up to a group), and its last slice fills what is left
+// with empty entries.
 constexpr int SLICE_TARGET = BIN_CAP - SUB_MAX;
 constexpr int PER = BIN_CAP / SORT_BLOCK;
 constexpr int MAXB = 8;            // buckets one bucket_sort workgroup walks
+constexpr int MAXSL = 8;           // slices one bucket_sort workgroup walks (the launch has >= 32 workgroups)
 constexpr int SUB_OWN = SUB_BINS / SORT_BLOCK;  // sub-bins a thread owns in the scans
-
-__device__ __forceinline__ void level1_scatter_body(const BinArgs &a, void *geom, void *bin) {
-  __shared__ uint32_t s_cur[MAX_BUCKETS];       // bucket totals, then bucket starts, then this workgroup's cursors
-  __shared__ uint32_t s_lstart[MAX_SUPER + 1];  // list start per supertile (multiples of SEG), [NS] = end
-  __shared__ uint32_t s_len[MAX_SUPER];
-  __shared__ uint32_t s_wt[4];
-  __shared__ uint32_t s_nslice;
-  __shared__ BigList s_big;
-  const uint32_t *__restrict__ tiles = at<uint32_t>(geom, a.g_tiles);
-  const uint32_t *__restrict__ key32 = at<uint32_t>(geom, a.g_key32);
-  const uint16_t *__restrict__ rect = at<uint16_t>(geom, a.g_rect);
-  uint32_t *__restrict__ bk = at<uint32_t>(geom, a.g_bk);
-  const uint32_t *__restrict__ wgbase = at<uint32_t>(geom, a.g_wgbase) + (size_t)blockIdx.x * MAX_BUCKETS;
-  uint4 *__restrict__ l1tmp = at<uint4>(bin, a.b_l1tmp);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int c0 = (int)blockIdx.x * a.per, c1 = min(a.nb, c0 + a.per);
-  const int NS = a.gi.NS, nbins = 1 << a.lg, nbuckets = NS << a.lg;
-  constexpr int OWN = MAX_BUCKETS / SORT_BLOCK;
-  BinTrace tr(2);
-  // everything this workgroup reads, requested at once: its first block's Gaussians, the bucket totals, its shares
-  // (the words of buckets it does not touch are stale and never used), the bin map
-  const int i0 = c0 * PRE_BLOCK + tid;
-  uint32_t v0 = i0 < a.N ? tiles[i0] : 0u;
-  uint32_t k0 = i0 < a.N ? key32[i0] : 0u;
-  uint2 r0 = i0 < a.N ? *reinterpret_cast<const uint2 *>(rect + 4 * (size_t)i0) : make_uint2(0u, 0u);
-  uint32_t share[OWN];
-#pragma unroll
-  for (int u = 0; u < OWN; ++u) share[u] = tid * OWN + u < nbuckets ? wgbase[tid * OWN + u] : 0u;
-  for (int j = tid; j < nbuckets; j += SORT_BLOCK) s_cur[j] = bk[BK_TOT + j];
-  const uint32_t lo = bk[BK_KMIN], shift = bk[BK_SHIFT];
-  __syncthreads();
-  tr.mark();
-  // ---- where the buckets start
-  {
-    uint32_t len = 0;
-    if (tid < NS)
-      for (int j = 0; j < nbins; ++j) len += s_cur[(tid << a.lg) + j];
-    const uint32_t padded = (len + SEG - 1) / SEG * SEG;
-    const uint32_t inc = wave_scan_incl(padded, lane);
-    if (lane == 63) s_wt[wave] = inc;
-    if (tid == 0) s_nslice = 0u;
-    __syncthreads();
-    uint32_t base = inc - padded;
-    for (int w = 0; w < wave; ++w) base += s_wt[w];
-    if (tid < NS) {
-      s_lstart[tid] = base, s_len[tid] = len;
-      if (tid == NS - 1) s_lstart[NS] = base + padded;
-      uint32_t run = base;
-      for (int j = 0; j < nbins; ++j) {  // totals -> starts, in place
-        const uint32_t n = s_cur[(tid << a.lg) + j];
-        s_cur[(tid << a.lg) + j] = run;
-        if (blockIdx.x == 0) {
-          const uint32_t b = ((uint32_t)tid << a.lg) + j;
-          bk[BK_START + b] = run;
-          uint32_t J = 0;
-          if (n > (uint32_t)BIN_CAP) {  // an oversized bucket: its slices go on the list (if they fit; else J stays 0)
-            const uint32_t want = (n + SLICE_TARGET - 1) / SLICE_TARGET;
-            const uint32_t pos = want <= 255u ? atomicAdd(&s_nslice, want) : (uint32_t)MAX_SLICES;
-            if (pos + want <= (uint32_t)MAX_SLICES) {
-              J = want;
-              for (uint32_t q = 0; q < want; ++q) bk[BK_SLICE + pos + q] = (b << 16) | (want << 8) | q;
-            } else if (want <= 255u) {  // (list full: the entries this bucket reserved stay unused; mark them so)
-              for (uint32_t q = pos; q < min(pos + want, (uint32_t)MAX_SLICES); ++q) bk[BK_SLICE + q] = 0xffffffffu;
-            }
-          }
-          bk[BK_BINJ + b] = J;
-        }
-        run += n;
-      }
-    }
-    __syncthreads();
-    if (blockIdx.x == 0) {  // the level-2 kernels' view of the lists
-      uint32_t *meta = at<uint32_t>(bin, a.b_meta);
-      if (tid == 0) bk[BK_NSLICE] = min(s_nslice, (uint32_t)MAX_SLICES);
-      if (tid < NS) meta[META_LEN + tid] = s_len[tid], meta[META_START + tid] = s_lstart[tid];
-      // window table, by ALL threads: window w belongs to the last supertile whose start (in windows) is <= w (an
-      // empty supertile shares its start with its successor) -- a binary search over the <= 256 starts in LDS
-      const uint32_t n_win = (uint32_t)min((size_t)(s_lstart[NS] / SEG), a.max_windows);
-      if (tid == 0) meta[META_NWIN] = n_win;
-      for (uint32_t w = tid; w < n_win; w += SORT_BLOCK) {
-        int l = 0, h = NS;
-        while (h - l > 1) {
-          const int mid = (l + h) >> 1;
-          if (s_lstart[mid] / SEG <= w) l = mid; else h = mid;
-        }
-        const uint32_t end = s_lstart[l] + s_len[l];
-        const uint32_t nvalid = end > w * SEG ? min(end - w * SEG, (uint32_t)SEG) : 0u;
-        uint4 *wintab = reinterpret_cast<uint4 *>(meta + META_WIN);
-        wintab[w] = make_uint4((uint32_t)l | (nvalid << 16), s_lstart[l] / SEG,
-                               (uint32_t)((l % a.gi.stx) << a.gi.ss_shift) | ((uint32_t)((l / a.gi.stx) << a.gi.ss_shift) << 16), 0u);
-      }
-    }
-  }
-  // ---- cursors of this workgroup, then every entry to its bucket's next slot (order inside a bucket: whatever the LDS
-  // atomics make of it -- bucket_sort orders by the whole 64-bit word)
-#pragma unroll
-  for (int u = 0; u < OWN; ++u)
-    if (tid * OWN + u < nbuckets) s_cur[tid * OWN + u] += share[u];
-  __syncthreads();
-  tr.mark();
-  uint32_t vn = v0, kn = k0;
-  uint2 rn = r0;
-  for (int c = c0; c < c1; ++c) {
-    const int i = c * PRE_BLOCK + tid;
-    v0 = vn, k0 = kn, r0 = rn;
-    if (c + 1 < c1) {  // the next block's Gaussians, requested before this block is worked on
-      const int i2 = i + PRE_BLOCK;
-      vn = i2 < a.N ? tiles[i2] : 0u;
-      kn = i2 < a.N ? key32[i2] : 0u;
-      rn = i2 < a.N ? *reinterpret_cast<const uint2 *>(rect + 4 * (size_t)i2) : make_uint2(0u, 0u);
-    }
-    const uint4 en = make_uint4(k0, (uint32_t)i, r0.x, r0.y);
-    const u64 lt = (1ull << lane) - 1ull;
-    lds_barrier();  // (the list of the previous block has been read)
-    if (tid == 0) s_big.n = 0u;
-    lds_barrier();
-    const bool big = v0 != 0u && rect_entries(r0, a.gi) > BIG_ENTRIES;
-    if (big) s_big.push((uint32_t)i, k0, r0);
-    for_each_group(v0 != 0u && !big, r0, depth_bin(k0, lo, shift, (uint32_t)nbins), a.gi, a.lg, lane,
-                   [&](uint32_t bl, u64 m, int leader, bool mine) {
-                     uint32_t first = 0;  // the group's slots: one returning LDS atomic by its leader
-                     if (lane == leader) first = atomicAdd(&s_cur[bl], (uint32_t)__popcll(m));
-                     first = (uint32_t)__builtin_amdgcn_readlane((int)first, leader);
-                     const size_t pos = (size_t)first + (uint32_t)__popcll(m & lt);
-                     if (mine && pos < a.l1cap) l1tmp[pos] = en;
-                   },
-                   [&](uint32_t bucket, bool mine) {
-                     if (mine) {
-                       const size_t pos = atomicAdd(&s_cur[bucket], 1u);
-                       if (pos < a.l1cap) l1tmp[pos] = en;
-                     }
-                   });
-    lds_barrier();
-    for_each_big(s_big, lo, shift, (uint32_t)nbins, a.gi, a.lg,
-                 [&](uint32_t bucket, uint32_t gi_, uint32_t key, uint2 rc) {
-                   const size_t pos = atomicAdd(&s_cur[bucket], 1u);
-                   if (pos < a.l1cap) l1tmp[pos] = make_uint4(key, gi_, rc.x, rc.y);
-                 });
-    tr.mark();
-  }
-  tr.flush();
-}
-
-// ------------------------------------------------------------------------------------ 3. bucket sort
+constexpr int MAX_UNITS = MAX_BUCKETS + MAX_SLICES;  // rows of per-tile totals: one per bucket, or per slice of a cut bucket
+static_assert(MAX_UNITS < 4096 && MAX_SUPER <= 256, "a group's word: unit and first unit in 12 bits each, supertile in 8");
+static_assert(MAX_SLICES == 256 && MAX_SLICES <= MAXSL * 32, "slice list");
 
 // One stable counting pass of a single workgroup over n 64-bit words: digit = byte `byte` of the word.
 __device__ __forceinline__ void wg_radix_pass(const u64 *kin, u64 *kout, uint32_t n, int byte, uint32_t *s_run,
@@ -548,16 +482,206 @@ __device__ __forceinline__ void wg_radix_pass(const u64 *kin, u64 *kout, uint32_
   }
 }
 
+// ---- level 2, first half: the tiles of a supertile that an entry's rectangle covers, as a bit mask (bit j = tile j of
+// the supertile, row-major over its SS x SS tiles: a row mask times a column pattern), and per group of 64 entries one
+// ballot + popcount + v_writelane per tile: lane j ends up with the number of the group's entries that cover tile j.
+template <int J>
+__device__ __forceinline__ uint32_t writelane(uint32_t v, uint32_t sval) {  // v[lane J] = sval (one SGPR operand: J is an immediate)
+  asm("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(sval), "n"(J));
+  return v;
+}
+template <int J, int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+  if constexpr (J < N) {
+    f(std::integral_constant<int, J>{});
+    static_for<J + 1, N>(f);
+  }
+}
+template <int SSH>
+__device__ __forceinline__ u64 tile_mask(const uint32_t rx, const uint32_t ry, int tx0, int ty0) {
+  constexpr int ss = 1 << SSH;
+  const int x0 = rx & 0xffff, y0 = rx >> 16, x1 = ry & 0xffff, y1 = ry >> 16;
+  const int lx0 = max(x0 - tx0, 0), lx1 = min(x1 - tx0, ss), ly0 = max(y0 - ty0, 0), ly1 = min(y1 - ty0, ss);
+  if (!(lx1 > lx0 && ly1 > ly0)) return 0ull;  // (an EMPTY entry -- rectangle 0 -- covers nothing)
+  const uint32_t rm = (1u << lx1) - (1u << lx0);  // the covered tiles of one row
+  if (SSH == 3) {
+    const u64 hi = ly1 >= 8 ? ~0ull : ((1ull << (8 * ly1)) - 1ull), lo = (1ull << (8 * ly0)) - 1ull;
+    return (u64)rm * ((hi ^ lo) & 0x0101010101010101ull);
+  }
+  const uint32_t yr = ((1u << (ss * ly1)) - (1u << (ss * ly0))) & (SSH == 2 ? 0x1111u : (SSH == 1 ? 0x5u : 0x1u));
+  return (u64)(rm * yr);
+}
+template <int SSH>
+__device__ __forceinline__ uint32_t group_counts(u64 mask) {
+  uint32_t c = 0;
+  static_for<0, (1 << SSH) * (1 << SSH)>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    const u64 bal = __ballot((mask >> j) & 1ull);
+    c = writelane<j>(c, (uint32_t)__popcll(bal));
+  });
+  return c;
+}
+
+// what a run of sorted entries (a bucket, or a slice of one) tells level 2
+struct Unit {
+  uint32_t unit, info;  // row of per-tile totals; the word every group of the run carries: unit | first unit of the supertile << 12 | supertile << 24
+  int tx0, ty0;         // first tile of the supertile
+  uint32_t *grpbase, *grpinfo, *cntu, *tile_tot;
+  int tiles_x, tiles_y;
+};
+struct UnitShared {
+  uint32_t wtot[SORT_BLOCK / 64][64];
+};
+// The run's `len` sorted rectangles (a whole number of groups, <= BIN_CAP: the padding behind the last entry holds
+// empty rectangles) are in LDS, its first group is group g0 of the level-1 array.  Wave w takes the groups
+// [w gpw, (w + 1) gpw): per group, the number of entries of the wave's earlier groups that cover tile j (lane j), kept
+// in registers until the waves have exchanged their totals; then the rows, the unit row and the tile totals.
+template <int SSH>
+__device__ __forceinline__ void count_run_lds(const uint2 *s_sr, uint32_t len, uint32_t g0, const Unit &U, UnitShared &sh) {
+  constexpr int ss = 1 << SSH, ntile = ss * ss, MAXG = BIN_CAP / GRP / (SORT_BLOCK / 64);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t ng = len / GRP, gpw = (ng + 3) / 4;
+  uint32_t pre[MAXG], run = 0;
+#pragma unroll
+  for (int i = 0; i < MAXG; ++i) {
+    const uint32_t g = (uint32_t)wave * gpw + i;
+    pre[i] = run;
+    if ((uint32_t)i < gpw && g < ng) {  // (wave-uniform)
+      const uint2 rc = s_sr[g * GRP + lane];
+      run += group_counts<SSH>(tile_mask<SSH>(rc.x, rc.y, U.tx0, U.ty0));
+    }
+  }
+  sh.wtot[wave][lane] = run;
+  lds_barrier();
+  uint32_t base = 0;
+  for (int w = 0; w < wave; ++w) base += sh.wtot[w][lane];
+#pragma unroll
+  for (int i = 0; i < MAXG; ++i) {
+    const uint32_t g = (uint32_t)wave * gpw + i;
+    if ((uint32_t)i < gpw && g < ng) {
+      U.grpbase[(size_t)(g0 + g) * GRP + lane] = base + pre[i];
+      if (lane == 0) U.grpinfo[g0 + g] = U.info;
+    }
+  }
+  if (wave == SORT_BLOCK / 64 - 1) {
+    const uint32_t tot = base + run;
+    U.cntu[(size_t)U.unit * GRP + lane] = tot;
+    const int my_tx = U.tx0 + (lane & (ss - 1)), my_ty = U.ty0 + (lane >> SSH);
+    if (lane < ntile && my_tx < U.tiles_x && my_ty < U.tiles_y && tot) atomicAdd(&U.tile_tot[my_ty * U.tiles_x + my_tx], tot);
+  }
+  lds_barrier();  // (wtot may be written again)
+}
+// The same for a run whose sorted entries are in GLOBAL memory (`out`, `len` of them, a whole number of groups; the
+// byte-pass fallback and the filler behind a cut bucket's last slice): two passes, the totals first.
+template <int SSH>
+__device__ __forceinline__ void count_run_global(const uint4 *out, uint32_t len, uint32_t g0, const Unit &U, UnitShared &sh,
+                                                 bool with_unit_row) {
+  constexpr int ss = 1 << SSH, ntile = ss * ss;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t ng = len / GRP, gpw = (ng + 3) / 4;
+  const uint32_t ga = min((uint32_t)wave * gpw, ng), gb = min(ga + gpw, ng);
+  uint32_t run = 0;
+  for (uint32_t g = ga; g < gb; ++g) {
+    const uint4 en = out[(size_t)g * GRP + lane];
+    run += group_counts<SSH>(tile_mask<SSH>(en.z, en.w, U.tx0, U.ty0));
+  }
+  sh.wtot[wave][lane] = run;
+  lds_barrier();
+  uint32_t base = 0;
+  for (int w = 0; w < wave; ++w) base += sh.wtot[w][lane];
+  uint32_t acc = base;
+  for (uint32_t g = ga; g < gb; ++g) {
+    const uint4 en = out[(size_t)g * GRP + lane];
+    U.grpbase[(size_t)(g0 + g) * GRP + lane] = acc;
+    if (lane == 0) U.grpinfo[g0 + g] = U.info;
+    acc += group_counts<SSH>(tile_mask<SSH>(en.z, en.w, U.tx0, U.ty0));
+  }
+  if (with_unit_row && wave == SORT_BLOCK / 64 - 1) {
+    const uint32_t tot = base + run;
+    U.cntu[(size_t)U.unit * GRP + lane] = tot;
+    const int my_tx = U.tx0 + (lane & (ss - 1)), my_ty = U.ty0 + (lane >> SSH);
+    if (lane < ntile && my_tx < U.tiles_x && my_ty < U.tiles_y && tot) atomicAdd(&U.tile_tot[my_ty * U.tiles_x + my_tx], tot);
+  }
+  lds_barrier();
+}
+__device__ __forceinline__ void count_run_lds_any(int ssh, const uint2 *s_sr, uint32_t len, uint32_t g0, const Unit &U,
+                                                  UnitShared &sh) {
+  switch (ssh) {  // (uniform)
+    case 0: count_run_lds<0>(s_sr, len, g0, U, sh); break;
+    case 1: count_run_lds<1>(s_sr, len, g0, U, sh); break;
+    case 2: count_run_lds<2>(s_sr, len, g0, U, sh); break;
+    default: count_run_lds<3>(s_sr, len, g0, U, sh); break;
+  }
+}
+__device__ __forceinline__ void count_run_global_any(int ssh, const uint4 *out, uint32_t len, uint32_t g0, const Unit &U,
+                                                     UnitShared &sh, bool with_unit_row) {
+  switch (ssh) {
+    case 0: count_run_global<0>(out, len, g0, U, sh, with_unit_row); break;
+    case 1: count_run_global<1>(out, len, g0, U, sh, with_unit_row); break;
+    case 2: count_run_global<2>(out, len, g0, U, sh, with_unit_row); break;
+    default: count_run_global<3>(out, len, g0, U, sh, with_unit_row); break;
+  }
+}
+// a row of zeros for a unit without entries of its own (a slice with an empty share, the slices of a bucket that went
+// to the byte passes as a whole)
+__device__ __forceinline__ void zero_unit_row(const Unit &U) {
+  if (threadIdx.x < GRP) U.cntu[(size_t)U.unit * GRP + threadIdx.x] = 0u;
+}
+
 __device__ __forceinline__ uint4 entry_of(u64 word, const uint16_t *__restrict__ rect) {
   const uint32_t id = (uint32_t)word;
   const uint2 rc = *reinterpret_cast<const uint2 *>(rect + 4 * (size_t)id);
   return make_uint4(id, (uint32_t)(word >> 32), rc.x, rc.y);
 }
 
-// the bucket's words go to la[0, n): eight byte passes a -> b -> ... -> a, then the entries
-__device__ __forceinline__ void radix_fallback(const uint4 *in, u64 *la, u64 *lb, uint4 *out, const uint16_t *rect,
-                                               uint32_t n, uint32_t *s_run, uint32_t (*s_cnt)[256]) {
-  for (uint32_t e = threadIdx.x; e < n; e += SORT_BLOCK) la[e] = ((u64)in[e].x << 32) | (u64)in[e].y;
+// The segments of a bucket (where the level-1 workgroups left its entries), as one virtual array of n entries.
+struct SegTable {
+  uint32_t *off;  // [nseg + 1] exclusive prefix of the segments' lengths (LDS)
+  uint32_t *src;  // [nseg] first entry of the segment in the unsorted array (LDS)
+  uint32_t nseg, steps;
+};
+// fills the table (all threads; ends with a barrier).  nseg <= MAX_SEG.
+__device__ __forceinline__ void load_segments(SegTable &S, const uint2 *__restrict__ segs, uint32_t nseg, uint32_t *s4) {
+  const int tid = threadIdx.x;
+  uint32_t carry = 0;
+  for (uint32_t s0 = 0; s0 < nseg; s0 += SORT_BLOCK) {
+    const uint32_t s = s0 + tid;
+    const uint2 rec = s < nseg ? segs[s] : make_uint2(0u, 0u);
+    uint32_t tot;
+    const uint32_t ex = block_scan_excl(rec.y, s4, tot);
+    if (s < nseg) S.off[s] = carry + ex, S.src[s] = rec.x;
+    carry += tot;
+  }
+  if (tid == 0) S.off[nseg] = carry;
+  S.nseg = nseg;
+  uint32_t steps = 0;
+  while ((1u << steps) < nseg) ++steps;
+  S.steps = steps;
+  lds_barrier();
+}
+// entry e of the bucket (e < n): the last segment whose first entry is <= e, by a search of `steps` halvings
+__device__ __forceinline__ size_t seg_pos(const SegTable &S, uint32_t e) {
+  uint32_t lo = 0;
+  for (uint32_t st = S.steps; st-- > 0;) {
+    const uint32_t mid = lo + (1u << st);
+    if (mid < S.nseg && S.off[mid] <= e) lo = mid;
+  }
+  return (size_t)S.src[lo] + (e - S.off[lo]);
+}
+__device__ __forceinline__ uint4 seg_entry(const SegTable &S, const uint4 *__restrict__ l1tmp, size_t l1cap, uint32_t e) {
+  const size_t p = seg_pos(S, e);
+  // (past the unsorted array: only when the instance capacity overflowed -- the render is flagged and never used)
+  return p < l1cap ? l1tmp[p] : make_uint4(0u, 0u, 0u, 0u);
+}
+
+// the bucket's words go to la[0, n): eight byte passes a -> b -> ... -> a, then the entries (and `pad` empty ones)
+__device__ __forceinline__ void radix_fallback(const SegTable &S, const uint4 *l1tmp, size_t l1cap, u64 *la, u64 *lb,
+                                               uint4 *out, const uint16_t *rect, uint32_t n, uint32_t len, uint32_t *s_run,
+                                               uint32_t (*s_cnt)[256]) {
+  for (uint32_t e = threadIdx.x; e < n; e += SORT_BLOCK) {
+    const uint4 en = seg_entry(S, l1tmp, l1cap, e);
+    la[e] = ((u64)en.x << 32) | (u64)en.y;
+  }
   for (int byte = 0; byte < 8; ++byte) {
     __threadfence_block();
     __syncthreads();
@@ -565,7 +689,9 @@ __device__ __forceinline__ void radix_fallback(const uint4 *in, u64 *la, u64 *lb
   }
   __threadfence_block();
   __syncthreads();
-  for (uint32_t e = threadIdx.x; e < n; e += SORT_BLOCK) out[e] = entry_of(la[e], rect);
+  for (uint32_t e = threadIdx.x; e < len; e += SORT_BLOCK) out[e] = e < n ? entry_of(la[e], rect) : make_uint4(0u, 0u, 0u, 0u);
+  __threadfence_block();
+  __syncthreads();
 }
 
 // exclusive scan of the SUB_BINS counts in s_cur (thread t owns sub-bins [4 t, 4 t + 4)) -> s_start (and, CURSORS,
@@ -594,75 +720,176 @@ __device__ __forceinline__ bool scan_sub_bins(uint32_t *s_cur, uint32_t *s_start
   return *s_big != 0u;
 }
 
-// every entry of s_k[0, m) ranks itself inside its sub-bin and goes to out[...].  Entries are taken in the order they
+// Every entry of s_k[0, m) ranks itself inside its sub-bin and goes to out[...]; entries are taken in the order they
 // sit in LDS (grouped by sub-bin): the 64 lanes of a wave walk the same one or two sub-bins, so a wave's trip count is
-// ITS sub-bins' size, not the largest sub-bin's of the bucket.
-__device__ __forceinline__ void rank_and_store(const u64 *s_k, const uint2 *s_r, const uint32_t *s_start, uint32_t origin,
-                                               uint32_t m, const SubMap &sm, uint4 *__restrict__ out) {
-  for (uint32_t e = threadIdx.x; e < m; e += SORT_BLOCK) {
-    const u64 c = s_k[e];
-    const uint2 rc = s_r[e];
-    const uint32_t f = sub_bin((uint32_t)(c >> 32), sm);
-    const uint32_t lo = s_start[f] - origin, hi = min(s_start[f + 1] - origin, m);
-    uint32_t r = 0;
-    for (uint32_t t = lo; t < hi; t += 8) {  // eight LDS reads in flight (clamped, masked)
-      u64 v[8];
+// ITS sub-bins' size, not the largest sub-bin's of the bucket.  Then the sorted RECTANGLES replace the words in LDS
+// (s_sr aliases s_k: every rank has been formed by then), `len - m` empty entries pad the run to whole groups, and the
+// run's level-2 rows are counted from LDS.
+__device__ __forceinline__ void rank_store_count(u64 *s_k, const uint2 *s_r, const uint32_t *s_start, uint32_t origin,
+                                                 uint32_t m, uint32_t len, const SubMap &sm, uint4 *__restrict__ out,
+                                                 int ssh, uint32_t g0, const Unit &U, UnitShared &sh) {
+  uint32_t pos[PER];
+  uint2 rcs[PER];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = s_k[min(t + u, hi - 1)];
+  for (int q = 0; q < PER; ++q) {
+    const uint32_t e = (uint32_t)q * SORT_BLOCK + threadIdx.x;
+    pos[q] = 0xffffffffu;
+    if (e < m) {
+      const u64 c = s_k[e];
+      const uint2 rc = s_r[e];
+      const uint32_t f = sub_bin((uint32_t)(c >> 32), sm);
+      const uint32_t lo = s_start[f] - origin, hi = min(s_start[f + 1] - origin, m);
+      uint32_t r = 0;
+      for (uint32_t t = lo; t < hi; t += 8) {  // eight LDS reads in flight (clamped, masked)
+        u64 v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) r += (t + u < hi && v[u] < c) ? 1u : 0u;
+        for (int u = 0; u < 8; ++u) v[u] = s_k[min(t + u, hi - 1)];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) r += (t + u < hi && v[u] < c) ? 1u : 0u;
+      }
+      pos[q] = lo + r, rcs[q] = rc;
+      out[lo + r] = make_uint4((uint32_t)c, (uint32_t)(c >> 32), rc.x, rc.y);
     }
-    out[lo + r] = make_uint4((uint32_t)c, (uint32_t)(c >> 32), rc.x, rc.y);
   }
+  lds_barrier();  // (every rank has been formed: the words are dead)
+  uint2 *s_sr = reinterpret_cast<uint2 *>(s_k);
+#pragma unroll
+  for (int q = 0; q < PER; ++q)
+    if (pos[q] != 0xffffffffu) s_sr[pos[q]] = rcs[q];
+  for (uint32_t e = m + threadIdx.x; e < len; e += SORT_BLOCK) s_sr[e] = make_uint2(0u, 0u), out[e] = make_uint4(0u, 0u, 0u, 0u);
+  lds_barrier();
+  count_run_lds_any(ssh, s_sr, len, g0, U, sh);
 }
+
+__device__ __forceinline__ uint32_t pad_grp(uint32_t n) { return (n + GRP - 1) / GRP * GRP; }
 
 __device__ __forceinline__ void bucket_sort_body(const BinArgs &a, void *geom, void *bin) {
   __shared__ u64 s_k[BIN_CAP];
   __shared__ uint2 s_r[BIN_CAP];  // the entries' tile rectangles travel with them (a gather of rect[id] per sorted
                                   // entry cost 8 us per 8 renders: random 8-byte reads)
-  __shared__ uint32_t s_start[SUB_BINS + 1], s_cur[SUB_BINS];
+  __shared__ uint32_t s_sub[2 * SUB_BINS + 1];  // sub-bin starts [SUB_BINS + 1], then counters / cursors [SUB_BINS]
+  uint32_t *const s_start = s_sub, *const s_cur = s_sub + SUB_BINS + 1;
   __shared__ uint32_t s_run[256];
   __shared__ uint32_t s_big;
+  __shared__ uint32_t s_wt[4];
+  __shared__ UnitShared s_unit;
   uint32_t (*s_cnt)[256] = reinterpret_cast<uint32_t (*)[256]>(s_cur);  // (the fallback sort's counters: s_cur is free then)
   static_assert(SUB_BINS >= (SORT_BLOCK / 64) * 256, "s_cnt overlay");
+  // the segment table of the bucket at hand lives where the sub-bin tables will be (it is consumed -- the entries are
+  // in registers -- before the first sub-bin is counted), except on the paths that read the entries more than once
+  static_assert(2 * MAX_SEG + 1 <= 2 * SUB_BINS + 1 && 2 * MAX_SEG + 1 <= 2 * BIN_CAP, "segment table overlays");
   const uint32_t *__restrict__ bk = at<uint32_t>(geom, a.g_bk);
+  const u64 *__restrict__ bk_tot = reinterpret_cast<const u64 *>(bk + BK_TOT);
   const uint16_t *__restrict__ rect = at<uint16_t>(geom, a.g_rect);
+  const uint2 *__restrict__ segs = at<uint2>(geom, a.g_segs);
   const uint4 *__restrict__ l1tmp = at<uint4>(bin, a.b_l1tmp);
   u64 *__restrict__ l1a = at<u64>(bin, a.b_l1a);
   u64 *__restrict__ l1b = at<u64>(bin, a.b_l1b);
   uint4 *__restrict__ l1list = at<uint4>(bin, a.b_l1);
   const int tid = threadIdx.x;
   const int nbins = 1 << a.lg, nbuckets = a.gi.NS << a.lg;
-  // ---- the workgroup's buckets: b = blockIdx.x, + gridDim.x, ... (at most MAXB of them: see bucket_grid).  Their
-  // (size, start, slices) words are fetched at once.
-  __shared__ uint32_t s_bn[MAXB], s_bbase[MAXB], s_bj[MAXB];
+  constexpr int OWN = MAX_BUCKETS / SORT_BLOCK;
   BinTrace tr(3);
-  if (tid < MAXB) {
-    const uint32_t b = blockIdx.x + (uint32_t)tid * gridDim.x;
-    s_bn[tid] = b < (uint32_t)nbuckets ? bk[BK_TOT + b] : 0u;
-    s_bbase[tid] = b < (uint32_t)nbuckets ? bk[BK_START + b] : 0u;
-    s_bj[tid] = b < (uint32_t)nbuckets ? bk[BK_BINJ + b] : 0u;
+  // ---- where every bucket's sorted entries start, which buckets are cut into slices, and the rows (units) of their
+  // per-tile totals: every workgroup scans the bucket totals itself (thread t owns buckets [8 t, 8 t + 8)).
+  // The workgroup's own buckets are b = blockIdx.x, + gridDim.x, ... (at most MAXB: see bucket_grid), its slices
+  // t = blockIdx.x, + gridDim.x, ... of the launch's slice list (at most MAXSL).
+  __shared__ uint32_t s_bn[MAXB], s_bbase[MAXB], s_bj[MAXB], s_bu[MAXB], s_bnseg[MAXB];
+  __shared__ uint32_t s_sb[MAXSL], s_sj[MAXSL];  // slices of this workgroup: bucket; J << 8 | j
+  __shared__ uint32_t s_sn[MAXSL], s_sbase[MAXSL], s_su[MAXSL], s_snseg[MAXSL];
+  __shared__ uint32_t s_nslice;
+  uint32_t *const s_unit_of = reinterpret_cast<uint32_t *>(s_k);  // [MAX_BUCKETS] first unit of the bucket (prologue only)
+  {
+    uint32_t tot[OWN], nsg[OWN], want[OWN], wsum = 0;
+#pragma unroll
+    for (int u = 0; u < OWN; ++u) {
+      const u64 w = tid * OWN + u < nbuckets ? bk_tot[tid * OWN + u] : 0ull;
+      tot[u] = (uint32_t)w, nsg[u] = (uint32_t)(w >> 32);
+      const uint32_t J = tot[u] > (uint32_t)BIN_CAP ? (tot[u] + SLICE_TARGET - 1) / SLICE_TARGET : 0u;
+      want[u] = J <= 255u ? J : 0u;  // (more: the byte passes)
+      wsum += want[u];
+    }
+    if (tid < MAXB) s_bn[tid] = 0u;
+    if (tid < MAXSL) s_sn[tid] = 0u;
+    uint32_t wall;
+    uint32_t wrun = block_scan_excl(wsum, s_wt, wall);
+    // a bucket gets its slices while the list has room (in bucket order: every workgroup takes the same decision)
+    uint32_t J[OWN], reg[OWN], rsum = 0, usum = 0;
+#pragma unroll
+    for (int u = 0; u < OWN; ++u) {
+      J[u] = want[u] && wrun + want[u] <= (uint32_t)MAX_SLICES ? want[u] : 0u;
+      wrun += want[u];
+      reg[u] = tot[u] ? pad_grp(tot[u] + (uint32_t)GRP * J[u]) : 0u;
+      rsum += reg[u], usum += tot[u] ? max(J[u], 1u) : 0u;
+    }
+    wrun -= wsum;  // (back to the exclusive prefix: the first slice of the thread's first cut bucket)
+    uint32_t rall, uall;
+    uint32_t start = block_scan_excl(rsum, s_wt, rall);
+    uint32_t unit = block_scan_excl(usum, s_wt, uall);
+#pragma unroll
+    for (int u = 0; u < OWN; ++u) s_unit_of[tid * OWN + u] = unit, unit += tot[u] ? max(J[u], 1u) : 0u;
+    unit -= usum;
+    lds_barrier();
+    uint32_t srun = wrun;
+#pragma unroll
+    for (int u = 0; u < OWN; ++u) {
+      const uint32_t b = (uint32_t)(tid * OWN + u);
+      if (tot[u]) {
+        if (b % gridDim.x == blockIdx.x && b / gridDim.x < (uint32_t)MAXB) {
+          const uint32_t k = b / gridDim.x;
+          s_bn[k] = tot[u], s_bbase[k] = start, s_bj[k] = J[u], s_bnseg[k] = nsg[u];
+          s_bu[k] = unit | (s_unit_of[(b >> a.lg) << a.lg] << 12) | ((b >> a.lg) << 24);
+        }
+        for (uint32_t j = 0; j < J[u]; ++j) {
+          const uint32_t t = srun + j;
+          if (t % gridDim.x == blockIdx.x && t / gridDim.x < (uint32_t)MAXSL) {
+            const uint32_t k = t / gridDim.x;
+            s_sb[k] = b, s_sj[k] = (J[u] << 8) | j, s_sn[k] = tot[u], s_sbase[k] = start, s_snseg[k] = nsg[u];
+            s_su[k] = (unit + j) | (s_unit_of[(b >> a.lg) << a.lg] << 12) | ((b >> a.lg) << 24);
+          }
+        }
+        srun += J[u];
+      }
+      start += reg[u], unit += tot[u] ? max(J[u], 1u) : 0u;
+    }
+    if (blockIdx.x == 0 && tid == 0) {
+      // the groups the fill walks: those of the buckets that fit the sorted array whole (all of them unless the
+      // instance capacity overflowed; the buckets are laid out in order, so the ones that fit are a prefix)
+      uint32_t *meta = at<uint32_t>(bin, a.b_meta);
+      meta[META_NGRP] = (uint32_t)(min((size_t)rall, a.l1cap) / GRP);
+    }
+    if (tid == 0) s_nslice = min(wall, (uint32_t)MAX_SLICES);
   }
   const uint32_t map_lo = bk[BK_KMIN], map_shift = bk[BK_SHIFT];
   __syncthreads();
+  Unit U;
+  U.grpbase = at<uint32_t>(bin, a.b_grpbase), U.grpinfo = at<uint32_t>(bin, a.b_grpinfo), U.cntu = at<uint32_t>(bin, a.b_cntu);
+  U.tile_tot = at<uint32_t>(bin, a.b_totals), U.tiles_x = a.gi.tiles_x, U.tiles_y = a.gi.tiles_y;
+  SegTable S;
+  S.off = s_sub, S.src = s_sub + MAX_SEG + 1;
   uint4 mine[PER];
   tr.mark();
   for (int k = 0; k < MAXB; ++k) {
     const uint32_t b = blockIdx.x + (uint32_t)k * gridDim.x;
     if (b >= (uint32_t)nbuckets) break;
     const uint32_t n = s_bn[k], base = s_bbase[k];
-    if (n == 0u || (size_t)base + n > a.l1cap) continue;  // (the second cannot happen while the instance capacity holds)
+    if (n == 0u) continue;
     if (n > (uint32_t)BIN_CAP && s_bj[k] != 0u) continue;  // cut into slices: sorted below
+    const uint32_t len = pad_grp(n);
+    if ((size_t)base + len > a.l1cap) continue;  // (only when the instance capacity overflowed)
+    const uint32_t sup = b >> a.lg;
+    U.unit = s_bu[k] & 0xfffu, U.info = s_bu[k];
+    U.tx0 = (int)((sup % a.gi.stx) << a.gi.ss_shift), U.ty0 = (int)((sup / a.gi.stx) << a.gi.ss_shift);
     const SubMap sm = sub_bin_map(map_lo, map_shift, b & (uint32_t)(nbins - 1));
+    lds_barrier();  // (the previous bucket's LDS has been consumed)
+    load_segments(S, segs + (size_t)b * a.nwg1, min(s_bnseg[k], (uint32_t)a.nwg1), s_wt);
     bool lds = n <= (uint32_t)BIN_CAP;
     if (lds) {
-      // the thread's entries, every load issued before the first use.  (Requesting bucket k + 1's entries before
-      // bucket k is sorted was tried: the second register set cost a third of the occupancy and more than the overlap
-      // returned.)
+      // the thread's entries, every load issued before the first use
 #pragma unroll
       for (int q = 0; q < PER; ++q)
-        if ((uint32_t)q * SORT_BLOCK < n) mine[q] = l1tmp[base + min((uint32_t)q * SORT_BLOCK + tid, n - 1)];
-      lds_barrier();  // (the previous bucket's LDS has been consumed)
+        if ((uint32_t)q * SORT_BLOCK < n) mine[q] = seg_entry(S, l1tmp, a.l1cap, min((uint32_t)q * SORT_BLOCK + tid, n - 1));
+      lds_barrier();  // (the segment table has been read)
 #pragma unroll
       for (int u = 0; u < SUB_OWN; ++u) s_cur[tid * SUB_OWN + u] = 0u;
       if (tid == 0) s_big = 0u;
@@ -672,10 +899,21 @@ __device__ __forceinline__ void bucket_sort_body(const BinArgs &a, void *geom, v
         if ((uint32_t)q * SORT_BLOCK + tid < n) atomicAdd(&s_cur[sub_bin(mine[q].x, sm)], 1u);
       lds_barrier();
       lds = !scan_sub_bins<true>(s_cur, s_start, s_run, &s_big);  // (workgroup-uniform)
+      if (!lds) {  // (the byte passes read the segments again)
+        lds_barrier();
+        load_segments(S, segs + (size_t)b * a.nwg1, min(s_bnseg[k], (uint32_t)a.nwg1), s_wt);
+      }
     }
     if (!lds) {  // hundreds of entries at nearly one depth, or an oversized bucket the slice list had no room for
+      // (the segment table moves out of the counters' way first)
+      uint32_t *keep = reinterpret_cast<uint32_t *>(s_r);
+      for (uint32_t s = tid; s <= S.nseg; s += SORT_BLOCK) keep[s] = S.off[s];
+      for (uint32_t s = tid; s < S.nseg; s += SORT_BLOCK) keep[MAX_SEG + 1 + s] = S.src[s];
+      SegTable K = S;
+      K.off = keep, K.src = keep + MAX_SEG + 1;
       __syncthreads();
-      radix_fallback(l1tmp + base, l1a + base, l1b + base, l1list + base, rect, n, s_run, s_cnt);
+      radix_fallback(K, l1tmp, a.l1cap, l1a + base, l1b + base, l1list + base, rect, n, len, s_run, s_cnt);
+      count_run_global_any(a.gi.ss_shift, l1list + base, len, base / GRP, U, s_unit, true);
       __syncthreads();
       continue;
     }
@@ -687,23 +925,31 @@ __device__ __forceinline__ void bucket_sort_body(const BinArgs &a, void *geom, v
         s_r[p] = make_uint2(mine[q].z, mine[q].w);
       }
     lds_barrier();
-    rank_and_store(s_k, s_r, s_start, 0u, n, sm, l1list + base);
+    rank_store_count(s_k, s_r, s_start, 0u, n, len, sm, l1list + base, a.gi.ss_shift, base / GRP, U, s_unit);
     tr.mark();
   }
   tr.mark();
   {
     // ---- slices of oversized buckets: every slice counts the bucket's sub-bins itself, takes the run of sub-bins
     // whose first entry falls into its share of the bucket, and sorts those (<= SLICE_TARGET + SUB_MAX = BIN_CAP entries)
-    __syncthreads();
-    const uint32_t n_slices = bk[BK_NSLICE];
-    for (uint32_t t = blockIdx.x; t < n_slices; t += gridDim.x) {
-      const uint32_t code = bk[BK_SLICE + t];
-      if (code == 0xffffffffu) continue;
-      const uint32_t b = code >> 16, J = (code >> 8) & 255u, j = code & 255u;
-      const uint32_t base = bk[BK_START + b], n = bk[BK_TOT + b];
-      if ((size_t)base + n > a.l1cap) continue;  // (cannot happen while the instance capacity holds)
+    uint32_t *const keep = reinterpret_cast<uint32_t *>(s_r);  // the segment table (the slice's own entries go to s_r LAST)
+    const uint32_t n_slices = s_nslice;
+    for (int k = 0; k < MAXSL; ++k) {
+      const uint32_t t = blockIdx.x + (uint32_t)k * gridDim.x;
+      if (t >= n_slices) break;
+      const uint32_t n = s_sn[k];
+      if (n == 0u) continue;
+      const uint32_t b = s_sb[k], J = s_sj[k] >> 8, j = s_sj[k] & 255u, base = s_sbase[k];
+      const uint32_t reserved = pad_grp(n + (uint32_t)GRP * J);
+      if ((size_t)base + reserved > a.l1cap) continue;  // (only when the instance capacity overflowed)
+      const uint32_t sup = b >> a.lg;
+      U.unit = s_su[k] & 0xfffu, U.info = s_su[k];
+      U.tx0 = (int)((sup % a.gi.stx) << a.gi.ss_shift), U.ty0 = (int)((sup / a.gi.stx) << a.gi.ss_shift);
       const SubMap sm = sub_bin_map(map_lo, map_shift, b & (uint32_t)(nbins - 1));
       __syncthreads();  // (the previous slice's LDS has been consumed)
+      SegTable K;
+      K.off = keep, K.src = keep + MAX_SEG + 1;
+      load_segments(K, segs + (size_t)b * a.nwg1, min(s_snseg[k], (uint32_t)a.nwg1), s_wt);
 #pragma unroll
       for (int u = 0; u < SUB_OWN; ++u) s_cur[tid * SUB_OWN + u] = 0u;
       if (tid == 0) s_big = 0u;
@@ -711,326 +957,267 @@ __device__ __forceinline__ void bucket_sort_body(const BinArgs &a, void *geom, v
       for (uint32_t e0 = 0; e0 < n; e0 += 8 * SORT_BLOCK) {
         uint32_t kk[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) kk[q] = l1tmp[base + min(e0 + q * SORT_BLOCK + tid, n - 1)].x;
+        for (int q = 0; q < 8; ++q) kk[q] = seg_entry(K, l1tmp, a.l1cap, min(e0 + q * SORT_BLOCK + tid, n - 1)).x;
 #pragma unroll
         for (int q = 0; q < 8; ++q)
           if (e0 + q * SORT_BLOCK + tid < n) atomicAdd(&s_cur[sub_bin(kk[q], sm)], 1u);
       }
       __syncthreads();
       if (scan_sub_bins<false>(s_cur, s_start, s_run, &s_big)) {  // a sub-bin too large to rank: slice 0 sorts the
-        if (j == 0) {                                              // whole bucket the slow way
+        if (j == 0) {                                              // whole bucket the slow way, as ONE run
           __syncthreads();
-          radix_fallback(l1tmp + base, l1a + base, l1b + base, l1list + base, rect, n, s_run, s_cnt);
+          radix_fallback(K, l1tmp, a.l1cap, l1a + base, l1b + base, l1list + base, rect, n, reserved, s_run, s_cnt);
+          count_run_global_any(a.gi.ss_shift, l1list + base, reserved, base / GRP, U, s_unit, true);
+        } else {
+          zero_unit_row(U);
         }
         continue;
       }
-      // this slice's sub-bins [f0, f1): those whose first entry lies in [j Tn, (j + 1) Tn) and that are not empty
+      // The slices' boundaries in the sorted bucket: P[i] = first entry of the first non-empty sub-bin that starts at
+      // or behind i Tn (P[0] = 0, P[J] = n).  A non-empty sub-bin [S, E) makes E the boundary of every i with
+      // S < i Tn <= E.  (s_run has 256 words: J <= 255.)
       const uint32_t Tn = (n + J - 1) / J;
-      uint32_t mnf = 0xffffu, mxf = 0u;
+      s_run[tid] = tid == 0 ? 0u : n;
+      lds_barrier();
 #pragma unroll
       for (int u = 0; u < SUB_OWN; ++u) {
-        const uint32_t f = (uint32_t)(tid * SUB_OWN + u), my0 = s_start[f];
-        if (my0 >= j * Tn && my0 < (j + 1) * Tn && s_start[f + 1] > my0) mnf = min(mnf, f), mxf = max(mxf, f + 1u);
+        const uint32_t f = (uint32_t)(tid * SUB_OWN + u), sb = s_start[f], se = s_start[f + 1];
+        if (se > sb)
+          for (uint32_t i = sb / Tn + 1; i * Tn <= se && i < J; ++i) s_run[i] = se;
       }
-      mnf = wave_min(mnf), mxf = wave_max(mxf);
-      if ((tid & 63) == 0) s_run[tid >> 6] = mnf, s_run[4 + (tid >> 6)] = mxf;
-      __syncthreads();
-      const uint32_t f0 = min(min(s_run[0], s_run[1]), min(s_run[2], s_run[3]));
-      const uint32_t f1 = max(max(s_run[4], s_run[5]), max(s_run[6], s_run[7]));
-      __syncthreads();
-      if (f0 >= f1) continue;  // (an empty share)
-      const uint32_t first = s_start[f0];
+      lds_barrier();
+      // this slice: sorted entries [P[j], P[j + 1]); its run starts behind the earlier slices' runs, each rounded up
+      // to whole groups
+      const uint32_t first = s_run[j], m = min(s_run[j + 1] - first, (uint32_t)BIN_CAP);
+      uint32_t oall;
+      const uint32_t oex = block_scan_excl((uint32_t)tid < J ? pad_grp(s_run[tid + 1] - s_run[tid]) : 0u, s_wt, oall);
+      if ((uint32_t)tid == j) s_big = oex;  // (s_big is free: the fat sub-bin test has been read)
+      lds_barrier();
+      const uint32_t run_off = s_big, len = pad_grp(m);
+      if (m > 0u) {
+        // cursors: the slice's sub-bins start at `first`
 #pragma unroll
-      for (int u = 0; u < SUB_OWN; ++u) s_cur[tid * SUB_OWN + u] = s_start[tid * SUB_OWN + u] - first;  // cursors
-      __syncthreads();
-      for (uint32_t e0 = 0; e0 < n; e0 += 8 * SORT_BLOCK) {
-        uint4 kv[8];
+        for (int u = 0; u < SUB_OWN; ++u) s_cur[tid * SUB_OWN + u] = s_start[tid * SUB_OWN + u] - first;
+        lds_barrier();
+        // the slice's entries: the bucket is read once more, through registers (s_r still holds the segment table)
+        for (uint32_t e0 = 0; e0 < n; e0 += 8 * SORT_BLOCK) {
+          uint4 kv[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) kv[q] = l1tmp[base + min(e0 + q * SORT_BLOCK + tid, n - 1)];
+          for (int q = 0; q < 8; ++q) kv[q] = seg_entry(K, l1tmp, a.l1cap, min(e0 + q * SORT_BLOCK + tid, n - 1));
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const uint32_t f = sub_bin(kv[q].x, sm);
-          if (e0 + q * SORT_BLOCK + tid < n && f >= f0 && f < f1) {
-            const uint32_t p = atomicAdd(&s_cur[f], 1u);
-            if (p < (uint32_t)BIN_CAP) s_k[p] = ((u64)kv[q].x << 32) | (u64)kv[q].y, s_r[p] = make_uint2(kv[q].z, kv[q].w);
+          for (int q = 0; q < 8; ++q) {
+            const uint32_t sbn = s_start[min(sub_bin(kv[q].x, sm), (uint32_t)SUB_BINS - 1u)];
+            if (e0 + q * SORT_BLOCK + tid < n && sbn >= first && sbn < first + m) {
+              const uint32_t p = atomicAdd(&s_cur[sub_bin(kv[q].x, sm)], 1u);
+              // (word now, rectangle once every thread has left the segment table: below)
+              if (p < (uint32_t)BIN_CAP) s_k[p] = ((u64)kv[q].x << 32) | (u64)kv[q].y;
+            }
           }
         }
+        __syncthreads();
+        // the rectangles of the slice's entries, by id (the segment table in s_r is dead now)
+        for (uint32_t e = tid; e < m; e += SORT_BLOCK)
+          s_r[e] = *reinterpret_cast<const uint2 *>(rect + 4 * (size_t)(uint32_t)s_k[e]);
+        lds_barrier();
+        rank_store_count(s_k, s_r, s_start, first, m, len, sm, l1list + base + run_off, a.gi.ss_shift,
+                         (base + run_off) / GRP, U, s_unit);
+      } else {
+        zero_unit_row(U);
       }
-      __syncthreads();
-      const uint32_t m = min(s_start[f1] - first, (uint32_t)BIN_CAP);  // entries of the slice
-      rank_and_store(s_k, s_r, s_start, first, m, sm, l1list + base + first);
+      if (j == J - 1) {  // what the bucket reserved beyond its slices' runs: empty entries, empty rows
+        const uint32_t used = oall;
+        if (used < reserved) {
+          for (uint32_t e = used + tid; e < reserved; e += SORT_BLOCK) l1list[base + e] = make_uint4(0u, 0u, 0u, 0u);
+          __threadfence_block();
+          __syncthreads();
+          count_run_global_any(a.gi.ss_shift, l1list + base + used, reserved - used, (base + used) / GRP, U, s_unit, false);
+        }
+      }
       tr.mark();
     }
   }
   tr.flush();
 }
 
-// ------------------------------------------------------------------------------------ 4. / 5. level 2
-// A workgroup (4 waves) works through windows w = blockIdx.x, + gridDim.x, ... of 256 entries each, one wave per 64
-// entries; the NEXT window's table words and entries are requested before the current one is worked on.  These
-// kernels are INSTRUCTION-ISSUE bound (a few thousand short waves: ~0.6 M wave-instructions per us chip-wide whatever
-// the mix -- tools/latency_model.hip, profiles/r03_sq_binning.txt), so the walk is written for instruction count: the
-// supertile edge is a template parameter, every entry forms the bit mask of the supertile's tiles its rectangle
-// covers once (a row mask times a column pattern), and the per-tile loop is unrolled over the mask bits: one ballot,
-// one popcount and one v_writelane (count) or one v_readlane + mbcnt + three stores (fill) per tile.
-// Lane j of every wave owns tile j of the supertile.  Count pass: each wave's per-tile counts -> cnt2w[window][wave]
-// [tile], the window's totals -> cnt2[window][tile] and, atomically, the tile totals.  Fill pass: a wave starts at the
-// tile's start + the counts of the supertile's earlier windows + the counts of the waves before it.
-template <int J>
-__device__ __forceinline__ uint32_t writelane(uint32_t v, uint32_t sval) {  // v[lane J] = sval (one SGPR operand: J is an immediate)
-  asm("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(sval), "n"(J));
-  return v;
-}
-template <int J, int N, class F>
-__device__ __forceinline__ void static_for(F &&f) {
-  if constexpr (J < N) {
-    f(std::integral_constant<int, J>{});
-    static_for<J + 1, N>(f);
-  }
-}
-constexpr int TS_LDS = 4096;  // tiles whose starts a fill workgroup keeps in LDS (1024^2 pixels); beyond: re-walked per window
-
+// ------------------------------------------------------------------------------------ 3. level 2, second half: fill
+// A WAVE per group of 64 sorted entries (persistent: group g = 4 blockIdx.x + wave, + 4 gridDim.x, ...), the next
+// group's entries and words requested before the current one is worked on.  No barrier inside the loop.
+// These kernels are INSTRUCTION-ISSUE bound, so the walk is written for instruction count: the supertile edge is a
+// template parameter, every entry forms the bit mask of the supertile's tiles its rectangle covers once, and the
+// per-tile loop is unrolled over the mask bits: one ballot, one v_readlane, mbcnt and ONE store per tile.
+// Lane j of every wave owns tile j of the supertile: its next free slot.
 template <int SSH>
-__device__ __forceinline__ u64 tile_mask(bool valid, const uint4 en, int tx0, int ty0) {
-  constexpr int ss = 1 << SSH;
-  const int x0 = en.z & 0xffff, y0 = en.z >> 16, x1 = en.w & 0xffff, y1 = en.w >> 16;
-  const int lx0 = max(x0 - tx0, 0), lx1 = min(x1 - tx0, ss), ly0 = max(y0 - ty0, 0), ly1 = min(y1 - ty0, ss);
-  if (!(valid && lx1 > lx0 && ly1 > ly0)) return 0ull;
-  const uint32_t rm = (1u << lx1) - (1u << lx0);  // the covered tiles of one row
-  if (SSH == 3) {
-    const u64 hi = ly1 >= 8 ? ~0ull : ((1ull << (8 * ly1)) - 1ull), lo = (1ull << (8 * ly0)) - 1ull;
-    return (u64)rm * ((hi ^ lo) & 0x0101010101010101ull);
-  }
-  const uint32_t yr = ((1u << (ss * ly1)) - (1u << (ss * ly0))) & (SSH == 2 ? 0x1111u : (SSH == 1 ? 0x5u : 0x1u));
-  return (u64)(rm * yr);
-}
-
-struct L2Shared {  // (declared once in level2_dispatch: the four supertile-edge instances share it)
-  uint32_t c[SEG / 64][64];
-  uint32_t tsw[64];  // fill, T > TS_LDS: first slot of the current supertile's tiles
-  uint32_t wt[4];
-};
-template <bool FILL, int SSH>
-__device__ __forceinline__ void level2_body(const BinArgs &a, void *geom, void *bin, uint8_t *__restrict__ grad_flags,
-                                            uint32_t *__restrict__ totals_out, L2Shared &sh,
-                                            uint32_t *s_ts /* fill: first slot of every tile (T <= TS_LDS) */) {
+__device__ __forceinline__ void level2_fill_body(const BinArgs &a, void *geom, void *bin, uint8_t *__restrict__ grad_flags,
+                                                 uint32_t *__restrict__ totals_out, uint32_t *s_ts, uint32_t *s_wt) {
   constexpr int ss = 1 << SSH, ntile = ss * ss;
-  uint32_t (&s_c)[SEG / 64][64] = sh.c;
-  uint32_t (&s_tsw)[64] = sh.tsw;
-  uint32_t (&s_wt)[4] = sh.wt;
   const uint32_t *__restrict__ meta = at<uint32_t>(bin, a.b_meta);
-  const uint4 *__restrict__ wintab = reinterpret_cast<const uint4 *>(meta + META_WIN);
   const uint4 *__restrict__ l1list = at<uint4>(bin, a.b_l1);
-  uint32_t *__restrict__ cnt2 = at<uint32_t>(bin, a.b_cnt2);
-  uint32_t *__restrict__ cnt2w = cnt2 + a.max_windows * 64;
+  const uint32_t *__restrict__ grpbase = at<uint32_t>(bin, a.b_grpbase);
+  const uint32_t *__restrict__ grpinfo = at<uint32_t>(bin, a.b_grpinfo);
+  const uint32_t *__restrict__ cntu = at<uint32_t>(bin, a.b_cntu);
   uint32_t *__restrict__ tile_tot = at<uint32_t>(bin, a.b_totals);
-  uint32_t *__restrict__ dkeys = at<uint32_t>(bin, a.b_dkeys);
   uint32_t *__restrict__ vals = at<uint32_t>(bin, a.b_vals);
+  const uint32_t *__restrict__ total = at<uint32_t>(geom, a.g_total);
   const int tiles_x = a.gi.tiles_x, tiles_y = a.gi.tiles_y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  BinTrace tr(FILL ? 5 : 4);
-  // the first window's entries and table words do not depend on anything: requested together with the window count
-  uint32_t w = blockIdx.x;
-  uint4 en_n = (size_t)w * SEG + tid < a.l1cap ? l1list[(size_t)w * SEG + tid] : make_uint4(0u, 0u, 0u, 0u);
-  uint4 rec_n = w < a.max_windows ? wintab[w] : make_uint4(0u, 0u, 0u, 0u);
-  const uint32_t n_win = meta[META_NWIN];
-  // fill: exclusive scan of the tile totals, by every workgroup itself -- thread t owns tiles [t K, (t + 1) K)
-  const int K = (a.T + SEG - 1) / SEG;
-  const bool ts_lds = a.T <= TS_LDS;
+  BinTrace tr(5);
+  // the first group's entries and words do not depend on anything: requested together with the group count
+  const uint32_t gstride = gridDim.x * (SORT_BLOCK / 64);
+  uint32_t g = blockIdx.x * (SORT_BLOCK / 64) + wave;
+  const uint32_t max_groups = (uint32_t)(a.l1cap / GRP);
+  uint4 en_n = g < max_groups ? l1list[(size_t)g * GRP + lane] : make_uint4(0u, 0u, 0u, 0u);
+  uint32_t row_n = g < max_groups ? grpbase[(size_t)g * GRP + lane] : 0u;
+  uint32_t info_n = g < max_groups ? grpinfo[g] : 0u;
+  const uint32_t n_grp = meta[META_NGRP];
+  const uint32_t R = total[0];
+  // exclusive scan of the tile totals, by every workgroup itself -- thread t owns tiles [t K, (t + 1) K)
+  const int K = (a.T + SORT_BLOCK - 1) / SORT_BLOCK;
   uint32_t my_first = 0;  // instances before this thread's tiles
-  if (FILL) {
-    if (blockIdx.x >= n_win && blockIdx.x != 0) return;
+  {
     uint32_t sum = 0;
     for (int q = 0; q < K; ++q) sum += tid * K + q < a.T ? tile_tot[tid * K + q] : 0u;
-    const uint32_t inc = wave_scan_incl(sum, lane);
-    if (lane == 63) s_wt[wave] = inc;
-    lds_barrier();
-    my_first = inc - sum;
-    for (int q = 0; q < wave; ++q) my_first += s_wt[q];
-    {
-      uint32_t run = my_first;
-      for (int q = 0; q < K; ++q) {
-        const int t = tid * K + q;
-        if (t >= a.T) break;
-        if (ts_lds) s_ts[t] = run;
-        run += tile_tot[t];
-      }
-    }
-    if (blockIdx.x == 0) {
-      // tile ranges clamped to the instance capacity, overflow flag, and the backward's three work counters cleared
-      // for the blend forward behind this kernel
-      uint32_t *ranges = at<uint32_t>(bin, a.b_ranges), *total = at<uint32_t>(geom, a.g_total);
-      uint32_t *work_count = at<uint32_t>(bin, a.b_work);
-      if (tid == 0) work_count[0] = 0, work_count[1] = 0, work_count[2] = 0;
-      // ... and the bucket totals, so that the chain can run again on the same projection (preprocess clears them too)
-      uint32_t *bk = at<uint32_t>(geom, a.g_bk);
-      for (int t = tid; t < MAX_BUCKETS; t += SEG) bk[BK_TOT + t] = 0u;
-      uint32_t run = my_first;
-      int ovf = 0;
-      for (int q = 0; q < K; ++q) {
-        const int t = tid * K + q;
-        if (t >= a.T) break;
-        const uint32_t v = tile_tot[t];
-        // an empty tile reports (0, 0) like the published identifyTileRanges leaves it
-        ranges[2 * t] = v ? min(run, a.R_cap) : 0u, ranges[2 * t + 1] = v ? min(run + v, a.R_cap) : 0u;
-        if (run + v > a.R_cap) total[1] = 1, ovf = 1;  // capacity overflow: flagged, never written out of bounds
-        run += v;
-      }
-      ovf = __syncthreads_or(ovf);
-      // the render's (R, overflow) for the step-level array (dimo_render_desc.totals_out)
-      if (totals_out && tid == 0) totals_out[0] = total[0], totals_out[1] = (uint32_t)(ovf != 0);
+    uint32_t all;
+    my_first = block_scan_excl(sum, s_wt, all);
+    uint32_t run = my_first;
+    for (int q = 0; q < K; ++q) {
+      const int t = tid * K + q;
+      if (t >= a.T) break;
+      s_ts[t] = run;
+      run += tile_tot[t];
     }
   }
+  if (grad_flags) {
+    // the backward's "gradient record written" flags, indexed by instance slot: cleared over [0, R) with wide stores
+    const size_t nb16 = ((size_t)min(R, a.R_cap) + 15) / 16;
+    uint4 *f4 = reinterpret_cast<uint4 *>(grad_flags);
+    for (size_t q = (size_t)blockIdx.x * SORT_BLOCK + tid; q < nb16; q += (size_t)gridDim.x * SORT_BLOCK)
+      f4[q] = make_uint4(0u, 0u, 0u, 0u);
+  }
+  if (blockIdx.x == 0) {
+    // tile ranges clamped to the instance capacity, overflow flag, and the backward's three work counters cleared
+    // for the blend forward behind this kernel
+    uint32_t *ranges = at<uint32_t>(bin, a.b_ranges), *total_w = at<uint32_t>(geom, a.g_total);
+    uint32_t *work_count = at<uint32_t>(bin, a.b_work);
+    if (tid == 0) work_count[0] = 0, work_count[1] = 0, work_count[2] = 0;
+    // ... and the bucket totals, so that the chain can run again on the same projection (preprocess clears them too)
+    uint32_t *bk = at<uint32_t>(geom, a.g_bk);
+    for (int t = tid; t < 2 * MAX_BUCKETS; t += SORT_BLOCK) bk[BK_TOT + t] = 0u;
+    uint32_t run = my_first;
+    int ovf = total_w[1] != 0u;
+    for (int q = 0; q < K; ++q) {
+      const int t = tid * K + q;
+      if (t >= a.T) break;
+      const uint32_t v = tile_tot[t];
+      // an empty tile reports (0, 0) like the published identifyTileRanges leaves it
+      ranges[2 * t] = v ? min(run, a.R_cap) : 0u, ranges[2 * t + 1] = v ? min(run + v, a.R_cap) : 0u;
+      if (run + v > a.R_cap) total_w[1] = 1, ovf = 1;  // capacity overflow: flagged, never written out of bounds
+      run += v;
+    }
+    ovf = __syncthreads_or(ovf);
+    // the render's (R, overflow) for the step-level array (dimo_render_desc.totals_out)
+    if (totals_out && tid == 0) totals_out[0] = R, totals_out[1] = (uint32_t)(ovf != 0);
+  }
+  lds_barrier();  // (the tile starts are complete)
   tr.mark();
-  for (; w < n_win; w += gridDim.x) {
-    tr.mark();
+  for (; g < n_grp; g += gstride) {
     const uint4 en = en_n;
-    const uint4 rec = rec_n;
-    {  // the next window of this workgroup
-      const uint32_t wn = w + gridDim.x;
-      if (wn < n_win) {
-        en_n = (size_t)wn * SEG + tid < a.l1cap ? l1list[(size_t)wn * SEG + tid] : make_uint4(0u, 0u, 0u, 0u);
-        rec_n = wintab[wn];
+    const uint32_t row = row_n, info = info_n;
+    {  // the next group of this wave
+      const uint32_t gn = g + gstride;
+      if (gn < n_grp) {
+        en_n = l1list[(size_t)gn * GRP + lane];
+        row_n = grpbase[(size_t)gn * GRP + lane];
+        info_n = grpinfo[gn];
       }
     }
-    const uint32_t nvalid = rec.x >> 16, w0 = rec.y;
-    const int tx0 = (int)(rec.z & 0xffffu), ty0 = (int)(rec.z >> 16);
-    // lane j owns tile j of the supertile: its count (count pass) or its next free slot (fill pass)
+    const uint32_t unit = info & 0xfffu, unit0 = (info >> 12) & 0xfffu, sup = info >> 24;
+    const int tx0 = (int)((sup % (uint32_t)a.gi.stx) << SSH), ty0 = (int)((sup / (uint32_t)a.gi.stx) << SSH);
     const int my_tx = tx0 + (lane & (ss - 1)), my_ty = ty0 + (lane >> SSH);
     const bool my_in = lane < ntile && my_tx < tiles_x && my_ty < tiles_y;
-    const u64 mask = tile_mask<SSH>((uint32_t)tid < nvalid, en, tx0, ty0);  // (an unwritten slot may hold anything)
-    uint32_t c = 0;
-    if (FILL) {
-      lds_barrier();  // (s_tsw / s_c of the previous window have been read)
-      // the counts of the supertile's earlier windows: wave v sums windows w0 + v, w0 + v + 4, ...
-      {
-        uint32_t acc = 0;
-        for (uint32_t q = w0 + wave; q < w; q += 4 * 8) {
-          uint32_t v[8];
+    const u64 mask = tile_mask<SSH>(en.z, en.w, tx0, ty0);
+    // lane j: the next free slot of tile j = tile start + the supertile's earlier units + the unit's earlier groups
+    uint32_t c = row;
+    for (uint32_t u0 = unit0; u0 < unit; u0 += 8) {
+      uint32_t v[8];
 #pragma unroll
-          for (int r = 0; r < 8; ++r) v[r] = q + 4 * r < w ? cnt2[(size_t)(q + 4 * r) * 64 + lane] : 0u;
+      for (int r = 0; r < 8; ++r) v[r] = u0 + r < unit ? cntu[(size_t)(u0 + r) * GRP + lane] : 0u;
 #pragma unroll
-          for (int r = 0; r < 8; ++r) acc += v[r];
-        }
-        s_c[wave][lane] = acc;
-      }
-      if (!ts_lds) {  // the starts of this supertile's tiles, picked out of the scan by the threads that own them
-        uint32_t run = my_first;
-        for (int q = 0; q < K; ++q) {
-          const int t = tid * K + q;
-          if (t >= a.T) break;
-          const int tx = t % tiles_x - tx0, ty = t / tiles_x - ty0;
-          if (tx >= 0 && tx < ss && ty >= 0 && ty < ss) s_tsw[(ty << SSH) + tx] = run;
-          run += tile_tot[t];
-        }
-      }
-      lds_barrier();
-      if (my_in) {
-        c = (ts_lds ? s_ts[my_ty * tiles_x + my_tx] : s_tsw[lane]) + s_c[0][lane] + s_c[1][lane] + s_c[2][lane] + s_c[3][lane];
-        for (int v = 0; v < wave; ++v) c += cnt2w[((size_t)w * (SEG / 64) + v) * 64 + lane];
-      }
+      for (int r = 0; r < 8; ++r) c += v[r];
+    }
+    if (my_in) c += s_ts[my_ty * tiles_x + my_tx];
 #pragma unroll
-      for (int j = 0; j < ntile; ++j) {
-        const bool cov = (mask >> j) & 1ull;
-        const u64 bal = __ballot(cov);
-        if (bal == 0) continue;
-        const uint32_t first = (uint32_t)__builtin_amdgcn_readlane((int)c, j);
-        const uint32_t pos = first + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-        if (cov && pos < a.R_cap) {
-          dkeys[pos] = en.y;
-          vals[pos] = en.x;
-          // the fill pass touches every instance slot [0, R) exactly once: it also clears the backward's "gradient
-          // record written" flags (indexed by emission position, the same range) -- a launch of its own before
-          if (grad_flags) grad_flags[pos] = 0;
-        }
-      }
-    } else {
-      static_for<0, ntile>([&](auto jc) {
-        constexpr int j = decltype(jc)::value;
-        const u64 bal = __ballot((mask >> j) & 1ull);
-        c = writelane<j>(c, (uint32_t)__popcll(bal));
-      });
-      cnt2w[((size_t)w * (SEG / 64) + wave) * 64 + lane] = c;
-      lds_barrier();  // (the previous window's sums have been read: see the barrier below)
-      s_c[wave][lane] = c;
-      lds_barrier();
-      if (wave == 0) {
-        const uint32_t tot = s_c[0][lane] + s_c[1][lane] + s_c[2][lane] + s_c[3][lane];
-        cnt2[(size_t)w * 64 + lane] = tot;
-        if (my_in && tot) atomicAdd(&tile_tot[my_ty * tiles_x + my_tx], tot);
-      }
+    for (int j = 0; j < ntile; ++j) {
+      const bool cov = (mask >> j) & 1ull;
+      const u64 bal = __ballot(cov);
+      if (bal == 0) continue;
+      const uint32_t first = (uint32_t)__builtin_amdgcn_readlane((int)c, j);
+      const uint32_t pos = first + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+      if (cov && pos < a.R_cap) vals[pos] = en.x;
     }
   }
-  if (FILL && blockIdx.x == 0) {
+  if (blockIdx.x == 0) {
     // ---- the blend forward's dispatch order: tiles by descending list length (a counting sort over 256 classes of
     // 16 entries; the order inside a class is whatever the LDS atomics make of it -- it only decides WHEN a tile's
-    // workgroup starts).  The launch otherwise ends with a tail a quarter of its length: every workgroup has started
-    // after 145 of 189 us (8 renders) and the last ones are as long as any.
+    // workgroup starts).  The launch otherwise ends with a tail a quarter of its length.
     uint32_t *__restrict__ order = at<uint32_t>(bin, a.b_order);
-    uint32_t *const s_hist = s_ts;  // (256 words; the tile starts are not needed any more)
+    __shared__ uint32_t s_hist[256];
     __syncthreads();
     s_hist[tid] = 0u;
     __syncthreads();
-    for (int t = tid; t < a.T; t += SEG) atomicAdd(&s_hist[255u - min(tile_tot[t] >> 4, 255u)], 1u);
+    for (int t = tid; t < a.T; t += SORT_BLOCK) atomicAdd(&s_hist[255u - min(tile_tot[t] >> 4, 255u)], 1u);
     __syncthreads();
     const uint32_t mine = s_hist[tid];
-    const uint32_t inc = wave_scan_incl(mine, lane);
-    if (lane == 63) s_wt[wave] = inc;
-    __syncthreads();
-    uint32_t start = inc - mine;
-    for (int w2 = 0; w2 < wave; ++w2) start += s_wt[w2];
+    uint32_t all;
+    const uint32_t start = block_scan_excl(mine, s_wt, all);
     s_hist[tid] = start;
     __syncthreads();
-    for (int t = tid; t < a.T; t += SEG) order[atomicAdd(&s_hist[255u - min(tile_tot[t] >> 4, 255u)], 1u)] = (uint32_t)t;
+    for (int t = tid; t < a.T; t += SORT_BLOCK) order[atomicAdd(&s_hist[255u - min(tile_tot[t] >> 4, 255u)], 1u)] = (uint32_t)t;
   }
   tr.flush();
 }
 
-template <bool FILL>
-__device__ __forceinline__ void level2_dispatch(const BinArgs &a, void *geom, void *bin, uint8_t *grad_flags,
-                                                uint32_t *totals_out) {
-  __shared__ L2Shared sh;
-  __shared__ uint32_t s_ts[FILL ? TS_LDS : 1];
+__device__ __forceinline__ void level2_fill_dispatch(const BinArgs &a, void *geom, void *bin, uint8_t *grad_flags,
+                                                     uint32_t *totals_out) {
+  HIP_DYNAMIC_SHARED(uint32_t, s_ts)  // first slot of every tile: [T]
+  __shared__ uint32_t s_wt[4];
   switch (a.gi.ss_shift) {  // (uniform)
-    case 0: level2_body<FILL, 0>(a, geom, bin, grad_flags, totals_out, sh, s_ts); break;
-    case 1: level2_body<FILL, 1>(a, geom, bin, grad_flags, totals_out, sh, s_ts); break;
-    case 2: level2_body<FILL, 2>(a, geom, bin, grad_flags, totals_out, sh, s_ts); break;
-    default: level2_body<FILL, 3>(a, geom, bin, grad_flags, totals_out, sh, s_ts); break;
+    case 0: level2_fill_body<0>(a, geom, bin, grad_flags, totals_out, s_ts, s_wt); break;
+    case 1: level2_fill_body<1>(a, geom, bin, grad_flags, totals_out, s_ts, s_wt); break;
+    case 2: level2_fill_body<2>(a, geom, bin, grad_flags, totals_out, s_ts, s_wt); break;
+    default: level2_fill_body<3>(a, geom, bin, grad_flags, totals_out, s_ts, s_wt); break;
   }
 }
 
 // ------------------------------------------------------------------------------------ kernel entry points
 // Every stage exists as a single-render kernel (the C-ABI calls) and as a batched one whose blockIdx.y selects the
 // render of a RenderBatch (the native step executor: one launch per stage for all renders of a range).
-__global__ void __launch_bounds__(SORT_BLOCK) level1_count_kernel(BinArgs a, void *geom, void *bin) {
-  level1_count_body(a, geom, bin);
-}
-__global__ void __launch_bounds__(SORT_BLOCK) level1_scatter_kernel(BinArgs a, void *geom, void *bin) {
-  level1_scatter_body(a, geom, bin);
-}
+__global__ void __launch_bounds__(SORT_BLOCK) level1_kernel(BinArgs a, void *geom, void *bin) { level1_body(a, geom, bin); }
 __global__ void __launch_bounds__(SORT_BLOCK) bucket_sort_kernel(BinArgs a, void *geom, void *bin) {
   bucket_sort_body(a, geom, bin);
 }
-template <bool FILL>
-__global__ void __launch_bounds__(SEG) level2_kernel(BinArgs a, void *geom, void *bin) {
-  level2_dispatch<FILL>(a, geom, bin, nullptr, nullptr);  // (the C-ABI backward clears its own scratch)
+__global__ void __launch_bounds__(SORT_BLOCK) level2_fill_kernel(BinArgs a, void *geom, void *bin) {
+  level2_fill_dispatch(a, geom, bin, nullptr, nullptr);  // (the C-ABI backward clears its own scratch)
 }
-__global__ void __launch_bounds__(SORT_BLOCK) level1_count_batched_kernel(BinArgs a, RenderBatch b) {
-  level1_count_body(a, b.r[blockIdx.y].geom, b.r[blockIdx.y].bin);
-}
-__global__ void __launch_bounds__(SORT_BLOCK) level1_scatter_batched_kernel(BinArgs a, RenderBatch b) {
-  level1_scatter_body(a, b.r[blockIdx.y].geom, b.r[blockIdx.y].bin);
+__global__ void __launch_bounds__(SORT_BLOCK) level1_batched_kernel(BinArgs a, RenderBatch b) {
+  level1_body(a, b.r[blockIdx.y].geom, b.r[blockIdx.y].bin);
 }
 __global__ void __launch_bounds__(SORT_BLOCK) bucket_sort_batched_kernel(BinArgs a, RenderBatch b) {
   bucket_sort_body(a, b.r[blockIdx.y].geom, b.r[blockIdx.y].bin);
 }
-template <bool FILL>
-__global__ void __launch_bounds__(SEG) level2_batched_kernel(BinArgs a, size_t flag_off, RenderBatch b) {
+__global__ void __launch_bounds__(SORT_BLOCK) level2_fill_batched_kernel(BinArgs a, size_t flag_off, RenderBatch b) {
   const dimo_render_desc &r = b.r[blockIdx.y];
-  level2_dispatch<FILL>(a, r.geom, r.bin, FILL ? at<uint8_t>(r.bwd_scratch, flag_off) : nullptr, FILL ? r.totals_out : nullptr);
+  level2_fill_dispatch(a, r.geom, r.bin, at<uint8_t>(r.bwd_scratch, flag_off), r.totals_out);
+}
+// Diagnostic (tests' inspect_state): the depth bits of every instance, gathered from its Gaussian's
+__global__ void __launch_bounds__(256) depth_keys_kernel(uint32_t R_cap, const uint32_t *__restrict__ total,
+                                                         const uint32_t *__restrict__ key32, const uint32_t *__restrict__ vals,
+                                                         uint32_t *__restrict__ out) {
+  const uint32_t R = min(total[0], R_cap);
+  for (uint32_t p = blockIdx.x * 256u + threadIdx.x; p < R; p += gridDim.x * 256u) out[p] = key32[vals[p]];
 }
 
 // ------------------------------------------------------------------------------------ host side
+static size_t level1_code_bytes(int per) { return (size_t)per * BIG_ENTRIES * SORT_BLOCK * sizeof(uint32_t); }
 static bool make_args(int N, int H, int W, int64_t R_cap, int n_renders, const GeomLayout &G, const BinLayout &B,
                       BinArgs &a) {
   if (!make_bin_grid(H, W, a.gi)) return false;  // more than MAX_SUPER * 64 tiles
@@ -1038,39 +1225,41 @@ static bool make_args(int N, int H, int W, int64_t R_cap, int n_renders, const G
   // tables) is per workgroup, and the kernels are instruction bound -- about 1024 workgroups per launch
   int per = (int)(((size_t)G.nb * (size_t)(n_renders > 0 ? n_renders : 1) + 1023) / 1024);
   // ... and at most ~256 workgroups per render: every workgroup adds to each bucket it touches with one returning
-  // atomic, and the workgroups of a model that was never Morton-sorted touch nearly all of them (391 workgroups x 400
-  // buckets on 512 words: 50 us of serialised atomics for one render).  (~128 until the workgroups' lifetimes were
-  // looked at: all of a launch's workgroups are resident at once, the launch lasts as long as its slowest one, and
-  // with four blocks each the slowest took twice the mean -- two blocks: 7130 against 7040 frames/s, and no worse
-  // for an unsorted model, 73.5 against 78.6 us per render for count + scatter + sort.)
+  // atomic, and the workgroups of a model that was never Morton-sorted touch nearly all of them.  (~128 until the
+  // workgroups' lifetimes were looked at: all of a launch's workgroups are resident at once, the launch lasts as long
+  // as its slowest one, and with four blocks each the slowest took twice the mean.)
   if (per < (G.nb + 255) / 256) per = (G.nb + 255) / 256;
+  if (per > MAX_L1_PER) per = MAX_L1_PER;
+  // (a bucket's segment list has a slot per level-1 workgroup, MAX_SEG of them at most; an entry's code stays in LDS
+  // between the count and the placement: MAX_L1_PER blocks per workgroup at most)
   if (per < G.per) per = G.per;
-  if (per > 8) per = 8 > G.per ? 8 : G.per;
+  if (per > MAX_L1_PER) return false;  // more than MAX_L1_PER * MAX_SEG * 256 Gaussians (2 M)
   a.N = N, a.nb = G.nb, a.per = per, a.nwg1 = (G.nb + per - 1) / per, a.lg = depth_bins_log2(N, a.gi.NS), a.T = B.T;
   a.R_cap = (uint32_t)B.cap;
-  a.l1cap = B.l1cap, a.max_windows = B.max_windows;
+  a.l1cap = B.l1cap;
   a.g_total = G.total, a.g_rect = G.rect, a.g_tiles = G.tiles, a.g_offsets = G.offsets, a.g_sums = G.block_sums;
-  a.g_key32 = G.key32, a.g_bk = G.bk, a.g_wgbase = G.wgbase;
-  a.b_meta = B.meta, a.b_l1tmp = B.l1tmp, a.b_l1a = B.l1a, a.b_l1b = B.l1b, a.b_l1 = B.l1list, a.b_cnt2 = B.cnt2;
-  a.b_totals = B.totals, a.b_ranges = B.ranges, a.b_work = B.work, a.b_dkeys = B.dkeys, a.b_vals = B.vals_b;
+  a.g_key32 = G.key32, a.g_bk = G.bk, a.g_segs = G.segs;
+  a.b_meta = B.meta, a.b_l1tmp = B.l1tmp, a.b_l1a = B.l1a, a.b_l1b = B.l1b, a.b_l1 = B.l1list;
+  a.b_grpbase = B.grpbase, a.b_grpinfo = B.grpinfo, a.b_cntu = B.cntu;
+  a.b_totals = B.totals, a.b_ranges = B.ranges, a.b_work = B.work, a.b_vals = B.vals_b;
   a.b_order = B.order;
   return true;
 }
 
-// persistent workgroups over the level-2 windows (their number, ~ entries / 256 + supertiles, is only known on the
-// device): sized so that all the renders of a launch fit the chip in one round (2048 workgroups of 256 threads),
-// a workgroup then walks ~5 windows at the benchmark configuration
-// bucket_sort: persistent workgroups, each walks <= MAXB buckets; sized so that the renders of a launch fit the chip
-// in about one round
+// bucket_sort: persistent workgroups, each walks <= MAXB buckets (and <= MAXSL slices: at least 32 workgroups); sized
+// so that the renders of a launch fit the chip in about one round
 static unsigned bucket_grid(unsigned nbuckets, int n_renders) {
-  const unsigned least = (nbuckets + MAXB - 1) / MAXB;  // (nbuckets <= 2048: at least 256 then)
-  const unsigned room = (unsigned)(768 / (n_renders > 0 ? n_renders : 1));  // (42 KB of LDS: 3 workgroups per CU)
+  const unsigned least = (nbuckets + MAXB - 1) / MAXB;  // (nbuckets <= 2048: at most 256 then)
+  const unsigned room = (unsigned)(768 / (n_renders > 0 ? n_renders : 1));  // (43 KB of LDS: 3 workgroups per CU)
   unsigned g = room < nbuckets ? room : nbuckets;
   if (g < least) g = least;
-  return g < 32u ? (nbuckets < 32u ? (nbuckets ? nbuckets : 1u) : 32u) : g;
+  return g < 32u ? 32u : g;
 }
-static unsigned level2_grid(int N, int n_renders, int NS) {
-  const unsigned want = (unsigned)((4 * (size_t)N) / SEG + NS + 1);  // ~ one window each, were there room
+// level2_fill: persistent waves over the groups (their number, ~ entries / 64 + half a group per bucket, is only known
+// on the device): sized so that all the renders of a launch fit the chip in one round (2048 workgroups of 256
+// threads); a wave then walks ~5 groups at the benchmark configuration
+static unsigned level2_grid(int N, int n_renders, int nbuckets) {
+  const unsigned want = (unsigned)((4 * (size_t)N) / SORT_BLOCK + nbuckets / 4 + 1);  // ~ one group per wave, were there room
   const unsigned room = (unsigned)(2048 / (n_renders > 0 ? n_renders : 1));
   return want < room ? want : (room > 64u ? room : 64u);
 }
@@ -1081,26 +1270,21 @@ int bin_instances(int N, int H, int W, int64_t R_cap, const void *geom_c, void *
   BinArgs a;
   if (!make_args(N, H, W, R_cap, 1, G, B, a)) return DIMO_E_ARG;
   void *geom = const_cast<void *>(geom_c);  // offsets, bucket tables and the overflow flag live in the geometry workspace
-  const unsigned nbuckets = (unsigned)(a.gi.NS << a.lg), g2 = level2_grid(N, 1, a.gi.NS);
+  const unsigned nbuckets = (unsigned)(a.gi.NS << a.lg);
   {
     ScopedTimer tm(T_SCAN, stream);
-    hipLaunchKernelGGL(level1_count_kernel, dim3(a.nwg1), dim3(SORT_BLOCK), 0, stream, a, geom, bin);
-  }
-  {
-    ScopedTimer tm(T_EMIT, stream);
-    hipLaunchKernelGGL(level1_scatter_kernel, dim3(a.nwg1), dim3(SORT_BLOCK), 0, stream, a, geom, bin);
+    hipLaunchKernelGGL(level1_kernel, dim3(a.nwg1), dim3(SORT_BLOCK), level1_code_bytes(a.per), stream, a, geom, bin);
   }
   {
     ScopedTimer tm(T_SORT, stream);
     hipLaunchKernelGGL(bucket_sort_kernel, dim3(bucket_grid(nbuckets, 1)), dim3(SORT_BLOCK), 0, stream, a, geom, bin);
   }
   {
-    ScopedTimer tm(T_RANGES, stream);
-    hipLaunchKernelGGL(level2_kernel<false>, dim3(g2), dim3(SEG), 0, stream, a, geom, bin);
-  }
-  {
     ScopedTimer tm(T_TILE_SORT, stream);
-    hipLaunchKernelGGL(level2_kernel<true>, dim3(g2), dim3(SEG), 0, stream, a, geom, bin);
+    const size_t ts_bytes = (size_t)a.T * sizeof(uint32_t);  // (up to 64 KB at 16384 tiles)
+    if (ts_bytes > 32768) (void)hipFuncSetAttribute((const void *)level2_fill_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ts_bytes);
+    hipLaunchKernelGGL(level2_fill_kernel, dim3(level2_grid(N, 1, (int)nbuckets)), dim3(SORT_BLOCK), ts_bytes, stream, a,
+                       geom, bin);
   }
   return check_launch();
 }
@@ -1115,29 +1299,32 @@ int bin_instances_batched(const dimo_step_common &c, const RenderBatch &b, int n
   if (c.bwd_scratch_bytes < align_up(B.cap * sizeof(SplatGrad)) + align_up(B.cap)) return DIMO_E_WORKSPACE;
   for (int i = 0; i < n; ++i)
     if (!b.r[i].bwd_scratch) return DIMO_E_ARG;  // the fill pass clears the backward's record flags
-  const unsigned nbuckets = (unsigned)(a.gi.NS << a.lg), g2 = level2_grid(c.N, n, a.gi.NS);
+  const unsigned nbuckets = (unsigned)(a.gi.NS << a.lg);
   {
     ScopedTimer tm(T_SCAN, stream);
-    hipLaunchKernelGGL(level1_count_batched_kernel, dim3(a.nwg1, n), dim3(SORT_BLOCK), 0, stream, a, b);
-  }
-  {
-    ScopedTimer tm(T_EMIT, stream);
-    hipLaunchKernelGGL(level1_scatter_batched_kernel, dim3(a.nwg1, n), dim3(SORT_BLOCK), 0, stream, a, b);
+    hipLaunchKernelGGL(level1_batched_kernel, dim3(a.nwg1, n), dim3(SORT_BLOCK), level1_code_bytes(a.per), stream, a, b);
   }
   {
     ScopedTimer tm(T_SORT, stream);
     hipLaunchKernelGGL(bucket_sort_batched_kernel, dim3(bucket_grid(nbuckets, n), n), dim3(SORT_BLOCK), 0, stream, a, b);
   }
   {
-    ScopedTimer tm(T_RANGES, stream);
-    hipLaunchKernelGGL(level2_batched_kernel<false>, dim3(g2, n), dim3(SEG), 0, stream, a, (size_t)0, b);
-  }
-  {
     ScopedTimer tm(T_TILE_SORT, stream);
     // (flags of the backward's scratch: [records: cap x 64 B][flags: cap x 1 B], see blend.hip)
-    hipLaunchKernelGGL(level2_batched_kernel<true>, dim3(g2, n), dim3(SEG), 0, stream, a,
-                       align_up(B.cap * sizeof(SplatGrad)), b);
+    const size_t ts_bytes = (size_t)a.T * sizeof(uint32_t);
+    if (ts_bytes > 32768) (void)hipFuncSetAttribute((const void *)level2_fill_batched_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ts_bytes);
+    hipLaunchKernelGGL(level2_fill_batched_kernel, dim3(level2_grid(c.N, n, (int)nbuckets), n), dim3(SORT_BLOCK), ts_bytes,
+                       stream, a, align_up(B.cap * sizeof(SplatGrad)), b);
   }
+  return check_launch();
+}
+
+int instance_depth_keys(int N, int H, int W, int64_t R_cap, const void *geom, const void *bin, uint32_t *out,
+                        hipStream_t stream) {
+  GeomLayout G(N);
+  BinLayout B(R_cap, H, W);
+  hipLaunchKernelGGL(depth_keys_kernel, dim3(1024), dim3(256), 0, stream, (uint32_t)B.cap, at<uint32_t>(geom, G.total),
+                     at<uint32_t>(geom, G.key32), at<uint32_t>(bin, B.vals_b), out);
   return check_launch();
 }
 

@@ -59,7 +59,9 @@ constexpr int SORT_BLOCK = 256;  // threads of a bucket-sort workgroup
 // level 2), the depth bits into 2^nb_log2 bins over a range that brackets the bulk of the keys.
 constexpr int MAX_SUPER = 256;     // supertiles
 constexpr int MAX_BUCKETS = 2048;  // supertiles x depth bins
-constexpr int MAX_L1_WG = 4096;    // level-1 workgroups (beyond: several preprocess blocks per workgroup)
+constexpr int MAX_SEG = 1024;      // level-1 workgroups per render = slots of a bucket's segment list (beyond: several
+                                   // preprocess blocks per workgroup)
+constexpr int MAX_L1_PER = 8;      // preprocess blocks a level-1 workgroup walks at most (N <= 8 * 1024 * 256 Gaussians)
 struct BinGrid {
   int tiles_x, tiles_y, ss_shift, stx, sty, NS;  // supertile edge = 1 << ss_shift tiles, stx * sty = NS supertiles
 };
@@ -88,15 +90,13 @@ inline __host__ __device__ int depth_bins_log2(int N, int NS) {
 // words of the `bk` area in the geometry workspace
 constexpr int MAX_SLICES = 256;                                          // slices of oversized buckets (one workgroup each)
 constexpr size_t BK_KMIN = 0, BK_SHIFT = 1, BK_KMIN0 = 2, BK_NBLOG = 3;  // bin map: origin, log2 bin width, smallest key, log2 bins
-constexpr size_t BK_NSLICE = 4;                                          // number of slices listed
-constexpr size_t BK_TOT = 8;                                             // [MAX_BUCKETS] entries per bucket (atomically summed)
-constexpr size_t BK_START = BK_TOT + MAX_BUCKETS;                        // [MAX_BUCKETS] first entry of the bucket in the level-1 array
-constexpr size_t BK_BINJ = BK_START + MAX_BUCKETS;                       // [MAX_BUCKETS] slices the bucket was cut into (0: none)
-constexpr size_t BK_SLICE = BK_BINJ + MAX_BUCKETS;                       // slice list: bucket << 16 | slices << 8 | slice
-constexpr size_t BK_WORDS = BK_SLICE + MAX_SLICES;
+// [MAX_BUCKETS] 64-bit words: entries of the bucket (low half) | segments listed for it (high half), summed by ONE
+// returning atomic per (level-1 workgroup, bucket it touches)
+constexpr size_t BK_TOT = 8;
+constexpr size_t BK_WORDS = BK_TOT + 2 * MAX_BUCKETS;
 
 struct GeomLayout {
-  size_t splat, rect, tiles, offsets, flags, total, block_sums, key32, bk, wgbase;
+  size_t splat, rect, tiles, offsets, flags, total, block_sums, key32, bk, segs;
   size_t bytes;
   int nb, per, nwg1;  // preprocess blocks; blocks per level-1 workgroup; level-1 workgroups
   __host__ explicit GeomLayout(int N) {
@@ -109,15 +109,16 @@ struct GeomLayout {
     flags = o, o = align_up(o + n);
     total = o, o = align_up(o + 4 * sizeof(uint32_t));  // R, overflow flag, level-1 entries, 0
     nb = (int)((n + PRE_BLOCK - 1) / PRE_BLOCK);
-    per = (nb + MAX_L1_WG - 1) / MAX_L1_WG, nwg1 = (nb + per - 1) / per;
+    per = (nb + MAX_SEG - 1) / MAX_SEG, nwg1 = (nb + per - 1) / per;
     // per preprocess block [nb + 1] each: tiles touched, min / max of the depth bits of its visible Gaussians,
     // level-1 entries (supertiles touched)
     block_sums = o, o = align_up(o + 4 * ((size_t)nb + 1) * sizeof(uint32_t));
     key32 = o, o = align_up(o + n * sizeof(uint32_t));  // depth bits, 0xffffffff for a Gaussian without tiles
     bk = o, o = align_up(o + BK_WORDS * sizeof(uint32_t));
-    // wgbase[workgroup][bucket]: where the level-1 workgroup's entries of that bucket start inside the bucket (only
-    // the words of the buckets a workgroup touches are written and read)
-    wgbase = o, o = align_up(o + (size_t)nwg1 * MAX_BUCKETS * sizeof(uint32_t));
+    // segs[bucket][slot]: (first entry in the unsorted level-1 array, entries) of every level-1 workgroup that has
+    // entries in the bucket -- `slot` from the bucket's atomic, row stride = the launch's level-1 workgroups (<= nwg1);
+    // only the listed slots are written and read
+    segs = o, o = align_up(o + (size_t)MAX_BUCKETS * nwg1 * 2 * sizeof(uint32_t));
     bytes = o;
   }
 };
@@ -125,32 +126,34 @@ struct GeomLayout {
 constexpr int BUCKET = 64;       // list entries per backward work item
 constexpr int CKPT_FLOATS = 9;   // T, 7 accumulated features, accumulated weight
 struct BinLayout {
-  size_t dkeys, vals_b, ranges, totals, meta, l1tmp, l1a, l1b, l1list, cnt2, ckpt, work, order, bytes;
+  size_t vals_b, ranges, totals, meta, l1tmp, l1a, l1b, l1list, grpbase, grpinfo, cntu, ckpt, work, order, bytes;
   int tiles_x, tiles_y, T;
-  size_t cap, ckpt_slots, l1cap, max_windows;
+  size_t cap, ckpt_slots, l1cap;
   __host__ BinLayout(int64_t R_cap, int H, int W) {
     cap = (size_t)(R_cap > 0 ? R_cap : 1);
     tiles_x = (W + TILE - 1) / TILE, tiles_y = (H + TILE - 1) / TILE, T = tiles_x * tiles_y;
     size_t o = 0;
-    // per instance, in the order of the per-tile lists: the 32 depth bits of its sort key (the key's tile is the
-    // list it sits in: `ranges`) and the Gaussian id
-    dkeys = o, o = align_up(o + cap * sizeof(uint32_t));
+    // per instance, in the order of the per-tile lists: the Gaussian id.  (The instance's sort key is not stored: its
+    // tile is the list it sits in -- `ranges` -- and its 32 depth bits are its Gaussian's, geom key32.)
     vals_b = o, o = align_up(o + cap * sizeof(uint32_t));
     ranges = o, o = align_up(o + (size_t)T * 2 * sizeof(uint32_t));
     totals = o, o = align_up(o + (size_t)T * sizeof(uint32_t));  // instances per tile (atomically summed)
-    // level 1 (binning.hip): per-supertile lists -- at most one entry per instance, every list start rounded up to
-    // a 256-entry window.  l1tmp: the 16-byte entries (depth bits, id, tile rectangle) bucket by bucket as the level-1
-    // scatter leaves them; l1a / l1b: 64-bit scratch of the byte-wise fallback sort; l1list: the sorted entries (id,
-    // depth bits, tile rectangle)
-    l1cap = (cap + 255) / 256 * 256 + 256 * 256;
-    max_windows = l1cap / 256;
+    // level 1 (binning.hip): at most one entry per instance.  l1tmp: the 16-byte entries (depth bits, id, tile
+    // rectangle) as the level-1 workgroups leave them, a contiguous segment per workgroup; l1a / l1b: 64-bit scratch of
+    // the byte-wise fallback sort; l1list: the sorted entries (id, depth bits, tile rectangle), bucket by bucket, every
+    // bucket (and every slice of a cut bucket) rounded up to whole groups of 64 -- hence the slack
+    l1cap = (cap + 255) / 256 * 256 + 64 * (size_t)(MAX_BUCKETS + 2 * MAX_SLICES);
     l1tmp = o, o = align_up(o + l1cap * 4 * sizeof(uint32_t));
     l1a = o, o = align_up(o + l1cap * sizeof(uint64_t));
     l1b = o, o = align_up(o + l1cap * sizeof(uint64_t));
     l1list = o, o = align_up(o + l1cap * 4 * sizeof(uint32_t));
-    // per-window tile counts [max_windows][64], then the same per (window, wave) [max_windows][4][64]
-    cnt2 = o, o = align_up(o + max_windows * 64 * 5 * sizeof(uint32_t));
-    meta = o, o = align_up(o + (4 * 256 + 4 * max_windows) * sizeof(uint32_t));
+    // level 2: per group of 64 sorted entries a row of 64 words (tile j of the supertile: entries of the bucket's
+    // earlier groups that cover it) and one word (unit | first unit of the supertile << 12 | supertile << 24); per
+    // unit (a bucket, or a slice of a cut one) a row of per-tile totals
+    grpbase = o, o = align_up(o + l1cap * sizeof(uint32_t));
+    grpinfo = o, o = align_up(o + (l1cap / 64) * sizeof(uint32_t));
+    cntu = o, o = align_up(o + (size_t)(MAX_BUCKETS + MAX_SLICES) * 64 * sizeof(uint32_t));
+    meta = o, o = align_up(o + 16 * sizeof(uint32_t));
     // blend checkpoints: per (tile, bucket of BUCKET list entries) the 256 pixels' compositing state at the
     // bucket's first entry -- slot (lo_tile / BUCKET + tile + bucket), see blend.hip; work: [0] = item count,
     // then one word (tile << 12 | bucket) per bucket some pixel of the tile reaches
@@ -256,6 +259,8 @@ int blend_backward_batched(const dimo_step_common &c, const RenderBatch &b, int 
 
 // ---- internal (C++ linkage) entry points shared between translation units ---------------------
 int bin_instances(int N, int H, int W, int64_t R_cap, const void *geom, void *bin, hipStream_t stream);
+int instance_depth_keys(int N, int H, int W, int64_t R_cap, const void *geom, const void *bin, uint32_t *out,
+                        hipStream_t stream);
 int preprocess_backward_launch(int N, int sh_degree, int M, int H, int W, int64_t R_cap, const float *means3D,
                                const float *shs, const float *colors_precomp, const float *scales,
                                const float *rotations, const float *cov3D_precomp, float scale_modifier,

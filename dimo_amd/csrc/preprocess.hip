@@ -24,7 +24,7 @@ __device__ __forceinline__ void preprocess_fwd_body(
   // the binning's per-bucket entry counters start every frame at zero: cleared here, one launch ahead of
   // the level-1 kernel that adds to them (binning.hip)
   if (blockIdx.x == 0)
-    for (int t = threadIdx.x; t < MAX_BUCKETS; t += PRE_BLOCK) bk[BK_TOT + t] = 0u;
+    for (int t = threadIdx.x; t < 2 * MAX_BUCKETS; t += PRE_BLOCK) bk[BK_TOT + t] = 0u;  // (64-bit words)
   // camera: uniform loads (scalar cache)
   float V[16], P[16], cam[3];
 #pragma unroll

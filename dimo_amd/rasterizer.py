@@ -417,11 +417,15 @@ def inspect_state(ctx_tensors, N, H, W, r_cap):
 
     n = max(N, 1)
     total = view(geom, go[5], 16, torch.int32)
-    ranges = view(bin_ws, bo[2], T * 8, torch.int32).view(T, 2)
-    # The library stores the 32 depth bits of every instance's sort key; the key's tile is the list the instance
-    # sits in (`ranges`), so the published 64-bit (tile << 32 | depth bits) keys are rebuilt here for inspection.
+    ranges = view(bin_ws, bo[1], T * 8, torch.int32).view(T, 2)
+    # The library stores neither half of an instance's sort key: the key's tile is the list the instance sits in
+    # (`ranges`) and its 32 depth bits are its Gaussian's (gathered by dimo_raster_depth_keys), so the published 64-bit
+    # (tile << 32 | depth bits) keys are rebuilt here for inspection.
     R = int(min(int(total[0]) & 0xFFFFFFFF, r_cap))
-    dkeys = view(bin_ws, bo[0], r_cap * 4, torch.int32)
+    dkeys = torch.zeros(max(r_cap, 1), dtype=torch.int32, device=geom.device)
+    _lib.check(L.dimo_raster_depth_keys(N, H, W, r_cap, geom.data_ptr(), bin_ws.data_ptr(), dkeys.data_ptr(),
+                                        torch.cuda.current_stream(geom.device).cuda_stream), "depth_keys")
+    torch.cuda.synchronize(geom.device)
     lens = (ranges[:, 1] - ranges[:, 0]).to(torch.int64).clamp_(min=0)
     tile_of = torch.repeat_interleave(torch.arange(T, dtype=torch.int64, device=geom.device), lens)[:R]
     keys = torch.zeros(max(R, 1), dtype=torch.int64, device=geom.device)
@@ -435,7 +439,7 @@ def inspect_state(ctx_tensors, N, H, W, r_cap):
         total=total,
         keys_sorted=keys,
         depth_keys_sorted=dkeys,
-        vals_sorted=view(bin_ws, bo[1], r_cap * 4, torch.int32),
+        vals_sorted=view(bin_ws, bo[0], r_cap * 4, torch.int32),
         ranges=ranges,
         final_T=view(img_ws, io[0], H * W * 4, torch.float32).view(H, W),
         n_contrib=view(img_ws, io[1], H * W * 4, torch.int32).view(H, W),

@@ -66,7 +66,7 @@ int dimo_timing_read(const char *name, double *total_ms, int64_t *launches);
 /* ------------------------------------------------------------------ rasterizer workspaces
  * geom : per-Gaussian state written by preprocess (splat records, tile rects, tiles_touched,
  *        offsets, flags, block sums).  Needed by backward.
- * bin  : tile-instance state (per-tile lists of depth bits and ids, tile ranges, level-1 lists, blend checkpoints).
+ * bin  : tile-instance state (per-tile lists of Gaussian ids, tile ranges, level-1 lists, blend checkpoints).
  *        Sized for a CAPACITY R_cap >= R (number of (Gaussian, tile) instances).  Needed by backward.
  * img  : per-pixel state (final transmittance, n_contrib).  Needed by backward.
  */
@@ -79,19 +79,20 @@ size_t dimo_raster_img_bytes(int H, int W);
  *       [1] rect  uint16[N][4] = (xmin ymin xmax ymax) in tiles     [2] tiles_touched uint32[N]
  *       [3] offsets uint32[N] (inclusive scan)                      [4] flags uint8[N] (bit c = SH channel c clamped)
  *       [5] total  uint32[4]  = (R, overflow flag, level-1 entries, 0)
- * bin : [0] depth_keys_sorted uint32[R_cap]   [1] vals_sorted uint32[R_cap]   [2] ranges uint32[T][2]
- *       The published 64-bit sort key of an instance is (tile << 32 | fp32 depth bits); an instance's tile is the
- *       list it sits in (tile t owns slots [ranges[t][0], ranges[t][1])), so only the depth bits are stored.
+ * bin : [0] vals_sorted uint32[R_cap] (Gaussian ids)   [1] ranges uint32[T][2]   [2] instances per tile uint32[T]
+ *       The published 64-bit sort key of an instance is (tile << 32 | fp32 depth bits).  Neither half is stored per
+ *       instance: an instance's tile is the list it sits in (tile t owns slots [ranges[t][0], ranges[t][1])) and its
+ *       depth bits are its Gaussian's (dimo_raster_depth_keys gathers them for inspection).
  *       (the instances are placed straight into their sorted slots: there is no unsorted emission to look at)
  * img : [0] final_T float[H*W]          [1] n_contrib uint32[H*W]
  */
 int dimo_raster_geom_layout(int N, size_t out_offsets[6]);
 int dimo_raster_bin_layout(int64_t R_cap, int H, int W, size_t out_offsets[3]);
 int dimo_raster_img_layout(int H, int W, size_t out_offsets[2]);
-/* Diagnostic (tools/bin_stats.py): where the binning's level-1 state lives -- out = (byte offset of the bucket words
- * in geom, of the unsorted and of the sorted level-1 entries in bin, buckets, log2 depth bins, supertiles,
- * word offsets of the bucket totals / starts / slice count inside the bucket words). */
-int dimo_debug_bin_layout(int N, int64_t R_cap, int H, int W, size_t out[9]);
+/* Inspection (parity tests): the fp32 depth bits of every instance in list order -- the low half of the published
+ * sort keys -- gathered from the instances' Gaussians into out uint32[R_cap] (the first min(R, R_cap) words). */
+int dimo_raster_depth_keys(int N, int H, int W, int64_t R_cap, const void *geom, const void *bin, uint32_t *out,
+                           void *stream);
 /* Diagnostic: per-workgroup phase trace of the binning kernels (tools/bin_trace.py; needs a library built with
  * DIMO_BIN_TRACE=1, else a non-NULL buffer is refused).  buffer = device memory for `capacity` records of 32 x u64,
  * NULL = off; returns the number of records written since the last call. */

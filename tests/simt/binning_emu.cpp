@@ -15,12 +15,16 @@ void simt_geom_layout(int N, size_t out[9]) {
   out[0] = G.rect, out[1] = G.tiles, out[2] = G.offsets, out[3] = G.total, out[4] = G.block_sums, out[5] = G.key32;
   out[6] = G.bk, out[7] = G.bytes, out[8] = (size_t)G.nb;
 }
-// out: dkeys, vals, ranges, totals, order, bytes, T, cap, l1tmp, l1list, meta, cnt2, l1cap, max_windows
+// out: vals, ranges, totals, order, bytes, T, cap, l1tmp, l1list, meta, grpbase, grpinfo, cntu, l1cap
 void simt_bin_layout(int64_t R_cap, int H, int W, size_t out[14]) {
   dimo::BinLayout B(R_cap, H, W);
-  out[0] = B.dkeys, out[1] = B.vals_b, out[2] = B.ranges, out[3] = B.totals, out[4] = B.order, out[5] = B.bytes;
-  out[6] = (size_t)B.T, out[7] = B.cap;
-  out[8] = B.l1tmp, out[9] = B.l1list, out[10] = B.meta, out[11] = B.cnt2, out[12] = B.l1cap, out[13] = B.max_windows;
+  out[0] = B.vals_b, out[1] = B.ranges, out[2] = B.totals, out[3] = B.order, out[4] = B.bytes;
+  out[5] = (size_t)B.T, out[6] = B.cap;
+  out[7] = B.l1tmp, out[8] = B.l1list, out[9] = B.meta, out[10] = B.grpbase, out[11] = B.grpinfo, out[12] = B.cntu;
+  out[13] = B.l1cap;
+}
+int simt_depth_keys(int N, int H, int W, int64_t R_cap, const void *geom, const void *bin, uint32_t *out) {
+  return dimo::instance_depth_keys(N, H, W, R_cap, geom, bin, out, nullptr);
 }
 int simt_supertile_shift(int H, int W) {
   dimo::BinGrid gi;

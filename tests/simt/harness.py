@@ -24,6 +24,7 @@ def lib():
                                                  C.c_size_t, C.c_void_p]
         L.simt_bwd_scratch_bytes.argtypes = [C.c_int64, C.c_int, C.c_int]
         L.simt_bwd_scratch_bytes.restype = C.c_size_t
+        L.simt_depth_keys.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -35,8 +36,8 @@ def _layouts(N, H, W, R_cap):
     L.simt_geom_layout(N, g)
     L.simt_bin_layout(R_cap, H, W, b)
     G = dict(zip(("rect", "tiles", "offsets", "total", "block_sums", "key32", "bk", "bytes", "nb"), [int(x) for x in g]))
-    B = dict(zip(("dkeys", "vals", "ranges", "totals", "order", "bytes", "T", "cap", "l1tmp", "l1list", "meta", "cnt2", "l1cap",
-                  "max_windows"), [int(x) for x in b]))
+    B = dict(zip(("vals", "ranges", "totals", "order", "bytes", "T", "cap", "l1tmp", "l1list", "meta", "grpbase", "grpinfo",
+                  "cntu", "l1cap"), [int(x) for x in b]))
     return G, B
 
 
@@ -98,13 +99,16 @@ def run_binning(rect, tiles, key32, H, W, R_cap=None, n_batched=0, poison=True):
     for i in range(n):
         tot = _read(geoms[i], G["total"], 4)
         Rk = min(int(tot[0]), R_cap)
+        dk = np.zeros(max(Rk, 1), np.uint32)  # the instances' depth bits: gathered on request (not stored per instance)
+        if not int(tot[1]):
+            assert L.simt_depth_keys(N, H, W, R_cap, geoms[i].ctypes.data, bins[i].ctypes.data, dk.ctypes.data) == 0
         d = dict(R=int(tot[0]), overflow=int(tot[1]), entries=int(tot[2]), offsets=_read(geoms[i], G["offsets"], N),
-                 dkeys=_read(bins[i], B["dkeys"], Rk), vals=_read(bins[i], B["vals"], Rk),
+                 dkeys=dk[:Rk], vals=_read(bins[i], B["vals"], Rk),
                  ranges=_read(bins[i], B["ranges"], 2 * B["T"]).reshape(-1, 2), order=_read(bins[i], B["order"], B["T"]),
-                 bk_tot=_read(geoms[i], G["bk"] + 4 * 8, 2048), bk=_read(geoms[i], G["bk"], 8 + 3 * 2048 + 256),
+                 bk_tot=_read(geoms[i], G["bk"] + 4 * 8, 2 * 2048), bk=_read(geoms[i], G["bk"], 8),
                  l1list=_read(bins[i], B["l1list"], 4 * min(B["l1cap"], 4 * N + 65536)).reshape(-1, 4),
                  l1tmp=_read(bins[i], B["l1tmp"], 4 * min(B["l1cap"], 4 * N + 65536)).reshape(-1, 4),
-                 meta=_read(bins[i], B["meta"], 4 * 256 + 4 * 64), totals=_read(bins[i], B["totals"], B["T"]))
+                 meta=_read(bins[i], B["meta"], 16), totals=_read(bins[i], B["totals"], B["T"]))
         if n_batched:
             d["totals_out"] = totals[2 * i:2 * i + 2].copy()
             d["flags"] = scr[i][sb - ((B["cap"] + 255) // 256 * 256):][:Rk].copy()

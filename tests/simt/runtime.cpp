@@ -59,6 +59,8 @@ struct Workgroup {
   unsigned bar_phase;
   unsigned long progress;
   void *main_sp;
+  void *dyn_lds;
+  size_t dyn_cap;
   Idx3 bid, bdim, gdim;
   const std::function<void()> *body;
 };
@@ -70,6 +72,7 @@ const Idx3 &block_idx() { return cur->wg->bid; }
 const Idx3 &block_dim() { return cur->wg->bdim; }
 const Idx3 &grid_dim() { return cur->wg->gdim; }
 int lane_id() { return cur->lane; }
+void *dynamic_lds() { return cur->wg->dyn_lds; }
 
 static void yield_from(Fiber *me) {
   Workgroup *g = me->wg;
@@ -223,13 +226,18 @@ static int pool_size() {
   return n < 1 ? 1 : (n > 64 ? 64 : n);
 }
 
-void launch(dim3 grid, dim3 block, const std::function<void()> &body) {
+void launch(dim3 grid, dim3 block, size_t dynamic_lds_bytes, const std::function<void()> &body) {
   const size_t total = (size_t)grid.x * grid.y * grid.z;
   if (total == 0) return;
   std::atomic<size_t> next{0};
   const Idx3 bdim{block.x, block.y, block.z}, gdim{grid.x, grid.y, grid.z};
   auto worker = [&]() {
     Workgroup *g = acquire_workgroup();  // (fiber stacks are kept for the next launches)
+    if (g->dyn_cap < dynamic_lds_bytes) {
+      free(g->dyn_lds);
+      g->dyn_lds = aligned_alloc(64, (dynamic_lds_bytes + 63) / 64 * 64), g->dyn_cap = dynamic_lds_bytes;
+    }
+    if (dynamic_lds_bytes) memset(g->dyn_lds, 0xCD, dynamic_lds_bytes);  // (LDS is not zero on the device either)
     for (;;) {
       const size_t i = next.fetch_add(1);
       if (i >= total) break;

@@ -59,7 +59,8 @@ const uint64_t *wave_exchange(uint64_t v);
 uint64_t wave_ballot(bool pred);
 void wg_barrier();
 int wg_barrier_or(int v);
-void launch(dim3 grid, dim3 block, const std::function<void()> &body);
+void launch(dim3 grid, dim3 block, size_t dynamic_lds_bytes, const std::function<void()> &body);
+void *dynamic_lds();  // the workgroup's dynamically sized LDS (extern __shared__)
 }  // namespace simt
 
 #define threadIdx (simt::thread_idx())
@@ -67,7 +68,10 @@ void launch(dim3 grid, dim3 block, const std::function<void()> &body);
 #define blockDim (simt::block_dim())
 #define gridDim (simt::grid_dim())
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
-  simt::launch((grid), (block), [&]() { kernel(__VA_ARGS__); })
+  simt::launch((grid), (block), (size_t)(shmem), [&]() { kernel(__VA_ARGS__); })
+#define HIP_DYNAMIC_SHARED(type, var) type *var = reinterpret_cast<type *>(simt::dynamic_lds());
+enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+static inline hipError_t hipFuncSetAttribute(const void *, hipFuncAttribute, int) { return hipSuccess; }
 
 static inline void __syncthreads() { simt::wg_barrier(); }
 static inline int __syncthreads_or(int v) { return simt::wg_barrier_or(v); }
