@@ -82,11 +82,12 @@ constexpr int META_NGRP = 0;
 struct BinArgs {
   int N, nb, per, nwg1, lg, T;  // Gaussians, preprocess blocks, blocks per level-1 workgroup, level-1 workgroups,
                                 // log2 depth bins, tiles
+  int sort_grid;                // workgroups per render of the bucket_sort launch
   uint32_t R_cap;
   BinGrid gi;
   size_t l1cap;
   // byte offsets into the geometry (g_) and bin (b_) workspaces
-  size_t g_total, g_rect, g_tiles, g_offsets, g_sums, g_key32, g_bk, g_segs;
+  size_t g_total, g_rect, g_tiles, g_offsets, g_sums, g_key32, g_bk, g_segs, g_work;
   size_t b_order;
   size_t b_meta, b_l1tmp, b_l1a, b_l1b, b_l1, b_grpbase, b_grpinfo, b_cntu, b_totals, b_ranges, b_work, b_vals;
 };
@@ -145,6 +146,10 @@ struct BinTrace {
   __device__ __forceinline__ void mark() {
     if (n < 32) t[n++] = __builtin_amdgcn_s_memrealtime();
   }
+  // (a mark that says what ended: the clock's two low bits -- 40 ns -- carry `kind`)
+  __device__ __forceinline__ void mark(unsigned kind) {
+    if (n < 32) t[n++] = (__builtin_amdgcn_s_memrealtime() & ~3ull) | (kind & 3u);
+  }
   __device__ __forceinline__ void flush() {
     mark();
     unsigned long long *buf = g_bin_trace;
@@ -156,6 +161,7 @@ struct BinTrace {
 #else
   __device__ __forceinline__ BinTrace(int) {}
   __device__ __forceinline__ void mark() {}
+  __device__ __forceinline__ void mark(unsigned) {}
   __device__ __forceinline__ void flush() {}
 #endif
 };
@@ -226,6 +232,111 @@ __device__ __forceinline__ void for_each_big(const BigList &L, uint32_t lo, uint
     const int cnt = rect_entries(rc, gi);
     for (int e = lane; e < cnt; e += 64)
       f((((uint32_t)((sy0 + e / nx) * gi.stx + sx0 + e % nx)) << lg) + db, i, key, rc);
+  }
+}
+
+
+// ------------------------------------------------------------------------------------ the sorted array's layout
+constexpr int BIN_CAP = 2048;      // entries a workgroup sorts in LDS (16 KB)
+constexpr int SUB_MAX = 512;       // largest sub-bin ranked quadratically
+// A bucket above BIN_CAP (thousands of Gaussians of one supertile in one depth bin) is cut into SLICES of
+// ~SLICE_TARGET entries along its sub-bins, sorted by different workgroups of the bucket_sort launch; only a SUB-bin
+// above SUB_MAX (hundreds of Gaussians at nearly ONE depth) sends its bucket to eight stable byte passes of a single
+// workgroup through global memory: slow, correct, rare.  The unsorted entries are read-only in bucket_sort, so every
+// slice of a bucket sees the same counts and takes the same decisions.  Every slice's sorted entries start at a whole
+// group: a bucket of n entries cut into J slices reserves n + 64 J slots (rounded up to a group), and its last slice
+// fills what is left with empty entries.
+constexpr int SLICE_TARGET = BIN_CAP - SUB_MAX;
+constexpr int MAX_UNITS = MAX_BUCKETS + MAX_SLICES;  // rows of per-tile totals: one per bucket, or per slice of a cut bucket
+static_assert(MAX_UNITS < 4096 && MAX_SUPER <= 256, "a group's word: unit and first unit in 12 bits each, supertile in 8");
+__device__ __forceinline__ uint32_t pad_grp(uint32_t n) { return (n + GRP - 1) / GRP * GRP; }
+
+// Run by ONE workgroup per render (level 1's last): where every bucket's sorted entries start (supertile by
+// supertile, a supertile's buckets by depth bin, every bucket rounded up to whole groups), which buckets are cut into
+// slices, and the rows (units) of their per-tile totals -- as bucket_sort's WORK LIST, which its workgroups take item
+// by item (the first `sort_grid` items one each, the rest through a ticket counter): the slices first (the longest
+// jobs), then the buckets that are sorted whole, largest size class first.  An item is two 16-byte words:
+// (first slot, entries, segments | slices << 16, unit | first unit of the supertile << 12 | supertile << 24) of its
+// bucket and (bucket | slice << 16 | (a slice) << 31, 0, 0, 0).
+// s_tab: MAX_BUCKETS words of LDS, s4: four.
+__device__ __forceinline__ void layout_buckets(const BinArgs &a, void *geom, void *bin, uint32_t *s_tab, uint32_t *s4) {
+  constexpr int OWN = MAX_BUCKETS / SORT_BLOCK;
+  uint32_t *__restrict__ bk = at<uint32_t>(geom, a.g_bk);
+  u64 *bk_tot = reinterpret_cast<u64 *>(bk + BK_TOT);
+  uint4 *__restrict__ work = at<uint4>(geom, a.g_work);
+  const int tid = threadIdx.x, nbuckets = a.gi.NS << a.lg;
+  constexpr int CLASSES = 32;  // size classes of 64 entries, the last one open
+  __shared__ uint32_t s_class[CLASSES];
+  if (tid < CLASSES) s_class[tid] = 0u;
+  uint32_t tot[OWN], nsg[OWN], want[OWN], wsum = 0;
+#pragma unroll
+  for (int u = 0; u < OWN; ++u) {
+    // (the totals were summed by atomics of workgroups all over the chip: read at device scope)
+    const u64 w = tid * OWN + u < nbuckets ? __hip_atomic_load(&bk_tot[tid * OWN + u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+    tot[u] = (uint32_t)w, nsg[u] = (uint32_t)(w >> 32);
+    const uint32_t J = tot[u] > (uint32_t)BIN_CAP ? (tot[u] + SLICE_TARGET - 1) / SLICE_TARGET : 0u;
+    want[u] = J <= 255u ? J : 0u;  // (more: the byte passes)
+    wsum += want[u];
+  }
+  uint32_t wall;
+  uint32_t wrun = block_scan_excl(wsum, s4, wall);
+  // a bucket gets its slices while the list has room (in bucket order)
+  uint32_t J[OWN], reg[OWN], rsum = 0, usum = 0;
+#pragma unroll
+  for (int u = 0; u < OWN; ++u) {
+    J[u] = want[u] && wrun + want[u] <= (uint32_t)MAX_SLICES ? want[u] : 0u;
+    wrun += want[u];
+    reg[u] = tot[u] ? pad_grp(tot[u] + (uint32_t)GRP * J[u]) : 0u;
+    rsum += reg[u], usum += tot[u] ? max(J[u], 1u) : 0u;
+  }
+  uint32_t rall, uall;
+  uint32_t start = block_scan_excl(rsum, s4, rall);
+  uint32_t unit = block_scan_excl(usum, s4, uall);
+#pragma unroll
+  for (int u = 0; u < OWN; ++u) s_tab[tid * OWN + u] = unit, unit += tot[u] ? max(J[u], 1u) : 0u;
+  unit -= usum;
+  // (the size classes of the buckets sorted whole: counted, largest first)
+#pragma unroll
+  for (int u = 0; u < OWN; ++u)
+    if (tot[u] && !J[u]) atomicAdd(&s_class[CLASSES - 1 - min(tot[u] >> 6, (uint32_t)CLASSES - 1u)], 1u);
+  lds_barrier();
+  uint32_t n_sl_all;
+  {
+    uint32_t jsum = 0;
+#pragma unroll
+    for (int u = 0; u < OWN; ++u) jsum += J[u];
+    const uint32_t jex = block_scan_excl(jsum, s4, n_sl_all);
+    wrun = jex;  // (= the want prefix for every accepted bucket: the accepted ones are a prefix of the cut ones)
+  }
+  {  // class cursors: behind the slices
+    const uint32_t c = tid < CLASSES ? s_class[tid] : 0u;
+    uint32_t call;
+    const uint32_t cex = block_scan_excl(c, s4, call);
+    if (tid < CLASSES) s_class[tid] = n_sl_all + cex;
+    if (tid == 0) bk[BK_NITEMS] = n_sl_all + call;
+    // the ticket counters (item i belongs to queue i % WORK_QUEUES): behind the items the workgroups take untold
+    if (tid < WORK_QUEUES) bk[BK_WORK + tid] = (uint32_t)(a.sort_grid > tid ? (a.sort_grid - tid + WORK_QUEUES - 1) / WORK_QUEUES : 0);
+  }
+  lds_barrier();
+#pragma unroll
+  for (int u = 0; u < OWN; ++u) {
+    const uint32_t b = (uint32_t)(tid * OWN + u);
+    if (tot[u]) {
+      const uint4 bi = make_uint4(start, tot[u], nsg[u] | (J[u] << 16), unit | (s_tab[(b >> a.lg) << a.lg] << 12) | ((b >> a.lg) << 24));
+      for (uint32_t j = 0; j < J[u]; ++j)
+        work[2 * (wrun + j)] = bi, work[2 * (wrun + j) + 1] = make_uint4(b | (j << 16) | 0x80000000u, 0u, 0u, 0u);
+      if (!J[u]) {
+        const uint32_t i = atomicAdd(&s_class[CLASSES - 1 - min(tot[u] >> 6, (uint32_t)CLASSES - 1u)], 1u);
+        work[2 * i] = bi, work[2 * i + 1] = make_uint4(b, 0u, 0u, 0u);
+      }
+    }
+    wrun += J[u], start += reg[u], unit += tot[u] ? max(J[u], 1u) : 0u;
+  }
+  if (tid == 0) {
+    // the groups the fill walks: those of the buckets that fit the sorted array whole (all of them unless the
+    // instance capacity overflowed; the buckets are laid out in order, so the ones that fit are a prefix)
+    uint32_t *meta = at<uint32_t>(bin, a.b_meta);
+    meta[META_NGRP] = (uint32_t)(min((size_t)rall, a.l1cap) / GRP);
   }
 }
 
@@ -368,15 +479,26 @@ __device__ __forceinline__ void level1_body(const BinArgs &a, void *geom, void *
     for (int u = 0; u < OWN; ++u) {
       const uint32_t t = cn[u] + cb[u], b = (uint32_t)(tid * OWN + u);
       if (t) {
+        // (what the atomic returns IS the segment's place in the bucket: entries of the segments listed before it)
         const u64 old = atomicAdd(&bk_tot[b], (1ull << 32) | (u64)t);
         const uint32_t slot = (uint32_t)(old >> 32);
-        if (slot < (uint32_t)a.nwg1) segs[(size_t)b * a.nwg1 + slot] = make_uint2(pre_e + run, t);
+        if (slot < (uint32_t)a.nwg1) segs[(size_t)b * a.nwg1 + slot] = make_uint2(pre_e + run, (uint32_t)old);
         s_hist[b] = run, s_bigc[b] = run + cn[u];
         run += t;
       }
     }
   }
+  // the LAST workgroup of the render to get here (every workgroup's entries are in the bucket totals then) lays the
+  // sorted array out for bucket_sort, once its own entries are placed.  (Nobody waits for the ticket before that: the
+  // tickets of a render are atomics on ONE word, which the memory side hands out at ~8 per us -- with a barrier
+  // behind the draw the launch took 53 us instead of 41.)
+  // (No device-wide fence: a release at device scope writes the whole L2 back on this chip -- 92 us per launch
+  // measured with one per workgroup.  None is needed: the bucket atomics are performed at the memory side and have
+  // RETURNED by the barrier below, the ticket is taken behind it, and the last workgroup reads the totals with
+  // device-scope loads; everything else it and the others write is for the next launch.)
+  __shared__ uint32_t s_last;
   __syncthreads();
+  if (tid == 0) s_last = atomicAdd(&bk[BK_DONE], 1u) == gridDim.x - 1u ? 1u : 0u;
   tr.mark();
   // ---- the entries, to the workgroup's segment: pre_e + the bucket's first slot + the entry's rank
   for (int c = c0; c < c1; ++c) {
@@ -407,27 +529,14 @@ __device__ __forceinline__ void level1_body(const BinArgs &a, void *geom, void *
       });
     }
   }
+  __syncthreads();
+  if (s_last) layout_buckets(a, geom, bin, s_hist, s_wt);
   tr.flush();
 }
 
 // ------------------------------------------------------------------------------------ 2. bucket sort + level-2 counts
-constexpr int BIN_CAP = 2048;      // entries a workgroup sorts in LDS (16 KB)
-constexpr int SUB_MAX = 512;       // largest sub-bin ranked quadratically
-// A bucket above BIN_CAP (thousands of Gaussians of one supertile in one depth bin) is cut into SLICES of
-// ~SLICE_TARGET entries along its sub-bins, sorted by the extra workgroups of the launch; only a SUB-bin above SUB_MAX
-// (hundreds of Gaussians at nearly ONE depth) sends its bucket to eight stable byte passes of a single workgroup
-// through global memory: slow, correct, rare.  The unsorted entries are read-only here, so every slice of a bucket sees
-// the same counts and takes the same decisions.  Every slice's sorted entries start at a whole group: a bucket of n
-// entries cut into J slices reserves n + 64 J slots (rounded up to a group), and its last slice fills what is left
-// with empty entries.
-constexpr int SLICE_TARGET = BIN_CAP - SUB_MAX;
 constexpr int PER = BIN_CAP / SORT_BLOCK;
-constexpr int MAXB = 8;            // buckets one bucket_sort workgroup walks
-constexpr int MAXSL = 8;           // slices one bucket_sort workgroup walks (the launch has >= 32 workgroups)
 constexpr int SUB_OWN = SUB_BINS / SORT_BLOCK;  // sub-bins a thread owns in the scans
-constexpr int MAX_UNITS = MAX_BUCKETS + MAX_SLICES;  // rows of per-tile totals: one per bucket, or per slice of a cut bucket
-static_assert(MAX_UNITS < 4096 && MAX_SUPER <= 256, "a group's word: unit and first unit in 12 bits each, supertile in 8");
-static_assert(MAX_SLICES == 256 && MAX_SLICES <= MAXSL * 32, "slice list");
 
 // One stable counting pass of a single workgroup over n 64-bit words: digit = byte `byte` of the word.
 __device__ __forceinline__ void wg_radix_pass(const u64 *kin, u64 *kout, uint32_t n, int byte, uint32_t *s_run,
@@ -532,47 +641,9 @@ struct Unit {
 struct UnitShared {
   uint32_t wtot[SORT_BLOCK / 64][64];
 };
-// The run's `len` sorted rectangles (a whole number of groups, <= BIN_CAP: the padding behind the last entry holds
-// empty rectangles) are in LDS, its first group is group g0 of the level-1 array.  Wave w takes the groups
-// [w gpw, (w + 1) gpw): per group, the number of entries of the wave's earlier groups that cover tile j (lane j), kept
-// in registers until the waves have exchanged their totals; then the rows, the unit row and the tile totals.
-template <int SSH>
-__device__ __forceinline__ void count_run_lds(const uint2 *s_sr, uint32_t len, uint32_t g0, const Unit &U, UnitShared &sh) {
-  constexpr int ss = 1 << SSH, ntile = ss * ss, MAXG = BIN_CAP / GRP / (SORT_BLOCK / 64);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const uint32_t ng = len / GRP, gpw = (ng + 3) / 4;
-  uint32_t pre[MAXG], run = 0;
-#pragma unroll
-  for (int i = 0; i < MAXG; ++i) {
-    const uint32_t g = (uint32_t)wave * gpw + i;
-    pre[i] = run;
-    if ((uint32_t)i < gpw && g < ng) {  // (wave-uniform)
-      const uint2 rc = s_sr[g * GRP + lane];
-      run += group_counts<SSH>(tile_mask<SSH>(rc.x, rc.y, U.tx0, U.ty0));
-    }
-  }
-  sh.wtot[wave][lane] = run;
-  lds_barrier();
-  uint32_t base = 0;
-  for (int w = 0; w < wave; ++w) base += sh.wtot[w][lane];
-#pragma unroll
-  for (int i = 0; i < MAXG; ++i) {
-    const uint32_t g = (uint32_t)wave * gpw + i;
-    if ((uint32_t)i < gpw && g < ng) {
-      U.grpbase[(size_t)(g0 + g) * GRP + lane] = base + pre[i];
-      if (lane == 0) U.grpinfo[g0 + g] = U.info;
-    }
-  }
-  if (wave == SORT_BLOCK / 64 - 1) {
-    const uint32_t tot = base + run;
-    U.cntu[(size_t)U.unit * GRP + lane] = tot;
-    const int my_tx = U.tx0 + (lane & (ss - 1)), my_ty = U.ty0 + (lane >> SSH);
-    if (lane < ntile && my_tx < U.tiles_x && my_ty < U.tiles_y && tot) atomicAdd(&U.tile_tot[my_ty * U.tiles_x + my_tx], tot);
-  }
-  lds_barrier();  // (wtot may be written again)
-}
-// The same for a run whose sorted entries are in GLOBAL memory (`out`, `len` of them, a whole number of groups; the
-// byte-pass fallback and the filler behind a cut bucket's last slice): two passes, the totals first.
+// The level-2 rows of a run whose sorted entries are in GLOBAL memory (`out`, `len` of them, a whole number of groups;
+// the byte-pass fallback and the filler behind a cut bucket's last slice): wave w takes the groups [w gpw, (w + 1) gpw),
+// two passes, the totals first.
 template <int SSH>
 __device__ __forceinline__ void count_run_global(const uint4 *out, uint32_t len, uint32_t g0, const Unit &U, UnitShared &sh,
                                                  bool with_unit_row) {
@@ -604,15 +675,6 @@ __device__ __forceinline__ void count_run_global(const uint4 *out, uint32_t len,
   }
   lds_barrier();
 }
-__device__ __forceinline__ void count_run_lds_any(int ssh, const uint2 *s_sr, uint32_t len, uint32_t g0, const Unit &U,
-                                                  UnitShared &sh) {
-  switch (ssh) {  // (uniform)
-    case 0: count_run_lds<0>(s_sr, len, g0, U, sh); break;
-    case 1: count_run_lds<1>(s_sr, len, g0, U, sh); break;
-    case 2: count_run_lds<2>(s_sr, len, g0, U, sh); break;
-    default: count_run_lds<3>(s_sr, len, g0, U, sh); break;
-  }
-}
 __device__ __forceinline__ void count_run_global_any(int ssh, const uint4 *out, uint32_t len, uint32_t g0, const Unit &U,
                                                      UnitShared &sh, bool with_unit_row) {
   switch (ssh) {
@@ -634,30 +696,28 @@ __device__ __forceinline__ uint4 entry_of(u64 word, const uint16_t *__restrict__
   return make_uint4(id, (uint32_t)(word >> 32), rc.x, rc.y);
 }
 
-// The segments of a bucket (where the level-1 workgroups left its entries), as one virtual array of n entries.
+// The segments of a bucket (where the level-1 workgroups left its entries), as one virtual array of n entries.  A
+// segment's record is (first entry in the unsorted array, its place in the bucket) -- the place is what the bucket's
+// atomic returned to the workgroup that listed the segment, so the records are in ascending order of it.
 struct SegTable {
-  uint32_t *off;  // [nseg + 1] exclusive prefix of the segments' lengths (LDS)
+  uint32_t *off;  // [nseg + 1] the segments' places in the bucket, off[nseg] = n (LDS)
   uint32_t *src;  // [nseg] first entry of the segment in the unsorted array (LDS)
   uint32_t nseg, steps;
 };
-// fills the table (all threads; ends with a barrier).  nseg <= MAX_SEG.
-__device__ __forceinline__ void load_segments(SegTable &S, const uint2 *__restrict__ segs, uint32_t nseg, uint32_t *s4) {
-  const int tid = threadIdx.x;
-  uint32_t carry = 0;
-  for (uint32_t s0 = 0; s0 < nseg; s0 += SORT_BLOCK) {
-    const uint32_t s = s0 + tid;
-    const uint2 rec = s < nseg ? segs[s] : make_uint2(0u, 0u);
-    uint32_t tot;
-    const uint32_t ex = block_scan_excl(rec.y, s4, tot);
-    if (s < nseg) S.off[s] = carry + ex, S.src[s] = rec.x;
-    carry += tot;
-  }
-  if (tid == 0) S.off[nseg] = carry;
+__device__ __forceinline__ void seg_table_shape(SegTable &S, uint32_t nseg) {
   S.nseg = nseg;
   uint32_t steps = 0;
   while ((1u << steps) < nseg) ++steps;
   S.steps = steps;
-  lds_barrier();
+}
+// fills the table from global memory (all threads; the caller's next barrier publishes it).  nseg <= MAX_SEG.
+__device__ __forceinline__ void load_segments(SegTable &S, const uint2 *__restrict__ segs, uint32_t nseg, uint32_t n) {
+  for (uint32_t q = threadIdx.x; q < nseg; q += SORT_BLOCK) {
+    const uint2 rec = segs[q];
+    S.src[q] = rec.x, S.off[q] = rec.y;
+  }
+  if (threadIdx.x == 0) S.off[nseg] = n;
+  seg_table_shape(S, nseg);
 }
 // entry e of the bucket (e < n): the last segment whose first entry is <= e, by a search of `steps` halvings
 __device__ __forceinline__ size_t seg_pos(const SegTable &S, uint32_t e) {
@@ -672,6 +732,10 @@ __device__ __forceinline__ uint4 seg_entry(const SegTable &S, const uint4 *__res
   const size_t p = seg_pos(S, e);
   // (past the unsorted array: only when the instance capacity overflowed -- the render is flagged and never used)
   return p < l1cap ? l1tmp[p] : make_uint4(0u, 0u, 0u, 0u);
+}
+__device__ __forceinline__ uint32_t seg_key(const SegTable &S, const uint4 *__restrict__ l1tmp, size_t l1cap, uint32_t e) {
+  const size_t p = seg_pos(S, e);
+  return p < l1cap ? l1tmp[p].x : 0u;
 }
 
 // the bucket's words go to la[0, n): eight byte passes a -> b -> ... -> a, then the entries (and `pad` empty ones)
@@ -722,18 +786,19 @@ __device__ __forceinline__ bool scan_sub_bins(uint32_t *s_cur, uint32_t *s_start
 
 // Every entry of s_k[0, m) ranks itself inside its sub-bin and goes to out[...]; entries are taken in the order they
 // sit in LDS (grouped by sub-bin): the 64 lanes of a wave walk the same one or two sub-bins, so a wave's trip count is
-// ITS sub-bins' size, not the largest sub-bin's of the bucket.  Then the sorted RECTANGLES replace the words in LDS
-// (s_sr aliases s_k: every rank has been formed by then), `len - m` empty entries pad the run to whole groups, and the
-// run's level-2 rows are counted from LDS.
-__device__ __forceinline__ void rank_store_count(u64 *s_k, const uint2 *s_r, const uint32_t *s_start, uint32_t origin,
+// ITS sub-bins' size, not the largest sub-bin's of the bucket.  An entry knows its GROUP then (its place / 64), and
+// adds one to the counter of (group, tile) for every tile of the supertile its rectangle covers -- LDS atomics on
+// s_gcnt[group][tile], zeroed by the caller: the first half of level 2, without the sorted entries ever being read
+// again.  `len - m` empty entries pad the run to whole groups.  Then, per tile, the prefix over the run's groups: the
+// rows, the unit row and the tile totals.
+template <int SSH>
+__device__ __forceinline__ void rank_store_count(const u64 *s_k, const uint2 *s_r, const uint32_t *s_start, uint32_t origin,
                                                  uint32_t m, uint32_t len, const SubMap &sm, uint4 *__restrict__ out,
-                                                 int ssh, uint32_t g0, const Unit &U, UnitShared &sh) {
-  uint32_t pos[PER];
-  uint2 rcs[PER];
+                                                 uint32_t g0, const Unit &U, uint32_t *s_gcnt, BinTrace &tr) {
+  constexpr int ss = 1 << SSH, ntile = ss * ss;
 #pragma unroll
   for (int q = 0; q < PER; ++q) {
     const uint32_t e = (uint32_t)q * SORT_BLOCK + threadIdx.x;
-    pos[q] = 0xffffffffu;
     if (e < m) {
       const u64 c = s_k[e];
       const uint2 rc = s_r[e];
@@ -747,21 +812,60 @@ __device__ __forceinline__ void rank_store_count(u64 *s_k, const uint2 *s_r, con
 #pragma unroll
         for (int u = 0; u < 8; ++u) r += (t + u < hi && v[u] < c) ? 1u : 0u;
       }
-      pos[q] = lo + r, rcs[q] = rc;
-      out[lo + r] = make_uint4((uint32_t)c, (uint32_t)(c >> 32), rc.x, rc.y);
+      const uint32_t p = lo + r;
+      out[p] = make_uint4((uint32_t)c, (uint32_t)(c >> 32), rc.x, rc.y);
+      uint32_t *cnt = s_gcnt + (p / GRP) * ntile;
+      if (ntile <= 32) {
+        for (uint32_t mk = (uint32_t)tile_mask<SSH>(rc.x, rc.y, U.tx0, U.ty0); mk; mk &= mk - 1u) atomicAdd(&cnt[__ffs((int)mk) - 1], 1u);
+      } else {
+        for (u64 mk = tile_mask<SSH>(rc.x, rc.y, U.tx0, U.ty0); mk; mk &= mk - 1ull) atomicAdd(&cnt[__ffsll((long long)mk) - 1], 1u);
+      }
     }
   }
-  lds_barrier();  // (every rank has been formed: the words are dead)
-  uint2 *s_sr = reinterpret_cast<uint2 *>(s_k);
-#pragma unroll
-  for (int q = 0; q < PER; ++q)
-    if (pos[q] != 0xffffffffu) s_sr[pos[q]] = rcs[q];
-  for (uint32_t e = m + threadIdx.x; e < len; e += SORT_BLOCK) s_sr[e] = make_uint2(0u, 0u), out[e] = make_uint4(0u, 0u, 0u, 0u);
+  for (uint32_t e = m + threadIdx.x; e < len; e += SORT_BLOCK) out[e] = make_uint4(0u, 0u, 0u, 0u);
   lds_barrier();
-  count_run_lds_any(ssh, s_sr, len, g0, U, sh);
+  tr.mark();
+  const uint32_t ng = len / GRP;
+  if (threadIdx.x < (uint32_t)ntile) {  // thread j: tile j of the supertile
+    const int j = (int)threadIdx.x;
+    uint32_t run = 0;
+    for (uint32_t gb = 0; gb < ng; gb += 8) {  // (eight LDS reads in flight)
+      uint32_t v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = s_gcnt[min(gb + u, ng - 1) * ntile + j];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (gb + u < ng) {
+          U.grpbase[(size_t)(g0 + gb + u) * GRP + j] = run;  // (the fill reads lanes [0, ntile) of a row only)
+          run += v[u];
+        }
+    }
+    U.cntu[(size_t)U.unit * GRP + j] = run;
+    const int my_tx = U.tx0 + (j & (ss - 1)), my_ty = U.ty0 + (j >> SSH);
+    if (my_tx < U.tiles_x && my_ty < U.tiles_y && run) atomicAdd(&U.tile_tot[my_ty * U.tiles_x + my_tx], run);
+  } else if (threadIdx.x >= 64 && threadIdx.x - 64 < ng) {
+    U.grpinfo[g0 + threadIdx.x - 64] = U.info;
+  }
+}
+__device__ __forceinline__ void rank_store_count_any(int ssh, const u64 *s_k, const uint2 *s_r, const uint32_t *s_start,
+                                                     uint32_t origin, uint32_t m, uint32_t len, const SubMap &sm, uint4 *out,
+                                                     uint32_t g0, const Unit &U, uint32_t *s_gcnt, BinTrace &tr) {
+  switch (ssh) {  // (uniform)
+    case 0: rank_store_count<0>(s_k, s_r, s_start, origin, m, len, sm, out, g0, U, s_gcnt, tr); break;
+    case 1: rank_store_count<1>(s_k, s_r, s_start, origin, m, len, sm, out, g0, U, s_gcnt, tr); break;
+    case 2: rank_store_count<2>(s_k, s_r, s_start, origin, m, len, sm, out, g0, U, s_gcnt, tr); break;
+    default: rank_store_count<3>(s_k, s_r, s_start, origin, m, len, sm, out, g0, U, s_gcnt, tr); break;
+  }
 }
 
-__device__ __forceinline__ uint32_t pad_grp(uint32_t n) { return (n + GRP - 1) / GRP * GRP; }
+// An item of the work list with what the workgroup needs to start on it: its two words (layout_buckets) and, for a
+// render with at most 256 level-1 workgroups, this thread's segment record (the words behind the bucket's last listed
+// segment are stale and never used).  Requested one item ahead.
+struct WorkItem {
+  uint4 bi;     // first slot, entries, segments | slices << 16, unit words
+  uint32_t w;   // bucket | slice << 16 | (a slice) << 31
+  uint2 rec;    // segs[bucket][tid]
+};
 
 __device__ __forceinline__ void bucket_sort_body(const BinArgs &a, void *geom, void *bin) {
   __shared__ u64 s_k[BIN_CAP];
@@ -769,17 +873,18 @@ __device__ __forceinline__ void bucket_sort_body(const BinArgs &a, void *geom, v
                                   // entry cost 8 us per 8 renders: random 8-byte reads)
   __shared__ uint32_t s_sub[2 * SUB_BINS + 1];  // sub-bin starts [SUB_BINS + 1], then counters / cursors [SUB_BINS]
   uint32_t *const s_start = s_sub, *const s_cur = s_sub + SUB_BINS + 1;
+  // the segment table of the bucket at hand ([segments + 1] places, [segments] sources), then the (group, tile)
+  // counters of its run: sized by the host (sort_lds_words)
+  HIP_DYNAMIC_SHARED(uint32_t, s_seg)
   __shared__ uint32_t s_run[256];
   __shared__ uint32_t s_big;
   __shared__ uint32_t s_wt[4];
+  __shared__ uint32_t s_ticket[2];
   __shared__ UnitShared s_unit;
   uint32_t (*s_cnt)[256] = reinterpret_cast<uint32_t (*)[256]>(s_cur);  // (the fallback sort's counters: s_cur is free then)
   static_assert(SUB_BINS >= (SORT_BLOCK / 64) * 256, "s_cnt overlay");
-  // the segment table of the bucket at hand lives where the sub-bin tables will be (it is consumed -- the entries are
-  // in registers -- before the first sub-bin is counted), except on the paths that read the entries more than once
-  static_assert(2 * MAX_SEG + 1 <= 2 * SUB_BINS + 1 && 2 * MAX_SEG + 1 <= 2 * BIN_CAP, "segment table overlays");
-  const uint32_t *__restrict__ bk = at<uint32_t>(geom, a.g_bk);
-  const u64 *__restrict__ bk_tot = reinterpret_cast<const u64 *>(bk + BK_TOT);
+  uint32_t *__restrict__ bk = at<uint32_t>(geom, a.g_bk);
+  const uint4 *__restrict__ work = at<uint4>(geom, a.g_work);
   const uint16_t *__restrict__ rect = at<uint16_t>(geom, a.g_rect);
   const uint2 *__restrict__ segs = at<uint2>(geom, a.g_segs);
   const uint4 *__restrict__ l1tmp = at<uint4>(bin, a.b_l1tmp);
@@ -787,192 +892,112 @@ __device__ __forceinline__ void bucket_sort_body(const BinArgs &a, void *geom, v
   u64 *__restrict__ l1b = at<u64>(bin, a.b_l1b);
   uint4 *__restrict__ l1list = at<uint4>(bin, a.b_l1);
   const int tid = threadIdx.x;
-  const int nbins = 1 << a.lg, nbuckets = a.gi.NS << a.lg;
-  constexpr int OWN = MAX_BUCKETS / SORT_BLOCK;
+  const int nbins = 1 << a.lg;
+  const bool seg_regs = a.nwg1 <= SORT_BLOCK;
   BinTrace tr(3);
-  // ---- where every bucket's sorted entries start, which buckets are cut into slices, and the rows (units) of their
-  // per-tile totals: every workgroup scans the bucket totals itself (thread t owns buckets [8 t, 8 t + 8)).
-  // The workgroup's own buckets are b = blockIdx.x, + gridDim.x, ... (at most MAXB: see bucket_grid), its slices
-  // t = blockIdx.x, + gridDim.x, ... of the launch's slice list (at most MAXSL).
-  __shared__ uint32_t s_bn[MAXB], s_bbase[MAXB], s_bj[MAXB], s_bu[MAXB], s_bnseg[MAXB];
-  __shared__ uint32_t s_sb[MAXSL], s_sj[MAXSL];  // slices of this workgroup: bucket; J << 8 | j
-  __shared__ uint32_t s_sn[MAXSL], s_sbase[MAXSL], s_su[MAXSL], s_snseg[MAXSL];
-  __shared__ uint32_t s_nslice;
-  uint32_t *const s_unit_of = reinterpret_cast<uint32_t *>(s_k);  // [MAX_BUCKETS] first unit of the bucket (prologue only)
-  {
-    uint32_t tot[OWN], nsg[OWN], want[OWN], wsum = 0;
-#pragma unroll
-    for (int u = 0; u < OWN; ++u) {
-      const u64 w = tid * OWN + u < nbuckets ? bk_tot[tid * OWN + u] : 0ull;
-      tot[u] = (uint32_t)w, nsg[u] = (uint32_t)(w >> 32);
-      const uint32_t J = tot[u] > (uint32_t)BIN_CAP ? (tot[u] + SLICE_TARGET - 1) / SLICE_TARGET : 0u;
-      want[u] = J <= 255u ? J : 0u;  // (more: the byte passes)
-      wsum += want[u];
-    }
-    if (tid < MAXB) s_bn[tid] = 0u;
-    if (tid < MAXSL) s_sn[tid] = 0u;
-    uint32_t wall;
-    uint32_t wrun = block_scan_excl(wsum, s_wt, wall);
-    // a bucket gets its slices while the list has room (in bucket order: every workgroup takes the same decision)
-    uint32_t J[OWN], reg[OWN], rsum = 0, usum = 0;
-#pragma unroll
-    for (int u = 0; u < OWN; ++u) {
-      J[u] = want[u] && wrun + want[u] <= (uint32_t)MAX_SLICES ? want[u] : 0u;
-      wrun += want[u];
-      reg[u] = tot[u] ? pad_grp(tot[u] + (uint32_t)GRP * J[u]) : 0u;
-      rsum += reg[u], usum += tot[u] ? max(J[u], 1u) : 0u;
-    }
-    wrun -= wsum;  // (back to the exclusive prefix: the first slice of the thread's first cut bucket)
-    uint32_t rall, uall;
-    uint32_t start = block_scan_excl(rsum, s_wt, rall);
-    uint32_t unit = block_scan_excl(usum, s_wt, uall);
-#pragma unroll
-    for (int u = 0; u < OWN; ++u) s_unit_of[tid * OWN + u] = unit, unit += tot[u] ? max(J[u], 1u) : 0u;
-    unit -= usum;
-    lds_barrier();
-    uint32_t srun = wrun;
-#pragma unroll
-    for (int u = 0; u < OWN; ++u) {
-      const uint32_t b = (uint32_t)(tid * OWN + u);
-      if (tot[u]) {
-        if (b % gridDim.x == blockIdx.x && b / gridDim.x < (uint32_t)MAXB) {
-          const uint32_t k = b / gridDim.x;
-          s_bn[k] = tot[u], s_bbase[k] = start, s_bj[k] = J[u], s_bnseg[k] = nsg[u];
-          s_bu[k] = unit | (s_unit_of[(b >> a.lg) << a.lg] << 12) | ((b >> a.lg) << 24);
-        }
-        for (uint32_t j = 0; j < J[u]; ++j) {
-          const uint32_t t = srun + j;
-          if (t % gridDim.x == blockIdx.x && t / gridDim.x < (uint32_t)MAXSL) {
-            const uint32_t k = t / gridDim.x;
-            s_sb[k] = b, s_sj[k] = (J[u] << 8) | j, s_sn[k] = tot[u], s_sbase[k] = start, s_snseg[k] = nsg[u];
-            s_su[k] = (unit + j) | (s_unit_of[(b >> a.lg) << a.lg] << 12) | ((b >> a.lg) << 24);
-          }
-        }
-        srun += J[u];
-      }
-      start += reg[u], unit += tot[u] ? max(J[u], 1u) : 0u;
-    }
-    if (blockIdx.x == 0 && tid == 0) {
-      // the groups the fill walks: those of the buckets that fit the sorted array whole (all of them unless the
-      // instance capacity overflowed; the buckets are laid out in order, so the ones that fit are a prefix)
-      uint32_t *meta = at<uint32_t>(bin, a.b_meta);
-      meta[META_NGRP] = (uint32_t)(min((size_t)rall, a.l1cap) / GRP);
-    }
-    if (tid == 0) s_nslice = min(wall, (uint32_t)MAX_SLICES);
-  }
+  // ---- The render's work list (level 1's last workgroup wrote it: slices first, then the buckets sorted whole by
+  // size class) is taken item by item through a ticket counter -- the workgroups' lives differed by 2x with a fixed
+  // share of buckets each (bucket sizes differ by 10x, a slice costs four average buckets).  A workgroup's first item
+  // is its own number (no ticket: one memory round trip less before the first entry is read); the ticket for the next
+  // one is drawn when an item is begun and its words are requested while the item is sorted.  The memory side hands
+  // out ~8 tickets per us and word (a single counter per render capped the launch at its 540 items' 50 us), so the
+  // list is dealt to WORK_QUEUES counters: item i belongs to queue i % WORK_QUEUES, a workgroup draws from the queue
+  // of its own number -- the list is in size order, so every queue holds the same mix.
+  uint32_t t = blockIdx.x;
+  const uint32_t queue = blockIdx.x % WORK_QUEUES;
+  WorkItem cur, nxt;
+  cur.bi = work[2 * t], cur.w = work[2 * t + 1].x;  // (stale beyond the list: checked against n_items below)
+  const uint32_t n_items = bk[BK_NITEMS];
   const uint32_t map_lo = bk[BK_KMIN], map_shift = bk[BK_SHIFT];
-  __syncthreads();
+  cur.rec = t < n_items && seg_regs && tid < a.nwg1 ? segs[(size_t)(cur.w & 0xffffu) * a.nwg1 + tid] : make_uint2(0u, 0u);
+  nxt = cur;
   Unit U;
   U.grpbase = at<uint32_t>(bin, a.b_grpbase), U.grpinfo = at<uint32_t>(bin, a.b_grpinfo), U.cntu = at<uint32_t>(bin, a.b_cntu);
   U.tile_tot = at<uint32_t>(bin, a.b_totals), U.tiles_x = a.gi.tiles_x, U.tiles_y = a.gi.tiles_y;
   SegTable S;
-  S.off = s_sub, S.src = s_sub + MAX_SEG + 1;
+  S.off = s_seg, S.src = s_seg + a.nwg1 + 1;
   uint4 mine[PER];
   tr.mark();
-  for (int k = 0; k < MAXB; ++k) {
-    const uint32_t b = blockIdx.x + (uint32_t)k * gridDim.x;
-    if (b >= (uint32_t)nbuckets) break;
-    const uint32_t n = s_bn[k], base = s_bbase[k];
-    if (n == 0u) continue;
-    if (n > (uint32_t)BIN_CAP && s_bj[k] != 0u) continue;  // cut into slices: sorted below
-    const uint32_t len = pad_grp(n);
-    if ((size_t)base + len > a.l1cap) continue;  // (only when the instance capacity overflowed)
+  for (uint32_t par = 0; t < n_items; par ^= 1u) {
+    // the next ticket: drawn now, published behind the first barrier that comes after the atomic has returned
+    uint32_t t_next = 0;
+    if (tid == 0) t_next = queue + (uint32_t)WORK_QUEUES * atomicAdd(&bk[BK_WORK + queue], 1u);
+    const bool is_slice = (cur.w >> 31) != 0u;
+    const uint32_t b = cur.w & 0xffffu, j = (cur.w >> 16) & 255u;
+    const uint4 bi = cur.bi;
+    const uint32_t n = bi.y, base = bi.x, J = (bi.z >> 16) & 255u, nseg = min(bi.z & 0xffffu, (uint32_t)a.nwg1);
+    const uint32_t reserved = pad_grp(n + (uint32_t)GRP * J);  // (a bucket sorted whole: J = 0)
     const uint32_t sup = b >> a.lg;
-    U.unit = s_bu[k] & 0xfffu, U.info = s_bu[k];
+    U.unit = (bi.w & 0xfffu) + (is_slice ? j : 0u), U.info = (bi.w & ~0xfffu) | U.unit;
     U.tx0 = (int)((sup % a.gi.stx) << a.gi.ss_shift), U.ty0 = (int)((sup / a.gi.stx) << a.gi.ss_shift);
     const SubMap sm = sub_bin_map(map_lo, map_shift, b & (uint32_t)(nbins - 1));
-    lds_barrier();  // (the previous bucket's LDS has been consumed)
-    load_segments(S, segs + (size_t)b * a.nwg1, min(s_bnseg[k], (uint32_t)a.nwg1), s_wt);
-    bool lds = n <= (uint32_t)BIN_CAP;
-    if (lds) {
-      // the thread's entries, every load issued before the first use
-#pragma unroll
-      for (int q = 0; q < PER; ++q)
-        if ((uint32_t)q * SORT_BLOCK < n) mine[q] = seg_entry(S, l1tmp, a.l1cap, min((uint32_t)q * SORT_BLOCK + tid, n - 1));
-      lds_barrier();  // (the segment table has been read)
-#pragma unroll
-      for (int u = 0; u < SUB_OWN; ++u) s_cur[tid * SUB_OWN + u] = 0u;
-      if (tid == 0) s_big = 0u;
-      lds_barrier();
-#pragma unroll
-      for (int q = 0; q < PER; ++q)
-        if ((uint32_t)q * SORT_BLOCK + tid < n) atomicAdd(&s_cur[sub_bin(mine[q].x, sm)], 1u);
-      lds_barrier();
-      lds = !scan_sub_bins<true>(s_cur, s_start, s_run, &s_big);  // (workgroup-uniform)
-      if (!lds) {  // (the byte passes read the segments again)
-        lds_barrier();
-        load_segments(S, segs + (size_t)b * a.nwg1, min(s_bnseg[k], (uint32_t)a.nwg1), s_wt);
-      }
-    }
-    if (!lds) {  // hundreds of entries at nearly one depth, or an oversized bucket the slice list had no room for
-      // (the segment table moves out of the counters' way first)
-      uint32_t *keep = reinterpret_cast<uint32_t *>(s_r);
-      for (uint32_t s = tid; s <= S.nseg; s += SORT_BLOCK) keep[s] = S.off[s];
-      for (uint32_t s = tid; s < S.nseg; s += SORT_BLOCK) keep[MAX_SEG + 1 + s] = S.src[s];
-      SegTable K = S;
-      K.off = keep, K.src = keep + MAX_SEG + 1;
-      __syncthreads();
-      radix_fallback(K, l1tmp, a.l1cap, l1a + base, l1b + base, l1list + base, rect, n, len, s_run, s_cnt);
-      count_run_global_any(a.gi.ss_shift, l1list + base, len, base / GRP, U, s_unit, true);
-      __syncthreads();
-      continue;
+    // (what does not fit the sorted array -- only when the instance capacity overflowed -- is skipped, like an item that
+    // is not what it says: cannot happen)
+    const bool skip = n == 0u || (size_t)base + reserved > a.l1cap || (is_slice ? j >= J : (J != 0u));
+    __syncthreads();  // (the previous item's LDS has been consumed)
+    // the segment table, from the registers (or, beyond 256 level-1 workgroups, from global memory); the sub-bin counters
+    if (seg_regs) {
+      if ((uint32_t)tid < nseg) S.src[tid] = cur.rec.x, S.off[tid] = cur.rec.y;
+      if (tid == 0) S.off[nseg] = n;
+      seg_table_shape(S, nseg);
+    } else {
+      load_segments(S, segs + (size_t)b * a.nwg1, nseg, n);
     }
 #pragma unroll
-    for (int q = 0; q < PER; ++q)
-      if ((uint32_t)q * SORT_BLOCK + tid < n) {
-        const uint32_t p = atomicAdd(&s_cur[sub_bin(mine[q].x, sm)], 1u);
-        s_k[p] = ((u64)mine[q].x << 32) | (u64)mine[q].y;
-        s_r[p] = make_uint2(mine[q].z, mine[q].w);
-      }
+    for (int u = 0; u < SUB_OWN; ++u) s_cur[tid * SUB_OWN + u] = 0u;
+    if (tid == 0) s_big = 0u;
     lds_barrier();
-    rank_store_count(s_k, s_r, s_start, 0u, n, len, sm, l1list + base, a.gi.ss_shift, base / GRP, U, s_unit);
     tr.mark();
-  }
-  tr.mark();
-  {
-    // ---- slices of oversized buckets: every slice counts the bucket's sub-bins itself, takes the run of sub-bins
-    // whose first entry falls into its share of the bucket, and sorts those (<= SLICE_TARGET + SUB_MAX = BIN_CAP entries)
-    uint32_t *const keep = reinterpret_cast<uint32_t *>(s_r);  // the segment table (the slice's own entries go to s_r LAST)
-    const uint32_t n_slices = s_nslice;
-    for (int k = 0; k < MAXSL; ++k) {
-      const uint32_t t = blockIdx.x + (uint32_t)k * gridDim.x;
-      if (t >= n_slices) break;
-      const uint32_t n = s_sn[k];
-      if (n == 0u) continue;
-      const uint32_t b = s_sb[k], J = s_sj[k] >> 8, j = s_sj[k] & 255u, base = s_sbase[k];
-      const uint32_t reserved = pad_grp(n + (uint32_t)GRP * J);
-      if ((size_t)base + reserved > a.l1cap) continue;  // (only when the instance capacity overflowed)
-      const uint32_t sup = b >> a.lg;
-      U.unit = s_su[k] & 0xfffu, U.info = s_su[k];
-      U.tx0 = (int)((sup % a.gi.stx) << a.gi.ss_shift), U.ty0 = (int)((sup / a.gi.stx) << a.gi.ss_shift);
-      const SubMap sm = sub_bin_map(map_lo, map_shift, b & (uint32_t)(nbins - 1));
-      __syncthreads();  // (the previous slice's LDS has been consumed)
-      SegTable K;
-      K.off = keep, K.src = keep + MAX_SEG + 1;
-      load_segments(K, segs + (size_t)b * a.nwg1, min(s_snseg[k], (uint32_t)a.nwg1), s_wt);
+    bool in_lds = false;  // the run's entries are sorted in LDS (else: nothing to do, or the byte passes)
+    uint32_t first = 0, m = n, len = pad_grp(n), run_off = 0, used = 0;
+    if (!skip && !is_slice) {
+      if (n <= (uint32_t)BIN_CAP) {
+        // the thread's entries, every load issued before the first use
 #pragma unroll
-      for (int u = 0; u < SUB_OWN; ++u) s_cur[tid * SUB_OWN + u] = 0u;
-      if (tid == 0) s_big = 0u;
-      __syncthreads();
+        for (int q = 0; q < PER; ++q)
+          if ((uint32_t)q * SORT_BLOCK < n) mine[q] = seg_entry(S, l1tmp, a.l1cap, min((uint32_t)q * SORT_BLOCK + tid, n - 1));
+#pragma unroll
+        for (int q = 0; q < PER; ++q)
+          if ((uint32_t)q * SORT_BLOCK + tid < n) atomicAdd(&s_cur[sub_bin(mine[q].x, sm)], 1u);
+      }
+    } else if (!skip) {
+      // a slice counts the bucket's sub-bins itself, takes the run of sub-bins whose first entry falls into its share
+      // of the bucket, and sorts those (<= SLICE_TARGET + SUB_MAX = BIN_CAP entries)
       for (uint32_t e0 = 0; e0 < n; e0 += 8 * SORT_BLOCK) {
         uint32_t kk[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) kk[q] = seg_entry(K, l1tmp, a.l1cap, min(e0 + q * SORT_BLOCK + tid, n - 1)).x;
+        for (int q = 0; q < 8; ++q) kk[q] = seg_key(S, l1tmp, a.l1cap, min(e0 + q * SORT_BLOCK + tid, n - 1));
 #pragma unroll
         for (int q = 0; q < 8; ++q)
           if (e0 + q * SORT_BLOCK + tid < n) atomicAdd(&s_cur[sub_bin(kk[q], sm)], 1u);
       }
-      __syncthreads();
-      if (scan_sub_bins<false>(s_cur, s_start, s_run, &s_big)) {  // a sub-bin too large to rank: slice 0 sorts the
-        if (j == 0) {                                              // whole bucket the slow way, as ONE run
-          __syncthreads();
-          radix_fallback(K, l1tmp, a.l1cap, l1a + base, l1b + base, l1list + base, rect, n, reserved, s_run, s_cnt);
-          count_run_global_any(a.gi.ss_shift, l1list + base, reserved, base / GRP, U, s_unit, true);
-        } else {
-          zero_unit_row(U);
+    }
+    if (tid == 0) s_ticket[par ^ 1u] = t_next;
+    lds_barrier();
+    tr.mark();
+    // the next item's words
+    const uint32_t tn = s_ticket[par ^ 1u];
+    if (tn < n_items) nxt.bi = work[2 * tn], nxt.w = work[2 * tn + 1].x;
+    bool fat = false;  // some sub-bin too large to rank
+    if (!skip && (is_slice || n <= (uint32_t)BIN_CAP)) {
+      fat = is_slice ? scan_sub_bins<false>(s_cur, s_start, s_run, &s_big) : scan_sub_bins<true>(s_cur, s_start, s_run, &s_big);
+      in_lds = !fat;
+    }
+    tr.mark();
+    const uint32_t n_gcnt = (uint32_t)(BIN_CAP / GRP) << (2 * a.gi.ss_shift);  // (group, tile) counters of a run
+    if (!skip && !is_slice && in_lds) {
+      // (the segment table has been consumed: its LDS becomes the (group, tile) counters of the run)
+      for (uint32_t q = tid; q < n_gcnt; q += SORT_BLOCK) s_seg[q] = 0u;
+#pragma unroll
+      for (int q = 0; q < PER; ++q)
+        if ((uint32_t)q * SORT_BLOCK + tid < n) {
+          const uint32_t p = atomicAdd(&s_cur[sub_bin(mine[q].x, sm)], 1u);
+          s_k[p] = ((u64)mine[q].x << 32) | (u64)mine[q].y;
+          s_r[p] = make_uint2(mine[q].z, mine[q].w);
         }
-        continue;
-      }
+      lds_barrier();
+      tr.mark();
+    } else if (!skip && is_slice && in_lds) {
       // The slices' boundaries in the sorted bucket: P[i] = first entry of the first non-empty sub-bin that starts at
       // or behind i Tn (P[0] = 0, P[J] = n).  A non-empty sub-bin [S, E) makes E the boundary of every i with
       // S < i Tn <= E.  (s_run has 256 words: J <= 255.)
@@ -988,53 +1013,63 @@ __device__ __forceinline__ void bucket_sort_body(const BinArgs &a, void *geom, v
       lds_barrier();
       // this slice: sorted entries [P[j], P[j + 1]); its run starts behind the earlier slices' runs, each rounded up
       // to whole groups
-      const uint32_t first = s_run[j], m = min(s_run[j + 1] - first, (uint32_t)BIN_CAP);
-      uint32_t oall;
-      const uint32_t oex = block_scan_excl((uint32_t)tid < J ? pad_grp(s_run[tid + 1] - s_run[tid]) : 0u, s_wt, oall);
+      first = s_run[j], m = min(s_run[j + 1] - first, (uint32_t)BIN_CAP);
+      const uint32_t oex = block_scan_excl((uint32_t)tid < J ? pad_grp(s_run[tid + 1] - s_run[tid]) : 0u, s_wt, used);
       if ((uint32_t)tid == j) s_big = oex;  // (s_big is free: the fat sub-bin test has been read)
       lds_barrier();
-      const uint32_t run_off = s_big, len = pad_grp(m);
+      run_off = s_big, len = pad_grp(m);
       if (m > 0u) {
         // cursors: the slice's sub-bins start at `first`
 #pragma unroll
         for (int u = 0; u < SUB_OWN; ++u) s_cur[tid * SUB_OWN + u] = s_start[tid * SUB_OWN + u] - first;
         lds_barrier();
-        // the slice's entries: the bucket is read once more, through registers (s_r still holds the segment table)
-        for (uint32_t e0 = 0; e0 < n; e0 += 8 * SORT_BLOCK) {
+        for (uint32_t e0 = 0; e0 < n; e0 += 8 * SORT_BLOCK) {  // the bucket once more: the slice's entries stay
           uint4 kv[8];
 #pragma unroll
-          for (int q = 0; q < 8; ++q) kv[q] = seg_entry(K, l1tmp, a.l1cap, min(e0 + q * SORT_BLOCK + tid, n - 1));
+          for (int q = 0; q < 8; ++q) kv[q] = seg_entry(S, l1tmp, a.l1cap, min(e0 + q * SORT_BLOCK + tid, n - 1));
 #pragma unroll
           for (int q = 0; q < 8; ++q) {
-            const uint32_t sbn = s_start[min(sub_bin(kv[q].x, sm), (uint32_t)SUB_BINS - 1u)];
+            const uint32_t f = sub_bin(kv[q].x, sm), sbn = s_start[f];
             if (e0 + q * SORT_BLOCK + tid < n && sbn >= first && sbn < first + m) {
-              const uint32_t p = atomicAdd(&s_cur[sub_bin(kv[q].x, sm)], 1u);
-              // (word now, rectangle once every thread has left the segment table: below)
-              if (p < (uint32_t)BIN_CAP) s_k[p] = ((u64)kv[q].x << 32) | (u64)kv[q].y;
+              const uint32_t p = atomicAdd(&s_cur[f], 1u);
+              if (p < (uint32_t)BIN_CAP) s_k[p] = ((u64)kv[q].x << 32) | (u64)kv[q].y, s_r[p] = make_uint2(kv[q].z, kv[q].w);
             }
           }
         }
-        __syncthreads();
-        // the rectangles of the slice's entries, by id (the segment table in s_r is dead now)
-        for (uint32_t e = tid; e < m; e += SORT_BLOCK)
-          s_r[e] = *reinterpret_cast<const uint2 *>(rect + 4 * (size_t)(uint32_t)s_k[e]);
         lds_barrier();
-        rank_store_count(s_k, s_r, s_start, first, m, len, sm, l1list + base + run_off, a.gi.ss_shift,
-                         (base + run_off) / GRP, U, s_unit);
-      } else {
-        zero_unit_row(U);
+        // (a slice reads the segment table twice: its counters are cleared here)
+        for (uint32_t q = tid; q < n_gcnt; q += SORT_BLOCK) s_seg[q] = 0u;
+        lds_barrier();
       }
-      if (j == J - 1) {  // what the bucket reserved beyond its slices' runs: empty entries, empty rows
-        const uint32_t used = oall;
-        if (used < reserved) {
-          for (uint32_t e = used + tid; e < reserved; e += SORT_BLOCK) l1list[base + e] = make_uint4(0u, 0u, 0u, 0u);
-          __threadfence_block();
-          __syncthreads();
-          count_run_global_any(a.gi.ss_shift, l1list + base + used, reserved - used, (base + used) / GRP, U, s_unit, false);
-        }
-      }
-      tr.mark();
     }
+    // ... and, its words having arrived behind all these barriers, the next item's segment record (it has the ranking to
+    // arrive in)
+    nxt.rec = tn < n_items && seg_regs && tid < a.nwg1 ? segs[(size_t)(nxt.w & 0xffffu) * a.nwg1 + tid] : make_uint2(0u, 0u);
+    if (skip) {
+      // nothing
+    } else if (in_lds) {
+      if (m > 0u)
+        rank_store_count_any(a.gi.ss_shift, s_k, s_r, s_start, first, m, len, sm, l1list + base + run_off, (base + run_off) / GRP, U,
+                             s_seg, tr);
+      else
+        zero_unit_row(U);
+      if (is_slice && j == J - 1 && used < reserved) {  // what the bucket reserved beyond its slices' runs: empty entries, empty rows
+        for (uint32_t e = used + tid; e < reserved; e += SORT_BLOCK) l1list[base + e] = make_uint4(0u, 0u, 0u, 0u);
+        __threadfence_block();
+        __syncthreads();
+        count_run_global_any(a.gi.ss_shift, l1list + base + used, reserved - used, (base + used) / GRP, U, s_unit, false);
+      }
+    } else if (!is_slice || j == 0u) {
+      // hundreds of entries at nearly one depth (or an oversized bucket the slice list had no room for): the byte
+      // passes, by ONE workgroup -- the bucket's, or its slice 0 -- over the whole bucket as one run
+      __syncthreads();
+      radix_fallback(S, l1tmp, a.l1cap, l1a + base, l1b + base, l1list + base, rect, n, reserved, s_run, s_cnt);
+      count_run_global_any(a.gi.ss_shift, l1list + base, reserved, base / GRP, U, s_unit, true);
+    } else {
+      zero_unit_row(U);  // (a further slice of such a bucket)
+    }
+    tr.mark(skip ? 0u : (in_lds ? (is_slice ? 2u : 1u) : 3u));  // (what the item was: sorted in LDS whole / a slice / the byte passes or their idle slices)
+    cur = nxt, t = tn;
   }
   tr.flush();
 }
@@ -1102,6 +1137,7 @@ __device__ __forceinline__ void level2_fill_body(const BinArgs &a, void *geom, v
     // ... and the bucket totals, so that the chain can run again on the same projection (preprocess clears them too)
     uint32_t *bk = at<uint32_t>(geom, a.g_bk);
     for (int t = tid; t < 2 * MAX_BUCKETS; t += SORT_BLOCK) bk[BK_TOT + t] = 0u;
+    if (tid == 0) bk[BK_DONE] = 0u;
     uint32_t run = my_first;
     int ovf = total_w[1] != 0u;
     for (int q = 0; q < K; ++q) {
@@ -1192,7 +1228,8 @@ __device__ __forceinline__ void level2_fill_dispatch(const BinArgs &a, void *geo
 // Every stage exists as a single-render kernel (the C-ABI calls) and as a batched one whose blockIdx.y selects the
 // render of a RenderBatch (the native step executor: one launch per stage for all renders of a range).
 __global__ void __launch_bounds__(SORT_BLOCK) level1_kernel(BinArgs a, void *geom, void *bin) { level1_body(a, geom, bin); }
-__global__ void __launch_bounds__(SORT_BLOCK) bucket_sort_kernel(BinArgs a, void *geom, void *bin) {
+// (three waves per SIMD -- three workgroups per CU, what their 50 KB of LDS allow -- is 168 VGPRs)
+__global__ void __launch_bounds__(SORT_BLOCK, 3) bucket_sort_kernel(BinArgs a, void *geom, void *bin) {
   bucket_sort_body(a, geom, bin);
 }
 __global__ void __launch_bounds__(SORT_BLOCK) level2_fill_kernel(BinArgs a, void *geom, void *bin) {
@@ -1201,7 +1238,7 @@ __global__ void __launch_bounds__(SORT_BLOCK) level2_fill_kernel(BinArgs a, void
 __global__ void __launch_bounds__(SORT_BLOCK) level1_batched_kernel(BinArgs a, RenderBatch b) {
   level1_body(a, b.r[blockIdx.y].geom, b.r[blockIdx.y].bin);
 }
-__global__ void __launch_bounds__(SORT_BLOCK) bucket_sort_batched_kernel(BinArgs a, RenderBatch b) {
+__global__ void __launch_bounds__(SORT_BLOCK, 3) bucket_sort_batched_kernel(BinArgs a, RenderBatch b) {
   bucket_sort_body(a, b.r[blockIdx.y].geom, b.r[blockIdx.y].bin);
 }
 __global__ void __launch_bounds__(SORT_BLOCK) level2_fill_batched_kernel(BinArgs a, size_t flag_off, RenderBatch b) {
@@ -1217,6 +1254,18 @@ __global__ void __launch_bounds__(256) depth_keys_kernel(uint32_t R_cap, const u
 }
 
 // ------------------------------------------------------------------------------------ host side
+// bucket_sort: persistent workgroups that take the render's work list item by item; sized so that the renders of a
+// launch fit the chip in one round (51 KB of LDS: 3 workgroups per CU), at least 32 per render
+static unsigned bucket_grid(unsigned nbuckets, int n_renders) {
+  static const unsigned slots = getenv("DIMO_SORT_SLOTS") ? (unsigned)atoi(getenv("DIMO_SORT_SLOTS")) : 768u;  // EXPERIMENT
+  const unsigned room = (unsigned)(slots / (n_renders > 0 ? n_renders : 1));
+  unsigned g = room < nbuckets ? room : nbuckets;
+  return g < 32u ? 32u : g;
+}
+static size_t sort_lds_bytes(const BinArgs &a) {
+  const size_t table = 2 * (size_t)a.nwg1 + 1, counters = (size_t)(BIN_CAP / GRP) << (2 * a.gi.ss_shift);
+  return (table > counters ? table : counters) * sizeof(uint32_t);
+}
 static size_t level1_code_bytes(int per) { return (size_t)per * BIG_ENTRIES * SORT_BLOCK * sizeof(uint32_t); }
 static bool make_args(int N, int H, int W, int64_t R_cap, int n_renders, const GeomLayout &G, const BinLayout &B,
                       BinArgs &a) {
@@ -1237,8 +1286,9 @@ static bool make_args(int N, int H, int W, int64_t R_cap, int n_renders, const G
   a.N = N, a.nb = G.nb, a.per = per, a.nwg1 = (G.nb + per - 1) / per, a.lg = depth_bins_log2(N, a.gi.NS), a.T = B.T;
   a.R_cap = (uint32_t)B.cap;
   a.l1cap = B.l1cap;
+  a.sort_grid = (int)bucket_grid((unsigned)(a.gi.NS << a.lg), n_renders);
   a.g_total = G.total, a.g_rect = G.rect, a.g_tiles = G.tiles, a.g_offsets = G.offsets, a.g_sums = G.block_sums;
-  a.g_key32 = G.key32, a.g_bk = G.bk, a.g_segs = G.segs;
+  a.g_key32 = G.key32, a.g_bk = G.bk, a.g_segs = G.segs, a.g_work = G.work;
   a.b_meta = B.meta, a.b_l1tmp = B.l1tmp, a.b_l1a = B.l1a, a.b_l1b = B.l1b, a.b_l1 = B.l1list;
   a.b_grpbase = B.grpbase, a.b_grpinfo = B.grpinfo, a.b_cntu = B.cntu;
   a.b_totals = B.totals, a.b_ranges = B.ranges, a.b_work = B.work, a.b_vals = B.vals_b;
@@ -1246,15 +1296,6 @@ static bool make_args(int N, int H, int W, int64_t R_cap, int n_renders, const G
   return true;
 }
 
-// bucket_sort: persistent workgroups, each walks <= MAXB buckets (and <= MAXSL slices: at least 32 workgroups); sized
-// so that the renders of a launch fit the chip in about one round
-static unsigned bucket_grid(unsigned nbuckets, int n_renders) {
-  const unsigned least = (nbuckets + MAXB - 1) / MAXB;  // (nbuckets <= 2048: at most 256 then)
-  const unsigned room = (unsigned)(768 / (n_renders > 0 ? n_renders : 1));  // (43 KB of LDS: 3 workgroups per CU)
-  unsigned g = room < nbuckets ? room : nbuckets;
-  if (g < least) g = least;
-  return g < 32u ? 32u : g;
-}
 // level2_fill: persistent waves over the groups (their number, ~ entries / 64 + half a group per bucket, is only known
 // on the device): sized so that all the renders of a launch fit the chip in one round (2048 workgroups of 256
 // threads); a wave then walks ~5 groups at the benchmark configuration
@@ -1277,7 +1318,7 @@ int bin_instances(int N, int H, int W, int64_t R_cap, const void *geom_c, void *
   }
   {
     ScopedTimer tm(T_SORT, stream);
-    hipLaunchKernelGGL(bucket_sort_kernel, dim3(bucket_grid(nbuckets, 1)), dim3(SORT_BLOCK), 0, stream, a, geom, bin);
+    hipLaunchKernelGGL(bucket_sort_kernel, dim3(a.sort_grid), dim3(SORT_BLOCK), sort_lds_bytes(a), stream, a, geom, bin);
   }
   {
     ScopedTimer tm(T_TILE_SORT, stream);
@@ -1306,7 +1347,7 @@ int bin_instances_batched(const dimo_step_common &c, const RenderBatch &b, int n
   }
   {
     ScopedTimer tm(T_SORT, stream);
-    hipLaunchKernelGGL(bucket_sort_batched_kernel, dim3(bucket_grid(nbuckets, n), n), dim3(SORT_BLOCK), 0, stream, a, b);
+    hipLaunchKernelGGL(bucket_sort_batched_kernel, dim3(a.sort_grid, n), dim3(SORT_BLOCK), sort_lds_bytes(a), stream, a, b);
   }
   {
     ScopedTimer tm(T_TILE_SORT, stream);

@@ -90,13 +90,17 @@ inline __host__ __device__ int depth_bins_log2(int N, int NS) {
 // words of the `bk` area in the geometry workspace
 constexpr int MAX_SLICES = 256;                                          // slices of oversized buckets (one workgroup each)
 constexpr size_t BK_KMIN = 0, BK_SHIFT = 1, BK_KMIN0 = 2, BK_NBLOG = 3;  // bin map: origin, log2 bin width, smallest key, log2 bins
+constexpr size_t BK_NITEMS = 4;                                          // items of bucket_sort's work list
+constexpr size_t BK_DONE = 5;                                            // level-1 workgroups that have added their entries
+constexpr int WORK_QUEUES = 16;
+constexpr size_t BK_WORK = 8;                                            // [WORK_QUEUES] ticket counters of the work list
 // [MAX_BUCKETS] 64-bit words: entries of the bucket (low half) | segments listed for it (high half), summed by ONE
 // returning atomic per (level-1 workgroup, bucket it touches)
-constexpr size_t BK_TOT = 8;
+constexpr size_t BK_TOT = 24;
 constexpr size_t BK_WORDS = BK_TOT + 2 * MAX_BUCKETS;
 
 struct GeomLayout {
-  size_t splat, rect, tiles, offsets, flags, total, block_sums, key32, bk, segs;
+  size_t splat, rect, tiles, offsets, flags, total, block_sums, key32, bk, segs, work;
   size_t bytes;
   int nb, per, nwg1;  // preprocess blocks; blocks per level-1 workgroup; level-1 workgroups
   __host__ explicit GeomLayout(int N) {
@@ -119,6 +123,9 @@ struct GeomLayout {
     // entries in the bucket -- `slot` from the bucket's atomic, row stride = the launch's level-1 workgroups (<= nwg1);
     // only the listed slots are written and read
     segs = o, o = align_up(o + (size_t)MAX_BUCKETS * nwg1 * 2 * sizeof(uint32_t));
+    // bucket_sort's work list = the sorted level-1 array's layout (binning.hip: layout_buckets): eight words per
+    // slice and per bucket sorted whole
+    work = o, o = align_up(o + (size_t)(MAX_BUCKETS + MAX_SLICES) * 8 * sizeof(uint32_t));
     bytes = o;
   }
 };

@@ -9,11 +9,11 @@ ScopedTimer::~ScopedTimer() {}
 }  // namespace dimo
 
 extern "C" {
-// out: rect, tiles, offsets, total, block_sums, key32, bk, bytes, nb
-void simt_geom_layout(int N, size_t out[9]) {
+// out: rect, tiles, offsets, total, block_sums, key32, bk, bytes, nb, byte offset of the bucket totals
+void simt_geom_layout(int N, size_t out[10]) {
   dimo::GeomLayout G(N);
   out[0] = G.rect, out[1] = G.tiles, out[2] = G.offsets, out[3] = G.total, out[4] = G.block_sums, out[5] = G.key32;
-  out[6] = G.bk, out[7] = G.bytes, out[8] = (size_t)G.nb;
+  out[6] = G.bk, out[7] = G.bytes, out[8] = (size_t)G.nb, out[9] = G.bk + dimo::BK_TOT * sizeof(uint32_t);
 }
 // out: vals, ranges, totals, order, bytes, T, cap, l1tmp, l1list, meta, grpbase, grpinfo, cntu, l1cap
 void simt_bin_layout(int64_t R_cap, int H, int W, size_t out[14]) {

@@ -31,11 +31,11 @@ def lib():
 
 def _layouts(N, H, W, R_cap):
     L = lib()
-    g = (C.c_size_t * 9)()
+    g = (C.c_size_t * 10)()
     b = (C.c_size_t * 14)()
     L.simt_geom_layout(N, g)
     L.simt_bin_layout(R_cap, H, W, b)
-    G = dict(zip(("rect", "tiles", "offsets", "total", "block_sums", "key32", "bk", "bytes", "nb"), [int(x) for x in g]))
+    G = dict(zip(("rect", "tiles", "offsets", "total", "block_sums", "key32", "bk", "bytes", "nb", "bk_tot"), [int(x) for x in g]))
     B = dict(zip(("vals", "ranges", "totals", "order", "bytes", "T", "cap", "l1tmp", "l1list", "meta", "grpbase", "grpinfo",
                   "cntu", "l1cap"), [int(x) for x in b]))
     return G, B
@@ -105,7 +105,7 @@ def run_binning(rect, tiles, key32, H, W, R_cap=None, n_batched=0, poison=True):
         d = dict(R=int(tot[0]), overflow=int(tot[1]), entries=int(tot[2]), offsets=_read(geoms[i], G["offsets"], N),
                  dkeys=dk[:Rk], vals=_read(bins[i], B["vals"], Rk),
                  ranges=_read(bins[i], B["ranges"], 2 * B["T"]).reshape(-1, 2), order=_read(bins[i], B["order"], B["T"]),
-                 bk_tot=_read(geoms[i], G["bk"] + 4 * 8, 2 * 2048), bk=_read(geoms[i], G["bk"], 8),
+                 bk_tot=_read(geoms[i], G["bk_tot"], 2 * 2048), bk=_read(geoms[i], G["bk"], 8),
                  l1list=_read(bins[i], B["l1list"], 4 * min(B["l1cap"], 4 * N + 65536)).reshape(-1, 4),
                  l1tmp=_read(bins[i], B["l1tmp"], 4 * min(B["l1cap"], 4 * N + 65536)).reshape(-1, 4),
                  meta=_read(bins[i], B["meta"], 16), totals=_read(bins[i], B["totals"], B["T"]))

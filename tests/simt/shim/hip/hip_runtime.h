@@ -117,10 +117,14 @@ static inline uint32_t simt_writelane(uint32_t v, uint32_t sval, int J) { return
 static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 static inline int __popc(unsigned x) { return __builtin_popcount(x); }
 static inline int __ffsll(long long x) { return __builtin_ffsll(x); }
+static inline int __ffs(int x) { return __builtin_ffs(x); }
 static inline int __clz(int x) { return x ? __builtin_clz((unsigned)x) : 32; }
 
 template <class T>
 static inline T atomicAdd(T *p, T v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+#define __HIP_MEMORY_SCOPE_AGENT 4
+template <class T>
+static inline T __hip_atomic_load(const T *p, int, int) { return __atomic_load_n(p, __ATOMIC_RELAXED); }
 template <class T>
 static inline T atomicMax(T *p, T v) {
   T o = __atomic_load_n(p, __ATOMIC_RELAXED);
