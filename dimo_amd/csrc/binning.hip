@@ -87,7 +87,7 @@ struct BinArgs {
   BinGrid gi;
   size_t l1cap;
   // byte offsets into the geometry (g_) and bin (b_) workspaces
-  size_t g_total, g_rect, g_tiles, g_offsets, g_sums, g_key32, g_bk, g_segs, g_work;
+  size_t g_total, g_rect, g_tiles, g_offsets, g_sums, g_key32, g_bk, g_segs, g_work, g_wgob;
   size_t b_order;
   size_t b_meta, b_l1tmp, b_l1a, b_l1b, b_l1, b_grpbase, b_grpinfo, b_cntu, b_totals, b_ranges, b_work, b_vals;
 };
@@ -256,7 +256,7 @@ __device__ __forceinline__ uint32_t pad_grp(uint32_t n) { return (n + GRP - 1) /
 // slices, and the rows (units) of their per-tile totals -- as bucket_sort's WORK LIST, which its workgroups take item
 // by item (the first `sort_grid` items one each, the rest through a ticket counter): the slices first (the longest
 // jobs), then the buckets that are sorted whole, largest size class first.  An item is two 16-byte words:
-// (first slot, entries, segments | slices << 16, unit | first unit of the supertile << 12 | supertile << 24) of its
+// (first slot, entries, overflow records | slices << 16, unit | first unit of the supertile << 12 | supertile << 24) of its
 // bucket and (bucket | slice << 16 | (a slice) << 31, 0, 0, 0).
 // s_tab: MAX_BUCKETS words of LDS, s4: four.
 __device__ __forceinline__ void layout_buckets(const BinArgs &a, void *geom, void *bin, uint32_t *s_tab, uint32_t *s4) {
@@ -344,8 +344,8 @@ __device__ __forceinline__ void layout_buckets(const BinArgs &a, void *geom, voi
 // LDS: two counters per bucket (16 KB), the list of big Gaussians (4 KB) and, dynamically sized, one 32-bit code
 // (bucket << 16 | rank in the workgroup's share of the bucket) per (block, entry number, thread): per x 4 KB.
 __device__ __forceinline__ void level1_body(const BinArgs &a, void *geom, void *bin) {
-  __shared__ uint32_t s_hist[MAX_BUCKETS];  // entries of the lanes' walk per bucket; then the bucket's first slot in the segment
-  __shared__ uint32_t s_bigc[MAX_BUCKETS];  // entries of the big Gaussians per bucket; then their cursor
+  __shared__ uint32_t s_hist[MAX_BUCKETS];  // entries of the lanes' walk per bucket; then the place of the workgroup's first entry in the bucket
+  __shared__ uint32_t s_bigc[MAX_BUCKETS];  // entries of the big Gaussians per bucket; then their cursor (a place in the bucket)
   __shared__ uint32_t s_w[4][9];
   __shared__ uint32_t s_wt[4];
   __shared__ uint32_t s_anybig;
@@ -358,8 +358,12 @@ __device__ __forceinline__ void level1_body(const BinArgs &a, void *geom, void *
   uint32_t *__restrict__ offsets = at<uint32_t>(geom, a.g_offsets);
   uint32_t *__restrict__ bk = at<uint32_t>(geom, a.g_bk);
   u64 *__restrict__ bk_tot = reinterpret_cast<u64 *>(bk + BK_TOT);
-  uint2 *__restrict__ segs = at<uint2>(geom, a.g_segs);
+  uint4 *__restrict__ segs = at<uint4>(geom, a.g_segs);
   uint4 *__restrict__ l1tmp = at<uint4>(bin, a.b_l1tmp);
+  uint4 *__restrict__ l1ovf = l1tmp + (size_t)MAX_BUCKETS * BUCKET_REGION;  // (entries beyond a bucket's region)
+  // (a bucket that outgrows its region, rare: overflow slot of place p = wgob[bucket] + p -- this workgroup's row of a
+  // table in global memory; LDS is what decides how many of these workgroups a CU holds)
+  uint32_t *__restrict__ wgob = at<uint32_t>(geom, a.g_wgob) + (size_t)blockIdx.x * MAX_BUCKETS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c0 = (int)blockIdx.x * a.per, c1 = min(a.nb, c0 + a.per);  // this workgroup's preprocess blocks
   const int stride = a.nb + 1;
@@ -380,24 +384,23 @@ __device__ __forceinline__ void level1_body(const BinArgs &a, void *geom, void *
   // smallest block maximum bracket the bulk whatever the order of the Gaussians (Morton order: A ~ far end, B ~ near
   // end; random order: the other way round); the range is [min(A, B), max(A, B)] widened by a quarter on both sides,
   // inside [min, max].  Keys outside it fall into the first / last bin (whose sub-bins start at the smallest key).
-  uint32_t pre_t = 0, pre_e = 0, tot_t = 0, tot_e = 0, mn = 0xffffffffu, mx = 0u, A_ = 0u, B_ = 0xffffffffu;
+  uint32_t pre_t = 0, tot_t = 0, tot_e = 0, mn = 0xffffffffu, mx = 0u, A_ = 0u, B_ = 0xffffffffu;
   for (int i = tid; i < a.nb; i += SORT_BLOCK) {
     const uint32_t t = sums[i], bmin = sums[stride + i], bmax = sums[2 * stride + i], e = sums[3 * stride + i];
     tot_t += t, tot_e += e;
-    if (i < c0) pre_t += t, pre_e += e;
+    if (i < c0) pre_t += t;
     if (bmin != 0xffffffffu) mn = min(mn, bmin), mx = max(mx, bmax), A_ = max(A_, bmin), B_ = min(B_, bmax);
   }
-  pre_t = wave_sum(pre_t), pre_e = wave_sum(pre_e), tot_t = wave_sum(tot_t), tot_e = wave_sum(tot_e);
+  pre_t = wave_sum(pre_t), tot_t = wave_sum(tot_t), tot_e = wave_sum(tot_e);
   mn = wave_min(mn), mx = wave_max(mx), A_ = wave_max(A_), B_ = wave_min(B_);
   if (lane == 0) {
-    s_w[wave][0] = pre_t, s_w[wave][1] = tot_t, s_w[wave][2] = tot_e, s_w[wave][3] = pre_e;
+    s_w[wave][0] = pre_t, s_w[wave][1] = tot_t, s_w[wave][2] = tot_e;
     s_w[wave][4] = mn, s_w[wave][5] = mx, s_w[wave][6] = A_, s_w[wave][7] = B_;
   }
   __syncthreads();
   pre_t = s_w[0][0] + s_w[1][0] + s_w[2][0] + s_w[3][0];
   tot_t = s_w[0][1] + s_w[1][1] + s_w[2][1] + s_w[3][1];
   tot_e = s_w[0][2] + s_w[1][2] + s_w[2][2] + s_w[3][2];
-  pre_e = s_w[0][3] + s_w[1][3] + s_w[2][3] + s_w[3][3];
   mn = min(min(s_w[0][4], s_w[1][4]), min(s_w[2][4], s_w[3][4]));
   mx = max(max(s_w[0][5], s_w[1][5]), max(s_w[2][5], s_w[3][5]));
   A_ = max(max(s_w[0][6], s_w[1][6]), max(s_w[2][6], s_w[3][6]));
@@ -463,28 +466,29 @@ __device__ __forceinline__ void level1_body(const BinArgs &a, void *geom, void *
   }
   __syncthreads();
   tr.mark();
-  // ---- every non-empty bucket of the workgroup (thread t owns buckets [8 t, 8 t + 8)): its place in the workgroup's
-  // segment, its entries added to the bucket total, and (first entry, count) left in the bucket's segment list
+  // ---- every non-empty bucket of the workgroup (thread t owns buckets [8 t, 8 t + 8)): ONE returning atomic on the
+  // bucket total reserves the places [share, share + entries) of the bucket for the workgroup.  A bucket's entries live
+  // in ITS OWN fixed region of the unsorted array (BUCKET_REGION slots: bucket_sort reads a bucket as one contiguous
+  // run and no bucket's start has to be known here).  Places beyond the region -- a bucket of more than 4096 entries:
+  // thousands of Gaussians of one supertile in one depth bin -- go to a shared overflow area: a slot range from its
+  // cursor, and a record (first overflow slot, first place, places) in the bucket's list.
   const bool any_big = s_anybig != 0u;
   {
     constexpr int OWN = MAX_BUCKETS / SORT_BLOCK;
-    uint32_t cn[OWN], cb[OWN], sum = 0, seg_total;
 #pragma unroll
     for (int u = 0; u < OWN; ++u) {
-      const bool in = tid * OWN + u < nbuckets;
-      cn[u] = in ? s_hist[tid * OWN + u] : 0u, cb[u] = in ? s_bigc[tid * OWN + u] : 0u, sum += cn[u] + cb[u];
-    }
-    uint32_t run = block_scan_excl(sum, s_wt, seg_total);
-#pragma unroll
-    for (int u = 0; u < OWN; ++u) {
-      const uint32_t t = cn[u] + cb[u], b = (uint32_t)(tid * OWN + u);
+      const uint32_t b = (uint32_t)(tid * OWN + u);
+      const uint32_t cn = b < (uint32_t)nbuckets ? s_hist[b] : 0u, cb = b < (uint32_t)nbuckets ? s_bigc[b] : 0u, t = cn + cb;
       if (t) {
-        // (what the atomic returns IS the segment's place in the bucket: entries of the segments listed before it)
-        const u64 old = atomicAdd(&bk_tot[b], (1ull << 32) | (u64)t);
-        const uint32_t slot = (uint32_t)(old >> 32);
-        if (slot < (uint32_t)a.nwg1) segs[(size_t)b * a.nwg1 + slot] = make_uint2(pre_e + run, (uint32_t)old);
-        s_hist[b] = run, s_bigc[b] = run + cn[u];
-        run += t;
+        const uint32_t share = (uint32_t)atomicAdd(&bk_tot[b], (u64)t);
+        s_hist[b] = share, s_bigc[b] = share + cn;
+        if (share + t > (uint32_t)BUCKET_REGION) {
+          const uint32_t place = max(share, (uint32_t)BUCKET_REGION), cnt = share + t - place;
+          const uint32_t osrc = atomicAdd(&bk[BK_OVF], cnt);
+          const uint32_t slot = (uint32_t)(atomicAdd(&bk_tot[b], 1ull << 32) >> 32);
+          if (slot < (uint32_t)a.nwg1) segs[(size_t)b * a.nwg1 + slot] = make_uint4(osrc, place, cnt, 0u);
+          wgob[b] = osrc - place;
+        }
       }
     }
   }
@@ -500,7 +504,7 @@ __device__ __forceinline__ void level1_body(const BinArgs &a, void *geom, void *
   __syncthreads();
   if (tid == 0) s_last = atomicAdd(&bk[BK_DONE], 1u) == gridDim.x - 1u ? 1u : 0u;
   tr.mark();
-  // ---- the entries, to the workgroup's segment: pre_e + the bucket's first slot + the entry's rank
+  // ---- the entries, to their places: the workgroup's first place in the bucket + the entry's rank
   for (int c = c0; c < c1; ++c) {
     const int i = c * PRE_BLOCK + tid;
     const uint32_t *code = s_code + (size_t)(c - c0) * BIG_ENTRIES * SORT_BLOCK + tid;
@@ -512,9 +516,13 @@ __device__ __forceinline__ void level1_body(const BinArgs &a, void *geom, void *
 #pragma unroll
       for (int it = 0; it < BIG_ENTRIES; ++it)
         if (it < cnt) {
-          const uint32_t cd = code[it * SORT_BLOCK];
-          const size_t pos = (size_t)pre_e + s_hist[cd >> 16] + (cd & 0xffffu);
-          if (pos < a.l1cap) l1tmp[pos] = en;
+          const uint32_t cd = code[it * SORT_BLOCK], bu = cd >> 16, p = s_hist[bu] + (cd & 0xffffu);
+          if (p < (uint32_t)BUCKET_REGION) {
+            l1tmp[(size_t)bu * BUCKET_REGION + p] = en;
+          } else {
+            const uint32_t o = wgob[bu] + p;
+            if ((size_t)o < a.l1cap) l1ovf[o] = en;
+          }
         }
     }
     if (any_big) {  // (workgroup-uniform)
@@ -524,8 +532,13 @@ __device__ __forceinline__ void level1_body(const BinArgs &a, void *geom, void *
       if (cnt > BIG_ENTRIES) s_big.push((uint32_t)i, k, r);
       lds_barrier();
       for_each_big(s_big, lo, shift, nbins, a.gi, a.lg, [&](uint32_t bucket, uint32_t gi_, uint32_t key, uint2 rc) {
-        const size_t pos = (size_t)pre_e + atomicAdd(&s_bigc[bucket], 1u);
-        if (pos < a.l1cap) l1tmp[pos] = make_uint4(key, gi_, rc.x, rc.y);
+        const uint32_t p = atomicAdd(&s_bigc[bucket], 1u);
+        if (p < (uint32_t)BUCKET_REGION) {
+          l1tmp[(size_t)bucket * BUCKET_REGION + p] = make_uint4(key, gi_, rc.x, rc.y);
+        } else {
+          const uint32_t o = wgob[bucket] + p;
+          if ((size_t)o < a.l1cap) l1ovf[o] = make_uint4(key, gi_, rc.x, rc.y);
+        }
       });
     }
   }
@@ -696,54 +709,42 @@ __device__ __forceinline__ uint4 entry_of(u64 word, const uint16_t *__restrict__
   return make_uint4(id, (uint32_t)(word >> 32), rc.x, rc.y);
 }
 
-// The segments of a bucket (where the level-1 workgroups left its entries), as one virtual array of n entries.  A
-// segment's record is (first entry in the unsorted array, its place in the bucket) -- the place is what the bucket's
-// atomic returned to the workgroup that listed the segment, so the records are in ascending order of it.
-struct SegTable {
-  uint32_t *off;  // [nseg + 1] the segments' places in the bucket, off[nseg] = n (LDS)
-  uint32_t *src;  // [nseg] first entry of the segment in the unsorted array (LDS)
-  uint32_t nseg, steps;
+// The unsorted entries of a bucket, as one array of n entries: the first BUCKET_REGION of them in the bucket's own
+// region, the rest -- rare -- in the overflow area, described by the records (first overflow slot, first place, places)
+// the level-1 workgroups left in the bucket's list (in no order: a linear search, uniform trip count).
+struct BucketSrc {
+  const uint4 *region;   // the bucket's region of the unsorted array
+  const uint4 *ovf;      // the overflow area
+  size_t ovf_cap;
+  const uint32_t *rec;   // [3][nrec] in LDS: overflow slot, first place, places
+  uint32_t nrec;
 };
-__device__ __forceinline__ void seg_table_shape(SegTable &S, uint32_t nseg) {
-  S.nseg = nseg;
-  uint32_t steps = 0;
-  while ((1u << steps) < nseg) ++steps;
-  S.steps = steps;
-}
-// fills the table from global memory (all threads; the caller's next barrier publishes it).  nseg <= MAX_SEG.
-__device__ __forceinline__ void load_segments(SegTable &S, const uint2 *__restrict__ segs, uint32_t nseg, uint32_t n) {
-  for (uint32_t q = threadIdx.x; q < nseg; q += SORT_BLOCK) {
-    const uint2 rec = segs[q];
-    S.src[q] = rec.x, S.off[q] = rec.y;
+// the overflow records of a bucket, to LDS (all threads; the caller's next barrier publishes them).  nrec <= nwg1.
+__device__ __forceinline__ void load_overflow_records(uint32_t *s_rec, const uint4 *__restrict__ segs, uint32_t nrec) {
+  for (uint32_t q = threadIdx.x; q < nrec; q += SORT_BLOCK) {
+    const uint4 r = segs[q];
+    s_rec[q] = r.x, s_rec[nrec + q] = r.y, s_rec[2 * nrec + q] = r.z;
   }
-  if (threadIdx.x == 0) S.off[nseg] = n;
-  seg_table_shape(S, nseg);
 }
-// entry e of the bucket (e < n): the last segment whose first entry is <= e, by a search of `steps` halvings
-__device__ __forceinline__ size_t seg_pos(const SegTable &S, uint32_t e) {
-  uint32_t lo = 0;
-  for (uint32_t st = S.steps; st-- > 0;) {
-    const uint32_t mid = lo + (1u << st);
-    if (mid < S.nseg && S.off[mid] <= e) lo = mid;
+__device__ __forceinline__ const uint4 *bucket_entry_ptr(const BucketSrc &B, uint32_t e) {
+  if (e < (uint32_t)BUCKET_REGION) return B.region + e;
+  uint32_t slot = 0xffffffffu;
+  for (uint32_t s = 0; s < B.nrec; ++s) {
+    const uint32_t d = e - B.rec[B.nrec + s];
+    if (d < B.rec[2 * B.nrec + s]) slot = B.rec[s] + d;
   }
-  return (size_t)S.src[lo] + (e - S.off[lo]);
+  // (no record, or past the overflow area: only when the instance capacity overflowed -- the render is flagged and
+  // never used; any entry will do)
+  return (size_t)slot < B.ovf_cap ? B.ovf + slot : B.region;
 }
-__device__ __forceinline__ uint4 seg_entry(const SegTable &S, const uint4 *__restrict__ l1tmp, size_t l1cap, uint32_t e) {
-  const size_t p = seg_pos(S, e);
-  // (past the unsorted array: only when the instance capacity overflowed -- the render is flagged and never used)
-  return p < l1cap ? l1tmp[p] : make_uint4(0u, 0u, 0u, 0u);
-}
-__device__ __forceinline__ uint32_t seg_key(const SegTable &S, const uint4 *__restrict__ l1tmp, size_t l1cap, uint32_t e) {
-  const size_t p = seg_pos(S, e);
-  return p < l1cap ? l1tmp[p].x : 0u;
-}
+__device__ __forceinline__ uint4 bucket_entry(const BucketSrc &B, uint32_t e) { return *bucket_entry_ptr(B, e); }
+__device__ __forceinline__ uint32_t bucket_key(const BucketSrc &B, uint32_t e) { return bucket_entry_ptr(B, e)->x; }
 
 // the bucket's words go to la[0, n): eight byte passes a -> b -> ... -> a, then the entries (and `pad` empty ones)
-__device__ __forceinline__ void radix_fallback(const SegTable &S, const uint4 *l1tmp, size_t l1cap, u64 *la, u64 *lb,
-                                               uint4 *out, const uint16_t *rect, uint32_t n, uint32_t len, uint32_t *s_run,
-                                               uint32_t (*s_cnt)[256]) {
+__device__ __forceinline__ void radix_fallback(const BucketSrc &S, u64 *la, u64 *lb, uint4 *out, const uint16_t *rect,
+                                               uint32_t n, uint32_t len, uint32_t *s_run, uint32_t (*s_cnt)[256]) {
   for (uint32_t e = threadIdx.x; e < n; e += SORT_BLOCK) {
-    const uint4 en = seg_entry(S, l1tmp, l1cap, e);
+    const uint4 en = bucket_entry(S, e);
     la[e] = ((u64)en.x << 32) | (u64)en.y;
   }
   for (int byte = 0; byte < 8; ++byte) {
@@ -858,13 +859,10 @@ __device__ __forceinline__ void rank_store_count_any(int ssh, const u64 *s_k, co
   }
 }
 
-// An item of the work list with what the workgroup needs to start on it: its two words (layout_buckets) and, for a
-// render with at most 256 level-1 workgroups, this thread's segment record (the words behind the bucket's last listed
-// segment are stale and never used).  Requested one item ahead.
+// An item of the work list (its two words: layout_buckets).  Requested one item ahead.
 struct WorkItem {
-  uint4 bi;     // first slot, entries, segments | slices << 16, unit words
+  uint4 bi;     // first slot, entries, overflow records | slices << 16, unit words
   uint32_t w;   // bucket | slice << 16 | (a slice) << 31
-  uint2 rec;    // segs[bucket][tid]
 };
 
 __device__ __forceinline__ void bucket_sort_body(const BinArgs &a, void *geom, void *bin) {
@@ -873,8 +871,8 @@ __device__ __forceinline__ void bucket_sort_body(const BinArgs &a, void *geom, v
                                   // entry cost 8 us per 8 renders: random 8-byte reads)
   __shared__ uint32_t s_sub[2 * SUB_BINS + 1];  // sub-bin starts [SUB_BINS + 1], then counters / cursors [SUB_BINS]
   uint32_t *const s_start = s_sub, *const s_cur = s_sub + SUB_BINS + 1;
-  // the segment table of the bucket at hand ([segments + 1] places, [segments] sources), then the (group, tile)
-  // counters of its run: sized by the host (sort_lds_words)
+  // the overflow records of the bucket at hand (three words each: a bucket beyond its region only), then the
+  // (group, tile) counters of its run: sized by the host (sort_lds_bytes)
   HIP_DYNAMIC_SHARED(uint32_t, s_seg)
   __shared__ uint32_t s_run[256];
   __shared__ uint32_t s_big;
@@ -886,14 +884,13 @@ __device__ __forceinline__ void bucket_sort_body(const BinArgs &a, void *geom, v
   uint32_t *__restrict__ bk = at<uint32_t>(geom, a.g_bk);
   const uint4 *__restrict__ work = at<uint4>(geom, a.g_work);
   const uint16_t *__restrict__ rect = at<uint16_t>(geom, a.g_rect);
-  const uint2 *__restrict__ segs = at<uint2>(geom, a.g_segs);
+  const uint4 *__restrict__ segs = at<uint4>(geom, a.g_segs);
   const uint4 *__restrict__ l1tmp = at<uint4>(bin, a.b_l1tmp);
   u64 *__restrict__ l1a = at<u64>(bin, a.b_l1a);
   u64 *__restrict__ l1b = at<u64>(bin, a.b_l1b);
   uint4 *__restrict__ l1list = at<uint4>(bin, a.b_l1);
   const int tid = threadIdx.x;
   const int nbins = 1 << a.lg;
-  const bool seg_regs = a.nwg1 <= SORT_BLOCK;
   BinTrace tr(3);
   // ---- The render's work list (level 1's last workgroup wrote it: slices first, then the buckets sorted whole by
   // size class) is taken item by item through a ticket counter -- the workgroups' lives differed by 2x with a fixed
@@ -909,13 +906,12 @@ __device__ __forceinline__ void bucket_sort_body(const BinArgs &a, void *geom, v
   cur.bi = work[2 * t], cur.w = work[2 * t + 1].x;  // (stale beyond the list: checked against n_items below)
   const uint32_t n_items = bk[BK_NITEMS];
   const uint32_t map_lo = bk[BK_KMIN], map_shift = bk[BK_SHIFT];
-  cur.rec = t < n_items && seg_regs && tid < a.nwg1 ? segs[(size_t)(cur.w & 0xffffu) * a.nwg1 + tid] : make_uint2(0u, 0u);
   nxt = cur;
   Unit U;
   U.grpbase = at<uint32_t>(bin, a.b_grpbase), U.grpinfo = at<uint32_t>(bin, a.b_grpinfo), U.cntu = at<uint32_t>(bin, a.b_cntu);
   U.tile_tot = at<uint32_t>(bin, a.b_totals), U.tiles_x = a.gi.tiles_x, U.tiles_y = a.gi.tiles_y;
-  SegTable S;
-  S.off = s_seg, S.src = s_seg + a.nwg1 + 1;
+  BucketSrc S;
+  S.ovf = l1tmp + (size_t)MAX_BUCKETS * BUCKET_REGION, S.ovf_cap = a.l1cap, S.rec = s_seg;
   uint4 mine[PER];
   tr.mark();
   for (uint32_t par = 0; t < n_items; par ^= 1u) {
@@ -925,7 +921,8 @@ __device__ __forceinline__ void bucket_sort_body(const BinArgs &a, void *geom, v
     const bool is_slice = (cur.w >> 31) != 0u;
     const uint32_t b = cur.w & 0xffffu, j = (cur.w >> 16) & 255u;
     const uint4 bi = cur.bi;
-    const uint32_t n = bi.y, base = bi.x, J = (bi.z >> 16) & 255u, nseg = min(bi.z & 0xffffu, (uint32_t)a.nwg1);
+    const uint32_t n = bi.y, base = bi.x, J = (bi.z >> 16) & 255u;
+    S.region = l1tmp + (size_t)b * BUCKET_REGION, S.nrec = n > (uint32_t)BUCKET_REGION ? min(bi.z & 0xffffu, (uint32_t)a.nwg1) : 0u;
     const uint32_t reserved = pad_grp(n + (uint32_t)GRP * J);  // (a bucket sorted whole: J = 0)
     const uint32_t sup = b >> a.lg;
     U.unit = (bi.w & 0xfffu) + (is_slice ? j : 0u), U.info = (bi.w & ~0xfffu) | U.unit;
@@ -935,14 +932,8 @@ __device__ __forceinline__ void bucket_sort_body(const BinArgs &a, void *geom, v
     // is not what it says: cannot happen)
     const bool skip = n == 0u || (size_t)base + reserved > a.l1cap || (is_slice ? j >= J : (J != 0u));
     __syncthreads();  // (the previous item's LDS has been consumed)
-    // the segment table, from the registers (or, beyond 256 level-1 workgroups, from global memory); the sub-bin counters
-    if (seg_regs) {
-      if ((uint32_t)tid < nseg) S.src[tid] = cur.rec.x, S.off[tid] = cur.rec.y;
-      if (tid == 0) S.off[nseg] = n;
-      seg_table_shape(S, nseg);
-    } else {
-      load_segments(S, segs + (size_t)b * a.nwg1, nseg, n);
-    }
+    // (a bucket beyond its region: its overflow records;) the sub-bin counters
+    if (S.nrec) load_overflow_records(s_seg, segs + (size_t)b * a.nwg1, S.nrec);
 #pragma unroll
     for (int u = 0; u < SUB_OWN; ++u) s_cur[tid * SUB_OWN + u] = 0u;
     if (tid == 0) s_big = 0u;
@@ -955,7 +946,7 @@ __device__ __forceinline__ void bucket_sort_body(const BinArgs &a, void *geom, v
         // the thread's entries, every load issued before the first use
 #pragma unroll
         for (int q = 0; q < PER; ++q)
-          if ((uint32_t)q * SORT_BLOCK < n) mine[q] = seg_entry(S, l1tmp, a.l1cap, min((uint32_t)q * SORT_BLOCK + tid, n - 1));
+          if ((uint32_t)q * SORT_BLOCK < n) mine[q] = S.region[min((uint32_t)q * SORT_BLOCK + tid, n - 1)];  // (n <= BIN_CAP: all in the region)
 #pragma unroll
         for (int q = 0; q < PER; ++q)
           if ((uint32_t)q * SORT_BLOCK + tid < n) atomicAdd(&s_cur[sub_bin(mine[q].x, sm)], 1u);
@@ -966,7 +957,7 @@ __device__ __forceinline__ void bucket_sort_body(const BinArgs &a, void *geom, v
       for (uint32_t e0 = 0; e0 < n; e0 += 8 * SORT_BLOCK) {
         uint32_t kk[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) kk[q] = seg_key(S, l1tmp, a.l1cap, min(e0 + q * SORT_BLOCK + tid, n - 1));
+        for (int q = 0; q < 8; ++q) kk[q] = bucket_key(S, min(e0 + q * SORT_BLOCK + tid, n - 1));
 #pragma unroll
         for (int q = 0; q < 8; ++q)
           if (e0 + q * SORT_BLOCK + tid < n) atomicAdd(&s_cur[sub_bin(kk[q], sm)], 1u);
@@ -986,7 +977,7 @@ __device__ __forceinline__ void bucket_sort_body(const BinArgs &a, void *geom, v
     tr.mark();
     const uint32_t n_gcnt = (uint32_t)(BIN_CAP / GRP) << (2 * a.gi.ss_shift);  // (group, tile) counters of a run
     if (!skip && !is_slice && in_lds) {
-      // (the segment table has been consumed: its LDS becomes the (group, tile) counters of the run)
+      // (the (group, tile) counters of the run)
       for (uint32_t q = tid; q < n_gcnt; q += SORT_BLOCK) s_seg[q] = 0u;
 #pragma unroll
       for (int q = 0; q < PER; ++q)
@@ -1026,7 +1017,7 @@ __device__ __forceinline__ void bucket_sort_body(const BinArgs &a, void *geom, v
         for (uint32_t e0 = 0; e0 < n; e0 += 8 * SORT_BLOCK) {  // the bucket once more: the slice's entries stay
           uint4 kv[8];
 #pragma unroll
-          for (int q = 0; q < 8; ++q) kv[q] = seg_entry(S, l1tmp, a.l1cap, min(e0 + q * SORT_BLOCK + tid, n - 1));
+          for (int q = 0; q < 8; ++q) kv[q] = bucket_entry(S, min(e0 + q * SORT_BLOCK + tid, n - 1));
 #pragma unroll
           for (int q = 0; q < 8; ++q) {
             const uint32_t f = sub_bin(kv[q].x, sm), sbn = s_start[f];
@@ -1037,14 +1028,11 @@ __device__ __forceinline__ void bucket_sort_body(const BinArgs &a, void *geom, v
           }
         }
         lds_barrier();
-        // (a slice reads the segment table twice: its counters are cleared here)
+        // (a slice reads the bucket -- through its overflow records, if any -- twice: the counters are cleared here)
         for (uint32_t q = tid; q < n_gcnt; q += SORT_BLOCK) s_seg[q] = 0u;
         lds_barrier();
       }
     }
-    // ... and, its words having arrived behind all these barriers, the next item's segment record (it has the ranking to
-    // arrive in)
-    nxt.rec = tn < n_items && seg_regs && tid < a.nwg1 ? segs[(size_t)(nxt.w & 0xffffu) * a.nwg1 + tid] : make_uint2(0u, 0u);
     if (skip) {
       // nothing
     } else if (in_lds) {
@@ -1063,7 +1051,7 @@ __device__ __forceinline__ void bucket_sort_body(const BinArgs &a, void *geom, v
       // hundreds of entries at nearly one depth (or an oversized bucket the slice list had no room for): the byte
       // passes, by ONE workgroup -- the bucket's, or its slice 0 -- over the whole bucket as one run
       __syncthreads();
-      radix_fallback(S, l1tmp, a.l1cap, l1a + base, l1b + base, l1list + base, rect, n, reserved, s_run, s_cnt);
+      radix_fallback(S, l1a + base, l1b + base, l1list + base, rect, n, reserved, s_run, s_cnt);
       count_run_global_any(a.gi.ss_shift, l1list + base, reserved, base / GRP, U, s_unit, true);
     } else {
       zero_unit_row(U);  // (a further slice of such a bucket)
@@ -1137,7 +1125,7 @@ __device__ __forceinline__ void level2_fill_body(const BinArgs &a, void *geom, v
     // ... and the bucket totals, so that the chain can run again on the same projection (preprocess clears them too)
     uint32_t *bk = at<uint32_t>(geom, a.g_bk);
     for (int t = tid; t < 2 * MAX_BUCKETS; t += SORT_BLOCK) bk[BK_TOT + t] = 0u;
-    if (tid == 0) bk[BK_DONE] = 0u;
+    if (tid == 0) bk[BK_DONE] = 0u, bk[BK_OVF] = 0u;
     uint32_t run = my_first;
     int ovf = total_w[1] != 0u;
     for (int q = 0; q < K; ++q) {
@@ -1263,7 +1251,7 @@ static unsigned bucket_grid(unsigned nbuckets, int n_renders) {
   return g < 32u ? 32u : g;
 }
 static size_t sort_lds_bytes(const BinArgs &a) {
-  const size_t table = 2 * (size_t)a.nwg1 + 1, counters = (size_t)(BIN_CAP / GRP) << (2 * a.gi.ss_shift);
+  const size_t table = 3 * (size_t)a.nwg1, counters = (size_t)(BIN_CAP / GRP) << (2 * a.gi.ss_shift);
   return (table > counters ? table : counters) * sizeof(uint32_t);
 }
 static size_t level1_code_bytes(int per) { return (size_t)per * BIG_ENTRIES * SORT_BLOCK * sizeof(uint32_t); }
@@ -1288,7 +1276,7 @@ static bool make_args(int N, int H, int W, int64_t R_cap, int n_renders, const G
   a.l1cap = B.l1cap;
   a.sort_grid = (int)bucket_grid((unsigned)(a.gi.NS << a.lg), n_renders);
   a.g_total = G.total, a.g_rect = G.rect, a.g_tiles = G.tiles, a.g_offsets = G.offsets, a.g_sums = G.block_sums;
-  a.g_key32 = G.key32, a.g_bk = G.bk, a.g_segs = G.segs, a.g_work = G.work;
+  a.g_key32 = G.key32, a.g_bk = G.bk, a.g_segs = G.segs, a.g_work = G.work, a.g_wgob = G.wgob;
   a.b_meta = B.meta, a.b_l1tmp = B.l1tmp, a.b_l1a = B.l1a, a.b_l1b = B.l1b, a.b_l1 = B.l1list;
   a.b_grpbase = B.grpbase, a.b_grpinfo = B.grpinfo, a.b_cntu = B.cntu;
   a.b_totals = B.totals, a.b_ranges = B.ranges, a.b_work = B.work, a.b_vals = B.vals_b;

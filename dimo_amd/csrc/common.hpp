@@ -92,15 +92,18 @@ constexpr int MAX_SLICES = 256;                                          // slic
 constexpr size_t BK_KMIN = 0, BK_SHIFT = 1, BK_KMIN0 = 2, BK_NBLOG = 3;  // bin map: origin, log2 bin width, smallest key, log2 bins
 constexpr size_t BK_NITEMS = 4;                                          // items of bucket_sort's work list
 constexpr size_t BK_DONE = 5;                                            // level-1 workgroups that have added their entries
+constexpr size_t BK_OVF = 6;                                             // cursor of the unsorted level-1 array's overflow area
+constexpr int BUCKET_REGION = 4096;  // slots of a bucket's own region in the unsorted level-1 array
 constexpr int WORK_QUEUES = 16;
 constexpr size_t BK_WORK = 8;                                            // [WORK_QUEUES] ticket counters of the work list
-// [MAX_BUCKETS] 64-bit words: entries of the bucket (low half) | segments listed for it (high half), summed by ONE
-// returning atomic per (level-1 workgroup, bucket it touches)
+// [MAX_BUCKETS] 64-bit words: entries of the bucket (low half: summed by ONE returning atomic per (level-1 workgroup,
+// bucket it touches) -- what it returns is the workgroup's first place in the bucket) | overflow records listed for it
+// (high half)
 constexpr size_t BK_TOT = 24;
 constexpr size_t BK_WORDS = BK_TOT + 2 * MAX_BUCKETS;
 
 struct GeomLayout {
-  size_t splat, rect, tiles, offsets, flags, total, block_sums, key32, bk, segs, work;
+  size_t splat, rect, tiles, offsets, flags, total, block_sums, key32, bk, segs, work, wgob;
   size_t bytes;
   int nb, per, nwg1;  // preprocess blocks; blocks per level-1 workgroup; level-1 workgroups
   __host__ explicit GeomLayout(int N) {
@@ -119,13 +122,16 @@ struct GeomLayout {
     block_sums = o, o = align_up(o + 4 * ((size_t)nb + 1) * sizeof(uint32_t));
     key32 = o, o = align_up(o + n * sizeof(uint32_t));  // depth bits, 0xffffffff for a Gaussian without tiles
     bk = o, o = align_up(o + BK_WORDS * sizeof(uint32_t));
-    // segs[bucket][slot]: (first entry in the unsorted level-1 array, entries) of every level-1 workgroup that has
-    // entries in the bucket -- `slot` from the bucket's atomic, row stride = the launch's level-1 workgroups (<= nwg1);
-    // only the listed slots are written and read
-    segs = o, o = align_up(o + (size_t)MAX_BUCKETS * nwg1 * 2 * sizeof(uint32_t));
+    // segs[bucket][slot]: (first overflow slot, first place, places, 0) of every level-1 workgroup whose share of the
+    // bucket reaches beyond the bucket's region -- `slot` from the bucket's atomic, row stride = the launch's level-1
+    // workgroups (<= nwg1); only the listed slots are written and read
+    segs = o, o = align_up(o + (size_t)MAX_BUCKETS * nwg1 * 4 * sizeof(uint32_t));
     // bucket_sort's work list = the sorted level-1 array's layout (binning.hip: layout_buckets): eight words per
     // slice and per bucket sorted whole
     work = o, o = align_up(o + (size_t)(MAX_BUCKETS + MAX_SLICES) * 8 * sizeof(uint32_t));
+    // wgob[level-1 workgroup][bucket]: where the workgroup's places beyond the bucket's region go in the overflow area
+    // (only the words of such buckets are written and read)
+    wgob = o, o = align_up(o + (size_t)nwg1 * MAX_BUCKETS * sizeof(uint32_t));
     bytes = o;
   }
 };
@@ -146,11 +152,12 @@ struct BinLayout {
     ranges = o, o = align_up(o + (size_t)T * 2 * sizeof(uint32_t));
     totals = o, o = align_up(o + (size_t)T * sizeof(uint32_t));  // instances per tile (atomically summed)
     // level 1 (binning.hip): at most one entry per instance.  l1tmp: the 16-byte entries (depth bits, id, tile
-    // rectangle) as the level-1 workgroups leave them, a contiguous segment per workgroup; l1a / l1b: 64-bit scratch of
+    // rectangle) as the level-1 workgroups leave them: a region of BUCKET_REGION slots per bucket -- address space
+    // more than memory: a bucket touches what it holds --, then an overflow area; l1a / l1b: 64-bit scratch of
     // the byte-wise fallback sort; l1list: the sorted entries (id, depth bits, tile rectangle), bucket by bucket, every
     // bucket (and every slice of a cut bucket) rounded up to whole groups of 64 -- hence the slack
     l1cap = (cap + 255) / 256 * 256 + 64 * (size_t)(MAX_BUCKETS + 2 * MAX_SLICES);
-    l1tmp = o, o = align_up(o + l1cap * 4 * sizeof(uint32_t));
+    l1tmp = o, o = align_up(o + ((size_t)MAX_BUCKETS * BUCKET_REGION + l1cap) * 4 * sizeof(uint32_t));
     l1a = o, o = align_up(o + l1cap * sizeof(uint64_t));
     l1b = o, o = align_up(o + l1cap * sizeof(uint64_t));
     l1list = o, o = align_up(o + l1cap * 4 * sizeof(uint32_t));

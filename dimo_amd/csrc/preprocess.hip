@@ -25,7 +25,7 @@ __device__ __forceinline__ void preprocess_fwd_body(
   // the level-1 kernel that adds to them (binning.hip)
   if (blockIdx.x == 0) {
     for (int t = threadIdx.x; t < 2 * MAX_BUCKETS; t += PRE_BLOCK) bk[BK_TOT + t] = 0u;  // (64-bit words)
-    if (threadIdx.x == 0) bk[BK_DONE] = 0u;  // (level-1 workgroups that have added their entries)
+    if (threadIdx.x == 0) bk[BK_DONE] = 0u, bk[BK_OVF] = 0u;  // (level-1 workgroups done; overflow cursor)
   }
   // camera: uniform loads (scalar cache)
   float V[16], P[16], cam[3];
