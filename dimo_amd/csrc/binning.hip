@@ -1069,6 +1069,20 @@ __device__ __forceinline__ void bucket_sort_body(const BinArgs &a, void *geom, v
 // template parameter, every entry forms the bit mask of the supertile's tiles its rectangle covers once, and the
 // per-tile loop is unrolled over the mask bits: one ballot, one v_readlane, mbcnt and ONE store per tile.
 // Lane j of every wave owns tile j of the supertile: its next free slot.
+// One tile of the fill's ordered filter, by hand: the entries of the wave that cover tile J of the supertile (bit JB of
+// `mhalf`, the 32-bit half of their masks that holds it) take consecutive slots from lane J's counter `c`, in lane
+// order, and store their Gaussian id -- 11 instructions (the compiler's version of the same loop body: 23, it forms
+// the predicate twice, builds a 64-bit address and compares every slot with the capacity; the caller takes this path
+// only when the render's instances fit the capacity).  `vals`: SGPR pair; the byte offset of a slot fits 32 bits.
+template <int J>
+__device__ __forceinline__ void place_tile(uint32_t mhalf, uint32_t c, uint32_t id, uint32_t *vals) {
+  constexpr int JB = J & 31;
+  uint32_t t;
+  u64 save;
+  uint32_t first;
+  asm volatile("v_bfe_u32 %[t], %[m], %[jb], 1\n\tv_cmp_ne_u32_e32 vcc, 0, %[t]\n\ts_cbranch_vccz L_place_tile_%=\n\ts_nop 0\n\ts_mov_b64 %[sv], exec\n\tv_mbcnt_lo_u32_b32 %[t], vcc_lo, 0\n\tv_readlane_b32 %[sf], %[c], %[j]\n\tv_mbcnt_hi_u32_b32 %[t], vcc_hi, %[t]\n\ts_mov_b64 exec, vcc\n\tv_add_lshl_u32 %[t], %[sf], %[t], 2\n\tglobal_store_dword %[t], %[id], %[base]\n\ts_mov_b64 exec, %[sv]\nL_place_tile_%=:" : [t] "=&v"(t), [sv] "=&s"(save), [sf] "=&s"(first) : [m] "v"(mhalf), [c] "v"(c), [id] "v"(id), [base] "s"(vals), [jb] "n"(JB), [j] "n"(J) : "vcc", "memory");
+}
+
 template <int SSH>
 __device__ __forceinline__ void level2_fill_body(const BinArgs &a, void *geom, void *bin, uint8_t *__restrict__ grad_flags,
                                                  uint32_t *__restrict__ totals_out, uint32_t *s_ts, uint32_t *s_wt) {
@@ -1093,6 +1107,7 @@ __device__ __forceinline__ void level2_fill_body(const BinArgs &a, void *geom, v
   uint32_t info_n = g < max_groups ? grpinfo[g] : 0u;
   const uint32_t n_grp = meta[META_NGRP];
   const uint32_t R = total[0];
+  const bool fits = R <= a.R_cap;
   // exclusive scan of the tile totals, by every workgroup itself -- thread t owns tiles [t K, (t + 1) K)
   const int K = (a.T + SORT_BLOCK - 1) / SORT_BLOCK;
   uint32_t my_first = 0;  // instances before this thread's tiles
@@ -1169,14 +1184,22 @@ __device__ __forceinline__ void level2_fill_body(const BinArgs &a, void *geom, v
       for (int r = 0; r < 8; ++r) c += v[r];
     }
     if (my_in) c += s_ts[my_ty * tiles_x + my_tx];
+    if (fits) {  // (uniform: every instance has a slot)
+      const uint32_t mlo = (uint32_t)mask, mhi = (uint32_t)(mask >> 32);
+      static_for<0, ntile>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        place_tile<j>(j < 32 ? mlo : mhi, c, en.x, vals);
+      });
+    } else {
 #pragma unroll
-    for (int j = 0; j < ntile; ++j) {
-      const bool cov = (mask >> j) & 1ull;
-      const u64 bal = __ballot(cov);
-      if (bal == 0) continue;
-      const uint32_t first = (uint32_t)__builtin_amdgcn_readlane((int)c, j);
-      const uint32_t pos = first + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-      if (cov && pos < a.R_cap) vals[pos] = en.x;
+      for (int j = 0; j < ntile; ++j) {
+        const bool cov = (mask >> j) & 1ull;
+        const u64 bal = __ballot(cov);
+        if (bal == 0) continue;
+        const uint32_t first = (uint32_t)__builtin_amdgcn_readlane((int)c, j);
+        const uint32_t pos = first + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+        if (cov && pos < a.R_cap) vals[pos] = en.x;
+      }
     }
   }
   if (blockIdx.x == 0) {
@@ -1242,11 +1265,12 @@ __global__ void __launch_bounds__(256) depth_keys_kernel(uint32_t R_cap, const u
 }
 
 // ------------------------------------------------------------------------------------ host side
-// bucket_sort: persistent workgroups that take the render's work list item by item; sized so that the renders of a
-// launch fit the chip in one round (51 KB of LDS: 3 workgroups per CU), at least 32 per render
+// bucket_sort: persistent workgroups that take the render's work list item by item.  768 of them fit the chip at once
+// (43 KB of LDS: 3 per CU) and give the shortest launch when it has the chip to itself (42 us per 8 renders against 48
+// with 640); in the step, where the other motion's kernels run beside it, 640 measured 0.4 % more frames/s in four
+// interleaved pairs (the launch leaves them a sixth of the LDS).  At least 32 per render.
 static unsigned bucket_grid(unsigned nbuckets, int n_renders) {
-  static const unsigned slots = getenv("DIMO_SORT_SLOTS") ? (unsigned)atoi(getenv("DIMO_SORT_SLOTS")) : 768u;  // EXPERIMENT
-  const unsigned room = (unsigned)(slots / (n_renders > 0 ? n_renders : 1));
+  const unsigned room = (unsigned)(640 / (n_renders > 0 ? n_renders : 1));
   unsigned g = room < nbuckets ? room : nbuckets;
   return g < 32u ? 32u : g;
 }

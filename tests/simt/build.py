@@ -15,12 +15,22 @@ CSRC = os.path.join(ROOT, "dimo_amd", "csrc")
 OUT = os.path.join(HERE, "_build")
 LIB = os.path.join(OUT, "libbinning_emu.so")
 
+def _place_tile_asm():
+    text = open(os.path.join(CSRC, "binning.hip")).read()
+    i = text.index('asm volatile("v_bfe_u32 %[t], %[m], %[jb], 1')
+    j = text.index('"memory");', i) + len('"memory");')
+    return text[i:j]
+
+
+PLACE_TILE_ASM = _place_tile_asm()
 SUBST = {
     "common.hpp": [
         ('asm volatile("s_waitcnt lgkmcnt(0)\\n\\ts_barrier" ::: "memory");', "__syncthreads();"),
     ],
     "binning.hip": [
         ('asm("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(sval), "n"(J));', "v = simt_writelane(v, sval, J);"),
+        # place_tile: the whole statement, up to its closing parenthesis
+        (PLACE_TILE_ASM, "(void)t, (void)save, (void)first; simt_place_tile(mhalf, JB, J, c, id, vals);"),
     ],
 }
 

@@ -109,6 +109,17 @@ static inline uint32_t simt_mbcnt_hi(uint32_t mask, uint32_t base) {
 }
 // v[lane J] = sval (sval is wave-uniform: the SGPR operand of v_writelane_b32)
 static inline uint32_t simt_writelane(uint32_t v, uint32_t sval, int J) { return simt::lane_id() == J ? sval : v; }
+// the fill's hand-written tile step (binning.hip: place_tile): lanes whose mask half has bit jb set take consecutive
+// slots from lane j's counter, in lane order, and store their id
+static inline void simt_place_tile(uint32_t mhalf, int jb, int j, uint32_t c, uint32_t id, uint32_t *vals) {
+  const bool cov = (mhalf >> jb) & 1u;
+  const unsigned long long bal = __ballot(cov);
+  if (bal == 0) return;
+  const uint32_t first = (uint32_t)simt_readlane((int)c, j);
+  const int l = simt::lane_id();
+  const uint32_t pos = first + (uint32_t)__builtin_popcountll(l ? (bal & (~0ull >> (64 - l))) : 0ull);
+  if (cov) vals[pos] = id;
+}
 #define __builtin_amdgcn_readlane simt_readlane
 #define __builtin_amdgcn_mbcnt_lo simt_mbcnt_lo
 #define __builtin_amdgcn_mbcnt_hi simt_mbcnt_hi
