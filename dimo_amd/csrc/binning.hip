@@ -644,6 +644,24 @@ __device__ __forceinline__ uint32_t group_counts(u64 mask) {
   return c;
 }
 
+// A SORTED level-1 entry is what the fill needs of it: the Gaussian id and the mask of the supertile's tiles its
+// rectangle covers -- 8 bytes up to 4 x 4 tiles per supertile (a 16-bit mask), 16 bytes for 8 x 8 (the sorted array is
+// allocated for 16).  An empty entry (the padding of a run to whole groups) has mask 0.
+template <int SSH>
+struct Sorted {
+  typedef typename std::conditional<(SSH <= 2), uint2, uint4>::type T;
+  static __device__ __forceinline__ T make(uint32_t id, u64 mask) {
+    if constexpr (SSH <= 2) return make_uint2(id, (uint32_t)mask);
+    else return make_uint4(id, 0u, (uint32_t)mask, (uint32_t)(mask >> 32));
+  }
+  static __device__ __forceinline__ u64 mask(const T &e) {
+    if constexpr (SSH <= 2) return (u64)e.y;
+    else return (u64)e.z | ((u64)e.w << 32);
+  }
+  static __device__ __forceinline__ T *at(void *base, size_t i) { return reinterpret_cast<T *>(base) + i; }
+  static __device__ __forceinline__ const T *at(const void *base, size_t i) { return reinterpret_cast<const T *>(base) + i; }
+};
+
 // what a run of sorted entries (a bucket, or a slice of one) tells level 2
 struct Unit {
   uint32_t unit, info;  // row of per-tile totals; the word every group of the run carries: unit | first unit of the supertile << 12 | supertile << 24
@@ -658,27 +676,25 @@ struct UnitShared {
 // the byte-pass fallback and the filler behind a cut bucket's last slice): wave w takes the groups [w gpw, (w + 1) gpw),
 // two passes, the totals first.
 template <int SSH>
-__device__ __forceinline__ void count_run_global(const uint4 *out, uint32_t len, uint32_t g0, const Unit &U, UnitShared &sh,
+__device__ __forceinline__ void count_run_global(const void *l1list, size_t first, uint32_t len, const Unit &U, UnitShared &sh,
                                                  bool with_unit_row) {
   constexpr int ss = 1 << SSH, ntile = ss * ss;
+  const typename Sorted<SSH>::T *out = Sorted<SSH>::at(l1list, first);
+  const uint32_t g0 = (uint32_t)(first / GRP);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint32_t ng = len / GRP, gpw = (ng + 3) / 4;
   const uint32_t ga = min((uint32_t)wave * gpw, ng), gb = min(ga + gpw, ng);
   uint32_t run = 0;
-  for (uint32_t g = ga; g < gb; ++g) {
-    const uint4 en = out[(size_t)g * GRP + lane];
-    run += group_counts<SSH>(tile_mask<SSH>(en.z, en.w, U.tx0, U.ty0));
-  }
+  for (uint32_t g = ga; g < gb; ++g) run += group_counts<SSH>(Sorted<SSH>::mask(out[(size_t)g * GRP + lane]));
   sh.wtot[wave][lane] = run;
   lds_barrier();
   uint32_t base = 0;
   for (int w = 0; w < wave; ++w) base += sh.wtot[w][lane];
   uint32_t acc = base;
   for (uint32_t g = ga; g < gb; ++g) {
-    const uint4 en = out[(size_t)g * GRP + lane];
     U.grpbase[(size_t)(g0 + g) * GRP + lane] = acc;
     if (lane == 0) U.grpinfo[g0 + g] = U.info;
-    acc += group_counts<SSH>(tile_mask<SSH>(en.z, en.w, U.tx0, U.ty0));
+    acc += group_counts<SSH>(Sorted<SSH>::mask(out[(size_t)g * GRP + lane]));
   }
   if (with_unit_row && wave == SORT_BLOCK / 64 - 1) {
     const uint32_t tot = base + run;
@@ -688,25 +704,27 @@ __device__ __forceinline__ void count_run_global(const uint4 *out, uint32_t len,
   }
   lds_barrier();
 }
-__device__ __forceinline__ void count_run_global_any(int ssh, const uint4 *out, uint32_t len, uint32_t g0, const Unit &U,
+__device__ __forceinline__ void count_run_global_any(int ssh, const void *l1list, size_t first, uint32_t len, const Unit &U,
                                                      UnitShared &sh, bool with_unit_row) {
   switch (ssh) {
-    case 0: count_run_global<0>(out, len, g0, U, sh, with_unit_row); break;
-    case 1: count_run_global<1>(out, len, g0, U, sh, with_unit_row); break;
-    case 2: count_run_global<2>(out, len, g0, U, sh, with_unit_row); break;
-    default: count_run_global<3>(out, len, g0, U, sh, with_unit_row); break;
+    case 0: count_run_global<0>(l1list, first, len, U, sh, with_unit_row); break;
+    case 1: count_run_global<1>(l1list, first, len, U, sh, with_unit_row); break;
+    case 2: count_run_global<2>(l1list, first, len, U, sh, with_unit_row); break;
+    default: count_run_global<3>(l1list, first, len, U, sh, with_unit_row); break;
+  }
+}
+// `len` empty entries from entry `first` on
+__device__ __forceinline__ void clear_sorted(int ssh, void *l1list, size_t first, uint32_t len) {
+  if (ssh <= 2) {
+    for (uint32_t e = threadIdx.x; e < len; e += SORT_BLOCK) *Sorted<0>::at(l1list, first + e) = make_uint2(0u, 0u);
+  } else {
+    for (uint32_t e = threadIdx.x; e < len; e += SORT_BLOCK) *Sorted<3>::at(l1list, first + e) = make_uint4(0u, 0u, 0u, 0u);
   }
 }
 // a row of zeros for a unit without entries of its own (a slice with an empty share, the slices of a bucket that went
 // to the byte passes as a whole)
 __device__ __forceinline__ void zero_unit_row(const Unit &U) {
   if (threadIdx.x < GRP) U.cntu[(size_t)U.unit * GRP + threadIdx.x] = 0u;
-}
-
-__device__ __forceinline__ uint4 entry_of(u64 word, const uint16_t *__restrict__ rect) {
-  const uint32_t id = (uint32_t)word;
-  const uint2 rc = *reinterpret_cast<const uint2 *>(rect + 4 * (size_t)id);
-  return make_uint4(id, (uint32_t)(word >> 32), rc.x, rc.y);
 }
 
 // The unsorted entries of a bucket, as one array of n entries: the first BUCKET_REGION of them in the bucket's own
@@ -740,9 +758,25 @@ __device__ __forceinline__ const uint4 *bucket_entry_ptr(const BucketSrc &B, uin
 __device__ __forceinline__ uint4 bucket_entry(const BucketSrc &B, uint32_t e) { return *bucket_entry_ptr(B, e); }
 __device__ __forceinline__ uint32_t bucket_key(const BucketSrc &B, uint32_t e) { return bucket_entry_ptr(B, e)->x; }
 
-// the bucket's words go to la[0, n): eight byte passes a -> b -> ... -> a, then the entries (and `pad` empty ones)
-__device__ __forceinline__ void radix_fallback(const BucketSrc &S, u64 *la, u64 *lb, uint4 *out, const uint16_t *rect,
-                                               uint32_t n, uint32_t len, uint32_t *s_run, uint32_t (*s_cnt)[256]) {
+// the bucket's words go to la[0, n): eight byte passes a -> b -> ... -> a, then the sorted entries (the rectangle by id:
+// a gather, on this path only) and `len - n` empty ones
+template <int SSH>
+__device__ __forceinline__ void emit_sorted_words(const u64 *la, void *l1list, size_t first, const uint16_t *rect, uint32_t n,
+                                                  uint32_t len, const Unit &U) {
+  for (uint32_t e = threadIdx.x; e < len; e += SORT_BLOCK) {
+    u64 mask = 0;
+    uint32_t id = 0;
+    if (e < n) {
+      id = (uint32_t)la[e];
+      const uint2 rc = *reinterpret_cast<const uint2 *>(rect + 4 * (size_t)id);
+      mask = tile_mask<SSH>(rc.x, rc.y, U.tx0, U.ty0);
+    }
+    *Sorted<SSH>::at(l1list, first + e) = Sorted<SSH>::make(id, mask);
+  }
+}
+__device__ __forceinline__ void radix_fallback(const BucketSrc &S, u64 *la, u64 *lb, void *l1list, size_t first, int ssh,
+                                               const Unit &U, const uint16_t *rect, uint32_t n, uint32_t len, uint32_t *s_run,
+                                               uint32_t (*s_cnt)[256]) {
   for (uint32_t e = threadIdx.x; e < n; e += SORT_BLOCK) {
     const uint4 en = bucket_entry(S, e);
     la[e] = ((u64)en.x << 32) | (u64)en.y;
@@ -754,7 +788,12 @@ __device__ __forceinline__ void radix_fallback(const BucketSrc &S, u64 *la, u64 
   }
   __threadfence_block();
   __syncthreads();
-  for (uint32_t e = threadIdx.x; e < len; e += SORT_BLOCK) out[e] = e < n ? entry_of(la[e], rect) : make_uint4(0u, 0u, 0u, 0u);
+  switch (ssh) {
+    case 0: emit_sorted_words<0>(la, l1list, first, rect, n, len, U); break;
+    case 1: emit_sorted_words<1>(la, l1list, first, rect, n, len, U); break;
+    case 2: emit_sorted_words<2>(la, l1list, first, rect, n, len, U); break;
+    default: emit_sorted_words<3>(la, l1list, first, rect, n, len, U); break;
+  }
   __threadfence_block();
   __syncthreads();
 }
@@ -794,9 +833,11 @@ __device__ __forceinline__ bool scan_sub_bins(uint32_t *s_cur, uint32_t *s_start
 // rows, the unit row and the tile totals.
 template <int SSH>
 __device__ __forceinline__ void rank_store_count(const u64 *s_k, const uint2 *s_r, const uint32_t *s_start, uint32_t origin,
-                                                 uint32_t m, uint32_t len, const SubMap &sm, uint4 *__restrict__ out,
-                                                 uint32_t g0, const Unit &U, uint32_t *s_gcnt, BinTrace &tr) {
+                                                 uint32_t m, uint32_t len, const SubMap &sm, void *l1list, size_t first_out,
+                                                 const Unit &U, uint32_t *s_gcnt, BinTrace &tr) {
   constexpr int ss = 1 << SSH, ntile = ss * ss;
+  typename Sorted<SSH>::T *__restrict__ out = Sorted<SSH>::at(l1list, first_out);
+  const uint32_t g0 = (uint32_t)(first_out / GRP);
 #pragma unroll
   for (int q = 0; q < PER; ++q) {
     const uint32_t e = (uint32_t)q * SORT_BLOCK + threadIdx.x;
@@ -814,16 +855,17 @@ __device__ __forceinline__ void rank_store_count(const u64 *s_k, const uint2 *s_
         for (int u = 0; u < 8; ++u) r += (t + u < hi && v[u] < c) ? 1u : 0u;
       }
       const uint32_t p = lo + r;
-      out[p] = make_uint4((uint32_t)c, (uint32_t)(c >> 32), rc.x, rc.y);
+      const u64 mask = tile_mask<SSH>(rc.x, rc.y, U.tx0, U.ty0);
+      out[p] = Sorted<SSH>::make((uint32_t)c, mask);
       uint32_t *cnt = s_gcnt + (p / GRP) * ntile;
       if (ntile <= 32) {
-        for (uint32_t mk = (uint32_t)tile_mask<SSH>(rc.x, rc.y, U.tx0, U.ty0); mk; mk &= mk - 1u) atomicAdd(&cnt[__ffs((int)mk) - 1], 1u);
+        for (uint32_t mk = (uint32_t)mask; mk; mk &= mk - 1u) atomicAdd(&cnt[__ffs((int)mk) - 1], 1u);
       } else {
-        for (u64 mk = tile_mask<SSH>(rc.x, rc.y, U.tx0, U.ty0); mk; mk &= mk - 1ull) atomicAdd(&cnt[__ffsll((long long)mk) - 1], 1u);
+        for (u64 mk = mask; mk; mk &= mk - 1ull) atomicAdd(&cnt[__ffsll((long long)mk) - 1], 1u);
       }
     }
   }
-  for (uint32_t e = m + threadIdx.x; e < len; e += SORT_BLOCK) out[e] = make_uint4(0u, 0u, 0u, 0u);
+  for (uint32_t e = m + threadIdx.x; e < len; e += SORT_BLOCK) out[e] = Sorted<SSH>::make(0u, 0ull);
   lds_barrier();
   tr.mark();
   const uint32_t ng = len / GRP;
@@ -849,13 +891,13 @@ __device__ __forceinline__ void rank_store_count(const u64 *s_k, const uint2 *s_
   }
 }
 __device__ __forceinline__ void rank_store_count_any(int ssh, const u64 *s_k, const uint2 *s_r, const uint32_t *s_start,
-                                                     uint32_t origin, uint32_t m, uint32_t len, const SubMap &sm, uint4 *out,
-                                                     uint32_t g0, const Unit &U, uint32_t *s_gcnt, BinTrace &tr) {
+                                                     uint32_t origin, uint32_t m, uint32_t len, const SubMap &sm, void *l1list,
+                                                     size_t first_out, const Unit &U, uint32_t *s_gcnt, BinTrace &tr) {
   switch (ssh) {  // (uniform)
-    case 0: rank_store_count<0>(s_k, s_r, s_start, origin, m, len, sm, out, g0, U, s_gcnt, tr); break;
-    case 1: rank_store_count<1>(s_k, s_r, s_start, origin, m, len, sm, out, g0, U, s_gcnt, tr); break;
-    case 2: rank_store_count<2>(s_k, s_r, s_start, origin, m, len, sm, out, g0, U, s_gcnt, tr); break;
-    default: rank_store_count<3>(s_k, s_r, s_start, origin, m, len, sm, out, g0, U, s_gcnt, tr); break;
+    case 0: rank_store_count<0>(s_k, s_r, s_start, origin, m, len, sm, l1list, first_out, U, s_gcnt, tr); break;
+    case 1: rank_store_count<1>(s_k, s_r, s_start, origin, m, len, sm, l1list, first_out, U, s_gcnt, tr); break;
+    case 2: rank_store_count<2>(s_k, s_r, s_start, origin, m, len, sm, l1list, first_out, U, s_gcnt, tr); break;
+    default: rank_store_count<3>(s_k, s_r, s_start, origin, m, len, sm, l1list, first_out, U, s_gcnt, tr); break;
   }
 }
 
@@ -888,7 +930,7 @@ __device__ __forceinline__ void bucket_sort_body(const BinArgs &a, void *geom, v
   const uint4 *__restrict__ l1tmp = at<uint4>(bin, a.b_l1tmp);
   u64 *__restrict__ l1a = at<u64>(bin, a.b_l1a);
   u64 *__restrict__ l1b = at<u64>(bin, a.b_l1b);
-  uint4 *__restrict__ l1list = at<uint4>(bin, a.b_l1);
+  void *l1list = at<char>(bin, a.b_l1);  // (sorted entries: Sorted<ss_shift>::T)
   const int tid = threadIdx.x;
   const int nbins = 1 << a.lg;
   BinTrace tr(3);
@@ -1037,22 +1079,21 @@ __device__ __forceinline__ void bucket_sort_body(const BinArgs &a, void *geom, v
       // nothing
     } else if (in_lds) {
       if (m > 0u)
-        rank_store_count_any(a.gi.ss_shift, s_k, s_r, s_start, first, m, len, sm, l1list + base + run_off, (base + run_off) / GRP, U,
-                             s_seg, tr);
+        rank_store_count_any(a.gi.ss_shift, s_k, s_r, s_start, first, m, len, sm, l1list, (size_t)base + run_off, U, s_seg, tr);
       else
         zero_unit_row(U);
       if (is_slice && j == J - 1 && used < reserved) {  // what the bucket reserved beyond its slices' runs: empty entries, empty rows
-        for (uint32_t e = used + tid; e < reserved; e += SORT_BLOCK) l1list[base + e] = make_uint4(0u, 0u, 0u, 0u);
+        clear_sorted(a.gi.ss_shift, l1list, (size_t)base + used, reserved - used);
         __threadfence_block();
         __syncthreads();
-        count_run_global_any(a.gi.ss_shift, l1list + base + used, reserved - used, (base + used) / GRP, U, s_unit, false);
+        count_run_global_any(a.gi.ss_shift, l1list, (size_t)base + used, reserved - used, U, s_unit, false);
       }
     } else if (!is_slice || j == 0u) {
       // hundreds of entries at nearly one depth (or an oversized bucket the slice list had no room for): the byte
       // passes, by ONE workgroup -- the bucket's, or its slice 0 -- over the whole bucket as one run
       __syncthreads();
-      radix_fallback(S, l1a + base, l1b + base, l1list + base, rect, n, reserved, s_run, s_cnt);
-      count_run_global_any(a.gi.ss_shift, l1list + base, reserved, base / GRP, U, s_unit, true);
+      radix_fallback(S, l1a + base, l1b + base, l1list, (size_t)base, a.gi.ss_shift, U, rect, n, reserved, s_run, s_cnt);
+      count_run_global_any(a.gi.ss_shift, l1list, (size_t)base, reserved, U, s_unit, true);
     } else {
       zero_unit_row(U);  // (a further slice of such a bucket)
     }
@@ -1088,7 +1129,7 @@ __device__ __forceinline__ void level2_fill_body(const BinArgs &a, void *geom, v
                                                  uint32_t *__restrict__ totals_out, uint32_t *s_ts, uint32_t *s_wt) {
   constexpr int ss = 1 << SSH, ntile = ss * ss;
   const uint32_t *__restrict__ meta = at<uint32_t>(bin, a.b_meta);
-  const uint4 *__restrict__ l1list = at<uint4>(bin, a.b_l1);
+  const typename Sorted<SSH>::T *__restrict__ l1list = Sorted<SSH>::at(at<char>(bin, a.b_l1), 0);
   const uint32_t *__restrict__ grpbase = at<uint32_t>(bin, a.b_grpbase);
   const uint32_t *__restrict__ grpinfo = at<uint32_t>(bin, a.b_grpinfo);
   const uint32_t *__restrict__ cntu = at<uint32_t>(bin, a.b_cntu);
@@ -1098,14 +1139,18 @@ __device__ __forceinline__ void level2_fill_body(const BinArgs &a, void *geom, v
   const int tiles_x = a.gi.tiles_x, tiles_y = a.gi.tiles_y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   BinTrace tr(5);
-  // the first group's entries and words do not depend on anything: requested together with the group count
-  const uint32_t gstride = gridDim.x * (SORT_BLOCK / 64);
-  uint32_t g = blockIdx.x * (SORT_BLOCK / 64) + wave;
-  const uint32_t max_groups = (uint32_t)(a.l1cap / GRP);
-  uint4 en_n = g < max_groups ? l1list[(size_t)g * GRP + lane] : make_uint4(0u, 0u, 0u, 0u);
-  uint32_t row_n = g < max_groups ? grpbase[(size_t)g * GRP + lane] : 0u;
-  uint32_t info_n = g < max_groups ? grpinfo[g] : 0u;
+  // The groups of a render lie supertile by supertile, and a tile's list is written by the groups of its supertile:
+  // each of the chip's eight XCDs (a workgroup's XCD = its number % 8: the launch's x dimension is a multiple of 8)
+  // takes ONE contiguous eighth of the groups, so that the pieces of a tile's list meet in one L2 and leave it as
+  // whole cache lines.  Inside its XCD's eighth a wave takes every (waves of the XCD)-th group.
   const uint32_t n_grp = meta[META_NGRP];
+  const uint32_t xcd = blockIdx.x & 7u, wg_in_xcd = blockIdx.x >> 3, gstride = (gridDim.x >> 3) * (SORT_BLOCK / 64);
+  const uint32_t per_xcd = (n_grp + 7u) / 8u, g_end = min((xcd + 1u) * per_xcd, n_grp);
+  uint32_t g = xcd * per_xcd + wg_in_xcd * (SORT_BLOCK / 64) + wave;
+  typename Sorted<SSH>::T en_n = Sorted<SSH>::make(0u, 0ull);
+  uint32_t row_n = 0u, info_n = 0u;
+  // (a row's first `ntile` words are all there is: the other lanes do not ask for theirs)
+  if (g < g_end) en_n = l1list[(size_t)g * GRP + lane], row_n = lane < ntile ? grpbase[(size_t)g * GRP + lane] : 0u, info_n = grpinfo[g];
   const uint32_t R = total[0];
   const bool fits = R <= a.R_cap;
   // exclusive scan of the tile totals, by every workgroup itself -- thread t owns tiles [t K, (t + 1) K)
@@ -1158,14 +1203,14 @@ __device__ __forceinline__ void level2_fill_body(const BinArgs &a, void *geom, v
   }
   lds_barrier();  // (the tile starts are complete)
   tr.mark();
-  for (; g < n_grp; g += gstride) {
-    const uint4 en = en_n;
+  for (; g < g_end; g += gstride) {
+    const typename Sorted<SSH>::T en = en_n;
     const uint32_t row = row_n, info = info_n;
     {  // the next group of this wave
       const uint32_t gn = g + gstride;
-      if (gn < n_grp) {
+      if (gn < g_end) {
         en_n = l1list[(size_t)gn * GRP + lane];
-        row_n = grpbase[(size_t)gn * GRP + lane];
+        row_n = lane < ntile ? grpbase[(size_t)gn * GRP + lane] : 0u;
         info_n = grpinfo[gn];
       }
     }
@@ -1173,16 +1218,17 @@ __device__ __forceinline__ void level2_fill_body(const BinArgs &a, void *geom, v
     const int tx0 = (int)((sup % (uint32_t)a.gi.stx) << SSH), ty0 = (int)((sup / (uint32_t)a.gi.stx) << SSH);
     const int my_tx = tx0 + (lane & (ss - 1)), my_ty = ty0 + (lane >> SSH);
     const bool my_in = lane < ntile && my_tx < tiles_x && my_ty < tiles_y;
-    const u64 mask = tile_mask<SSH>(en.z, en.w, tx0, ty0);
+    const u64 mask = Sorted<SSH>::mask(en);
     // lane j: the next free slot of tile j = tile start + the supertile's earlier units + the unit's earlier groups
     uint32_t c = row;
-    for (uint32_t u0 = unit0; u0 < unit; u0 += 8) {
-      uint32_t v[8];
+    if (lane < ntile)
+      for (uint32_t u0 = unit0; u0 < unit; u0 += 8) {
+        uint32_t v[8];
 #pragma unroll
-      for (int r = 0; r < 8; ++r) v[r] = u0 + r < unit ? cntu[(size_t)(u0 + r) * GRP + lane] : 0u;
+        for (int r = 0; r < 8; ++r) v[r] = u0 + r < unit ? cntu[(size_t)(u0 + r) * GRP + lane] : 0u;
 #pragma unroll
-      for (int r = 0; r < 8; ++r) c += v[r];
-    }
+        for (int r = 0; r < 8; ++r) c += v[r];
+      }
     if (my_in) c += s_ts[my_ty * tiles_x + my_tx];
     if (fits) {  // (uniform: every instance has a slot)
       const uint32_t mlo = (uint32_t)mask, mhi = (uint32_t)(mask >> 32);
@@ -1314,7 +1360,8 @@ static bool make_args(int N, int H, int W, int64_t R_cap, int n_renders, const G
 static unsigned level2_grid(int N, int n_renders, int nbuckets) {
   const unsigned want = (unsigned)((4 * (size_t)N) / SORT_BLOCK + nbuckets / 4 + 1);  // ~ one group per wave, were there room
   const unsigned room = (unsigned)(2048 / (n_renders > 0 ? n_renders : 1));
-  return want < room ? want : (room > 64u ? room : 64u);
+  const unsigned g = want < room ? want : (room > 64u ? room : 64u);
+  return (g + 7u) / 8u * 8u;  // (a multiple of 8: the fill deals its groups to the XCDs by workgroup number % 8)
 }
 
 int bin_instances(int N, int H, int W, int64_t R_cap, const void *geom_c, void *bin, hipStream_t stream) {
