@@ -449,7 +449,7 @@ __device__ __forceinline__ void level1_body(const BinArgs &a, void *geom, void *
     carry += s_wt[0] + s_wt[1] + s_wt[2] + s_wt[3];
     if (i < a.N) offsets[i] = off + inc;
     const bool big = v0 != 0u && rect_entries(r0, a.gi) > BIG_ENTRIES;
-    if (big) s_big.push((uint32_t)i, k0, r0), s_anybig = 1u;
+    if (big) s_big.push((uint32_t)i, k0, r0), atomicOr(&s_anybig, 1u << (c - c0));  // (which blocks have big Gaussians)
     for_each_group(v0 != 0u && !big, r0, depth_bin(k0, lo, shift, nbins), a.gi, a.lg, lane,
                    [&](uint32_t bl, u64 m, int leader, bool mine, int it) {
                      uint32_t first = 0;  // the group's ranks: one returning LDS atomic by its leader
@@ -472,7 +472,7 @@ __device__ __forceinline__ void level1_body(const BinArgs &a, void *geom, void *
   // run and no bucket's start has to be known here).  Places beyond the region -- a bucket of more than 4096 entries:
   // thousands of Gaussians of one supertile in one depth bin -- go to a shared overflow area: a slot range from its
   // cursor, and a record (first overflow slot, first place, places) in the bucket's list.
-  const bool any_big = s_anybig != 0u;
+  const uint32_t big_blocks = s_anybig;
   {
     constexpr int OWN = MAX_BUCKETS / SORT_BLOCK;
 #pragma unroll
@@ -505,11 +505,21 @@ __device__ __forceinline__ void level1_body(const BinArgs &a, void *geom, void *
   if (tid == 0) s_last = atomicAdd(&bk[BK_DONE], 1u) == gridDim.x - 1u ? 1u : 0u;
   tr.mark();
   // ---- the entries, to their places: the workgroup's first place in the bucket + the entry's rank
+  {
+    const int i = c0 * PRE_BLOCK + tid;
+    vn = i < a.N ? tiles[i] : 0u, kn = i < a.N ? key32[i] : 0u;
+    rn = i < a.N ? *reinterpret_cast<const uint2 *>(rect + 4 * (size_t)i) : make_uint2(0u, 0u);
+  }
   for (int c = c0; c < c1; ++c) {
     const int i = c * PRE_BLOCK + tid;
     const uint32_t *code = s_code + (size_t)(c - c0) * BIG_ENTRIES * SORT_BLOCK + tid;
-    const uint32_t v = i < a.N ? tiles[i] : 0u, k = i < a.N ? key32[i] : 0u;
-    const uint2 r = i < a.N ? *reinterpret_cast<const uint2 *>(rect + 4 * (size_t)i) : make_uint2(0u, 0u);
+    const uint32_t v = vn, k = kn;
+    const uint2 r = rn;
+    if (c + 1 < c1) {  // the next block's Gaussians, requested before this block is worked on
+      const int i2 = i + PRE_BLOCK;
+      vn = i2 < a.N ? tiles[i2] : 0u, kn = i2 < a.N ? key32[i2] : 0u;
+      rn = i2 < a.N ? *reinterpret_cast<const uint2 *>(rect + 4 * (size_t)i2) : make_uint2(0u, 0u);
+    }
     const int cnt = v != 0u ? rect_entries(r, a.gi) : 0;
     if (cnt <= BIG_ENTRIES) {
       const uint4 en = make_uint4(k, (uint32_t)i, r.x, r.y);
@@ -525,7 +535,7 @@ __device__ __forceinline__ void level1_body(const BinArgs &a, void *geom, void *
           }
         }
     }
-    if (any_big) {  // (workgroup-uniform)
+    if ((big_blocks >> (c - c0)) & 1u) {  // (workgroup-uniform: this block has big Gaussians)
       lds_barrier();  // (the list of the previous block has been read)
       if (tid == 0) s_big.n = 0u;
       lds_barrier();
@@ -542,8 +552,11 @@ __device__ __forceinline__ void level1_body(const BinArgs &a, void *geom, void *
       });
     }
   }
-  __syncthreads();
-  if (s_last) layout_buckets(a, geom, bin, s_hist, s_wt);
+  lds_barrier();  // (thread 0 has written s_last.  Not __syncthreads(): that would wait for this workgroup's stores)
+  if (s_last) {   // (workgroup-uniform)
+    __syncthreads();
+    layout_buckets(a, geom, bin, s_hist, s_wt);
+  }
   tr.flush();
 }
 
