@@ -171,10 +171,12 @@ def test_long_tile_lists_with_depth_ties(N):
 
 @pytest.mark.parametrize("case", ["one_depth_1500", "one_depth_5000", "slab_and_outliers", "two_depths"])
 def test_depth_sort_bucket_paths(case):
-    """The depth sort cuts [min, max] of the depth bits into 4096 buckets and ranks each on its own (binning.hip):
-    a wave per bucket up to 256 entries, a workgroup in LDS up to 2048, a single-workgroup radix sort above.  Scenes
-    that drive the large-bucket paths -- thousands of Gaussians at ONE depth (order = index), a thin slab next to far
-    outliers, two depths only -- must give the oracle's keys and order bit for bit."""
+    """Level 1 drops the entries into (supertile, depth bin) buckets and bucket_sort ranks each bucket on its own
+    (binning.hip): a workgroup in LDS up to 2048 entries, slices of a larger bucket by several workgroups, eight byte
+    passes of a single workgroup when hundreds of entries share nearly one depth; a bucket of more than 4096 entries
+    spills into the overflow area of the unsorted array.  Scenes that drive those paths -- thousands of Gaussians at ONE
+    depth (order = index), a thin slab next to far outliers, two depths only -- must give the oracle's keys and order
+    bit for bit.  (The same scenes run on the CPU SIMT emulation in tests/test_binning_emulated.py.)"""
     cam = camera_np(0.0, W=96, H=64)
     if case.startswith("one_depth"):
         N = int(case.split("_")[-1])
@@ -219,8 +221,8 @@ def test_depth_sort_with_256_bins_above_400k_gaussians():
 
 @pytest.mark.parametrize("H,W", [(1040, 2048), (1296, 1296)])
 def test_images_with_more_than_4096_tiles(H, W):
-    """Above 4096 tiles the level-2 fill no longer keeps every tile's first slot in LDS and walks the current
-    supertile's starts per window instead (binning.hip: TS_LDS); 8 x 8-tile supertiles (ss_shift 3)."""
+    """8 x 8-tile supertiles (ss_shift 3: 64-bit tile masks, 16-byte sorted entries) and more than 4096 tiles: the
+    fill keeps every tile's first slot in dynamically sized LDS (33 KB at 8320 tiles)."""
     cam = camera_np(15.0, elevation=-5, W=W, H=H)
     sc = random_scene(6000, seed=77, scale=0.02)
     _check_forward(sc, cam, (0.0, 0.0, 0.0), 0)
