@@ -75,11 +75,11 @@ def kernel_rooflines(timing_iso, N, V, R, P, C=NFEAT, renders_in_window=None, vi
         "deform_fwd": 92 * N,
         "preprocess_fwd": 56 * N + 77 * V,
         # binning (dimo_amd/csrc/binning.hip), E = level-1 entries ~ 2.4 N (one per supertile a Gaussian touches):
-        # three launches since round 5 (count + scatter are one kernel, the level-2 counts ride in the bucket sort's
-        # epilogue: the "emit" and "ranges" groups have no launches any more and drop out of the table)
+        # three launches since round 5 (count + scatter are one kernel, the level-2 counts ride in the bucket sort:
+        # the "emit" and "ranges" groups have no launches any more and drop out of the table)
         "scan": 20 * N + 16 * N + 16 * 2.4 * N,  # level 1: tiles, depth key, rectangle in (twice); offsets and one 16-byte entry per supertile touched out
-        "sort": (2 * 16 + 4) * 2.4 * N,    # per-bucket LDS sort: entries in, sorted entries + one row word per entry out
-        "place": (16 + 4) * 2.4 * N + 5 * R,     # level-2 fill: entries + row words in; id + cleared flag per instance out
+        "sort": (16 + 8 + 4) * 2.4 * N,    # per-bucket LDS sort: entries in; (id, tile mask) + a quarter row word per entry out
+        "place": (8 + 1) * 2.4 * N + 5 * R,      # level-2 fill: sorted entries + row words in; id + cleared flag per instance out
         "blend_fwd": (28 + 4 * C) * R + 4 * (C + 1) * P + 8 * P,
         "blend_bwd": (28 + 4 * C) * R + (8 * (C + 1) + 8) * P + (24 + 4 * C) * V,
         "preprocess_bwd": (24 + 4 * C) * V + 56 * N + 56 * N + 12 * N,

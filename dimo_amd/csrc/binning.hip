@@ -847,7 +847,7 @@ __device__ __forceinline__ bool scan_sub_bins(uint32_t *s_cur, uint32_t *s_start
 template <int SSH>
 __device__ __forceinline__ void rank_store_count(const u64 *s_k, const uint2 *s_r, const uint32_t *s_start, uint32_t origin,
                                                  uint32_t m, uint32_t len, const SubMap &sm, void *l1list, size_t first_out,
-                                                 const Unit &U, uint32_t *s_gcnt, BinTrace &tr) {
+                                                 const Unit &U, uint32_t *s_gcnt) {
   constexpr int ss = 1 << SSH, ntile = ss * ss;
   typename Sorted<SSH>::T *__restrict__ out = Sorted<SSH>::at(l1list, first_out);
   const uint32_t g0 = (uint32_t)(first_out / GRP);
@@ -880,7 +880,6 @@ __device__ __forceinline__ void rank_store_count(const u64 *s_k, const uint2 *s_
   }
   for (uint32_t e = m + threadIdx.x; e < len; e += SORT_BLOCK) out[e] = Sorted<SSH>::make(0u, 0ull);
   lds_barrier();
-  tr.mark();
   const uint32_t ng = len / GRP;
   if (threadIdx.x < (uint32_t)ntile) {  // thread j: tile j of the supertile
     const int j = (int)threadIdx.x;
@@ -905,12 +904,12 @@ __device__ __forceinline__ void rank_store_count(const u64 *s_k, const uint2 *s_
 }
 __device__ __forceinline__ void rank_store_count_any(int ssh, const u64 *s_k, const uint2 *s_r, const uint32_t *s_start,
                                                      uint32_t origin, uint32_t m, uint32_t len, const SubMap &sm, void *l1list,
-                                                     size_t first_out, const Unit &U, uint32_t *s_gcnt, BinTrace &tr) {
+                                                     size_t first_out, const Unit &U, uint32_t *s_gcnt) {
   switch (ssh) {  // (uniform)
-    case 0: rank_store_count<0>(s_k, s_r, s_start, origin, m, len, sm, l1list, first_out, U, s_gcnt, tr); break;
-    case 1: rank_store_count<1>(s_k, s_r, s_start, origin, m, len, sm, l1list, first_out, U, s_gcnt, tr); break;
-    case 2: rank_store_count<2>(s_k, s_r, s_start, origin, m, len, sm, l1list, first_out, U, s_gcnt, tr); break;
-    default: rank_store_count<3>(s_k, s_r, s_start, origin, m, len, sm, l1list, first_out, U, s_gcnt, tr); break;
+    case 0: rank_store_count<0>(s_k, s_r, s_start, origin, m, len, sm, l1list, first_out, U, s_gcnt); break;
+    case 1: rank_store_count<1>(s_k, s_r, s_start, origin, m, len, sm, l1list, first_out, U, s_gcnt); break;
+    case 2: rank_store_count<2>(s_k, s_r, s_start, origin, m, len, sm, l1list, first_out, U, s_gcnt); break;
+    default: rank_store_count<3>(s_k, s_r, s_start, origin, m, len, sm, l1list, first_out, U, s_gcnt); break;
   }
 }
 
@@ -993,7 +992,6 @@ __device__ __forceinline__ void bucket_sort_body(const BinArgs &a, void *geom, v
     for (int u = 0; u < SUB_OWN; ++u) s_cur[tid * SUB_OWN + u] = 0u;
     if (tid == 0) s_big = 0u;
     lds_barrier();
-    tr.mark();
     bool in_lds = false;  // the run's entries are sorted in LDS (else: nothing to do, or the byte passes)
     uint32_t first = 0, m = n, len = pad_grp(n), run_off = 0, used = 0;
     if (!skip && !is_slice) {
@@ -1020,7 +1018,6 @@ __device__ __forceinline__ void bucket_sort_body(const BinArgs &a, void *geom, v
     }
     if (tid == 0) s_ticket[par ^ 1u] = t_next;
     lds_barrier();
-    tr.mark();
     // the next item's words
     const uint32_t tn = s_ticket[par ^ 1u];
     if (tn < n_items) nxt.bi = work[2 * tn], nxt.w = work[2 * tn + 1].x;
@@ -1029,7 +1026,6 @@ __device__ __forceinline__ void bucket_sort_body(const BinArgs &a, void *geom, v
       fat = is_slice ? scan_sub_bins<false>(s_cur, s_start, s_run, &s_big) : scan_sub_bins<true>(s_cur, s_start, s_run, &s_big);
       in_lds = !fat;
     }
-    tr.mark();
     const uint32_t n_gcnt = (uint32_t)(BIN_CAP / GRP) << (2 * a.gi.ss_shift);  // (group, tile) counters of a run
     if (!skip && !is_slice && in_lds) {
       // (the (group, tile) counters of the run)
@@ -1042,7 +1038,6 @@ __device__ __forceinline__ void bucket_sort_body(const BinArgs &a, void *geom, v
           s_r[p] = make_uint2(mine[q].z, mine[q].w);
         }
       lds_barrier();
-      tr.mark();
     } else if (!skip && is_slice && in_lds) {
       // The slices' boundaries in the sorted bucket: P[i] = first entry of the first non-empty sub-bin that starts at
       // or behind i Tn (P[0] = 0, P[J] = n).  A non-empty sub-bin [S, E) makes E the boundary of every i with
@@ -1092,7 +1087,7 @@ __device__ __forceinline__ void bucket_sort_body(const BinArgs &a, void *geom, v
       // nothing
     } else if (in_lds) {
       if (m > 0u)
-        rank_store_count_any(a.gi.ss_shift, s_k, s_r, s_start, first, m, len, sm, l1list, (size_t)base + run_off, U, s_seg, tr);
+        rank_store_count_any(a.gi.ss_shift, s_k, s_r, s_start, first, m, len, sm, l1list, (size_t)base + run_off, U, s_seg);
       else
         zero_unit_row(U);
       if (is_slice && j == J - 1 && used < reserved) {  // what the bucket reserved beyond its slices' runs: empty entries, empty rows

@@ -26,8 +26,8 @@ tr.train_step()
 torch.cuda.synchronize()
 n = L.dimo_debug_bin_trace(None, 0)
 rec = buf.cpu().numpy().reshape(cap, 32)[:min(n, cap)]
-# bucket_sort's marks: start, prologue done, then for the workgroup's FIRST bucket: segment table, entries + sub-bin scan,
-# placement, ranks formed, rows counted; one mark per further bucket; buckets done; slices done
+# bucket_sort's marks: start, first item's words in, then one per item of the work list the workgroup took (its two low
+# bits say what the item was), end
 names = {1: "level1", 2: "level1_scatter (until round 4)", 3: "bucket_sort", 4: "level2_count (until round 4)", 5: "level2_fill"}
 print("records", n)
 for kid, name in names.items():
@@ -55,37 +55,14 @@ for kid, name in names.items():
             d = d[~np.isnan(d)]
             if len(d):
                 print(f"     mark {k - 1}->{k}: n {len(d):5d} mean {d.mean():6.2f} p90 {np.percentile(d, 90):6.2f} max {d.max():6.2f}")
-        if kid == 3:
-            # plain items leave six marks (table | entries + sub-bin count | sub-bin scan | placement | ranks + counts | rows):
-            # the phases of the items that are whole in the record
-            raw = r[g][:, 1:]
-            ph = [[] for _ in range(6)]
-            for row in raw:
-                ts = [int(x) for x in row[row != 0]][2:]  # behind start and prologue
-                k = 0
-                while k + 6 <= len(ts):
-                    if (ts[k + 5] & 3) == 1 and all((x & 3) != 2 for x in ts[k:k + 5]) or True:
-                        if (ts[k + 5] & 3) == 1:
-                            prev = ts[k - 1] if k else None
-                            if prev is not None:
-                                ph[0].append((ts[k] - prev) / 100.0)
-                            for q in range(1, 6):
-                                ph[q].append((ts[k + q] - ts[k + q - 1]) / 100.0)
-                            k += 6
-                            continue
-                    break
-            for q, nm in enumerate(("top barrier + table", "entries + sub-bin count", "sub-bin scan", "placement", "ranks + tile counts", "rows")):
-                if ph[q]:
-                    d = np.array(ph[q])
-                    print(f"     plain item phase '{nm}': n {len(d)} mean {d.mean():.2f} p90 {np.percentile(d, 90):.2f}")
-        if kid == 3 and False:  # (the items by kind: only with one mark per item)
+        if kid == 3:  # bucket_sort: the items by kind (two low bits of the mark that ends them)
             kinds = {1: "bucket sorted in LDS", 2: "slice", 3: "byte passes (or an idle slice of such a bucket)", 0: "skipped"}
             raw = r[g][:, 1:]
             for kd, kname in kinds.items():
                 d = []
                 for row in raw:
                     ts = row[row != 0]
-                    for k in range(2, len(ts)):
+                    for k in range(2, len(ts) - 1):  # (the last mark is the flush: no kind)
                         if (int(ts[k]) & 3) == kd:
                             d.append((int(ts[k]) - int(ts[k - 1])) / 100.0)
                 if d:
