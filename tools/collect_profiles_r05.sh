@@ -39,7 +39,7 @@ fi
 if [ "$part" = "core" ]; then ls -la $out; exit 0; fi
 cd /tmp
 # 4. SQ counters
-timeout 600 bash $R/tools/pmc_sq.sh $tag blend_bwd_batched blend_fwd_batched ssim_loss_tile ssim_fused lbs_bwd_batched preprocess_bwd image_loss level1_count_batched level1_scatter_batched bucket_sort_batched "level2_batched_kernel<false>" "level2_batched_kernel<true>" timenet_fwd_fused timenet_bwd_fused8 knn4 wgrad > $out/${tag}_sq.log 2>&1
+timeout 600 bash $R/tools/pmc_sq.sh $tag blend_bwd_batched blend_fwd_batched ssim_loss_tile ssim_fused lbs_bwd_batched preprocess_bwd image_loss level1_batched bucket_sort_batched level2_fill_batched timenet_fwd_fused timenet_bwd_fused8 knn4 wgrad > $out/${tag}_sq.log 2>&1
 cd /tmp
 # 5. every stage ONE launch over the 8 renders, each kernel alone on the device
 DIMO_EXEC_STREAMS=0 timeout 300 bash $R/tools/kstats_all.sh $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-dropin --sustained-steps 0 --no-live-pmc > $out/${tag}_kernel_stats_serial_8renders.txt 2>&1

@@ -34,7 +34,7 @@ def main():
     kw = (GiB_KiB / cal_w) if cal_w else 1.0
     res["calibration"]["fetch_factor"], res["calibration"]["write_factor"] = kf, kw
     for name, pat in (("blend_bwd", "blend_bwd_batched_kernel"), ("blend_fwd", "blend_fwd_batched_kernel"),
-                      ("preprocess_bwd", "preprocess_bwd_batched_kernel"), ("level2_fill", "level2_batched_kernel<true>")):
+                      ("preprocess_bwd", "preprocess_bwd_batched_kernel"), ("level2_fill", "level2_fill_batched_kernel")):
         fk, wk = mean(find(fetch, pat)), mean(find(write, pat))
         if fk is None or wk is None:
             continue
