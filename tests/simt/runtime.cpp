@@ -50,6 +50,7 @@ struct Fiber {
   Workgroup *wg;
   Idx3 tid;
   int linear, wave, lane;
+  int pos;  // place in the workgroup's schedule ring
   bool done;
 };
 struct Workgroup {
@@ -59,6 +60,7 @@ struct Workgroup {
   unsigned bar_phase;
   unsigned long progress;
   void *main_sp;
+  int ring[MAX_THREADS];  // the order the fibers take turns in (SIMT_ORDER: forward, reverse or a seeded shuffle)
   void *dyn_lds;
   size_t dyn_cap;
   Idx3 bid, bdim, gdim;
@@ -76,13 +78,14 @@ void *dynamic_lds() { return cur->wg->dyn_lds; }
 
 static void yield_from(Fiber *me) {
   Workgroup *g = me->wg;
-  int i = me->linear;
+  int p = me->pos;
   for (int k = 0; k < g->n; ++k) {
-    i = i + 1 == g->n ? 0 : i + 1;
-    if (!g->f[i].done) {
-      if (&g->f[i] == me) return;
-      cur = &g->f[i];
-      simt_switch(&me->sp, g->f[i].sp);
+    p = p + 1 == g->n ? 0 : p + 1;
+    Fiber *f = &g->f[g->ring[p]];
+    if (!f->done) {
+      if (f == me) return;
+      cur = f;
+      simt_switch(&me->sp, f->sp);
       return;
     }
   }
@@ -201,8 +204,25 @@ static void run_workgroup(Workgroup *g, Idx3 bid, Idx3 bdim, Idx3 gdim, const st
     for (int r = 3; r <= 8; ++r) s[-r] = nullptr;
     f.sp = (void *)(s - 8);
   }
-  cur = &g->f[0];
-  simt_switch(&g->main_sp, g->f[0].sp);
+  // The order the fibers take turns in.  Between two rendezvous a fiber runs undisturbed, so the schedule decides
+  // which lane's plain LDS / global accesses come first: "forward" lets thread 0 write before anybody reads -- what a
+  // missing barrier needs to go unnoticed --, "reverse" and a seeded shuffle do not.
+  const char *order = getenv("SIMT_ORDER");  // forward (default) | reverse | random[:seed]
+  for (int i = 0; i < n; ++i) g->ring[i] = i;
+  if (order && !strncmp(order, "reverse", 7)) {
+    for (int i = 0; i < n; ++i) g->ring[i] = n - 1 - i;
+  } else if (order && !strncmp(order, "random", 6)) {
+    uint64_t x = (order[6] == ':' ? strtoull(order + 7, nullptr, 10) : 1u) * 0x9E3779B97F4A7C15ull + bid.x * 0x100000001B3ull + bid.y * 7919u + 1u;
+    for (int i = n - 1; i > 0; --i) {
+      x ^= x << 13, x ^= x >> 7, x ^= x << 17;
+      const int j = (int)(x % (uint64_t)(i + 1));
+      const int t = g->ring[i];
+      g->ring[i] = g->ring[j], g->ring[j] = t;
+    }
+  }
+  for (int i = 0; i < n; ++i) g->f[g->ring[i]].pos = i;
+  cur = &g->f[g->ring[0]];
+  simt_switch(&g->main_sp, cur->sp);
   cur = nullptr;
 }
 

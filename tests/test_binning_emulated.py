@@ -146,6 +146,26 @@ def test_emulated_capacity_overflow_is_flagged_and_clamped():
         assert np.array_equal(r["vals"][a:b], st["vals_sorted"][a:b])
 
 
+@pytest.mark.parametrize("order", ["reverse", "random:1", "random:2"])
+def test_emulated_binning_under_other_fiber_schedules(order, monkeypatch):
+    """Between two rendezvous a fiber runs undisturbed, so the order the fibers take turns in decides whose plain LDS /
+    global accesses come first.  The default (thread 0 first) is the order a missing barrier is most likely to survive;
+    the reverse order and seeded shuffles are not.  Every path once more: slices, byte passes, overflow records, big
+    Gaussians, the batched entry point."""
+    monkeypatch.setenv("SIMT_ORDER", order)
+    cam = camera_np(0.0, W=96, H=64)
+    sc = random_scene(5000, seed=5000, scale=0.02)
+    sc["means3D"][:] = sc["means3D"][0]  # one depth, one bucket of 5000 entries per tile: overflow records, byte passes
+    _scene_check(sc, cam)
+    cam = camera_np(0.0, W=128, H=96)
+    sc = random_scene(30_000, seed=7, scale=0.006, opacity=(0.05, 0.4))  # slices
+    _scene_check(sc, cam)
+    cam = camera_np(20.0, W=256, H=256)
+    st, rect, tiles, key = _project(random_scene(3000, seed=21, scale=0.08), cam)  # big Gaussians, 2 x 2-tile supertiles
+    for r in hz.run_binning(rect, tiles, key, 256, 256, n_batched=2):
+        _check(r, st)
+
+
 def test_emulated_unsorted_model_many_buckets_per_workgroup():
     """Gaussians in no spatial order: every level-1 workgroup touches most buckets (the `direct` path of the group walk)."""
     cam = camera_np(0.0, W=512, H=512)
