@@ -4,22 +4,25 @@
 //   1. level1      : a Gaussian has one LEVEL-1 ENTRY per supertile (SS x SS tiles) it touches; an entry belongs to
 //                    the BUCKET (supertile, coarse depth bin).  A workgroup walks its 256 x `per` Gaussians ONCE: it
 //                    counts its entries per bucket in LDS and every entry learns its rank inside the workgroup's share of
-//                    its bucket (kept as a 32-bit code in LDS); the workgroup's entries then go to ITS OWN contiguous
-//                    SEGMENT of the unsorted level-1 array (its place is known from the per-block entry counts the
-//                    projection kernel left: no bucket start is needed), grouped by bucket; one returning 64-bit atomic
-//                    per (workgroup, non-empty bucket) adds the entries to the bucket total and takes a slot in the
-//                    bucket's SEGMENT LIST, where the workgroup leaves (first entry, count).  Also: offsets (the
-//                    inclusive scan of tiles_touched), R, and the depth-bin map -- every workgroup reduces the per-block
-//                    words of the projection kernel (a few hundred) itself.
-//   2. bucket_sort : every workgroup scans the <= 2048 bucket totals itself (where the buckets start in the SORTED
-//                    level-1 array: supertile by supertile, a supertile's buckets by depth bin, every bucket rounded up
-//                    to whole GROUPS of 64 entries), then ONE WORKGROUP PER BUCKET gathers the bucket's segments and
-//                    sorts the entries in LDS by the 64-bit word (depth bits << 32 | id): a counting pass over 1024
-//                    sub-bins of the bucket's key range, then every entry ranks itself inside its sub-bin (all words are
-//                    distinct because the ids are).  While the sorted tile rectangles are still in LDS the workgroup runs
-//                    the first half of level 2 on them: per group of 64 sorted entries and per tile of the supertile,
-//                    how many entries of the bucket's EARLIER groups cover the tile (a row of 64 words per group), the
-//                    bucket's totals per tile (one row per bucket: the UNIT row), and the tile totals (atomics).
+//                    its bucket (kept as a 32-bit code in LDS); ONE returning atomic per (workgroup, non-empty bucket)
+//                    adds the share to the bucket total -- what it returns is the share's first PLACE in the bucket --
+//                    and the 16-byte entries go to region(bucket) + place: every bucket owns a fixed region of
+//                    BUCKET_REGION slots of the unsorted level-1 array, so no bucket start has to be known (which is
+//                    what made count and scatter two launches) and a bucket is still one contiguous run for the sort.
+//                    Places beyond a region (rare) go to an overflow area, with a record in the bucket's list.  Also:
+//                    offsets (the inclusive scan of tiles_touched), R, and the depth-bin map -- every workgroup reduces
+//                    the per-block words of the projection kernel (a few hundred) itself.  The render's LAST workgroup
+//                    (a ticket) reads the bucket totals and lays the SORTED array out: bucket starts (supertile by
+//                    supertile, a supertile's buckets by depth bin, every bucket rounded up to whole GROUPS of 64
+//                    entries), the slices of oversized buckets, the rows of per-tile totals, bucket_sort's work list.
+//   2. bucket_sort : persistent workgroups take the work list item by item (tickets); an item = a bucket, sorted in
+//                    LDS by the 64-bit word (depth bits << 32 | id): a counting pass over 1024 sub-bins of the bucket's
+//                    key range, then every entry ranks itself inside its sub-bin (all words are distinct because the
+//                    ids are).  An entry that has its sorted place also has its group, and adds one to an LDS counter
+//                    per tile of the supertile its rectangle covers: the first half of level 2 -- per group of 64 sorted
+//                    entries and per tile, how many entries of the bucket's EARLIER groups cover the tile (a row per
+//                    group), the bucket's totals per tile (one row per bucket: the UNIT row), and the tile totals
+//                    (atomics).  The sorted entry is (id, tile mask).
 //   3. level2_fill : one WAVE per group, no barriers: first slot of tile j for the group = tile start (every workgroup
 //                    scans the tile totals itself) + the unit rows of the supertile's earlier buckets + the group's own
 //                    row; an ORDERED filter (ballot / popcount ranks) then writes the Gaussian id per instance as long
@@ -1345,8 +1348,8 @@ static bool make_args(int N, int H, int W, int64_t R_cap, int n_renders, const G
   // as its slowest one, and with four blocks each the slowest took twice the mean.)
   if (per < (G.nb + 255) / 256) per = (G.nb + 255) / 256;
   if (per > MAX_L1_PER) per = MAX_L1_PER;
-  // (a bucket's segment list has a slot per level-1 workgroup, MAX_SEG of them at most; an entry's code stays in LDS
-  // between the count and the placement: MAX_L1_PER blocks per workgroup at most)
+  // (a bucket's list of overflow records has a slot per level-1 workgroup, MAX_SEG of them at most; an entry's code
+  // stays in LDS between the count and the placement: MAX_L1_PER blocks per workgroup at most)
   if (per < G.per) per = G.per;
   if (per > MAX_L1_PER) return false;  // more than MAX_L1_PER * MAX_SEG * 256 Gaussians (2 M)
   a.N = N, a.nb = G.nb, a.per = per, a.nwg1 = (G.nb + per - 1) / per, a.lg = depth_bins_log2(N, a.gi.NS), a.T = B.T;

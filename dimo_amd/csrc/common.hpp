@@ -59,8 +59,8 @@ constexpr int SORT_BLOCK = 256;  // threads of a bucket-sort workgroup
 // level 2), the depth bits into 2^nb_log2 bins over a range that brackets the bulk of the keys.
 constexpr int MAX_SUPER = 256;     // supertiles
 constexpr int MAX_BUCKETS = 2048;  // supertiles x depth bins
-constexpr int MAX_SEG = 1024;      // level-1 workgroups per render = slots of a bucket's segment list (beyond: several
-                                   // preprocess blocks per workgroup)
+constexpr int MAX_SEG = 1024;      // level-1 workgroups per render = slots of a bucket's list of overflow records
+                                   // (beyond: several preprocess blocks per workgroup)
 constexpr int MAX_L1_PER = 8;      // preprocess blocks a level-1 workgroup walks at most (N <= 8 * 1024 * 256 Gaussians)
 struct BinGrid {
   int tiles_x, tiles_y, ss_shift, stx, sty, NS;  // supertile edge = 1 << ss_shift tiles, stx * sty = NS supertiles
