@@ -152,8 +152,8 @@ struct BinLayout {
     ranges = o, o = align_up(o + (size_t)T * 2 * sizeof(uint32_t));
     totals = o, o = align_up(o + (size_t)T * sizeof(uint32_t));  // instances per tile (atomically summed)
     // level 1 (binning.hip): at most one entry per instance.  l1tmp: the 16-byte entries (depth bits, id, tile
-    // rectangle) as the level-1 workgroups leave them: a region of BUCKET_REGION slots per bucket -- address space
-    // more than memory: a bucket touches what it holds --, then an overflow area; l1a / l1b: 64-bit scratch of
+    // rectangle) as the level-1 workgroups leave them: a region of BUCKET_REGION slots per bucket -- 128 MB of
+    // HBM per render slot, of which a bucket touches what it holds --, then an overflow area; l1a / l1b: 64-bit scratch of
     // the byte-wise fallback sort; l1list: the sorted entries (id, depth bits, tile rectangle), bucket by bucket, every
     // bucket (and every slice of a cut bucket) rounded up to whole groups of 64 -- hence the slack
     l1cap = (cap + 255) / 256 * 256 + 64 * (size_t)(MAX_BUCKETS + 2 * MAX_SLICES);
