@@ -29,6 +29,8 @@ _SIGNATURES = {
     "dimo_raster_img_layout": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_size_t)]),
     "dimo_debug_bin_trace": (C.c_int64, [C.c_void_p, C.c_int64]),
     "dimo_raster_depth_keys": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "dimo_debug_bin_geom_layout": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_size_t)]),
+    "dimo_debug_bin_instances": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dimo_raster_preprocess_forward": (C.c_int, [C.c_int] * 5 + [c_ptr] * 7 + [C.c_float] + [c_ptr] * 3
                                        + [C.c_float, C.c_float, c_ptr, c_ptr, C.c_size_t, C.POINTER(C.c_int64), c_ptr]),
     "dimo_raster_render_forward": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int64, c_ptr, c_ptr, c_ptr, C.c_size_t,

@@ -27,6 +27,20 @@ extern "C" int dimo_raster_depth_keys(int N, int H, int W, int64_t R_cap, const 
   clear_errors();
   return instance_depth_keys(N, H, W, R_cap, geom, bin, out, (hipStream_t)stream);
 }
+extern "C" int dimo_debug_bin_geom_layout(int N, int H, int W, size_t out[10]) {
+  if (!out || N < 0 || H <= 0 || W <= 0) return DIMO_E_ARG;
+  GeomLayout G(N);
+  BinGrid gi;
+  if (!make_bin_grid(H, W, gi)) return DIMO_E_ARG;
+  out[0] = G.rect, out[1] = G.tiles, out[2] = G.offsets, out[3] = G.total, out[4] = G.block_sums, out[5] = G.key32;
+  out[6] = G.bk, out[7] = G.bytes, out[8] = (size_t)G.nb, out[9] = (size_t)gi.ss_shift;
+  return DIMO_OK;
+}
+extern "C" int dimo_debug_bin_instances(int N, int H, int W, int64_t R_cap, void *geom, void *bin, void *stream) {
+  if (N < 0 || H <= 0 || W <= 0 || R_cap < 0 || R_cap > 0xfffffff0LL || !geom || !bin) return DIMO_E_ARG;
+  clear_errors();
+  return bin_instances(N, H, W, R_cap, geom, bin, (hipStream_t)stream);
+}
 extern "C" int dimo_raster_img_layout(int H, int W, size_t out[2]) {
   if (!out || H <= 0 || W <= 0) return DIMO_E_ARG;
   ImgLayout L(H, W);

@@ -93,6 +93,12 @@ int dimo_raster_img_layout(int H, int W, size_t out_offsets[2]);
  * sort keys -- gathered from the instances' Gaussians into out uint32[R_cap] (the first min(R, R_cap) words). */
 int dimo_raster_depth_keys(int N, int H, int W, int64_t R_cap, const void *geom, const void *bin, uint32_t *out,
                            void *stream);
+/* Test entry (tests/test_gpu_binning_fuzz.py): the tile binning ALONE on a geometry workspace the caller filled as
+ * the projection kernel would (tile rectangles, tiles touched, depth bits, the per-block words; bucket words zero) --
+ * dimo_debug_bin_geom_layout: out = byte offsets of (rect, tiles, offsets, total, block_sums, key32, bucket words),
+ * the workspace's bytes, the number of 256-Gaussian blocks, the supertile edge's log2 for an H x W image. */
+int dimo_debug_bin_geom_layout(int N, int H, int W, size_t out[10]);
+int dimo_debug_bin_instances(int N, int H, int W, int64_t R_cap, void *geom, void *bin, void *stream);
 /* Diagnostic: per-workgroup phase trace of the binning kernels (tools/bin_trace.py; needs a library built with
  * DIMO_BIN_TRACE=1, else a non-NULL buffer is refused).  buffer = device memory for `capacity` records of 32 x u64,
  * NULL = off; returns the number of records written since the last call. */

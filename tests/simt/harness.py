@@ -46,23 +46,11 @@ def make_geom(rect, tiles, key32, H, W, G):
     N = len(tiles)
     ssh = lib().simt_supertile_shift(H, W)
     assert ssh >= 0
+    r16, t32, key, sums = geom_words(rect, tiles, key32, ssh, G["nb"])
     geom = np.zeros(G["bytes"], np.uint8)
-    vis = tiles > 0
-    key = np.where(vis, key32, 0xFFFFFFFF).astype(np.uint32)
-    r16 = np.where(vis[:, None], rect, 0).astype(np.uint16)
     geom[G["rect"]:G["rect"] + 8 * N] = r16.reshape(-1).view(np.uint8)
-    geom[G["tiles"]:G["tiles"] + 4 * N] = tiles.astype(np.uint32).view(np.uint8)
+    geom[G["tiles"]:G["tiles"] + 4 * N] = t32.view(np.uint8)
     geom[G["key32"]:G["key32"] + 4 * N] = key.view(np.uint8)
-    nb = G["nb"]
-    pad = nb * PRE_BLOCK - N
-    x0, y0, x1, y1 = (rect[:, i].astype(np.int64) for i in range(4))
-    ent = np.where(vis, (((x1 - 1) >> ssh) - (x0 >> ssh) + 1) * (((y1 - 1) >> ssh) - (y0 >> ssh) + 1), 0)
-    blk = lambda a, fill: np.concatenate([a, np.full(pad, fill, a.dtype)]).reshape(nb, PRE_BLOCK)
-    sums = np.zeros((4, nb + 1), np.uint32)
-    sums[0, :nb] = blk(tiles.astype(np.uint32), 0).sum(1)
-    sums[1, :nb] = blk(key, 0xFFFFFFFF).min(1)
-    sums[2, :nb] = blk(np.where(vis, key, 0).astype(np.uint32), 0).max(1)
-    sums[3, :nb] = blk(ent.astype(np.uint32), 0).sum(1)
     geom[G["block_sums"]:G["block_sums"] + sums.nbytes] = sums.reshape(-1).view(np.uint8)
     return geom
 
@@ -141,3 +129,64 @@ def expected(rect, tiles, key32, H, W):
     ranges[nz, 0] = (end - cnt)[nz]
     ranges[nz, 1] = end[nz]
     return dict(R=len(ks), dkeys=(ks & np.uint64(0xFFFFFFFF)).astype(np.uint32), vals=vs.astype(np.uint32), ranges=ranges)
+
+
+def fuzz_config(rng, max_instances=1_500_000):
+    """One random binning input (H, W, rect, tiles, key32): image sizes from 16^2 to 1300 x 2048 (every supertile edge,
+    partial supertiles, more and fewer than 32 buckets), 1 to 20 000 Gaussians, rectangles of a tile / a few tiles / the
+    whole image, visible fractions down to 5 %, depths uniform / one value / three values / a thin slab with floaters."""
+    while True:
+        H = int(rng.choice([16, 33, 64, 100, 128, 200, 256, 400, 512, 777, 1024, 1300]))
+        W = int(rng.choice([16, 48, 64, 96, 128, 250, 256, 512, 640, 1024, 2048]))
+        tx, ty = (W + 15) // 16, (H + 15) // 16
+        N = int(rng.choice([1, 2, 63, 64, 65, 255, 256, 257, 1000, 3000, 8000, 20000]))
+        mode, km = int(rng.integers(0, 5)), int(rng.integers(0, 4))
+        cx, cy = rng.integers(0, tx, N), rng.integers(0, ty, N)
+        if mode == 0:
+            ext = rng.integers(1, 3, (N, 2))
+        elif mode == 1:
+            ext = rng.integers(1, max(2, min(tx, ty)), (N, 2))
+        elif mode == 2:
+            ext = np.stack([np.full(N, tx), np.full(N, ty)], 1)
+        elif mode == 3:
+            ext = rng.integers(1, 6, (N, 2))
+        else:
+            ext = np.where(rng.random((N, 1)) < 0.02, max(tx, ty), rng.integers(1, 3, (N, 2)))
+        x0 = np.clip(cx - ext[:, 0] // 2, 0, tx - 1)
+        y0 = np.clip(cy - ext[:, 1] // 2, 0, ty - 1)
+        x1, y1 = np.clip(x0 + ext[:, 0], 1, tx), np.clip(y0 + ext[:, 1], 1, ty)
+        rect = np.stack([x0, y0, np.maximum(x1, x0 + 1), np.maximum(y1, y0 + 1)], 1).astype(np.int32)
+        vis = rng.random(N) < rng.choice([1.0, 0.9, 0.5, 0.05])
+        tiles = np.where(vis, (rect[:, 2] - rect[:, 0]) * (rect[:, 3] - rect[:, 1]), 0).astype(np.uint32)
+        if km == 0:
+            key = rng.uniform(0.3, 50.0, N).astype(np.float32).view(np.uint32)
+        elif km == 1:
+            key = np.full(N, np.float32(2.5).view(np.uint32))
+        elif km == 2:
+            key = rng.choice(np.array([1.0, 1.5, 3.0], np.float32), N).view(np.uint32)
+        else:
+            k = rng.normal(2.0, 0.01, N).astype(np.float32)
+            k[: max(1, N // 500)] = 90.0
+            k[-1] = 0.21
+            key = np.abs(k).astype(np.float32).view(np.uint32)
+        if int(tiles.astype(np.int64).sum()) <= max_instances:
+            return H, W, rect, tiles, key, (H, W, N, mode, km)
+
+
+def geom_words(rect, tiles, key32, ssh, nb):
+    """What preprocess_fwd leaves for the binning (preprocess.hip:125-157), as numpy arrays: rect u16 [N,4], tiles u32,
+    key32 u32 (0xffffffff without tiles), the four per-block rows [4, nb + 1]."""
+    N = len(tiles)
+    vis = tiles > 0
+    key = np.where(vis, key32, 0xFFFFFFFF).astype(np.uint32)
+    r16 = np.where(vis[:, None], rect, 0).astype(np.uint16)
+    pad = nb * PRE_BLOCK - N
+    x0, y0, x1, y1 = (rect[:, i].astype(np.int64) for i in range(4))
+    ent = np.where(vis, (((x1 - 1) >> ssh) - (x0 >> ssh) + 1) * (((y1 - 1) >> ssh) - (y0 >> ssh) + 1), 0)
+    blk = lambda a, fill: np.concatenate([a, np.full(pad, fill, a.dtype)]).reshape(nb, PRE_BLOCK)
+    sums = np.zeros((4, nb + 1), np.uint32)
+    sums[0, :nb] = blk(tiles.astype(np.uint32), 0).sum(1)
+    sums[1, :nb] = blk(key, 0xFFFFFFFF).min(1)
+    sums[2, :nb] = blk(np.where(vis, key, 0).astype(np.uint32), 0).max(1)
+    sums[3, :nb] = blk(ent.astype(np.uint32), 0).sum(1)
+    return r16, tiles.astype(np.uint32), key, sums

@@ -182,51 +182,14 @@ def test_emulated_binning_fuzz(seed):
     the published order.  (275 such configurations were run when the chain was rewritten, under the forward, reverse
     and shuffled fiber schedules.)"""
     rng = np.random.default_rng(seed)
-    done = 0
-    while done < 8:
-        H = int(rng.choice([16, 33, 64, 100, 128, 200, 256, 400, 512, 777, 1024, 1300]))
-        W = int(rng.choice([16, 48, 64, 96, 128, 250, 256, 512, 640, 1024, 2048]))
-        tx, ty = (W + 15) // 16, (H + 15) // 16
-        N = int(rng.choice([1, 2, 63, 64, 65, 255, 256, 257, 1000, 3000, 8000, 20000]))
-        mode, km = int(rng.integers(0, 5)), int(rng.integers(0, 4))
-        cx, cy = rng.integers(0, tx, N), rng.integers(0, ty, N)
-        if mode == 0:
-            ext = rng.integers(1, 3, (N, 2))
-        elif mode == 1:
-            ext = rng.integers(1, max(2, min(tx, ty)), (N, 2))
-        elif mode == 2:
-            ext = np.stack([np.full(N, tx), np.full(N, ty)], 1)
-        elif mode == 3:
-            ext = rng.integers(1, 6, (N, 2))
-        else:
-            ext = np.where(rng.random((N, 1)) < 0.02, max(tx, ty), rng.integers(1, 3, (N, 2)))
-        x0 = np.clip(cx - ext[:, 0] // 2, 0, tx - 1)
-        y0 = np.clip(cy - ext[:, 1] // 2, 0, ty - 1)
-        x1, y1 = np.clip(x0 + ext[:, 0], 1, tx), np.clip(y0 + ext[:, 1], 1, ty)
-        rect = np.stack([x0, y0, np.maximum(x1, x0 + 1), np.maximum(y1, y0 + 1)], 1).astype(np.int32)
-        vis = rng.random(N) < rng.choice([1.0, 0.9, 0.5, 0.05])
-        tiles = np.where(vis, (rect[:, 2] - rect[:, 0]) * (rect[:, 3] - rect[:, 1]), 0).astype(np.uint32)
-        if km == 0:
-            key = rng.uniform(0.3, 50.0, N).astype(np.float32).view(np.uint32)
-        elif km == 1:
-            key = np.full(N, np.float32(2.5).view(np.uint32))
-        elif km == 2:
-            key = rng.choice(np.array([1.0, 1.5, 3.0], np.float32), N).view(np.uint32)
-        else:
-            k = rng.normal(2.0, 0.01, N).astype(np.float32)
-            k[: max(1, N // 500)] = 90.0
-            k[-1] = 0.21
-            key = np.abs(k).astype(np.float32).view(np.uint32)
+    for done in range(8):
+        H, W, rect, tiles, key, what = hz.fuzz_config(rng)
         nb = int(rng.choice([0, 0, 2, 3]))
         poison = bool(rng.integers(0, 2))
-        if int(tiles.astype(np.int64).sum()) > 1_500_000:
-            continue
         r = hz.run_binning(rect, tiles, key, H, W, n_batched=nb, poison=poison)
         e = hz.expected(rect, tiles, key, H, W)
         for rr in (r if nb else [r]):
-            what = (seed, done, H, W, N, mode, km, nb)
-            assert rr["R"] == e["R"] and rr["overflow"] == 0, what
-            assert np.array_equal(rr["ranges"], e["ranges"]), what
-            assert np.array_equal(rr["vals"], e["vals"]), what
-            assert np.array_equal(rr["dkeys"], e["dkeys"]), what
-        done += 1
+            assert rr["R"] == e["R"] and rr["overflow"] == 0, (seed, done, what, nb)
+            assert np.array_equal(rr["ranges"], e["ranges"]), (seed, done, what, nb)
+            assert np.array_equal(rr["vals"], e["vals"]), (seed, done, what, nb)
+            assert np.array_equal(rr["dkeys"], e["dkeys"]), (seed, done, what, nb)
