@@ -970,6 +970,7 @@ __device__ __forceinline__ void bucket_sort_body(const BinArgs &a, void *geom, v
   BucketSrc S;
   S.ovf = l1tmp + (size_t)MAX_BUCKETS * BUCKET_REGION, S.ovf_cap = a.l1cap, S.rec = s_seg;
   uint4 mine[PER];
+  bool have_mine = false;  // `mine` holds this item's entries already (requested while the previous item was ranked)
   tr.mark();
   for (uint32_t par = 0; t < n_items; par ^= 1u) {
     // the next ticket: drawn now, published behind the first barrier that comes after the atomic has returned
@@ -999,10 +1000,12 @@ __device__ __forceinline__ void bucket_sort_body(const BinArgs &a, void *geom, v
     uint32_t first = 0, m = n, len = pad_grp(n), run_off = 0, used = 0;
     if (!skip && !is_slice) {
       if (n <= (uint32_t)BIN_CAP) {
-        // the thread's entries, every load issued before the first use
+        // the thread's entries, every load issued before the first use (unless they are here already)
+        if (!have_mine) {  // (uniform)
 #pragma unroll
-        for (int q = 0; q < PER; ++q)
-          if ((uint32_t)q * SORT_BLOCK < n) mine[q] = S.region[min((uint32_t)q * SORT_BLOCK + tid, n - 1)];  // (n <= BIN_CAP: all in the region)
+          for (int q = 0; q < PER; ++q)
+            if ((uint32_t)q * SORT_BLOCK < n) mine[q] = S.region[min((uint32_t)q * SORT_BLOCK + tid, n - 1)];  // (n <= BIN_CAP: all in the region)
+        }
 #pragma unroll
         for (int q = 0; q < PER; ++q)
           if ((uint32_t)q * SORT_BLOCK + tid < n) atomicAdd(&s_cur[sub_bin(mine[q].x, sm)], 1u);
@@ -1084,6 +1087,19 @@ __device__ __forceinline__ void bucket_sort_body(const BinArgs &a, void *geom, v
         // (a slice reads the bucket -- through its overflow records, if any -- twice: the counters are cleared here)
         for (uint32_t q = tid; q < n_gcnt; q += SORT_BLOCK) s_seg[q] = 0u;
         lds_barrier();
+      }
+    }
+    // The next item's entries, into the registers this item's have just left -- a bucket sorted whole is one contiguous
+    // read, and its words arrived behind the barriers above: the entries arrive while this item is ranked, instead
+    // of a memory round trip with nothing to do at the top of the next item.
+    {
+      const uint32_t nn = nxt.bi.y;
+      have_mine = tn < n_items && (nxt.w >> 31) == 0u && nn != 0u && nn <= (uint32_t)BIN_CAP && ((nxt.bi.z >> 16) & 255u) == 0u;
+      if (have_mine) {
+        const uint4 *__restrict__ rn = l1tmp + (size_t)(nxt.w & 0xffffu) * BUCKET_REGION;
+#pragma unroll
+        for (int q = 0; q < PER; ++q)
+          if ((uint32_t)q * SORT_BLOCK < nn) mine[q] = rn[min((uint32_t)q * SORT_BLOCK + tid, nn - 1)];
       }
     }
     if (skip) {
