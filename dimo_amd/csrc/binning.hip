@@ -1175,9 +1175,27 @@ __device__ __forceinline__ void level2_fill_body(const BinArgs &a, void *geom, v
   const uint32_t per_xcd = (n_grp + 7u) / 8u, g_end = min((xcd + 1u) * per_xcd, n_grp);
   uint32_t g = xcd * per_xcd + wg_in_xcd * (SORT_BLOCK / 64) + wave;
   typename Sorted<SSH>::T en_n = Sorted<SSH>::make(0u, 0ull);
-  uint32_t row_n = 0u, info_n = 0u;
+  uint32_t row_n = 0u, info_n = 0u, info_nn = 0u;
   // (a row's first `ntile` words are all there is: the other lanes do not ask for theirs)
   if (g < g_end) en_n = l1list[(size_t)g * GRP + lane], row_n = lane < ntile ? grpbase[(size_t)g * GRP + lane] : 0u, info_n = grpinfo[g];
+  if (g + gstride < g_end) info_nn = grpinfo[g + gstride];  // (a group's word is known TWO groups ahead: see the loop)
+  // The unit rows of the supertile's earlier buckets, summed per tile (lanes [0, ntile)): requested one group ahead --
+  // the first eight rows, what a supertile's depth bins come to; a supertile with more units (slices) fetches the rest
+  // when it gets there.
+  auto unit_rows_request = [&](uint32_t info_w, uint32_t (&v)[8]) {
+    const uint32_t unit = info_w & 0xfffu, unit0 = (info_w >> 12) & 0xfffu;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] = lane < ntile && unit0 + r < unit ? cntu[(size_t)(unit0 + r) * GRP + lane] : 0u;
+  };
+  auto unit_rows_sum = [&](uint32_t info_w, const uint32_t (&v)[8]) {
+    const uint32_t unit = info_w & 0xfffu, unit0 = (info_w >> 12) & 0xfffu;
+    uint32_t c = 0;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) c += v[r];
+    if (lane < ntile)
+      for (uint32_t u = unit0 + 8; u < unit; ++u) c += cntu[(size_t)u * GRP + lane];
+    return c;
+  };
   const uint32_t R = total[0];
   const bool fits = R <= a.R_cap;
   // exclusive scan of the tile totals, by every workgroup itself -- thread t owns tiles [t K, (t + 1) K)
@@ -1230,32 +1248,33 @@ __device__ __forceinline__ void level2_fill_body(const BinArgs &a, void *geom, v
   }
   lds_barrier();  // (the tile starts are complete)
   tr.mark();
+  uint32_t csum_n = 0;  // the unit rows' sum of the group at hand
+  {
+    uint32_t v[8];
+    unit_rows_request(info_n, v);
+    csum_n = g < g_end ? unit_rows_sum(info_n, v) : 0u;
+  }
   for (; g < g_end; g += gstride) {
     const typename Sorted<SSH>::T en = en_n;
-    const uint32_t row = row_n, info = info_n;
-    {  // the next group of this wave
+    const uint32_t row = row_n, info = info_n, csum = csum_n;
+    uint32_t vn[8];
+    {  // the next group of this wave: its entries and row; its unit rows (its word arrived a group ago); the word of the one behind it
       const uint32_t gn = g + gstride;
+      info_n = info_nn;
       if (gn < g_end) {
         en_n = l1list[(size_t)gn * GRP + lane];
         row_n = lane < ntile ? grpbase[(size_t)gn * GRP + lane] : 0u;
-        info_n = grpinfo[gn];
+        unit_rows_request(info_n, vn);
+        if (gn + gstride < g_end) info_nn = grpinfo[gn + gstride];
       }
     }
-    const uint32_t unit = info & 0xfffu, unit0 = (info >> 12) & 0xfffu, sup = info >> 24;
+    const uint32_t sup = info >> 24;
     const int tx0 = (int)((sup % (uint32_t)a.gi.stx) << SSH), ty0 = (int)((sup / (uint32_t)a.gi.stx) << SSH);
     const int my_tx = tx0 + (lane & (ss - 1)), my_ty = ty0 + (lane >> SSH);
     const bool my_in = lane < ntile && my_tx < tiles_x && my_ty < tiles_y;
     const u64 mask = Sorted<SSH>::mask(en);
     // lane j: the next free slot of tile j = tile start + the supertile's earlier units + the unit's earlier groups
-    uint32_t c = row;
-    if (lane < ntile)
-      for (uint32_t u0 = unit0; u0 < unit; u0 += 8) {
-        uint32_t v[8];
-#pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] = u0 + r < unit ? cntu[(size_t)(u0 + r) * GRP + lane] : 0u;
-#pragma unroll
-        for (int r = 0; r < 8; ++r) c += v[r];
-      }
+    uint32_t c = row + csum;
     if (my_in) c += s_ts[my_ty * tiles_x + my_tx];
     if (fits) {  // (uniform: every instance has a slot)
       const uint32_t mlo = (uint32_t)mask, mhi = (uint32_t)(mask >> 32);
@@ -1274,6 +1293,7 @@ __device__ __forceinline__ void level2_fill_body(const BinArgs &a, void *geom, v
         if (cov && pos < a.R_cap) vals[pos] = en.x;
       }
     }
+    if (g + gstride < g_end) csum_n = unit_rows_sum(info_n, vn);  // (requested above: arrived behind the tile steps)
   }
   if (blockIdx.x == 0) {
     // ---- the blend forward's dispatch order: tiles by descending list length (a counting sort over 256 classes of
