@@ -219,10 +219,10 @@ def test_depth_sort_with_256_bins_above_400k_gaussians():
     _check_forward(sc, cam, (0.1, 0.1, 0.1), 0)
 
 
-@pytest.mark.parametrize("H,W", [(1040, 2048), (1296, 1296)])
+@pytest.mark.parametrize("H,W", [(1040, 2048), (1296, 1296), (2048, 2048)])  # (the last: the largest image allowed, 16384 tiles)
 def test_images_with_more_than_4096_tiles(H, W):
     """8 x 8-tile supertiles (ss_shift 3: 64-bit tile masks, 16-byte sorted entries) and more than 4096 tiles: the
-    fill keeps every tile's first slot in dynamically sized LDS (33 KB at 8320 tiles)."""
+    fill keeps every tile's first slot in dynamically sized LDS (33 KB at 8320 tiles, 64 KB at 16384)."""
     cam = camera_np(15.0, elevation=-5, W=W, H=H)
     sc = random_scene(6000, seed=77, scale=0.02)
     _check_forward(sc, cam, (0.0, 0.0, 0.0), 0)
