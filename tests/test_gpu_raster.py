@@ -228,6 +228,15 @@ def test_images_with_more_than_4096_tiles(H, W):
     _check_forward(sc, cam, (0.0, 0.0, 0.0), 0)
 
 
+def test_more_than_two_million_gaussians_are_refused():
+    """A level-1 workgroup walks at most 8 blocks of 256 Gaussians and a render has at most 1024 of them (binning.hip:
+    MAX_L1_PER, MAX_SEG): beyond 2 097 152 Gaussians per render the binning returns DIMO_E_ARG, no launch."""
+    cam = camera_np(0.0, W=64, H=64)
+    sc = random_scene(2_097_153 + 255, seed=1, scale=0.001)
+    with pytest.raises(RuntimeError):
+        _run_hip(sc, cam, (0, 0, 0), 0)
+
+
 def test_image_beyond_the_supertile_grid_is_refused():
     """More than 256 supertiles of 8 x 8 tiles (16384 tiles, e.g. above 2048^2 pixels): DIMO_E_ARG, no launch."""
     cam = camera_np(0.0, W=2064, H=2064)
