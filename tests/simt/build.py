@@ -13,7 +13,6 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.normpath(os.path.join(HERE, "..", ".."))
 CSRC = os.path.join(ROOT, "dimo_amd", "csrc")
 OUT = os.path.join(HERE, "_build")
-LIB = os.path.join(OUT, "libbinning_emu.so")
 
 def _place_tile_asm():
     text = open(os.path.join(CSRC, "binning.hip")).read()
@@ -44,25 +43,40 @@ def _transformed(name):
     return text
 
 
-def build(force=False):
-    srcs = [os.path.join(CSRC, n) for n in SUBST] + [os.path.join(HERE, n) for n in
-            ("runtime.cpp", "binning_emu.cpp", "build.py", os.path.join("shim", "hip", "hip_runtime.h"))] + \
+# emulated libraries: name -> (.hip sources of dimo_amd/csrc it compiles, its driver)
+TARGETS = {
+    "binning": (["binning.hip"], "binning_emu.cpp"),
+    "points": (["knn.hip", "fps.hip"], "points_emu.cpp"),  # KNN / distCUDA2 / farthest point sampling
+}
+SUBST.setdefault("knn.hip", [])
+SUBST.setdefault("fps.hip", [])
+
+
+def build(force=False, target="binning"):
+    hips, driver = TARGETS[target]
+    lib = os.path.join(OUT, "lib%s_emu.so" % target)
+    srcs = [os.path.join(CSRC, n) for n in ["common.hpp"] + hips] + [os.path.join(HERE, n) for n in
+            ("runtime.cpp", driver, "build.py", os.path.join("shim", "hip", "hip_runtime.h"))] + \
            [os.path.join(ROOT, "include", "dimo_hip.h")]
-    if not force and os.path.exists(LIB) and all(os.path.getmtime(s) <= os.path.getmtime(LIB) for s in srcs):
-        return LIB
-    # the transformed sources keep their relative include paths: _build/src/dimo_amd/csrc/{common.hpp, binning_src.inc}
+    if not force and os.path.exists(lib) and all(os.path.getmtime(s) <= os.path.getmtime(lib) for s in srcs):
+        return lib
+    # the transformed sources keep their relative include paths: _build/src/dimo_amd/csrc/{common.hpp, <name>_src.inc}
     d = os.path.join(OUT, "src", "dimo_amd", "csrc")
     os.makedirs(d, exist_ok=True)
     os.makedirs(os.path.join(OUT, "src", "include"), exist_ok=True)
     open(os.path.join(d, "common.hpp"), "w").write(_transformed("common.hpp"))
-    open(os.path.join(d, "binning_src.inc"), "w").write(_transformed("binning.hip"))
+    for h in hips:
+        open(os.path.join(d, h.replace(".hip", "_src.inc")), "w").write(_transformed(h))
     open(os.path.join(OUT, "src", "include", "dimo_hip.h"), "w").write(open(os.path.join(ROOT, "include", "dimo_hip.h")).read())
-    cmd = ["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-pthread", "-fno-omit-frame-pointer",
+    # (-ffp-contract=off: knn.hip and fps.hip are built that way for the GPU too -- dimo_amd/csrc/build.py -- so that their
+    # distances are bit for bit the oracle's)
+    cmd = ["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-pthread", "-fno-omit-frame-pointer", "-ffp-contract=off",
            "-I", os.path.join(HERE, "shim"), "-I", d, "-Wno-unused-function",
-           os.path.join(HERE, "runtime.cpp"), os.path.join(HERE, "binning_emu.cpp"), "-o", LIB]
+           os.path.join(HERE, "runtime.cpp"), os.path.join(HERE, driver), "-o", lib]
     subprocess.check_call(cmd)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force=True))
+    for t in TARGETS:
+        print(build(force=True, target=t))

@@ -14,7 +14,7 @@ PRE_BLOCK = 256
 def lib():
     global _lib
     if _lib is None:
-        L = C.CDLL(_build.build())
+        L = C.CDLL(_build.build(target="binning"))
         L.simt_geom_layout.argtypes = [C.c_int, C.POINTER(C.c_size_t)]
         L.simt_bin_layout.argtypes = [C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_size_t)]
         L.simt_supertile_shift.argtypes = [C.c_int, C.c_int]

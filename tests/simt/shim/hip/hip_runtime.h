@@ -9,6 +9,7 @@
 // deadlock instead of hanging.  Workgroups of a launch run in any order on a pool of OS threads; global atomics are
 // real atomics.  Timing, memory-model races inside a wave and LDS bank behaviour are NOT modelled.
 #pragma once
+#include <math.h>
 #include <stddef.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -33,12 +34,15 @@ struct float2 { float x, y; };
 struct float4 { float x, y, z, w; };
 static inline uint2 make_uint2(uint32_t x, uint32_t y) { return uint2{x, y}; }
 static inline uint4 make_uint4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { return uint4{x, y, z, w}; }
+static inline float2 make_float2(float x, float y) { return float2{x, y}; }
+static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
 
 typedef void *hipStream_t;
 typedef void *hipEvent_t;
 enum hipError_t { hipSuccess = 0, hipErrorUnknown = 999 };
 static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+static inline hipError_t hipMemsetAsync(void *p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
 #define HIP_SYMBOL(x) (&(x))
 template <class T>
 static inline hipError_t hipMemcpyFromSymbol(void *dst, T *sym, size_t n) { memcpy(dst, sym, n); return hipSuccess; }
@@ -98,6 +102,28 @@ static inline int __shfl_down(int x, int delta, int width = 64) {
   const uint64_t *v = simt::wave_exchange((uint32_t)x);
   return l + delta < 64 ? (int)(uint32_t)v[l + delta] : x;
 }
+static inline uint32_t __float_as_uint(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static inline float __uint_as_float(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+static inline int __float_as_int(float f) { int u; memcpy(&u, &f, 4); return u; }
+static inline float __int_as_float(int u) { float f; memcpy(&f, &u, 4); return f; }
+static inline double __longlong_as_double(long long x) { double d; memcpy(&d, &x, 8); return d; }
+static inline long long __double_as_longlong(double d) { long long x; memcpy(&x, &d, 8); return x; }
+static inline double __hiloint2double(int hi, int lo) { return __longlong_as_double((long long)(((unsigned long long)(uint32_t)hi << 32) | (uint32_t)lo)); }
+static inline int __double2hiint(double d) { return (int)((unsigned long long)__double_as_longlong(d) >> 32); }
+static inline int __double2loint(double d) { return (int)(uint32_t)__double_as_longlong(d); }
+static inline float __shfl_xor(float x, int mask, int width = 64) { return __int_as_float(__shfl_xor(__float_as_int(x), mask, width)); }
+static inline float __shfl_up(float x, int d, int width = 64) { return __int_as_float(__shfl_up(__float_as_int(x), d, width)); }
+static inline float __shfl_down(float x, int d, int width = 64) { return __int_as_float(__shfl_down(__float_as_int(x), d, width)); }
+static inline unsigned __shfl_xor(unsigned x, int mask, int width = 64) { return (unsigned)__shfl_xor((int)x, mask, width); }
+static inline unsigned __shfl_down(unsigned x, int d, int width = 64) { return (unsigned)__shfl_down((int)x, d, width); }
+static inline unsigned __shfl_up(unsigned x, int d, int width = 64) { return (unsigned)__shfl_up((int)x, d, width); }
+static inline long long __shfl_xor(long long x, int mask, int width = 64) {
+  const uint64_t *v = simt::wave_exchange((uint64_t)x);
+  (void)width;
+  return (long long)v[(simt::lane_id() ^ mask) & 63];
+}
+static inline double __shfl_xor(double x, int mask, int width = 64) { return __longlong_as_double(__shfl_xor(__double_as_longlong(x), mask, width)); }
+#define __builtin_amdgcn_ballot_w64(p) __ballot((p) ? 1 : 0)
 static inline int simt_readlane(int x, int lane) { return (int)(uint32_t)simt::wave_exchange((uint32_t)x)[lane & 63]; }
 static inline uint32_t simt_mbcnt_lo(uint32_t mask, uint32_t base) {
   const int l = simt::lane_id();
@@ -140,6 +166,12 @@ template <class T>
 static inline T atomicMax(T *p, T v) {
   T o = __atomic_load_n(p, __ATOMIC_RELAXED);
   while (o < v && !__atomic_compare_exchange_n(p, &o, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+  return o;
+}
+template <class T>
+static inline T atomicMin(T *p, T v) {
+  T o = __atomic_load_n(p, __ATOMIC_RELAXED);
+  while (o > v && !__atomic_compare_exchange_n(p, &o, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
   return o;
 }
 template <class T>
