@@ -47,15 +47,19 @@ def _transformed(name):
 TARGETS = {
     "binning": (["binning.hip"], "binning_emu.cpp"),
     "points": (["knn.hip", "fps.hip"], "points_emu.cpp"),  # KNN / distCUDA2 / farthest point sampling
+    "project": (["preprocess.hip"], "project_emu.cpp"),    # the projection kernel (forward and backward)
 }
 SUBST.setdefault("knn.hip", [])
 SUBST.setdefault("fps.hip", [])
+SUBST.setdefault("preprocess.hip", [])
+SUBST.setdefault("proj_math.hpp", [])
+HEADERS = ["common.hpp", "proj_math.hpp"]  # copied beside the sources (substitutions applied)
 
 
 def build(force=False, target="binning"):
     hips, driver = TARGETS[target]
     lib = os.path.join(OUT, "lib%s_emu.so" % target)
-    srcs = [os.path.join(CSRC, n) for n in ["common.hpp"] + hips] + [os.path.join(HERE, n) for n in
+    srcs = [os.path.join(CSRC, n) for n in HEADERS + hips] + [os.path.join(HERE, n) for n in
             ("runtime.cpp", driver, "build.py", os.path.join("shim", "hip", "hip_runtime.h"))] + \
            [os.path.join(ROOT, "include", "dimo_hip.h")]
     if not force and os.path.exists(lib) and all(os.path.getmtime(s) <= os.path.getmtime(lib) for s in srcs):
@@ -64,7 +68,8 @@ def build(force=False, target="binning"):
     d = os.path.join(OUT, "src", "dimo_amd", "csrc")
     os.makedirs(d, exist_ok=True)
     os.makedirs(os.path.join(OUT, "src", "include"), exist_ok=True)
-    open(os.path.join(d, "common.hpp"), "w").write(_transformed("common.hpp"))
+    for h in HEADERS:
+        open(os.path.join(d, h), "w").write(_transformed(h))
     for h in hips:
         open(os.path.join(d, h.replace(".hip", "_src.inc")), "w").write(_transformed(h))
     open(os.path.join(OUT, "src", "include", "dimo_hip.h"), "w").write(open(os.path.join(ROOT, "include", "dimo_hip.h")).read())

@@ -22,6 +22,7 @@
 #define __host__
 #define __forceinline__ inline
 #define __shared__ static thread_local
+#define __constant__ static const
 #define __launch_bounds__(...)
 
 struct dim3 {
@@ -43,6 +44,9 @@ enum hipError_t { hipSuccess = 0, hipErrorUnknown = 999 };
 static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 static inline hipError_t hipMemsetAsync(void *p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
+enum hipMemcpyKind { hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3 };
+static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 #define HIP_SYMBOL(x) (&(x))
 template <class T>
 static inline hipError_t hipMemcpyFromSymbol(void *dst, T *sym, size_t n) { memcpy(dst, sym, n); return hipSuccess; }
