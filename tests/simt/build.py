@@ -39,7 +39,7 @@ def _transformed(name):
     for old, new in SUBST[name]:
         assert text.count(old) >= 1, (name, old)
         text = text.replace(old, new)
-    assert "asm" not in text.replace("__builtin_amdgcn", ""), name + ": an inline-asm statement without a substitution"
+    assert "asm volatile(" not in text and "asm(" not in text, name + ": an inline-asm statement without a substitution"
     return text
 
 
@@ -48,12 +48,28 @@ TARGETS = {
     "binning": (["binning.hip"], "binning_emu.cpp"),
     "points": (["knn.hip", "fps.hip"], "points_emu.cpp"),  # KNN / distCUDA2 / farthest point sampling
     "project": (["preprocess.hip"], "project_emu.cpp"),    # the projection kernel (forward and backward)
+    "deform": (["deform.hip", "adam.hip"], "deform_emu.cpp"),  # skinning forward / backward, the flat Adam step
 }
 SUBST.setdefault("knn.hip", [])
 SUBST.setdefault("fps.hip", [])
 SUBST.setdefault("preprocess.hip", [])
 SUBST.setdefault("proj_math.hpp", [])
-HEADERS = ["common.hpp", "proj_math.hpp"]  # copied beside the sources (substitutions applied)
+SUBST["deform.hip"] = [  # extern __shared__ arrays -> the workgroup's dynamic LDS of the emulation
+    ("extern __shared__ __attribute__((aligned(16))) float s_cp[];", "HIP_DYNAMIC_SHARED(float, s_cp)"),
+    ("extern __shared__ __attribute__((aligned(16))) float smem[];", "HIP_DYNAMIC_SHARED(float, smem)"),
+]
+SUBST.setdefault("adam.hip", [])
+SUBST.setdefault("deform_body.hpp", [])
+# wave_reduce16's asm block (one per value count) -> the shim's instruction-for-instruction spelling of it
+SUBST["wave_ops.hpp"] = [
+    ('asm volatile("s_nop 1\\n\\t" DIMO_RA(0, 8) DIMO_RA(1, 9) DIMO_RA(2, 10) DIMO_RA(3, 11) DIMO_RA(4, 12) DIMO_RA(5, 13)\n'
+     '                 DIMO_RA(6, 14) DIMO_RA(7, 15) DIMO_RTAIL DIMO_ROPS);', "simt_wave_reduce16<16>(v);"),
+    ('asm volatile("s_nop 1\\n\\t" DIMO_RA(0, 8) DIMO_RA(1, 9) DIMO_RA(2, 10) DIMO_RA(3, 11) DIMO_RA(4, 12) DIMO_RA1(5)\n'
+     '                 DIMO_RA1(6) DIMO_RA1(7) DIMO_RTAIL DIMO_ROPS);', "simt_wave_reduce16<13>(v);"),
+    ('asm volatile("s_nop 1\\n\\t" DIMO_RA(0, 8) DIMO_RA(1, 9) DIMO_RA1(2) DIMO_RA1(3) DIMO_RA1(4) DIMO_RA1(5) DIMO_RA1(6)\n'
+     '                 DIMO_RA1(7) DIMO_RTAIL DIMO_ROPS);', "simt_wave_reduce16<10>(v);"),
+]
+HEADERS = ["common.hpp", "proj_math.hpp", "wave_ops.hpp", "deform_body.hpp"]  # copied beside the sources (substitutions applied)
 
 
 def build(force=False, target="binning"):

@@ -17,6 +17,9 @@
 
 #include <functional>
 
+#define __expf expf  // (the device's fast exponential: a few ulp from expf; tolerances, not bits, for float kernels)
+#define __logf logf
+
 #define __global__
 #define __device__
 #define __host__
@@ -85,6 +88,7 @@ static inline void __syncthreads() { simt::wg_barrier(); }
 static inline int __syncthreads_or(int v) { return simt::wg_barrier_or(v); }
 static inline void __threadfence_block() {}
 static inline void __threadfence() {}
+static inline void __threadfence_system() {}
 static inline unsigned long long __ballot(int pred) { return simt::wave_ballot(pred != 0); }
 static inline int __shfl(int x, int src, int width = 64) {
   (void)width;
@@ -150,6 +154,67 @@ static inline void simt_place_tile(uint32_t mhalf, int jb, int j, uint32_t c, ui
   const uint32_t pos = first + (uint32_t)__builtin_popcountll(l ? (bal & (~0ull >> (64 - l))) : 0ull);
   if (cov) vals[pos] = id;
 }
+// DPP source lane of `lane` under the control word (quad_perm 0x00-0xff, row_shl 0x101-0x10f, row_shr 0x111-0x11f,
+// row_ror 0x121-0x12f); -1 = out of the row (the lane is then left alone unless bound_ctrl is set)
+static inline int simt_dpp_source(int lane, int ctrl) {
+  const int row = lane & ~15, pos = lane & 15;
+  if (ctrl < 0x100) return (lane & ~3) | ((ctrl >> (2 * (lane & 3))) & 3);
+  const int n = ctrl & 15, kind = ctrl & ~15;
+  if (kind == 0x100) return pos + n < 16 ? row | (pos + n) : -1;
+  if (kind == 0x110) return pos - n >= 0 ? row | (pos - n) : -1;
+  if (kind == 0x120) return row | ((pos - n) & 15);
+  abort();
+}
+static inline bool simt_dpp_enabled(int lane, int row_mask, int bank_mask) {
+  return ((row_mask >> (lane >> 4)) & 1) && ((bank_mask >> ((lane & 15) >> 2)) & 1);
+}
+static inline int simt_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
+  const int l = simt::lane_id();
+  const uint64_t *v = simt::wave_exchange((uint32_t)src);
+  const int from = simt_dpp_source(l, ctrl);
+  if (!simt_dpp_enabled(l, row_mask, bank_mask)) return old;
+  if (from < 0) return bound_ctrl ? 0 : old;
+  return (int)(uint32_t)v[from];
+}
+// v_add_f32_dpp dst, src0, src1 <ctrl> row_mask:0xf bank_mask:<bm>: dst = dpp(src0) + src1 in the enabled lanes whose
+// source is inside the row; the others keep dst
+static inline void simt_add_f32_dpp(float &dst, float src0, float src1, int ctrl, int bank_mask) {
+  const int l = simt::lane_id();
+  const uint64_t *v = simt::wave_exchange(__float_as_uint(src0));
+  const int from = simt_dpp_source(l, ctrl);
+  if (simt_dpp_enabled(l, 0xf, bank_mask) && from >= 0) dst = __uint_as_float((uint32_t)v[from]) + src1;
+}
+// v_permlane32_swap_b32 a, b: a's lanes 32-63 trade places with b's lanes 0-31; v_permlane16_swap_b32 a, b: a's odd
+// rows of 16 trade places with b's even rows
+static inline void simt_permlane_swap(float &a, float &b, int half) {
+  const int l = simt::lane_id();
+  const uint64_t *v = simt::wave_exchange(((uint64_t)__float_as_uint(a) << 32) | __float_as_uint(b));
+  if (l & half) a = __uint_as_float((uint32_t)v[l - half]);        // b of the partner
+  else b = __uint_as_float((uint32_t)(v[l + half] >> 32));          // a of the partner
+}
+// wave_ops.hpp's wave_reduce16, instruction for instruction (its asm block spelled as calls; the s_nop wait states
+// have no meaning here).  NV as there: the first halving step leaves out the values that are not in use.
+template <int NV>
+static inline void simt_wave_reduce16(float (&v)[16]) {
+  constexpr int ROR8 = 0x128, SHL4 = 0x104, SHR4 = 0x114;
+  for (int s = 0; s < 8; ++s) {
+    simt_add_f32_dpp(v[s], v[s], v[s], ROR8, 0x3);
+    if (s + 8 < NV) simt_add_f32_dpp(v[s], v[s + 8], v[s + 8], ROR8, 0xc);
+  }
+  for (int t = 0; t < 4; ++t) {
+    simt_add_f32_dpp(v[t], v[t], v[t], SHL4, 0x5);
+    simt_add_f32_dpp(v[t], v[t + 4], v[t + 4], SHR4, 0xa);
+  }
+  simt_permlane_swap(v[0], v[2], 32);
+  simt_permlane_swap(v[1], v[3], 32);
+  v[0] = v[0] + v[2];
+  v[1] = v[1] + v[3];
+  simt_permlane_swap(v[0], v[1], 16);
+  v[0] = v[0] + v[1];
+  simt_add_f32_dpp(v[1], v[0], v[0], 0xB1, 0xf);
+  simt_add_f32_dpp(v[0], v[1], v[1], 0x4E, 0xf);
+}
+#define __builtin_amdgcn_update_dpp simt_update_dpp
 #define __builtin_amdgcn_readlane simt_readlane
 #define __builtin_amdgcn_mbcnt_lo simt_mbcnt_lo
 #define __builtin_amdgcn_mbcnt_hi simt_mbcnt_hi
@@ -163,7 +228,16 @@ static inline int __clz(int x) { return x ? __builtin_clz((unsigned)x) : 32; }
 
 template <class T>
 static inline T atomicAdd(T *p, T v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+static inline float atomicAdd(float *p, float v) {  // (the order of the adds is the schedule's, as on the device)
+  uint32_t *u = reinterpret_cast<uint32_t *>(p), o = __atomic_load_n(u, __ATOMIC_RELAXED);
+  while (!__atomic_compare_exchange_n(u, &o, __float_as_uint(__uint_as_float(o) + v), true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+  return __uint_as_float(o);
+}
+static inline float unsafeAtomicAdd(float *p, float v) { return atomicAdd(p, v); }
 #define __HIP_MEMORY_SCOPE_AGENT 4
+#define __HIP_MEMORY_SCOPE_SYSTEM 5
+template <class T>
+static inline void __hip_atomic_store(T *p, T v, int order, int) { __atomic_store_n(p, v, order); }
 template <class T>
 static inline T __hip_atomic_load(const T *p, int, int) { return __atomic_load_n(p, __ATOMIC_RELAXED); }
 template <class T>
