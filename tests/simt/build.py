@@ -49,7 +49,18 @@ TARGETS = {
     "points": (["knn.hip", "fps.hip"], "points_emu.cpp"),  # KNN / distCUDA2 / farthest point sampling
     "project": (["preprocess.hip"], "project_emu.cpp"),    # the projection kernel (forward and backward)
     "deform": (["deform.hip", "adam.hip"], "deform_emu.cpp"),  # skinning forward / backward, the flat Adam step
+    # the rasterizer's whole C ABI: projection, binning, blend forward / backward, projection backward -- one
+    # translation unit per source, as on the GPU (SEPARATE below)
+    "raster": (["preprocess.hip", "binning.hip", "blend.hip"], "raster_emu.cpp"),
 }
+SEPARATE = {"raster"}
+SUBST["blend.hip"] = [
+    # (a register-allocation hint: an empty asm statement with a VGPR constraint)
+    ('if (k < (NORMAL ? 13 : 10)) asm volatile("" : "+v"(v[k]));', ""),
+    # the trace's hardware-id reads (trace builds only; the branch is dead here)
+    ('asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));', "hw = 0;"),
+    ('asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));', "xcc = 0;"),
+]
 SUBST.setdefault("knn.hip", [])
 SUBST.setdefault("fps.hip", [])
 SUBST.setdefault("preprocess.hip", [])
@@ -91,9 +102,14 @@ def build(force=False, target="binning"):
     open(os.path.join(OUT, "src", "include", "dimo_hip.h"), "w").write(open(os.path.join(ROOT, "include", "dimo_hip.h")).read())
     # (-ffp-contract=off: knn.hip and fps.hip are built that way for the GPU too -- dimo_amd/csrc/build.py -- so that their
     # distances are bit for bit the oracle's)
+    units = []
+    if target in SEPARATE:
+        for h in hips:
+            units.append(os.path.join(d, h.replace(".hip", "_tu.cpp")))
+            open(units[-1], "w").write('#include "%s"\n' % h.replace(".hip", "_src.inc"))
     cmd = ["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-pthread", "-fno-omit-frame-pointer", "-ffp-contract=off",
            "-I", os.path.join(HERE, "shim"), "-I", d, "-Wno-unused-function",
-           os.path.join(HERE, "runtime.cpp"), os.path.join(HERE, driver), "-o", lib]
+           os.path.join(HERE, "runtime.cpp"), os.path.join(HERE, driver)] + units + ["-o", lib]
     subprocess.check_call(cmd)
     return lib
 

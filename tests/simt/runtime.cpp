@@ -139,11 +139,12 @@ uint64_t wave_ballot(bool pred) {
   return m & part;
 }
 
-int wg_barrier_or(int v) {
+// the barrier with a vote: returns how many of the arriving threads passed a nonzero v
+int wg_barrier_count(int v) {
   Fiber *me = cur;
   Workgroup *g = me->wg;
   const unsigned ph = g->bar_phase;
-  if (v) g->bar_or[ph & 1] = 1;
+  if (v) g->bar_or[ph & 1] += 1;
   g->progress++;
   if (++g->bar_arrived == g->live) {
     g->bar_arrived = 0;
@@ -154,7 +155,8 @@ int wg_barrier_or(int v) {
   }
   return g->bar_or[ph & 1];
 }
-void wg_barrier() { (void)wg_barrier_or(0); }
+int wg_barrier_or(int v) { return wg_barrier_count(v) != 0; }
+void wg_barrier() { (void)wg_barrier_count(0); }
 
 static void fiber_main() {
   Fiber *me = cur;

@@ -70,6 +70,7 @@ const uint64_t *wave_exchange(uint64_t v);
 uint64_t wave_ballot(bool pred);
 void wg_barrier();
 int wg_barrier_or(int v);
+int wg_barrier_count(int v);
 void launch(dim3 grid, dim3 block, size_t dynamic_lds_bytes, const std::function<void()> &body);
 void *dynamic_lds();  // the workgroup's dynamically sized LDS (extern __shared__)
 }  // namespace simt
@@ -86,6 +87,7 @@ static inline hipError_t hipFuncSetAttribute(const void *, hipFuncAttribute, int
 
 static inline void __syncthreads() { simt::wg_barrier(); }
 static inline int __syncthreads_or(int v) { return simt::wg_barrier_or(v); }
+static inline int __syncthreads_count(int pred) { return simt::wg_barrier_count(pred); }
 static inline void __threadfence_block() {}
 static inline void __threadfence() {}
 static inline void __threadfence_system() {}
@@ -214,6 +216,16 @@ static inline void simt_wave_reduce16(float (&v)[16]) {
   simt_add_f32_dpp(v[1], v[0], v[0], 0xB1, 0xf);
   simt_add_f32_dpp(v[0], v[1], v[1], 0x4E, 0xf);
 }
+// v_readfirstlane_b32: the value of the lowest live lane that takes part (the kernels use it on wave-uniform values)
+static inline int simt_readfirstlane(int x) {
+  const unsigned long long live = __ballot(1);
+  return (int)(uint32_t)simt::wave_exchange((uint32_t)x)[__builtin_ctzll(live)];
+}
+#define __builtin_amdgcn_readfirstlane simt_readfirstlane
+#define __builtin_amdgcn_sched_barrier(x) ((void)0)
+#define __builtin_amdgcn_exp2f exp2f  // (v_exp_f32 / v_rcp_f32 are 1 ulp: tolerances, not bits)
+#define __builtin_amdgcn_rcpf(x) (1.0f / (x))
+#define __builtin_amdgcn_rsqf(x) (1.0f / sqrtf(x))
 #define __builtin_amdgcn_update_dpp simt_update_dpp
 #define __builtin_amdgcn_readlane simt_readlane
 #define __builtin_amdgcn_mbcnt_lo simt_mbcnt_lo
