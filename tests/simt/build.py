@@ -53,7 +53,15 @@ TARGETS = {
     # translation unit per source, as on the GPU (SEPARATE below)
     "raster": (["preprocess.hip", "binning.hip", "blend.hip"], "raster_emu.cpp"),
 }
-SEPARATE = {"raster"}
+# the image losses: SSIM (forward, backward, fused), the other image terms, SSIM + every term in one tile pass
+TARGETS["losses"] = (["ssim.hip", "image_loss.hip"], "losses_emu.cpp")
+SEPARATE = {"raster", "losses"}
+SUBST["ssim.hip"] = [
+    # the window's taps moved from SGPRs into VGPRs
+    ('asm volatile("v_mov_b32 %0, %1" : "=v"(v.w[k]) : "s"(win.w[k]));', "v.w[k] = win.w[k];"),
+]
+SUBST.setdefault("image_loss.hip", [])
+SUBST.setdefault("loss_terms.hpp", [])
 SUBST["blend.hip"] = [
     # (a register-allocation hint: an empty asm statement with a VGPR constraint)
     ('if (k < (NORMAL ? 13 : 10)) asm volatile("" : "+v"(v[k]));', ""),
@@ -80,7 +88,7 @@ SUBST["wave_ops.hpp"] = [
     ('asm volatile("s_nop 1\\n\\t" DIMO_RA(0, 8) DIMO_RA(1, 9) DIMO_RA1(2) DIMO_RA1(3) DIMO_RA1(4) DIMO_RA1(5) DIMO_RA1(6)\n'
      '                 DIMO_RA1(7) DIMO_RTAIL DIMO_ROPS);', "simt_wave_reduce16<10>(v);"),
 ]
-HEADERS = ["common.hpp", "proj_math.hpp", "wave_ops.hpp", "deform_body.hpp"]  # copied beside the sources (substitutions applied)
+HEADERS = ["common.hpp", "proj_math.hpp", "wave_ops.hpp", "deform_body.hpp", "loss_terms.hpp"]  # copied beside the sources (substitutions applied)
 
 
 def build(force=False, target="binning"):

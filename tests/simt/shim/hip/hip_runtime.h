@@ -157,10 +157,16 @@ static inline void simt_place_tile(uint32_t mhalf, int jb, int j, uint32_t c, ui
   if (cov) vals[pos] = id;
 }
 // DPP source lane of `lane` under the control word (quad_perm 0x00-0xff, row_shl 0x101-0x10f, row_shr 0x111-0x11f,
-// row_ror 0x121-0x12f); -1 = out of the row (the lane is then left alone unless bound_ctrl is set)
+// row_ror 0x121-0x12f, the wave shifts / rotates by one, the row mirrors); -1 = out of the row (the lane is then left alone unless bound_ctrl is set)
 static inline int simt_dpp_source(int lane, int ctrl) {
   const int row = lane & ~15, pos = lane & 15;
   if (ctrl < 0x100) return (lane & ~3) | ((ctrl >> (2 * (lane & 3))) & 3);
+  if (ctrl == 0x130) return lane + 1 < 64 ? lane + 1 : -1;  // wave_shl:1
+  if (ctrl == 0x134) return (lane + 1) & 63;                 // wave_rol:1
+  if (ctrl == 0x138) return lane - 1;                        // wave_shr:1 (-1 for lane 0)
+  if (ctrl == 0x13c) return (lane - 1) & 63;                 // wave_ror:1
+  if (ctrl == 0x140) return row | (15 - pos);                // row_mirror
+  if (ctrl == 0x141) return row | (pos & 8) | (7 - (pos & 7));  // row_half_mirror
   const int n = ctrl & 15, kind = ctrl & ~15;
   if (kind == 0x100) return pos + n < 16 ? row | (pos + n) : -1;
   if (kind == 0x110) return pos - n >= 0 ? row | (pos - n) : -1;
