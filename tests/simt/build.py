@@ -7,6 +7,7 @@ barrier and v_writelane_b32) by their emulation calls, and compiles with g++ int
 The .hip sources carry no host / emulation switches of their own.
 """
 import os
+import re
 import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -39,6 +40,8 @@ def _transformed(name):
     for old, new in SUBST[name]:
         assert text.count(old) >= 1, (name, old)
         text = text.replace(old, new)
+    # kernel<<<grid, block, lds, stream>>>(args) -> hipLaunchKernelGGL((kernel), grid, block, lds, stream, args)
+    text = re.sub(r"\b([A-Za-z_]\w*(?:<[^<>;]*>)?)<<<(.+?)>>>\(", r"hipLaunchKernelGGL((\1), \2, ", text)
     assert "asm volatile(" not in text and "asm(" not in text, name + ": an inline-asm statement without a substitution"
     return text
 
@@ -55,7 +58,15 @@ TARGETS = {
 }
 # the image losses: SSIM (forward, backward, fused), the other image terms, SSIM + every term in one tile pass
 TARGETS["losses"] = (["ssim.hip", "image_loss.hip"], "losses_emu.cpp")
-SEPARATE = {"raster", "losses"}
+# the TimeNet: forward, dgrad chain, weight gradients (fp32 MFMA: the builtins are wave rendezvous in the shim)
+TARGETS["timenet"] = (["timenet.hip"], "timenet_emu.cpp")
+SEPARATE = {"raster", "losses", "timenet"}
+SUBST["timenet.hip"] = [
+    # clang's vector extension -> GCC's
+    ("typedef float f32x4 __attribute__((ext_vector_type(4)));", "typedef float f32x4 __attribute__((vector_size(16)));"),
+    ("typedef float f32x16 __attribute__((ext_vector_type(16)));", "typedef float f32x16 __attribute__((vector_size(64)));"),
+    ('asm volatile("s_waitcnt lgkmcnt(0)\\n\\ts_barrier" ::: "memory");', "__syncthreads();"),
+]
 SUBST["ssim.hip"] = [
     # the window's taps moved from SGPRs into VGPRs
     ('asm volatile("v_mov_b32 %0, %1" : "=v"(v.w[k]) : "s"(win.w[k]));', "v.w[k] = win.w[k];"),

@@ -232,6 +232,55 @@ static inline int simt_readfirstlane(int x) {
 #define __builtin_amdgcn_exp2f exp2f  // (v_exp_f32 / v_rcp_f32 are 1 ulp: tolerances, not bits)
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))
 #define __builtin_amdgcn_rsqf(x) (1.0f / sqrtf(x))
+#define __builtin_amdgcn_s_setprio(x) ((void)0)
+// The fp32 MFMAs of the TimeNet kernels as wave rendezvous (CDNA3/4 ISA, matrix-core operand layouts; cbsz / abid /
+// blgp = 0 as the kernels pass them).  Every lane deposits its (a, b), then computes the result registers it owns.
+typedef float simt_f32x4 __attribute__((vector_size(16)));
+typedef float simt_f32x16 __attribute__((vector_size(64)));
+static inline const uint64_t *simt_mfma_operands(float a, float b) {
+  return simt::wave_exchange(((uint64_t)__float_as_uint(a) << 32) | __float_as_uint(b));
+}
+#define SIMT_A(l) __uint_as_float((uint32_t)(ab[l] >> 32))
+#define SIMT_B(l) __uint_as_float((uint32_t)ab[l])
+// v_mfma_f32_16x16x4_f32: lane l holds A[i = l % 16][k = l / 16], B[k = l / 16][j = l % 16]; register r of lane l is
+// D[i = 4 (l / 16) + r][j = l % 16]
+static inline simt_f32x4 simt_mfma_16x16x4(float a, float b, simt_f32x4 c, int, int, int) {
+  const int l = simt::lane_id(), j = l & 15;
+  const uint64_t *ab = simt_mfma_operands(a, b);
+  for (int r = 0; r < 4; ++r) {
+    const int i = 4 * (l >> 4) + r;
+    float s = c[r];
+    for (int k = 0; k < 4; ++k) s = fmaf(SIMT_A(16 * k + i), SIMT_B(16 * k + j), s);
+    c[r] = s;
+  }
+  return c;
+}
+// v_mfma_f32_32x32x2_f32: lane l holds A[i = l % 32][k = l / 32], B[k = l / 32][j = l % 32]; register r of lane l is
+// D[i = 8 (r / 4) + 4 (l / 32) + r % 4][j = l % 32]
+static inline simt_f32x16 simt_mfma_32x32x2(float a, float b, simt_f32x16 c, int, int, int) {
+  const int l = simt::lane_id(), j = l & 31;
+  const uint64_t *ab = simt_mfma_operands(a, b);
+  for (int r = 0; r < 16; ++r) {
+    const int i = 8 * (r >> 2) + 4 * (l >> 5) + (r & 3);
+    float s = c[r];
+    for (int k = 0; k < 2; ++k) s = fmaf(SIMT_A(32 * k + i), SIMT_B(32 * k + j), s);
+    c[r] = s;
+  }
+  return c;
+}
+// v_mfma_f32_4x4x1_16b_f32: sixteen 4x4x1 blocks, block = l / 4: lane l holds A_block[i = l % 4], B_block[j = l % 4];
+// register r of lane l is D_block[i = r][j = l % 4]
+static inline simt_f32x4 simt_mfma_4x4x1(float a, float b, simt_f32x4 c, int, int, int) {
+  const int l = simt::lane_id();
+  const uint64_t *ab = simt_mfma_operands(a, b);
+  for (int r = 0; r < 4; ++r) c[r] = fmaf(SIMT_A((l & ~3) + r), SIMT_B(l), c[r]);
+  return c;
+}
+#undef SIMT_A
+#undef SIMT_B
+#define __builtin_amdgcn_mfma_f32_16x16x4f32 simt_mfma_16x16x4
+#define __builtin_amdgcn_mfma_f32_32x32x2f32 simt_mfma_32x32x2
+#define __builtin_amdgcn_mfma_f32_4x4x1f32 simt_mfma_4x4x1
 #define __builtin_amdgcn_update_dpp simt_update_dpp
 #define __builtin_amdgcn_readlane simt_readlane
 #define __builtin_amdgcn_mbcnt_lo simt_mbcnt_lo
