@@ -60,7 +60,11 @@ TARGETS = {
 TARGETS["losses"] = (["ssim.hip", "image_loss.hip"], "losses_emu.cpp")
 # the TimeNet: forward, dgrad chain, weight gradients (fp32 MFMA: the builtins are wave rendezvous in the shim)
 TARGETS["timenet"] = (["timenet.hip"], "timenet_emu.cpp")
-SEPARATE = {"raster", "losses", "timenet"}
+# the native step executor over the batched forms of the kernels (streams and events are no-ops: a launch has run
+# when hipLaunchKernelGGL returns)
+TARGETS["step"] = (["executor.hip", "deform.hip", "preprocess.hip", "binning.hip", "blend.hip"], "step_emu.cpp")
+SEPARATE = {"raster", "losses", "timenet", "step"}
+SUBST.setdefault("executor.hip", [])
 SUBST["timenet.hip"] = [
     # clang's vector extension -> GCC's
     ("typedef float f32x4 __attribute__((ext_vector_type(4)));", "typedef float f32x4 __attribute__((vector_size(16)));"),

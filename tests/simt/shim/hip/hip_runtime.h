@@ -50,6 +50,24 @@ static inline hipError_t hipMemsetAsync(void *p, int v, size_t n, hipStream_t) {
 enum hipMemcpyKind { hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3 };
 static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+// Streams and events: a launch has run when hipLaunchKernelGGL returns, so every cross-stream dependency holds
+// trivially -- the executor's SCHEDULE is not what the emulation tests.  Handles are distinct heap words.
+enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2, hipStreamWaitValueGte = 0 };
+static inline hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
+static inline hipError_t hipDeviceGetStreamPriorityRange(int *lo, int *hi) { *lo = 0, *hi = 0; return hipSuccess; }
+static inline hipError_t hipStreamCreateWithPriority(hipStream_t *s, unsigned, int) { *s = new int(0); return hipSuccess; }
+static inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { *e = new int(0); return hipSuccess; }
+static inline hipError_t hipEventDestroy(hipEvent_t e) { delete static_cast<int *>(e); return hipSuccess; }
+static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
+static inline hipError_t hipStreamWriteValue32(hipStream_t, void *p, uint32_t v, unsigned) { *static_cast<uint32_t *>(p) = v; return hipSuccess; }
+static inline hipError_t hipStreamWaitValue32(hipStream_t, void *p, uint32_t v, unsigned, uint32_t mask) {
+  return ((*static_cast<uint32_t *>(p)) & mask) >= v ? hipSuccess : hipErrorUnknown;  // (written at enqueue: must hold)
+}
+static inline hipError_t hipMalloc(void **p, size_t n) { *p = malloc(n); return *p ? hipSuccess : hipErrorUnknown; }
+static inline hipError_t hipFree(void *p) { free(p); return hipSuccess; }
+static inline hipError_t hipMemset(void *p, int v, size_t n) { memset(p, v, n); return hipSuccess; }
 #define HIP_SYMBOL(x) (&(x))
 template <class T>
 static inline hipError_t hipMemcpyFromSymbol(void *dst, T *sym, size_t n) { memcpy(dst, sym, n); return hipSuccess; }

@@ -1,0 +1,317 @@
+"""The native step executor (dimo_amd/csrc/executor.hip) over the BATCHED kernels the benchmark times -- skinning,
+projection, tile binning, blend forward; blend backward, projection backward, skinning backward and the fold into the
+shared gradient views: deform.hip, preprocess.hip, binning.hip, blend.hip as hipcc compiles them -- run on the CPU SIMT
+emulation (tests/simt/) in each of the executor's three modes and each of its backward call sequences, per render
+against the C oracle like tests/test_gpu_executor.py (integer stages bit for bit, images and per-Gaussian gradients
+within 1e-4), and the ACCUMULATED gradients of the step (canonical Gaussians, control points, the TimeNet rows of every
+(motion, frame) pair) against autograd through oracle/deform_ref.py fed the oracle rasterizer's gradients.
+
+Streams and events are no-ops here (a launch has run when the call returns): what is tested is what the executor
+launches, over which renders, in which groups and chunks -- not its cross-stream schedule, which stays with
+tests/test_gpu_deform.py's C3-size schedule test on the GPU."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from dimo_amd.executor import RenderDesc, StepCommon
+from oracle import raster_oracle as ro
+from oracle.deform_ref import skinning_ref
+from tests.scenes import camera_np, random_scene
+from tests.simt import build as simt_build
+
+L1_TOL = 1e-4
+_S = None
+
+
+def S_():
+    global _S
+    if _S is None:
+        lib = C.CDLL(simt_build.build(target="step"))
+        p, i, q = C.c_void_p, C.c_int, C.c_int64
+        lib.dimo_executor_create.argtypes = [i]
+        lib.dimo_executor_create.restype = p
+        lib.dimo_executor_destroy.argtypes = [p]
+        for name in ("forward_range", "backward_launch", "backward_launch_in_order", "backward_skinning_in_order",
+                     "backward_launch_joint", "backward_accumulate"):
+            getattr(lib, "dimo_executor_" + name).argtypes = [p, p, i, i, p, p]
+        lib.dimo_executor_forward.argtypes = [p, p, i, p, p]
+        lib.dimo_executor_join.argtypes = [p, i, i, p]
+        lib.dimo_executor_join_ranges.argtypes = [p, i, i, p]
+        lib.simt_step_layout.argtypes = [i, i, i, i, q, C.POINTER(C.c_size_t)]
+        _S = lib
+    return _S
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, np.float32)
+
+
+class Step:
+    """A model, n renders (pair_of[i] = the (motion, frame) pair render i shows) and every buffer of
+    dimo_amd/executor.py's StepExecutor, in host memory."""
+
+    def __init__(self, N, M, H, W, pair_of, seed=0, with_normal=True):
+        self.N, self.M, self.H, self.W, self.pair_of, self.n = N, M, H, W, pair_of, len(pair_of)
+        n, P = self.n, max(pair_of) + 1
+        rng = np.random.default_rng(seed)
+        sc = random_scene(N, seed=seed, scale=0.03)
+        self.xyz = _f32(sc["means3D"])
+        self.rotation = _f32(sc["rotations"] * rng.uniform(0.5, 2.0, (N, 1)))  # (raw: not unit length)
+        self.scaling = _f32(np.log(sc["scales"]))
+        op = sc["opacities"]
+        self.opacity = _f32(np.log(op / (1 - op)))
+        self.f_dc = _f32(sc["shs"][:, :1])
+        self.c_xyz = _f32(rng.uniform(-0.5, 0.5, (M, 3)))
+        self.c_log_radius = _f32(np.log(rng.uniform(0.05, 0.25, (M, 1))))
+        d = torch.cdist(torch.from_numpy(self.xyz), torch.from_numpy(self.c_xyz))
+        nd, ni = torch.topk(d, 4, dim=1, largest=False)
+        self.nn_dist, self.nn_idx = _f32(nd.numpy()), np.ascontiguousarray(ni.numpy(), np.int64)
+        self.d_xyz = _f32(0.02 * rng.standard_normal((P, M, 3)))
+        self.d_rot = _f32(np.array([1.0, 0, 0, 0]) + 0.1 * rng.standard_normal((P, M, 4)))
+        self.bg = _f32([0.2, 0.5, 0.8])
+        self.cams = [camera_np(37.0 * i + 11.0 * pair_of[i], elevation=5.0 * (i % 3) - 5.0, W=W, H=H) for i in range(n)]
+        self.cam_arrays = [[_f32(c[k]).reshape(-1) for k in ("view", "proj", "campos")] for c in self.cams]
+        self.gw = [_f32(rng.standard_normal((n, c, H, W))) for c in (3, 1, 3, 1)]
+        self.r_cap = 64 * N
+        lay = (C.c_size_t * 8)()
+        S_().simt_step_layout(N, M, H, W, self.r_cap, lay)
+        self.lay = dict(zip(("geom", "bin", "img", "bwd", "lbs", "vals", "ranges", "total"), (int(x) for x in lay)))
+        self.fresh()
+
+    def fresh(self):
+        """New outputs, workspaces and zeroed gradient accumulators; the descriptors over them."""
+        N, M, H, W, n, L = self.N, self.M, self.H, self.W, self.n, self.lay
+        P = max(self.pair_of) + 1
+        nan = lambda *s: np.full(s, np.nan, np.float32)
+        self.out = dict(color=nan(n, 3, H, W), depth=nan(n, 1, H, W), normal=nan(n, 3, H, W), alpha=nan(n, 1, H, W))
+        self.slots = [dict(pts=nan(N, 3), rot=nan(N, 4), scales=nan(N, 3), opac=nan(N, 1), radii=np.full(N, -1, np.int32),
+                           geom=np.full(L["geom"], 0x5A, np.uint8), bin=np.full(L["bin"], 0x5A, np.uint8),
+                           img=np.full(L["img"], 0x5A, np.uint8), bwd_scratch=np.full(L["bwd"], 0x5A, np.uint8),
+                           g_means3D=nan(N, 3), g_means2D=nan(N, 3), g_shs=nan(N, 1, 3), g_opac=nan(N, 1),
+                           g_scales=nan(N, 3), g_rot=nan(N, 4)) for _ in range(n)]
+        self.acc = dict(xyz=np.zeros((N, 3), np.float32), rotation=np.zeros((N, 4), np.float32),
+                        scaling=np.zeros((N, 3), np.float32), opacity=np.zeros((N, 1), np.float32),
+                        f_dc=np.zeros((N, 1, 3), np.float32), c_xyz=np.zeros((M, 3), np.float32),
+                        c_log_radius=np.zeros((M, 1), np.float32), d_xyz=np.zeros((P, M, 3), np.float32),
+                        d_rot=np.zeros((P, M, 4), np.float32))
+        self.lbs_scratch = np.full(L["lbs"] * n, 0x5A, np.uint8)
+        self.totals = np.zeros((n, 2), np.int32)
+        p = lambda a: a.ctypes.data
+        c = self.common = StepCommon()
+        c.N, c.M, c.H, c.W, c.with_normal, c.local_frame, c.R_cap = N, M, H, W, 1, 1, self.r_cap
+        c.xyz, c.rotation, c.scaling, c.opacity, c.f_dc = p(self.xyz), p(self.rotation), p(self.scaling), p(self.opacity), p(self.f_dc)
+        c.c_xyz, c.c_log_radius, c.nn_dist, c.nn_idx, c.bg = p(self.c_xyz), p(self.c_log_radius), p(self.nn_dist), p(self.nn_idx), p(self.bg)
+        c.scale_modifier = 1.0
+        a = self.acc
+        c.g_xyz, c.g_rotation, c.g_scaling, c.g_opacity = p(a["xyz"]), p(a["rotation"]), p(a["scaling"]), p(a["opacity"])
+        c.g_f_dc, c.g_c_xyz, c.g_c_log_radius = p(a["f_dc"]), p(a["c_xyz"]), p(a["c_log_radius"])
+        c.lbs_scratch, c.lbs_scratch_bytes = p(self.lbs_scratch), self.lbs_scratch.nbytes
+        c.geom_bytes, c.bin_bytes, c.img_bytes, c.bwd_scratch_bytes = L["geom"], L["bin"], L["img"], L["bwd"]
+        self.descs = (RenderDesc * n)()
+        for i, (d, s) in enumerate(zip(self.descs, self.slots)):
+            for k in ("pts", "rot", "scales", "opac", "radii", "geom", "img", "bin", "bwd_scratch", "g_means3D",
+                      "g_means2D", "g_shs", "g_opac", "g_scales", "g_rot"):
+                setattr(d, k, p(s[k]))
+            view, proj, campos = self.cam_arrays[i]
+            d.view, d.proj, d.campos = p(view), p(proj), p(campos)
+            d.tanfovx, d.tanfovy = self.cams[i]["tanfovx"], self.cams[i]["tanfovy"]
+            q = self.pair_of[i]
+            d.d_xyz, d.d_rot = p(self.d_xyz[q]), p(self.d_rot[q])
+            d.g_d_xyz, d.g_d_rot = p(a["d_xyz"][q]), p(a["d_rot"][q])
+            for k, name in (("color", "out_color"), ("depth", "out_depth"), ("normal", "out_normal"), ("alpha", "out_alpha")):
+                setattr(d, name, p(self.out[k][i]))
+            for g, name in zip(self.gw, ("g_color", "g_depth", "g_normal", "g_alpha")):
+                setattr(d, name, p(g[i]))
+            d.totals_out = p(self.totals[i])
+
+    # ---- the reference: per render the C oracle, for the step autograd through the skinning restatement
+    def reference(self):
+        if hasattr(self, "_ref"):
+            return self._ref
+        t = lambda a: torch.from_numpy(a).double().requires_grad_(True)
+        names = ("xyz", "rotation", "scaling", "opacity", "c_xyz", "c_log_radius")
+        leaves = {k: t(getattr(self, k)) for k in names}
+        d_xyz, d_rot = t(self.d_xyz), t(self.d_rot)
+        per_render, f_dc_grad = [], np.zeros((self.N, 1, 3))
+        for i in range(self.n):
+            q, cam = self.pair_of[i], self.cams[i]
+            outs = skinning_ref(**leaves, d_xyz=d_xyz[q], d_rot=d_rot[q], nn_dist=torch.from_numpy(self.nn_dist).double(),
+                                nn_idx=torch.from_numpy(self.nn_idx), local_frame=True)
+            pts, rot, scales, opac = (_f32(o.detach().numpy()) for o in outs)
+            o = ro.forward(pts, self.f_dc, None, opac, scales, rot, None, 1.0, cam["view"], cam["proj"], cam["campos"],
+                           self.bg, cam["tanfovx"], cam["tanfovy"], self.H, self.W, 0, f64=False)
+            go = ro.backward(o, *[g[i] for g in self.gw])
+            tg = lambda a, ref: torch.from_numpy(np.asarray(a, np.float64)).reshape(ref.shape)
+            torch.autograd.backward(list(outs), [tg(go["dL_dmeans3D"], outs[0]), tg(go["dL_drot"], outs[1]),
+                                                 tg(go["dL_dscales"], outs[2]), tg(go["dL_dopacity"], outs[3])])
+            f_dc_grad += go["dL_dshs"].reshape(self.N, 1, 3)
+            per_render.append((o, go, (pts, rot, scales, opac)))
+        acc = {k: v.grad.numpy() for k, v in leaves.items()}
+        acc["f_dc"], acc["d_xyz"], acc["d_rot"] = f_dc_grad, d_xyz.grad.numpy(), d_rot.grad.numpy()
+        self._ref = (per_render, acc)
+        return self._ref
+
+    def check_forward(self):
+        per_render, _ = self.reference()
+        N, H, W, L = self.N, self.H, self.W, self.lay
+        T = ((H + 15) // 16) * ((W + 15) // 16)
+        leader = {}
+        for i in range(self.n):
+            o, _, skinned = per_render[i]
+            s = self.slots[leader.setdefault((self.pair_of[i], self._launch_of(i)), i)]  # the group's leader holds them
+            for got, want in zip((s["pts"], s["rot"], s["scales"], s["opac"]), skinned):
+                assert np.abs(got - want).mean() <= 1e-5 * max(1.0, np.abs(want).mean())
+            assert int(self.totals[i, 0]) == o["R"] and int(self.totals[i, 1]) == 0
+            assert np.array_equal(self.slots[i]["radii"], o["radii"])
+            b = self.slots[i]["bin"]
+            assert np.array_equal(b[L["vals"]:L["vals"] + 4 * o["R"]].view(np.uint32), o["vals_sorted"]), "sorted order differs"
+            assert np.array_equal(b[L["ranges"]:L["ranges"] + 8 * T].view(np.uint32).reshape(T, 2), o["ranges"].reshape(T, 2))
+            for k, ok in (("color", "out_color"), ("depth", "out_depth"), ("alpha", "out_alpha"), ("normal", "out_normal")):
+                assert np.isfinite(self.out[k][i]).all()
+                err = np.abs(self.out[k][i] - o[ok]).mean()
+                assert err <= L1_TOL, (i, k, err)
+
+    def _launch_of(self, i):
+        return self.launch_of[i] if hasattr(self, "launch_of") else 0
+
+    def hand_over_dot_planes(self):
+        """The optional per-pixel plane S = sum over the channels of gradient x rendered value (what the loss kernels
+        emit): handed to the second half of the renders; for the first half the blend backward forms S itself."""
+        o, g = self.out, self.gw
+        self.dot = _f32((g[0] * o["color"]).sum(1, keepdims=True) + g[1] * o["depth"]
+                        + (g[2] * o["normal"]).sum(1, keepdims=True) + g[3] * o["alpha"])
+        for i in range(self.n // 2, self.n):
+            self.descs[i].g_dot = self.dot[i].ctypes.data
+
+    def check_raster_gradients(self, renders=None):
+        per_render, _ = self.reference()
+        rel = lambda a, b: np.abs(a - b).sum() / (np.abs(b).sum() + 1e-12)
+        for i in (range(self.n) if renders is None else renders):
+            _, go, _ = per_render[i]
+            s = self.slots[i]
+            assert rel(s["g_means2D"][:, :2].reshape(-1), go["dL_dmean2D"].reshape(-1)) <= L1_TOL
+            assert rel(s["g_shs"].reshape(-1), go["dL_dshs"].reshape(-1)) <= L1_TOL
+
+    def check_accumulated(self):
+        _, acc = self.reference()
+        for k, want in acc.items():
+            got = self.acc[k].astype(np.float64)
+            assert np.isfinite(got).all(), k
+            err = np.abs(got - want.reshape(got.shape)).sum() / (np.abs(want).sum() + 1e-12)
+            assert err <= 2 * L1_TOL, (k, err)
+
+
+PAIRS_4 = [0, 0, 1, 1]           # two motions x (one pair, two views)
+PAIRS_6 = [0, 0, 1, 2, 2, 3]     # two motions x (a pair seen twice + a pair seen once)
+
+
+@pytest.fixture(scope="module")
+def step4():
+    return Step(1200, 24, 64, 48, PAIRS_4, seed=1)
+
+
+@pytest.fixture(scope="module")
+def step6():
+    return Step(900, 17, 48, 64, PAIRS_6, seed=2)
+
+
+def _ranges(st):
+    half = st.n // 2
+    return [(0, half), (half, st.n - half)]
+
+
+@pytest.mark.parametrize("sequence", ["in_order", "in_order_skinned", "joint", "launch"])
+@pytest.mark.parametrize("which", ["step4", "step6"])
+def test_emulated_executor_batched_ranges(which, sequence, request, monkeypatch):
+    """n_streams < 0 (the benchmark's mode): a range per motion; the default schedule's backward (`joint`: ONE blend
+    backward over all the step's renders, skinning per range, one fold) and its alternatives."""
+    st = request.getfixturevalue(which)
+    st.fresh()
+    if sequence == "launch":
+        monkeypatch.setenv("DIMO_XSTREAM", "event")
+    ex = S_().dimo_executor_create(-2)
+    assert ex
+    c, d = C.addressof(st.common), C.addressof(st.descs)
+    st.launch_of = [0 if i < st.n // 2 else 1 for i in range(st.n)]
+    for first, count in _ranges(st):
+        assert S_().dimo_executor_forward_range(ex, c, first, count, d, None) == 0
+    assert S_().dimo_executor_join(ex, 0, st.n, None) == 0
+    st.check_forward()
+    st.hand_over_dot_planes()
+    # the call sequences of Trainer._forward_backward_direct (dimo_amd/trainer.py)
+    if sequence == "joint":  # ONE blend backward over all the step's renders, then skinning backward + fold
+        assert S_().dimo_executor_backward_launch_joint(ex, c, 0, st.n, d, None) == 0
+        st.check_raster_gradients()
+        assert S_().dimo_executor_backward_accumulate(ex, c, 0, st.n, d, None) == 0
+    elif sequence == "in_order_skinned":  # the default: a motion's whole chain on its stream, ONE fold at the end
+        for first, count in _ranges(st):
+            assert S_().dimo_executor_backward_launch_in_order(ex, c, first, count, d, None) == 0
+            if first == 0:
+                st.check_raster_gradients(range(first, first + count))  # (the skinning backward works in place)
+            assert S_().dimo_executor_backward_skinning_in_order(ex, c, first, count, d, None) == 0
+        assert S_().dimo_executor_join_ranges(ex, 0, st.n, None) == 0
+        assert S_().dimo_executor_backward_accumulate(ex, c, 0, st.n, d, None) == 0
+    else:  # rasterizer backward per motion, the skinning backward per motion on the caller's stream
+        for first, count in _ranges(st):
+            fn = S_().dimo_executor_backward_launch if sequence == "launch" else S_().dimo_executor_backward_launch_in_order
+            assert fn(ex, c, first, count, d, None) == 0
+        st.check_raster_gradients()
+        for first, count in _ranges(st):
+            assert S_().dimo_executor_backward_accumulate(ex, c, first, count, d, None) == 0
+    st.check_accumulated()
+    S_().dimo_executor_destroy(ex)
+    del st.launch_of
+
+
+@pytest.mark.parametrize("which", ["step4", "step6"])
+def test_emulated_executor_one_launch_per_stage(which, request):
+    """n_streams = 0: every stage ONE launch over all the renders of the call, on the caller's stream."""
+    st = request.getfixturevalue(which)
+    st.fresh()
+    ex = S_().dimo_executor_create(0)
+    c, d = C.addressof(st.common), C.addressof(st.descs)
+    assert S_().dimo_executor_forward(ex, c, st.n, d, None) == 0
+    st.check_forward()
+    st.hand_over_dot_planes()
+    assert S_().dimo_executor_backward_launch(ex, c, 0, st.n, d, None) == 0
+    st.check_raster_gradients()
+    assert S_().dimo_executor_backward_accumulate(ex, c, 0, st.n, d, None) == 0
+    st.check_accumulated()
+    S_().dimo_executor_destroy(ex)
+
+
+def test_emulated_executor_per_render_chains(step4):
+    """n_streams > 0: every render its own chain of the single-render entry points."""
+    st = step4
+    st.fresh()
+    st.launch_of = list(range(st.n))  # no deformation groups: every slot holds its own skinned Gaussians
+    ex = S_().dimo_executor_create(2)
+    c, d = C.addressof(st.common), C.addressof(st.descs)
+    assert S_().dimo_executor_forward(ex, c, st.n, d, None) == 0
+    assert S_().dimo_executor_join(ex, 0, st.n, None) == 0
+    st.totals[:, 0] = [r[0]["R"] for r in st.reference()[0]]  # (this mode does not write totals_out)
+    st.check_forward()
+    assert S_().dimo_executor_backward_launch(ex, c, 0, st.n, d, None) == 0
+    st.check_raster_gradients()
+    assert S_().dimo_executor_backward_accumulate(ex, c, 0, st.n, d, None) == 0
+    st.check_accumulated()
+    S_().dimo_executor_destroy(ex)
+    del st.launch_of
+
+
+def test_emulated_executor_refuses_what_the_product_refuses(step4):
+    st = step4
+    st.fresh()
+    ex = S_().dimo_executor_create(-2)
+    c, d = C.addressof(st.common), C.addressof(st.descs)
+    assert S_().dimo_executor_create(17) is None
+    assert S_().dimo_executor_forward_range(ex, c, -1, 2, d, None) != 0
+    assert S_().dimo_executor_forward_range(ex, None, 0, 2, d, None) != 0
+    assert S_().dimo_executor_forward_range(ex, c, 0, 0, d, None) == 0
+    assert S_().dimo_executor_forward_range(ex, c, 0, 2, d, None) == 0
+    # a backward over a range that was never started as one
+    assert S_().dimo_executor_backward_launch_in_order(ex, c, 1, 1, d, None) != 0
+    assert S_().dimo_executor_backward_skinning_in_order(ex, c, 0, 1, d, None) != 0  # not the range's length
+    S_().dimo_executor_destroy(ex)
