@@ -4,6 +4,7 @@
 #include <stdio.h>
 
 #include <atomic>
+#include <deque>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -278,4 +279,117 @@ void launch(dim3 grid, dim3 block, size_t dynamic_lds_bytes, const std::function
   for (auto &t : th) t.join();
 }
 
+// ---------------------------------------------------------------------------------------------- streams and events
+// (see shim/hip/hip_runtime.h).  Host calls come from one thread (the test's).
+struct Event {
+  uint64_t recorded = 0;  // records enqueued so far
+  uint64_t done = 0;      // ... executed
+};
+struct Op {
+  std::function<void()> run;            // what it does when it executes (may be empty)
+  std::function<bool()> ready;          // empty: always
+};
+struct Stream {
+  std::deque<Op> q;
+  int id;
+};
+static Stream g_null_stream{{}, 0};
+static std::vector<Stream *> &all_streams() {
+  static std::vector<Stream *> v{&g_null_stream};
+  return v;
+}
+static Stream *stream_of(hipStream_t s) { return s ? static_cast<Stream *>(s) : &g_null_stream; }
+static size_t g_queued = 0;
+
+// SIMT_STREAMS: unset / "immediate" | "deferred[:seed]" | "deferred:lifo" | "deferred:fifo" (read at every call, so a
+// test can switch; switching drains)
+static bool deferred_mode() {
+  const char *m = getenv("SIMT_STREAMS");
+  return m && !strncmp(m, "deferred", 8);
+}
+
+void synchronize() {
+  if (g_queued == 0) return;
+  const char *m = getenv("SIMT_STREAMS");
+  const char *arg = (m && !strncmp(m, "deferred:", 9)) ? m + 9 : "1";
+  const bool lifo = !strcmp(arg, "lifo"), fifo = !strcmp(arg, "fifo");
+  uint64_t x = strtoull(arg, nullptr, 10) * 0x9E3779B97F4A7C15ull + 0x2545F4914F6CDD1Dull;
+  std::vector<Stream *> &S = all_streams();
+  while (g_queued) {
+    std::vector<Stream *> ready;
+    for (Stream *s : S)
+      if (!s->q.empty() && (!s->q.front().ready || s->q.front().ready())) ready.push_back(s);
+    if (ready.empty()) {
+      fprintf(stderr, "simt: stream deadlock -- %zu operations queued, every stream's head waits for something that "
+                      "is not going to happen\n", g_queued);
+      abort();
+    }
+    Stream *pick;
+    if (lifo) pick = ready.back();
+    else if (fifo) pick = ready.front();
+    else {
+      x ^= x << 13, x ^= x >> 7, x ^= x << 17;
+      pick = ready[x % ready.size()];
+    }
+    Op op = std::move(pick->q.front());
+    pick->q.pop_front();
+    --g_queued;
+    if (op.run) op.run();
+  }
+}
+
+static void enqueue(hipStream_t s, Op op) {
+  if (!deferred_mode()) {
+    synchronize();  // (whatever a deferred phase left)
+    if (op.ready && !op.ready()) {
+      fprintf(stderr, "simt: a stream waits for something that has not been enqueued before it (immediate mode)\n");
+      abort();
+    }
+    if (op.run) op.run();
+    return;
+  }
+  stream_of(s)->q.push_back(std::move(op));
+  ++g_queued;
+}
+
+void submit(hipStream_t stream, std::function<void()> op) { enqueue(stream, Op{std::move(op), nullptr}); }
+hipStream_t stream_create() {
+  Stream *s = new Stream();
+  s->id = (int)all_streams().size();
+  all_streams().push_back(s);
+  return s;
+}
+hipEvent_t event_create() { return new Event(); }
+void event_destroy(hipEvent_t e) {
+  synchronize();
+  delete static_cast<Event *>(e);
+}
+void event_record(hipEvent_t e_, hipStream_t s) {
+  Event *e = static_cast<Event *>(e_);
+  const uint64_t n = ++e->recorded;
+  enqueue(s, Op{[e, n]() { if (e->done < n) e->done = n; }, nullptr});
+}
+// waits for the LATEST record enqueued before this call (none: nothing to wait for)
+void stream_wait_event(hipStream_t s, hipEvent_t e_) {
+  Event *e = static_cast<Event *>(e_);
+  const uint64_t n = e->recorded;
+  if (n == 0) return;
+  enqueue(s, Op{nullptr, [e, n]() { return e->done >= n; }});
+}
+void stream_write_value(hipStream_t s, uint32_t *p, uint32_t v) {
+  enqueue(s, Op{[p, v]() { __atomic_store_n(p, v, __ATOMIC_RELEASE); }, nullptr});
+}
+bool stream_wait_value(hipStream_t s, const uint32_t *p, uint32_t v, uint32_t mask) {
+  if (!deferred_mode()) {
+    synchronize();
+    return (__atomic_load_n(p, __ATOMIC_ACQUIRE) & mask) >= v;
+  }
+  enqueue(s, Op{nullptr, [p, v, mask]() { return (__atomic_load_n(p, __ATOMIC_ACQUIRE) & mask) >= v; }});
+  return true;
+}
+
+
 }  // namespace simt
+
+// for the tests: run everything that is queued (a no-op unless SIMT_STREAMS=deferred...)
+extern "C" void simt_synchronize() { simt::synchronize(); }

@@ -44,35 +44,61 @@ static inline float4 make_float4(float x, float y, float z, float w) { return fl
 typedef void *hipStream_t;
 typedef void *hipEvent_t;
 enum hipError_t { hipSuccess = 0, hipErrorUnknown = 999 };
-static inline hipError_t hipGetLastError() { return hipSuccess; }
-static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
-static inline hipError_t hipMemsetAsync(void *p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
 enum hipMemcpyKind { hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3 };
-static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
-static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
-// Streams and events: a launch has run when hipLaunchKernelGGL returns, so every cross-stream dependency holds
-// trivially -- the executor's SCHEDULE is not what the emulation tests.  Handles are distinct heap words.
 enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2, hipStreamWaitValueGte = 0 };
+
+// Streams and events (runtime.cpp).  By default an operation runs when it is enqueued (a launch has run when
+// hipLaunchKernelGGL returns; a wait must then already hold).  With SIMT_STREAMS=deferred[:seed | :lifo | :fifo] the
+// operations QUEUE per stream and run when something synchronises (hipDeviceSynchronize, hipStreamSynchronize,
+// hipEventSynchronize, a synchronous copy, simt_synchronize() from a test): one at a time, each time from a stream
+// whose head operation is ready -- chosen by a seeded draw, or always the youngest / the oldest ready stream -- so a
+// cross-stream dependency that was never enqueued lets a consumer run before its producer.  The null stream is a
+// stream like the others (the executor's private streams are non-blocking).
+namespace simt {
+void submit(hipStream_t stream, std::function<void()> op);
+hipStream_t stream_create();
+hipEvent_t event_create();
+void event_destroy(hipEvent_t e);
+void event_record(hipEvent_t e, hipStream_t s);
+void stream_wait_event(hipStream_t s, hipEvent_t e);
+void stream_write_value(hipStream_t s, uint32_t *p, uint32_t v);
+bool stream_wait_value(hipStream_t s, const uint32_t *p, uint32_t v, uint32_t mask);  // false: cannot ever hold (immediate mode)
+void synchronize();
+}  // namespace simt
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline hipError_t hipDeviceSynchronize() { simt::synchronize(); return hipSuccess; }
+static inline hipError_t hipStreamSynchronize(hipStream_t) { simt::synchronize(); return hipSuccess; }
+static inline hipError_t hipMemsetAsync(void *p, int v, size_t n, hipStream_t s) {
+  simt::submit(s, [=]() { memset(p, v, n); });
+  return hipSuccess;
+}
+static inline hipError_t hipMemcpyAsync(void *d, const void *src, size_t n, hipMemcpyKind, hipStream_t s) {
+  simt::submit(s, [=]() { memcpy(d, src, n); });
+  return hipSuccess;
+}
 static inline hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
 static inline hipError_t hipDeviceGetStreamPriorityRange(int *lo, int *hi) { *lo = 0, *hi = 0; return hipSuccess; }
-static inline hipError_t hipStreamCreateWithPriority(hipStream_t *s, unsigned, int) { *s = new int(0); return hipSuccess; }
-static inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { *e = new int(0); return hipSuccess; }
-static inline hipError_t hipEventDestroy(hipEvent_t e) { delete static_cast<int *>(e); return hipSuccess; }
-static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
-static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
-static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
-static inline hipError_t hipStreamWriteValue32(hipStream_t, void *p, uint32_t v, unsigned) { *static_cast<uint32_t *>(p) = v; return hipSuccess; }
-static inline hipError_t hipStreamWaitValue32(hipStream_t, void *p, uint32_t v, unsigned, uint32_t mask) {
-  return ((*static_cast<uint32_t *>(p)) & mask) >= v ? hipSuccess : hipErrorUnknown;  // (written at enqueue: must hold)
+static inline hipError_t hipStreamCreateWithPriority(hipStream_t *s, unsigned, int) { *s = simt::stream_create(); return hipSuccess; }
+static inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { *e = simt::event_create(); return hipSuccess; }
+static inline hipError_t hipEventDestroy(hipEvent_t e) { simt::event_destroy(e); return hipSuccess; }
+static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t s) { simt::event_record(e, s); return hipSuccess; }
+static inline hipError_t hipEventSynchronize(hipEvent_t) { simt::synchronize(); return hipSuccess; }
+static inline hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned) { simt::stream_wait_event(s, e); return hipSuccess; }
+static inline hipError_t hipStreamWriteValue32(hipStream_t s, void *p, uint32_t v, unsigned) {
+  simt::stream_write_value(s, static_cast<uint32_t *>(p), v);
+  return hipSuccess;
+}
+static inline hipError_t hipStreamWaitValue32(hipStream_t s, void *p, uint32_t v, unsigned, uint32_t mask) {
+  return simt::stream_wait_value(s, static_cast<const uint32_t *>(p), v, mask) ? hipSuccess : hipErrorUnknown;
 }
 static inline hipError_t hipMalloc(void **p, size_t n) { *p = malloc(n); return *p ? hipSuccess : hipErrorUnknown; }
-static inline hipError_t hipFree(void *p) { free(p); return hipSuccess; }
-static inline hipError_t hipMemset(void *p, int v, size_t n) { memset(p, v, n); return hipSuccess; }
+static inline hipError_t hipFree(void *p) { simt::synchronize(); free(p); return hipSuccess; }
+static inline hipError_t hipMemset(void *p, int v, size_t n) { simt::synchronize(); memset(p, v, n); return hipSuccess; }
 #define HIP_SYMBOL(x) (&(x))
 template <class T>
-static inline hipError_t hipMemcpyFromSymbol(void *dst, T *sym, size_t n) { memcpy(dst, sym, n); return hipSuccess; }
+static inline hipError_t hipMemcpyFromSymbol(void *dst, T *sym, size_t n) { simt::synchronize(); memcpy(dst, sym, n); return hipSuccess; }
 template <class T>
-static inline hipError_t hipMemcpyToSymbol(T *sym, const void *src, size_t n) { memcpy(sym, src, n); return hipSuccess; }
+static inline hipError_t hipMemcpyToSymbol(T *sym, const void *src, size_t n) { simt::synchronize(); memcpy(sym, src, n); return hipSuccess; }
 
 namespace simt {
 struct Idx3 { unsigned x, y, z; };
@@ -97,8 +123,13 @@ void *dynamic_lds();  // the workgroup's dynamically sized LDS (extern __shared_
 #define blockIdx (simt::block_idx())
 #define blockDim (simt::block_dim())
 #define gridDim (simt::grid_dim())
-#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
-  simt::launch((grid), (block), (size_t)(shmem), [&]() { kernel(__VA_ARGS__); })
+// (arguments are captured BY VALUE: the launch may run after the caller has returned)
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...)                           \
+  do {                                                                                        \
+    const dim3 simt_grid_ = (grid), simt_block_ = (block);                                    \
+    const size_t simt_lds_ = (size_t)(shmem);                                                 \
+    simt::submit((stream), [=]() { simt::launch(simt_grid_, simt_block_, simt_lds_, [&]() { kernel(__VA_ARGS__); }); }); \
+  } while (0)
 #define HIP_DYNAMIC_SHARED(type, var) type *var = reinterpret_cast<type *>(simt::dynamic_lds());
 enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
 static inline hipError_t hipFuncSetAttribute(const void *, hipFuncAttribute, int) { return hipSuccess; }

@@ -24,3 +24,9 @@ void simt_step_layout(int N, int M, int H, int W, int64_t R_cap, size_t out[8]) 
   out[5] = B.vals_b, out[6] = B.ranges, out[7] = G.total;
 }
 }
+
+// what a loss kernel is to the executor: something on `stream` that reads a render's images and leaves its gradient
+// images -- here two asynchronous copies (tests/test_executor_emulated.py)
+extern "C" void simt_enqueue_copy(void *dst, const void *src, size_t n, void *stream) {
+  (void)hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, (hipStream_t)stream);
+}

@@ -22,13 +22,13 @@ from tests.scenes import camera_np, random_scene
 from tests.simt import build as simt_build
 
 L1_TOL = 1e-4
-_S = None
+_LIBS = {}
+_CURRENT = "step"  # which build of the executor S_() hands out (the broken-schedule variants: see the last test)
 
 
 def S_():
-    global _S
-    if _S is None:
-        lib = C.CDLL(simt_build.build(target="step"))
+    if _CURRENT not in _LIBS:
+        lib = C.CDLL(simt_build.build(target=_CURRENT))
         p, i, q = C.c_void_p, C.c_int, C.c_int64
         lib.dimo_executor_create.argtypes = [i]
         lib.dimo_executor_create.restype = p
@@ -40,8 +40,16 @@ def S_():
         lib.dimo_executor_join.argtypes = [p, i, i, p]
         lib.dimo_executor_join_ranges.argtypes = [p, i, i, p]
         lib.simt_step_layout.argtypes = [i, i, i, i, q, C.POINTER(C.c_size_t)]
-        _S = lib
-    return _S
+        lib.simt_synchronize.argtypes = []
+        lib.simt_enqueue_copy.argtypes = [p, p, C.c_size_t, p]
+        lib.dimo_executor_range_stream.argtypes = [p, i]
+        lib.dimo_executor_range_stream.restype = p
+        lib.dimo_executor_private_stream.argtypes = [p, i]
+        lib.dimo_executor_private_stream.restype = p
+        lib.dimo_executor_side_done.argtypes = [p, i]
+        lib.dimo_executor_wait_side.argtypes = [p, i, p]
+        _LIBS[_CURRENT] = lib
+    return _LIBS[_CURRENT]
 
 
 def _f32(a):
@@ -80,15 +88,18 @@ class Step:
         self.lay = dict(zip(("geom", "bin", "img", "bwd", "lbs", "vals", "ranges", "total"), (int(x) for x in lay)))
         self.fresh()
 
-    def fresh(self):
-        """New outputs, workspaces and zeroed gradient accumulators; the descriptors over them."""
+    def fresh(self, fill=0x5A):
+        """New outputs, workspaces and zeroed gradient accumulators; the descriptors over them.  The gradient images
+        the descriptors point to start as NaN: `losses` puts the real ones there."""
         N, M, H, W, n, L = self.N, self.M, self.H, self.W, self.n, self.lay
         P = max(self.pair_of) + 1
         nan = lambda *s: np.full(s, np.nan, np.float32)
         self.out = dict(color=nan(n, 3, H, W), depth=nan(n, 1, H, W), normal=nan(n, 3, H, W), alpha=nan(n, 1, H, W))
+        self.seen = {k: nan(*v.shape) for k, v in self.out.items()}  # the images as the "loss kernels" saw them
+        self.gw_live = [nan(*g.shape) for g in self.gw]
         self.slots = [dict(pts=nan(N, 3), rot=nan(N, 4), scales=nan(N, 3), opac=nan(N, 1), radii=np.full(N, -1, np.int32),
-                           geom=np.full(L["geom"], 0x5A, np.uint8), bin=np.full(L["bin"], 0x5A, np.uint8),
-                           img=np.full(L["img"], 0x5A, np.uint8), bwd_scratch=np.full(L["bwd"], 0x5A, np.uint8),
+                           geom=np.full(L["geom"], fill, np.uint8), bin=np.full(L["bin"], fill, np.uint8),
+                           img=np.full(L["img"], fill, np.uint8), bwd_scratch=np.full(L["bwd"], fill, np.uint8),
                            g_means3D=nan(N, 3), g_means2D=nan(N, 3), g_shs=nan(N, 1, 3), g_opac=nan(N, 1),
                            g_scales=nan(N, 3), g_rot=nan(N, 4)) for _ in range(n)]
         self.acc = dict(xyz=np.zeros((N, 3), np.float32), rotation=np.zeros((N, 4), np.float32),
@@ -96,7 +107,7 @@ class Step:
                         f_dc=np.zeros((N, 1, 3), np.float32), c_xyz=np.zeros((M, 3), np.float32),
                         c_log_radius=np.zeros((M, 1), np.float32), d_xyz=np.zeros((P, M, 3), np.float32),
                         d_rot=np.zeros((P, M, 4), np.float32))
-        self.lbs_scratch = np.full(L["lbs"] * n, 0x5A, np.uint8)
+        self.lbs_scratch = np.full(L["lbs"] * n, fill, np.uint8)
         self.totals = np.zeros((n, 2), np.int32)
         p = lambda a: a.ctypes.data
         c = self.common = StepCommon()
@@ -122,7 +133,7 @@ class Step:
             d.g_d_xyz, d.g_d_rot = p(a["d_xyz"][q]), p(a["d_rot"][q])
             for k, name in (("color", "out_color"), ("depth", "out_depth"), ("normal", "out_normal"), ("alpha", "out_alpha")):
                 setattr(d, name, p(self.out[k][i]))
-            for g, name in zip(self.gw, ("g_color", "g_depth", "g_normal", "g_alpha")):
+            for g, name in zip(self.gw_live, ("g_color", "g_depth", "g_normal", "g_alpha")):
                 setattr(d, name, p(g[i]))
             d.totals_out = p(self.totals[i])
 
@@ -154,6 +165,7 @@ class Step:
         return self._ref
 
     def check_forward(self):
+        S_().simt_synchronize()  # (deferred streams: run what is queued)
         per_render, _ = self.reference()
         N, H, W, L = self.N, self.H, self.W, self.lay
         T = ((H + 15) // 16) * ((W + 15) // 16)
@@ -176,9 +188,24 @@ class Step:
     def _launch_of(self, i):
         return self.launch_of[i] if hasattr(self, "launch_of") else 0
 
+    def losses(self, first, count, stream):
+        """What the trainer enqueues between a range's forward and its backward, on `stream`: something that reads the
+        renders' images and leaves their gradient images."""
+        for i in range(first, first + count):
+            for k in self.out:
+                S_().simt_enqueue_copy(self.seen[k][i].ctypes.data, self.out[k][i].ctypes.data, self.out[k][i].nbytes, stream)
+            for live, g in zip(self.gw_live, self.gw):
+                S_().simt_enqueue_copy(live[i].ctypes.data, g[i].ctypes.data, g[i].nbytes, stream)
+
+    def check_seen(self):
+        S_().simt_synchronize()
+        for k in self.out:
+            assert np.array_equal(self.seen[k], self.out[k]), "a loss kernel ran before its render had finished: " + k
+
     def hand_over_dot_planes(self):
         """The optional per-pixel plane S = sum over the channels of gradient x rendered value (what the loss kernels
         emit): handed to the second half of the renders; for the first half the blend backward forms S itself."""
+        S_().simt_synchronize()
         o, g = self.out, self.gw
         self.dot = _f32((g[0] * o["color"]).sum(1, keepdims=True) + g[1] * o["depth"]
                         + (g[2] * o["normal"]).sum(1, keepdims=True) + g[3] * o["alpha"])
@@ -186,6 +213,7 @@ class Step:
             self.descs[i].g_dot = self.dot[i].ctypes.data
 
     def check_raster_gradients(self, renders=None):
+        S_().simt_synchronize()
         per_render, _ = self.reference()
         rel = lambda a, b: np.abs(a - b).sum() / (np.abs(b).sum() + 1e-12)
         for i in (range(self.n) if renders is None else renders):
@@ -195,6 +223,7 @@ class Step:
             assert rel(s["g_shs"].reshape(-1), go["dL_dshs"].reshape(-1)) <= L1_TOL
 
     def check_accumulated(self):
+        S_().simt_synchronize()
         _, acc = self.reference()
         for k, want in acc.items():
             got = self.acc[k].astype(np.float64)
@@ -222,47 +251,89 @@ def _ranges(st):
     return [(0, half), (half, st.n - half)]
 
 
-@pytest.mark.parametrize("sequence", ["in_order", "in_order_skinned", "joint", "launch"])
-@pytest.mark.parametrize("which", ["step4", "step6"])
-def test_emulated_executor_batched_ranges(which, sequence, request, monkeypatch):
-    """n_streams < 0 (the benchmark's mode): a range per motion; the default schedule's backward (`joint`: ONE blend
-    backward over all the step's renders, skinning per range, one fold) and its alternatives."""
-    st = request.getfixturevalue(which)
-    st.fresh()
-    if sequence == "launch":
-        monkeypatch.setenv("DIMO_XSTREAM", "event")
+# How the streams' operations are ordered (tests/simt/runtime.cpp): run at enqueue, or QUEUED per stream and run at the
+# next synchronisation one at a time from any stream whose head is ready -- by a seeded draw, youngest stream first
+# (the private streams run as far as they can before the caller's), or oldest first.  An edge the executor forgot to
+# enqueue lets a consumer run ahead of its producer in at least one of these.
+DEFERRED = ["deferred:1", "deferred:2", "deferred:lifo", "deferred:fifo"]
+STREAM_ORDERS = ["immediate"] + DEFERRED
+SEQUENCES = ["in_order", "in_order_skinned", "in_order_skinned_side", "joint", "launch"]
+
+
+def run_ranged_step(st, sequence, deferred):
+    """One step in the batched-ranges mode with the call sequence of Trainer._forward_backward_direct
+    (dimo_amd/trainer.py) named by `sequence`.  In the deferred orders nothing synchronises between the first enqueue
+    and the last (the trainer's host never waits for the device inside a step either)."""
     ex = S_().dimo_executor_create(-2)
     assert ex
     c, d = C.addressof(st.common), C.addressof(st.descs)
     st.launch_of = [0 if i < st.n // 2 else 1 for i in range(st.n)]
-    for first, count in _ranges(st):
-        assert S_().dimo_executor_forward_range(ex, c, first, count, d, None) == 0
-    assert S_().dimo_executor_join(ex, 0, st.n, None) == 0
-    st.check_forward()
-    st.hand_over_dot_planes()
-    # the call sequences of Trainer._forward_backward_direct (dimo_amd/trainer.py)
-    if sequence == "joint":  # ONE blend backward over all the step's renders, then skinning backward + fold
-        assert S_().dimo_executor_backward_launch_joint(ex, c, 0, st.n, d, None) == 0
+    E = S_()
+    try:
+        for first, count in _ranges(st):
+            assert E.dimo_executor_forward_range(ex, c, first, count, d, None) == 0
+        if not deferred:
+            st.check_forward()
+            st.hand_over_dot_planes()
+        own = sequence != "launch"  # a motion's losses on the stream its chain runs on, or on the caller's stream
+        if not own:
+            assert E.dimo_executor_join(ex, 0, st.n, None) == 0
+        for first, count in _ranges(st):
+            st.losses(first, count, E.dimo_executor_range_stream(ex, first) if own else None)
+            if sequence == "launch":
+                assert E.dimo_executor_backward_launch(ex, c, first, count, d, None) == 0
+            elif sequence != "joint":
+                assert E.dimo_executor_backward_launch_in_order(ex, c, first, count, d, None) == 0
+                if sequence.startswith("in_order_skinned"):  # the default: ... and its skinning backward behind it
+                    assert E.dimo_executor_backward_skinning_in_order(ex, c, first, count, d, None) == 0
+        if sequence == "joint":  # ONE blend backward over all the step's renders, then skinning backward + fold
+            assert E.dimo_executor_backward_launch_joint(ex, c, 0, st.n, d, None) == 0
+            assert E.dimo_executor_backward_accumulate(ex, c, 0, st.n, d, None) == 0
+        elif sequence == "in_order_skinned":  # ONE fold over the step's renders
+            assert E.dimo_executor_backward_accumulate(ex, c, 0, st.n, d, None) == 0
+        elif sequence == "in_order_skinned_side":
+            # ... on private stream 0 (followed there by the optimizer's early launch, next to the TimeNet backward on
+            # the caller's stream, which needs the ranges' TimeNet-row gradients: join_ranges)
+            side = E.dimo_executor_private_stream(ex, 0)
+            assert side
+            assert E.dimo_executor_join_ranges(ex, 0, st.n, None) == 0
+            # (what the TimeNet backward is to the executor: a reader of the rows' gradients on the caller's stream)
+            rows = st.acc["d_xyz"]
+            st.rows_seen = np.full_like(rows, np.nan)
+            E.simt_enqueue_copy(st.rows_seen.ctypes.data, rows.ctypes.data, rows.nbytes, None)
+            assert E.dimo_executor_backward_accumulate(ex, c, 0, st.n, d, side) == 0
+            assert E.dimo_executor_side_done(ex, 0) == 0
+            assert E.dimo_executor_wait_side(ex, 0, None) == 0
+        else:  # the skinning backward per motion on the caller's stream
+            for first, count in _ranges(st):
+                assert E.dimo_executor_backward_accumulate(ex, c, first, count, d, None) == 0
+        st.check_seen()
+        st.check_forward()
         st.check_raster_gradients()
-        assert S_().dimo_executor_backward_accumulate(ex, c, 0, st.n, d, None) == 0
-    elif sequence == "in_order_skinned":  # the default: a motion's whole chain on its stream, ONE fold at the end
-        for first, count in _ranges(st):
-            assert S_().dimo_executor_backward_launch_in_order(ex, c, first, count, d, None) == 0
-            if first == 0:
-                st.check_raster_gradients(range(first, first + count))  # (the skinning backward works in place)
-            assert S_().dimo_executor_backward_skinning_in_order(ex, c, first, count, d, None) == 0
-        assert S_().dimo_executor_join_ranges(ex, 0, st.n, None) == 0
-        assert S_().dimo_executor_backward_accumulate(ex, c, 0, st.n, d, None) == 0
-    else:  # rasterizer backward per motion, the skinning backward per motion on the caller's stream
-        for first, count in _ranges(st):
-            fn = S_().dimo_executor_backward_launch if sequence == "launch" else S_().dimo_executor_backward_launch_in_order
-            assert fn(ex, c, first, count, d, None) == 0
-        st.check_raster_gradients()
-        for first, count in _ranges(st):
-            assert S_().dimo_executor_backward_accumulate(ex, c, first, count, d, None) == 0
-    st.check_accumulated()
-    S_().dimo_executor_destroy(ex)
-    del st.launch_of
+        st.check_accumulated()
+        if sequence == "in_order_skinned_side":
+            assert np.array_equal(st.rows_seen, st.acc["d_xyz"]), "the caller's stream read the TimeNet rows' gradients early"
+    finally:
+        E.simt_synchronize()
+        E.dimo_executor_destroy(ex)
+        del st.launch_of
+
+
+@pytest.mark.parametrize("streams", STREAM_ORDERS)
+@pytest.mark.parametrize("sequence", SEQUENCES)
+@pytest.mark.parametrize("which", ["step4", "step6"])
+def test_emulated_executor_batched_ranges(which, sequence, streams, request, monkeypatch):
+    """n_streams < 0 (the benchmark's mode): a range per motion on a private stream; the trainer's backward call
+    sequences, each under every ordering of the streams' operations; cross-stream dependencies through stream
+    write / wait values (the default) and, for `launch`, through events."""
+    st = request.getfixturevalue(which)
+    if streams != "immediate" and which == "step6" and sequence in ("in_order", "launch"):
+        pytest.skip("covered by step4")
+    st.fresh()
+    monkeypatch.setenv("SIMT_STREAMS", streams)
+    if sequence == "launch":
+        monkeypatch.setenv("DIMO_XSTREAM", "event")
+    run_ranged_step(st, sequence, streams != "immediate")
 
 
 @pytest.mark.parametrize("which", ["step4", "step6"])
@@ -275,6 +346,7 @@ def test_emulated_executor_one_launch_per_stage(which, request):
     assert S_().dimo_executor_forward(ex, c, st.n, d, None) == 0
     st.check_forward()
     st.hand_over_dot_planes()
+    st.losses(0, st.n, None)
     assert S_().dimo_executor_backward_launch(ex, c, 0, st.n, d, None) == 0
     st.check_raster_gradients()
     assert S_().dimo_executor_backward_accumulate(ex, c, 0, st.n, d, None) == 0
@@ -282,23 +354,32 @@ def test_emulated_executor_one_launch_per_stage(which, request):
     S_().dimo_executor_destroy(ex)
 
 
-def test_emulated_executor_per_render_chains(step4):
-    """n_streams > 0: every render its own chain of the single-render entry points."""
+@pytest.mark.parametrize("streams", ["immediate", "deferred:3", "deferred:lifo", "deferred:fifo"])
+def test_emulated_executor_per_render_chains(step4, streams, monkeypatch):
+    """n_streams > 0: every render its own chain of the single-render entry points, renders round-robin over two
+    private streams, events between them and the caller's stream."""
     st = step4
     st.fresh()
+    monkeypatch.setenv("SIMT_STREAMS", streams)
     st.launch_of = list(range(st.n))  # no deformation groups: every slot holds its own skinned Gaussians
     ex = S_().dimo_executor_create(2)
     c, d = C.addressof(st.common), C.addressof(st.descs)
-    assert S_().dimo_executor_forward(ex, c, st.n, d, None) == 0
-    assert S_().dimo_executor_join(ex, 0, st.n, None) == 0
-    st.totals[:, 0] = [r[0]["R"] for r in st.reference()[0]]  # (this mode does not write totals_out)
-    st.check_forward()
-    assert S_().dimo_executor_backward_launch(ex, c, 0, st.n, d, None) == 0
-    st.check_raster_gradients()
-    assert S_().dimo_executor_backward_accumulate(ex, c, 0, st.n, d, None) == 0
-    st.check_accumulated()
-    S_().dimo_executor_destroy(ex)
-    del st.launch_of
+    try:
+        assert S_().dimo_executor_forward(ex, c, st.n, d, None) == 0
+        assert S_().dimo_executor_join(ex, 0, st.n, None) == 0
+        st.losses(0, st.n, None)
+        assert S_().dimo_executor_backward_launch(ex, c, 0, st.n, d, None) == 0
+        assert S_().dimo_executor_backward_accumulate(ex, c, 0, st.n, d, None) == 0
+        S_().simt_synchronize()
+        st.totals[:, 0] = [r[0]["R"] for r in st.reference()[0]]  # (this mode does not write totals_out)
+        st.check_seen()
+        st.check_forward()
+        st.check_raster_gradients()
+        st.check_accumulated()
+    finally:
+        S_().simt_synchronize()
+        S_().dimo_executor_destroy(ex)
+        del st.launch_of
 
 
 def test_emulated_executor_refuses_what_the_product_refuses(step4):
@@ -315,3 +396,33 @@ def test_emulated_executor_refuses_what_the_product_refuses(step4):
     assert S_().dimo_executor_backward_launch_in_order(ex, c, 1, 1, d, None) != 0
     assert S_().dimo_executor_backward_skinning_in_order(ex, c, 0, 1, d, None) != 0  # not the range's length
     S_().dimo_executor_destroy(ex)
+
+
+@pytest.mark.parametrize("variant,sequence", [("step_no_accumulate_wait", "in_order_skinned"),
+                                              ("step_no_joint_wait", "joint"), ("step_no_backward_fork", "launch")])
+def test_the_deferred_stream_orders_catch_a_missing_dependency(variant, sequence, monkeypatch):
+    """The detector's own test.  tests/simt/build.py builds the executor three more times, each with ONE cross-stream
+    dependency taken out of executor.hip -- the fold's wait for the ranges' backward, the joint backward's wait for the
+    ranges' forward (and losses), the fork of a range's backward from the caller's stream (the losses there) -- and
+    every one of them must come out WRONG under at least one deferred order, while run at enqueue (as a launch-order
+    emulation would) each still passes: that is what the deferred orders add."""
+    global _CURRENT
+    st = Step(500, 12, 48, 48, PAIRS_4, seed=4)
+    st.reference()
+    monkeypatch.setenv("DIMO_XSTREAM", "event" if sequence == "launch" else "value")
+    _CURRENT = variant
+    try:
+        monkeypatch.setenv("SIMT_STREAMS", "immediate")
+        st.fresh(fill=0)
+        run_ranged_step(st, sequence, True)  # (in enqueue order the missing edge goes unnoticed)
+        caught = []
+        for order in DEFERRED:
+            monkeypatch.setenv("SIMT_STREAMS", order)
+            st.fresh(fill=0)  # (zeroed workspaces: a consumer that runs too early sees empty lists, not wild indices)
+            try:
+                run_ranged_step(st, sequence, True)
+            except AssertionError:
+                caught.append(order)
+        assert caught, "no deferred order exposed the missing dependency"
+    finally:
+        _CURRENT = "step"
