@@ -60,8 +60,9 @@ class Step:
     """A model, n renders (pair_of[i] = the (motion, frame) pair render i shows) and every buffer of
     dimo_amd/executor.py's StepExecutor, in host memory."""
 
-    def __init__(self, N, M, H, W, pair_of, seed=0, with_normal=True):
+    def __init__(self, N, M, H, W, pair_of, seed=0, stage1=False):
         self.N, self.M, self.H, self.W, self.pair_of, self.n = N, M, H, W, pair_of, len(pair_of)
+        self.stage1 = stage1  # stage s1: the TimeNet moves every Gaussian itself, one shared log-radius
         n, P = self.n, max(pair_of) + 1
         rng = np.random.default_rng(seed)
         sc = random_scene(N, seed=seed, scale=0.03)
@@ -76,7 +77,8 @@ class Step:
         d = torch.cdist(torch.from_numpy(self.xyz), torch.from_numpy(self.c_xyz))
         nd, ni = torch.topk(d, 4, dim=1, largest=False)
         self.nn_dist, self.nn_idx = _f32(nd.numpy()), np.ascontiguousarray(ni.numpy(), np.int64)
-        self.d_xyz = _f32(0.02 * rng.standard_normal((P, M, 3)))
+        self.d_xyz = _f32(0.02 * rng.standard_normal((P, N if stage1 else M, 3)))
+        self.log_r = _f32([[np.log(0.03)]])
         self.d_rot = _f32(np.array([1.0, 0, 0, 0]) + 0.1 * rng.standard_normal((P, M, 4)))
         self.bg = _f32([0.2, 0.5, 0.8])
         self.cams = [camera_np(37.0 * i + 11.0 * pair_of[i], elevation=5.0 * (i % 3) - 5.0, W=W, H=H) for i in range(n)]
@@ -105,8 +107,8 @@ class Step:
         self.acc = dict(xyz=np.zeros((N, 3), np.float32), rotation=np.zeros((N, 4), np.float32),
                         scaling=np.zeros((N, 3), np.float32), opacity=np.zeros((N, 1), np.float32),
                         f_dc=np.zeros((N, 1, 3), np.float32), c_xyz=np.zeros((M, 3), np.float32),
-                        c_log_radius=np.zeros((M, 1), np.float32), d_xyz=np.zeros((P, M, 3), np.float32),
-                        d_rot=np.zeros((P, M, 4), np.float32))
+                        c_log_radius=np.zeros((M, 1), np.float32), d_xyz=np.zeros(self.d_xyz.shape, np.float32),
+                        d_rot=np.zeros((P, M, 4), np.float32), log_r=np.zeros((1, 1), np.float32))
         self.lbs_scratch = np.full(L["lbs"] * n, fill, np.uint8)
         self.totals = np.zeros((n, 2), np.int32)
         p = lambda a: a.ctypes.data
@@ -120,6 +122,8 @@ class Step:
         c.g_f_dc, c.g_c_xyz, c.g_c_log_radius = p(a["f_dc"]), p(a["c_xyz"]), p(a["c_log_radius"])
         c.lbs_scratch, c.lbs_scratch_bytes = p(self.lbs_scratch), self.lbs_scratch.nbytes
         c.geom_bytes, c.bin_bytes, c.img_bytes, c.bwd_scratch_bytes = L["geom"], L["bin"], L["img"], L["bwd"]
+        if self.stage1:
+            c.stage1, c.log_r, c.g_log_r, c.nn_dist, c.nn_idx = 1, p(self.log_r), p(a["log_r"]), None, None
         self.descs = (RenderDesc * n)()
         for i, (d, s) in enumerate(zip(self.descs, self.slots)):
             for k in ("pts", "rot", "scales", "opac", "radii", "geom", "img", "bin", "bwd_scratch", "g_means3D",
@@ -145,11 +149,17 @@ class Step:
         names = ("xyz", "rotation", "scaling", "opacity", "c_xyz", "c_log_radius")
         leaves = {k: t(getattr(self, k)) for k in names}
         d_xyz, d_rot = t(self.d_xyz), t(self.d_rot)
+        log_r = t(self.log_r)
         per_render, f_dc_grad = [], np.zeros((self.N, 1, 3))
         for i in range(self.n):
             q, cam = self.pair_of[i], self.cams[i]
-            outs = skinning_ref(**leaves, d_xyz=d_xyz[q], d_rot=d_rot[q], nn_dist=torch.from_numpy(self.nn_dist).double(),
-                                nn_idx=torch.from_numpy(self.nn_idx), local_frame=True)
+            if self.stage1:  # renderer/latent_gs_renderer.py:1176-1177, 1211-1212, get_scaling :341-351
+                rot = leaves["rotation"]
+                outs = (leaves["xyz"] + d_xyz[q], rot / rot.norm(dim=1, keepdim=True).clamp_min(1e-12),
+                        torch.exp(log_r).expand(self.N, 3), torch.sigmoid(leaves["opacity"]))
+            else:
+                outs = skinning_ref(**leaves, d_xyz=d_xyz[q], d_rot=d_rot[q], nn_dist=torch.from_numpy(self.nn_dist).double(),
+                                    nn_idx=torch.from_numpy(self.nn_idx), local_frame=True)
             pts, rot, scales, opac = (_f32(o.detach().numpy()) for o in outs)
             o = ro.forward(pts, self.f_dc, None, opac, scales, rot, None, 1.0, cam["view"], cam["proj"], cam["campos"],
                            self.bg, cam["tanfovx"], cam["tanfovy"], self.H, self.W, 0, f64=False)
@@ -159,8 +169,12 @@ class Step:
                                                  tg(go["dL_dscales"], outs[2]), tg(go["dL_dopacity"], outs[3])])
             f_dc_grad += go["dL_dshs"].reshape(self.N, 1, 3)
             per_render.append((o, go, (pts, rot, scales, opac)))
-        acc = {k: v.grad.numpy() for k, v in leaves.items()}
-        acc["f_dc"], acc["d_xyz"], acc["d_rot"] = f_dc_grad, d_xyz.grad.numpy(), d_rot.grad.numpy()
+        acc = {k: v.grad.numpy() for k, v in leaves.items() if v.grad is not None}
+        acc["f_dc"], acc["d_xyz"] = f_dc_grad, d_xyz.grad.numpy()
+        if self.stage1:
+            acc["log_r"] = log_r.grad.numpy()
+        else:
+            acc["d_rot"] = d_rot.grad.numpy()
         self._ref = (per_render, acc)
         return self._ref
 
@@ -334,6 +348,22 @@ def test_emulated_executor_batched_ranges(which, sequence, streams, request, mon
     if sequence == "launch":
         monkeypatch.setenv("DIMO_XSTREAM", "event")
     run_ranged_step(st, sequence, streams != "immediate")
+
+
+@pytest.fixture(scope="module")
+def step_s1():
+    return Step(400, 8, 48, 48, PAIRS_6, seed=6, stage1=True)
+
+
+@pytest.mark.parametrize("streams", ["immediate", "deferred:5", "deferred:lifo", "deferred:fifo"])
+@pytest.mark.parametrize("sequence", ["in_order_skinned", "joint"])
+def test_emulated_executor_stage_s1(step_s1, sequence, streams, monkeypatch):
+    """Stage s1 on the batched executor: the TimeNet's rows move the Gaussians themselves, scales = exp of the one
+    shared log-radius (renderer/latent_gs_renderer.py:1176-1177, 1211-1212, 341-351): s1_fwd / s1_bwd_batched_kernel,
+    the radius gradient included."""
+    step_s1.fresh()
+    monkeypatch.setenv("SIMT_STREAMS", streams)
+    run_ranged_step(step_s1, sequence, streams != "immediate")
 
 
 @pytest.mark.parametrize("which", ["step4", "step6"])
