@@ -299,6 +299,18 @@ def test_backward_parity_precomp():
                                                    opacities="dL_dopacity", cov3D="dL_dcov3D"))
 
 
+@pytest.mark.parametrize("seed", range(16))
+def test_raster_fuzz_small_and_ragged_shapes(seed):
+    """The seeded shapes of tests/test_raster_emulated.py's fuzz (one to a few Gaussians, images of a single row /
+    column / tile, splats from specks to larger than the image, cameras inside the cloud, opacities down to 0, both
+    flavours, SH degrees 0-3), here on the GPU: forward and backward against the oracle."""
+    from tests.test_raster_emulated import _fuzz_case
+    sc, cam, bg, deg, with_normal = _fuzz_case(seed)
+    _, _, o = _check_forward(sc, cam, bg, deg, with_normal)
+    if o["R"] > 0:
+        _check_backward(sc, cam, bg, deg, GRADS_SH, with_normal, seed=seed)
+
+
 def test_capacity_policy_async_and_overflow():
     from dimo_amd.rasterizer import CapacityPolicy
     cam = camera_np(10.0, W=128, H=128)

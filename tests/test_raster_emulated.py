@@ -233,3 +233,33 @@ def test_emulated_forward_and_backward_under_other_fiber_schedules(order, monkey
     sc = random_scene(3000, seed=9, scale=0.05)
     _check_forward(sc, cam, (0.3, 0.3, 0.3), 0)
     _check_backward(sc, cam, (0.3, 0.3, 0.3), 0, GRADS_SH)
+
+
+def _fuzz_case(seed):
+    rng = np.random.default_rng(1000 + seed)
+    N = int(rng.choice([1, 3, 63, 64, 65, 200, 700, 1500]))
+    H, W = int(rng.integers(1, 90)), int(rng.integers(1, 90))
+    deg = int(rng.integers(0, 4))
+    M = (deg + 1) ** 2
+    scale = float(rng.choice([0.005, 0.02, 0.08, 0.4]))  # specks ... splats larger than the image
+    cam = camera_np(float(rng.uniform(0, 360)), elevation=float(rng.uniform(-60, 60)), radius=float(rng.uniform(0.6, 3.0)),
+                    W=W, H=H)
+    sc = random_scene(N, seed=seed, sh_coeffs=M, scale=scale, opacity=(0.0 if seed % 3 == 0 else 0.2, 1.0))
+    bg = tuple(float(x) for x in rng.random(3))
+    return sc, cam, bg, deg, bool(rng.integers(0, 2))
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_emulated_raster_fuzz(seed):
+    """Seeded random shapes the fixed cases do not hold: one to a few Gaussians, images of a single row / column / tile,
+    sizes that are no multiple of 16, splats from specks to larger than the image, cameras inside the cloud (near-plane
+    culling), opacities down to 0 (below the 1/255 threshold), both rasterizer flavours, SH degrees 0-3 -- forward and
+    backward against the oracle."""
+    sc, cam, bg, deg, with_normal = _fuzz_case(seed)
+    r, o = _check_forward(sc, cam, bg, deg, with_normal)
+    if o["R"] > 0:
+        _check_backward(sc, cam, bg, deg, GRADS_SH, with_normal, seed=seed)
+    else:
+        g = r.backward([np.ones(s, np.float32) for s in ((3, cam["H"], cam["W"]), (1, cam["H"], cam["W"]),
+                                                          (3, cam["H"], cam["W"]), (1, cam["H"], cam["W"]))])
+        assert all(np.abs(v).max() == 0 for v in g.values() if v is not None)
