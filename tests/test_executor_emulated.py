@@ -261,6 +261,8 @@ def step6():
 
 
 def _ranges(st):
+    if getattr(st, "ranges", None):
+        return st.ranges
     half = st.n // 2
     return [(0, half), (half, st.n - half)]
 
@@ -281,7 +283,8 @@ def run_ranged_step(st, sequence, deferred):
     ex = S_().dimo_executor_create(-2)
     assert ex
     c, d = C.addressof(st.common), C.addressof(st.descs)
-    st.launch_of = [0 if i < st.n // 2 else 1 for i in range(st.n)]
+    # (deformation groups are formed per LAUNCH: a range longer than 8 renders is cut from its start)
+    st.launch_of = [next((k, (i - f) // 8) for k, (f, cnt) in enumerate(_ranges(st)) if f <= i < f + cnt) for i in range(st.n)]
     E = S_()
     try:
         for first, count in _ranges(st):
@@ -344,6 +347,34 @@ def test_emulated_executor_batched_ranges(which, sequence, streams, request, mon
     if streams != "immediate" and which == "step6" and sequence in ("in_order", "launch"):
         pytest.skip("covered by step4")
     st.fresh()
+    monkeypatch.setenv("SIMT_STREAMS", streams)
+    if sequence == "launch":
+        monkeypatch.setenv("DIMO_XSTREAM", "event")
+    run_ranged_step(st, sequence, streams != "immediate")
+
+
+@pytest.mark.parametrize("lengths,sequence,streams", [
+    ((10,), "joint", "immediate"),              # a range longer than a launch: cut 8 + 2 like its forward
+    ((10,), "in_order_skinned", "deferred:lifo"),
+    ((9, 2), "joint", "deferred:2"),            # ... followed by a short one
+    ((3, 3, 3), "joint", "deferred:fifo"),      # three motions on two streams: 3 + 3 merge into a launch, the third alone
+    ((3, 3, 3), "in_order_skinned_side", "deferred:1"),
+    ((1, 1), "in_order", "deferred:lifo"),      # one render per motion
+    ((6, 6), "joint", "immediate"),             # two ranges that do not fit one launch together
+    ((5, 1, 4), "launch", "deferred:3"),
+])
+def test_emulated_executor_range_shapes(lengths, sequence, streams, monkeypatch):
+    """How the executor cuts ranges into launches (plan_chunks: whole ranges merged while they fit eight renders, a
+    longer range cut from its start exactly like its forward, deformation groups formed per launch) -- range shapes
+    beyond the benchmark's two motions of four."""
+    pair_of, ranges, q = [], [], 0
+    for n in lengths:
+        ranges.append((len(pair_of), n))
+        for j in range(n):
+            pair_of.append(q + j // 2)  # two views per (motion, frame) pair, the last pair of an odd range alone
+        q += (n + 1) // 2
+    st = Step(300, 9, 32, 48, pair_of, seed=sum(lengths))
+    st.ranges = ranges
     monkeypatch.setenv("SIMT_STREAMS", streams)
     if sequence == "launch":
         monkeypatch.setenv("DIMO_XSTREAM", "event")
