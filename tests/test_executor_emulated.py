@@ -60,7 +60,7 @@ class Step:
     """A model, n renders (pair_of[i] = the (motion, frame) pair render i shows) and every buffer of
     dimo_amd/executor.py's StepExecutor, in host memory."""
 
-    def __init__(self, N, M, H, W, pair_of, seed=0, stage1=False):
+    def __init__(self, N, M, H, W, pair_of, seed=0, stage1=False, r_cap=None):
         self.N, self.M, self.H, self.W, self.pair_of, self.n = N, M, H, W, pair_of, len(pair_of)
         self.stage1 = stage1  # stage s1: the TimeNet moves every Gaussian itself, one shared log-radius
         n, P = self.n, max(pair_of) + 1
@@ -84,7 +84,7 @@ class Step:
         self.cams = [camera_np(37.0 * i + 11.0 * pair_of[i], elevation=5.0 * (i % 3) - 5.0, W=W, H=H) for i in range(n)]
         self.cam_arrays = [[_f32(c[k]).reshape(-1) for k in ("view", "proj", "campos")] for c in self.cams]
         self.gw = [_f32(rng.standard_normal((n, c, H, W))) for c in (3, 1, 3, 1)]
-        self.r_cap = 64 * N
+        self.r_cap = 64 * N if r_cap is None else r_cap
         lay = (C.c_size_t * 8)()
         S_().simt_step_layout(N, M, H, W, self.r_cap, lay)
         self.lay = dict(zip(("geom", "bin", "img", "bwd", "lbs", "vals", "ranges", "total"), (int(x) for x in lay)))
@@ -379,6 +379,29 @@ def test_emulated_executor_range_shapes(lengths, sequence, streams, monkeypatch)
     if sequence == "launch":
         monkeypatch.setenv("DIMO_XSTREAM", "event")
     run_ranged_step(st, sequence, streams != "immediate")
+
+
+def test_emulated_executor_instance_capacity_overflow():
+    """Workspaces sized for fewer tile instances than the renders produce (the capacity policy runs a step ahead of
+    the device's counts): every render flags the overflow in its (R, overflow) words -- the words that turn the step's
+    Adam update into a no-op --, nothing is written out of bounds (a stray write into host memory here is a crash or a
+    corrupted neighbour, not something a GPU forgives) and every accumulated gradient stays finite."""
+    st = Step(1200, 24, 64, 48, PAIRS_4, seed=1, r_cap=3000)
+    st.fresh()
+    ex = S_().dimo_executor_create(-2)
+    c, d = C.addressof(st.common), C.addressof(st.descs)
+    for first, count in _ranges(st):
+        assert S_().dimo_executor_forward_range(ex, c, first, count, d, None) == 0
+    st.losses(0, st.n, None)
+    assert S_().dimo_executor_backward_launch_joint(ex, c, 0, st.n, d, None) == 0
+    assert S_().dimo_executor_backward_accumulate(ex, c, 0, st.n, d, None) == 0
+    S_().simt_synchronize()
+    assert (st.totals[:, 0] > 3000).all() and (st.totals[:, 1] == 1).all()
+    for k, v in st.out.items():
+        assert np.isfinite(v).all(), k
+    for k, v in st.acc.items():
+        assert np.isfinite(v).all(), k
+    S_().dimo_executor_destroy(ex)
 
 
 @pytest.fixture(scope="module")

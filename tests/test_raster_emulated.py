@@ -263,3 +263,47 @@ def test_emulated_raster_fuzz(seed):
         g = r.backward([np.ones(s, np.float32) for s in ((3, cam["H"], cam["W"]), (1, cam["H"], cam["W"]),
                                                           (3, cam["H"], cam["W"]), (1, cam["H"], cam["W"]))])
         assert all(np.abs(v).max() == 0 for v in g.values() if v is not None)
+
+
+@pytest.mark.parametrize("fraction", [0.9, 0.5, 0.1, 0.0])
+def test_emulated_instance_capacity_overflow_stays_in_bounds(fraction):
+    """A render with MORE tile instances than its workspaces were sized for (the capacity policy sizes them from a
+    running bound without waiting for the device: dimo_amd/rasterizer.py CapacityPolicy) must flag the overflow, write
+    nothing out of bounds and leave finite images; forward and backward.  Here every workspace sits between two guard
+    regions in host memory, so a stray write is seen (or is a segmentation fault) rather than forgiven."""
+    cam = camera_np(25.0, elevation=8, W=96, H=80)
+    sc = random_scene(1500, seed=12, scale=0.04)
+    full = Run(sc, cam, (0.1, 0.1, 0.1), 0)
+    r_cap = max(1, int(full.R * fraction))
+    G = 4096  # guard bytes on either side
+    L = _layout(full.N, full.H, full.W, r_cap)
+
+    def guarded(nbytes):
+        buf = np.full(nbytes + 2 * G, 0xA7, np.uint8)
+        return buf, buf[G:G + nbytes]
+    bin_all, bin_ws = guarded(L["bin_bytes"])
+    img_all, img_ws = guarded(L["img_bytes"])
+    scr_all, scratch = guarded(L["scratch_bytes"])
+    H, W, N = full.H, full.W, full.N
+    color, depth, normal, alpha = (np.full(s, np.nan, np.float32) for s in ((3, H, W), (1, H, W), (3, H, W), (1, H, W)))
+    rc = R_().dimo_raster_render_forward(N, H, W, r_cap, _ptr(full.bg), _ptr(full.geom), _ptr(bin_ws), bin_ws.nbytes,
+                                         _ptr(img_ws), img_ws.nbytes, _ptr(color), _ptr(depth), _ptr(normal), _ptr(alpha), None)
+    assert rc == 0
+    total = full.geom[L["total"]:L["total"] + 16].view(np.uint32)
+    assert int(total[0]) == full.R and int(total[1]) == 1, "the overflow is flagged next to the instance count"
+    for a in (color, depth, normal, alpha):
+        assert np.isfinite(a).all()
+    a = full.a
+    g = [np.full(s, np.nan, np.float32) for s in ((N, 3), (N, 3), (N, 1, 3), (N, 1), (N, 3), (N, 4))]
+    gw = [np.ones(s, np.float32) for s in ((3, H, W), (1, H, W), (3, H, W), (1, H, W))]
+    rc = R_().dimo_raster_backward(
+        N, 0, 1, H, W, r_cap, _ptr(a["means3D"]), _ptr(a["shs"]), None, _ptr(a["opacities"]), _ptr(a["scales"]),
+        _ptr(a["rotations"]), None, 1.0, _ptr(full.view), _ptr(full.proj), _ptr(full.campos), _ptr(full.bg),
+        cam["tanfovx"], cam["tanfovy"], _ptr(full.radii), _ptr(full.geom), _ptr(bin_ws), _ptr(img_ws), _ptr(gw[0]),
+        _ptr(gw[1]), _ptr(gw[2]), _ptr(gw[3]), _ptr(g[0]), _ptr(g[1]), _ptr(g[2]), None, _ptr(g[3]), _ptr(g[4]), _ptr(g[5]),
+        None, _ptr(scratch), scratch.nbytes, None)
+    assert rc == 0
+    for x in g:
+        assert np.isfinite(x).all()
+    for whole in (bin_all, img_all, scr_all):
+        assert (whole[:G] == 0xA7).all() and (whole[-G:] == 0xA7).all(), "a write outside a workspace"
