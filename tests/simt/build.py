@@ -127,7 +127,11 @@ HEADERS = ["common.hpp", "proj_math.hpp", "wave_ops.hpp", "deform_body.hpp", "lo
 
 def build(force=False, target="binning"):
     hips, driver = TARGETS[target]
-    lib = os.path.join(OUT, "lib%s_emu.so" % target)
+    # SIMT_ASAN=1: the same libraries under AddressSanitizer (run the tests with LD_PRELOAD=$(gcc -print-file-name=libasan.so)
+    # ASAN_OPTIONS=detect_leaks=0:detect_stack_use_after_return=0): numpy's buffers are malloc'ed, so a kernel's read or
+    # write past the end of a workspace -- forgiven on a GPU while the page is mapped -- is reported with its source line
+    asan = bool(os.environ.get("SIMT_ASAN"))
+    lib = os.path.join(OUT, "lib%s_emu%s.so" % (target, "_asan" if asan else ""))
     srcs = [os.path.join(CSRC, n) for n in HEADERS + hips] + [os.path.join(HERE, n) for n in
             ("runtime.cpp", driver, "build.py", os.path.join("shim", "hip", "hip_runtime.h"))] + \
            [os.path.join(ROOT, "include", "dimo_hip.h")]
@@ -153,6 +157,8 @@ def build(force=False, target="binning"):
     cmd = ["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-pthread", "-fno-omit-frame-pointer", "-ffp-contract=off",
            "-I", os.path.join(HERE, "shim"), "-I", d, "-Wno-unused-function", "-Wno-psabi",
            os.path.join(HERE, "runtime.cpp"), os.path.join(HERE, driver)] + units + ["-o", lib]
+    if asan:
+        cmd[1:1] = ["-fsanitize=address"]
     subprocess.check_call(cmd)
     return lib
 

@@ -2,6 +2,9 @@
 // TEST INFRASTRUCTURE ONLY.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#ifdef __SANITIZE_ADDRESS__
+#include <sanitizer/asan_interface.h>
+#endif
 
 #include <atomic>
 #include <deque>
@@ -198,6 +201,10 @@ static void run_workgroup(Workgroup *g, Idx3 bid, Idx3 bdim, Idx3 gdim, const st
   for (int i = 0; i < n; ++i) {
     Fiber &f = g->f[i];
     if (!f.stack) f.stack = (char *)aligned_alloc(64, STACK_BYTES);
+#ifdef __SANITIZE_ADDRESS__
+    // (the frames a fiber left when it switched away for the last time never unpoisoned their redzones)
+    __asan_unpoison_memory_region(f.stack, STACK_BYTES);
+#endif
     f.wg = g, f.linear = i, f.wave = i >> 6, f.lane = i & 63, f.done = false;
     f.tid.x = i % bdim.x, f.tid.y = (i / bdim.x) % bdim.y, f.tid.z = i / (bdim.x * bdim.y);
     uintptr_t top = ((uintptr_t)f.stack + STACK_BYTES) & ~(uintptr_t)63;
