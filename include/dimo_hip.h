@@ -69,6 +69,8 @@ int dimo_timing_read(const char *name, double *total_ms, int64_t *launches);
  * bin  : tile-instance state (per-tile lists of Gaussian ids, tile ranges, level-1 lists, blend checkpoints).
  *        Sized for a CAPACITY R_cap >= R (number of (Gaussian, tile) instances).  Needed by backward.
  * img  : per-pixel state (final transmittance, n_contrib).  Needed by backward.
+ * Every workspace and scratch pointer of this header must sit on a 256-byte boundary (hipMalloc and torch's allocator
+ * give that): the kernels use 16- and 64-byte vector accesses at the layouts' offsets.
  */
 size_t dimo_raster_geom_bytes(int N);
 size_t dimo_raster_bin_bytes(int64_t R_cap, int H, int W);

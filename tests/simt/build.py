@@ -131,7 +131,10 @@ def build(force=False, target="binning"):
     # ASAN_OPTIONS=detect_leaks=0:detect_stack_use_after_return=0): numpy's buffers are malloc'ed, so a kernel's read or
     # write past the end of a workspace -- forgiven on a GPU while the page is mapped -- is reported with its source line
     asan = bool(os.environ.get("SIMT_ASAN"))
-    lib = os.path.join(OUT, "lib%s_emu%s.so" % (target, "_asan" if asan else ""))
+    # SIMT_UBSAN=1: ... under UndefinedBehaviorSanitizer (shifts by the operand's width or more, misaligned vector loads,
+    # signed overflow, out-of-range float -> int conversions: each hardware-defined on the GPU, none of them meant)
+    ubsan = bool(os.environ.get("SIMT_UBSAN"))
+    lib = os.path.join(OUT, "lib%s_emu%s%s.so" % (target, "_asan" if asan else "", "_ubsan" if ubsan else ""))
     srcs = [os.path.join(CSRC, n) for n in HEADERS + hips] + [os.path.join(HERE, n) for n in
             ("runtime.cpp", driver, "build.py", os.path.join("shim", "hip", "hip_runtime.h"))] + \
            [os.path.join(ROOT, "include", "dimo_hip.h")]
@@ -159,6 +162,8 @@ def build(force=False, target="binning"):
            os.path.join(HERE, "runtime.cpp"), os.path.join(HERE, driver)] + units + ["-o", lib]
     if asan:
         cmd[1:1] = ["-fsanitize=address"]
+    if ubsan:
+        cmd[1:1] = ["-fsanitize=undefined,float-cast-overflow", "-fno-sanitize=vptr"]
     subprocess.check_call(cmd)
     return lib
 

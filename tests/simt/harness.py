@@ -2,6 +2,7 @@
 not-gpu tests: inputs are what the projection kernel leaves per Gaussian (tile rectangle, tiles touched, depth bits,
 the per-block words), outputs the per-tile lists.  TEST INFRASTRUCTURE ONLY."""
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -10,6 +11,22 @@ from . import build as _build
 _lib = None
 PRE_BLOCK = 256
 
+
+
+def workspace(nbytes, fill=0x5A, align=256):
+    """`nbytes` of host memory on a 256-byte boundary, as hipMalloc and torch's allocator hand out (include/dimo_hip.h:
+    the kernels use 16- and 64-byte vector accesses on their workspaces).  Under AddressSanitizer
+    (tools/emulated_asan.sh) the slack in front of and behind the view is poisoned, so an access one byte past the
+    workspace is still reported."""
+    raw = np.full(nbytes + align, fill, np.uint8)
+    off = (-raw.ctypes.data) % align
+    view = raw[off:off + nbytes]
+    poison = getattr(C.CDLL(None), "__asan_poison_memory_region", None) if os.environ.get("SIMT_ASAN") else None
+    if poison is not None:
+        poison.argtypes = [C.c_void_p, C.c_size_t]
+        poison(raw.ctypes.data, off)
+        poison(raw.ctypes.data + off + nbytes, align - off)
+    return view
 
 def lib():
     global _lib
@@ -72,10 +89,10 @@ def run_binning(rect, tiles, key32, H, W, R_cap=None, n_batched=0, poison=True):
     n = max(n_batched, 1)
     geoms = [make_geom(rect, tiles, key32, H, W, G) for _ in range(n)]
     # (stale contents from an earlier use of the workspace must not matter)
-    bins = [np.full(B["bytes"], 0xA5 if poison else 0, np.uint8) for _ in range(n)]
+    bins = [workspace(B["bytes"], 0xA5 if poison else 0) for _ in range(n)]
     if n_batched:
         sb = int(L.simt_bwd_scratch_bytes(R_cap, H, W))
-        scr = [np.full(sb, 0x5A, np.uint8) for _ in range(n)]
+        scr = [workspace(sb, 0x5A) for _ in range(n)]
         arr = lambda bufs: (C.c_void_p * n)(*[b.ctypes.data for b in bufs])
         totals = np.zeros(2 * n, np.uint32)
         rc = L.simt_bin_instances_batched(N, H, W, R_cap, n, arr(geoms), arr(bins), arr(scr), G["bytes"], B["bytes"], sb,

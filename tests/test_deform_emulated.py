@@ -12,6 +12,7 @@ import torch
 
 from oracle.deform_ref import skinning_ref
 from tests.simt import build as simt_build
+from tests.simt import harness as hz
 
 _D = None
 NAMES = ("xyz", "rotation", "scaling", "opacity", "c_xyz", "c_log_radius", "d_xyz", "d_rot")
@@ -66,7 +67,7 @@ def _emulated(a, local_frame, w):
     assert rc == 0
     grads = [np.full(_np(a[k]).shape, np.nan, np.float32) for k in NAMES]
     nb = D().dimo_deform_backward_scratch_bytes(N, M)
-    scratch = np.full(max(nb, 16), 0x5A, np.uint8)
+    scratch = hz.workspace(max(nb, 16), 0x5A)
     rc = D().dimo_deform_backward(N, M, int(local_frame), 0, *[ptr(x) for x in ins], *[ptr(_np(x)) for x in w],
                                   *[ptr(x) for x in grads], ptr(scratch), nb, None)
     assert rc == 0

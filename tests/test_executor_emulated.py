@@ -20,6 +20,7 @@ from oracle import raster_oracle as ro
 from oracle.deform_ref import skinning_ref
 from tests.scenes import camera_np, random_scene
 from tests.simt import build as simt_build
+from tests.simt import harness as hz
 
 L1_TOL = 1e-4
 _LIBS = {}
@@ -100,8 +101,8 @@ class Step:
         self.seen = {k: nan(*v.shape) for k, v in self.out.items()}  # the images as the "loss kernels" saw them
         self.gw_live = [nan(*g.shape) for g in self.gw]
         self.slots = [dict(pts=nan(N, 3), rot=nan(N, 4), scales=nan(N, 3), opac=nan(N, 1), radii=np.full(N, -1, np.int32),
-                           geom=np.full(L["geom"], fill, np.uint8), bin=np.full(L["bin"], fill, np.uint8),
-                           img=np.full(L["img"], fill, np.uint8), bwd_scratch=np.full(L["bwd"], fill, np.uint8),
+                           geom=hz.workspace(L["geom"], fill), bin=hz.workspace(L["bin"], fill),
+                           img=hz.workspace(L["img"], fill), bwd_scratch=hz.workspace(L["bwd"], fill),
                            g_means3D=nan(N, 3), g_means2D=nan(N, 3), g_shs=nan(N, 1, 3), g_opac=nan(N, 1),
                            g_scales=nan(N, 3), g_rot=nan(N, 4)) for _ in range(n)]
         self.acc = dict(xyz=np.zeros((N, 3), np.float32), rotation=np.zeros((N, 4), np.float32),
@@ -109,7 +110,7 @@ class Step:
                         f_dc=np.zeros((N, 1, 3), np.float32), c_xyz=np.zeros((M, 3), np.float32),
                         c_log_radius=np.zeros((M, 1), np.float32), d_xyz=np.zeros(self.d_xyz.shape, np.float32),
                         d_rot=np.zeros((P, M, 4), np.float32), log_r=np.zeros((1, 1), np.float32))
-        self.lbs_scratch = np.full(L["lbs"] * n, fill, np.uint8)
+        self.lbs_scratch = hz.workspace(L["lbs"] * n, fill)
         self.totals = np.zeros((n, 2), np.int32)
         p = lambda a: a.ctypes.data
         c = self.common = StepCommon()

@@ -38,7 +38,7 @@ def _project(sc, cam, deg):
     lay = (C.c_size_t * 8)()
     P().simt_project_layout(N, lay)
     G = dict(zip(("splat", "rect", "tiles", "flags", "total", "key32", "block_sums", "bytes"), [int(x) for x in lay]))
-    geom = np.full(G["bytes"], 0x5A, np.uint8)
+    geom = hz.workspace(G["bytes"], 0x5A)
     radii = np.full(N, -1, np.int32)
     R = np.zeros(1, np.int64)
     arrs = {k: f(k) for k in ("means3D", "shs", "colors", "opacities", "scales", "rotations", "cov3D")}
@@ -92,7 +92,7 @@ def test_emulated_projection_into_emulated_binning():
     assert Gb["bytes"] == G["bytes"]
     # (the workspace was poisoned: the bucket totals and counters the binning starts from are what the projection's first
     # block cleared)
-    bin_ws = np.full(Bb["bytes"], 0xA5, np.uint8)
+    bin_ws = hz.workspace(Bb["bytes"], 0xA5)
     assert L.simt_bin_instances(N, H, W, max(R, 1), geom.ctypes.data, bin_ws.ctypes.data) == 0
     vals = bin_ws[Bb["vals"]:Bb["vals"] + 4 * R].view(np.uint32)
     ranges = bin_ws[Bb["ranges"]:Bb["ranges"] + 8 * Bb["T"]].view(np.uint32).reshape(-1, 2)

@@ -13,6 +13,7 @@ import pytest
 from oracle import raster_oracle as ro
 from tests.scenes import camera_np, random_scene
 from tests.simt import build as simt_build
+from tests.simt import harness as hz
 
 L1_TOL = 1e-4
 _R = None
@@ -58,7 +59,7 @@ class Run:
         self.bg = np.asarray(bg, np.float32)
         H, W = self.H, self.W
         L0 = _layout(N, H, W, 1)
-        self.geom = np.full(L0["geom_bytes"], 0x5A, np.uint8)
+        self.geom = hz.workspace(L0["geom_bytes"], 0x5A)
         self.radii = np.full(N, -1, np.int32)
         r = np.zeros(1, np.int64)
         rc = R_().dimo_raster_preprocess_forward(N, deg, self.M, H, W, _ptr(a["means3D"]), _ptr(a["shs"]), _ptr(a["colors"]),
@@ -69,8 +70,8 @@ class Run:
         self.R = int(r[0])
         self.r_cap = max(self.R, 1)
         self.L = L = _layout(N, H, W, self.r_cap)
-        self.bin = np.full(L["bin_bytes"], 0x5A, np.uint8)
-        self.img = np.full(L["img_bytes"], 0x5A, np.uint8)
+        self.bin = hz.workspace(L["bin_bytes"], 0x5A)
+        self.img = hz.workspace(L["img_bytes"], 0x5A)
         self.color, self.depth = np.full((3, H, W), np.nan, np.float32), np.full((1, H, W), np.nan, np.float32)
         self.normal = np.full((3, H, W), np.nan, np.float32) if with_normal else None
         self.alpha = np.full((1, H, W), np.nan, np.float32)
@@ -91,7 +92,7 @@ class Run:
                  scales=None if a["cov3D"] is not None else np.full((N, 3), np.nan, np.float32),
                  rotations=None if a["cov3D"] is not None else np.full((N, 4), np.nan, np.float32),
                  cov3D=None if a["cov3D"] is None else np.full((N, 6), np.nan, np.float32))
-        scratch = np.full(self.L["scratch_bytes"], 0x5A, np.uint8)
+        scratch = hz.workspace(self.L["scratch_bytes"], 0x5A)
         gw = [np.ascontiguousarray(x, np.float32) for x in gw]
         rc = R_().dimo_raster_backward(
             N, self.deg, self.M, self.H, self.W, self.r_cap, _ptr(a["means3D"]), _ptr(a["shs"]), _ptr(a["colors"]),
