@@ -13,7 +13,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.normpath(os.path.join(HERE, "..", ".."))
 CSRC = os.path.join(ROOT, "dimo_amd", "csrc")
-OUT = os.path.join(HERE, "_build")
+OUT = os.environ.get("SIMT_BUILD_DIR") or os.path.join(HERE, "_build")  # (the sanitizer builds go to /tmp: tools/emulated_asan.sh)
 
 def _place_tile_asm():
     text = open(os.path.join(CSRC, "binning.hip")).read()

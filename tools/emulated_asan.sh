@@ -7,6 +7,7 @@
 # misaligned vector accesses, signed overflow, out-of-range float -> int conversions); its reports go to /tmp/ubsan.log.*
 set -u
 cd "$(dirname "$0")/.."
+export SIMT_BUILD_DIR=${SIMT_BUILD_DIR:-/tmp/simt_build_sanitizers}
 if [ -n "${SIMT_UBSAN:-}" ]; then
   rm -f /tmp/ubsan.log.*
   export UBSAN_OPTIONS=print_stacktrace=0:log_path=/tmp/ubsan.log
