@@ -37,7 +37,19 @@ SUBST = {
 
 def _transformed(name, extra=()):
     text = open(os.path.join(CSRC, name)).read()
+    # SIMT_MUTANT="<file>|<k>|<old>|<new>": the k-th occurrence of <old> in the RAW <file> becomes <new>
+    # (tools/mutate_emulated.py: how many deliberately wrong kernels the emulated tests catch)
+    mutant = os.environ.get("SIMT_MUTANT")
+    if mutant:
+        mfile, k, mold, mnew = mutant.split("|")
+        if mfile == name:
+            at = -1
+            for _ in range(int(k) + 1):
+                at = text.index(mold, at + 1)
+            text = text[:at] + mnew + text[at + len(mold):]
     for old, new in list(SUBST[name]) + list(extra):
+        if mutant and text.count(old) < 1:
+            raise SystemExit("SIMT_MUTANT lands inside a substituted statement")
         assert text.count(old) >= 1, (name, old)
         text = text.replace(old, new)
     # kernel<<<grid, block, lds, stream>>>(args) -> hipLaunchKernelGGL((kernel), grid, block, lds, stream, args)
