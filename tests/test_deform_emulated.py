@@ -161,11 +161,16 @@ def test_emulated_flat_adam_matches_torch_adam_and_skip_flag():
     """dimo_flat_adam_step on the emulation vs torch.optim.Adam with per-segment learning rates (the GPU test's
     tolerance), a learning-rate change, the skip flag, the gradient clear and the two-launch split of a step."""
     g = torch.Generator().manual_seed(0)
-    sizes, lrs = [3000, 3000, 1000, 37, 2600, 160], [0.01, 0.0025, 0.05, 0.005, 0.0002, 0.0]
+    sizes, lrs = [3000, 3000, 1000, 39, 2600, 160], [0.01, 0.0025, 0.05, 0.005, 0.0002, 0.0]
     total = sum(sizes)
     flat = _np(torch.randn(total + 3, generator=g))[:total]  # (16-byte alignment: numpy's allocations are)
-    p, m, v = flat.copy(), np.zeros(total, np.float32), np.zeros(total, np.float32)
-    grads = np.zeros(total, np.float32)
+    # (every bucket is followed by eight sentinel floats: total = 9799 = 3 mod 4, the kernel's float4 path must
+    # stop in front of the ragged tail and the tail loop at n -- a mutant of either bound wrote one element too far and
+    # went unnoticed: tools/mutate_emulated.py)
+    SENT = np.float32(-12345.0)
+    bufs = [np.full(total + 8, SENT, np.float32) for _ in range(4)]
+    p, m, v, grads = (b[:total] for b in bufs)
+    p[:], m[:], v[:], grads[:] = flat, 0.0, 0.0, 0.0
     ref_params = [torch.nn.Parameter(torch.from_numpy(flat[o - n:o].copy())) for n, o in zip(sizes, np.cumsum(sizes))]
     ref = torch.optim.Adam([{"params": [q], "lr": lr} for q, lr in zip(ref_params, lrs)], lr=0.0, eps=1e-15)
     ends = np.cumsum(sizes).astype(np.int64)
@@ -194,6 +199,7 @@ def test_emulated_flat_adam_matches_torch_adam_and_skip_flag():
             assert step(k + 1) == 0
         ref.step()
         assert np.count_nonzero(grads) == 0
+    assert all((b[total:] == SENT).all() for b in bufs), "a write past the end of a bucket"
     want = torch.cat([q.detach() for q in ref_params]).numpy()
     assert np.abs(p - want).max() <= 2e-6 * max(1.0, np.abs(want).max())
     before = (p.copy(), m.copy(), v.copy())

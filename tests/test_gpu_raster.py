@@ -101,6 +101,16 @@ def _check_forward(sc, cam, bg, deg, with_normal=True, scale_mod=1.0):
     assert np.array_equal(n(st["keys_sorted"])[:R].view(np.uint64), o["keys_sorted"]), "sort keys differ"
     assert np.array_equal(n(st["vals_sorted"])[:R].view(np.uint32), o["vals_sorted"]), "sorted order differs"
     assert np.array_equal(n(st["ranges"]).view(np.uint32), o["ranges"])
+    # the (supertile, depth bin) entries the projection counted per Gaussian (what the level-1 capacity check rests on;
+    # found unverified by tools/mutate_emulated.py) against the tile rectangles
+    import ctypes as C
+    from dimo_amd import _lib
+    lay = (C.c_size_t * 10)()
+    assert _lib.lib().dimo_debug_bin_geom_layout(len(o["radii"]), cam["H"], cam["W"], lay) == 0
+    ss, rc = int(lay[9]), n(st["rect"]).astype(np.int64)
+    on = o["tiles_touched"] > 0
+    ent = ((((rc[:, 2] - 1) >> ss) - (rc[:, 0] >> ss) + 1) * (((rc[:, 3] - 1) >> ss) - (rc[:, 1] >> ss) + 1))[on].sum()
+    assert int(n(st["total"])[2]) == int(ent), "level-1 entry count"
     # ---- images
     H, W = cam["H"], cam["W"]
     nc = n(st["n_contrib"]).view(np.uint32)

@@ -133,3 +133,17 @@ def test_emulated_farthest_point_sampling(N, K):
     out = np.full(K, -1, np.int64)
     assert L().dimo_farthest_point_sample(N, K, _ptr(xyz), _ptr(scratch), _ptr(out), None) == 0
     assert np.array_equal(out, farthest_point_sample_ref(xyz, K))
+
+
+@pytest.mark.parametrize("N,K", [(700, 40), (300, 300)])
+def test_emulated_farthest_point_sampling_with_ties_across_waves(N, K):
+    """Points on a small integer lattice, many of them several times: the farthest distance is shared by points of
+    different waves at almost every step, and the LOWEST index has to win (the cross-wave tie-break went untested with
+    random points: tools/mutate_emulated.py)."""
+    from oracle.regularizers_ref import farthest_point_sample_ref
+    rng = np.random.default_rng(N)
+    xyz = rng.integers(0, 4, (N, 3)).astype(np.float32)
+    scratch = np.zeros(N, np.float32)
+    out = np.full(K, -1, np.int64)
+    assert L().dimo_farthest_point_sample(N, K, _ptr(xyz), _ptr(scratch), _ptr(out), None) == 0
+    assert np.array_equal(out, farthest_point_sample_ref(xyz, K))

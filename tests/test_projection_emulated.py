@@ -97,3 +97,11 @@ def test_emulated_projection_into_emulated_binning():
     vals = bin_ws[Bb["vals"]:Bb["vals"] + 4 * R].view(np.uint32)
     ranges = bin_ws[Bb["ranges"]:Bb["ranges"] + 8 * Bb["T"]].view(np.uint32).reshape(-1, 2)
     assert np.array_equal(vals, o["vals_sorted"]) and np.array_equal(ranges, o["ranges"])
+    # the (supertile, depth bin) ENTRIES the projection counted per Gaussian -- what the level-1 capacity check rests on
+    # (a mutant that dropped a "+ 1" from that count went unnoticed: tools/mutate_emulated.py) -- against the rectangles
+    ss = L.simt_supertile_shift(H, W)
+    rect = geom[G["rect"]:G["rect"] + 8 * N].view(np.uint16).reshape(N, 4).astype(np.int64)
+    on = o["tiles_touched"] > 0
+    ent = ((((rect[:, 2] - 1) >> ss) - (rect[:, 0] >> ss) + 1) * (((rect[:, 3] - 1) >> ss) - (rect[:, 1] >> ss) + 1))[on].sum()
+    total = geom[G["total"]:G["total"] + 16].view(np.uint32)
+    assert int(total[0]) == R and int(total[1]) == 0 and int(total[2]) == int(ent)

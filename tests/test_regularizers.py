@@ -92,3 +92,16 @@ def test_farthest_point_sampling_matches_restatement(N, K):
     assert len(set(want.tolist())) == K  # distinct points
     with pytest.raises(RuntimeError):
         rg.sample_farthest_points(pts, K)  # CPU tensors: no fallback
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,K", [(700, 40), (300, 300)])
+def test_farthest_point_sampling_with_ties_across_waves(N, K):
+    """Lattice points, many of them several times (tests/test_points_emulated.py's case on the GPU): at almost every
+    step the farthest distance is shared by points of different waves and the lowest index has to win."""
+    from dimo_amd import regularizers as rg
+    from oracle.regularizers_ref import farthest_point_sample_ref
+    rng = np.random.default_rng(N)
+    xyz = rng.integers(0, 4, (N, 3)).astype(np.float32)
+    _, idx = rg.sample_farthest_points(torch.from_numpy(xyz)[None].cuda(), K)
+    assert np.array_equal(idx[0].cpu().numpy(), farthest_point_sample_ref(xyz, K))

@@ -71,6 +71,8 @@ class EmulatedTimeNet:
 @pytest.mark.parametrize("D,W,skips,L,P,M", [
     (8, 256, (4,), 32, 2, 96),    # DIMO's TimeNet (the one-launch kernels), a small batch
     (8, 256, (4,), 32, 3, 53),    # ragged rows, a latent row used twice
+    (8, 256, (4,), 32, 2, 250),   # 500 rows: the weight-gradient tiles walk SEVERAL 64-row stages per K chunk (their
+                                  # "previous stage consumed" barrier was untested below ~320 rows: tools/mutate_emulated.py)
     (3, 64, (), 8, 2, 70),        # no skip, narrow: the per-layer GEMM path
     (4, 128, (1,), 0, 1, 33),     # no latent code
     (4, 256, (1,), 0, 2, 40),     # one-launch path: early skip, no latent code (72 embedding columns)
@@ -112,3 +114,4 @@ def test_emulated_timenet_under_other_fiber_schedules(order, monkeypatch):
     they need must be there when the fibers take turns in reverse or shuffled order."""
     monkeypatch.setenv("SIMT_ORDER", order)
     test_emulated_timenet_forward_backward_matches_float64_autograd(8, 256, (4,), 32, 3, 53)
+    test_emulated_timenet_forward_backward_matches_float64_autograd(8, 256, (4,), 32, 2, 250)

@@ -26,7 +26,7 @@ TESTS = {
     "preprocess.hip": ["tests/test_projection_emulated.py", "tests/test_raster_emulated.py"],
     "proj_math.hpp": ["tests/test_projection_emulated.py", "tests/test_raster_emulated.py"],
     "deform.hip": ["tests/test_deform_emulated.py", "tests/test_executor_emulated.py"],
-    "deform_body.hpp": ["tests/test_deform_emulated.py"],
+    "deform_body.hpp": ["tests/test_deform_emulated.py", "tests/test_executor_emulated.py"],
     "wave_ops.hpp": ["tests/test_deform_emulated.py", "tests/test_raster_emulated.py"],
     "adam.hip": ["tests/test_deform_emulated.py"],
     "ssim.hip": ["tests/test_losses_emulated.py"],
