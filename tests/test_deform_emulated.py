@@ -208,3 +208,26 @@ def test_emulated_flat_adam_matches_torch_adam_and_skip_flag():
     assert step(6) == 0
     assert np.array_equal(p, before[0]) and np.array_equal(m, before[1]) and np.array_equal(v, before[2])
     assert np.count_nonzero(grads) == 0 and skipped.max() == 1
+
+
+def test_emulated_flat_adam_report_and_next_steps_accumulators():
+    """dimo_flat_adam_step's optional extras (tests/test_gpu_ops.py holds the GPU to the same): `report` -- device words
+    copied behind a sequence number into a host-visible slot by the FINAL part of a step only --, and a scratch region
+    zeroed for the next step."""
+    n = 4096
+    p, g, m, v = (np.zeros(n, np.float32) for _ in range(4))
+    g[:] = 1.0
+    ends, lr = np.array([n], np.int64), np.array([0.1], np.float32)
+    src = np.array([1234, 1], np.uint32)
+    dst = np.zeros(3, np.uint32)
+    extra = np.ones(1000, np.float32)
+    ptr = lambda x: x.ctypes.data
+
+    def step(lo, hi, final, seq):
+        return D().dimo_flat_adam_step(n, ptr(p), ptr(g), ptr(m), ptr(v), 1, ptr(ends), ptr(lr), 0.9, 0.999, 1e-15, 1,
+                                       None, 0, 0, 1, None, ptr(src), 2, ptr(dst), seq, ptr(extra), extra.size, lo, hi,
+                                       final, None)
+    assert step(0, 2048, 0, 7) == 0  # the early part of a two-launch step: no report, nothing zeroed
+    assert dst[0] == 0 and (extra == 1.0).all() and (p[:2048] != 0).all() and (p[2048:] == 0).all()
+    assert step(2048, n, 1, 7) == 0
+    assert list(dst) == [7, 1234, 1] and (extra == 0.0).all() and (p != 0).all() and (g == 0).all()
