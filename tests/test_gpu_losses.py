@@ -28,6 +28,7 @@ def test_image_loss_kernel_vs_reference_assembly(B, H, W, share, dn):
     g = torch.Generator().manual_seed(B * H + W)
     image = torch.rand(B, 3, H, W, generator=g) * 1.4 - 0.2  # values outside [0,1] exercise the clamp mask
     image[:, :, :4] = 1.0  # exact boundary values (white background) must pass gradient like torch.clamp
+    image[:, :, 4:6] = 0.0  # ... and the lower boundary (a mutant that closed it went unnoticed: tools/mutate_emulated.py)
     depth = torch.rand(B, 1, H, W, generator=g) * 2
     normal = torch.randn(B, 3, H, W, generator=g)
     alpha = torch.rand(B, 1, H, W, generator=g)
@@ -92,6 +93,7 @@ def test_one_pass_ssim_and_image_losses_vs_reference_assembly(B, H, W, share, dn
     g = torch.Generator().manual_seed(B * H + W)
     image = torch.rand(B, 3, H, W, generator=g) * 1.4 - 0.2
     image[:, :, :4] = 1.0
+    image[:, :, 4:6] = 0.0
     depth = torch.rand(B, 1, H, W, generator=g) * 2
     normal = torch.randn(B, 3, H, W, generator=g)
     alpha = torch.rand(B, 1, H, W, generator=g)

@@ -147,3 +147,20 @@ def test_emulated_farthest_point_sampling_with_ties_across_waves(N, K):
     out = np.full(K, -1, np.int64)
     assert L().dimo_farthest_point_sample(N, K, _ptr(xyz), _ptr(scratch), _ptr(out), None) == 0
     assert np.array_equal(out, farthest_point_sample_ref(xyz, K))
+
+
+def test_emulated_farthest_point_sampling_tie_inside_one_thread_and_output_bound():
+    """Two identical far points whose indices are 1024 apart -- the same thread scans both -- among points at the origin:
+    the lower index has to win inside the thread too; and the kernel writes K indices, not K + 1 (a sentinel behind the
+    output).  Both went unnoticed by a mutant (tools/mutate_emulated.py)."""
+    from oracle.regularizers_ref import farthest_point_sample_ref
+    N, K = 1100, 5
+    xyz = np.zeros((N, 3), np.float32)
+    xyz[5] = xyz[1029] = (3.0, 4.0, 0.0)
+    xyz[300] = (0.0, 0.0, 1.0)
+    scratch = np.zeros(N, np.float32)
+    out = np.full(K + 1, -7, np.int64)
+    assert L().dimo_farthest_point_sample(N, K, _ptr(xyz), _ptr(scratch), _ptr(out), None) == 0
+    want = farthest_point_sample_ref(xyz, K)
+    assert want[1] == 5
+    assert np.array_equal(out[:K], want) and out[K] == -7
