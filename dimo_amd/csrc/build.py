@@ -63,7 +63,9 @@ def _stale(out, deps):
 
 def build(force=False, verbose=False):
     hipcc = _hipcc()
-    headers = [os.path.join(HERE, h) for h in ("common.hpp", "wave_ops.hpp", "proj_math.hpp", "deform_body.hpp")] + \
+    # every header of this directory is a dependency of every object (a glob, so that a new one cannot be forgotten:
+    # loss_terms.hpp was missing from the hand-written list in round 5)
+    headers = sorted(os.path.join(HERE, h) for h in os.listdir(HERE) if h.endswith(".hpp")) + \
               [os.path.join(HERE, "..", "..", "include", "dimo_hip.h"), __file__]
     objdir = os.path.join(HERE, "build" + ("_" + VARIANT if VARIANT else ""))
     os.makedirs(objdir, exist_ok=True)
@@ -72,7 +74,7 @@ def build(force=False, verbose=False):
     for src, extra in SOURCES.items():
         path = os.path.join(HERE, src)
         if not os.path.exists(path):
-            continue
+            raise FileNotFoundError(f"{path}: listed in SOURCES but missing -- the library would link without it")
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
         jobs.append((path, obj, extra))
 

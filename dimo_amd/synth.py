@@ -23,8 +23,14 @@ def ball_points(n, radius, rng):
     return np.stack((r * np.sin(thetas) * np.cos(phis), r * np.sin(thetas) * np.sin(phis), r * np.cos(thetas)), 1)
 
 
+REGIMES = ("init", "low", "trained")
+
+
 def init_synthetic_model(renderer, num_pts, num_cpts, seed=0, regime="trained", num_latent=51):
-    """Fills renderer.gaussians with the SURVEY 8d synthetic state (stage-2 layout: Gaussians + control points)."""
+    """Fills renderer.gaussians with the SURVEY 8d synthetic state (stage-2 layout: Gaussians + control points).
+    `regime` sets the opacities: "init" = every Gaussian at 0.05, what the reference creates them with
+    (renderer/latent_gs_renderer.py:431) and stage s2 starts from (:1038-1058) -- nothing saturates, every pixel looks
+    through its tile's whole list; "low" = U(0.01, 0.1); "trained" = sigmoid(U(-2, 4)), lists saturate early."""
     g = renderer.gaussians
     dev = g.device
     rng = np.random.default_rng(seed)
@@ -35,10 +41,14 @@ def init_synthetic_model(renderer, num_pts, num_cpts, seed=0, regime="trained", 
     rots = torch.zeros(num_pts, 4)
     rots[:, 0] = 1
     rots = rots + 0.1 * torch.randn(num_pts, 4, generator=tg)
-    if regime == "init":
+    if regime == "init":  # the reference's own initial state: every opacity 0.05 (latent_gs_renderer.py:431)
         opac = inverse_sigmoid(0.05 * torch.ones(num_pts, 1))
-    else:  # "trained": logits U(-2, 4)
+    elif regime == "low":  # early training, right behind "init": opacities U(0.01, 0.1)
+        opac = inverse_sigmoid(0.01 + 0.09 * torch.rand(num_pts, 1, generator=tg))
+    elif regime == "trained":  # logits U(-2, 4)
         opac = torch.rand(num_pts, 1, generator=tg) * 6 - 2
+    else:
+        raise ValueError(f"unknown regime {regime!r} (init | low | trained)")
     f_dc = RGB2SH(torch.rand(num_pts, 1, 3, generator=tg))
     k = (g.max_sh_degree + 1) ** 2
     P = lambda t: nn.Parameter(t.to(dev).float().contiguous().requires_grad_(True))

@@ -102,9 +102,11 @@ def test_train_step_gpu_matches_cpu_oracle_pipeline():
     assert rel < 2e-4, rel
 
 
-def test_train_step_at_benchmark_size_default_switches_matches_cpu_oracle_pipeline():
+@pytest.mark.parametrize("regime", ["trained", "init"])
+def test_train_step_at_benchmark_size_default_switches_matches_cpu_oracle_pipeline(regime):
     """The same comparison at C3 size (100 k Gaussians, 512 control points, 512^2, 8 renders) with every switch at
-    its default: the executor tests hold the KERNELS to the oracle at this size, this one holds the cross-stream
+    its default -- in the trained regime and in the reference's own initial state (every opacity 0.05: SURVEY 8d's
+    "init" regime, 7x the compositing work per render) --: the executor tests hold the KERNELS to the oracle at this size, this one holds the cross-stream
     SCHEDULE (two motions' chains on two private streams, skinning backward in order, fold + Adam head next to the
     TimeNet backward) -- a missed dependency shows as a wrong gradient bucket here, not as a rare flake."""
     from dimo_amd.rasterizer import CapacityPolicy
@@ -114,10 +116,10 @@ def test_train_step_at_benchmark_size_default_switches_matches_cpu_oracle_pipeli
     from tests.cpu_backend import make_cpu_trainer
     cfg = TrainConfig(num_pts=100000, num_cpts=512, num_motions=6, num_frames=6, num_views=4, motions_per_step=2,
                       views_per_step=2, frames_per_step=2, resolution=512, progressive_resolution=False)
-    cpu = make_cpu_trainer(cfg)
+    cpu = make_cpu_trainer(cfg, regime=regime)
     rd = Renderer(sh_degree=0, num_latent_code=cfg.num_motions, add_normal=True, device="cuda",
                   capacity=CapacityPolicy(initial=1 << 22))
-    init_synthetic_model(rd, cfg.num_pts, cfg.num_cpts, seed=cfg.seed, num_latent=cfg.num_motions)
+    init_synthetic_model(rd, cfg.num_pts, cfg.num_cpts, seed=cfg.seed, num_latent=cfg.num_motions, regime=regime)
     gpu = Trainer(cfg, rd)
     assert gpu.direct
     cpu.step = gpu.step = 300

@@ -29,7 +29,8 @@ def _rel_l1(a, b):
     return np.abs(a - b).sum() / (np.abs(b).sum() + 1e-12)
 
 
-def _run_batched(N, res, renders_per_motion, n_motions, seed=0, streams="-2", monkeypatch=None, joint=False):
+def _run_batched(N, res, renders_per_motion, n_motions, seed=0, streams="-2", monkeypatch=None, joint=False,
+                 regime="trained"):
     """Drives the executor the way Trainer._forward_backward_direct does (one range per motion, each range in
     order on its private stream) with random TimeNet outputs and random gradient images."""
     from dimo_amd import _lib  # noqa: F401
@@ -45,7 +46,7 @@ def _run_batched(N, res, renders_per_motion, n_motions, seed=0, streams="-2", mo
                       progressive_resolution=False)
     rd = Renderer(sh_degree=0, num_latent_code=cfg.num_motions, add_normal=True, device="cuda",
                   capacity=CapacityPolicy(initial=max(1 << 20, 40 * N)))
-    init_synthetic_model(rd, cfg.num_pts, cfg.num_cpts, seed=seed, num_latent=cfg.num_motions)
+    init_synthetic_model(rd, cfg.num_pts, cfg.num_cpts, seed=seed, num_latent=cfg.num_motions, regime=regime)
     tr = Trainer(cfg, rd)
     g = rd.gaussians
     tr.find_knn(4)
@@ -187,6 +188,24 @@ def test_joint_backward_launch_against_the_oracle(N, res, per_motion, motions, m
     assert ex.batched and ex.ranged
     for o in outs:
         _check_render(o, f_dc, bg, res, res)
+
+
+@pytest.mark.timeout(3600)
+@pytest.mark.parametrize("regime,joint", [("init", False), ("init", True), ("low", True)])
+def test_init_regime_batched_kernels_at_c3_against_the_oracle(regime, joint, monkeypatch):
+    """The benchmark's 8-render C3 batch in SURVEY 8d's "init" regime (every opacity 0.05, the state the reference's
+    stage s2 starts from: renderer/latent_gs_renderer.py:431,1038-1058) and right behind it (U(0.01, 0.1)): every pixel
+    looks through its tile's whole list, the forward checkpoints every bucket of every tile and the backward's deep
+    queue holds ~13 of every 15 items.  Per-motion launches (the timed default) and the joint launch (the roofline's),
+    per render against the C oracle, same bars as the trained regime."""
+    outs, f_dc, bg, ex = _run_batched(100_000, 512, 4, 2, seed=11, monkeypatch=monkeypatch, joint=joint, regime=regime)
+    assert ex.batched and ex.ranged
+    deep = []
+    for o in outs:
+        _check_render(o, f_dc, bg, 512, 512)
+        rg = o["st"]["ranges"].view(np.uint32).astype(np.int64)
+        deep.append(o["st"]["n_contrib"].view(np.uint32).mean() / max((rg[:, 1] - rg[:, 0]).mean(), 1))
+    assert min(deep) > 0.8, deep  # the deep regime: a pixel's last entry sits near the end of its list
 
 
 def test_batched_executor_single_stream_mode_small(monkeypatch):

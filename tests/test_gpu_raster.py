@@ -390,6 +390,24 @@ def test_baseline_config_sizes_against_the_oracle(N, R, scale):
     _check_backward(sc, cam, (0.0, 0.0, 0.0), 0, GRADS_SH)
 
 
+@pytest.mark.timeout(1800)
+@pytest.mark.parametrize("opacity", [(0.05, 0.05), (0.01, 0.1)], ids=["every_opacity_0.05", "opacity_0.01_to_0.1"])
+def test_init_regime_at_c3_size_against_the_oracle(opacity):
+    """SURVEY 8d's FIRST synthetic regime at C3 size: the reference creates every Gaussian at opacity 0.05
+    (renderer/latent_gs_renderer.py:431) and stage s2 starts from 102 400 of them (:1038-1058).  Nothing saturates: a
+    pixel's last contributing entry sits near the end of its tile's list (~900 entries deep against ~85 in the trained
+    regime), so the forward writes a checkpoint at every bucket boundary of every tile and the backward runs ~15 buckets
+    per tile from them -- the deep-chain path the trained scenes barely touch.  Same comparison as above: integer stages
+    bit for bit, images and every gradient within 1e-4."""
+    cam = camera_np(40.0, elevation=5, W=512, H=512)
+    sc = random_scene(100_000, seed=100_007, scale=0.012, anisotropy=0.3, opacity=opacity)
+    res, st, o = _check_forward(sc, cam, (0.0, 0.0, 0.0), 0)
+    ranges = o["ranges"].astype(np.int64)
+    mean_list = (ranges[:, 1] - ranges[:, 0]).mean()
+    assert o["n_contrib"].mean() > 0.8 * mean_list > 500, "not the deep regime this test is for"
+    _check_backward(sc, cam, (0.0, 0.0, 0.0), 0, GRADS_SH)
+
+
 def test_full_size_properties_100k_512():
     """BASELINE config size (100k Gaussians, 512^2): size-independent properties instead of the oracle."""
     cam = camera_np(40.0, W=512, H=512)

@@ -213,6 +213,20 @@ def test_emulated_backward_long_lists_read_checkpoints():
     _check_backward(sc, cam, (0.0, 0.0, 0.0), 0, GRADS_SH)
 
 
+@pytest.mark.parametrize("opacity", [(0.05, 0.05), (0.01, 0.1)], ids=["every_opacity_0.05", "opacity_0.01_to_0.1"])
+def test_emulated_init_regime_whole_lists_deep(opacity):
+    """SURVEY 8d's "init" regime (every opacity 0.05, renderer/latent_gs_renderer.py:431) at small size: nothing
+    saturates, every pixel's last entry sits near the end of its tile's list of several hundred, so the forward
+    checkpoints every bucket and the backward's deep queue carries most of the items (tests/test_gpu_raster.py and
+    tests/test_gpu_executor.py hold the same regime at C3 size on the GPU)."""
+    cam = camera_np(40.0, W=48, H=48)
+    sc = random_scene(3000, seed=13, scale=0.05, opacity=opacity)
+    r, o = _check_forward(sc, cam, (0.0, 0.0, 0.0), 0)
+    rg = o["ranges"].reshape(-1, 2).astype(np.int64)
+    assert o["n_contrib"].mean() > 0.8 * (rg[:, 1] - rg[:, 0]).mean() > 300
+    _check_backward(sc, cam, (0.0, 0.0, 0.0), 0, GRADS_SH)
+
+
 def test_emulated_backward_precomputed_colour_and_cov():
     cam = camera_np(120.0, elevation=-20, W=96, H=96)
     sc = random_scene(1500, seed=5, scale=0.04)

@@ -14,12 +14,14 @@ from dimo_amd import _lib
 
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(dev)
-tr, pol = bench.make_trainer(dev, 0, 1, 100000, 512)
+regime = sys.argv[sys.argv.index("--regime") + 1] if "--regime" in sys.argv else "trained"
+tr, pol = bench.make_trainer(dev, 0, 1, 100000, 512, regime=regime)
+print("regime:", regime)
 for _ in range(4):
     tr.train_step()
 torch.cuda.synchronize()
 L = _lib.lib()
-cap = 1 << 17
+cap = 1 << 18
 buf = torch.zeros(cap * 4, dtype=torch.int64, device=dev)
 import ctypes as C
 
@@ -60,7 +62,7 @@ hist, edges = np.histogram(ratio, bins=[1.0, 1.25, 1.5, 2.0, 2.5, 3.0, 3.5, 4.01
 print("items by mean quadrant visits per record:",
       ", ".join(f"[{edges[i]:.2f}, {edges[i + 1]:.2f}): {hist[i] / max(1, len(ratio)):.3f}" for i in range(len(hist))),
       f"| records weighted mean {n_quad.sum() / max(1, n_rec.sum()):.2f}")
-for b in range(0, 8):
+for b in range(0, 18):
     m = bucket == b
     if m.any():
         print(f"   bucket {b}: {m.sum():5d} items, duration mean {d[m].mean():8.0f} max {d[m].max():8d}, records/item "

@@ -20,7 +20,8 @@ if "--no-calibration" not in sys.argv:
     for _ in range(3):
         dst = src.clone()  # vectorized copy kernel: 1 GiB in, 1 GiB out
     torch.cuda.synchronize()
-tr, pol = bench.make_trainer(dev, 0, 1, 100000, 512)
+regime = sys.argv[sys.argv.index("--regime") + 1] if "--regime" in sys.argv else "trained"
+tr, pol = bench.make_trainer(dev, 0, 1, 100000, 512, regime=regime)
 if "--default-schedule" not in sys.argv:
     tr._joint_bwd = True  # the counters are read per launch of the roofline kernel: ONE launch over the step's 8 renders
 steps = int(sys.argv[sys.argv.index("--steps") + 1]) if "--steps" in sys.argv else 4
