@@ -22,7 +22,7 @@ _SIGNATURES = {
     "dimo_timing_select": (C.c_int, [C.c_char_p]),
     "dimo_timing_read": (C.c_int, [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "dimo_raster_geom_bytes": (C.c_size_t, [C.c_int]),
-    "dimo_raster_bin_bytes": (C.c_size_t, [C.c_int64, C.c_int, C.c_int]),
+    "dimo_raster_bin_bytes": (C.c_size_t, [C.c_int, C.c_int64, C.c_int, C.c_int]),
     "dimo_raster_img_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "dimo_raster_geom_layout": (C.c_int, [C.c_int, C.POINTER(C.c_size_t)]),
     "dimo_raster_bin_layout": (C.c_int, [C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_size_t)]),

@@ -6,7 +6,7 @@ using namespace dimo;
 extern "C" const char *dimo_version(void) { return "dimo_hip gfx950 0.1"; }
 
 extern "C" size_t dimo_raster_geom_bytes(int N) { return GeomLayout(N).bytes; }
-extern "C" size_t dimo_raster_bin_bytes(int64_t R_cap, int H, int W) { return BinLayout(R_cap, H, W).bytes; }
+extern "C" size_t dimo_raster_bin_bytes(int N, int64_t R_cap, int H, int W) { return BinLayout(R_cap, H, W, N).bytes; }
 extern "C" size_t dimo_raster_img_bytes(int H, int W) { return ImgLayout(H, W).bytes; }
 
 extern "C" int dimo_raster_geom_layout(int N, size_t out[6]) {
@@ -17,7 +17,7 @@ extern "C" int dimo_raster_geom_layout(int N, size_t out[6]) {
 }
 extern "C" int dimo_raster_bin_layout(int64_t R_cap, int H, int W, size_t out[3]) {
   if (!out || R_cap < 0 || H <= 0 || W <= 0) return DIMO_E_ARG;
-  BinLayout L(R_cap, H, W);
+  BinLayout L(R_cap, H, W, 1);  // (the three inspectable arrays lead the workspace: their offsets do not depend on N)
   out[0] = L.vals_b, out[1] = L.ranges, out[2] = L.totals;
   return DIMO_OK;
 }

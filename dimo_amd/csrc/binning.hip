@@ -363,7 +363,7 @@ __device__ __forceinline__ void level1_body(const BinArgs &a, void *geom, void *
   u64 *__restrict__ bk_tot = reinterpret_cast<u64 *>(bk + BK_TOT);
   uint4 *__restrict__ segs = at<uint4>(geom, a.g_segs);
   uint4 *__restrict__ l1tmp = at<uint4>(bin, a.b_l1tmp);
-  uint4 *__restrict__ l1ovf = l1tmp + (size_t)MAX_BUCKETS * BUCKET_REGION;  // (entries beyond a bucket's region)
+  uint4 *__restrict__ l1ovf = l1tmp + (size_t)(a.gi.NS << a.lg) * BUCKET_REGION;  // (entries beyond a bucket's region)
   // (a bucket that outgrows its region, rare: overflow slot of place p = wgob[bucket] + p -- this workgroup's row of a
   // table in global memory; LDS is what decides how many of these workgroups a CU holds)
   uint32_t *__restrict__ wgob = at<uint32_t>(geom, a.g_wgob) + (size_t)blockIdx.x * MAX_BUCKETS;
@@ -982,7 +982,7 @@ __device__ __forceinline__ void bucket_sort_body(const BinArgs &a, void *geom, v
   U.grpbase = at<uint32_t>(bin, a.b_grpbase), U.grpinfo = at<uint32_t>(bin, a.b_grpinfo), U.cntu = at<uint32_t>(bin, a.b_cntu);
   U.tile_tot = at<uint32_t>(bin, a.b_totals), U.tiles_x = a.gi.tiles_x, U.tiles_y = a.gi.tiles_y;
   BucketSrc S;
-  S.ovf = l1tmp + (size_t)MAX_BUCKETS * BUCKET_REGION, S.ovf_cap = a.l1cap, S.rec = s_seg;
+  S.ovf = l1tmp + (size_t)(a.gi.NS << a.lg) * BUCKET_REGION, S.ovf_cap = a.l1cap, S.rec = s_seg;
   uint4 mine[PER];
   bool have_mine = false;  // `mine` holds this item's entries already (requested while the previous item was ranked)
   tr.mark();
@@ -1403,6 +1403,7 @@ static bool make_args(int N, int H, int W, int64_t R_cap, int n_renders, const G
   if (per < G.per) per = G.per;
   if (per > MAX_L1_PER) return false;  // more than MAX_L1_PER * MAX_SEG * 256 Gaussians (2 M)
   a.N = N, a.nb = G.nb, a.per = per, a.nwg1 = (G.nb + per - 1) / per, a.lg = depth_bins_log2(N, a.gi.NS), a.T = B.T;
+  if ((a.gi.NS << a.lg) != B.nbuckets) return false;  // (the layout was built for another model size)
   a.R_cap = (uint32_t)B.cap;
   a.l1cap = B.l1cap;
   a.sort_grid = (int)bucket_grid((unsigned)(a.gi.NS << a.lg), n_renders);
@@ -1427,7 +1428,7 @@ static unsigned level2_grid(int N, int n_renders, int nbuckets) {
 
 int bin_instances(int N, int H, int W, int64_t R_cap, const void *geom_c, void *bin, hipStream_t stream) {
   GeomLayout G(N);
-  BinLayout B(R_cap, H, W);
+  BinLayout B(R_cap, H, W, N);
   BinArgs a;
   if (!make_args(N, H, W, R_cap, 1, G, B, a)) return DIMO_E_ARG;
   void *geom = const_cast<void *>(geom_c);  // offsets, bucket tables and the overflow flag live in the geometry workspace
@@ -1453,7 +1454,7 @@ int bin_instances(int N, int H, int W, int64_t R_cap, const void *geom_c, void *
 int bin_instances_batched(const dimo_step_common &c, const RenderBatch &b, int n, hipStream_t stream) {
   if (n <= 0) return DIMO_OK;
   GeomLayout G(c.N);
-  BinLayout B(c.R_cap, c.H, c.W);
+  BinLayout B(c.R_cap, c.H, c.W, c.N);
   BinArgs a;
   if (!make_args(c.N, c.H, c.W, c.R_cap, n, G, B, a)) return DIMO_E_ARG;
   if (c.bin_bytes < B.bytes || c.geom_bytes < G.bytes) return DIMO_E_WORKSPACE;
@@ -1483,7 +1484,7 @@ int bin_instances_batched(const dimo_step_common &c, const RenderBatch &b, int n
 int instance_depth_keys(int N, int H, int W, int64_t R_cap, const void *geom, const void *bin, uint32_t *out,
                         hipStream_t stream) {
   GeomLayout G(N);
-  BinLayout B(R_cap, H, W);
+  BinLayout B(R_cap, H, W, N);
   hipLaunchKernelGGL(depth_keys_kernel, dim3(1024), dim3(256), 0, stream, (uint32_t)B.cap, at<uint32_t>(geom, G.total),
                      at<uint32_t>(geom, G.key32), at<uint32_t>(bin, B.vals_b), out);
   return check_launch();

@@ -187,7 +187,11 @@ __device__ __forceinline__ void blend_fwd_body(
       // the state at the first entry of every bucket that STARTS A CHAIN of the backward (every `chain`-th bucket;
       // not bucket 0, whose state is T = 1 and empty sums)
       const uint32_t bucket = (start - lo) / BUCKET + (uint32_t)ch;
+#ifdef DIMO_ABL_NOCKPT
+      if (false) {
+#else
       if (bucket != 0u && bucket % chain == 0u) {
+#endif
         float *ck = ck_base + (size_t)bucket * (CKPT_FLOATS * TILE * TILE);
         ck[0] = T;
 #pragma unroll
@@ -299,6 +303,23 @@ __device__ unsigned long long *g_bwd_trace = nullptr;
 __device__ unsigned int g_bwd_trace_cap = 0;
 __device__ unsigned int g_bwd_trace_n = 0;
 
+// ablation builds (timing diagnostics, results wrong): -DDIMO_ABL_NOVISIT skips every quadrant visit, -DDIMO_ABL_NOREDUCE
+// keeps the visits and drops the per-record wave reduction, -DDIMO_ABL_NOCKPT drops the forward's checkpoint stores
+#ifdef DIMO_ABL_NOVISIT
+#define DIMO_ABL_SKIPVISIT true
+#else
+#define DIMO_ABL_SKIPVISIT false
+#endif
+#ifdef DIMO_ABL_NOREDUCE
+__device__ __forceinline__ float abl_keep(float (&v)[16]) {
+#pragma unroll
+  for (int k = 0; k < 13; ++k) asm volatile("" ::"v"(v[k]));
+  return v[0];
+}
+#define DIMO_ABL_REDUCE(v) abl_keep(v)
+#else
+#define DIMO_ABL_REDUCE(v) wave_reduce16<13>(v)
+#endif
 struct BwdView {  // one render's buffers as the backward sees them
   const uint32_t *vals;
   const Splat *splat;
@@ -458,7 +479,7 @@ __device__ __forceinline__ void blend_bwd_item(int H, int W, int tiles_x, uint32
     }                                                                                                              \
     bool any = false;                                                                                              \
     _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                                \
-      if (!((qm >> q) & 1u) || pos >= deepest[q]) continue; /* wave-uniform */                                      \
+      if (DIMO_ABL_SKIPVISIT || !((qm >> q) & 1u) || pos >= deepest[q]) continue; /* wave-uniform */                \
       any = true;                                                                                                  \
       ++n_quad;                                                                                                    \
       const float dx = dx0 - (float)((q & 1) * 8), dy = dy0 - (float)((q >> 1) * 8);                               \
@@ -485,7 +506,7 @@ __device__ __forceinline__ void blend_bwd_item(int H, int W, int tiles_x, uint32
     }                                                                                                              \
     if (any) {                                                                                                     \
       ++n_rec;                                                                                                     \
-      const float tot = wave_reduce16<13>(v); /* lane l: the wave total of value reduce16_slot(l); 13 in use */      \
+      const float tot = DIMO_ABL_REDUCE(v); /* lane l: the wave total of value reduce16_slot(l); 13 in use */         \
       if ((lane & 3) == 0) s_acc[(TT)][reduce16_slot(lane)] = tot; /* this wave is the only writer of the record */ \
     } else if (pos >= wlast) {                                                                                     \
       break; /* the list is ascending: nothing further reaches this tile */                                         \
@@ -652,7 +673,10 @@ __global__ void __launch_bounds__(64, BWD_WAVES_PER_SIMD) blend_bwd_batched_kern
 // / 3 / 4 buckets per item -- what a longer chain saves in state loads it loses several times over in the tail of the
 // launch -- so the switch that selected it is gone (round 5) and the head bucket (no checkpoint to read) is where the
 // traffic saving comes from.
-constexpr uint32_t BWD_CHAIN = 1u;
+#ifndef DIMO_BWD_CHAIN
+#define DIMO_BWD_CHAIN 1
+#endif
+constexpr uint32_t BWD_CHAIN = DIMO_BWD_CHAIN;
 
 static BlendOffsets blend_offsets(const GeomLayout &G, const BinLayout &B, const ImgLayout &I) {
   BlendOffsets o;
@@ -666,7 +690,7 @@ static BlendOffsets blend_offsets(const GeomLayout &G, const BinLayout &B, const
 int blend_forward_batched(const dimo_step_common &c, const RenderBatch &b, int n, hipStream_t stream) {
   if (n <= 0) return DIMO_OK;
   GeomLayout G(c.N);
-  BinLayout B(c.R_cap, c.H, c.W);
+  BinLayout B(c.R_cap, c.H, c.W, c.N);
   ImgLayout I(c.H, c.W);
   if (c.bin_bytes < B.bytes || c.img_bytes < I.bytes) return DIMO_E_WORKSPACE;
   const BlendOffsets o = blend_offsets(G, B, I);
@@ -684,7 +708,7 @@ int blend_forward_batched(const dimo_step_common &c, const RenderBatch &b, int n
 int blend_backward_batched(const dimo_step_common &c, const RenderBatch &b, int n, hipStream_t stream, bool joint) {
   if (n <= 0 || c.N <= 0) return DIMO_OK;
   GeomLayout G(c.N);
-  BinLayout B(c.R_cap, c.H, c.W);
+  BinLayout B(c.R_cap, c.H, c.W, c.N);
   ImgLayout I(c.H, c.W);
   if (c.bwd_scratch_bytes < align_up(B.cap * sizeof(SplatGrad)) + align_up(B.cap)) return DIMO_E_WORKSPACE;
   const BlendOffsets o = blend_offsets(G, B, I);
@@ -717,7 +741,7 @@ extern "C" int dimo_raster_render_forward(int N, int H, int W, int64_t R_cap, co
   if (N < 0 || H <= 0 || W <= 0 || R_cap < 0 || R_cap > 0xfffffff0LL) return DIMO_E_ARG;
   if (!bg || !geom || !bin || !img || !out_color || !out_depth || !out_alpha) return DIMO_E_ARG;
   GeomLayout G(N);
-  BinLayout B(R_cap, H, W);
+  BinLayout B(R_cap, H, W, N);
   ImgLayout I(H, W);
   if (bin_bytes < B.bytes || img_bytes < I.bytes) return DIMO_E_WORKSPACE;
   int rc = bin_instances(N, H, W, R_cap, geom, bin, stream);
@@ -806,7 +830,7 @@ extern "C" int dimo_raster_backward(int N, int sh_degree, int M, int H, int W, i
     return DIMO_E_ARG;
   if (scratch_bytes < dimo_raster_backward_scratch_bytes(N, R_cap)) return DIMO_E_WORKSPACE;
   GeomLayout G(N);
-  BinLayout B(R_cap, H, W);
+  BinLayout B(R_cap, H, W, N);
   ImgLayout I(H, W);
   const uint32_t cap = (uint32_t)B.cap;
   SplatGrad *inst = reinterpret_cast<SplatGrad *>(scratch);

@@ -142,9 +142,16 @@ struct BinLayout {
   size_t vals_b, ranges, totals, meta, l1tmp, l1a, l1b, l1list, grpbase, grpinfo, cntu, ckpt, work, order, bytes;
   int tiles_x, tiles_y, T;
   size_t cap, ckpt_slots, l1cap;
-  __host__ BinLayout(int64_t R_cap, int H, int W) {
+  int nbuckets;  // (supertile, depth bin) buckets of a render of N Gaussians: each owns a region of l1tmp
+  // N = the Gaussians of the model the workspace serves: the bucket count follows it (depth_bins_log2), and with it
+  // the regions of the unsorted level-1 array -- 32 MB at 100 k Gaussians / 512^2 (512 buckets) where the layout's
+  // limit of 2048 buckets would reserve 128 MB per workspace (round-5 advice: the drop-in path retains one bin workspace
+  // per render until the backward).  Every user of a workspace must build its layout from the same (R_cap, H, W, N).
+  __host__ BinLayout(int64_t R_cap, int H, int W, int N) {
     cap = (size_t)(R_cap > 0 ? R_cap : 1);
     tiles_x = (W + TILE - 1) / TILE, tiles_y = (H + TILE - 1) / TILE, T = tiles_x * tiles_y;
+    BinGrid gi_;
+    nbuckets = make_bin_grid(H, W, gi_) ? (gi_.NS << depth_bins_log2(N > 0 ? N : 1, gi_.NS)) : MAX_BUCKETS;
     size_t o = 0;
     // per instance, in the order of the per-tile lists: the Gaussian id.  (The instance's sort key is not stored: its
     // tile is the list it sits in -- `ranges` -- and its 32 depth bits are its Gaussian's, geom key32.)
@@ -152,12 +159,12 @@ struct BinLayout {
     ranges = o, o = align_up(o + (size_t)T * 2 * sizeof(uint32_t));
     totals = o, o = align_up(o + (size_t)T * sizeof(uint32_t));  // instances per tile (atomically summed)
     // level 1 (binning.hip): at most one entry per instance.  l1tmp: the 16-byte entries (depth bits, id, tile
-    // rectangle) as the level-1 workgroups leave them: a region of BUCKET_REGION slots per bucket -- 128 MB of
-    // HBM per render slot, of which a bucket touches what it holds --, then an overflow area; l1a / l1b: 64-bit scratch of
+    // rectangle) as the level-1 workgroups leave them: a region of BUCKET_REGION slots per bucket -- 64 KB of
+    // HBM per bucket, of which a bucket touches what it holds --, then an overflow area; l1a / l1b: 64-bit scratch of
     // the byte-wise fallback sort; l1list: the sorted entries (id, depth bits, tile rectangle), bucket by bucket, every
     // bucket (and every slice of a cut bucket) rounded up to whole groups of 64 -- hence the slack
     l1cap = (cap + 255) / 256 * 256 + 64 * (size_t)(MAX_BUCKETS + 2 * MAX_SLICES);
-    l1tmp = o, o = align_up(o + ((size_t)MAX_BUCKETS * BUCKET_REGION + l1cap) * 4 * sizeof(uint32_t));
+    l1tmp = o, o = align_up(o + ((size_t)nbuckets * BUCKET_REGION + l1cap) * 4 * sizeof(uint32_t));
     l1a = o, o = align_up(o + l1cap * sizeof(uint64_t));
     l1b = o, o = align_up(o + l1cap * sizeof(uint64_t));
     l1list = o, o = align_up(o + l1cap * 4 * sizeof(uint32_t));

@@ -496,7 +496,7 @@ int preprocess_backward_batched(const dimo_step_common &c, const RenderBatch &b,
   const uint32_t cap = (uint32_t)(c.R_cap > 0xffffffffLL ? 0xffffffffu : (uint32_t)c.R_cap);
   const size_t flag_offset = align_up((size_t)(c.R_cap > 0 ? c.R_cap : 1) * sizeof(SplatGrad));
   // few Gaussians (stage s1): their instance records are summed one workgroup per Gaussian first
-  BinLayout B(c.R_cap, c.H, c.W);
+  BinLayout B(c.R_cap, c.H, c.W, c.N);
   const bool presum = c.N <= PRESUM_MAX_N && B.l1b - B.l1a >= 64 * (size_t)c.N && c.bin_bytes >= B.bytes;
   ScopedTimer tm(T_PREPROCESS_BWD, stream);
   if (presum)

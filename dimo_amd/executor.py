@@ -103,7 +103,7 @@ class StepExecutor:
         # knows nothing about) still use the old workspaces
         torch.cuda.synchronize()
         self.r_cap = r_cap
-        self.bin_bytes = self.L.dimo_raster_bin_bytes(r_cap, self.H, self.W)
+        self.bin_bytes = self.L.dimo_raster_bin_bytes(self.N, r_cap, self.H, self.W)
         self.bwd_bytes = self.L.dimo_raster_backward_scratch_bytes(self.N, r_cap)
         for s in self.slots:
             s["bin"] = torch.empty(self.bin_bytes, dtype=torch.uint8, device=self.device)

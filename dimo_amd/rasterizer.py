@@ -252,7 +252,7 @@ def raster_forward(means3D, shs, colors_precomp, opacities, scales, rotations, c
         r_cap = int(capacity.next_capacity())
         capacity.track(_total_view(geom, N))
 
-    bin_ws = torch.empty(L.dimo_raster_bin_bytes(r_cap, H, W), dtype=torch.uint8, device=dev)
+    bin_ws = torch.empty(L.dimo_raster_bin_bytes(N, r_cap, H, W), dtype=torch.uint8, device=dev)
     img_ws = torch.empty(L.dimo_raster_img_bytes(H, W), dtype=torch.uint8, device=dev)
     if out is None:
         color = torch.empty(3, H, W, dtype=torch.float32, device=dev)

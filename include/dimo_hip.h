@@ -73,7 +73,10 @@ int dimo_timing_read(const char *name, double *total_ms, int64_t *launches);
  * give that): the kernels use 16- and 64-byte vector accesses at the layouts' offsets.
  */
 size_t dimo_raster_geom_bytes(int N);
-size_t dimo_raster_bin_bytes(int64_t R_cap, int H, int W);
+/* (bin: N = the Gaussians of the model the workspace serves -- the binning's (supertile, depth bin) bucket count, and
+ * with it the size of the unsorted level-1 array's bucket regions, follows N; every call that takes the workspace takes
+ * the same N) */
+size_t dimo_raster_bin_bytes(int N, int64_t R_cap, int H, int W);
 size_t dimo_raster_img_bytes(int H, int W);
 
 /* Byte offsets of the inspectable sub-buffers (used by the parity tests; all 256-B aligned).

@@ -16,8 +16,8 @@ void simt_geom_layout(int N, size_t out[10]) {
   out[6] = G.bk, out[7] = G.bytes, out[8] = (size_t)G.nb, out[9] = G.bk + dimo::BK_TOT * sizeof(uint32_t);
 }
 // out: vals, ranges, totals, order, bytes, T, cap, l1tmp, l1list, meta, grpbase, grpinfo, cntu, l1cap
-void simt_bin_layout(int64_t R_cap, int H, int W, size_t out[14]) {
-  dimo::BinLayout B(R_cap, H, W);
+void simt_bin_layout(int N, int64_t R_cap, int H, int W, size_t out[14]) {
+  dimo::BinLayout B(R_cap, H, W, N);
   out[0] = B.vals_b, out[1] = B.ranges, out[2] = B.totals, out[3] = B.order, out[4] = B.bytes;
   out[5] = (size_t)B.T, out[6] = B.cap;
   out[7] = B.l1tmp, out[8] = B.l1list, out[9] = B.meta, out[10] = B.grpbase, out[11] = B.grpinfo, out[12] = B.cntu;
@@ -49,7 +49,7 @@ int simt_bin_instances_batched(int N, int H, int W, int64_t R_cap, int n, void *
   return dimo::bin_instances_batched(c, b, n, nullptr);
 }
 size_t simt_bwd_scratch_bytes(int64_t R_cap, int H, int W) {
-  dimo::BinLayout B(R_cap, H, W);
+  dimo::BinLayout B(R_cap, H, W, 1);
   return dimo::align_up(B.cap * sizeof(dimo::SplatGrad)) + dimo::align_up(B.cap);
 }
 }

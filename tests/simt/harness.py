@@ -33,7 +33,7 @@ def lib():
     if _lib is None:
         L = C.CDLL(_build.build(target="binning"))
         L.simt_geom_layout.argtypes = [C.c_int, C.POINTER(C.c_size_t)]
-        L.simt_bin_layout.argtypes = [C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_size_t)]
+        L.simt_bin_layout.argtypes = [C.c_int, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_size_t)]
         L.simt_supertile_shift.argtypes = [C.c_int, C.c_int]
         L.simt_bin_instances.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]
         L.simt_bin_instances_batched.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int, C.POINTER(C.c_void_p),
@@ -51,7 +51,7 @@ def _layouts(N, H, W, R_cap):
     g = (C.c_size_t * 10)()
     b = (C.c_size_t * 14)()
     L.simt_geom_layout(N, g)
-    L.simt_bin_layout(R_cap, H, W, b)
+    L.simt_bin_layout(N, R_cap, H, W, b)
     G = dict(zip(("rect", "tiles", "offsets", "total", "block_sums", "key32", "bk", "bytes", "nb", "bk_tot"), [int(x) for x in g]))
     B = dict(zip(("vals", "ranges", "totals", "order", "bytes", "T", "cap", "l1tmp", "l1list", "meta", "grpbase", "grpinfo",
                   "cntu", "l1cap"), [int(x) for x in b]))

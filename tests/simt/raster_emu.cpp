@@ -15,7 +15,7 @@ extern "C" {
 // geom: splat, rect, tiles, offsets, total; bin: vals, ranges; img: final_T, n_contrib, final_acc; bin capacity
 void simt_raster_layout(int N, int H, int W, int64_t R_cap, size_t out[16]) {
   dimo::GeomLayout G(N);
-  dimo::BinLayout B(R_cap, H, W);
+  dimo::BinLayout B(R_cap, H, W, N);
   dimo::ImgLayout I(H, W);
   out[0] = G.bytes, out[1] = B.bytes, out[2] = I.bytes;
   out[3] = dimo::align_up(B.cap * sizeof(dimo::SplatGrad)) + dimo::align_up(B.cap);

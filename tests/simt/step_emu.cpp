@@ -16,7 +16,7 @@ extern "C" {
 size_t dimo_deform_backward_scratch_bytes(int N, int M);
 void simt_step_layout(int N, int M, int H, int W, int64_t R_cap, size_t out[8]) {
   dimo::GeomLayout G(N);
-  dimo::BinLayout B(R_cap, H, W);
+  dimo::BinLayout B(R_cap, H, W, N);
   dimo::ImgLayout I(H, W);
   out[0] = G.bytes, out[1] = B.bytes, out[2] = I.bytes;
   out[3] = dimo::align_up(B.cap * sizeof(dimo::SplatGrad)) + dimo::align_up(B.cap);

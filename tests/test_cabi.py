@@ -41,7 +41,11 @@ def test_layout_queries(lib):
         assert offs == sorted(offs) and all(o % 256 == 0 for o in offs)
     assert g[1] - g[0] >= 1000 * 64 and b[1] - b[0] >= 50000 * 4 and i[1] - i[0] >= 128 * 96 * 4
     assert lib.dimo_raster_geom_bytes(1000) > g[5]
-    assert lib.dimo_raster_bin_bytes(50000, 128, 96) > b[2]
+    assert lib.dimo_raster_bin_bytes(1000, 50000, 128, 96) > b[2]
+    # the bucket regions of the unsorted level-1 array follow the model's size (64 KB per (supertile, depth bin) bucket):
+    # a 100 k-Gaussian model at 512^2 reserves 512 of them, not the layout's limit of 2048
+    small, big = lib.dimo_raster_bin_bytes(100_000, 1 << 20, 512, 512), lib.dimo_raster_bin_bytes(2_000_000, 1 << 20, 512, 512)
+    assert big - small == (2048 - 512) * 4096 * 16
     assert lib.dimo_raster_geom_bytes(0) > 0  # empty scenes still get a valid workspace
     assert lib.dimo_raster_bin_layout(-1, 128, 96, b) == -1  # DIMO_E_ARG
 

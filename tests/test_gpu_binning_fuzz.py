@@ -28,7 +28,7 @@ def _run(L, rect, tiles, key, H, W, dev):
     host[G["key32"]:G["key32"] + 4 * N] = k32.view(np.uint8)
     host[G["block_sums"]:G["block_sums"] + sums.nbytes] = sums.reshape(-1).view(np.uint8)
     geom = torch.from_numpy(host).to(dev)
-    bin_ws = torch.full((int(L.dimo_raster_bin_bytes(cap, H, W)),), 0xA5, dtype=torch.uint8, device=dev)
+    bin_ws = torch.full((int(L.dimo_raster_bin_bytes(N, cap, H, W)),), 0xA5, dtype=torch.uint8, device=dev)
     s = torch.cuda.current_stream(dev).cuda_stream
     assert L.dimo_debug_bin_instances(N, H, W, cap, geom.data_ptr(), bin_ws.data_ptr(), s) == 0
     dk = torch.zeros(cap, dtype=torch.int32, device=dev)
