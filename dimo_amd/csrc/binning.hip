@@ -79,8 +79,7 @@ __device__ __forceinline__ uint32_t sub_bin(uint32_t key, const SubMap &m) {
 }
 
 constexpr int GRP = 64;  // sorted level-1 entries per level-2 group: one wave
-// the small words of the bin workspace (`meta`, uint32): [0] number of groups the fill walks
-constexpr int META_NGRP = 0;
+// (the small words of the bin workspace, `meta`: common.hpp)
 
 struct BinArgs {
   int N, nb, per, nwg1, lg, T;  // Gaussians, preprocess blocks, blocks per level-1 workgroup, level-1 workgroups,
@@ -1240,7 +1239,11 @@ __device__ __forceinline__ void level2_fill_body(const BinArgs &a, void *geom, v
     // for the blend forward behind this kernel
     uint32_t *ranges = at<uint32_t>(bin, a.b_ranges), *total_w = at<uint32_t>(geom, a.g_total);
     uint32_t *work_count = at<uint32_t>(bin, a.b_work);
-    if (tid == 0) work_count[0] = 0, work_count[1] = 0, work_count[2] = 0;
+    if (tid == 0) {
+      work_count[0] = 0, work_count[1] = 0, work_count[2] = 0;
+      uint32_t *meta_w = at<uint32_t>(bin, a.b_meta);
+      meta_w[META_TICK] = 0u, meta_w[META_TICK + 1] = 0u;  // the blend forward's (tiles done | buckets reached) word
+    }
     // ... and the bucket totals, so that the chain can run again on the same projection (preprocess clears them too)
     uint32_t *bk = at<uint32_t>(geom, a.g_bk);
     for (int t = tid; t < 2 * MAX_BUCKETS; t += SORT_BLOCK) bk[BK_TOT + t] = 0u;

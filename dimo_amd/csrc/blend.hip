@@ -112,7 +112,17 @@ __device__ __forceinline__ void blend_fwd_body(
     const Splat *__restrict__ splat, const float *__restrict__ bg, float *__restrict__ out_color,
     float *__restrict__ out_depth, float *__restrict__ out_normal, float *__restrict__ out_alpha,
     float *__restrict__ final_T, uint32_t *__restrict__ n_contrib, float *__restrict__ final_acc,
-    float *__restrict__ ckpt, uint32_t *__restrict__ work, uint32_t chain, int tile) {
+    float *__restrict__ ckpt, uint32_t *__restrict__ work, uint32_t chain_arg, uint32_t *__restrict__ meta,
+    int tile) {
+  // Buckets per backward work item (chain).  Fixed by the caller (chain_arg > 0), or ADAPTIVE (chain_arg = 0, the step
+  // executor's persistent render slots): read from the workspace, where the previous forward over it left what ITS lists
+  // called for -- see the end of this function.  The backward needs no word of it: its items say where they start and
+  // how many buckets they walk.
+  uint32_t chain = chain_arg;
+  if (chain == 0u) {
+    const uint32_t cw = meta[META_CHAIN];
+    chain = (cw == 2u || cw == 4u) ? cw : 1u;  // (a fresh workspace holds anything)
+  }
   __shared__ uint32_t s_last[BLEND_BLOCK / 64];
   __shared__ float4 s_geo[BATCH];   // x y A B
   __shared__ float4 s_col[BATCH];   // C opacity r g
@@ -187,11 +197,7 @@ __device__ __forceinline__ void blend_fwd_body(
       // the state at the first entry of every bucket that STARTS A CHAIN of the backward (every `chain`-th bucket;
       // not bucket 0, whose state is T = 1 and empty sums)
       const uint32_t bucket = (start - lo) / BUCKET + (uint32_t)ch;
-#ifdef DIMO_ABL_NOCKPT
-      if (false) {
-#else
       if (bucket != 0u && bucket % chain == 0u) {
-#endif
         float *ck = ck_base + (size_t)bucket * (CKPT_FLOATS * TILE * TILE);
         ck[0] = T;
 #pragma unroll
@@ -274,6 +280,23 @@ __device__ __forceinline__ void blend_fwd_body(
           q[2 * T + base + (i - 2)] = make_uint4(((uint32_t)tile << 12) | (i * chain), lo, hi, min(chain, nb - i * chain));
       }
     }
+    // Adaptive chains.  One bucket per item is right where lists saturate early (a trained scene: ~2.3 buckets per tile
+    // reached, ~2 400 items per render -- longer items lose more in the launch's tail than they save in state loads: 2 %
+    // slower at two buckets per item); where every pixel walks its whole list (the reference's initial state, every
+    // opacity 0.05: ~15.5 buckets per tile, 16 000 items per render) the items are plenty, and what an item of four
+    // buckets saves -- three of four checkpoint stores here, three of four checkpoint + pixel-state loads there -- shows:
+    // forward 659 -> 629 us, backward 1396 -> 1302 us per 8 renders (profiles/r06_blend_chains.txt).  The render's last
+    // tile (ONE 64-bit atomic per tile carries the count of tiles done and the buckets they reached: whoever sees
+    // T - 1 tiles before it holds the total) leaves the length for the next forward over this workspace.
+    if (chain_arg == 0u) {
+      const uint32_t n_tiles = gridDim.x;  // (a launch has one workgroup per tile and render)
+      const unsigned long long old = atomicAdd(reinterpret_cast<unsigned long long *>(meta + META_TICK),
+                                               1ull | ((unsigned long long)nb << 32));
+      if ((uint32_t)old == n_tiles - 1u) {
+        const uint32_t total_nb = (uint32_t)(old >> 32) + nb;
+        meta[META_CHAIN] = total_nb >= 8u * n_tiles ? 4u : (total_nb >= 4u * n_tiles ? 2u : 1u);
+      }
+    }
   }
 }
 
@@ -303,23 +326,6 @@ __device__ unsigned long long *g_bwd_trace = nullptr;
 __device__ unsigned int g_bwd_trace_cap = 0;
 __device__ unsigned int g_bwd_trace_n = 0;
 
-// ablation builds (timing diagnostics, results wrong): -DDIMO_ABL_NOVISIT skips every quadrant visit, -DDIMO_ABL_NOREDUCE
-// keeps the visits and drops the per-record wave reduction, -DDIMO_ABL_NOCKPT drops the forward's checkpoint stores
-#ifdef DIMO_ABL_NOVISIT
-#define DIMO_ABL_SKIPVISIT true
-#else
-#define DIMO_ABL_SKIPVISIT false
-#endif
-#ifdef DIMO_ABL_NOREDUCE
-__device__ __forceinline__ float abl_keep(float (&v)[16]) {
-#pragma unroll
-  for (int k = 0; k < 13; ++k) asm volatile("" ::"v"(v[k]));
-  return v[0];
-}
-#define DIMO_ABL_REDUCE(v) abl_keep(v)
-#else
-#define DIMO_ABL_REDUCE(v) wave_reduce16<13>(v)
-#endif
 struct BwdView {  // one render's buffers as the backward sees them
   const uint32_t *vals;
   const Splat *splat;
@@ -479,7 +485,7 @@ __device__ __forceinline__ void blend_bwd_item(int H, int W, int tiles_x, uint32
     }                                                                                                              \
     bool any = false;                                                                                              \
     _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                                \
-      if (DIMO_ABL_SKIPVISIT || !((qm >> q) & 1u) || pos >= deepest[q]) continue; /* wave-uniform */                \
+      if (!((qm >> q) & 1u) || pos >= deepest[q]) continue; /* wave-uniform */                                      \
       any = true;                                                                                                  \
       ++n_quad;                                                                                                    \
       const float dx = dx0 - (float)((q & 1) * 8), dy = dy0 - (float)((q >> 1) * 8);                               \
@@ -506,7 +512,7 @@ __device__ __forceinline__ void blend_bwd_item(int H, int W, int tiles_x, uint32
     }                                                                                                              \
     if (any) {                                                                                                     \
       ++n_rec;                                                                                                     \
-      const float tot = DIMO_ABL_REDUCE(v); /* lane l: the wave total of value reduce16_slot(l); 13 in use */         \
+      const float tot = wave_reduce16<13>(v); /* lane l: the wave total of value reduce16_slot(l); 13 in use */      \
       if ((lane & 3) == 0) s_acc[(TT)][reduce16_slot(lane)] = tot; /* this wave is the only writer of the record */ \
     } else if (pos >= wlast) {                                                                                     \
       break; /* the list is ascending: nothing further reaches this tile */                                         \
@@ -601,7 +607,7 @@ __global__ void __launch_bounds__(BLEND_BLOCK) blend_fwd_kernel(
     float *__restrict__ final_T, uint32_t *__restrict__ n_contrib, float *__restrict__ final_acc,
     float *__restrict__ ckpt, uint32_t *__restrict__ work, uint32_t chain) {
   blend_fwd_body<NORMAL>(H, W, tiles_x, ranges, vals_sorted, splat, bg, out_color, out_depth, out_normal, out_alpha,
-                         final_T, n_contrib, final_acc, ckpt, work, chain, (int)blockIdx.x);
+                         final_T, n_contrib, final_acc, ckpt, work, chain, nullptr, (int)blockIdx.x);
 }
 // (Round 4 also built the visit's eight accumulations on the matrix pipe -- two v_mfma_f32_4x4x1_16b_f32 per visit,
 // accumulators transposed: 27 vector instructions + 2 MFMAs instead of 37, parity identical -- and measured it slower,
@@ -621,7 +627,7 @@ __global__ void __launch_bounds__(64, BWD_WAVES_PER_SIMD) blend_bwd_kernel(int H
 // the renders' items over a one-dimensional grid.
 struct BlendOffsets {
   size_t splat, rect, offsets, total;           // geom
-  size_t ranges, vals, ckpt, work, order;       // bin
+  size_t ranges, vals, ckpt, work, order, meta; // bin
   size_t final_T, n_contrib, final_acc;         // img
   size_t flag;                                  // backward scratch: records at 0, flags here
 };
@@ -639,7 +645,7 @@ __global__ void __launch_bounds__(BLEND_BLOCK) blend_fwd_batched_kernel(int H, i
                          at<Splat>(r.geom, o.splat), bg, r.out_color, r.out_depth, NORMAL ? r.out_normal : nullptr,
                          r.out_alpha, at<float>(r.img, o.final_T), at<uint32_t>(r.img, o.n_contrib),
                          at<float>(r.img, o.final_acc), at<float>(r.bin, o.ckpt), at<uint32_t>(r.bin, o.work),
-                         chain, tile);
+                         chain, at<uint32_t>(r.bin, o.meta), tile);
 }
 template <bool NORMAL>
 struct BatchView {
@@ -667,21 +673,22 @@ __global__ void __launch_bounds__(64, BWD_WAVES_PER_SIMD) blend_bwd_batched_kern
                                                                                     RenderBatch b) {
   blend_bwd_loop<NORMAL>(H, W, tiles_x, R_cap, bg, n, BatchView<NORMAL>{b, o});
 }
-// Buckets per backward item: ONE.  The kernels take the number as an argument (an item walking 2-4 consecutive buckets
-// with the pixel state in registers, checkpoints only at chain starts, was built and oracle-tested in round 2), but
-// measured on the C3 batch (4 renders, ~10^4 buckets for 4096 wave slots) 189 / 231 / 245 / 273 us per launch at 1 / 2
-// / 3 / 4 buckets per item -- what a longer chain saves in state loads it loses several times over in the tail of the
-// launch -- so the switch that selected it is gone (round 5) and the head bucket (no checkpoint to read) is where the
-// traffic saving comes from.
+// Buckets per backward item.  Rounds 2-5 ran ONE: measured on the trained C3 batch (4 renders, ~10^4 buckets for 4096
+// wave slots) 189 / 231 / 245 / 273 us per launch at 1 / 2 / 3 / 4 buckets per item -- what a longer chain saves in state
+// loads it loses several times over in the tail of the launch.  Round 6 measured the reference's INITIAL state (every
+// opacity 0.05: every pixel walks its whole list, 127 000 items per 8-render launch): 1396 / 1314 / 1302 us at 1 / 2 / 4
+// (forward 659 / 635 / 629), the step +4.9 % / +6.9 %, and the trained step -2.5 % at 2.  So the length follows the
+// lists: the batched forward picks it per render slot from what the slot's previous render looked like (blend_fwd_body).
 #ifndef DIMO_BWD_CHAIN
-#define DIMO_BWD_CHAIN 1
+#define DIMO_BWD_CHAIN 0
 #endif
-constexpr uint32_t BWD_CHAIN = DIMO_BWD_CHAIN;
+constexpr uint32_t BWD_CHAIN = DIMO_BWD_CHAIN;          // batched launches: 0 = adaptive (a build may fix 1, 2 or 4)
+constexpr uint32_t BWD_CHAIN_SINGLE = DIMO_BWD_CHAIN ? DIMO_BWD_CHAIN : 1;  // single-render launches (fresh workspaces)
 
 static BlendOffsets blend_offsets(const GeomLayout &G, const BinLayout &B, const ImgLayout &I) {
   BlendOffsets o;
   o.splat = G.splat, o.rect = G.rect, o.offsets = G.offsets, o.total = G.total;
-  o.ranges = B.ranges, o.vals = B.vals_b, o.ckpt = B.ckpt, o.work = B.work, o.order = B.order;
+  o.ranges = B.ranges, o.vals = B.vals_b, o.ckpt = B.ckpt, o.work = B.work, o.order = B.order, o.meta = B.meta;
   o.final_T = I.final_T, o.n_contrib = I.n_contrib, o.final_acc = I.final_acc;
   o.flag = align_up(B.cap * sizeof(SplatGrad));
   return o;
@@ -694,7 +701,7 @@ int blend_forward_batched(const dimo_step_common &c, const RenderBatch &b, int n
   ImgLayout I(c.H, c.W);
   if (c.bin_bytes < B.bytes || c.img_bytes < I.bytes) return DIMO_E_WORKSPACE;
   const BlendOffsets o = blend_offsets(G, B, I);
-  const uint32_t chain = BWD_CHAIN;
+  const uint32_t chain = BWD_CHAIN;  // (0: adaptive, the length the slot's previous forward left in its workspace)
   ScopedTimer tm(T_BLEND_FWD, stream);
 #define DIMO_LAUNCH_FWD(N_)                                                                                    \
   hipLaunchKernelGGL((blend_fwd_batched_kernel<N_>), dim3(B.T, n), dim3(BLEND_BLOCK), 0, stream, c.H, c.W, B.tiles_x, \
@@ -754,7 +761,7 @@ extern "C" int dimo_raster_render_forward(int N, int H, int W, int64_t R_cap, co
   hipLaunchKernelGGL((blend_fwd_kernel<N_>), dim3(B.T), dim3(BLEND_BLOCK), 0, stream, H, W, B.tiles_x, ranges, vals, \
                      splat, bg, out_color, out_depth, out_normal, out_alpha, at<float>(img, I.final_T),              \
                      at<uint32_t>(img, I.n_contrib), at<float>(img, I.final_acc), at<float>(bin, B.ckpt),            \
-                     at<uint32_t>(bin, B.work), BWD_CHAIN)
+                     at<uint32_t>(bin, B.work), BWD_CHAIN_SINGLE)
   if (out_normal) DIMO_LAUNCH_FWD(true);
   else DIMO_LAUNCH_FWD(false);
 #undef DIMO_LAUNCH_FWD

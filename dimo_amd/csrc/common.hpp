@@ -136,6 +136,10 @@ struct GeomLayout {
   }
 };
 
+// the small words of the bin workspace (`BinLayout::meta`, uint32[16]): [0] number of groups the level-2 fill walks;
+// [2..3] one 64-bit word of the blend forward (tiles done | buckets reached << 32, reset by the fill); [4] the chain
+// length -- buckets per backward work item -- the NEXT forward over this workspace uses (blend.hip: adaptive chains)
+constexpr int META_NGRP = 0, META_TICK = 2, META_CHAIN = 4;
 constexpr int BUCKET = 64;       // list entries per backward work item
 constexpr int CKPT_FLOATS = 9;   // T, 7 accumulated features, accumulated weight
 struct BinLayout {

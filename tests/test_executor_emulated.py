@@ -61,12 +61,12 @@ class Step:
     """A model, n renders (pair_of[i] = the (motion, frame) pair render i shows) and every buffer of
     dimo_amd/executor.py's StepExecutor, in host memory."""
 
-    def __init__(self, N, M, H, W, pair_of, seed=0, stage1=False, r_cap=None):
+    def __init__(self, N, M, H, W, pair_of, seed=0, stage1=False, r_cap=None, scale=0.03, opacity=(0.2, 0.95)):
         self.N, self.M, self.H, self.W, self.pair_of, self.n = N, M, H, W, pair_of, len(pair_of)
         self.stage1 = stage1  # stage s1: the TimeNet moves every Gaussian itself, one shared log-radius
         n, P = self.n, max(pair_of) + 1
         rng = np.random.default_rng(seed)
-        sc = random_scene(N, seed=seed, scale=0.03)
+        sc = random_scene(N, seed=seed, scale=scale, opacity=opacity)
         self.xyz = _f32(sc["means3D"])
         self.rotation = _f32(sc["rotations"] * rng.uniform(0.5, 2.0, (N, 1)))  # (raw: not unit length)
         self.scaling = _f32(np.log(sc["scales"]))
@@ -91,9 +91,10 @@ class Step:
         self.lay = dict(zip(("geom", "bin", "img", "bwd", "lbs", "vals", "ranges", "total"), (int(x) for x in lay)))
         self.fresh()
 
-    def fresh(self, fill=0x5A):
+    def fresh(self, fill=0x5A, keep_bin=False):
         """New outputs, workspaces and zeroed gradient accumulators; the descriptors over them.  The gradient images
-        the descriptors point to start as NaN: `losses` puts the real ones there."""
+        the descriptors point to start as NaN: `losses` puts the real ones there.  keep_bin: the bin workspaces keep
+        what the previous step left in them, like the trainer's persistent render slots."""
         N, M, H, W, n, L = self.N, self.M, self.H, self.W, self.n, self.lay
         P = max(self.pair_of) + 1
         nan = lambda *s: np.full(s, np.nan, np.float32)
@@ -105,8 +106,9 @@ class Step:
             self._ws = [dict(geom=hz.workspace(L["geom"], fill), bin=hz.workspace(L["bin"], fill),
                              img=hz.workspace(L["img"], fill), bwd_scratch=hz.workspace(L["bwd"], fill)) for _ in range(n)]
         for w in self._ws:
-            for a_ in w.values():
-                a_[...] = fill
+            for k_, a_ in w.items():
+                if not (keep_bin and k_ == "bin"):
+                    a_[...] = fill
         self.slots = [dict(pts=nan(N, 3), rot=nan(N, 4), scales=nan(N, 3), opac=nan(N, 1), radii=np.full(N, -1, np.int32),
                            **self._ws[i],
                            g_means3D=nan(N, 3), g_means2D=nan(N, 3), g_shs=nan(N, 1, 3), g_opac=nan(N, 1),
@@ -341,6 +343,28 @@ def run_ranged_step(st, sequence, deferred):
         E.simt_synchronize()
         E.dimo_executor_destroy(ex)
         del st.launch_of
+
+
+def test_emulated_executor_adaptive_chains():
+    """The batched forward picks the backward's chain length (buckets of 64 list entries per work item) per render slot
+    from what the slot's PREVIOUS forward left in its bin workspace (blend.hip: adaptive chains).  Deep lists -- every
+    Gaussian over most of a small image at opacity 0.01-0.05, ~11 buckets per tile, SURVEY 8d's "init" regime in
+    miniature -- ask for four: the first step over fresh workspaces runs one bucket per item and leaves 4, the second
+    and third run four; every step must match the oracle, and shallow lists take the length back to one."""
+    st = Step(700, 12, 48, 32, PAIRS_4, seed=5, scale=0.25, opacity=(0.01, 0.05))
+    meta = hz._layouts(st.N, st.H, st.W, st.r_cap)[1]["meta"]
+    word = lambda i: int(st._ws[i]["bin"][meta + 16:meta + 20].view(np.uint32)[0])
+    for rnd, sequence in enumerate(("in_order_skinned", "joint", "in_order")):
+        st.fresh(keep_bin=rnd > 0)
+        run_ranged_step(st, sequence, False)
+        assert [word(i) for i in range(st.n)] == [4] * st.n
+    # the same slots then serve a model with short lists: the first step still runs chains of four (correctly), and
+    # leaves 1
+    shallow = Step(700, 12, 48, 32, PAIRS_4, seed=7, scale=0.02)
+    shallow._ws = st._ws
+    shallow.fresh(keep_bin=True)
+    run_ranged_step(shallow, "in_order_skinned", False)
+    assert [word(i) for i in range(shallow.n)] == [1] * shallow.n
 
 
 @pytest.mark.parametrize("streams", STREAM_ORDERS)
