@@ -360,7 +360,7 @@ def test_emulated_executor_adaptive_chains():
         assert [word(i) for i in range(st.n)] == [4] * st.n
     # the same slots then serve a model with short lists: the first step still runs chains of four (correctly), and
     # leaves 1
-    shallow = Step(700, 12, 48, 32, PAIRS_4, seed=7, scale=0.02)
+    shallow = Step(700, 12, 48, 32, PAIRS_4, seed=7, scale=0.006)
     shallow._ws = st._ws
     shallow.fresh(keep_bin=True)
     run_ranged_step(shallow, "in_order_skinned", False)
