@@ -186,11 +186,14 @@ def scene_stats(tr, slot=0):
     deepest = pad.view(ty, 16, tx, 16).amax(dim=(1, 3)).reshape(-1)
     nb = (deepest + 63) // 64
     lens = (st["ranges"][:, 1] - st["ranges"][:, 0]).to(torch.int64).clamp_(min=0)
+    # buckets per backward item as the forward picks them per render slot (blend.hip, adaptive chains: the rule below
+    # on the PREVIOUS render of the slot -- the same scene in steady state): a checkpoint is written where a chain starts
+    chain = 4 if int(nb.sum()) >= 8 * nb.numel() else (2 if int(nb.sum()) >= 4 * nb.numel() else 1)
     return {"R_tile_instances": int(st["total"][0].item()) & 0xFFFFFFFF,
             "mean_tile_list": float(lens.float().mean()), "n_contrib_mean": float(nc.float().mean()),
-            "pixel_entry_pairs": int((deepest * 256).sum()), "blend_bwd_items": int(nb.sum()),
-            "buckets_per_tile_mean": float(nb.float().mean()),
-            "checkpoint_bytes_written": int((nb - 1).clamp_(min=0).sum()) * 9 * 256 * 4,
+            "pixel_entry_pairs": int((deepest * 256).sum()), "blend_bwd_items": int(((nb + chain - 1) // chain).sum()),
+            "buckets_per_tile_mean": float(nb.float().mean()), "buckets_per_backward_item": chain,
+            "checkpoint_bytes_written": int(((nb - 1).clamp_(min=0) // chain).sum()) * 9 * 256 * 4,
             "instance_capacity": int(ex.r_cap)}
 
 

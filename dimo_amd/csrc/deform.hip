@@ -162,106 +162,132 @@ __global__ void __launch_bounds__(DEF_BLOCK) lbs_bwd_kernel(
   lbs_bwd_body<LOCAL_FRAME, ACC>(N, M, g, t, g_xyz, g_rot, g_scales, g_opacity, d_xyz_out, d_rot_out, d_scaling_out,
                                  d_opacity_out, partials, NoExtra{});
 }
-// blockIdx.y = deformation group.  Per-Gaussian gradients are written IN PLACE over the LEADER's rasterizer
-// gradients (g_means3D -> d xyz, g_rot -> d rotation, g_scales -> d scaling, g_opac -> d opacity: same shapes);
-// accumulate_batched_kernel then folds the leaders into the shared gradient views in a fixed order.
+// The step executor's skinning backward (round 6): ONE kernel per launch of up to MAX_BATCH renders, no partial tables,
+// no reduction kernel, no fold.  A thread owns one Gaussian and walks the launch's deformation GROUPS (the renders that
+// share their TimeNet rows) one after the other: the group's control-point table goes to LDS, the thread sums the
+// rasterizer gradients of the group's renders (the backward is linear in them), runs the skinning backward of its
+// Gaussian, and keeps the per-Gaussian results -- d xyz, d rotation, d scaling, d opacity and the colour gradient -- in
+// registers across the groups; the control-point sums of a group (LDS table, scatter by matching lanes: wave_ops.hpp)
+// leave the workgroup as global fp32 atomics on the rows it TOUCHED -- a workgroup of Morton-neighbours names 10-30 of
+// the 512 control points; rounds 2-5 wrote the whole 22 KB table per workgroup and group (69 MB per step) and summed the
+// tables in a second kernel.  At the end a thread adds its 14 sums to the flat gradient bucket with one atomic each.
+// Run-to-run: a launch's contribution to a word is one add of a value formed in a fixed order, so a step of TWO launches
+// (the benchmark's two motions, each on its own stream) leaves the per-Gaussian head of the bucket bit-identical
+// whatever their order ((0 + a) + b == (0 + b) + a); the control-point words were and are order-dependent in the last
+// bits (LDS float atomics inside a workgroup, now also across workgroups).
+// Reference: renderer/latent_gs_renderer.py:1191-1219 (the autograd of the LBS block), main_train_dimo.py:415.
 template <bool LOCAL_FRAME>
-__global__ void __launch_bounds__(DEF_BLOCK) lbs_bwd_batched_kernel(int N, int M, GaussIO g, const float *c_xyz,
-                                                                    const float *c_lr, RenderBatch b,
-                                                                    float *__restrict__ partials) {
-  const int lead = b.leader[blockIdx.y];
-  const dimo_render_desc &r = b.r[lead];
-  lbs_bwd_body<LOCAL_FRAME, false>(N, M, g, CtrlTable{c_xyz, c_lr, r.d_xyz, r.d_rot}, r.g_means3D, r.g_rot,
-                                   r.g_scales, r.g_opac, r.g_means3D, r.g_rot, r.g_scales, r.g_opac,
-                                   partials + (size_t)blockIdx.y * gridDim.x * M * CP_STRIDE,
-                                   GroupExtra{b, b.members[blockIdx.y] & ~(1u << lead)});
+__global__ void __launch_bounds__(DEF_BLOCK) lbs_bwd_groups_kernel(int N, int M, GaussIO g, const float *c_xyz,
+                                                                   const float *c_lr, RenderBatch b, float *g_xyz,
+                                                                   float *g_rotation, float *g_scaling,
+                                                                   float *g_opacity, float *g_f_dc, float *g_c_xyz,
+                                                                   float *g_c_lr) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *s_cp = smem;                   // the group's control-point table
+  float *s_acc = smem + M * CP_STRIDE;  // ... and its gradient accumulators
+  const int lane = threadIdx.x & 63;
+  const int i0 = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  // whole waves stay in the loop (the control-point scatter combines lanes); lanes past N compute on the last
+  // Gaussian and contribute / store nothing
+  const bool valid = i0 < N;
+  const int i = valid ? i0 : N - 1;
+  const float x0 = g.xyz[3 * i], x1 = g.xyz[3 * i + 1], x2 = g.xyz[3 * i + 2];
+  const float4 q0 = *reinterpret_cast<const float4 *>(g.rot + 4 * (size_t)i);
+  const float4 dd = *reinterpret_cast<const float4 *>(g.nn_dist + 4 * (size_t)i);
+  const float op_raw = g.opacity[i];
+  const float sc_raw[3] = {g.scaling[3 * i], g.scaling[3 * i + 1], g.scaling[3 * i + 2]};
+  int idx0[DEF_K];
+#pragma unroll
+  for (int k = 0; k < DEF_K; ++k) idx0[k] = (int)g.nn_idx[4 * (size_t)i + k];
+  float a_rot[4] = {0.f, 0.f, 0.f, 0.f}, a_xyz[3] = {0.f, 0.f, 0.f}, a_sc[3] = {0.f, 0.f, 0.f}, a_op = 0.f;
+  float a_f[3] = {0.f, 0.f, 0.f};
+  for (int q = 0; q < b.n_groups; ++q) {
+    const int lead = b.leader[q];
+    const unsigned mem = b.members[q];
+    const dimo_render_desc &r = b.r[lead];
+    __syncthreads();  // (the previous group's flush has read both tables)
+    load_ctrl_to_lds(CtrlTable{c_xyz, c_lr, r.d_xyz, r.d_rot}, M, s_cp);
+    for (int j = threadIdx.x; j < M * CP_STRIDE; j += blockDim.x) s_acc[j] = 0.f;
+    // the rasterizer gradients of the group's renders, summed: every load of a member is requested before its first add
+    float4 go = make_float4(0.f, 0.f, 0.f, 0.f);
+    float gp[3] = {0.f, 0.f, 0.f}, gsc[3] = {0.f, 0.f, 0.f}, gopac = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAX_BATCH; ++j)
+      if ((mem >> j) & 1u) {  // (wave-uniform)
+        const dimo_render_desc &rj = b.r[j];
+        const float4 t = *reinterpret_cast<const float4 *>(rj.g_rot + 4 * (size_t)i);
+        const float p0 = rj.g_means3D[3 * i], p1 = rj.g_means3D[3 * i + 1], p2 = rj.g_means3D[3 * i + 2];
+        const float s0 = rj.g_scales[3 * i], s1 = rj.g_scales[3 * i + 1], s2 = rj.g_scales[3 * i + 2];
+        const float o = rj.g_opac[i];
+        const float f0 = rj.g_shs[3 * i], f1 = rj.g_shs[3 * i + 1], f2 = rj.g_shs[3 * i + 2];
+        go.x += t.x, go.y += t.y, go.z += t.z, go.w += t.w;
+        gp[0] += p0, gp[1] += p1, gp[2] += p2;
+        gsc[0] += s0, gsc[1] += s1, gsc[2] += s2;
+        gopac += o;
+        a_f[0] += f0, a_f[1] += f1, a_f[2] += f2;
+      }
+    __syncthreads();
+    int idx[DEF_K];  // (lbs_bwd_math re-orders its copy together with the distances)
+#pragma unroll
+    for (int k = 0; k < DEF_K; ++k) idx[k] = idx0[k];
+    float4 d_rot;
+    float dxs[3];
+    lbs_bwd_math<LOCAL_FRAME>(s_cp, s_acc, x0, x1, x2, q0, dd, idx, go, gp, valid, lane, d_rot, dxs);
+    a_rot[0] += d_rot.x, a_rot[1] += d_rot.y, a_rot[2] += d_rot.z, a_rot[3] += d_rot.w;
+    a_xyz[0] += dxs[0], a_xyz[1] += dxs[1], a_xyz[2] += dxs[2];
+    a_sc[0] += gsc[0], a_sc[1] += gsc[1], a_sc[2] += gsc[2];
+    a_op += gopac;
+    __syncthreads();
+    if (LOCAL_FRAME) {  // columns 0..2 from the summed columns 4..6 (deform_body.hpp)
+      lbs_ctrl_position_grad(M, s_cp, s_acc);
+      __syncthreads();
+    }
+    // the rows this workgroup touched: columns 0..2 -> d c_xyz, 3 -> d c_log_radius (shared by every group), 4..6 / 7..10
+    // -> the gradients of this group's TimeNet rows
+    for (int m = threadIdx.x; m < M; m += blockDim.x) {
+      const float *ac = s_acc + m * CP_STRIDE;
+      float v[CP_STRIDE];
+#pragma unroll
+      for (int c = 0; c < CP_STRIDE; ++c) v[c] = ac[c];
+      bool any = false;
+#pragma unroll
+      for (int c = 3; c < CP_STRIDE; ++c) any |= v[c] != 0.f;  // (columns 0..2 derive from 4..6)
+      if (!any) continue;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) unsafeAtomicAdd(g_c_xyz + 3 * m + c, v[c]);
+      unsafeAtomicAdd(g_c_lr + m, v[3]);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) unsafeAtomicAdd(r.g_d_xyz + 3 * m + c, v[4 + c]);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) unsafeAtomicAdd(r.g_d_rot + 4 * m + c, v[7 + c]);
+    }
+  }
+  if (valid) {
+    const float o = 1.0f / (1.0f + __expf(-op_raw));
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      unsafeAtomicAdd(g_xyz + 3 * (size_t)i + c, a_xyz[c]);
+      unsafeAtomicAdd(g_scaling + 3 * (size_t)i + c, a_sc[c] * __expf(sc_raw[c]));
+      unsafeAtomicAdd(g_f_dc + 3 * (size_t)i + c, a_f[c]);
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) unsafeAtomicAdd(g_rotation + 4 * (size_t)i + c, a_rot[c]);
+    unsafeAtomicAdd(g_opacity + i, a_op * o * (1.0f - o));
+  }
 }
 
-// Batched control-point reduction: the sums of a group's partial tables are formed by 16 chunk-threads per output
-// (tables chunk, chunk + 16, ...), up to four groups side by side in the workgroup's third dimension, every load of a
-// thread issued before its first add -- the kernel is a few hundred workgroups of pure memory latency on the step's
-// critical path (a loop with one load in flight took 90 us next to the other motion's blend kernels; groups one
-// after the other in the same threads, 20-30 us once the backward wrote 384 tables per group).  One thread then owns
-// output j of EVERY group, so the adds into the shared control-point gradients are ordered.
-constexpr int RED_GROUPS = 4;   // groups reduced side by side (threadIdx.z)
-constexpr int RED_LOADS = 32;   // tables per chunk-thread and pass: 16 x 32 = 512 tables in one round of loads
-//
-// `stage_end` (optional): the sums that go to the SHARED control-point gradients (d c_xyz, d c_log_radius) are not
-// added there but STORED in the group leader's staging table -- M x 4 floats at stage_end - (slot + 1) * stride, slot =
-// first_abs + leader -- and folded in by accumulate_batched_kernel: the skinning backward of two motions can then run
-// on two streams at once (nothing shared is written), and the fold adds the groups in a fixed order.
-__global__ void __launch_bounds__(256 * RED_GROUPS) lbs_reduce_batched_kernel(int M, int nblocks, int n_groups,
-                                                                              const float *__restrict__ partials,
-                                                                              float *d_c_xyz, float *d_c_lr,
-                                                                              RenderBatch b, float *stage_end,
-                                                                              size_t stage_stride, int first_abs) {
-  __shared__ float s_part[MAX_BATCH][16][17];
-  const int jj = threadIdx.x & 15, chunk = threadIdx.x >> 4, zz = threadIdx.z;
-  const int j = blockIdx.x * 16 + jj;
-  const int jc = min(j, M * CP_STRIDE - 1);
-  const int m = jc / CP_STRIDE, c = jc % CP_STRIDE;
-  for (int r = zz; r < n_groups; r += RED_GROUPS) {
-    const float *p = partials + (size_t)r * nblocks * M * CP_STRIDE + jc;
-    float s = 0.f;
-    for (int k0 = chunk; k0 < nblocks; k0 += 16 * RED_LOADS) {
-      float v[RED_LOADS];
-#pragma unroll
-      for (int it = 0; it < RED_LOADS; ++it) v[it] = p[(size_t)min(k0 + 16 * it, nblocks - 1) * M * CP_STRIDE];
-#pragma unroll
-      for (int it = 0; it < RED_LOADS; ++it) s += (k0 + 16 * it < nblocks) ? v[it] : 0.f;
-    }
-    s_part[r][chunk][jj] = s;
-  }
-  __syncthreads();
-  if (zz != 0 || chunk != 0 || j >= M * CP_STRIDE) return;
-  for (int r = 0; r < n_groups; ++r) {
-    float s = 0.f;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) s += s_part[r][k][jj];
-    float *dst;
-    if (c < 4 && stage_end) {
-      (stage_end - (size_t)(first_abs + (int)b.leader[r] + 1) * stage_stride)[4 * m + c] = s;
-      continue;
-    }
-    if (c < 3) dst = d_c_xyz + 3 * m + c;
-    else if (c == 3) dst = d_c_lr + m;
-    else if (c < 7) dst = b.r[b.leader[r]].g_d_xyz + 3 * m + (c - 4);
-    else dst = b.r[b.leader[r]].g_d_rot + 4 * m + (c - 7);
-    *dst += s;
-  }
-}
-
-// dst[i] += sum_r src_r[i] for the five per-Gaussian gradient arrays of a batch (fixed order): the skinning
-// backward left the first four in the group leaders' buffers, the colour gradient is per render
-// (+ with `stage_end`: the staged control-point sums of the batch's groups, see lbs_reduce_batched_kernel -- 4 M more
-// outputs behind the 14 N per-Gaussian ones)
+// Stage s1 only (the stage-s2 skinning backward adds its sums itself): dst[i] += sum_r src_r[i] for the five
+// per-Gaussian gradient arrays of a batch, in a fixed order -- s1_bwd_batched_kernel left the first four in the group
+// leaders' buffers, the colour gradient is per render.
 __global__ void __launch_bounds__(256) accumulate_batched_kernel(int N, int n_renders, RenderBatch b, float *g_xyz,
                                                                  float *g_rotation, float *g_scaling,
-                                                                 float *g_opacity, float *g_f_dc, int M,
-                                                                 float *g_c_xyz, float *g_c_lr,
-                                                                 const float *stage_end, size_t stage_stride,
-                                                                 int first_abs) {
+                                                                 float *g_opacity, float *g_f_dc) {
   // segments: [0,3N) xyz | [3N,7N) rotation | [7N,10N) scaling | [10N,11N) opacity | [11N,14N) f_dc
   const size_t n = (size_t)N;
-  const size_t total = 14 * n + (stage_end ? 4 * (size_t)M : 0);
+  const size_t total = 14 * n;
   unsigned leaders = 0;
   for (int q = 0; q < b.n_groups; ++q) leaders |= 1u << b.leader[q];
-  // (grid-stride over a capped grid: in the training step this runs on a private stream next to the TimeNet backward,
-  // whose one-per-CU workgroups of 16 waves must find room)
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    if (i >= 14 * n) {
-      const size_t j = i - 14 * n;
-      const int m = (int)(j >> 2), cc = (int)(j & 3);
-      // The staged sums are formed in a fixed order and ADDED ATOMICALLY: in the training step this fold runs on a
-      // private stream next to the TimeNet backward, whose embedding backward adds its input gradient to the same
-      // `_c_xyz.grad` words with atomics (timenet.hip) -- a plain read-modify-write here could lose those.
-      float *dst = cc < 3 ? g_c_xyz + 3 * m + cc : g_c_lr + m;
-      float s = 0.0f;
-      for (int q = 0; q < b.n_groups; ++q)
-        s += (stage_end - (size_t)(first_abs + (int)b.leader[q] + 1) * stage_stride)[j];
-      unsafeAtomicAdd(dst, s);
-      continue;
-    }
     float *dst;
     size_t k;
     int which;
@@ -350,9 +376,9 @@ inline void allow_big_lds() {
                               hipFuncAttributeMaxDynamicSharedMemorySize, lim);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(lbs_fwd_batched_kernel<false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lim);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(lbs_bwd_batched_kernel<true>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(lbs_bwd_groups_kernel<true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lim);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(lbs_bwd_batched_kernel<false>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(lbs_bwd_groups_kernel<false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lim);
     return true;
   }();
@@ -472,24 +498,23 @@ int lbs_forward_batched(const dimo_step_common &c, const RenderBatch &b, int n, 
   return check_launch();
 }
 
-// Per render: room for the partial control-point tables of one group (an upper bound for any grouping of n renders)
-// + the group leader's staging table of the shared control-point sums (phased backward, below).  The partial tables of
-// a launch over renders [first, first + n) start at first x `lbs_partials_slice`; the staging tables sit at the END of
-// the scratch buffer, slot r at end - (r + 1) x `lbs_stage_stride`.
-static size_t lbs_partials_slice(int N, int M) {
-  const size_t per = (size_t)((N > 0 ? N : 1) + DEF_BLOCK - 1) / DEF_BLOCK;
-  return align_up(per * (size_t)(M > 0 ? M : 1) * CP_STRIDE * sizeof(float));
-}
-static size_t lbs_stage_stride(int M) { return align_up((size_t)(M > 0 ? M : 1) * 4 * sizeof(float)); }
+// (Rounds 2-5 kept per-workgroup partial control-point tables and per-leader staging tables in `lbs_scratch`; the
+// group-loop kernel needs neither.  The size query stays for callers that still allocate it.)
 size_t lbs_backward_batched_scratch_bytes(int N, int M, int n) {
-  return (size_t)n * (lbs_partials_slice(N, M) + lbs_stage_stride(M));
+  (void)N, (void)M, (void)n;
+  return ALIGN;
 }
 
-// phase 0: the whole skinning backward of the batch on `stream` (skin, control-point reduction INTO the shared
-// gradients, per-Gaussian accumulation).  Phased form for batches that are skinned on different streams at once:
-// phase 1 = skin + reduction into the leaders' staging tables (touches nothing shared), phase 2 = the accumulation,
-// which also folds the staged control-point sums in, over ALL the step's renders on one stream.  `first_abs` = slot of
-// the batch's first render in the caller's slot numbering (places this launch's scratch).
+// Threads per workgroup of the group-loop kernel: 128 -- 782 workgroups at 100 k Gaussians, three per CU by their 45 KB
+// of LDS (M = 512), against 391 of 256 threads that leave 121 CUs one workgroup and 135 two.
+#ifndef DIMO_LBS_BLOCK
+#define DIMO_LBS_BLOCK 128
+#endif
+
+// The skinning backward of a launch's renders on `stream`, accumulating into the shared gradient views (atomically:
+// launches of different motions may run on different streams at once).  `phase` keeps the executor's call structure:
+// 0 and 1 run it, 2 -- the fold that followed phase 1 through round 5 -- has nothing left to do.  Stage s1 (no control
+// points) keeps its two kernels.
 int lbs_backward_batched(const dimo_step_common &c, const RenderBatch &b, int n, hipStream_t stream, int first_abs,
                          int phase) {
   if (c.N <= 0 || n <= 0) return DIMO_OK;
@@ -500,49 +525,28 @@ int lbs_backward_batched(const dimo_step_common &c, const RenderBatch &b, int n,
     hipLaunchKernelGGL(s1_bwd_batched_kernel, dim3((c.N + 255) / 256, b.n_groups), dim3(256), 0, stream, c.N,
                        c.rotation, c.opacity, c.log_r, c.g_log_r, b);
     const size_t total = 14 * (size_t)c.N;
-    hipLaunchKernelGGL(accumulate_batched_kernel, dim3(acc_grid(total)), dim3(256), 0, stream, c.N, n,
-                       b, c.g_xyz, c.g_rotation, c.g_scaling, c.g_opacity, c.g_f_dc, 0, (float *)nullptr,
-                       (float *)nullptr, (const float *)nullptr, (size_t)0, 0);
+    hipLaunchKernelGGL(accumulate_batched_kernel, dim3(acc_grid(total)), dim3(256), 0, stream, c.N, n, b, c.g_xyz,
+                       c.g_rotation, c.g_scaling, c.g_opacity, c.g_f_dc);
     return check_launch();
   }
   if (first_abs < 0 || phase < 0 || phase > 2) return DIMO_E_ARG;
-  if (c.lbs_scratch_bytes < lbs_backward_batched_scratch_bytes(c.N, c.M, first_abs + n)) return DIMO_E_WORKSPACE;
-  const size_t stage_stride = lbs_stage_stride(c.M) / sizeof(float);
-  float *const stage_end = phase ? reinterpret_cast<float *>(static_cast<char *>(c.lbs_scratch) + c.lbs_scratch_bytes)
-                                 : nullptr;
-  if (phase == 2) {
-    const size_t total = 14 * (size_t)c.N + 4 * (size_t)c.M;
-    ScopedTimer tm(T_DEFORM_BWD, stream);
-    hipLaunchKernelGGL(accumulate_batched_kernel, dim3(acc_grid(total)), dim3(256), 0, stream, c.N, n, b,
-                       c.g_xyz, c.g_rotation, c.g_scaling, c.g_opacity, c.g_f_dc, c.M, c.g_c_xyz, c.g_c_log_radius,
-                       (const float *)stage_end, stage_stride, first_abs);
-    return check_launch();
-  }
+  if (phase == 2) return DIMO_OK;
+  if (!c.g_xyz || !c.g_rotation || !c.g_scaling || !c.g_opacity || !c.g_f_dc || !c.g_c_xyz || !c.g_c_log_radius)
+    return DIMO_E_ARG;
   GaussIO g{c.xyz, c.rotation, c.scaling, c.opacity, c.nn_dist, c.nn_idx};
   const size_t lds = 2 * (size_t)c.M * CP_STRIDE * sizeof(float);
   allow_big_lds();
-  // 768 = three workgroups (45 KB of LDS, 144 VGPRs) on each of the 256 CUs.  The kernel is a latency chain per wave
-  // (1 700 VALU instructions and 32 LDS-atomic instructions per 64 Gaussians) with N / 64 waves per group in all, so
-  // it wants every CU slot: with 128 workgroups per group (round 1) a launch of two groups ran one wave per SIMD.
-  const int bwd_total = 768;
-  const int grid = batched_grid(c.N, b.n_groups, bwd_total);
-  float *partials = reinterpret_cast<float *>(static_cast<char *>(c.lbs_scratch) +
-                                              (phase ? (size_t)first_abs * lbs_partials_slice(c.N, c.M) : 0));
+  const int block = DIMO_LBS_BLOCK;
+  const int grid = (c.N + block - 1) / block;
   ScopedTimer tm(T_DEFORM_BWD, stream);
   if (c.local_frame)
-    hipLaunchKernelGGL(lbs_bwd_batched_kernel<true>, dim3(grid, b.n_groups), dim3(DEF_BLOCK), lds, stream, c.N, c.M, g, c.c_xyz,
-                       c.c_log_radius, b, partials);
+    hipLaunchKernelGGL(lbs_bwd_groups_kernel<true>, dim3(grid), dim3(block), lds, stream, c.N, c.M, g, c.c_xyz,
+                       c.c_log_radius, b, c.g_xyz, c.g_rotation, c.g_scaling, c.g_opacity, c.g_f_dc, c.g_c_xyz,
+                       c.g_c_log_radius);
   else
-    hipLaunchKernelGGL(lbs_bwd_batched_kernel<false>, dim3(grid, b.n_groups), dim3(DEF_BLOCK), lds, stream, c.N, c.M, g,
-                       c.c_xyz, c.c_log_radius, b, partials);
-  hipLaunchKernelGGL(lbs_reduce_batched_kernel, dim3((c.M * CP_STRIDE + 15) / 16),
-                     dim3(256, 1, b.n_groups < RED_GROUPS ? b.n_groups : RED_GROUPS), 0, stream, c.M, grid, b.n_groups,
-                     partials, c.g_c_xyz, c.g_c_log_radius, b, stage_end, stage_stride, first_abs);
-  if (phase == 1) return check_launch();
-  const size_t total = 14 * (size_t)c.N;
-  hipLaunchKernelGGL(accumulate_batched_kernel, dim3(acc_grid(total)), dim3(256), 0, stream, c.N, n, b,
-                     c.g_xyz, c.g_rotation, c.g_scaling, c.g_opacity, c.g_f_dc, 0, (float *)nullptr, (float *)nullptr,
-                     (const float *)nullptr, (size_t)0, 0);
+    hipLaunchKernelGGL(lbs_bwd_groups_kernel<false>, dim3(grid), dim3(block), lds, stream, c.N, c.M, g, c.c_xyz,
+                       c.c_log_radius, b, c.g_xyz, c.g_rotation, c.g_scaling, c.g_opacity, c.g_f_dc, c.g_c_xyz,
+                       c.g_c_log_radius);
   return check_launch();
 }
 
@@ -553,7 +557,8 @@ using namespace dimo;
 extern "C" int dimo_deform_max_ctrl_points(void) { return (160 * 1024 / 2) / (CP_STRIDE * (int)sizeof(float)); }
 
 extern "C" size_t dimo_deform_backward_scratch_bytes(int N, int M) {  // one table per DEF_BLOCK Gaussians at most
-  return lbs_backward_batched_scratch_bytes(N, M, 1);
+  const size_t per = (size_t)((N > 0 ? N : 1) + DEF_BLOCK - 1) / DEF_BLOCK;
+  return align_up(per * (size_t)(M > 0 ? M : 1) * CP_STRIDE * sizeof(float));
 }
 
 extern "C" int dimo_deform_forward(int N, int M, int local_frame, const float *xyz, const float *rotation,

@@ -315,8 +315,13 @@ def run_ranged_step(st, sequence, deferred):
         if sequence == "joint":  # ONE blend backward over all the step's renders, then skinning backward + fold
             assert E.dimo_executor_backward_launch_joint(ex, c, 0, st.n, d, None) == 0
             assert E.dimo_executor_backward_accumulate(ex, c, 0, st.n, d, None) == 0
-        elif sequence == "in_order_skinned":  # ONE fold over the step's renders
+        elif sequence == "in_order_skinned":
+            # the caller's stream joins the ranges' streams (round 6: the skinning backward adds its sums to the shared
+            # gradients itself, the call has no kernel of its own any more) ...
             assert E.dimo_executor_backward_accumulate(ex, c, 0, st.n, d, None) == 0
+            # ... and what the optimizer is to the executor follows: a reader of the gradient bucket on that stream
+            st.bucket_seen = np.full_like(st.acc["xyz"], np.nan)
+            E.simt_enqueue_copy(st.bucket_seen.ctypes.data, st.acc["xyz"].ctypes.data, st.acc["xyz"].nbytes, None)
         elif sequence == "in_order_skinned_side":
             # ... on private stream 0 (followed there by the optimizer's early launch, next to the TimeNet backward on
             # the caller's stream, which needs the ranges' TimeNet-row gradients: join_ranges)
@@ -339,6 +344,8 @@ def run_ranged_step(st, sequence, deferred):
         st.check_accumulated()
         if sequence == "in_order_skinned_side":
             assert np.array_equal(st.rows_seen, st.acc["d_xyz"]), "the caller's stream read the TimeNet rows' gradients early"
+        if sequence == "in_order_skinned":
+            assert np.array_equal(st.bucket_seen, st.acc["xyz"]), "the caller's stream read the gradient bucket early"
     finally:
         E.simt_synchronize()
         E.dimo_executor_destroy(ex)
