@@ -273,8 +273,13 @@ __device__ __forceinline__ void layout_buckets(const BinArgs &a, void *geom, voi
   uint32_t tot[OWN], nsg[OWN], want[OWN], wsum = 0;
 #pragma unroll
   for (int u = 0; u < OWN; ++u) {
-    // (the totals were summed by atomics of workgroups all over the chip: read at device scope)
-    const u64 w = tid * OWN + u < nbuckets ? __hip_atomic_load(&bk_tot[tid * OWN + u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+    // The totals were summed by returning atomics of workgroups all over the chip, every one of them complete before
+    // its workgroup drew the ticket that made this one the last.  They are read with an atomic read-modify-write
+    // themselves (+ 0): performed where the adds were performed -- at the memory side, behind them in the word's own
+    // modification order -- instead of a load that has to be ASSUMED to bypass this XCD's L2 (round-5 advice; a
+    // device-scope release / acquire pair on the ticket would be the textbook form and writes the L2 back on this
+    // chip: 92 us per launch measured).  Two returning atomics per thread of ONE workgroup per render.
+    const u64 w = tid * OWN + u < nbuckets ? atomicAdd(&bk_tot[tid * OWN + u], (u64)0) : 0ull;
     tot[u] = (uint32_t)w, nsg[u] = (uint32_t)(w >> 32);
     const uint32_t J = tot[u] > (uint32_t)BIN_CAP ? (tot[u] + SLICE_TARGET - 1) / SLICE_TARGET : 0u;
     want[u] = J <= 255u ? J : 0u;  // (more: the byte passes)

@@ -86,13 +86,48 @@ __global__ void __launch_bounds__(DEF_BLOCK) lbs_fwd_batched_kernel(int N, int M
   lbs_fwd_body<LOCAL_FRAME>(N, M, g, CtrlTable{c_xyz, c_lr, r.d_xyz, r.d_rot}, r.pts, r.rot, r.scales, r.opac);
 }
 
-template <bool LOCAL_FRAME, bool ACC, class EXTRA>
+// Where a workgroup's control-point sums (LDS table [M][CP_STRIDE]) go: its own partial table in global memory, summed
+// by lbs_reduce_kernel in a fixed order (the single-render C ABI, deterministic) ...
+struct PartialTable {
+  float *partials;  // [gridDim.x][M][CP_STRIDE]
+  __device__ __forceinline__ void store(int M, const float *s_acc) const {
+    float *dst = partials + (size_t)blockIdx.x * M * CP_STRIDE;
+    for (int j = threadIdx.x; j < M * CP_STRIDE; j += blockDim.x) dst[j] = s_acc[j];
+  }
+};
+// ... or straight to their destinations as fp32 atomics on the rows the workgroup TOUCHED (the step executor, round 6:
+// a workgroup of Morton-neighbours names 10-30 of the 512 control points; rounds 2-5 wrote the whole 22 KB table per
+// workgroup -- 69 MB per step -- and summed 384 tables per group in a second kernel on every motion's critical path).
+// Columns 0..2 -> d c_xyz, 3 -> d c_log_radius (shared by all groups and streams: atomics, like the TimeNet backward's
+// adds to the same words), 4..6 / 7..10 -> the gradients of the group's TimeNet rows.
+struct AtomicRows {
+  float *g_c_xyz, *g_c_lr, *g_d_xyz, *g_d_rot;
+  __device__ __forceinline__ void store(int M, const float *s_acc) const {
+    for (int m = threadIdx.x; m < M; m += blockDim.x) {
+      const float *ac = s_acc + m * CP_STRIDE;
+      float v[CP_STRIDE];
+#pragma unroll
+      for (int c = 0; c < CP_STRIDE; ++c) v[c] = ac[c];
+      bool any = false;
+#pragma unroll
+      for (int c = 3; c < CP_STRIDE; ++c) any |= v[c] != 0.f;  // (columns 0..2 derive from 4..6)
+      if (!any) continue;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) unsafeAtomicAdd(g_c_xyz + 3 * m + c, v[c]);
+      unsafeAtomicAdd(g_c_lr + m, v[3]);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) unsafeAtomicAdd(g_d_xyz + 3 * m + c, v[4 + c]);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) unsafeAtomicAdd(g_d_rot + 4 * m + c, v[7 + c]);
+    }
+  }
+};
+
+template <bool LOCAL_FRAME, bool ACC, class EXTRA, class SINK>
 __device__ __forceinline__ void lbs_bwd_body(int N, int M, GaussIO g, CtrlTable t, const float *g_xyz,
                                              const float *g_rot, const float *g_scales, const float *g_opacity,
                                              float *d_xyz_out, float *d_rot_out, float *d_scaling_out,
-                                             float *d_opacity_out,
-                                             float *__restrict__ partials /* [gridDim.x][M][CP_STRIDE] */,
-                                             const EXTRA extra) {
+                                             float *d_opacity_out, const SINK sink, const EXTRA extra) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float *s_cp = smem;                    // control-point table
   float *s_acc = smem + M * CP_STRIDE;   // control-point gradient accumulators
@@ -149,8 +184,7 @@ __device__ __forceinline__ void lbs_bwd_body(int N, int M, GaussIO g, CtrlTable 
     lbs_ctrl_position_grad(M, s_cp, s_acc);
     __syncthreads();
   }
-  float *dst = partials + (size_t)blockIdx.x * M * CP_STRIDE;
-  for (int j = threadIdx.x; j < M * CP_STRIDE; j += blockDim.x) dst[j] = s_acc[j];
+  sink.store(M, s_acc);
 }
 
 template <bool LOCAL_FRAME, bool ACC>
@@ -160,125 +194,32 @@ __global__ void __launch_bounds__(DEF_BLOCK) lbs_bwd_kernel(
     float *__restrict__ d_rot_out, float *__restrict__ d_scaling_out, float *__restrict__ d_opacity_out,
     float *__restrict__ partials) {
   lbs_bwd_body<LOCAL_FRAME, ACC>(N, M, g, t, g_xyz, g_rot, g_scales, g_opacity, d_xyz_out, d_rot_out, d_scaling_out,
-                                 d_opacity_out, partials, NoExtra{});
+                                 d_opacity_out, PartialTable{partials}, NoExtra{});
 }
-// The step executor's skinning backward (round 6): ONE kernel per launch of up to MAX_BATCH renders, no partial tables,
-// no reduction kernel, no fold.  A thread owns one Gaussian and walks the launch's deformation GROUPS (the renders that
-// share their TimeNet rows) one after the other: the group's control-point table goes to LDS, the thread sums the
-// rasterizer gradients of the group's renders (the backward is linear in them), runs the skinning backward of its
-// Gaussian, and keeps the per-Gaussian results -- d xyz, d rotation, d scaling, d opacity and the colour gradient -- in
-// registers across the groups; the control-point sums of a group (LDS table, scatter by matching lanes: wave_ops.hpp)
-// leave the workgroup as global fp32 atomics on the rows it TOUCHED -- a workgroup of Morton-neighbours names 10-30 of
-// the 512 control points; rounds 2-5 wrote the whole 22 KB table per workgroup and group (69 MB per step) and summed the
-// tables in a second kernel.  At the end a thread adds its 14 sums to the flat gradient bucket with one atomic each.
-// Run-to-run: a launch's contribution to a word is one add of a value formed in a fixed order, so a step of TWO launches
-// (the benchmark's two motions, each on its own stream) leaves the per-Gaussian head of the bucket bit-identical
-// whatever their order ((0 + a) + b == (0 + b) + a); the control-point words were and are order-dependent in the last
-// bits (LDS float atomics inside a workgroup, now also across workgroups).
-// Reference: renderer/latent_gs_renderer.py:1191-1219 (the autograd of the LBS block), main_train_dimo.py:415.
+// The step executor's skinning backward.  blockIdx.y = deformation group; per-Gaussian gradients are written IN PLACE
+// over the LEADER's rasterizer gradients (g_means3D -> d xyz, g_rot -> d rotation, g_scales -> d scaling, g_opac ->
+// d opacity: same shapes) and accumulate_batched_kernel folds the leaders into the shared gradient views in a fixed
+// order (the per-Gaussian head of the bucket stays bit-reproducible); the control-point sums leave the workgroup as
+// atomics on the rows it touched (AtomicRows): no partial tables, no reduction kernel on the motion's critical path.
+// (Round 6 also built the other end of that idea -- ONE thread per Gaussian walking the launch's groups one after the
+// other, all 14 per-Gaussian sums kept in registers and added to the bucket with one atomic each: no fold either.  Parity
+// green, and SLOWER: 106 us per launch of four groups against 38 + 15 + 24, the step -4 % -- the kernel is a latency
+// chain per wave, and groups walked in sequence by a third of the waves take the sum of their latencies:
+// profiles/r06_skinning_backward.txt.)
 template <bool LOCAL_FRAME>
-__global__ void __launch_bounds__(DEF_BLOCK) lbs_bwd_groups_kernel(int N, int M, GaussIO g, const float *c_xyz,
-                                                                   const float *c_lr, RenderBatch b, float *g_xyz,
-                                                                   float *g_rotation, float *g_scaling,
-                                                                   float *g_opacity, float *g_f_dc, float *g_c_xyz,
-                                                                   float *g_c_lr) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float *s_cp = smem;                   // the group's control-point table
-  float *s_acc = smem + M * CP_STRIDE;  // ... and its gradient accumulators
-  const int lane = threadIdx.x & 63;
-  const int i0 = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-  // whole waves stay in the loop (the control-point scatter combines lanes); lanes past N compute on the last
-  // Gaussian and contribute / store nothing
-  const bool valid = i0 < N;
-  const int i = valid ? i0 : N - 1;
-  const float x0 = g.xyz[3 * i], x1 = g.xyz[3 * i + 1], x2 = g.xyz[3 * i + 2];
-  const float4 q0 = *reinterpret_cast<const float4 *>(g.rot + 4 * (size_t)i);
-  const float4 dd = *reinterpret_cast<const float4 *>(g.nn_dist + 4 * (size_t)i);
-  const float op_raw = g.opacity[i];
-  const float sc_raw[3] = {g.scaling[3 * i], g.scaling[3 * i + 1], g.scaling[3 * i + 2]};
-  int idx0[DEF_K];
-#pragma unroll
-  for (int k = 0; k < DEF_K; ++k) idx0[k] = (int)g.nn_idx[4 * (size_t)i + k];
-  float a_rot[4] = {0.f, 0.f, 0.f, 0.f}, a_xyz[3] = {0.f, 0.f, 0.f}, a_sc[3] = {0.f, 0.f, 0.f}, a_op = 0.f;
-  float a_f[3] = {0.f, 0.f, 0.f};
-  for (int q = 0; q < b.n_groups; ++q) {
-    const int lead = b.leader[q];
-    const unsigned mem = b.members[q];
-    const dimo_render_desc &r = b.r[lead];
-    __syncthreads();  // (the previous group's flush has read both tables)
-    load_ctrl_to_lds(CtrlTable{c_xyz, c_lr, r.d_xyz, r.d_rot}, M, s_cp);
-    for (int j = threadIdx.x; j < M * CP_STRIDE; j += blockDim.x) s_acc[j] = 0.f;
-    // the rasterizer gradients of the group's renders, summed: every load of a member is requested before its first add
-    float4 go = make_float4(0.f, 0.f, 0.f, 0.f);
-    float gp[3] = {0.f, 0.f, 0.f}, gsc[3] = {0.f, 0.f, 0.f}, gopac = 0.f;
-#pragma unroll
-    for (int j = 0; j < MAX_BATCH; ++j)
-      if ((mem >> j) & 1u) {  // (wave-uniform)
-        const dimo_render_desc &rj = b.r[j];
-        const float4 t = *reinterpret_cast<const float4 *>(rj.g_rot + 4 * (size_t)i);
-        const float p0 = rj.g_means3D[3 * i], p1 = rj.g_means3D[3 * i + 1], p2 = rj.g_means3D[3 * i + 2];
-        const float s0 = rj.g_scales[3 * i], s1 = rj.g_scales[3 * i + 1], s2 = rj.g_scales[3 * i + 2];
-        const float o = rj.g_opac[i];
-        const float f0 = rj.g_shs[3 * i], f1 = rj.g_shs[3 * i + 1], f2 = rj.g_shs[3 * i + 2];
-        go.x += t.x, go.y += t.y, go.z += t.z, go.w += t.w;
-        gp[0] += p0, gp[1] += p1, gp[2] += p2;
-        gsc[0] += s0, gsc[1] += s1, gsc[2] += s2;
-        gopac += o;
-        a_f[0] += f0, a_f[1] += f1, a_f[2] += f2;
-      }
-    __syncthreads();
-    int idx[DEF_K];  // (lbs_bwd_math re-orders its copy together with the distances)
-#pragma unroll
-    for (int k = 0; k < DEF_K; ++k) idx[k] = idx0[k];
-    float4 d_rot;
-    float dxs[3];
-    lbs_bwd_math<LOCAL_FRAME>(s_cp, s_acc, x0, x1, x2, q0, dd, idx, go, gp, valid, lane, d_rot, dxs);
-    a_rot[0] += d_rot.x, a_rot[1] += d_rot.y, a_rot[2] += d_rot.z, a_rot[3] += d_rot.w;
-    a_xyz[0] += dxs[0], a_xyz[1] += dxs[1], a_xyz[2] += dxs[2];
-    a_sc[0] += gsc[0], a_sc[1] += gsc[1], a_sc[2] += gsc[2];
-    a_op += gopac;
-    __syncthreads();
-    if (LOCAL_FRAME) {  // columns 0..2 from the summed columns 4..6 (deform_body.hpp)
-      lbs_ctrl_position_grad(M, s_cp, s_acc);
-      __syncthreads();
-    }
-    // the rows this workgroup touched: columns 0..2 -> d c_xyz, 3 -> d c_log_radius (shared by every group), 4..6 / 7..10
-    // -> the gradients of this group's TimeNet rows
-    for (int m = threadIdx.x; m < M; m += blockDim.x) {
-      const float *ac = s_acc + m * CP_STRIDE;
-      float v[CP_STRIDE];
-#pragma unroll
-      for (int c = 0; c < CP_STRIDE; ++c) v[c] = ac[c];
-      bool any = false;
-#pragma unroll
-      for (int c = 3; c < CP_STRIDE; ++c) any |= v[c] != 0.f;  // (columns 0..2 derive from 4..6)
-      if (!any) continue;
-#pragma unroll
-      for (int c = 0; c < 3; ++c) unsafeAtomicAdd(g_c_xyz + 3 * m + c, v[c]);
-      unsafeAtomicAdd(g_c_lr + m, v[3]);
-#pragma unroll
-      for (int c = 0; c < 3; ++c) unsafeAtomicAdd(r.g_d_xyz + 3 * m + c, v[4 + c]);
-#pragma unroll
-      for (int c = 0; c < 4; ++c) unsafeAtomicAdd(r.g_d_rot + 4 * m + c, v[7 + c]);
-    }
-  }
-  if (valid) {
-    const float o = 1.0f / (1.0f + __expf(-op_raw));
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      unsafeAtomicAdd(g_xyz + 3 * (size_t)i + c, a_xyz[c]);
-      unsafeAtomicAdd(g_scaling + 3 * (size_t)i + c, a_sc[c] * __expf(sc_raw[c]));
-      unsafeAtomicAdd(g_f_dc + 3 * (size_t)i + c, a_f[c]);
-    }
-#pragma unroll
-    for (int c = 0; c < 4; ++c) unsafeAtomicAdd(g_rotation + 4 * (size_t)i + c, a_rot[c]);
-    unsafeAtomicAdd(g_opacity + i, a_op * o * (1.0f - o));
-  }
+__global__ void __launch_bounds__(DEF_BLOCK) lbs_bwd_batched_kernel(int N, int M, GaussIO g, const float *c_xyz,
+                                                                    const float *c_lr, RenderBatch b, float *g_c_xyz,
+                                                                    float *g_c_lr) {
+  const int lead = b.leader[blockIdx.y];
+  const dimo_render_desc &r = b.r[lead];
+  lbs_bwd_body<LOCAL_FRAME, false>(N, M, g, CtrlTable{c_xyz, c_lr, r.d_xyz, r.d_rot}, r.g_means3D, r.g_rot,
+                                   r.g_scales, r.g_opac, r.g_means3D, r.g_rot, r.g_scales, r.g_opac,
+                                   AtomicRows{g_c_xyz, g_c_lr, r.g_d_xyz, r.g_d_rot},
+                                   GroupExtra{b, b.members[blockIdx.y] & ~(1u << lead)});
 }
 
-// Stage s1 only (the stage-s2 skinning backward adds its sums itself): dst[i] += sum_r src_r[i] for the five
-// per-Gaussian gradient arrays of a batch, in a fixed order -- s1_bwd_batched_kernel left the first four in the group
-// leaders' buffers, the colour gradient is per render.
+// dst[i] += sum_r src_r[i] for the five per-Gaussian gradient arrays of a batch (fixed order): the skinning backward
+// left the first four in the group leaders' buffers, the colour gradient is per render.
 __global__ void __launch_bounds__(256) accumulate_batched_kernel(int N, int n_renders, RenderBatch b, float *g_xyz,
                                                                  float *g_rotation, float *g_scaling,
                                                                  float *g_opacity, float *g_f_dc) {
@@ -376,9 +317,9 @@ inline void allow_big_lds() {
                               hipFuncAttributeMaxDynamicSharedMemorySize, lim);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(lbs_fwd_batched_kernel<false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lim);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(lbs_bwd_groups_kernel<true>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(lbs_bwd_batched_kernel<true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lim);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(lbs_bwd_groups_kernel<false>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(lbs_bwd_batched_kernel<false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lim);
     return true;
   }();
@@ -498,55 +439,54 @@ int lbs_forward_batched(const dimo_step_common &c, const RenderBatch &b, int n, 
   return check_launch();
 }
 
-// (Rounds 2-5 kept per-workgroup partial control-point tables and per-leader staging tables in `lbs_scratch`; the
-// group-loop kernel needs neither.  The size query stays for callers that still allocate it.)
+// (Rounds 2-5 kept per-workgroup partial control-point tables and per-leader staging tables in `lbs_scratch`; since
+// round 6 the control-point sums leave the kernel as atomics.  The size query stays for callers that still allocate it.)
 size_t lbs_backward_batched_scratch_bytes(int N, int M, int n) {
   (void)N, (void)M, (void)n;
   return ALIGN;
 }
 
-// Threads per workgroup of the group-loop kernel: 128 -- 782 workgroups at 100 k Gaussians, three per CU by their 45 KB
-// of LDS (M = 512), against 391 of 256 threads that leave 121 CUs one workgroup and 135 two.
-#ifndef DIMO_LBS_BLOCK
-#define DIMO_LBS_BLOCK 128
-#endif
-
-// The skinning backward of a launch's renders on `stream`, accumulating into the shared gradient views (atomically:
-// launches of different motions may run on different streams at once).  `phase` keeps the executor's call structure:
-// 0 and 1 run it, 2 -- the fold that followed phase 1 through round 5 -- has nothing left to do.  Stage s1 (no control
-// points) keeps its two kernels.
+// phase 0: the whole skinning backward of the batch on `stream` (skin + per-Gaussian fold).  Phased form for batches
+// that are skinned on different streams at once: phase 1 = skin (per-Gaussian gradients in place in the leaders' buffers;
+// what it adds to shared words -- the control-point sums -- it adds atomically), phase 2 = the fold over ALL the step's
+// renders on one stream.
 int lbs_backward_batched(const dimo_step_common &c, const RenderBatch &b, int n, hipStream_t stream, int first_abs,
                          int phase) {
   if (c.N <= 0 || n <= 0) return DIMO_OK;
+  const size_t total = 14 * (size_t)c.N;
   if (c.stage1) {
     if (phase == 2) return DIMO_OK;  // (stage s1 has no control points: phase 1 does everything)
     if (!c.log_r || !c.g_log_r) return DIMO_E_ARG;
     ScopedTimer tm(T_DEFORM_BWD, stream);
     hipLaunchKernelGGL(s1_bwd_batched_kernel, dim3((c.N + 255) / 256, b.n_groups), dim3(256), 0, stream, c.N,
                        c.rotation, c.opacity, c.log_r, c.g_log_r, b);
-    const size_t total = 14 * (size_t)c.N;
     hipLaunchKernelGGL(accumulate_batched_kernel, dim3(acc_grid(total)), dim3(256), 0, stream, c.N, n, b, c.g_xyz,
                        c.g_rotation, c.g_scaling, c.g_opacity, c.g_f_dc);
     return check_launch();
   }
   if (first_abs < 0 || phase < 0 || phase > 2) return DIMO_E_ARG;
-  if (phase == 2) return DIMO_OK;
   if (!c.g_xyz || !c.g_rotation || !c.g_scaling || !c.g_opacity || !c.g_f_dc || !c.g_c_xyz || !c.g_c_log_radius)
     return DIMO_E_ARG;
-  GaussIO g{c.xyz, c.rotation, c.scaling, c.opacity, c.nn_dist, c.nn_idx};
-  const size_t lds = 2 * (size_t)c.M * CP_STRIDE * sizeof(float);
-  allow_big_lds();
-  const int block = DIMO_LBS_BLOCK;
-  const int grid = (c.N + block - 1) / block;
   ScopedTimer tm(T_DEFORM_BWD, stream);
-  if (c.local_frame)
-    hipLaunchKernelGGL(lbs_bwd_groups_kernel<true>, dim3(grid), dim3(block), lds, stream, c.N, c.M, g, c.c_xyz,
-                       c.c_log_radius, b, c.g_xyz, c.g_rotation, c.g_scaling, c.g_opacity, c.g_f_dc, c.g_c_xyz,
-                       c.g_c_log_radius);
-  else
-    hipLaunchKernelGGL(lbs_bwd_groups_kernel<false>, dim3(grid), dim3(block), lds, stream, c.N, c.M, g, c.c_xyz,
-                       c.c_log_radius, b, c.g_xyz, c.g_rotation, c.g_scaling, c.g_opacity, c.g_f_dc, c.g_c_xyz,
-                       c.g_c_log_radius);
+  if (phase != 2) {
+    GaussIO g{c.xyz, c.rotation, c.scaling, c.opacity, c.nn_dist, c.nn_idx};
+    const size_t lds = 2 * (size_t)c.M * CP_STRIDE * sizeof(float);
+    allow_big_lds();
+    // 768 = three workgroups (45 KB of LDS, 144 VGPRs) on each of the 256 CUs.  The kernel is a latency chain per wave
+    // (1 700 VALU instructions and 32 LDS-atomic instructions per 64 Gaussians) with N / 64 waves per group in all, so
+    // it wants every CU slot: with 128 workgroups per group (round 1) a launch of two groups ran one wave per SIMD.
+    const int bwd_total = 768;
+    const int grid = batched_grid(c.N, b.n_groups, bwd_total);
+    if (c.local_frame)
+      hipLaunchKernelGGL(lbs_bwd_batched_kernel<true>, dim3(grid, b.n_groups), dim3(DEF_BLOCK), lds, stream, c.N, c.M,
+                         g, c.c_xyz, c.c_log_radius, b, c.g_c_xyz, c.g_c_log_radius);
+    else
+      hipLaunchKernelGGL(lbs_bwd_batched_kernel<false>, dim3(grid, b.n_groups), dim3(DEF_BLOCK), lds, stream, c.N, c.M,
+                         g, c.c_xyz, c.c_log_radius, b, c.g_c_xyz, c.g_c_log_radius);
+  }
+  if (phase != 1)
+    hipLaunchKernelGGL(accumulate_batched_kernel, dim3(acc_grid(total)), dim3(256), 0, stream, c.N, n, b, c.g_xyz,
+                       c.g_rotation, c.g_scaling, c.g_opacity, c.g_f_dc);
   return check_launch();
 }
 
