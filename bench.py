@@ -748,6 +748,52 @@ def main():
         if pol is not None:
             pol.check()
 
+    # ---- per-rank phases of a step and the replicas' agreement (every rank; gathered on rank 0).  Phase marks are events
+    # on the caller's stream: head = weight packing + TimeNet forward (+ the KNN beside it) up to the forks; chains = the
+    # motions' chains on their private streams up to the join (render, losses, rasterizer + skinning backward); tail =
+    # TimeNet backward, collectives, optimizer.  The checksum is the parameter bucket's bit pattern.
+    phases = None
+    try:
+        tr.marks = []
+        for _ in range(6):
+            tr.train_step()
+        barrier()
+        marks, tr.marks = tr.marks, None
+        steps_m, cur = [], None
+        for name, ev in marks:
+            if name == "start":
+                cur = {}
+                steps_m.append(cur)
+            if cur is not None:
+                cur[name] = ev
+        acc, cnt = {"head_ms": 0.0, "chains_ms": 0.0, "tail_ms": 0.0}, 0
+        for k_, m_ in enumerate(steps_m[1:], 1):  # (the first marked step also absorbs the switch-over)
+            if not all(x in m_ for x in ("start", "timenet_fwd", "raster_bwd+skinning_bwd", "allreduce+adam")):
+                continue
+            prev_end = steps_m[k_ - 1].get("allreduce+adam")
+            acc["head_ms"] += (prev_end.elapsed_time(m_["timenet_fwd"]) if prev_end is not None
+                               else m_["start"].elapsed_time(m_["timenet_fwd"]))
+            acc["chains_ms"] += m_["timenet_fwd"].elapsed_time(m_["raster_bwd+skinning_bwd"])
+            acc["tail_ms"] += m_["raster_bwd+skinning_bwd"].elapsed_time(m_["allreduce+adam"])
+            cnt += 1
+        phases = {k_: v_ / max(cnt, 1) for k_, v_ in acc.items()}
+        phases["renders_per_step_this_rank"] = renders / max(args.steps, 1)
+    except Exception as e:  # (diagnostics only)
+        tr.marks = None
+        phases = {"failed": repr(e)}
+    fp = tr.renderer.gaussians.flat_params.detach()
+    chk = fp.view(torch.int32).to(torch.int64)
+    chk = torch.stack([chk.sum(), (chk * torch.arange(1, chk.numel() + 1, device=device, dtype=torch.int64) % 1000003).sum()])
+    rank_phases, replicas_identical = [phases], True
+    if world > 1:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, phases)
+        rank_phases = gathered
+        cmax, cmin = chk.clone(), chk.clone()
+        dist.all_reduce(cmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(cmin, op=dist.ReduceOp.MIN)
+        replicas_identical = bool(torch.equal(cmax, cmin))
+
     # sustained rate: the fresh-state figure above is steps ~26-45 of a process; a long run drifts (random targets blow
     # a few Gaussians up, R grows) and crosses the schedule's stage-s2 opacity prune (step % 1000 == 0: the Gaussian
     # count changes, every workspace is rebuilt).  >= 1000 consecutive steps, every rank, collectives included.
@@ -863,6 +909,9 @@ def main():
             "setup_steps_before_warmup": PRESTEPS + SETTLE,
             "skipped_steps": {"timed_region": skipped_timed, "whole_run": skipped_total},
             "allreduce_exposed_ms_per_step": (sum(ar_ms) / len(ar_ms)) if ar_ms else (0.0 if world == 1 else None),
+            # every rank's step by phase (events on its caller's stream, 5 steps) and whether the replicas' parameter
+            # buckets agree bit for bit after everything above
+            "rank_phases_ms": rank_phases, "replicas_bit_identical": replicas_identical,
             "roofline": {"bound": "valu", "frac_is_of": "hbm peak (as the metric asks)",
                          "kernel": "blend_bwd_batched_kernel<true, true> (the joint launch over the step's renders)",
                          "achieved": achieved,

@@ -223,29 +223,52 @@ __global__ void __launch_bounds__(DEF_BLOCK) lbs_bwd_batched_kernel(int N, int M
 __global__ void __launch_bounds__(256) accumulate_batched_kernel(int N, int n_renders, RenderBatch b, float *g_xyz,
                                                                  float *g_rotation, float *g_scaling,
                                                                  float *g_opacity, float *g_f_dc) {
-  // segments: [0,3N) xyz | [3N,7N) rotation | [7N,10N) scaling | [10N,11N) opacity | [11N,14N) f_dc
+  // segments of the flat index space, in units of FOUR floats (every array starts on a 16-byte boundary: the gradient
+  // views by construction of the flat bucket, the slots' buffers by allocation): [0, 3N) xyz | rotation 4N | scaling 3N
+  // | opacity N | f_dc 3N, each rounded up to whole float4s -- 16-byte loads and stores (round 6: the scalar form read
+  // 38 MB in 23 us), the last float4 of a segment whose length is not a multiple of four element by element.
   const size_t n = (size_t)N;
-  const size_t total = 14 * n;
+  const size_t len[5] = {3 * n, 4 * n, 3 * n, n, 3 * n};
+  size_t q4[6];
+  q4[0] = 0;
+#pragma unroll
+  for (int k = 0; k < 5; ++k) q4[k + 1] = q4[k] + (len[k] + 3) / 4;
   unsigned leaders = 0;
   for (int q = 0; q < b.n_groups; ++q) leaders |= 1u << b.leader[q];
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    float *dst;
-    size_t k;
-    int which;
-    if (i < 3 * n) dst = g_xyz, k = i, which = 0;
-    else if (i < 7 * n) dst = g_rotation, k = i - 3 * n, which = 1;
-    else if (i < 10 * n) dst = g_scaling, k = i - 7 * n, which = 2;
-    else if (i < 11 * n) dst = g_opacity, k = i - 10 * n, which = 3;
-    else dst = g_f_dc, k = i - 11 * n, which = 4;
-    float s = dst[k];
-    for (int r = 0; r < n_renders; ++r) {
-      if (which != 4 && !((leaders >> r) & 1u)) continue;
-      const dimo_render_desc &d = b.r[r];
-      const float *src = which == 0 ? d.g_means3D : which == 1 ? d.g_rot : which == 2 ? d.g_scales
-                         : which == 3 ? d.g_opac : d.g_shs;
-      s += src[k];
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < q4[5]; i += (size_t)gridDim.x * 256) {
+    const int which = i < q4[1] ? 0 : i < q4[2] ? 1 : i < q4[3] ? 2 : i < q4[4] ? 3 : 4;
+    const size_t k = 4 * (i - q4[which]);
+    float *dst = which == 0 ? g_xyz : which == 1 ? g_rotation : which == 2 ? g_scaling : which == 3 ? g_opacity : g_f_dc;
+    if (k + 4 <= len[which]) {
+      float4 s = *reinterpret_cast<const float4 *>(dst + k);
+      float4 v[MAX_BATCH];
+#pragma unroll
+      for (int r = 0; r < MAX_BATCH; ++r) {  // (every load of the sum requested before the first add)
+        const bool on = r < n_renders && (which == 4 || ((leaders >> r) & 1u));
+        const dimo_render_desc &d = b.r[r];
+        const float *src = which == 0 ? d.g_means3D : which == 1 ? d.g_rot : which == 2 ? d.g_scales
+                           : which == 3 ? d.g_opac : d.g_shs;
+        v[r] = on ? *reinterpret_cast<const float4 *>(src + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int r = 0; r < MAX_BATCH; ++r) {
+        const bool on = r < n_renders && (which == 4 || ((leaders >> r) & 1u));
+        if (on) s.x += v[r].x, s.y += v[r].y, s.z += v[r].z, s.w += v[r].w;  // (fixed order: render 0, 1, ...)
+      }
+      *reinterpret_cast<float4 *>(dst + k) = s;
+    } else {
+      for (size_t e = k; e < len[which]; ++e) {
+        float s = dst[e];
+        for (int r = 0; r < n_renders; ++r) {
+          if (which != 4 && !((leaders >> r) & 1u)) continue;
+          const dimo_render_desc &d = b.r[r];
+          const float *src = which == 0 ? d.g_means3D : which == 1 ? d.g_rot : which == 2 ? d.g_scales
+                             : which == 3 ? d.g_opac : d.g_shs;
+          s += src[e];
+        }
+        dst[e] = s;
+      }
     }
-    dst[k] = s;
   }
 }
 
@@ -453,7 +476,7 @@ size_t lbs_backward_batched_scratch_bytes(int N, int M, int n) {
 int lbs_backward_batched(const dimo_step_common &c, const RenderBatch &b, int n, hipStream_t stream, int first_abs,
                          int phase) {
   if (c.N <= 0 || n <= 0) return DIMO_OK;
-  const size_t total = 14 * (size_t)c.N;
+  const size_t total = (14 * (size_t)c.N + 3) / 4 + 5;  // float4s of the fold's five segments
   if (c.stage1) {
     if (phase == 2) return DIMO_OK;  // (stage s1 has no control points: phase 1 does everything)
     if (!c.log_r || !c.g_log_r) return DIMO_E_ARG;

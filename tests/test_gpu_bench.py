@@ -11,9 +11,9 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(cmd):
+def _run(cmd, timeout=900):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith('{"metric"')]
     assert len(lines) == 1, p.stdout[-2000:]
@@ -40,6 +40,28 @@ def test_bench_two_ranks_on_one_device(strong):
     assert r["allreduce_exposed_ms_per_step"] is not None and r["allreduce_exposed_ms_per_step"] >= 0.0
     assert r["value"] > 0 and abs(r["value"] - 16 * 1e3 / r["ms_per_step"]) < 1e-6 * r["value"]
     assert r["roofline"]["bound"] in ("hbm", "mfma", "valu") and r["roofline"]["achieved"] > 0
+    assert r["replicas_bit_identical"] is True and len(r["rank_phases_ms"]) == 2
+
+
+@pytest.mark.timeout(1800)
+def test_bench_eight_ranks_strong_scaling_shape_on_one_device():
+    """The driver's 8-GPU command shape (`--gpus 8`, one process per rank) with the reference's own batch (b = 2: a
+    FIXED step of 4 x 2 x 2 = 16 renders, main_train_dimo.py:266-293, two per rank) -- eight ranks over gloo sharing the
+    one device this box has.  What it can show without an 8-GPU node: the ranks shard, reduce and update as one
+    (replicas bit-identical after every step of the run: the parameter buckets' checksums agree), no step is skipped,
+    and every rank reports its step by phase.  (Nothing about speed: eight processes time-share one GPU here.)"""
+    port = 25600 + (os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "8", "--backend", "gloo", "--no-dropin",
+           "--sustained-steps", "20", "--global-batch", "2"] + SMALL
+    r = _run(cmd, timeout=1600)
+    assert r["n_gpus"] == 8 and r["ranks_seen"] == 8 and r["scaling"] == "strong"
+    assert r["config"]["renders_per_step"] == 16
+    assert r["replicas_bit_identical"] is True
+    assert r["skipped_steps"] == {"timed_region": 0, "whole_run": 0}
+    ph = r["rank_phases_ms"]
+    assert len(ph) == 8 and all(p["renders_per_step_this_rank"] == 2 for p in ph)
+    assert all(p["head_ms"] > 0 and p["chains_ms"] > 0 and p["tail_ms"] > 0 for p in ph)
 
 
 @pytest.mark.timeout(1200)
