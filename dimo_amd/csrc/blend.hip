@@ -473,27 +473,13 @@ __device__ __forceinline__ void blend_bwd_item(int H, int W, int tiles_x, uint32
     M = s_mask[tt_], G = s_geo[tt_], C = s_col[tt_], A = s_aux[tt_]; \
     if (NORMAL) NZ = s_nz[tt_];                                \
   }
-#define DIMO_BWD_RECORD(M, G, C, A, NZ, TT)                                                                        \
-  {                                                                                                                \
-    const uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane((int)M);                                           \
-    const uint32_t pos = blo + (m >> 8), qm = m & 0xfu;                                                            \
-    const float dx0 = G.x - bxf, dy0 = G.y - byf;                                                                  \
-    float v[16];                                                                                                   \
-    _Pragma("unroll") for (int k = 0; k < 16; ++k) {                                                               \
-      v[k] = 0.0f;                                                                                                 \
-      if (k < (NORMAL ? 13 : 10)) asm volatile("" : "+v"(v[k])); /* every quadrant accumulates the same way */      \
-    }                                                                                                              \
-    bool any = false;                                                                                              \
-    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                                \
-      if (!((qm >> q) & 1u) || pos >= deepest[q]) continue; /* wave-uniform */                                      \
-      any = true;                                                                                                  \
-      ++n_quad;                                                                                                    \
-      const float dx = dx0 - (float)((q & 1) * 8), dy = dy0 - (float)((q >> 1) * 8);                               \
+#define DIMO_BWD_VISIT(q, G, C, A, NZ)                                                                              \
+    {                                                                                                              \
+      const float dx = dx0 - (float)(((q) & 1) * 8), dy = dy0 - (float)(((q) >> 1) * 8);                           \
       const float power = fmaf(C.x * dy, dy, fmaf(G.w, dy, G.z * dx) * dx); /* log2(e) x the exponent */          \
       const float Gs = __builtin_amdgcn_exp2f(power);                                                              \
       const float alpha = fminf(ALPHA_MAX, C.y * Gs);                                                              \
-      const bool active = pos < last[q] && power <= 0.0f && alpha >= ALPHA_MIN;                                    \
-      const float ae = active ? alpha : 0.0f;                                                                      \
+      DIMO_BWD_PREDICATE(q)                                                                                        \
       if (trace && __ballot(active) != 0ull) ++n_useful; /* (trace builds only) */                                 \
       const float w = ae * T[q];                                                                                   \
       float D = dp[q][7] + C.z * dp[q][0] + C.w * dp[q][1] + A.x * dp[q][2] + A.y * dp[q][3];                      \
@@ -509,7 +495,19 @@ __device__ __forceinline__ void blend_bwd_item(int H, int W, int tiles_x, uint32
       v[3] += gx * dx, v[4] += gx * dy, v[5] += gy * dy;                                                           \
       v[6] += w * dp[q][0], v[7] += w * dp[q][1], v[8] += w * dp[q][2], v[9] += w * dp[q][3];                      \
       if (NORMAL) v[10] += w * dp[q][4], v[11] += w * dp[q][5], v[12] += w * dp[q][6];                             \
+    }
+#define DIMO_BWD_RECORD(M, G, C, A, NZ, TT)                                                                        \
+  {                                                                                                                \
+    const uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane((int)M);                                           \
+    const uint32_t pos = blo + (m >> 8), qm = m & 0xfu;                                                            \
+    const float dx0 = G.x - bxf, dy0 = G.y - byf;                                                                  \
+    float v[16];                                                                                                   \
+    _Pragma("unroll") for (int k = 0; k < 16; ++k) {                                                               \
+      v[k] = 0.0f;                                                                                                 \
+      if (k < (NORMAL ? 13 : 10)) asm volatile("" : "+v"(v[k])); /* every quadrant accumulates the same way */      \
     }                                                                                                              \
+    bool any = false;                                                                                              \
+    DIMO_BWD_QUADRANTS(G, C, A, NZ)                                                                                \
     if (any) {                                                                                                     \
       ++n_rec;                                                                                                     \
       const float tot = wave_reduce16<13>(v); /* lane l: the wave total of value reduce16_slot(l); 13 in use */      \
@@ -518,6 +516,40 @@ __device__ __forceinline__ void blend_bwd_item(int H, int W, int tiles_x, uint32
       break; /* the list is ascending: nothing further reaches this tile */                                         \
     }                                                                                                              \
   }
+    /* Which quadrants a record is evaluated on: the ones its mask names and some pixel still looks at (wave-uniform
+       branches) -- or, PAIRS, both quadrants of a tile half in ONE straight-line block when either qualifies: an
+       unneeded quadrant evaluates to nothing (no lane passes the tests) and two independent chains interleave. */
+#define DIMO_BWD_NEED(q) (((qm >> (q)) & 1u) && pos < deepest[(q)])
+#ifdef DIMO_BWD_PAIRS
+#define DIMO_BWD_QUADRANTS(G, C, A, NZ)                                      \
+    _Pragma("unroll") for (int h = 0; h < 4; h += 2) {                      \
+      if (!(DIMO_BWD_NEED(h) || DIMO_BWD_NEED(h + 1))) continue;             \
+      any = true;                                                           \
+      n_quad += 2;                                                          \
+      DIMO_BWD_VISIT(h, G, C, A, NZ)                                         \
+      DIMO_BWD_VISIT(h + 1, G, C, A, NZ)                                     \
+    }
+#else
+#define DIMO_BWD_QUADRANTS(G, C, A, NZ)                                      \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                         \
+      if (!DIMO_BWD_NEED(q)) continue;                                       \
+      any = true;                                                           \
+      ++n_quad;                                                             \
+      DIMO_BWD_VISIT(q, G, C, A, NZ)                                         \
+    }
+#endif
+#ifdef DIMO_BWD_SELECT_CHAIN
+    /* the three rejection tests as a chain of selects on alpha (VALU only) instead of three compares joined on the scalar unit */ 
+#define DIMO_BWD_PREDICATE(q)                                      \
+      const float al1 = power <= 0.0f ? alpha : 0.0f;              \
+      const float al2 = pos < last[q] ? al1 : 0.0f;                \
+      const bool active = al2 >= ALPHA_MIN;                        \
+      const float ae = active ? al2 : 0.0f;
+#else
+#define DIMO_BWD_PREDICATE(q)                                                          \
+      const bool active = pos < last[q] && power <= 0.0f && alpha >= ALPHA_MIN;       \
+      const float ae = active ? alpha : 0.0f;
+#endif
     uint32_t m0 = 0, m1 = 0;
     float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), c0 = g0, a0 = g0, g1 = g0, c1 = g0, a1 = g0;
     float nz0 = 0.0f, nz1 = 0.0f;
@@ -531,6 +563,10 @@ __device__ __forceinline__ void blend_bwd_item(int H, int W, int tiles_x, uint32
     }
 #undef DIMO_BWD_LOAD
 #undef DIMO_BWD_RECORD
+#undef DIMO_BWD_PREDICATE
+#undef DIMO_BWD_QUADRANTS
+#undef DIMO_BWD_NEED
+#undef DIMO_BWD_VISIT
     __syncthreads();
     if (my_hit) {
       const float4 *src = reinterpret_cast<const float4 *>(&s_acc[my_rank][0]);
