@@ -285,7 +285,7 @@ __device__ __forceinline__ void blend_fwd_body(
     // slower at two buckets per item); where every pixel walks its whole list (the reference's initial state, every
     // opacity 0.05: ~15.5 buckets per tile, 16 000 items per render) the items are plenty, and what an item of four
     // buckets saves -- three of four checkpoint stores here, three of four checkpoint + pixel-state loads there -- shows:
-    // forward 659 -> 629 us, backward 1396 -> 1302 us per 8 renders (profiles/r06_blend_chains.txt).  The render's last
+    // forward 659 -> 629 us, backward 1396 -> 1302 us per 8 renders (profiles/r06_blend_init_regime_ablation.txt).  The render's last
     // tile (ONE 64-bit atomic per tile carries the count of tiles done and the buckets they reached: whoever sees
     // T - 1 tiles before it holds the total) leaves the length for the next forward over this workspace.
     if (chain_arg == 0u) {
