@@ -517,19 +517,13 @@ __device__ __forceinline__ void blend_bwd_item(int H, int W, int tiles_x, uint32
     }                                                                                                              \
   }
     /* Which quadrants a record is evaluated on: the ones its mask names and some pixel still looks at (wave-uniform
-       branches) -- or, PAIRS, both quadrants of a tile half in ONE straight-line block when either qualifies: an
-       unneeded quadrant evaluates to nothing (no lane passes the tests) and two independent chains interleave. */
+       branches).  Round 6 measured two other forms of this part and dropped both (profiles/r06_blend_bwd_visits.txt):
+       BOTH quadrants of a tile half in ONE straight-line block whenever either qualifies (an unneeded quadrant
+       evaluates to nothing, and two independent chains interleave): a visit got ~13 % cheaper, but 3.35 instead of
+       2.51 of them per record: 283 against 257 us per 8-render launch, 1483 against 1315 in the init regime; and the
+       three rejection tests as a chain of selects on alpha instead of compares joined on the scalar unit: equal
+       (254.9 / 1317 us). */
 #define DIMO_BWD_NEED(q) (((qm >> (q)) & 1u) && pos < deepest[(q)])
-#ifdef DIMO_BWD_PAIRS
-#define DIMO_BWD_QUADRANTS(G, C, A, NZ)                                      \
-    _Pragma("unroll") for (int h = 0; h < 4; h += 2) {                      \
-      if (!(DIMO_BWD_NEED(h) || DIMO_BWD_NEED(h + 1))) continue;             \
-      any = true;                                                           \
-      n_quad += 2;                                                          \
-      DIMO_BWD_VISIT(h, G, C, A, NZ)                                         \
-      DIMO_BWD_VISIT(h + 1, G, C, A, NZ)                                     \
-    }
-#else
 #define DIMO_BWD_QUADRANTS(G, C, A, NZ)                                      \
     _Pragma("unroll") for (int q = 0; q < 4; ++q) {                         \
       if (!DIMO_BWD_NEED(q)) continue;                                       \
@@ -537,19 +531,9 @@ __device__ __forceinline__ void blend_bwd_item(int H, int W, int tiles_x, uint32
       ++n_quad;                                                             \
       DIMO_BWD_VISIT(q, G, C, A, NZ)                                         \
     }
-#endif
-#ifdef DIMO_BWD_SELECT_CHAIN
-    /* the three rejection tests as a chain of selects on alpha (VALU only) instead of three compares joined on the scalar unit */ 
-#define DIMO_BWD_PREDICATE(q)                                      \
-      const float al1 = power <= 0.0f ? alpha : 0.0f;              \
-      const float al2 = pos < last[q] ? al1 : 0.0f;                \
-      const bool active = al2 >= ALPHA_MIN;                        \
-      const float ae = active ? al2 : 0.0f;
-#else
 #define DIMO_BWD_PREDICATE(q)                                                          \
       const bool active = pos < last[q] && power <= 0.0f && alpha >= ALPHA_MIN;       \
       const float ae = active ? alpha : 0.0f;
-#endif
     uint32_t m0 = 0, m1 = 0;
     float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), c0 = g0, a0 = g0, g1 = g0, c1 = g0, a1 = g0;
     float nz0 = 0.0f, nz1 = 0.0f;
