@@ -794,6 +794,12 @@ def main():
         dist.all_reduce(cmin, op=dist.ReduceOp.MIN)
         replicas_identical = bool(torch.equal(cmax, cmin))
 
+    trained_stats = None
+    if rank == 0 and world == 1:
+        try:  # (what a render looks like to the blend kernels NOW: the sustained run below drifts away from it)
+            trained_stats = scene_stats(tr)
+        except Exception:
+            trained_stats = None
     # sustained rate: the fresh-state figure above is steps ~26-45 of a process; a long run drifts (random targets blow
     # a few Gaussians up, R grows) and crosses the schedule's stage-s2 opacity prune (step % 1000 == 0: the Gaussian
     # count changes, every workspace is rebuilt).  >= 1000 consecutive steps, every rank, collectives included.
@@ -1002,7 +1008,7 @@ def main():
         # second trainer built here
         if world == 1 and c3_default and not args.no_regimes and args.regime == "trained":
             try:
-                st = scene_stats(tr)
+                st = trained_stats if trained_stats is not None else scene_stats(tr)
                 fm, fn = timing_all["blend_fwd"]
                 regimes = {"trained": {
                     "frames_per_s": res["value"], "ms_per_step": res["ms_per_step"], "steps": args.steps,
