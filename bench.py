@@ -559,6 +559,10 @@ def main():
                     help="opacities of the synthetic Gaussians the HEADLINE is quoted on (SURVEY 8d): trained = "
                          "sigmoid(U(-2, 4)), lists saturate early (every round's headline); init = every opacity 0.05, "
                          "the reference's own initial state; low = U(0.01, 0.1)")
+    ap.add_argument("--main-stream-allreduce", action="store_true",
+                    help="several ranks: the plain schedule -- fold, ONE all-reduce of the whole gradient bucket and one "
+                         "Adam launch on the caller's stream (Trainer._split_adam = False) -- instead of the head's "
+                         "all-reduce on a private stream under the TimeNet backward (the fallback, never needed so far)")
     ap.add_argument("--no-regimes", action="store_true",
                     help="skip the `regimes` block (the same step in the init regime, measured in this process)")
     args = ap.parse_args()
@@ -591,6 +595,8 @@ def main():
     tr, pol = make_trainer(device, rank, world, args.num_pts, args.resolution, per_gpu=per_gpu,
                            capacity=not args.sync_exact, global_batch=args.global_batch or None, regime=args.regime)
     tr.time_allreduce = world > 1  # event pairs around the step's collective: its EXPOSED time on this stream
+    if args.main_stream_allreduce:
+        tr._split_adam = False
 
     def barrier():
         if world > 1:
