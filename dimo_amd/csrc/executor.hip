@@ -73,7 +73,7 @@ struct Executor {
   // per range start: its rasterizer backward ran on the CALLER's stream (joint launch, or a range whose whole chain is
   // on the caller's stream): dimo_executor_backward_accumulate has no event to wait for
   std::vector<char> range_bwd_main;
-  // per range start: its skinning backward (phase 1: skin + control-point reduction into staging tables) already ran,
+  // per range start: its skinning backward (phase 1: skin; control-point sums added atomically) already ran,
   // in order behind its rasterizer backward: dimo_executor_backward_accumulate only folds (phase 2)
   std::vector<char> range_skinned;
   // Cross-stream dependencies through stream memory operations instead of events (DIMO_XSTREAM=value): the producer
@@ -508,8 +508,8 @@ extern "C" int dimo_executor_backward_launch_in_order(void *h, const dimo_step_c
 }
 
 // Batched ranges only, after dimo_executor_backward_launch_in_order of the same range: the range's SKINNING backward
-// (per-Gaussian gradients in place in the group leaders' buffers, control-point sums into the leaders' staging tables:
-// nothing shared is written) in order on the same stream.  dimo_executor_backward_accumulate over the step's renders
+// (per-Gaussian gradients in place in the group leaders' buffers, control-point sums as atomics on the shared
+// gradient words) in order on the same stream.  dimo_executor_backward_accumulate over the step's renders
 // then only folds -- one launch on the caller's stream instead of one skinning backward per motion there (57 + 46 us
 // serial on the step's critical path at the benchmark size).
 extern "C" int dimo_executor_backward_skinning_in_order(void *h, const dimo_step_common *c, int first, int count,

@@ -776,8 +776,8 @@ class Trainer:
         # private streams' kernels add to atomically.  They run BEFORE the forward forks: their gradient writes -- GA into
         # the TimeNet-row gradients `g_dxyz` and `_c_xyz.grad`, ARAP through autograd into the control points, the
         # TimeNet and the latents, KL into `_mu` / `_log_var` -- are plain read-modify-writes, and the private streams'
-        # skinning backward (`lbs_reduce`: `*dst += s` into the same `g_d_xyz` rows) and the fold (control-point sums
-        # into `_c_xyz.grad`) must be ordered behind them; every private stream forks from this one below.
+        # skinning backward (atomic adds into the same `g_d_xyz` rows and into `_c_xyz.grad`) must be ordered behind
+        # them; every private stream forks from this one below.
         extra = None
         if self._ga_active():
             extra = self._ga_direct(mine, pair_of, dxyz_c, g_dxyz)

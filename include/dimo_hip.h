@@ -429,8 +429,9 @@ int dimo_executor_wait_side(void *executor, int which, void *main_stream);
 void *dimo_executor_private_stream(void *executor, int which);
 int dimo_executor_join_ranges(void *executor, int first, int count, void *stream);
 /* Batched ranges only, after dimo_executor_backward_launch_in_order of the same range: the range's skinning backward
- * on the same stream, writing nothing shared (per-Gaussian gradients in place in the deformation groups' leader
- * buffers, the control-point sums into per-leader staging tables inside lbs_scratch).
+ * on the same stream: per-Gaussian gradients in place in the deformation groups' leader buffers; what it adds to
+ * SHARED words -- the control-point sums into g_c_xyz / g_c_log_radius, the TimeNet-row gradients -- it adds atomically
+ * (round 6: no partial tables, no staging, lbs_scratch is unused by this path).
  * dimo_executor_backward_accumulate over the step's renders then only folds those into the gradient views (one
  * launch, fixed order), instead of running every motion's skinning backward on main_stream one after the other.
  * (The LBS block of latent_gs_renderer.py:1191-1219, backward, per motion of main_train_dimo.py:276-318.) */

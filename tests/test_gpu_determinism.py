@@ -6,7 +6,7 @@ mode for gradient accumulation so parity runs are reproducible").  What the HIP 
     the skinning backward's per-Gaussian outputs and the fold into the gradient views (fixed render order) -- i.e. the
     whole per-Gaussian HEAD of the flat bucket (xyz, colour, opacity, scaling, rotation): asserted bit for bit;
   * order-dependent (fp32 atomics): the skinning backward's control-point scatter (LDS float atomics inside a
-    workgroup; the per-workgroup partial tables are then summed in a fixed order) and the TimeNet weight gradients
+    workgroup; since round 6 the workgroups' sums are added with global fp32 atomics too) and the TimeNet weight gradients
     (split-K partial products added with hardware fp32 atomics) -- and everything downstream of the first: control
     points, radii, the TimeNet's output-row gradients, latents.  These differ run to run by rounding only: asserted
     within 1e-5 of each group's largest magnitude.  Data-parallel replicas are unaffected: every rank applies the
