@@ -89,7 +89,7 @@ struct BinArgs {
   BinGrid gi;
   size_t l1cap;
   // byte offsets into the geometry (g_) and bin (b_) workspaces
-  size_t g_total, g_rect, g_tiles, g_offsets, g_sums, g_key32, g_bk, g_segs, g_work, g_wgob;
+  size_t g_total, g_rect, g_tiles, g_offsets, g_sums, g_key32, g_bk, g_segs, g_work, g_wgob, g_hit;
   size_t b_order;
   size_t b_meta, b_l1tmp, b_l1a, b_l1b, b_l1, b_grpbase, b_grpinfo, b_cntu, b_totals, b_ranges, b_work, b_vals;
 };
@@ -1238,6 +1238,11 @@ __device__ __forceinline__ void level2_fill_body(const BinArgs &a, void *geom, v
     uint4 *f4 = reinterpret_cast<uint4 *>(grad_flags);
     for (size_t q = (size_t)blockIdx.x * SORT_BLOCK + tid; q < nb16; q += (size_t)gridDim.x * SORT_BLOCK)
       f4[q] = make_uint4(0u, 0u, 0u, 0u);
+    // ... and the per-Gaussian hit masks (one 64-bit word each: what the projection backward reads instead of the flags)
+    uint4 *h4 = at<uint4>(geom, a.g_hit);
+    const size_t nh16 = ((size_t)a.N + 1) / 2;
+    for (size_t q = (size_t)blockIdx.x * SORT_BLOCK + tid; q < nh16; q += (size_t)gridDim.x * SORT_BLOCK)
+      h4[q] = make_uint4(0u, 0u, 0u, 0u);
   }
   if (blockIdx.x == 0) {
     // tile ranges clamped to the instance capacity, overflow flag, and the backward's three work counters cleared
@@ -1417,6 +1422,7 @@ static bool make_args(int N, int H, int W, int64_t R_cap, int n_renders, const G
   a.sort_grid = (int)bucket_grid((unsigned)(a.gi.NS << a.lg), n_renders);
   a.g_total = G.total, a.g_rect = G.rect, a.g_tiles = G.tiles, a.g_offsets = G.offsets, a.g_sums = G.block_sums;
   a.g_key32 = G.key32, a.g_bk = G.bk, a.g_segs = G.segs, a.g_work = G.work, a.g_wgob = G.wgob;
+  a.g_hit = G.hitmask;
   a.b_meta = B.meta, a.b_l1tmp = B.l1tmp, a.b_l1a = B.l1a, a.b_l1b = B.l1b, a.b_l1 = B.l1list;
   a.b_grpbase = B.grpbase, a.b_grpinfo = B.grpinfo, a.b_cntu = B.cntu;
   a.b_totals = B.totals, a.b_ranges = B.ranges, a.b_work = B.work, a.b_vals = B.vals_b;

@@ -339,6 +339,7 @@ struct BwdView {  // one render's buffers as the backward sees them
   const float *dL_dcolor, *dL_ddepth, *dL_dnormal, *dL_dalpha;
   SplatGrad *inst_grad;
   uint8_t *inst_flag;
+  unsigned long long *hitmask;  // per Gaussian: bit k = its k-th instance has a record (k < 64; geom workspace)
   const float *dot;  // optional: per pixel sum over the channels of gradient x rendered value (= S below)
 };
 
@@ -436,7 +437,7 @@ __device__ __forceinline__ void blend_bwd_item(int H, int W, int tiles_x, uint32
     // every lane keeps the rank / emission slot of the record it staged for the epilogue
     float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra, rc4 = ra;
     float rnz = 0.0f;
-    uint32_t qmask = 0, my_emit = 0;
+    uint32_t qmask = 0, my_emit = 0, my_hit_word = 0;  // (Gaussian << 7 | min(instance of the Gaussian, 127))
     if (lane < count) {
       const uint32_t g = r.vals[lo + blo + lane];
       const float4 *rp = reinterpret_cast<const float4 *>(r.splat + g);
@@ -447,7 +448,9 @@ __device__ __forceinline__ void blend_bwd_item(int H, int W, int tiles_x, uint32
       ra.z = rd.y, ra.w = rd.z, rb.x = rd.w;  // (staged pre-multiplied: see CONIC_HALF)
       const uint2 rc = *reinterpret_cast<const uint2 *>(r.rect + 4 * (size_t)g);
       const int x0 = rc.x & 0xffff, y0 = rc.x >> 16, x1 = rc.y & 0xffff;
-      my_emit = (g == 0 ? 0u : r.offsets[g - 1]) + (uint32_t)((tile_y - y0) * (x1 - x0) + (tile_x - x0));
+      const uint32_t local = (uint32_t)((tile_y - y0) * (x1 - x0) + (tile_x - x0));
+      my_emit = (g == 0 ? 0u : r.offsets[g - 1]) + local;
+      my_hit_word = (g << 7) | min(local, 127u);
     }
     const bool my_hit = qmask != 0u;
     const unsigned long long bal = __ballot(my_hit);
@@ -562,6 +565,9 @@ __device__ __forceinline__ void blend_bwd_item(int H, int W, int tiles_x, uint32
         float4 *dst = reinterpret_cast<float4 *>(r.inst_grad + my_emit);
         dst[0] = r0, dst[1] = r1, dst[2] = r2, dst[3] = r3;
         r.inst_flag[my_emit] = 1;
+        // the projection backward finds a Gaussian's records by ONE word (its instances are contiguous from
+        // offsets[g - 1]): two dependent rounds of scattered flag bytes per four instances before (round 6)
+        if ((my_hit_word & 127u) < 64u) atomicOr(r.hitmask + (my_hit_word >> 7), 1ull << (my_hit_word & 127u));
       }
     }
   }
@@ -650,6 +656,7 @@ struct BlendOffsets {
   size_t ranges, vals, ckpt, work, order, meta; // bin
   size_t final_T, n_contrib, final_acc;         // img
   size_t flag;                                  // backward scratch: records at 0, flags here
+  size_t hit;                                   // geom: per-Gaussian hit masks
 };
 template <bool NORMAL>
 __global__ void __launch_bounds__(BLEND_BLOCK) blend_fwd_batched_kernel(int H, int W, int tiles_x,
@@ -678,7 +685,7 @@ struct BatchView {
                    at<float>(r.img, o.final_acc),    at<float>(r.bin, o.ckpt),         at<uint32_t>(r.bin, o.work),
                    r.g_color,                        r.g_depth,                        NORMAL ? r.g_normal : nullptr,
                    r.g_alpha,                        reinterpret_cast<SplatGrad *>(r.bwd_scratch),
-                   at<uint8_t>(r.bwd_scratch, o.flag), r.g_dot};
+                   at<uint8_t>(r.bwd_scratch, o.flag), at<unsigned long long>(r.geom, o.hit), r.g_dot};
   }
 };
 // JOINT only names the launch (no code depends on it): the joint launch over ALL the step's renders on the caller's
@@ -711,6 +718,7 @@ static BlendOffsets blend_offsets(const GeomLayout &G, const BinLayout &B, const
   o.ranges = B.ranges, o.vals = B.vals_b, o.ckpt = B.ckpt, o.work = B.work, o.order = B.order, o.meta = B.meta;
   o.final_T = I.final_T, o.n_contrib = I.n_contrib, o.final_acc = I.final_acc;
   o.flag = align_up(B.cap * sizeof(SplatGrad));
+  o.hit = G.hitmask;
   return o;
 }
 
@@ -865,10 +873,12 @@ extern "C" int dimo_raster_backward(int N, int sh_degree, int M, int H, int W, i
   if (N > 0) {
     ScopedTimer tm(T_BLEND_BWD, stream);
     if (hipMemsetAsync(inst_flag, 0, B.cap, stream) != hipSuccess) return DIMO_E_LAUNCH;
+    unsigned long long *hitmask = at<unsigned long long>(const_cast<void *>(geom), G.hitmask);
+    if (hipMemsetAsync(hitmask, 0, (size_t)N * sizeof(unsigned long long), stream) != hipSuccess) return DIMO_E_LAUNCH;
     SingleView sv{BwdView{at<uint32_t>(bin, B.vals_b), at<Splat>(geom, G.splat), at<uint16_t>(geom, G.rect),
                           at<uint32_t>(geom, G.offsets), at<float>(img, I.final_T), at<uint32_t>(img, I.n_contrib),
                           at<float>(img, I.final_acc), at<float>(bin, B.ckpt), at<uint32_t>(bin, B.work), dL_dcolor,
-                          dL_ddepth, dL_dnormal, dL_dalpha, inst, inst_flag, nullptr}};
+                          dL_ddepth, dL_dnormal, dL_dalpha, inst, inst_flag, hitmask, nullptr}};
     if (dL_dnormal)
       hipLaunchKernelGGL(blend_bwd_kernel<true>, dim3(BWD_GRID), dim3(64), 0, stream, H, W, B.tiles_x, cap, bg, sv);
     else

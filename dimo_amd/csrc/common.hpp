@@ -103,7 +103,7 @@ constexpr size_t BK_TOT = 24;
 constexpr size_t BK_WORDS = BK_TOT + 2 * MAX_BUCKETS;
 
 struct GeomLayout {
-  size_t splat, rect, tiles, offsets, flags, total, block_sums, key32, bk, segs, work, wgob;
+  size_t splat, rect, tiles, offsets, flags, total, block_sums, key32, bk, segs, work, wgob, hitmask;
   size_t bytes;
   int nb, per, nwg1;  // preprocess blocks; blocks per level-1 workgroup; level-1 workgroups
   __host__ explicit GeomLayout(int N) {
@@ -132,6 +132,9 @@ struct GeomLayout {
     // wgob[level-1 workgroup][bucket]: where the workgroup's places beyond the bucket's region go in the overflow area
     // (only the words of such buckets are written and read)
     wgob = o, o = align_up(o + (size_t)nwg1 * MAX_BUCKETS * sizeof(uint32_t));
+    // per Gaussian one 64-bit word: bit k = its k-th tile instance got a gradient record from the blend backward
+    // (cleared with the record flags, set by atomic OR; a Gaussian of more than 64 instances goes by the flags)
+    hitmask = o, o = align_up(o + n * sizeof(uint64_t));
     bytes = o;
   }
 };

@@ -210,7 +210,7 @@ __device__ __forceinline__ void preprocess_bwd_body(
     const float *__restrict__ Vg, const float *__restrict__ Pg, const float *__restrict__ camg, float tanfovx,
     float tanfovy, const int32_t *__restrict__ radii, const Splat *__restrict__ splat,
     const uint32_t *__restrict__ offsets, const uint8_t *__restrict__ flags, const SplatGrad *__restrict__ inst_grad,
-    const uint8_t *__restrict__ inst_flag,
+    const uint8_t *__restrict__ inst_flag, const unsigned long long *__restrict__ hitmask,
     float *__restrict__ dL_dmeans3D, float *__restrict__ dL_dmeans2D, float *__restrict__ dL_dshs,
     float *__restrict__ dL_dcolors, float *__restrict__ dL_dopacity, float *__restrict__ dL_dscales,
     float *__restrict__ dL_drot, float *__restrict__ dL_dcov3D, const float *__restrict__ presum = nullptr) {
@@ -238,6 +238,7 @@ __device__ __forceinline__ void preprocess_bwd_body(
   const bool visible = valid && N > 0 && radii[i] > 0;
   // the Gaussian's own inputs are requested before the gather loop (they are only needed after it)
   uint32_t lo = N > 0 ? offsets[i == 0 ? 0 : i - 1] : 0u, hi = N > 0 ? offsets[i] : 0u;
+  const unsigned long long hm = N > 0 ? hitmask[i] : 0ull;
   const Splat sp = N > 0 ? splat[i] : Splat{};
   const float p[3] = {N > 0 ? means3D[3 * i] : 0.f, N > 0 ? means3D[3 * i + 1] : 0.f, N > 0 ? means3D[3 * i + 2] : 0.f};
   float q[4] = {1, 0, 0, 0}, s[3] = {0, 0, 0};
@@ -290,7 +291,9 @@ __device__ __forceinline__ void preprocess_bwd_body(
     // (FOUR per round: eight held 104 registers of records in flight, 149 VGPRs = three waves per SIMD, and a stamp per
     // workgroup showed 1.65 workgroups per CU alive on average; four: 122 VGPRs, four waves per SIMD, the same number
     // of loads in flight per SIMD -- 100 -> 94 us per 8 renders in the timed step.)
-    sum_instance_records(inst_grad, inst_flag, lo, hi, m0, mx, my, mxx, mxy, myy, dfeat);
+    // (a Gaussian of up to 64 instances -- every one the wave or the presum did not take -- is summed from its hit mask;
+    // the mask only names instances below the capacity: the blend backward set no bit beyond it)
+    if (hi > lo) sum_hit_records(inst_grad, lo, hm, m0, mx, my, mxx, mxy, myy, dfeat);
     // conic -> cov2D -> (Sigma, t) -> (scale, quaternion, mean), projection, depth feature, normal (proj_math.hpp)
     ProjGrad pg = {};
     proj_backward_math(i, W, H, tanfovx, tanfovy, scale_mod, sp, p, q, s, cov3D_precomp, V, P, cam, m0, mx, my, mxx, mxy,
@@ -401,11 +404,13 @@ __global__ void __launch_bounds__(PRE_BLOCK) preprocess_bwd_kernel(
     const float *__restrict__ Vg, const float *__restrict__ Pg, const float *__restrict__ camg, float tanfovx,
     float tanfovy, const int32_t *__restrict__ radii, const Splat *__restrict__ splat,
     const uint32_t *__restrict__ offsets, const uint8_t *__restrict__ flags, const SplatGrad *__restrict__ inst_grad,
-    const uint8_t *__restrict__ inst_flag, float *__restrict__ dL_dmeans3D, float *__restrict__ dL_dmeans2D,
+    const uint8_t *__restrict__ inst_flag, const unsigned long long *__restrict__ hitmask,
+    float *__restrict__ dL_dmeans3D, float *__restrict__ dL_dmeans2D,
     float *__restrict__ dL_dshs, float *__restrict__ dL_dcolors, float *__restrict__ dL_dopacity,
     float *__restrict__ dL_dscales, float *__restrict__ dL_drot, float *__restrict__ dL_dcov3D) {
   preprocess_bwd_body(N, deg, M, H, W, R_cap, means3D, shs, colors_precomp, scales, rotations, cov3D_precomp, scale_mod,
-                      Vg, Pg, camg, tanfovx, tanfovy, radii, splat, offsets, flags, inst_grad, inst_flag, dL_dmeans3D,
+                      Vg, Pg, camg, tanfovx, tanfovy, radii, splat, offsets, flags, inst_grad, inst_flag, hitmask,
+                      dL_dmeans3D,
                       dL_dmeans2D, dL_dshs, dL_dcolors, dL_dopacity, dL_dscales, dL_drot, dL_dcov3D);
 }
 __global__ void __launch_bounds__(PRE_BLOCK) preprocess_bwd_batched_kernel(int N, int H, int W, uint32_t R_cap,
@@ -418,7 +423,7 @@ __global__ void __launch_bounds__(PRE_BLOCK) preprocess_bwd_batched_kernel(int N
                       r.campos, r.tanfovx, r.tanfovy, r.radii, at<Splat>(r.geom, L.splat),
                       at<uint32_t>(r.geom, L.offsets), at<uint8_t>(r.geom, L.flags),
                       reinterpret_cast<const SplatGrad *>(r.bwd_scratch), at<uint8_t>(r.bwd_scratch, flag_offset),
-                      r.g_means3D, r.g_means2D, r.g_shs, nullptr, r.g_opac, r.g_scales, r.g_rot, nullptr,
+                      at<unsigned long long>(r.geom, L.hitmask), r.g_means3D, r.g_means2D, r.g_shs, nullptr, r.g_opac, r.g_scales, r.g_rot, nullptr,
                       presum_offset != ~(size_t)0 ? at<float>(r.bin, presum_offset) : nullptr);
 }
 
@@ -570,7 +575,7 @@ int dimo::preprocess_backward_launch(
                      at<uint8_t>(geom, L.flags), reinterpret_cast<const SplatGrad *>(inst_grad),
                      reinterpret_cast<const uint8_t *>(inst_grad) +
                          align_up((size_t)(R_cap > 0 ? R_cap : 1) * sizeof(SplatGrad)),
-                     dL_dmeans3D,
+                     at<unsigned long long>(geom, L.hitmask), dL_dmeans3D,
                      dL_dmeans2D, dL_dshs, dL_dcolors, dL_dopacity, dL_dscales, dL_drot, dL_dcov3D);
   return check_launch();
 }

@@ -143,6 +143,37 @@ __device__ __forceinline__ void sum_instance_records(const SplatGrad *__restrict
     }
   }
 }
+// The same sums from the Gaussian's HIT MASK (bit k = instance lo + k has a record; Gaussians of up to 64 instances):
+// no flag bytes are read -- the word arrives with the Gaussian's own inputs -- and only records that exist are fetched,
+// four per round in ascending order (the order of additions of the loop above).  In the trained regime one instance
+// in nine has a record: the flag loop issued 16 record loads per round whatever the flags said.
+__device__ __forceinline__ void sum_hit_records(const SplatGrad *__restrict__ inst_grad, uint32_t lo,
+                                                unsigned long long hm, float &m0, float &mx, float &my, float &mxx,
+                                                float &mxy, float &myy, float (&dfeat)[NFEAT]) {
+  constexpr int GR = 4;
+  const float4 *const dummy = reinterpret_cast<const float4 *>(inst_grad);
+  while (hm != 0ull) {
+    bool on[GR];
+    float4 ra[GR], rb[GR], rc[GR], rd[GR];
+#pragma unroll
+    for (int k = 0; k < GR; ++k) {
+      on[k] = hm != 0ull;
+      const uint32_t e = lo + (uint32_t)(on[k] ? __builtin_ctzll(hm) : 0);
+      hm &= hm - 1ull;  // (0 stays 0)
+      const float4 *rp = on[k] ? reinterpret_cast<const float4 *>(inst_grad + e) : dummy;
+      ra[k] = rp[0], rb[k] = rp[1], rc[k] = rp[2], rd[k] = rp[3];
+    }
+#pragma unroll
+    for (int k = 0; k < GR; ++k) {
+      if (on[k]) {
+        m0 += ra[k].x, mx += ra[k].y, my += ra[k].z, mxx += ra[k].w;
+        mxy += rb[k].x, myy += rb[k].y, dfeat[0] += rb[k].z, dfeat[1] += rb[k].w;
+        dfeat[2] += rc[k].x, dfeat[3] += rc[k].y, dfeat[4] += rc[k].z, dfeat[5] += rc[k].w;
+        dfeat[6] += rd[k].x;
+      }
+    }
+  }
+}
 // ... and by a whole WAVE (lanes stride over the records, butterfly reduction): a Gaussian blown up over hundreds of
 // tiles would keep its thread in the loop above long after the rest of the chip has finished.  Every lane returns the
 // 13 sums in a[].
