@@ -447,10 +447,11 @@ __device__ __forceinline__ void blend_bwd_item(int H, int W, int tiles_x, uint32
       qmask = quadrant_mask(ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, tile_x, tile_y);
       ra.z = rd.y, ra.w = rd.z, rb.x = rd.w;  // (staged pre-multiplied: see CONIC_HALF)
       const uint2 rc = *reinterpret_cast<const uint2 *>(r.rect + 4 * (size_t)g);
-      const int x0 = rc.x & 0xffff, y0 = rc.x >> 16, x1 = rc.y & 0xffff;
+      const int x0 = rc.x & 0xffff, y0 = rc.x >> 16, x1 = rc.y & 0xffff, y1 = rc.y >> 16;
       const uint32_t local = (uint32_t)((tile_y - y0) * (x1 - x0) + (tile_x - x0));
       my_emit = (g == 0 ? 0u : r.offsets[g - 1]) + local;
-      my_hit_word = (g << 7) | min(local, 127u);
+      // (a Gaussian of up to 64 instances is found by its hit mask, a larger one by the record flags: preprocess.hip)
+      my_hit_word = (g << 7) | ((x1 - x0) * (y1 - y0) <= 64 ? local : 127u);
     }
     const bool my_hit = qmask != 0u;
     const unsigned long long bal = __ballot(my_hit);
@@ -564,10 +565,10 @@ __device__ __forceinline__ void blend_bwd_item(int H, int W, int tiles_x, uint32
       if (my_emit < R_cap && nonzero) {
         float4 *dst = reinterpret_cast<float4 *>(r.inst_grad + my_emit);
         dst[0] = r0, dst[1] = r1, dst[2] = r2, dst[3] = r3;
-        r.inst_flag[my_emit] = 1;
         // the projection backward finds a Gaussian's records by ONE word (its instances are contiguous from
         // offsets[g - 1]): two dependent rounds of scattered flag bytes per four instances before (round 6)
         if ((my_hit_word & 127u) < 64u) atomicOr(r.hitmask + (my_hit_word >> 7), 1ull << (my_hit_word & 127u));
+        else r.inst_flag[my_emit] = 1;
       }
     }
   }

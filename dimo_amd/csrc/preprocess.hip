@@ -247,10 +247,11 @@ __device__ __forceinline__ void preprocess_bwd_body(
     s[0] = scales[3 * i], s[1] = scales[3 * i + 1], s[2] = scales[3 * i + 2];
   }
   lo = i == 0 ? 0u : lo;
+  const uint32_t n_inst = hi - lo;  // (before the capacity clamp: what the blend backward's choice of mask / flags went by)
   lo = min(lo, R_cap), hi = min(hi, R_cap);
   if (threadIdx.x == 0) s_big_n = 0u;
   __syncthreads();
-  const bool big = visible && hi > lo && hi - lo > BIG;
+  const bool big = visible && hi > lo && n_inst > BIG;
   uint32_t big_slot = 0;
   if (big && !presum) {
     big_slot = atomicAdd(&s_big_n, 1u);
@@ -438,8 +439,9 @@ __global__ void __launch_bounds__(256) instance_sums_batched_kernel(int N, uint3
   const dimo_render_desc &r = b.r[blockIdx.y];
   const int g = blockIdx.x;
   const uint32_t *__restrict__ offsets = at<uint32_t>(r.geom, L.offsets);
-  const uint32_t lo = min(g == 0 ? 0u : offsets[g - 1], R_cap), hi = min(offsets[g], R_cap);
-  if (hi <= lo || hi - lo <= PRESUM_MIN) return;  // (workgroup-uniform)
+  const uint32_t lo_raw = g == 0 ? 0u : offsets[g - 1], hi_raw = offsets[g];
+  const uint32_t lo = min(lo_raw, R_cap), hi = min(hi_raw, R_cap);
+  if (hi <= lo || hi_raw - lo_raw <= PRESUM_MIN) return;  // (workgroup-uniform; the count BEFORE the capacity clamp: preprocess_bwd_body)
   const SplatGrad *__restrict__ inst_grad = reinterpret_cast<const SplatGrad *>(r.bwd_scratch);
   const uint8_t *__restrict__ inst_flag = at<uint8_t>(r.bwd_scratch, flag_offset);
   const float4 *const dummy = reinterpret_cast<const float4 *>(inst_grad);

@@ -312,6 +312,18 @@ def test_backward_view_direction_gradient_of_the_sh_colours():
         assert err <= L1_TOL, (k, err)
 
 
+def test_backward_gaussians_over_more_than_64_tiles():
+    """Two ways from the blend backward's gradient records to a Gaussian's sums: up to 64 tile instances by its 64-bit hit
+    mask (one atomic OR per record), more by the record flags and a whole wave (preprocess.hip).  A scene that has both
+    kinds -- 256 tiles, a third of the Gaussians over most of them -- must give the oracle's gradients."""
+    cam = camera_np(20.0, W=256, H=256)
+    sc = random_scene(900, seed=5, scale=0.02)
+    sc["scales"][::3] *= 10.0
+    o = _oracle(sc, cam, (0.2, 0.2, 0.2), 0)
+    assert (o["tiles_touched"] > 64).sum() > 100 and ((o["tiles_touched"] > 0) & (o["tiles_touched"] <= 64)).sum() > 100
+    _check_backward(sc, cam, (0.2, 0.2, 0.2), 0, GRADS_SH)
+
+
 def test_backward_parity_four_output_flavour():
     cam = camera_np(200.0, W=96, H=128)
     sc = random_scene(3000, seed=21, scale=0.03)

@@ -227,6 +227,16 @@ def test_emulated_init_regime_whole_lists_deep(opacity):
     _check_backward(sc, cam, (0.0, 0.0, 0.0), 0, GRADS_SH)
 
 
+def test_emulated_backward_gaussians_over_more_than_64_tiles():
+    """Two ways from the blend backward's gradient records to a Gaussian's sums: up to 64 tile instances by its 64-bit hit
+    mask (one atomic OR per record), more by the record flags and a whole wave (preprocess.hip).  A scene that has both
+    kinds -- 100 tiles, a third of the Gaussians over most of them -- must give the oracle's gradients."""
+    cam = camera_np(20.0, W=160, H=160)
+    sc = random_scene(240, seed=5, scale=0.02)
+    sc["scales"][::3] *= 10.0
+    _check_backward(sc, cam, (0.2, 0.2, 0.2), 0, GRADS_SH)
+
+
 def test_emulated_backward_precomputed_colour_and_cov():
     cam = camera_np(120.0, elevation=-20, W=96, H=96)
     sc = random_scene(1500, seed=5, scale=0.04)
