@@ -170,11 +170,16 @@ __device__ __forceinline__ void blend_fwd_body(
   G = s_geo[J], C = s_col[J], A = s_aux[J]; \
   if (NORMAL) NZ = s_nz[J];
 
+  // (the list entry of the NEXT batch is requested while this one is worked on: a batch's staging was two dependent
+  // memory round trips -- list entry, then record -- in front of every 256 records)
+  uint32_t next_id = lo + threadIdx.x < hi ? vals_sorted[lo + threadIdx.x] : 0u;
   for (uint32_t start = lo; start < hi; start += BATCH) {
     if (__syncthreads_count(Tw == 0.0f) == BLEND_BLOCK) break;
     const uint32_t idx = start + threadIdx.x;
+    const uint32_t id = next_id;
+    next_id = idx + BATCH < hi ? vals_sorted[idx + BATCH] : 0u;
     if (idx < hi) {
-      const float4 *rp = reinterpret_cast<const float4 *>(splat + vals_sorted[idx]);
+      const float4 *rp = reinterpret_cast<const float4 *>(splat + id);
       const float4 a = rp[0], b = rp[1], c = rp[2];
       s_geo[threadIdx.x] = a;
       s_col[threadIdx.x] = b;
@@ -378,6 +383,10 @@ __device__ __forceinline__ void blend_bwd_item(int H, int W, int tiles_x, uint32
   const bool head = b0 == 0u;  // the chain starts at the head of the list: T = 1, nothing accumulated yet
   const float *const ck_item = r.ckpt + ((size_t)(lo / BUCKET) + tile + b0) * (CKPT_FLOATS * TILE * TILE);
   const uint32_t blo0 = b0 * BUCKET;
+  // (the first bucket's list entries are requested here, in front of the pixel state: the records they name are
+  // gathered right behind it -- one dependent memory round trip less per item; a chain requests the next bucket's
+  // while it works on the current one)
+  uint32_t next_g = blo0 + (uint32_t)lane < hi - lo ? r.vals[lo + blo0 + (uint32_t)lane] : 0u;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int px = bx + (q & 1) * 8, py = by + (q >> 1) * 8;
@@ -438,8 +447,9 @@ __device__ __forceinline__ void blend_bwd_item(int H, int W, int tiles_x, uint32
     float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra, rc4 = ra;
     float rnz = 0.0f;
     uint32_t qmask = 0, my_emit = 0, my_hit_word = 0;  // (Gaussian << 7 | min(instance of the Gaussian, 127))
+    const uint32_t g = next_g;
+    next_g = bk + 1u < nbk && blo + BUCKET + (uint32_t)lane < hi - lo ? r.vals[lo + blo + BUCKET + (uint32_t)lane] : 0u;
     if (lane < count) {
-      const uint32_t g = r.vals[lo + blo + lane];
       const float4 *rp = reinterpret_cast<const float4 *>(r.splat + g);
       ra = rp[0], rb = rp[1], rc4 = rp[2];
       const float4 rd = rp[3];  // nz, A', B', C'
