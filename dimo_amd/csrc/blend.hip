@@ -433,8 +433,10 @@ __device__ __forceinline__ void blend_bwd_item(int H, int W, int tiles_x, uint32
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
     deepest[q] = (uint32_t)__builtin_amdgcn_readfirstlane((int)m);
-    // one quadrant's loads in flight at a time: hoisting all four above the first use spills
-    __builtin_amdgcn_sched_barrier(0);
+    // (round 2 kept one quadrant's loads in flight at a time with a scheduling barrier here: hoisting all four above
+    // the first use spilled then.  It does not any more -- 120 VGPRs, no scratch -- and the four quadrants' ~76 loads in
+    // flight together are three memory round trips less per item: 259.6 -> 255.9 us per 8-render launch, +0.7 % in
+    // the step, profiles/r06_hit_mask_and_early_list_entries.txt)
   }
   const uint32_t wlast = max(max(deepest[0], deepest[1]), max(deepest[2], deepest[3]));
 
